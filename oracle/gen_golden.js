@@ -1,0 +1,170 @@
+// oracle/gen_golden.js — TEST INFRASTRUCTURE ONLY.
+//
+// Runs the REAL reference (bundle evaluated by ref_shim.js) in this container and writes the golden vectors that
+// tests/ compare both the C restatement (oracle/*.c) and the HIP path against.  The reference ships no MSM/NTT
+// golden vectors and no golden proofs (SURVEY.md §8c), so these are "outputs of the reference itself run here".
+// Regenerate with:   make -C oracle golden        (needs /root/reference; ≈1–2 min on 8 cores)
+//
+// Synthetic inputs are defined so that Python (tests/synth.py) regenerates them bit-identically:
+//   word(seed,k) = fmix32(seed + k*0x9E3779B9)   (murmur3 finaliser), little-endian u32 stream;
+//   field/scalar element i = words 8i..8i+7, top byte &= 0x1f  (uniform 253-bit, < r on both curves).
+'use strict';
+const fs = require('fs'), path = require('path'), crypto = require('crypto');
+const snarkjs = require('./ref_shim.js');
+const OUT = path.join(__dirname, '..', 'tests', 'golden');
+const sha = b => crypto.createHash('sha256').update(b).digest('hex');
+const hex = b => Buffer.from(b).toString('hex');
+
+function fmix32(h) {
+    h ^= h >>> 16; h = Math.imul(h, 0x85ebca6b); h ^= h >>> 13; h = Math.imul(h, 0xc2b2ae35); h ^= h >>> 16;
+    return h >>> 0;
+}
+function synthElems(seed, n, maskTop = 0x1f) {          // n × 32 B
+    const out = new Uint8Array(n * 32), dv = new DataView(out.buffer);
+    for (let k = 0; k < n * 8; k++) dv.setUint32(4 * k, fmix32((seed + Math.imul(k, 0x9E3779B9)) >>> 0), true);
+    for (let i = 0; i < n; i++) out[32 * i + 31] &= maskTop;
+    return out;
+}
+function iota(n) {                                       // element i = integer (i+1), little-endian, as-is
+    const x = new Uint8Array(n * 32);
+    for (let i = 0; i < n; i++) { const v = i + 1; x[i * 32] = v & 255; x[i * 32 + 1] = (v >> 8) & 255; x[i * 32 + 2] = (v >> 16) & 255; }
+    return x;
+}
+// witness-like mix (SURVEY §8d): 60 % {0,1}, 30 % 64-bit, 10 % full width — selector from word stream seed^0xabcdef
+function synthWitnessLike(seed, n) {
+    const full = synthElems(seed, n);
+    for (let i = 0; i < n; i++) {
+        const sel = fmix32(((seed ^ 0xabcdef) + Math.imul(i, 0x9E3779B9)) >>> 0) % 100;
+        if (sel < 60) { const b = full[32 * i] & 1; full.fill(0, 32 * i, 32 * i + 32); full[32 * i] = b; }
+        else if (sel < 90) full.fill(0, 32 * i + 8, 32 * i + 32);
+    }
+    return full;
+}
+
+async function geomBases(curve, G, n) {                  // P_i = 7·11^i·G, affine Montgomery (SURVEY Appendix C.1)
+    const sG = G.F.n8 * 2, buf = new Uint8Array(n * sG), g = G.toAffine(G.g);
+    for (let i = 0; i < n; i++) buf.set(g, i * sG);
+    return await G.batchApplyKey(buf, curve.Fr.e(7), curve.Fr.e(11));
+}
+
+async function kernelVectors(name, tag) {
+    const curve = await snarkjs.curves.getCurveFromName(name);
+    const { Fr, G1, G2 } = curve, res = { curve: name, n8q: G1.F.n8, n8r: Fr.n8 };
+    res.Fr_one = hex(Fr.one); res.Fq_one = hex(G1.F.one); res.s = Fr.s; res.nqr = Fr.toString(Fr.nqr);
+    res.w_s = Fr.toString(Fr.w[Fr.s]); res.shift = Fr.toString(Fr.shift);
+    res.w = []; for (let i = 0; i <= Fr.s; i++) res.w.push(hex(Fr.w[i]));
+    res.r = Fr.p.toString(); res.q = G1.F.p.toString();
+    res.G1_g = hex(G1.toAffine(G1.g)); res.G2_g = hex(G2.toAffine(G2.g));
+    const save = (f, b) => fs.writeFileSync(path.join(OUT, `${tag}_${f}.bin`), b);
+
+    // ---- n = 1024, iota input: raw files (SURVEY Appendix C.1) ----
+    const n = 1024, x = iota(n);
+    const v = res.n1024 = {};
+    const put = (k, b, raw = true) => { v[k] = sha(b); if (raw) save(`n1024_${k}`, b); };
+    put('fft', await Fr.fft(x)); put('ifft', await Fr.ifft(x));
+    put('applykey_7_11', await Fr.batchApplyKey(x, Fr.e(7), Fr.e(11)));
+    put('to_mont', await Fr.batchToMontgomery(x)); put('from_mont', await Fr.batchFromMontgomery(x));
+    put('inverse', await Fr.batchInverse(x));
+    const b1 = await geomBases(curve, G1, n), b2 = await geomBases(curve, G2, n);
+    put('g1_bases', b1); put('g2_bases', b2);
+    put('g1_msm_affine', G1.toAffine(await G1.multiExpAffine(b1, x)));
+    put('g2_msm_affine', G2.toAffine(await G2.multiExpAffine(b2, x)));
+
+    // ---- NTT over synthetic inputs, several sizes (hash only; inputs regenerated from the seed) ----
+    res.ntt = {};
+    for (const lg of [0, 1, 2, 3, 5, 8, 11, 12, 14, 16, 17]) {
+        const xs = synthElems(0x1000 + lg, 1 << lg);
+        const f = await Fr.fft(xs), fi = await Fr.ifft(xs);
+        res.ntt[lg] = { seed: 0x1000 + lg, fft: sha(f), ifft: sha(fi), fft_first: hex(f.slice(0, 32)), ifft_last: hex(fi.slice(fi.length - 32)) };
+    }
+    // Groth16's coset chain  ifft → batchApplyKey(1, w[lg+1]) → fft   (src/groth16_prove.js:64-76)
+    res.coset_chain = {};
+    for (const lg of [4, 10, 13]) {
+        const xs = synthElems(0x2000 + lg, 1 << lg);
+        const a = await Fr.ifft(xs), b = await Fr.batchApplyKey(a, Fr.e(1), Fr.w[lg + 1]), c = await Fr.fft(b);
+        res.coset_chain[lg] = { seed: 0x2000 + lg, out: sha(c) };
+    }
+    // batch ops on synthetic input incl. zero elements (batchInverse: 0 ↦ 0)
+    {
+        const xs = synthElems(0x3000, 4096); xs.fill(0, 32 * 5, 32 * 6); xs.fill(0, 32 * 4095, 32 * 4096);
+        res.batch = { seed: 0x3000, n: 4096, zeroed: [5, 4095], inverse: sha(await Fr.batchInverse(xs)),
+            to_mont: sha(await Fr.batchToMontgomery(xs)), from_mont: sha(await Fr.batchFromMontgomery(xs)),
+            applykey_shift: sha(await Fr.batchApplyKey(xs, Fr.e(3), Fr.shift)) };
+    }
+
+    // ---- MSM: sizes, scalar widths, edge cases (results hashed after toAffine; zero = all-zero bytes) ----
+    res.msm = {};
+    const msmCase = async (key, G, bases, scalars, extra) => {
+        const r = G.toAffine(await G.multiExpAffine(bases, scalars));
+        res.msm[key] = Object.assign({ affine: hex(r) }, extra || {});
+    };
+    const NB = 1 << 14, B1 = await geomBases(curve, G1, NB), B2 = await geomBases(curve, G2, 1 << 12);
+    res.g1_bases_16384 = sha(B1); res.g2_bases_4096 = sha(B2);
+    const s1 = G1.F.n8 * 2, s2 = G2.F.n8 * 2;
+    for (const k of [1, 2, 3, 63, 64, 65, 1000, 4096, 16384])
+        await msmCase(`g1_uniform_${k}`, G1, B1.slice(0, k * s1), synthElems(0x4000 + k, k), { seed: 0x4000 + k, n: k });
+    for (const k of [1, 2, 100, 4096])
+        await msmCase(`g2_uniform_${k}`, G2, B2.slice(0, k * s2), synthElems(0x5000 + k, k), { seed: 0x5000 + k, n: k });
+    await msmCase('g1_witnesslike_16384', G1, B1, synthWitnessLike(0x6000, NB), { seed: 0x6000, n: NB });
+    await msmCase('g2_witnesslike_4096', G2, B2, synthWitnessLike(0x6001, 4096), { seed: 0x6001, n: 4096 });
+    // scalars ≥ r are NOT reduced by the reference (full 256-bit, no top mask)
+    await msmCase('g1_full256_2048', G1, B1.slice(0, 2048 * s1), synthElems(0x7000, 2048, 0xff), { seed: 0x7000, n: 2048, mask: 0xff });
+    { const sc = new Uint8Array(64 * 32).fill(0xff); await msmCase('g1_allff_64', G1, B1.slice(0, 64 * s1), sc, { n: 64 }); }
+    // 4-byte scalars (src/powersoftau_verify.js:371 uses them)
+    { const w = synthElems(0x7100, 128); await msmCase('g1_scalar4B_1024', G1, B1.slice(0, 1024 * s1), w.slice(0, 4096), { seed: 0x7100, n: 1024, scalar_bytes: 4 }); }
+    // zero scalars, zero (infinity = all-zero bytes) bases, repeated bases (forces P+P doubling inside a bucket), P + (−P)
+    { const sc = synthElems(0x7200, 1024); for (let i = 0; i < 1024; i += 3) sc.fill(0, 32 * i, 32 * i + 32);
+      const bz = B1.slice(0, 1024 * s1); for (let i = 1; i < 1024; i += 5) bz.fill(0, i * s1, (i + 1) * s1);
+      await msmCase('g1_zeros_1024', G1, bz, sc, { seed: 0x7200, n: 1024, zero_scalar_stride: 3, zero_base_from1_stride: 5 }); }
+    { const bz = new Uint8Array(512 * s1); for (let i = 0; i < 512; i++) bz.set(B1.slice((i & 3) * s1, ((i & 3) + 1) * s1), i * s1);
+      const sc = new Uint8Array(512 * 32); for (let i = 0; i < 512; i++) { sc[32 * i] = 5; sc[32 * i + 2] = i >> 6; }
+      await msmCase('g1_repeated_512', G1, bz, sc, { n: 512 }); }
+    { const bz = new Uint8Array(2 * s1); bz.set(B1.slice(0, s1), 0); bz.set(G1.toAffine(G1.neg(B1.slice(0, s1))), s1);
+      const sc = new Uint8Array(64); sc[0] = 9; sc[32] = 9; await msmCase('g1_cancel_2', G1, bz, sc, { n: 2 }); }
+    await msmCase('g1_allzero_scalars_100', G1, B1.slice(0, 100 * s1), new Uint8Array(3200), { n: 100 });
+    res.msm.g1_empty = { affine: hex(G1.toAffine(await G1.multiExpAffine(new Uint8Array(0), new Uint8Array(0)))) };
+    fs.writeFileSync(path.join(OUT, `${tag}_kernel_vectors.json`), JSON.stringify(res, null, 1));
+    console.log(tag, 'kernel vectors done');
+    return curve;
+}
+
+// Fully seeded in-memory Groth16 ceremony → zkey, witness, proof (SURVEY.md Appendix C.3); also records r, s and the
+// bytes crossing every bulk-op boundary inside groth16.prove so that single stages can be replayed.
+async function groth16Golden() {
+    const curve = await snarkjs.curves.getCurveFromName('bn128');
+    const T = '/root/reference/test/groth16/';
+    const mem = () => ({ type: 'mem' });
+    const p0 = mem(), p1 = mem(), pf = mem(), z0 = mem(), z1 = mem(), w = mem();
+    await snarkjs.powersOfTau.newAccumulator(curve, 11, p0);
+    await snarkjs.powersOfTau.contribute(p0, p1, 'C1', 'Entropy1');
+    await snarkjs.powersOfTau.preparePhase2(p1, pf);
+    await snarkjs.zKey.newZKey(new Uint8Array(fs.readFileSync(T + 'circuit.r1cs')), pf, z0);
+    await snarkjs.zKey.contribute(z0, z1, 'p2_C1', 'pa_Entropy1');
+    await snarkjs.wtns.calculate({ a: 11, b: 2 }, new Uint8Array(fs.readFileSync(T + 'circuit.wasm')), w);
+    const rnd = [], calls = [], Fr = curve.Fr;
+    const origRandom = Fr.random.bind(Fr); Fr.random = () => { const v = origRandom(); rnd.push(hex(v)); return v; };
+    const wrap = (obj, nm, label) => { const o = obj[nm].bind(obj); obj[nm] = async (...a) => { const r = await o(...a);
+        calls.push({ op: label, in_len: a[0].byteLength, in0: sha(a[0].slice(0, a[0].byteLength)), in1: (a[1] && a[1].byteLength !== undefined && a[1].byteLength > 32) ? sha(a[1].slice(0, a[1].byteLength)) : undefined, out: sha(r.slice(0, r.byteLength)) }); return r; }; return o; };
+    const undo = [[Fr, 'fft', wrap(Fr, 'fft', 'Fr.fft')], [Fr, 'ifft', wrap(Fr, 'ifft', 'Fr.ifft')], [Fr, 'batchApplyKey', wrap(Fr, 'batchApplyKey', 'Fr.batchApplyKey')],
+        [curve.G1, 'multiExpAffine', wrap(curve.G1, 'multiExpAffine', 'G1.multiExpAffine')], [curve.G2, 'multiExpAffine', wrap(curve.G2, 'multiExpAffine', 'G2.multiExpAffine')]];
+    const { proof, publicSignals } = await snarkjs.groth16.prove(z1.data, w.data);
+    for (const [o, nm, f] of undo) o[nm] = f; Fr.random = origRandom;
+    const vk = await snarkjs.zKey.exportVerificationKey(z1.data);
+    const ok = await snarkjs.groth16.verify(vk, publicSignals, proof);
+    if (!ok) throw new Error('golden groth16 proof does not verify');
+    fs.writeFileSync(path.join(OUT, 'groth16_bn128_n1024.zkey'), z1.data);
+    fs.writeFileSync(path.join(OUT, 'groth16_bn128_n1024.wtns'), w.data);
+    fs.writeFileSync(path.join(OUT, 'groth16_bn128_n1024.json'), JSON.stringify({
+        zkey_sha256: sha(z1.data), wtns_sha256: sha(w.data), proof_sha256: sha(JSON.stringify(proof)),
+        r_mont: rnd[0], s_mont: rnd[1], n_random_calls: rnd.length, proof, publicSignals, verified: ok, vk, calls }, null, 1));
+    console.log('groth16 golden done: proof sha', sha(JSON.stringify(proof)), 'verify', ok);
+}
+
+(async () => {
+    fs.mkdirSync(OUT, { recursive: true });
+    const what = process.argv[2] || 'all';
+    if (what === 'all' || what === 'bn128') await kernelVectors('bn128', 'bn128');
+    if (what === 'all' || what === 'bls12381') await kernelVectors('bls12381', 'bls12381');
+    if (what === 'all' || what === 'groth16') await groth16Golden();
+    process.exit(0);
+})().catch(e => { console.error(e); process.exit(1); });

@@ -1,0 +1,174 @@
+"""ctypes binding of oracle/libzkoracle.so — the CPU restatement used as the parity checker.
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = os.path.join(_ORACLE_DIR, "libzkoracle.so")
+
+BN128, BLS12381 = 0, 1
+CURVE_ID = {"bn128": 0, "bls12381": 1}
+
+
+def build():
+    src = os.path.join(_ORACLE_DIR, "zk_oracle.c")
+    if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "libzkoracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_fr_from_u64.argtypes = [C.c_int, C.c_uint64, C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(x):
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        x = np.frombuffer(bytes(x), dtype=np.uint8)
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+def n8q(curve):
+    return lib().orc_n8q(curve)
+
+
+def fr_w(curve, i):
+    out = np.zeros(32, np.uint8)
+    lib().orc_fr_w(curve, i, _p(out))
+    return out
+
+
+def fr_one(curve):
+    out = np.zeros(32, np.uint8)
+    lib().orc_fr_one(curve, _p(out))
+    return out
+
+
+def fr_e(curve, v):
+    out = np.zeros(32, np.uint8)
+    lib().orc_fr_from_u64(curve, v, _p(out))
+    return out
+
+
+def generator(curve, group):
+    out = np.zeros(2 * group * n8q(curve), np.uint8)
+    lib().orc_generator(curve, group, _p(out))
+    return out
+
+
+def ntt(curve, x, inverse=False):
+    x = _u8(x)
+    n = x.size // 32
+    out = np.empty_like(x)
+    rc = lib().orc_fr_ntt(curve, _p(x), _p(out), C.c_uint(max(n, 1).bit_length() - 1), int(inverse))
+    assert rc == 0
+    return out
+
+
+def _batch(fn, curve, x):
+    x = _u8(x)
+    out = np.empty_like(x)
+    assert fn(curve, _p(x), _p(out), C.c_size_t(x.size // 32)) == 0
+    return out
+
+
+def to_mont(curve, x):
+    return _batch(lib().orc_fr_batch_to_mont, curve, x)
+
+
+def from_mont(curve, x):
+    return _batch(lib().orc_fr_batch_from_mont, curve, x)
+
+
+def batch_inverse(curve, x):
+    return _batch(lib().orc_fr_batch_inverse, curve, x)
+
+
+def apply_key(curve, x, first, inc):
+    x = _u8(x)
+    out = np.empty_like(x)
+    first, inc = _u8(first), _u8(inc)
+    assert lib().orc_fr_batch_apply_key(curve, _p(x), _p(out), C.c_size_t(x.size // 32), _p(first), _p(inc)) == 0
+    return out
+
+
+def msm(curve, group, bases, scalars, n, scalar_bytes=32, naive=False):
+    bases, scalars = _u8(bases), _u8(scalars)
+    out = np.zeros(3 * group * n8q(curve), np.uint8)
+    fn = lib().orc_msm_naive if naive else lib().orc_msm
+    assert fn(curve, group, _p(bases), _p(scalars), C.c_size_t(n), scalar_bytes, _p(out)) == 0
+    return out
+
+
+def to_affine(curve, group, jac):
+    jac = _u8(jac)
+    out = np.zeros(2 * group * n8q(curve), np.uint8)
+    lib().orc_to_affine(curve, group, _p(jac), _p(out))
+    return out
+
+
+def generator_mul(curve, group, k: int):
+    kb = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).copy()
+    out = np.zeros(3 * group * n8q(curve), np.uint8)
+    lib().orc_generator_mul(curve, group, _p(kb), 32, _p(out))
+    return out
+
+
+def geom_bases(curve, group, n):
+    out = np.zeros(n * 2 * group * n8q(curve), np.uint8)
+    lib().orc_geom_bases(curve, group, C.c_size_t(n), _p(out))
+    return out
+
+
+def fq_from_mont(curve, x):
+    x = _u8(x)
+    out = np.empty_like(x)
+    lib().orc_fq_from_mont(curve, _p(x), _p(out), C.c_size_t(x.size // n8q(curve)))
+    return out
+
+
+def build_abc(curve, coeffs, witness, n_vars, domain):
+    coeffs, witness = _u8(coeffs), _u8(witness)
+    A, B, Cc = (np.zeros(domain * 32, np.uint8) for _ in range(3))
+    rc = lib().orc_groth16_build_abc(curve, _p(coeffs), C.c_size_t(coeffs.size), _p(witness), C.c_size_t(n_vars),
+                                     C.c_size_t(domain), _p(A), _p(B), _p(Cc))
+    assert rc == 0
+    return A, B, Cc
+
+
+def join_abc(curve, A, B, Cc):
+    A, B, Cc = _u8(A), _u8(B), _u8(Cc)
+    out = np.empty_like(A)
+    lib().orc_groth16_join_abc(curve, _p(A), _p(B), _p(Cc), C.c_size_t(A.size // 32), _p(out))
+    return out
+
+
+def groth16_prove(curve, zk, wtns_witness, r_mont, s_mont):
+    """zk: dict from tests/binfile.py read_groth16_zkey(); returns (pi_a, pi_b, pi_c) affine Montgomery bytes."""
+    q = n8q(curve)
+    pi_a, pi_b, pi_c = np.zeros(2 * q, np.uint8), np.zeros(4 * q, np.uint8), np.zeros(2 * q, np.uint8)
+    keep = [_u8(zk[k]) for k in ("coeffs", "A", "B1", "B2", "C", "H", "vk_alpha_1", "vk_beta_1", "vk_beta_2",
+                                 "vk_delta_1", "vk_delta_2")]
+    w, r, s = _u8(wtns_witness), _u8(r_mont), _u8(s_mont)
+    rc = lib().orc_groth16_prove(curve, C.c_size_t(zk["nVars"]), C.c_size_t(zk["nPublic"]), C.c_size_t(zk["domainSize"]),
+                                 _p(keep[0]), C.c_size_t(keep[0].size), _p(w), _p(keep[1]), _p(keep[2]), _p(keep[3]),
+                                 _p(keep[4]), _p(keep[5]), _p(keep[6]), _p(keep[7]), _p(keep[8]), _p(keep[9]), _p(keep[10]),
+                                 _p(r), _p(s), _p(pi_a), _p(pi_b), _p(pi_c))
+    assert rc == 0
+    return pi_a, pi_b, pi_c

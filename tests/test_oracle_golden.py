@@ -1,0 +1,186 @@
+"""Pins the C restatement (oracle/zk_oracle.c) against golden vectors produced by the REAL reference
+(oracle/gen_golden.js running /root/reference/build/snarkjs.min.js).  CPU only.
+
+Covers SURVEY.md §8a rows a1-a9 at the byte level (NTT / batch ops) or as group elements after toAffine (MSM),
+and the seeded Groth16 proof of Appendix C.3 (proof JSON hash).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import binfile
+import oracle_lib as O
+import synth
+
+CURVES = ["bn128", "bls12381"]
+sha = lambda b: hashlib.sha256(bytes(b)).hexdigest()
+
+
+def load(golden_dir, name):
+    with open(os.path.join(golden_dir, f"{name}_kernel_vectors.json")) as f:
+        return json.load(f)
+
+
+def raw(golden_dir, name, key):
+    return np.fromfile(os.path.join(golden_dir, f"{name}_n1024_{key}.bin"), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_constants(golden_dir, name):
+    d, c = load(golden_dir, name), O.CURVE_ID[name]
+    assert bytes(O.fr_one(c)).hex() == d["Fr_one"]
+    assert O.lib().orc_two_adicity(c) == d["s"]
+    for i in range(d["s"] + 1):
+        assert bytes(O.fr_w(c, i)).hex() == d["w"][i]
+    assert bytes(O.generator(c, 1)).hex() == d["G1_g"]
+    assert bytes(O.generator(c, 2)).hex() == d["G2_g"]
+    assert O.n8q(c) == d["n8q"]
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_n1024_bytes(golden_dir, name):
+    d, c = load(golden_dir, name), O.CURVE_ID[name]
+    x = synth.iota(1024)
+    got = {
+        "fft": O.ntt(c, x), "ifft": O.ntt(c, x, True),
+        "applykey_7_11": O.apply_key(c, x, O.fr_e(c, 7), O.fr_e(c, 11)),
+        "to_mont": O.to_mont(c, x), "from_mont": O.from_mont(c, x), "inverse": O.batch_inverse(c, x),
+        "g1_bases": O.geom_bases(c, 1, 1024), "g2_bases": O.geom_bases(c, 2, 1024),
+    }
+    for k, v in got.items():
+        assert np.array_equal(v, raw(golden_dir, name, k)), k
+        assert sha(v) == d["n1024"][k]
+    for g in (1, 2):
+        jac = O.msm(c, g, got[f"g{g}_bases"], x, 1024)
+        assert np.array_equal(O.to_affine(c, g, jac), raw(golden_dir, name, f"g{g}_msm_affine"))
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_ntt_sizes(golden_dir, name):
+    d, c = load(golden_dir, name), O.CURVE_ID[name]
+    for lg, v in d["ntt"].items():
+        x = synth.elems(v["seed"], 1 << int(lg))
+        f, fi = O.ntt(c, x), O.ntt(c, x, True)
+        assert sha(f) == v["fft"] and sha(fi) == v["ifft"], lg
+        assert np.array_equal(O.ntt(c, fi), x)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_coset_chain_and_batch(golden_dir, name):
+    d, c = load(golden_dir, name), O.CURVE_ID[name]
+    for lg, v in d["coset_chain"].items():
+        lg = int(lg)
+        x = synth.elems(v["seed"], 1 << lg)
+        y = O.ntt(c, O.apply_key(c, O.ntt(c, x, True), O.fr_one(c), O.fr_w(c, lg + 1)))
+        assert sha(y) == v["out"], lg
+    b = d["batch"]
+    x = synth.elems(b["seed"], b["n"]).reshape(-1, 32)
+    for z in b["zeroed"]:
+        x[z] = 0
+    x = x.reshape(-1)
+    assert sha(O.batch_inverse(c, x)) == b["inverse"]
+    assert sha(O.to_mont(c, x)) == b["to_mont"]
+    assert sha(O.from_mont(c, x)) == b["from_mont"]
+    assert sha(O.apply_key(c, x, O.fr_e(c, 3), O.fr_e(c, 25))) == b["applykey_shift"]   # Fr.shift = nqr^2 = 25
+
+
+def msm_inputs(c, key, v, B1, B2):
+    """Rebuild the inputs of one golden MSM case (mirror of oracle/gen_golden.js kernelVectors)."""
+    q = O.n8q(c)
+    s1, s2 = 2 * q, 4 * q
+    n = v.get("n", 0)
+    if key.startswith("g1_uniform") or key == "g1_full256_2048":
+        return 1, B1[: n * s1], synth.elems(v["seed"], n, v.get("mask", 0x1F)), n, 32
+    if key.startswith("g2_uniform"):
+        return 2, B2[: n * s2], synth.elems(v["seed"], n), n, 32
+    if key == "g1_witnesslike_16384":
+        return 1, B1, synth.witness_like(v["seed"], n), n, 32
+    if key == "g2_witnesslike_4096":
+        return 2, B2, synth.witness_like(v["seed"], n), n, 32
+    if key == "g1_allff_64":
+        return 1, B1[: 64 * s1], np.full(64 * 32, 0xFF, np.uint8), 64, 32
+    if key == "g1_scalar4B_1024":
+        return 1, B1[: 1024 * s1], synth.elems(v["seed"], 128)[:4096], 1024, 4
+    if key == "g1_zeros_1024":
+        sc = synth.elems(v["seed"], 1024).reshape(1024, 32).copy()
+        sc[0::3] = 0
+        bz = B1[: 1024 * s1].reshape(1024, s1).copy()
+        bz[1::5] = 0
+        return 1, bz.reshape(-1), sc.reshape(-1), 1024, 32
+    if key == "g1_repeated_512":
+        idx = np.arange(512) & 3
+        bz = B1.reshape(-1, s1)[idx].reshape(-1).copy()
+        sc = np.zeros((512, 32), np.uint8)
+        sc[:, 0] = 5
+        sc[:, 2] = np.arange(512) >> 6
+        return 1, bz, sc.reshape(-1), 512, 32
+    if key == "g1_cancel_2":
+        P = B1[:s1].copy()
+        qmod = int(load.__globals__["_Q"][c])
+        y = int.from_bytes(bytes(P[q:]), "little")
+        negy = np.frombuffer(((qmod - y) % qmod).to_bytes(q, "little"), np.uint8)
+        bz = np.concatenate([P, P[:q], negy])
+        sc = np.zeros(64, np.uint8)
+        sc[0] = 9
+        sc[32] = 9
+        return 1, bz, sc, 2, 32
+    if key == "g1_allzero_scalars_100":
+        return 1, B1[: 100 * s1], np.zeros(3200, np.uint8), 100, 32
+    if key == "g1_empty":
+        return 1, np.zeros(0, np.uint8), np.zeros(0, np.uint8), 0, 32
+    raise KeyError(key)
+
+
+_Q = {}
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_msm_cases(golden_dir, name):
+    d, c = load(golden_dir, name), O.CURVE_ID[name]
+    _Q[c] = d["q"]
+    B1, B2 = O.geom_bases(c, 1, 1 << 14), O.geom_bases(c, 2, 1 << 12)
+    assert sha(B1) == d["g1_bases_16384"] and sha(B2) == d["g2_bases_4096"]
+    for key, v in d["msm"].items():
+        g, bases, scalars, n, sb = msm_inputs(c, key, v, B1, B2)
+        jac = O.msm(c, g, bases, scalars, n, sb)
+        assert bytes(O.to_affine(c, g, jac)).hex() == v["affine"], key
+        if n <= 100:   # independent double-and-add cross-check on the small cases
+            assert bytes(O.to_affine(c, g, O.msm(c, g, bases, scalars, n, sb, naive=True))).hex() == v["affine"], key
+
+
+def test_msm_closed_form():
+    """sum s_i·7·11^i mod r · G   equals the Pippenger restatement."""
+    c, n = O.BN128, 3000
+    r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    sc = synth.elems(0x9999, n)
+    k, f = 0, 7
+    for i in range(n):
+        k = (k + synth.to_int(sc[32 * i:32 * i + 32]) * f) % r
+        f = f * 11 % r
+    want = O.to_affine(c, 1, O.generator_mul(c, 1, k))
+    got = O.to_affine(c, 1, O.msm(c, 1, O.geom_bases(c, 1, n), sc, n))
+    assert np.array_equal(want, got)
+
+
+def test_groth16_golden_proof(golden_dir):
+    """Seeded Groth16 proof: the C restatement reproduces the reference's proof JSON hash."""
+    with open(os.path.join(golden_dir, "groth16_bn128_n1024.json")) as f:
+        g = json.load(f)
+    zkey = open(os.path.join(golden_dir, "groth16_bn128_n1024.zkey"), "rb").read()
+    wtns = open(os.path.join(golden_dir, "groth16_bn128_n1024.wtns"), "rb").read()
+    assert sha(zkey) == g["zkey_sha256"] == "10c89c8325ab5dd0abb8f39bd02aa32a19d18b4e288c5b33a226c91fca9983f2"
+    assert sha(wtns) == g["wtns_sha256"]
+    zk, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)
+    assert w["nWitness"] == zk["nVars"]
+    c = O.BN128
+    pa, pb, pc = O.groth16_prove(c, zk, w["witness"], bytes.fromhex(g["r_mont"]), bytes.fromhex(g["s_mont"]))
+    proof, js = binfile.proof_json("bn128", 32, O.fq_from_mont(c, pa), O.fq_from_mont(c, pb), O.fq_from_mont(c, pc))
+    assert proof == g["proof"]
+    assert sha(js.encode()) == g["proof_sha256"] == "08797809c8de2c2053a925b1772af3e04c41f8c9b4c41f5b71ae5135435da44d"
+    # stage-level replay: the bytes the reference passed across each bulk-op boundary inside groth16.prove
+    A, B, Cc = O.build_abc(c, zk["coeffs"], w["witness"], zk["nVars"], zk["domainSize"])
+    calls = [x for x in g["calls"] if x["op"] == "Fr.ifft"]
+    assert [sha(A), sha(B), sha(Cc)] == [x["in0"] for x in calls]
