@@ -1,0 +1,143 @@
+// snarkjs_amd/csrc/curve.cuh — short-Weierstrass (a = 0) group arithmetic for the MSM kernels, gfx950.
+//
+// Replaces wasmcurves' g1m_/g2m_ Jacobian add/addMixed/double (reference bundle build/snarkjs.min.js:1@86766) inside
+// the Pippenger kernels. The accumulators use extended-Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ,
+// ZZ^3 = ZZZ^2): a mixed addition costs 8M+2S (vs 7M+4S Jacobian) and a doubling never needs Z. Points cross the
+// C-ABI in the reference's own formats: affine (x,y) Montgomery with all-zero = infinity in, Jacobian out.
+#pragma once
+#include "field.cuh"
+
+namespace zkmi {
+
+// ---- quadratic extension Fq2 = Fq[u]/(u^2+1) (both BN254 and BLS12-381) ----------------------------------------
+template <class C> struct Fp2 {
+    Fp<C> c0, c1;
+    using Cfg = C;
+};
+
+// uniform free-function interface over Fp<C> and Fp2<C>
+template <class C> ZK_DEV Fp<C> f_add(const Fp<C>& a, const Fp<C>& b) { return fp_add(a, b); }
+template <class C> ZK_DEV Fp<C> f_sub(const Fp<C>& a, const Fp<C>& b) { return fp_sub(a, b); }
+template <class C> ZK_DEV Fp<C> f_mul(const Fp<C>& a, const Fp<C>& b) { return fp_mul(a, b); }
+template <class C> ZK_DEV Fp<C> f_sqr(const Fp<C>& a) { return fp_sqr(a); }
+template <class C> ZK_DEV Fp<C> f_dbl(const Fp<C>& a) { return fp_dbl(a); }
+template <class C> ZK_DEV Fp<C> f_neg(const Fp<C>& a) { return fp_neg(a); }
+template <class C> ZK_DEV bool f_is_zero(const Fp<C>& a) { return fp_is_zero(a); }
+template <class C> ZK_DEV bool f_eq(const Fp<C>& a, const Fp<C>& b) { return fp_eq(a, b); }
+template <class C> ZK_DEV void f_set_zero(Fp<C>& a) { a = fp_zero<C>(); }
+template <class C> ZK_DEV void f_set_one(Fp<C>& a) { a = fp_one<C>(); }
+template <class C> ZK_DEV Fp<C> f_inv(const Fp<C>& a) { return fp_inv(a); }
+
+template <class C> ZK_DEV Fp2<C> f_add(const Fp2<C>& a, const Fp2<C>& b) { return Fp2<C>{fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; }
+template <class C> ZK_DEV Fp2<C> f_sub(const Fp2<C>& a, const Fp2<C>& b) { return Fp2<C>{fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }
+template <class C> ZK_DEV Fp2<C> f_dbl(const Fp2<C>& a) { return Fp2<C>{fp_dbl(a.c0), fp_dbl(a.c1)}; }
+template <class C> ZK_DEV Fp2<C> f_neg(const Fp2<C>& a) { return Fp2<C>{fp_neg(a.c0), fp_neg(a.c1)}; }
+template <class C> ZK_DEV bool f_is_zero(const Fp2<C>& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
+template <class C> ZK_DEV bool f_eq(const Fp2<C>& a, const Fp2<C>& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
+template <class C> ZK_DEV void f_set_zero(Fp2<C>& a) { a.c0 = fp_zero<C>(); a.c1 = fp_zero<C>(); }
+template <class C> ZK_DEV void f_set_one(Fp2<C>& a) { a.c0 = fp_one<C>(); a.c1 = fp_zero<C>(); }
+// Karatsuba: 3 base-field multiplications
+template <class C> ZK_DEV Fp2<C> f_mul(const Fp2<C>& a, const Fp2<C>& b) {
+    Fp<C> t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
+    Fp<C> t2 = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+    return Fp2<C>{fp_sub(t0, t1), fp_sub(fp_sub(t2, t0), t1)};
+}
+// (a0+a1)(a0-a1) + 2 a0 a1 u : 2 multiplications
+template <class C> ZK_DEV Fp2<C> f_sqr(const Fp2<C>& a) {
+    Fp<C> t = fp_mul(a.c0, a.c1);
+    return Fp2<C>{fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
+}
+template <class C> ZK_DEV Fp2<C> f_inv(const Fp2<C>& a) {
+    Fp<C> d = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
+    return Fp2<C>{fp_mul(a.c0, d), fp_neg(fp_mul(a.c1, d))};
+}
+
+// element size in 32-bit words
+template <class F> struct FieldWords;
+template <class C> struct FieldWords<Fp<C>> { static constexpr int value = C::N; };
+template <class C> struct FieldWords<Fp2<C>> { static constexpr int value = 2 * C::N; };
+
+template <class C> ZK_DEV void f_load(Fp<C>& r, const uint32_t* p) { r = fp_load<C>(p); }
+template <class C> ZK_DEV void f_store(uint32_t* p, const Fp<C>& a) { fp_store<C>(p, a); }
+template <class C> ZK_DEV void f_load(Fp2<C>& r, const uint32_t* p) { r.c0 = fp_load<C>(p); r.c1 = fp_load<C>(p + C::N); }
+template <class C> ZK_DEV void f_store(uint32_t* p, const Fp2<C>& a) { fp_store<C>(p, a.c0); fp_store<C>(p + C::N, a.c1); }
+
+// ---- points ----------------------------------------------------------------------------------------------------
+template <class F> struct Affine { F x, y; };                 // infinity: x = y = 0 (the reference's all-zero encoding)
+template <class F> struct XYZZ { F X, Y, ZZ, ZZZ; };           // infinity: ZZ = 0
+
+template <class F> ZK_DEV bool pt_is_inf(const Affine<F>& p) { return f_is_zero(p.x) && f_is_zero(p.y); }
+template <class F> ZK_DEV bool pt_is_inf(const XYZZ<F>& p) { return f_is_zero(p.ZZ); }
+template <class F> ZK_DEV void pt_set_inf(XYZZ<F>& p) { f_set_zero(p.X); f_set_zero(p.Y); f_set_zero(p.ZZ); f_set_zero(p.ZZZ); }
+
+template <class F> ZK_DEV void pt_load(Affine<F>& p, const uint32_t* src) {
+    constexpr int W = FieldWords<F>::value;
+    f_load(p.x, src); f_load(p.y, src + W);
+}
+template <class F> ZK_DEV void pt_load(XYZZ<F>& p, const uint32_t* src) {
+    constexpr int W = FieldWords<F>::value;
+    f_load(p.X, src); f_load(p.Y, src + W); f_load(p.ZZ, src + 2 * W); f_load(p.ZZZ, src + 3 * W);
+}
+template <class F> ZK_DEV void pt_store(uint32_t* dst, const XYZZ<F>& p) {
+    constexpr int W = FieldWords<F>::value;
+    f_store(dst, p.X); f_store(dst + W, p.Y); f_store(dst + 2 * W, p.ZZ); f_store(dst + 3 * W, p.ZZZ);
+}
+
+// doubling of an affine point into XYZZ (EFD mdbl-2008-s-1, a = 0)
+template <class F> ZK_DEV XYZZ<F> pt_dbl_affine(const Affine<F>& p) {
+    XYZZ<F> r;
+    F U = f_dbl(p.y), V = f_sqr(U), W = f_mul(U, V), S = f_mul(p.x, V);
+    F xx = f_sqr(p.x), M = f_add(f_dbl(xx), xx);
+    r.X = f_sub(f_sqr(M), f_dbl(S));
+    r.Y = f_sub(f_mul(M, f_sub(S, r.X)), f_mul(W, p.y));
+    r.ZZ = V; r.ZZZ = W;
+    return r;
+}
+// XYZZ doubling (EFD dbl-2008-s-1, a = 0). noinline: used off the hot loop (bucket reduction); keeps code size and
+// compile time bounded — the call costs nothing next to 9 field multiplications.
+template <class F> __device__ __noinline__ XYZZ<F> pt_dbl(const XYZZ<F>& p) {
+    if (pt_is_inf(p)) return p;
+    XYZZ<F> r;
+    F U = f_dbl(p.Y), V = f_sqr(U), W = f_mul(U, V), S = f_mul(p.X, V);
+    F xx = f_sqr(p.X), M = f_add(f_dbl(xx), xx);
+    r.X = f_sub(f_sqr(M), f_dbl(S));
+    r.Y = f_sub(f_mul(M, f_sub(S, r.X)), f_mul(W, p.Y));
+    r.ZZ = f_mul(V, p.ZZ); r.ZZZ = f_mul(W, p.ZZZ);
+    return r;
+}
+// acc += q (q affine, not infinity unless flagged by the caller). EFD madd-2008-s: 8M + 2S.
+template <class F> ZK_DEV void pt_madd(XYZZ<F>& acc, const Affine<F>& q) {
+    if (pt_is_inf(q)) return;
+    if (pt_is_inf(acc)) { acc.X = q.x; acc.Y = q.y; f_set_one(acc.ZZ); f_set_one(acc.ZZZ); return; }
+    F U2 = f_mul(q.x, acc.ZZ), S2 = f_mul(q.y, acc.ZZZ);
+    F P = f_sub(U2, acc.X), R = f_sub(S2, acc.Y);
+    if (f_is_zero(P)) {
+        if (f_is_zero(R)) acc = pt_dbl_affine(q); else pt_set_inf(acc);
+        return;
+    }
+    F PP = f_sqr(P), PPP = f_mul(P, PP), Q = f_mul(acc.X, PP);
+    F X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
+    acc.Y = f_sub(f_mul(R, f_sub(Q, X3)), f_mul(acc.Y, PPP));
+    acc.X = X3;
+    acc.ZZ = f_mul(acc.ZZ, PP); acc.ZZZ = f_mul(acc.ZZZ, PPP);
+}
+// full addition (EFD add-2008-s: 12M + 2S) with all special cases
+template <class F> __device__ __noinline__ XYZZ<F> pt_add(const XYZZ<F>& a, const XYZZ<F>& b) {
+    if (pt_is_inf(a)) return b;
+    if (pt_is_inf(b)) return a;
+    F U1 = f_mul(a.X, b.ZZ), U2 = f_mul(b.X, a.ZZ), S1 = f_mul(a.Y, b.ZZZ), S2 = f_mul(b.Y, a.ZZZ);
+    F P = f_sub(U2, U1), R = f_sub(S2, S1);
+    if (f_is_zero(P)) {
+        if (f_is_zero(R)) return pt_dbl(a);
+        XYZZ<F> z; pt_set_inf(z); return z;
+    }
+    XYZZ<F> r;
+    F PP = f_sqr(P), PPP = f_mul(P, PP), Q = f_mul(U1, PP);
+    r.X = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
+    r.Y = f_sub(f_mul(R, f_sub(Q, r.X)), f_mul(S1, PPP));
+    r.ZZ = f_mul(f_mul(a.ZZ, b.ZZ), PP);
+    r.ZZZ = f_mul(f_mul(a.ZZZ, b.ZZZ), PPP);
+    return r;
+}
+
+}  // namespace zkmi

@@ -1,0 +1,255 @@
+// snarkjs_amd/csrc/msm.cuh — Pippenger multi-scalar multiplication for gfx950.
+//
+// Replaces ffjavascript's engine_multiexp (window tasks over Web Workers, build/snarkjs.min.js:1@213360/@214651)
+// and wasmcurves' g1m_/g2m_multiexpAffine_chunk (@75966): instead of one 2^c-bucket pass per (chunk, window) task
+// with the bases re-copied per window, the whole MSM is five data-parallel device stages over all windows at once:
+//
+//   1. k_msm_count    signed-digit recoding of every scalar, histogram of bucket sizes        (global atomics)
+//   2. k_msm_scan     exclusive scan of the histogram per window                              (LDS block scan)
+//   3. k_msm_scatter  counting-sort scatter: per bucket, the list of (point index, sign)
+//   4. k_msm_accum    one lane per bucket: gather bases, XYZZ mixed additions (the hot loop: n·W of them)
+//   5. k_msm_reduce*  per window sum_b (b+1)·B_b: lane-sequential running sums over 8 buckets, then LDS
+//                     suffix-scan + tree levels (depth O(log) instead of the reference's recursive _reduceTable)
+//
+// The W per-window points go back to the host, which folds them with c doublings per window (the reference also
+// does this step on the host, @213360).  Signed digits halve the bucket count: 2^(c-1) buckets per window.
+#pragma once
+#include "curve.cuh"
+
+namespace zkmi {
+
+struct MsmShape {
+    uint32_t n;        // terms
+    int c;             // window bits
+    int W;             // windows = ceil((8*scalar_bytes + 1) / c)
+    uint32_t nb;       // buckets per window = 2^(c-1)
+    int sb;            // scalar bytes
+};
+
+// ---- scalar access / signed-digit recoding ----------------------------------------------------------------------
+template <int NW> ZK_DEV void load_scalar(uint32_t (&s)[NW], const uint8_t* scalars, size_t i, int sb) {
+    const uint8_t* p = scalars + i * (size_t)sb;
+    if ((sb & 3) == 0 && ((uintptr_t)scalars & 3) == 0) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+        for (int k = 0; k < NW; k++) s[k] = (4 * k < sb) ? q[k] : 0u;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            uint32_t v = 0;
+            for (int b = 0; b < 4; b++) if (4 * k + b < sb) v |= (uint32_t)p[4 * k + b] << (8 * b);
+            s[k] = v;
+        }
+    }
+}
+// bits [bit, bit+c) of the little-endian integer s (zero beyond 32*NW)
+template <int NW> ZK_DEV uint32_t window_bits(const uint32_t (&s)[NW], int bit, int c) {
+    int wi = bit >> 5, sh = bit & 31;
+    uint64_t lo = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        if (k == wi) lo |= s[k];
+        if (k == wi + 1) lo |= (uint64_t)s[k] << 32;
+    }
+    return (uint32_t)(lo >> sh) & ((1u << c) - 1u);
+}
+// Calls f(window, magnitude in [1, 2^(c-1)], negative) for every non-zero signed digit of s.
+template <int NW, class Fn> ZK_DEV void for_each_digit(const uint32_t (&s)[NW], int c, int W, Fn f) {
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (c - 1);
+    for (int w = 0; w < W; w++) {
+        uint32_t raw = window_bits<NW>(s, w * c, c) + carry;
+        bool neg = raw > half;
+        uint32_t mag = neg ? ((1u << c) - raw) : raw;
+        carry = neg ? 1u : 0u;
+        if (mag) f(w, mag, neg);
+    }
+}
+
+template <int NW> __global__ void k_msm_count(const uint8_t* __restrict__ scalars, MsmShape sh, uint32_t* __restrict__ counts) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sh.n) return;
+    uint32_t s[NW];
+    load_scalar<NW>(s, scalars, i, sh.sb);
+    for_each_digit<NW>(s, sh.c, sh.W, [&](int w, uint32_t mag, bool) { atomicAdd(&counts[(size_t)w * sh.nb + (mag - 1)], 1u); });
+}
+
+// one block per window: starts[w][b] = exclusive prefix sum of counts[w][*]
+static __global__ void k_msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts, uint32_t nb) {
+    __shared__ uint32_t part[1024];
+    const uint32_t* cw = counts + (size_t)blockIdx.x * nb;
+    uint32_t* sw = starts + (size_t)blockIdx.x * nb;
+    const uint32_t per = (nb + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = threadIdx.x * per, hi = min(nb, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += cw[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
+        uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t b = lo; b < hi; b++) { sw[b] = run; run += cw[b]; }
+}
+
+template <int NW> __global__ void k_msm_scatter(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ starts,
+                                               uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sh.n) return;
+    uint32_t s[NW];
+    load_scalar<NW>(s, scalars, i, sh.sb);
+    for_each_digit<NW>(s, sh.c, sh.W, [&](int w, uint32_t mag, bool neg) {
+        size_t g = (size_t)w * sh.nb + (mag - 1);
+        uint32_t pos = starts[g] + atomicAdd(&cursor[g], 1u);
+        sorted[(size_t)w * sh.n + pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+    });
+}
+
+// ---- bucket accumulation: one lane per bucket -----------------------------------------------------------------------
+// order == nullptr: bucket g = global thread id; otherwise g = order[tid] (buckets sorted by size so that the lanes of
+// a wave run equally long loops).
+template <class F> __global__ void __launch_bounds__(256)
+k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
+            const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order, uint32_t* __restrict__ buckets) {
+    constexpr int FW = FieldWords<F>::value;
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)sh.W * sh.nb;
+    if (tid >= total) return;
+    size_t g = order ? order[tid] : tid;
+    const uint32_t w = (uint32_t)(g / sh.nb);
+    const uint32_t cnt = counts[g];
+    const uint32_t* list = sorted + (size_t)w * sh.n + starts[g];
+    XYZZ<F> acc;
+    pt_set_inf(acc);
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t e = list[k];
+        Affine<F> q;
+        pt_load(q, bases + (size_t)(e & 0x7fffffffu) * (2 * FW));
+        if (e >> 31) q.y = f_neg(q.y);
+        pt_madd(acc, q);
+    }
+    pt_store(buckets + g * (4 * FW), acc);
+}
+
+// ---- bucket reduction -------------------------------------------------------------------------------------------------
+// Invariant carried through the levels (per window):  result = sum_t A_t + scale * sum_t t*R_t  + (top level) sum_t R_t,
+// where t is the index inside the window at that level. Level 0 has A = 0, R = buckets, scale = 1.
+//
+// Level 1: each lane takes G consecutive buckets:  A' = sum_j j*B_j (running sums), R' = sum_j B_j.
+template <class F> __global__ void __launch_bounds__(256)
+k_msm_reduce_seq(const uint32_t* __restrict__ buckets, uint32_t nb, uint32_t G, uint32_t groups_per_window, uint32_t total_groups,
+                 uint32_t* __restrict__ outA, uint32_t* __restrict__ outR) {
+    constexpr int PW = 4 * FieldWords<F>::value;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_groups) return;
+    uint32_t w = t / groups_per_window, u = t % groups_per_window;
+    const uint32_t* src = buckets + ((size_t)w * nb + (size_t)u * G) * PW;
+    XYZZ<F> run, acc;
+    pt_set_inf(run); pt_set_inf(acc);
+    for (int j = (int)G - 1; j >= 1; j--) {
+        XYZZ<F> b; pt_load(b, src + (size_t)j * PW);
+        run = pt_add(run, b);
+        acc = pt_add(acc, run);
+    }
+    { XYZZ<F> b; pt_load(b, src); run = pt_add(run, b); }
+    pt_store(outA + (size_t)t * PW, acc);
+    pt_store(outR + (size_t)t * PW, run);
+}
+// Level >= 2: one block of M lanes per M consecutive (A,R) pairs of a window:
+//   A' = sum_t A_t + scale * sum_{t>=1} suffix_t(R),  R' = suffix_0(R);  if `final`: out = A' + R' (one point per window).
+template <class F, int M> __global__ void __launch_bounds__(M)
+k_msm_reduce_block(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inR, uint32_t m_per_window, uint32_t blocks_per_window,
+                   int log_scale, int final, uint32_t* __restrict__ outA, uint32_t* __restrict__ outR) {
+    constexpr int PW = 4 * FieldWords<F>::value;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* sR = lds;
+    uint32_t* sA = lds + M * PW;
+    const uint32_t w = blockIdx.x / blocks_per_window, blk = blockIdx.x % blocks_per_window, t = threadIdx.x;
+    const uint32_t idx = blk * M + t;
+    XYZZ<F> myR, myA;
+    if (idx < m_per_window) {
+        pt_load(myR, inR + ((size_t)w * m_per_window + idx) * PW);
+        pt_load(myA, inA + ((size_t)w * m_per_window + idx) * PW);
+    } else { pt_set_inf(myR); pt_set_inf(myA); }
+    pt_store(sR + t * PW, myR);
+    __syncthreads();
+    // inclusive suffix scan of R (Hillis-Steele)
+    for (int d = 1; d < M; d <<= 1) {
+        XYZZ<F> o;
+        if (t + d < M) pt_load(o, sR + (t + d) * PW); else pt_set_inf(o);
+        __syncthreads();
+        myR = pt_add(myR, o);
+        pt_store(sR + t * PW, myR);
+        __syncthreads();
+    }
+    // X_t = suffix_t for t >= 1 (else 0); tree-sum X and A together
+    XYZZ<F> myX = myR;
+    if (t == 0) pt_set_inf(myX);
+    pt_store(sR + t * PW, myX);
+    pt_store(sA + t * PW, myA);
+    __syncthreads();
+    for (int d = M / 2; d >= 1; d >>= 1) {
+        if (t < (uint32_t)d) {
+            XYZZ<F> o; pt_load(o, sR + (t + d) * PW); myX = pt_add(myX, o); pt_store(sR + t * PW, myX);
+            XYZZ<F> p; pt_load(p, sA + (t + d) * PW); myA = pt_add(myA, p); pt_store(sA + t * PW, myA);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        for (int k = 0; k < log_scale; k++) myX = pt_dbl(myX);
+        XYZZ<F> a = pt_add(myA, myX);
+        size_t o = (size_t)w * blocks_per_window + blk;
+        if (final) a = pt_add(a, myR);          // myR of lane 0 = suffix_0 = sum of all R
+        pt_store(outA + o * PW, a);
+        if (!final) pt_store(outR + o * PW, myR);
+    }
+}
+
+// ---- bucket ordering by size (descending) so that a wave's lanes get equal trip counts ----------------------------------
+static __global__ void k_msm_size_hist(const uint32_t* __restrict__ counts, uint32_t total, uint32_t max_bin, uint32_t* __restrict__ hist) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    atomicAdd(&hist[min(counts[g], max_bin)], 1u);
+}
+// single block: descending exclusive scan over the (small) size histogram
+static __global__ void k_msm_size_scan(uint32_t* __restrict__ hist, uint32_t bins) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t run = 0;
+        for (int b = (int)bins - 1; b >= 0; b--) { uint32_t v = hist[b]; hist[b] = run; run += v; }
+    }
+}
+static __global__ void k_msm_size_scatter(const uint32_t* __restrict__ counts, uint32_t total, uint32_t max_bin, uint32_t* __restrict__ hist, uint32_t* __restrict__ order) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    uint32_t pos = atomicAdd(&hist[min(counts[g], max_bin)], 1u);
+    order[pos] = g;
+}
+
+// ---- synthetic base table (zkmi_gen_geometric_bases_dev): P_i = (f*g^i mod r)*G ----------------------------------------
+// One lane per point: scalar k_i = f*g^i by square-and-multiply in Fr, then k_i*G by double-and-add (XYZZ), then
+// affine by one Fermat inversion. Off the hot path (benchmark/test set-up only).
+template <class F, class FrC> __global__ void __launch_bounds__(256)
+k_gen_geometric_bases(const uint32_t* __restrict__ gen_affine, uint32_t n, uint64_t f, uint64_t g, uint32_t* __restrict__ out) {
+    constexpr int FW = FieldWords<F>::value;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<FrC> fm = fp_zero<FrC>(), gm = fp_zero<FrC>();
+    fm.l[0] = (uint32_t)f; fm.l[1] = (uint32_t)(f >> 32); gm.l[0] = (uint32_t)g; gm.l[1] = (uint32_t)(g >> 32);
+    fm = fp_to_mont(fm); gm = fp_to_mont(gm);
+    Fp<FrC> k = fp_from_mont(fp_mul(fm, fp_pow_u32(gm, i)));
+    Affine<F> G; pt_load(G, gen_affine);
+    XYZZ<F> acc; pt_set_inf(acc);
+    for (int b = 32 * FrC::N - 1; b >= 0; b--) {
+        acc = pt_dbl(acc);
+        if ((k.l[b >> 5] >> (b & 31)) & 1) pt_madd(acc, G);
+    }
+    Affine<F> r;
+    if (pt_is_inf(acc)) { f_set_zero(r.x); f_set_zero(r.y); }
+    else { r.x = f_mul(acc.X, f_inv(acc.ZZ)); r.y = f_mul(acc.Y, f_inv(acc.ZZZ)); }
+    f_store(out + (size_t)i * 2 * FW, r.x); f_store(out + (size_t)i * 2 * FW + FW, r.y);
+}
+
+}  // namespace zkmi

@@ -1,0 +1,40 @@
+// snarkjs_amd/csrc/msm_bn254.hip — BN254 (bn128) instantiations of the MSM pipeline: G1 over Fq, G2 over Fq2.
+#include "msm_host.hpp"
+
+namespace zkmi {
+
+// generators, normal form (x, y) / ((x.c0,x.c1),(y.c0,y.c1)); converted to Montgomery form on first use
+static const uint64_t BN254_G1[2][4] = {{1, 0, 0, 0}, {2, 0, 0, 0}};
+static const uint64_t BN254_G2[4][4] = {
+    {0x46debd5cd992f6edULL, 0x674322d4f75edaddULL, 0x426a00665e5c4479ULL, 0x1800deef121f1e76ULL},
+    {0x97e485b7aef312c2ULL, 0xf1aa493335a9e712ULL, 0x7260bfb731fb5d25ULL, 0x198e9393920d483aULL},
+    {0x4ce6cc0166fa7daaULL, 0xe3d1e7690c43d37bULL, 0x4aab71808dcb408fULL, 0x12c85ea5db8c6debULL},
+    {0x55acdadcd122975bULL, 0xbc4b313370b38ef3ULL, 0xec9e99ad690c3395ULL, 0x090689d0585ff075ULL}};
+
+static void bn254_generator(int group, uint8_t* out) {
+    auto F = host::HField<4>::from_cfg<Bn254Fq>();
+    const int k = 2 * group;
+    for (int i = 0; i < k; i++) {
+        host::HFp<4> e;
+        memcpy(e.v, group == 1 ? BN254_G1[i] : BN254_G2[i], 32);
+        e = F.to_mont(e);
+        memcpy(out + 32 * i, e.v, 32);
+    }
+}
+
+int msm_bn254(int group, const void* d_bases, const void* d_scalars, size_t n, size_t sb, uint8_t* out_jac) {
+    if (group == 1) return msm_run<Fp<Bn254Fq>>(d_bases, d_scalars, n, sb, out_jac);
+    return msm_run<Fp2<Bn254Fq>>(d_bases, d_scalars, n, sb, out_jac);
+}
+int gen_bases_bn254(int group, size_t n, uint64_t f, uint64_t g, void* d_out) {
+    uint8_t gen[128];
+    bn254_generator(group, gen);
+    if (group == 1) return gen_bases_run<Fp<Bn254Fq>, Bn254Fr>(gen, n, f, g, d_out);
+    return gen_bases_run<Fp2<Bn254Fq>, Bn254Fr>(gen, n, f, g, d_out);
+}
+int to_affine_bn254(int group, const uint8_t* jac, uint8_t* aff) {
+    if (group == 1) return to_affine_host<Fp<Bn254Fq>>(jac, aff);
+    return to_affine_host<Fp2<Bn254Fq>>(jac, aff);
+}
+
+}  // namespace zkmi

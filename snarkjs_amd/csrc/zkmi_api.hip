@@ -1,0 +1,262 @@
+// snarkjs_amd/csrc/zkmi_api.hip — C-ABI entry points of libzkmi.so (include/zkmi.h): context, memory, page
+// marshalling and dispatch to the per-curve kernel drivers.  No CPU fallback: every compute entry point requires a
+// HIP device and fails with ZKMI_ERR_NO_DEVICE otherwise.
+#include <string.h>
+#include "zkmi_common.hpp"
+
+namespace zkmi {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+static Ctx g_ctx;
+Ctx& ctx() { return g_ctx; }
+
+int require_ctx() {
+    if (g_ctx.ready) return ZKMI_OK;
+    return zkmi_init(0);
+}
+
+int ws_get(const std::string& name, size_t bytes, void** out) {
+    DevBuf& b = g_ctx.ws[name];
+    if (b.cap < bytes) {
+        if (b.p) { ZK_HIP(hipStreamSynchronize(g_ctx.stream)); ZK_HIP(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+        size_t cap = bytes + bytes / 8 + 256;
+        ZK_HIP(hipMalloc(&b.p, cap));
+        b.cap = cap;
+    }
+    *out = b.p;
+    return ZKMI_OK;
+}
+
+static size_t pages_total(const zkmi_pages& pg) { size_t t = 0; for (int i = 0; i < pg.n_pages; i++) t += pg.len[i]; return t; }
+
+int upload_pages(const zkmi_pages& pg, size_t total_bytes, void* d_dst) {
+    if (pages_total(pg) < total_bytes) return fail(ZKMI_ERR_INVALID, "input buffer shorter than n elements");
+    size_t off = 0;
+    for (int i = 0; i < pg.n_pages && off < total_bytes; i++) {
+        size_t k = pg.len[i] < total_bytes - off ? pg.len[i] : total_bytes - off;
+        if (k) ZK_HIP(hipMemcpyAsync((uint8_t*)d_dst + off, pg.ptr[i], k, hipMemcpyHostToDevice, g_ctx.stream));
+        off += k;
+    }
+    return ZKMI_OK;
+}
+int download_pages(const void* d_src, size_t total_bytes, uint8_t* const* out_ptr, const size_t* out_len, int n_out_pages) {
+    size_t cap = 0;
+    for (int i = 0; i < n_out_pages; i++) cap += out_len[i];
+    if (cap < total_bytes) return fail(ZKMI_ERR_INVALID, "output buffer too small");
+    size_t off = 0;
+    for (int i = 0; i < n_out_pages && off < total_bytes; i++) {
+        size_t k = out_len[i] < total_bytes - off ? out_len[i] : total_bytes - off;
+        if (k) ZK_HIP(hipMemcpyAsync(out_ptr[i], (const uint8_t*)d_src + off, k, hipMemcpyDeviceToHost, g_ctx.stream));
+        off += k;
+    }
+    ZK_HIP(hipStreamSynchronize(g_ctx.stream));
+    return ZKMI_OK;
+}
+
+int msm_bn254(int group, const void*, const void*, size_t, size_t, uint8_t*);
+int msm_bls12381(int group, const void*, const void*, size_t, size_t, uint8_t*);
+int gen_bases_bn254(int group, size_t, uint64_t, uint64_t, void*);
+int gen_bases_bls12381(int group, size_t, uint64_t, uint64_t, void*);
+int to_affine_bn254(int group, const uint8_t*, uint8_t*);
+int to_affine_bls12381(int group, const uint8_t*, uint8_t*);
+
+static int check_cg(int curve, int group) {
+    if (curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381) return fail(ZKMI_ERR_INVALID, "unknown curve");
+    if (group != 1 && group != 2) return fail(ZKMI_ERR_INVALID, "Invalid group");
+    return ZKMI_OK;
+}
+int msm_dev_dispatch(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t sb, uint8_t* out) {
+    ZK_TRY(check_cg(curve, group));
+    return curve == ZKMI_CURVE_BN128 ? msm_bn254(group, d_bases, d_scalars, n, sb, out) : msm_bls12381(group, d_bases, d_scalars, n, sb, out);
+}
+int gen_bases_dispatch(int curve, int group, size_t n, uint64_t f, uint64_t g, void* d_out) {
+    ZK_TRY(check_cg(curve, group));
+    return curve == ZKMI_CURVE_BN128 ? gen_bases_bn254(group, n, f, g, d_out) : gen_bases_bls12381(group, n, f, g, d_out);
+}
+int to_affine_dispatch(int curve, int group, const uint8_t* jac, uint8_t* aff) {
+    ZK_TRY(check_cg(curve, group));
+    return curve == ZKMI_CURVE_BN128 ? to_affine_bn254(group, jac, aff) : to_affine_bls12381(group, jac, aff);
+}
+
+}  // namespace zkmi
+
+using namespace zkmi;
+
+extern "C" {
+
+const char* zkmi_version(void) { return "snarkjs-amd 0.1 (gfx950)"; }
+const char* zkmi_last_error(void) { return g_err.c_str(); }
+
+int zkmi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int zkmi_init(int device) {
+    if (g_ctx.ready && (device < 0 || device == g_ctx.device)) return ZKMI_OK;
+    if (g_ctx.ready) return fail(ZKMI_ERR_INVALID, "zkmi_init: already bound to another device (one process per GPU)");
+    int n = zkmi_device_count();
+    if (n <= 0) return fail(ZKMI_ERR_NO_DEVICE, "no HIP device visible: the MI355X backend has no CPU fallback");
+    if (device < 0) device = 0;
+    if (device >= n) return fail(ZKMI_ERR_INVALID, "zkmi_init: device index out of range");
+    ZK_HIP(hipSetDevice(device));
+    ZK_HIP(hipStreamCreateWithFlags(&g_ctx.own_stream, hipStreamNonBlocking));
+    g_ctx.stream = g_ctx.own_stream;
+    ZK_HIP(hipEventCreate(&g_ctx.ev0));
+    ZK_HIP(hipEventCreate(&g_ctx.ev1));
+    g_ctx.device = device;
+    g_ctx.ready = true;
+    return ZKMI_OK;
+}
+int zkmi_set_stream(void* s) {
+    ZK_TRY(require_ctx());
+    g_ctx.stream = s ? (hipStream_t)s : g_ctx.own_stream;
+    return ZKMI_OK;
+}
+int zkmi_synchronize(void) {
+    ZK_TRY(require_ctx());
+    ZK_HIP(hipStreamSynchronize(g_ctx.stream));
+    return ZKMI_OK;
+}
+double zkmi_last_kernel_ms(void) {
+    if (!g_ctx.ready) return 0.0;
+    if (hipEventSynchronize(g_ctx.ev1) != hipSuccess) return 0.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g_ctx.ev0, g_ctx.ev1) != hipSuccess) return g_ctx.last_ms;
+    return ms;
+}
+int zkmi_dev_alloc(size_t bytes, void** d_ptr) {
+    ZK_TRY(require_ctx());
+    ZK_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    g_ctx.user_allocs[*d_ptr] = bytes;
+    return ZKMI_OK;
+}
+int zkmi_dev_free(void* d_ptr) {
+    ZK_TRY(require_ctx());
+    if (!d_ptr) return ZKMI_OK;
+    g_ctx.user_allocs.erase(d_ptr);
+    ZK_HIP(hipFree(d_ptr));
+    return ZKMI_OK;
+}
+int zkmi_memcpy_h2d(void* d, const void* h, size_t bytes) {
+    ZK_TRY(require_ctx());
+    ZK_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+    ZK_HIP(hipStreamSynchronize(g_ctx.stream));
+    return ZKMI_OK;
+}
+int zkmi_memcpy_d2h(void* h, const void* d, size_t bytes) {
+    ZK_TRY(require_ctx());
+    ZK_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+    ZK_HIP(hipStreamSynchronize(g_ctx.stream));
+    return ZKMI_OK;
+}
+
+int zkmi_msm_set_window_bits(int c) {
+    if (c < 0 || c > 20) return fail(ZKMI_ERR_INVALID, "window bits must be 0 (auto) or 1..20");
+    g_ctx.msm_c_override = c;
+    return ZKMI_OK;
+}
+int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t scalar_bytes, uint8_t* out) {
+    ZK_TRY(require_ctx());
+    if (!out) return fail(ZKMI_ERR_INVALID, "null output");
+    return msm_dev_dispatch(curve, group, d_bases, d_scalars, n, scalar_bytes, out);
+}
+int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t n, size_t scalar_bytes, uint64_t key, uint8_t* out) {
+    ZK_TRY(require_ctx());
+    ZK_TRY(check_cg(curve, group));
+    if (!out) return fail(ZKMI_ERR_INVALID, "null output");
+    const size_t pb = (size_t)2 * group * n8q_of(curve);
+    if (n == 0) { memset(out, 0, 3 * group * n8q_of(curve)); return ZKMI_OK; }
+    if (pages_total(scalars) != n * scalar_bytes) return fail(ZKMI_ERR_INVALID, "Scalar size does not match");
+    void *d_b = nullptr, *d_s = nullptr;
+    if (key) {
+        DevBuf& b = g_ctx.base_cache[key];
+        if (b.cap != n * pb) {
+            if (b.p) ZK_HIP(hipFree(b.p));
+            b.p = nullptr; b.cap = 0;
+            ZK_HIP(hipMalloc(&b.p, n * pb));
+            b.cap = n * pb;
+            ZK_TRY(upload_pages(bases, n * pb, b.p));
+        }
+        d_b = b.p;
+    } else {
+        ZK_TRY(ws_get("api.bases", n * pb, &d_b));
+        ZK_TRY(upload_pages(bases, n * pb, d_b));
+    }
+    ZK_TRY(ws_get("api.scalars", n * scalar_bytes, &d_s));
+    ZK_TRY(upload_pages(scalars, n * scalar_bytes, d_s));
+    return msm_dev_dispatch(curve, group, d_b, d_s, n, scalar_bytes, out);
+}
+int zkmi_release_bases(uint64_t key) {
+    auto it = g_ctx.base_cache.find(key);
+    if (it == g_ctx.base_cache.end()) return ZKMI_OK;
+    if (it->second.p) ZK_HIP(hipFree(it->second.p));
+    g_ctx.base_cache.erase(it);
+    return ZKMI_OK;
+}
+
+int zkmi_ntt_dev(int curve, const void* d_in, void* d_out, unsigned log_n, int inverse, const uint8_t* first, const uint8_t* inc) {
+    ZK_TRY(require_ctx());
+    return ntt_dev_dispatch(curve, d_in, d_out, log_n, inverse, first, inc);
+}
+int zkmi_ntt(int curve, zkmi_pages in, uint8_t* const* out_ptr, const size_t* out_len, int n_out, unsigned log_n, int inverse,
+             const uint8_t* first, const uint8_t* inc) {
+    ZK_TRY(require_ctx());
+    if (log_n > 40) return fail(ZKMI_ERR_INVALID, "fft: size out of range");
+    const size_t bytes = ((size_t)1 << log_n) * 32;
+    if (pages_total(in) != bytes) return fail(ZKMI_ERR_INVALID, "fft must be multiple of 2");
+    void *d_i, *d_o;
+    ZK_TRY(ws_get("api.ntt_in", bytes, &d_i));
+    ZK_TRY(ws_get("api.ntt_out", bytes, &d_o));
+    ZK_TRY(upload_pages(in, bytes, d_i));
+    ZK_TRY(ntt_dev_dispatch(curve, d_i, d_o, log_n, inverse, first, inc));
+    return download_pages(d_o, bytes, out_ptr, out_len, n_out);
+}
+int zkmi_fr_batch_apply_key_dev(int curve, const void* d_in, void* d_out, size_t n, const uint8_t* first, const uint8_t* inc) {
+    ZK_TRY(require_ctx());
+    return apply_key_dev_dispatch(curve, d_in, d_out, n, first, inc);
+}
+int zkmi_fr_batch_apply_key(int curve, zkmi_pages in, uint8_t* const* out_ptr, const size_t* out_len, int n_out, size_t n,
+                            const uint8_t* first, const uint8_t* inc) {
+    ZK_TRY(require_ctx());
+    void *d_i, *d_o;
+    ZK_TRY(ws_get("api.b_in", n * 32, &d_i)); ZK_TRY(ws_get("api.b_out", n * 32, &d_o));
+    ZK_TRY(upload_pages(in, n * 32, d_i));
+    ZK_TRY(apply_key_dev_dispatch(curve, d_i, d_o, n, first, inc));
+    return download_pages(d_o, n * 32, out_ptr, out_len, n_out);
+}
+int zkmi_fr_batch_dev(int curve, int op, const void* d_in, void* d_out, size_t n) {
+    ZK_TRY(require_ctx());
+    return fr_batch_dev_dispatch(curve, op, d_in, d_out, n);
+}
+int zkmi_fr_batch(int curve, int op, zkmi_pages in, uint8_t* const* out_ptr, const size_t* out_len, int n_out, size_t n) {
+    ZK_TRY(require_ctx());
+    void *d_i, *d_o;
+    ZK_TRY(ws_get("api.b_in", n * 32, &d_i)); ZK_TRY(ws_get("api.b_out", n * 32, &d_o));
+    ZK_TRY(upload_pages(in, n * 32, d_i));
+    ZK_TRY(fr_batch_dev_dispatch(curve, op, d_i, d_o, n));
+    return download_pages(d_o, n * 32, out_ptr, out_len, n_out);
+}
+int zkmi_groth16_join_abc_dev(int curve, const void* a, const void* b, const void* c, void* out, size_t n) {
+    ZK_TRY(require_ctx());
+    return join_abc_dev_dispatch(curve, a, b, c, out, n);
+}
+int zkmi_groth16_join_abc(int curve, zkmi_pages a, zkmi_pages b, zkmi_pages c, uint8_t* const* out_ptr, const size_t* out_len, int n_out, size_t n) {
+    ZK_TRY(require_ctx());
+    void *d_a, *d_b, *d_c, *d_o;
+    ZK_TRY(ws_get("api.j_a", n * 32, &d_a)); ZK_TRY(ws_get("api.j_b", n * 32, &d_b)); ZK_TRY(ws_get("api.j_c", n * 32, &d_c)); ZK_TRY(ws_get("api.b_out", n * 32, &d_o));
+    ZK_TRY(upload_pages(a, n * 32, d_a)); ZK_TRY(upload_pages(b, n * 32, d_b)); ZK_TRY(upload_pages(c, n * 32, d_c));
+    ZK_TRY(join_abc_dev_dispatch(curve, d_a, d_b, d_c, d_o, n));
+    return download_pages(d_o, n * 32, out_ptr, out_len, n_out);
+}
+int zkmi_gen_geometric_bases_dev(int curve, int group, size_t n, uint64_t f, uint64_t g, void* d_out) {
+    ZK_TRY(require_ctx());
+    if (n >= (1ull << 32)) return fail(ZKMI_ERR_UNSUPPORTED, "n too large");
+    return gen_bases_dispatch(curve, group, n, f, g, d_out);
+}
+int zkmi_to_affine(int curve, int group, const uint8_t* jac, uint8_t* aff) { return to_affine_dispatch(curve, group, jac, aff); }
+
+}  // extern "C"

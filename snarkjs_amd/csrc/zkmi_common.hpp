@@ -1,0 +1,73 @@
+// snarkjs_amd/csrc/zkmi_common.hpp — library context shared by the translation units of libzkmi.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+#include "../../include/zkmi.h"
+
+namespace zkmi {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define ZK_HIP(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) return ::zkmi::fail(ZKMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define ZK_TRY(expr)            \
+    do {                        \
+        int _rc = (expr);       \
+        if (_rc) return _rc;    \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct NttPlan {
+    unsigned log_n = 0;
+    int n_pass = 0;
+    uint32_t l[4] = {0, 0, 0, 0};
+    uint32_t log_lb = 0;
+    uint32_t *T_lo = nullptr, *T_hi = nullptr, *T_hi_last = nullptr, *n_inv = nullptr;
+    uint32_t* LT[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0;
+    int msm_c_override = 0;
+    std::map<std::string, DevBuf> ws;                       // named scratch buffers (grow-only)
+    std::map<uint64_t, DevBuf> base_cache;                  // zkmi_msm base_cache_key -> resident table
+    std::map<std::tuple<int, unsigned, int>, NttPlan> plans;  // (curve, log_n, inverse)
+    std::map<void*, size_t> user_allocs;
+};
+Ctx& ctx();
+int require_ctx();
+// scratch buffer `name` with at least `bytes` capacity (contents undefined)
+int ws_get(const std::string& name, size_t bytes, void** out);
+
+// pages <-> device
+int upload_pages(const zkmi_pages& pg, size_t total_bytes, void* d_dst);
+int download_pages(const void* d_src, size_t total_bytes, uint8_t* const* out_ptr, const size_t* out_len, int n_out_pages);
+
+// per-module entry points (implemented in msm_*.hip / ntt.hip)
+int msm_dev_dispatch(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t sb, uint8_t* out_jac);
+int gen_bases_dispatch(int curve, int group, size_t n, uint64_t f, uint64_t g, void* d_out);
+int ntt_dev_dispatch(int curve, const void* d_in, void* d_out, unsigned log_n, int inverse, const uint8_t* first, const uint8_t* inc);
+int apply_key_dev_dispatch(int curve, const void* d_in, void* d_out, size_t n, const uint8_t* first, const uint8_t* inc);
+int fr_batch_dev_dispatch(int curve, int op, const void* d_in, void* d_out, size_t n);
+int join_abc_dev_dispatch(int curve, const void* a, const void* b, const void* c, void* out, size_t n);
+int to_affine_dispatch(int curve, int group, const uint8_t* jac, uint8_t* aff);
+
+inline int n8q_of(int curve) { return curve == ZKMI_CURVE_BN128 ? 32 : 48; }
+
+}  // namespace zkmi

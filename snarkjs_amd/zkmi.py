@@ -1,0 +1,168 @@
+"""ctypes binding of libzkmi.so (include/zkmi.h) — the C-ABI of the MI355X proving backend.
+
+Thin plumbing only: every function maps 1:1 to a C entry point.  There is NO CPU fallback — if the HIP library is
+missing or no device is visible, calls raise ZkmiError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkmi.so")
+
+BN128, BLS12381 = 0, 1
+CURVE_ID = {"bn128": 0, "bn254": 0, "bls12381": 1}
+BATCH_TO_MONTGOMERY, BATCH_FROM_MONTGOMERY, BATCH_INVERSE = 0, 1, 2
+ERR_NO_DEVICE = 1
+
+# every symbol include/zkmi.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "zkmi_init", "zkmi_device_count", "zkmi_last_error", "zkmi_version", "zkmi_set_stream", "zkmi_synchronize",
+    "zkmi_dev_alloc", "zkmi_dev_free", "zkmi_memcpy_h2d", "zkmi_memcpy_d2h",
+    "zkmi_msm", "zkmi_release_bases", "zkmi_msm_dev", "zkmi_msm_set_window_bits",
+    "zkmi_ntt", "zkmi_ntt_dev",
+    "zkmi_fr_batch_apply_key", "zkmi_fr_batch_apply_key_dev", "zkmi_fr_batch", "zkmi_fr_batch_dev",
+    "zkmi_groth16_join_abc", "zkmi_groth16_join_abc_dev",
+    "zkmi_groth16_prove", "zkmi_groth16_release", "zkmi_groth16_prove_dev_timing",
+    "zkmi_gen_geometric_bases_dev", "zkmi_to_affine", "zkmi_last_kernel_ms",
+]
+
+
+class ZkmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"zkmi error {code}: {msg}")
+        self.code = code
+
+
+class Pages(C.Structure):
+    _fields_ = [("ptr", C.POINTER(C.c_void_p)), ("len", C.POINTER(C.c_size_t)), ("n_pages", C.c_int)]
+
+
+class Groth16Zkey(C.Structure):
+    _fields_ = [("curve", C.c_int), ("n_vars", C.c_uint32), ("n_public", C.c_uint32), ("domain_size", C.c_uint32),
+                ("coeffs", C.c_void_p), ("coeffs_len", C.c_size_t),
+                ("bases_a", C.c_void_p), ("bases_b1", C.c_void_p), ("bases_b2", C.c_void_p), ("bases_c", C.c_void_p),
+                ("bases_h", C.c_void_p),
+                ("vk_alpha_1", C.c_void_p), ("vk_beta_1", C.c_void_p), ("vk_beta_2", C.c_void_p),
+                ("vk_delta_1", C.c_void_p), ("vk_delta_2", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libzkmi.so (built in-tree by snarkjs_amd/build.py). Raises if it is missing: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZkmiError(-1, f"{LIB_PATH} not built (run python -c 'import __graft_entry__ as g; g.build()')")
+    L = C.CDLL(LIB_PATH)
+    L.zkmi_last_error.restype = C.c_char_p
+    L.zkmi_version.restype = C.c_char_p
+    L.zkmi_last_kernel_ms.restype = C.c_double
+    vp, sz, u8p = C.c_void_p, C.c_size_t, C.c_void_p
+    L.zkmi_init.argtypes = [C.c_int]
+    L.zkmi_set_stream.argtypes = [vp]
+    L.zkmi_dev_alloc.argtypes = [sz, C.POINTER(vp)]
+    L.zkmi_dev_free.argtypes = [vp]
+    L.zkmi_memcpy_h2d.argtypes = [vp, vp, sz]
+    L.zkmi_memcpy_d2h.argtypes = [vp, vp, sz]
+    L.zkmi_msm.argtypes = [C.c_int, C.c_int, Pages, Pages, sz, sz, C.c_uint64, u8p]
+    L.zkmi_release_bases.argtypes = [C.c_uint64]
+    L.zkmi_msm_dev.argtypes = [C.c_int, C.c_int, vp, vp, sz, sz, u8p]
+    L.zkmi_msm_set_window_bits.argtypes = [C.c_int]
+    L.zkmi_ntt.argtypes = [C.c_int, Pages, C.POINTER(vp), C.POINTER(sz), C.c_int, C.c_uint, C.c_int, u8p, u8p]
+    L.zkmi_ntt_dev.argtypes = [C.c_int, vp, vp, C.c_uint, C.c_int, u8p, u8p]
+    L.zkmi_fr_batch_apply_key.argtypes = [C.c_int, Pages, C.POINTER(vp), C.POINTER(sz), C.c_int, sz, u8p, u8p]
+    L.zkmi_fr_batch_apply_key_dev.argtypes = [C.c_int, vp, vp, sz, u8p, u8p]
+    L.zkmi_fr_batch.argtypes = [C.c_int, C.c_int, Pages, C.POINTER(vp), C.POINTER(sz), C.c_int, sz]
+    L.zkmi_fr_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, sz]
+    L.zkmi_groth16_join_abc.argtypes = [C.c_int, Pages, Pages, Pages, C.POINTER(vp), C.POINTER(sz), C.c_int, sz]
+    L.zkmi_groth16_join_abc_dev.argtypes = [C.c_int, vp, vp, vp, vp, sz]
+    L.zkmi_gen_geometric_bases_dev.argtypes = [C.c_int, C.c_int, sz, C.c_uint64, C.c_uint64, vp]
+    L.zkmi_to_affine.argtypes = [C.c_int, C.c_int, u8p, u8p]
+    if hasattr(L, "zkmi_groth16_prove"):
+        L.zkmi_groth16_prove.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p]
+        L.zkmi_groth16_release.argtypes = [C.c_uint64]
+    if hasattr(L, "zkmi_groth16_prove_dev_timing"):
+        L.zkmi_groth16_prove_dev_timing.argtypes = [C.POINTER(C.c_double), C.c_int]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise ZkmiError(rc, lib().zkmi_last_error().decode(errors="replace"))
+
+
+def init(device=0):
+    check(lib().zkmi_init(device))
+
+
+def device_count():
+    return lib().zkmi_device_count()
+
+
+def u8(x):
+    """View anything bytes-like as a contiguous uint8 numpy array (no copy when already one)."""
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x).view(np.uint8).reshape(-1)
+    return np.frombuffer(x, dtype=np.uint8)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _PagesHolder:
+    """Keeps the ctypes arrays of a zkmi_pages alive for the duration of a call."""
+
+    def __init__(self, bufs):
+        self.bufs = [u8(b) for b in bufs]
+        n = len(self.bufs)
+        self.ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in self.bufs])
+        self.lens = (C.c_size_t * n)(*[b.size for b in self.bufs])
+        self.pages = Pages(C.cast(self.ptrs, C.POINTER(C.c_void_p)), C.cast(self.lens, C.POINTER(C.c_size_t)), n)
+        self.total = sum(b.size for b in self.bufs)
+
+
+def pages_of(buf):
+    """A logical buffer is one bytes-like object or a BigBuffer-like list of them (ffjavascript BigBuffer.buffers)."""
+    if isinstance(buf, (list, tuple)):
+        return _PagesHolder(list(buf))
+    return _PagesHolder([buf])
+
+
+class DeviceBuffer:
+    """Device memory owned by the library (zkmi_dev_alloc)."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(lib().zkmi_dev_alloc(nbytes, C.byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    @classmethod
+    def from_host(cls, data):
+        a = u8(data)
+        b = cls(a.size)
+        check(lib().zkmi_memcpy_h2d(b.ptr, ptr(a), a.size))
+        return b
+
+    def to_host(self, nbytes=None, offset=0):
+        n = self.nbytes - offset if nbytes is None else nbytes
+        out = np.empty(n, np.uint8)
+        check(lib().zkmi_memcpy_d2h(ptr(out), self.ptr + offset, n))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().zkmi_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

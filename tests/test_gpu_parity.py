@@ -1,0 +1,214 @@
+"""GPU parity tests: the HIP path (through the C-ABI, include/zkmi.h) against the CPU oracle and the committed
+golden vectors generated from the reference.  Bit-exact for all byte outputs; MSM results compared as group
+elements after toAffine (SURVEY.md §8c parity procedure).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+from test_oracle_golden import load, raw, msm_inputs, _Q
+
+pytestmark = pytest.mark.gpu
+CURVES = ["bn128", "bls12381"]
+sha = lambda b: hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def zk():
+    import snarkjs_amd
+    from snarkjs_amd import zkmi
+    zkmi.init(0)
+    return snarkjs_amd
+
+
+def curve_of(zk, name):
+    return zk.get_curve_from_name(name)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_n1024_golden(zk, golden_dir, name):
+    d, c, cv = load(golden_dir, name), O.CURVE_ID[name], curve_of(zk, name)
+    x = synth.iota(1024)
+    got = {
+        "fft": cv.Fr.fft(x), "ifft": cv.Fr.ifft(x),
+        "applykey_7_11": cv.Fr.batchApplyKey(x, O.fr_e(c, 7), O.fr_e(c, 11)),
+        "to_mont": cv.Fr.batchToMontgomery(x), "from_mont": cv.Fr.batchFromMontgomery(x),
+        "inverse": cv.Fr.batchInverse(x),
+    }
+    for k, v in got.items():
+        assert np.array_equal(v, raw(golden_dir, name, k)), k
+        assert sha(v) == d["n1024"][k]
+    for g, G in ((1, cv.G1), (2, cv.G2)):
+        jac = G.multiExpAffine(raw(golden_dir, name, f"g{g}_bases"), x)
+        assert np.array_equal(O.to_affine(c, g, jac), raw(golden_dir, name, f"g{g}_msm_affine"))
+        assert np.array_equal(G.toAffine(jac), raw(golden_dir, name, f"g{g}_msm_affine"))
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_ntt_all_sizes_vs_oracle(zk, name):
+    c, cv = O.CURVE_ID[name], curve_of(zk, name)
+    for lg in range(0, 19):
+        x = synth.elems(0x1000 + lg, 1 << lg)
+        assert np.array_equal(cv.Fr.fft(x), O.ntt(c, x)), f"fft 2^{lg}"
+        assert np.array_equal(cv.Fr.ifft(x), O.ntt(c, x, True)), f"ifft 2^{lg}"
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_ntt_golden_hashes(zk, golden_dir, name):
+    d, cv = load(golden_dir, name), curve_of(zk, name)
+    for lg, v in d["ntt"].items():
+        x = synth.elems(v["seed"], 1 << int(lg))
+        assert sha(cv.Fr.fft(x)) == v["fft"] and sha(cv.Fr.ifft(x)) == v["ifft"], lg
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_coset_chain_and_batch_golden(zk, golden_dir, name):
+    d, c, cv = load(golden_dir, name), O.CURVE_ID[name], curve_of(zk, name)
+    for lg, v in d["coset_chain"].items():
+        lg = int(lg)
+        x = synth.elems(v["seed"], 1 << lg)
+        y = cv.Fr.fft(cv.Fr.batchApplyKey(cv.Fr.ifft(x), O.fr_one(c), O.fr_w(c, lg + 1)))
+        assert sha(y) == v["out"], lg
+    b = d["batch"]
+    x = synth.elems(b["seed"], b["n"]).reshape(-1, 32)
+    for z in b["zeroed"]:
+        x[z] = 0
+    x = x.reshape(-1)
+    assert sha(cv.Fr.batchInverse(x)) == b["inverse"]
+    assert sha(cv.Fr.batchToMontgomery(x)) == b["to_mont"]
+    assert sha(cv.Fr.batchFromMontgomery(x)) == b["from_mont"]
+    assert sha(cv.Fr.batchApplyKey(x, O.fr_e(c, 3), O.fr_e(c, 25))) == b["applykey_shift"]
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_fused_prescale_ntt(zk, name):
+    """zkmi_ntt_dev with prescale == batchApplyKey followed by fft (the Groth16 coset step, src/groth16_prove.js:66-76)."""
+    from snarkjs_amd import zkmi
+    c = O.CURVE_ID[name]
+    for lg in (0, 1, 3, 8, 11, 12, 15, 17):
+        n = 1 << lg
+        x = synth.elems(0x77 + lg, n)
+        first, inc = O.fr_e(c, 5), O.fr_w(c, lg + 1)
+        want = O.ntt(c, O.apply_key(c, x, first, inc))
+        din, dout = zkmi.DeviceBuffer.from_host(x), zkmi.DeviceBuffer(n * 32)
+        zkmi.check(zkmi.lib().zkmi_ntt_dev(c, din.ptr, dout.ptr, lg, 0, zkmi.ptr(first), zkmi.ptr(inc)))
+        assert np.array_equal(dout.to_host(), want), lg
+        # in-place inverse
+        zkmi.check(zkmi.lib().zkmi_ntt_dev(c, dout.ptr, dout.ptr, lg, 1, None, None))
+        assert np.array_equal(dout.to_host(), O.apply_key(c, x, first, inc)), lg
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_ntt_large_roundtrip(zk, name):
+    """Size-independent property at BASELINE sizes: ifft(fft(x)) == x bytes; linearity spot check via x -> 2x."""
+    cv = curve_of(zk, name)
+    for lg in (20, 22, 24):
+        x = synth.elems(0xABC + lg, 1 << lg)
+        X = cv.Fr.fft(x)
+        assert np.array_equal(cv.Fr.ifft(X), x), lg
+        if lg == 20:   # DC term: X[0] = sum_j x[j] mod r (residues add linearly), independent host computation
+            r = int(load(os.path.join(os.path.dirname(__file__), "golden"), name)["r"])
+            v = x.reshape(-1, 32).view("<u8").astype(object)
+            tot = sum(int(v[:, k].sum()) << (64 * k) for k in range(4)) % r
+            assert int.from_bytes(bytes(X[:32]), "little") == tot
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_msm_golden_cases(zk, golden_dir, name):
+    d, c, cv = load(golden_dir, name), O.CURVE_ID[name], curve_of(zk, name)
+    _Q[c] = d["q"]
+    B1, B2 = O.geom_bases(c, 1, 1 << 14), O.geom_bases(c, 2, 1 << 12)
+    for key, v in d["msm"].items():
+        g, bases, scalars, n, sb = msm_inputs(c, key, v, B1, B2)
+        G = cv.G1 if g == 1 else cv.G2
+        jac = G.multiExpAffine(bases, scalars)
+        assert bytes(O.to_affine(c, g, jac)).hex() == v["affine"], key
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_msm_window_sweep(zk, name):
+    """Every window width gives the same group element (different bucket layouts / reduction depths)."""
+    from snarkjs_amd import zkmi
+    c, cv = O.CURVE_ID[name], curve_of(zk, name)
+    n = 3000
+    B1 = O.geom_bases(c, 1, n)
+    sc = synth.witness_like(0x4242, n)
+    want = O.to_affine(c, 1, O.msm(c, 1, B1, sc, n))
+    try:
+        for cbits in (1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 16):
+            zkmi.check(zkmi.lib().zkmi_msm_set_window_bits(cbits))
+            assert np.array_equal(O.to_affine(c, 1, cv.G1.multiExpAffine(B1, sc)), want), cbits
+    finally:
+        zkmi.lib().zkmi_msm_set_window_bits(0)
+
+
+def test_msm_edge_cases(zk):
+    c, cv = O.BN128, curve_of(zk, "bn128")
+    assert not cv.G1.multiExpAffine(b"", b"").any()
+    B = O.geom_bases(c, 1, 8)
+    assert not cv.G1.multiExpAffine(B, np.zeros(8 * 32, np.uint8)).any()
+    with pytest.raises(ValueError):
+        cv.G1.multiExpAffine(B, np.zeros(8 * 32 - 1, np.uint8))
+    with pytest.raises(ValueError):
+        cv.Fr.fft(np.zeros(3 * 32, np.uint8))
+    # P + (-P) and P + P through the same bucket
+    q = int(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bn128_kernel_vectors.json")))["q"])
+    P = B[:64].copy()
+    y = int.from_bytes(bytes(P[32:]), "little")
+    negP = np.concatenate([P[:32], np.frombuffer(((q - y) % q).to_bytes(32, "little"), np.uint8)])
+    sc = np.zeros(64, np.uint8); sc[0] = 9; sc[32] = 9
+    assert not O.to_affine(c, 1, cv.G1.multiExpAffine(np.concatenate([P, negP]), sc)).any()
+    jac = cv.G1.multiExpAffine(np.concatenate([P, P]), sc)
+    k = np.zeros(32, np.uint8); k[0] = 18
+    assert np.array_equal(O.to_affine(c, 1, jac), O.to_affine(c, 1, O.msm(c, 1, P, k, 1)))
+    # paged ("BigBuffer") inputs split at an arbitrary boundary give the same result
+    n = 1000
+    B1, sc = O.geom_bases(c, 1, n), synth.elems(0x31337, n)
+    want = O.to_affine(c, 1, O.msm(c, 1, B1, sc, n))
+    jac = cv.G1.multiExpAffine([B1[:64 * 300], B1[64 * 300:]], [sc[:32 * 700], sc[32 * 700:]])
+    assert np.array_equal(O.to_affine(c, 1, jac), want)
+    x = synth.elems(0x777, 1024)
+    out = cv.Fr.fft([x[:32 * 300], x[32 * 300:]])
+    assert isinstance(out, list) and np.array_equal(np.concatenate(out), O.ntt(c, x))
+
+
+@pytest.mark.parametrize("name,group,lg", [("bn128", 1, 16), ("bn128", 1, 20), ("bn128", 2, 16), ("bls12381", 1, 16), ("bls12381", 2, 14)])
+def test_msm_closed_form_large(zk, name, group, lg):
+    """bases P_i = 7·11^i·G generated on the device, uniform 253-bit scalars;
+    result must equal (sum s_i·7·11^i mod r)·G — an O(n) host computation independent of any MSM."""
+    from snarkjs_amd import zkmi
+    c = O.CURVE_ID[name]
+    n = 1 << lg
+    r = int(json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"{name}_kernel_vectors.json")))["r"])
+    q8 = O.n8q(c)
+    pb = 2 * group * q8
+    d_b = zkmi.DeviceBuffer(n * pb)
+    zkmi.check(zkmi.lib().zkmi_gen_geometric_bases_dev(c, group, n, 7, 11, d_b.ptr))
+    # the generated table equals the oracle's (prefix check)
+    m = min(n, 512)
+    assert np.array_equal(d_b.to_host(m * pb), O.geom_bases(c, group, m))
+    sc = synth.elems(0x5EED + lg, n)
+    d_s = zkmi.DeviceBuffer.from_host(sc)
+    out = np.zeros(3 * group * q8, np.uint8)
+    zkmi.check(zkmi.lib().zkmi_msm_dev(c, group, d_b.ptr, d_s.ptr, n, 32, zkmi.ptr(out)))
+    s = sc.reshape(n, 32).view("<u8").astype(object)      # n x 4 python ints
+    k, f = 0, 7
+    vals = [int(s[i, 0]) | int(s[i, 1]) << 64 | int(s[i, 2]) << 128 | int(s[i, 3]) << 192 for i in range(n)]
+    for v in vals:
+        k = (k + v * f) % r
+        f = f * 11 % r
+    want = O.to_affine(c, group, O.generator_mul(c, group, k))
+    assert np.array_equal(O.to_affine(c, group, out), want)
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_join_abc(zk, name):
+    c, cv = O.CURVE_ID[name], curve_of(zk, name)
+    n = 5000
+    a, b, cc = (synth.elems(s, n) for s in (1, 2, 3))
+    assert np.array_equal(cv.joinABC(a, b, cc), O.join_abc(c, a, b, cc))
