@@ -123,9 +123,20 @@ typedef struct zkmi_groth16_zkey {
     const uint8_t *bases_a, *bases_b1, *bases_b2, *bases_c, *bases_h;
     const uint8_t *vk_alpha_1, *vk_beta_1, *vk_beta_2, *vk_delta_1, *vk_delta_2;
 } zkmi_groth16_zkey;
+/* Upload the proving key under `zkey_cache_key` (!= 0): base tables + CSR form of the coefficient section. */
+int zkmi_groth16_load(const zkmi_groth16_zkey* zkey, uint64_t zkey_cache_key);
+/* One proof. zkey_cache_key != 0: the key is loaded on first use (zkey may be NULL afterwards) and stays resident;
+ * zkey_cache_key == 0: load, prove, release. `witness` is a HOST pointer (n_vars x 32 B, normal form). */
 int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t zkey_cache_key, const uint8_t* witness,
                        const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
+/* Same with the witness already in device memory and the key loaded (bench.py: inputs resident in HBM). */
+int zkmi_groth16_prove_dev(uint64_t zkey_cache_key, const void* d_witness, const uint8_t* r_mont, const uint8_t* s_mont,
+                           uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 int zkmi_groth16_release(uint64_t zkey_cache_key);
+/* Device time (ms, HIP events) of the stages of the last proof, in order: buildABC, 6 NTTs, joinABC, sort(witness),
+ * MSM A, MSM B1, MSM B2, MSM C, sort(H scalars), MSM H. Writes min(n, ZKMI_GROTH16_STAGES) values. */
+#define ZKMI_GROTH16_STAGES 10
+int zkmi_groth16_stage_ms(double* out, int n);
 
 /* ---- utilities --------------------------------------------------------------------------------------------------- */
 /* Synthetic base table of SURVEY.md §8d: P_i = (f*g^i mod r)*G written to device memory as affine Montgomery points

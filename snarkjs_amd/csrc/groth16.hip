@@ -1,0 +1,307 @@
+// snarkjs_amd/csrc/groth16.hip — fused Groth16 prover: the whole of groth16Prove (reference src/groth16_prove.js:28-144)
+// between "sections read" and "proof points", on the device.
+//
+//   buildABC1 (:147-187, a single-threaded JS loop in the reference)  ->  CSR sparse matrix x witness kernel
+//   3 x { Fr.ifft -> Fr.batchApplyKey(1, w[power+1]) -> Fr.fft } (:64-76) ->  iNTT + NTT with the coset scale fused on load
+//   joinABC (:320-374)                                                ->  element-wise kernel
+//   5 x multiExpAffine (:84-101)                                      ->  device Pippenger; A, B1, B2 and C share ONE digit
+//                                                                         sort of the witness (C = witness[nPublic+1:])
+//   blinding + toAffine (:103-132)                                    ->  host (O(1) group operations)
+//
+// The zkey is static per circuit: zkmi_groth16_load uploads the five base tables once and converts the coefficient
+// section into CSR form (rows = (matrix, constraint)) on the device; a proof then moves only the witness.
+#include <string.h>
+#include <memory>
+#include "msm_host.hpp"
+#include "zkmi_common.hpp"
+
+namespace zkmi {
+
+// ---- coefficient section -> CSR -------------------------------------------------------------------------------------
+// zkey section 4: u32 nCoef, then nCoef x { u32 matrix, u32 constraint, u32 signal, Fr value (x R^2) } (44-byte records,
+// src/zkey_utils.js:108-118 / src/zkey_new.js:320-333). Row id = matrix * domain + constraint.
+constexpr int COEF_REC_WORDS = 11;
+static __global__ void k_coef_count(const uint32_t* __restrict__ raw, uint32_t n_coef, uint32_t domain, uint32_t n_vars, uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ bad) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_coef) return;
+    const uint32_t* rec = raw + 1 + (size_t)i * COEF_REC_WORDS;
+    uint32_t m = rec[0], c = rec[1], s = rec[2];
+    if (m > 1 || c >= domain || s >= n_vars) { atomicAdd(bad, 1u); return; }
+    atomicAdd(&row_cnt[m * domain + c], 1u);
+}
+static __global__ void k_coef_scatter(const uint32_t* __restrict__ raw, uint32_t n_coef, uint32_t domain, uint32_t n_vars, const uint32_t* __restrict__ row_start,
+                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sig, uint32_t* __restrict__ val) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_coef) return;
+    const uint32_t* rec = raw + 1 + (size_t)i * COEF_REC_WORDS;
+    uint32_t m = rec[0], c = rec[1], s = rec[2];
+    if (m > 1 || c >= domain || s >= n_vars) return;
+    uint32_t row = m * domain + c;
+    uint32_t pos = row_start[row] + atomicAdd(&cursor[row], 1u);
+    sig[pos] = s;
+#pragma unroll
+    for (int k = 0; k < 8; k++) val[(size_t)pos * 8 + k] = rec[3 + k];
+}
+// exclusive scan of `n` counters by one workgroup (n <= 2^26 in practice; one-off per zkey)
+static __global__ void k_scan_u32(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += in[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
+        uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t b = lo; b < hi; b++) { out[b] = run; run += in[b]; }
+}
+// A_T[c] = sum coef*w[s] over matrix 0, B_T[c] likewise over matrix 1, C_T[c] = A_T[c]*B_T[c]  (buildABC1).
+// coef is stored x R^2 and the witness is in normal form, so the Montgomery product is (coef*w) x R.
+template <class C> __global__ void __launch_bounds__(256)
+k_build_abc(const uint32_t* __restrict__ row_start, const uint32_t* __restrict__ row_cnt, const uint32_t* __restrict__ sig, const uint32_t* __restrict__ val,
+            const uint32_t* __restrict__ witness, uint32_t domain, uint32_t* __restrict__ A, uint32_t* __restrict__ B, uint32_t* __restrict__ Cc) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= domain) return;
+    Fp<C> ab[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const uint32_t row = m * domain + c, st = row_start[row], cnt = row_cnt[row];
+        Fp<C> acc = fp_zero<C>();
+        for (uint32_t k = 0; k < cnt; k++) {
+            Fp<C> v = fp_load<C>(val + (size_t)(st + k) * 8);
+            Fp<C> w = fp_load<C>(witness + (size_t)sig[st + k] * 8);
+            acc = fp_add(acc, fp_mul(v, w));
+        }
+        ab[m] = acc;
+    }
+    fp_store<C>(A + (size_t)c * 8, ab[0]);
+    fp_store<C>(B + (size_t)c * 8, ab[1]);
+    fp_store<C>(Cc + (size_t)c * 8, fp_mul(ab[0], ab[1]));
+}
+
+// ---- resident proving key ---------------------------------------------------------------------------------------------
+enum { ST_BUILD = 0, ST_NTT, ST_JOIN, ST_SORT_W, ST_MSM_A, ST_MSM_B1, ST_MSM_B2, ST_MSM_C, ST_SORT_H, ST_MSM_H, ST_COUNT };
+
+struct G16Key {
+    int curve = 0;
+    uint32_t n_vars = 0, n_public = 0, domain = 0, power = 0, n_coef = 0;
+    void *bA = nullptr, *bB1 = nullptr, *bB2 = nullptr, *bC = nullptr, *bH = nullptr;
+    uint32_t *row_cnt = nullptr, *row_start = nullptr, *sig = nullptr, *val = nullptr;
+    uint32_t *w = nullptr, *A = nullptr, *B = nullptr, *C = nullptr, *T = nullptr;
+    std::vector<uint8_t> vk_alpha_1, vk_beta_1, vk_beta_2, vk_delta_1, vk_delta_2;
+    hipEvent_t ev[ST_COUNT + 1] = {};
+    double stage_ms[ST_COUNT] = {};
+    void release() {
+        void* ptrs[] = {bA, bB1, bB2, bC, bH, row_cnt, row_start, sig, val, w, A, B, C, T};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+static int upload(void** d, const uint8_t* h, size_t bytes, hipStream_t st) {
+    ZK_HIP(hipMalloc(d, bytes ? bytes : 16));
+    if (bytes) ZK_HIP(hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, st));
+    return ZKMI_OK;
+}
+
+static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key) {
+    Ctx& cx = ctx();
+    hipStream_t st = cx.stream;
+    if (zk->curve != ZKMI_CURVE_BN128 && zk->curve != ZKMI_CURVE_BLS12381) return fail(ZKMI_ERR_INVALID, "unknown curve");
+    const uint32_t n = zk->domain_size;
+    if (n == 0 || (n & (n - 1))) return fail(ZKMI_ERR_INVALID, "groth16: domain size must be a power of two");
+    if (zk->n_vars <= zk->n_public) return fail(ZKMI_ERR_INVALID, "groth16: nVars must exceed nPublic");
+    if (zk->coeffs_len < 4 || (zk->coeffs_len - 4) % 44) return fail(ZKMI_ERR_INVALID, "groth16: malformed coefficient section");
+    auto K = std::make_unique<G16Key>();
+    K->curve = zk->curve; K->n_vars = zk->n_vars; K->n_public = zk->n_public; K->domain = n;
+    K->power = (uint32_t)ilog2_sz(n);
+    K->n_coef = (uint32_t)((zk->coeffs_len - 4) / 44);            // buildABC1: nCoef = (byteLength-4)/sCoef (:149-150)
+    const size_t q = n8q_of(zk->curve), g1 = 2 * q, g2 = 4 * q;
+    const size_t m = zk->n_vars, mc = m - zk->n_public - 1;
+    ZK_TRY(upload(&K->bA, zk->bases_a, m * g1, st));
+    ZK_TRY(upload(&K->bB1, zk->bases_b1, m * g1, st));
+    ZK_TRY(upload(&K->bB2, zk->bases_b2, m * g2, st));
+    ZK_TRY(upload(&K->bC, zk->bases_c, mc * g1, st));
+    ZK_TRY(upload(&K->bH, zk->bases_h, (size_t)n * g1, st));
+    K->vk_alpha_1.assign(zk->vk_alpha_1, zk->vk_alpha_1 + g1); K->vk_beta_1.assign(zk->vk_beta_1, zk->vk_beta_1 + g1);
+    K->vk_beta_2.assign(zk->vk_beta_2, zk->vk_beta_2 + g2); K->vk_delta_1.assign(zk->vk_delta_1, zk->vk_delta_1 + g1);
+    K->vk_delta_2.assign(zk->vk_delta_2, zk->vk_delta_2 + g2);
+    // CSR conversion of the coefficient section, on the device
+    void* raw = nullptr;
+    ZK_TRY(upload(&raw, zk->coeffs, zk->coeffs_len, st));
+    const size_t rows = 2 * (size_t)n;
+    uint32_t* cursor = nullptr;
+    ZK_HIP(hipMalloc((void**)&K->row_cnt, rows * 4)); ZK_HIP(hipMalloc((void**)&K->row_start, rows * 4));
+    ZK_HIP(hipMalloc((void**)&cursor, rows * 4 + 16));
+    ZK_HIP(hipMalloc((void**)&K->sig, std::max<size_t>(K->n_coef, 1) * 4)); ZK_HIP(hipMalloc((void**)&K->val, std::max<size_t>(K->n_coef, 1) * 32));
+    ZK_HIP(hipMemsetAsync(K->row_cnt, 0, rows * 4, st)); ZK_HIP(hipMemsetAsync(cursor, 0, rows * 4 + 16, st));
+    uint32_t* bad = cursor + rows;
+    if (K->n_coef) {
+        const unsigned blocks = (K->n_coef + 255) / 256;
+        hipLaunchKernelGGL(k_coef_count, dim3(blocks), dim3(256), 0, st, (const uint32_t*)raw, K->n_coef, n, zk->n_vars, K->row_cnt, bad);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, K->row_cnt, K->row_start, (uint32_t)rows);
+        hipLaunchKernelGGL(k_coef_scatter, dim3(blocks), dim3(256), 0, st, (const uint32_t*)raw, K->n_coef, n, zk->n_vars, K->row_start, cursor, K->sig, K->val);
+    } else ZK_HIP(hipMemsetAsync(K->row_start, 0, rows * 4, st));
+    uint32_t nbad = 0;
+    ZK_HIP(hipMemcpyAsync(&nbad, bad, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    (void)hipFree(raw); (void)hipFree(cursor);
+    if (nbad) { K->release(); return fail(ZKMI_ERR_INVALID, "groth16: coefficient record out of range (matrix > 1, constraint >= domain or signal >= nVars)"); }
+    ZK_HIP(hipMalloc((void**)&K->w, m * 32));
+    for (uint32_t** p : {&K->A, &K->B, &K->C, &K->T}) ZK_HIP(hipMalloc((void**)p, (size_t)n * 32));
+    for (auto& e : K->ev) ZK_HIP(hipEventCreate(&e));
+    auto it = cx.groth16.find(key);
+    if (it != cx.groth16.end()) { ((G16Key*)it->second)->release(); delete (G16Key*)it->second; }
+    cx.groth16[key] = K.release();
+    return ZKMI_OK;
+}
+
+// ---- host epilogue: blinding + toAffine (src/groth16_prove.js:103-132) -------------------------------------------------
+template <class G1F, class G2F, class FrC>
+static void g16_finish(const G16Key& K, const uint8_t* jA, const uint8_t* jB1, const uint8_t* jB2, const uint8_t* jC, const uint8_t* jH,
+                       const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+    typedef typename HostOf<G1F>::FT F1;
+    typedef typename HostOf<G2F>::FT F2;
+    host::HCurve<F1> c1{HostOf<G1F>::make()};
+    host::HCurve<F2> c2{HostOf<G2F>::make()};
+    const host::HField<4> Fr = host::HField<4>::from_cfg<FrC>();
+    constexpr int B1 = 4 * FieldWords<G1F>::value, B2 = 4 * FieldWords<G2F>::value;   // bytes per coordinate
+    auto ld1 = [&](const uint8_t* p) { typename host::HCurve<F1>::P r; memcpy(&r.X, p, B1); memcpy(&r.Y, p + B1, B1); memcpy(&r.Z, p + 2 * B1, B1); return r; };
+    auto ld2 = [&](const uint8_t* p) { typename host::HCurve<F2>::P r; memcpy(&r.X, p, B2); memcpy(&r.Y, p + B2, B2); memcpy(&r.Z, p + 2 * B2, B2); return r; };
+    auto af1 = [&](const std::vector<uint8_t>& v) { typename F1::E x, y; memcpy(&x, v.data(), B1); memcpy(&y, v.data() + B1, B1); return c1.from_affine(x, y); };
+    auto af2 = [&](const std::vector<uint8_t>& v) { typename F2::E x, y; memcpy(&x, v.data(), B2); memcpy(&y, v.data() + B2, B2); return c2.from_affine(x, y); };
+    host::HFp<4> r, s;
+    memcpy(r.v, r_mont, 32); memcpy(s.v, s_mont, 32);
+    // timesFr(P, k): k is a Montgomery Fr element; the scalar is its normal form
+    auto bits = [&](const host::HFp<4>& k_mont, uint8_t* out) { host::HFp<4> k = Fr.from_mont(k_mont); memcpy(out, k.v, 32); };
+    uint8_t rb[32], sb[32], rsb[32];
+    bits(r, rb); bits(s, sb); bits(Fr.neg(Fr.mul(r, s)), rsb);
+    auto alpha1 = af1(K.vk_alpha_1), beta1 = af1(K.vk_beta_1), delta1 = af1(K.vk_delta_1);
+    auto beta2 = af2(K.vk_beta_2), delta2 = af2(K.vk_delta_2);
+    auto pa = c1.add(c1.add(ld1(jA), alpha1), c1.mul_bits(delta1, rb, 256));                   // :106-107
+    auto pb = c2.add(c2.add(ld2(jB2), beta2), c2.mul_bits(delta2, sb, 256));                   // :109-110
+    auto pb1 = c1.add(c1.add(ld1(jB1), beta1), c1.mul_bits(delta1, sb, 256));                  // :112-113
+    auto pc = c1.add(ld1(jC), ld1(jH));                                                        // :115
+    pc = c1.add(pc, c1.mul_bits(pa, sb, 256));                                                 // :118
+    pc = c1.add(pc, c1.mul_bits(pb1, rb, 256));                                                // :119
+    pc = c1.add(pc, c1.mul_bits(delta1, rsb, 256));                                            // :120
+    typename F1::E x1, y1; typename F2::E x2, y2;
+    c1.to_affine(pa, x1, y1); memcpy(pi_a, &x1, B1); memcpy(pi_a + B1, &y1, B1);               // :130-132
+    c2.to_affine(pb, x2, y2); memcpy(pi_b, &x2, B2); memcpy(pi_b + B2, &y2, B2);
+    c1.to_affine(pc, x1, y1); memcpy(pi_c, &x1, B1); memcpy(pi_c + B1, &y1, B1);
+}
+
+template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+    Ctx& cx = ctx();
+    hipStream_t st = cx.stream;
+    const uint32_t n = K.domain;
+    const host::HField<4> Fr = host::HField<4>::from_cfg<FrC>();
+    const uint32_t* w = (const uint32_t*)d_witness;
+    ZK_HIP(hipEventRecord(K.ev[ST_BUILD], st));
+    hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, w, n, K.A, K.B, K.C);
+    ZK_HIP(hipEventRecord(K.ev[ST_NTT], st));
+    // inc = power == Fr.s ? Fr.shift : Fr.w[power+1] (:64); Fr.shift = nqr^2 — both come from the NTT module's root table
+    uint8_t one[32], inc[32];
+    memcpy(one, Fr.one, 32);
+    ZK_TRY(fr_coset_inc(K.curve, K.power, inc));
+    uint32_t* bufs[3] = {K.A, K.B, K.C};
+    for (int k = 0; k < 3; k++) {
+        ZK_TRY(ntt_dev_dispatch(K.curve, bufs[k], K.T, K.power, 1, nullptr, nullptr));
+        ZK_TRY(ntt_dev_dispatch(K.curve, K.T, bufs[k], K.power, 0, one, inc));
+    }
+    ZK_HIP(hipEventRecord(K.ev[ST_JOIN], st));
+    ZK_TRY(join_abc_dev_dispatch(K.curve, K.A, K.B, K.C, K.T, n));          // T = H-MSM scalars (normal form)
+    ZK_HIP(hipEventRecord(K.ev[ST_SORT_W], st));
+    MsmPlan pl;
+    MsmJob job[5];
+    for (int i = 0; i < 5; i++) ZK_TRY(msm_job_slot(i, job[i]));
+    ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl));
+    ZK_HIP(hipEventRecord(K.ev[ST_MSM_A], st));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bA, pl, 0, job[0]));
+    ZK_HIP(hipEventRecord(K.ev[ST_MSM_B1], st));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bB1, pl, 0, job[1]));
+    ZK_HIP(hipEventRecord(K.ev[ST_MSM_B2], st));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 2, K.bB2, pl, 0, job[2]));
+    ZK_HIP(hipEventRecord(K.ev[ST_MSM_C], st));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.n_public + 1, job[3]));
+    ZK_HIP(hipEventRecord(K.ev[ST_SORT_H], st));
+    ZK_TRY(msm_sort(K.T, n, 32, pl));
+    ZK_HIP(hipEventRecord(K.ev[ST_MSM_H], st));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, pl, 0, job[4]));
+    ZK_HIP(hipEventRecord(K.ev[ST_COUNT], st));
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    for (int i = 0; i < ST_COUNT; i++) { float ms = 0; if (hipEventElapsedTime(&ms, K.ev[i], K.ev[i + 1]) == hipSuccess) K.stage_ms[i] = ms; }
+    uint8_t jA[144], jB1[144], jB2[288], jC[144], jH[144];
+    ZK_TRY(msm_fold_dispatch(K.curve, 1, job[0], jA)); ZK_TRY(msm_fold_dispatch(K.curve, 1, job[1], jB1));
+    ZK_TRY(msm_fold_dispatch(K.curve, 2, job[2], jB2)); ZK_TRY(msm_fold_dispatch(K.curve, 1, job[3], jC));
+    ZK_TRY(msm_fold_dispatch(K.curve, 1, job[4], jH));
+    if (K.curve == ZKMI_CURVE_BN128) g16_finish<Fp<Bn254Fq>, Fp2<Bn254Fq>, Bn254Fr>(K, jA, jB1, jB2, jC, jH, r_mont, s_mont, pi_a, pi_b, pi_c);
+    else g16_finish<Fp<Bls12381Fq>, Fp2<Bls12381Fq>, Bls12381Fr>(K, jA, jB1, jB2, jC, jH, r_mont, s_mont, pi_a, pi_b, pi_c);
+    return ZKMI_OK;
+}
+
+static G16Key* g16_find(uint64_t key) {
+    auto it = ctx().groth16.find(key);
+    return it == ctx().groth16.end() ? nullptr : (G16Key*)it->second;
+}
+static uint64_t g_last_key = 0;
+
+}  // namespace zkmi
+
+using namespace zkmi;
+
+extern "C" {
+
+int zkmi_groth16_load(const zkmi_groth16_zkey* zkey, uint64_t key) {
+    ZK_TRY(require_ctx());
+    if (!zkey || !key) return fail(ZKMI_ERR_INVALID, "groth16_load: null zkey or key 0");
+    return g16_load(zkey, key);
+}
+int zkmi_groth16_release(uint64_t key) {
+    auto it = ctx().groth16.find(key);
+    if (it == ctx().groth16.end()) return ZKMI_OK;
+    if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+    ((G16Key*)it->second)->release();
+    delete (G16Key*)it->second;
+    ctx().groth16.erase(it);
+    return ZKMI_OK;
+}
+int zkmi_groth16_prove_dev(uint64_t key, const void* d_witness, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+    ZK_TRY(require_ctx());
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_prove_dev: key not loaded");
+    if (!d_witness || !r_mont || !s_mont || !pi_a || !pi_b || !pi_c) return fail(ZKMI_ERR_INVALID, "groth16_prove_dev: null argument");
+    g_last_key = key;
+    if (K->curve == ZKMI_CURVE_BN128) return g16_prove_dev<Bn254Fr>(*K, d_witness, r_mont, s_mont, pi_a, pi_b, pi_c);
+    return g16_prove_dev<Bls12381Fr>(*K, d_witness, r_mont, s_mont, pi_a, pi_b, pi_c);
+}
+int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_t* witness, const uint8_t* r_mont, const uint8_t* s_mont,
+                       uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+    ZK_TRY(require_ctx());
+    if (!witness) return fail(ZKMI_ERR_INVALID, "groth16_prove: null witness");
+    const uint64_t k = key ? key : 0xffffffffffffffffull;          // key 0: load, prove, release
+    if (!g16_find(k) || !key) {
+        if (!zkey) return fail(ZKMI_ERR_INVALID, "groth16_prove: key not loaded and no zkey given");
+        ZK_TRY(g16_load(zkey, k));
+    }
+    G16Key* K = g16_find(k);
+    ZK_HIP(hipMemcpyAsync(K->w, witness, (size_t)K->n_vars * 32, hipMemcpyHostToDevice, ctx().stream));
+    int rc = zkmi_groth16_prove_dev(k, K->w, r_mont, s_mont, pi_a, pi_b, pi_c);
+    if (!key) zkmi_groth16_release(k);
+    return rc;
+}
+int zkmi_groth16_stage_ms(double* out, int n) {
+    G16Key* K = g16_find(g_last_key);
+    if (!K || !out) return fail(ZKMI_ERR_INVALID, "groth16_stage_ms: no proof has been run");
+    for (int i = 0; i < n && i < ST_COUNT; i++) out[i] = K->stage_ms[i];
+    return ZKMI_OK;
+}
+
+}  // extern "C"

@@ -108,30 +108,143 @@ template <int NW> __global__ void k_msm_scatter(const uint8_t* __restrict__ scal
     });
 }
 
-// ---- bucket accumulation: one lane per bucket -----------------------------------------------------------------------
-// order == nullptr: bucket g = global thread id; otherwise g = order[tid] (buckets sorted by size so that the lanes of
-// a wave run equally long loops).
+// ---- bucket accumulation: load-balanced lane groups ---------------------------------------------------------------
+// A bucket with cnt points gets L lanes: L = 1 while cnt < 2*cap, else L = 2^j with j = floor(log2(cnt/cap)) (so every
+// lane adds < 2*cap points).  Buckets are ordered by a key (descending): multi-lane groups first (largest first, so a
+// group of 2^j lanes always starts at a multiple of 2^j), then single-lane buckets by exact size so that the lanes of a
+// wave run equally long loops.  Scalar distributions with huge buckets (real witnesses are mostly 0/1; the partial top
+// window) therefore cost the same as uniform ones.  Group partial sums are combined by k_msm_tree / k_msm_giant.
+constexpr uint32_t MSM_MAX_CAP = 256;
+constexpr uint32_t MSM_NKEYS = 2 * MSM_MAX_CAP + 32;
+// meta words: [0] total lanes, [1] lanes that belong to multi-lane groups, [2] number of giant buckets (> one tree block)
+ZK_DEV uint32_t msm_key(uint32_t cnt, uint32_t cap) {
+    if (cnt < 2 * cap) return cnt;                                   // 0 = empty, else single lane, key = size
+    return 2 * cap - 1 + (31 - __clz(cnt / cap));                    // j >= 1
+}
+ZK_DEV uint32_t msm_key_lanes_log(uint32_t key, uint32_t cap) { return key < 2 * cap ? 0u : key - (2 * cap - 1); }
+
+static __global__ void __launch_bounds__(256) k_msm_classify(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[MSM_NKEYS];
+    for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < total) { uint32_t k = msm_key(counts[g], cap); if (k) atomicAdd(&h[k], 1u); }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+// single lane: first lane of every key class in descending key order
+static __global__ void k_msm_class_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ meta, uint32_t cap) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t run = 0, multi = 0;
+    for (int k = (int)MSM_NKEYS - 1; k >= 1; k--) {
+        off[k] = run;
+        run += hist[k] << msm_key_lanes_log((uint32_t)k, cap);
+        if ((uint32_t)k == 2 * cap) multi = run;
+    }
+    meta[0] = run; meta[1] = multi;
+}
+static __global__ void __launch_bounds__(256)
+k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, uint32_t log_tb, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
+             uint32_t* __restrict__ lane_g, uint32_t* __restrict__ lane_sub, uint32_t* __restrict__ giants, uint32_t* __restrict__ meta) {
+    __shared__ uint32_t h[MSM_NKEYS], base[MSM_NKEYS];
+    for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k = g < total ? msm_key(counts[g], cap) : 0u, lr = 0;
+    if (k) lr = atomicAdd(&h[k], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) if (h[i]) base[i] = atomicAdd(&cursor[i], h[i]);
+    __syncthreads();
+    if (!k) return;
+    const uint32_t j = msm_key_lanes_log(k, cap), rank = base[k] + lr;
+    const uint32_t lane0 = off[k] + (rank << j);
+    for (uint32_t l = 0; l < (1u << j); l++) { lane_g[lane0 + l] = g; lane_sub[lane0 + l] = l; }
+    if (j > log_tb) {
+        uint32_t idx = atomicAdd(&meta[2], 1u);
+        giants[3 * idx] = g; giants[3 * idx + 1] = lane0 >> log_tb; giants[3 * idx + 2] = 1u << (j - log_tb);
+    }
+}
 template <class F> __global__ void __launch_bounds__(256)
-k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
-            const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order, uint32_t* __restrict__ buckets) {
+k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
+            const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub, const uint32_t* __restrict__ meta,
+            uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials) {
     constexpr int FW = FieldWords<F>::value;
-    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)sh.W * sh.nb;
-    if (tid >= total) return;
-    size_t g = order ? order[tid] : tid;
-    const uint32_t w = (uint32_t)(g / sh.nb);
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= meta[0]) return;
+    const uint32_t g = lane_g[lane];
+    const uint32_t w = g / sh.nb;
     const uint32_t cnt = counts[g];
+    const uint32_t j = msm_key_lanes_log(msm_key(cnt, cap), cap);
+    uint32_t lo = 0, hi = cnt;
+    if (j) {
+        const uint32_t chunk = (cnt + (1u << j) - 1) >> j;
+        lo = min(cnt, lane_sub[lane] * chunk);
+        hi = min(cnt, lo + chunk);
+    }
     const uint32_t* list = sorted + (size_t)w * sh.n + starts[g];
     XYZZ<F> acc;
     pt_set_inf(acc);
-    for (uint32_t k = 0; k < cnt; k++) {
+    for (uint32_t k = lo; k < hi; k++) {
         uint32_t e = list[k];
+        const uint32_t idx = e & 0x7fffffffu;
+        if (idx < skip) continue;
         Affine<F> q;
-        pt_load(q, bases + (size_t)(e & 0x7fffffffu) * (2 * FW));
+        pt_load(q, bases + (size_t)(idx - skip) * (2 * FW));
         if (e >> 31) q.y = f_neg(q.y);
         pt_madd(acc, q);
     }
-    pt_store(buckets + g * (4 * FW), acc);
+    if (j) pt_store(lane_partials + (size_t)lane * (4 * FW), acc);
+    else pt_store(buckets + (size_t)g * (4 * FW), acc);
+}
+// Combine the lane partials of multi-lane groups (they occupy lanes [0, meta[1])): LDS tree inside each block of TB
+// lanes; groups wider than a block leave one partial per block for k_msm_giant.
+template <class F, int TB> __global__ void __launch_bounds__(TB)
+k_msm_tree(const uint32_t* __restrict__ lane_partials, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ counts, uint32_t cap,
+           const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ block_partials) {
+    constexpr int PW = 4 * FieldWords<F>::value;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ uint32_t jmax_s;
+    const uint32_t t = threadIdx.x, lane = blockIdx.x * TB + t, multi = meta[1];
+    if (blockIdx.x * TB >= multi) return;
+    XYZZ<F> acc;
+    uint32_t j = 0, g = 0;
+    if (lane < multi) {
+        g = lane_g[lane];
+        j = msm_key_lanes_log(msm_key(counts[g], cap), cap);
+        pt_load(acc, lane_partials + (size_t)lane * PW);
+    } else pt_set_inf(acc);
+    if (t == 0) jmax_s = j;
+    pt_store(lds + t * PW, acc);
+    __syncthreads();
+    constexpr uint32_t LOG_TB = (TB == 256) ? 8 : (TB == 128 ? 7 : 6);
+    const uint32_t steps = min(jmax_s, LOG_TB);
+    for (uint32_t s = 0; s < steps; s++) {
+        const bool act = ((t & ((2u << s) - 1)) == 0) && (s < j);
+        if (act) { XYZZ<F> o; pt_load(o, lds + (t + (1u << s)) * PW); acc = pt_add(acc, o); }
+        __syncthreads();
+        if (act) pt_store(lds + t * PW, acc);
+        __syncthreads();
+    }
+    if (lane >= multi) return;
+    if (j <= LOG_TB) { if ((t & ((1u << j) - 1)) == 0) pt_store(buckets + (size_t)g * PW, acc); }
+    else if (t == 0) pt_store(block_partials + (size_t)blockIdx.x * PW, acc);
+}
+template <class F, int TB> __global__ void __launch_bounds__(TB)
+k_msm_giant(const uint32_t* __restrict__ giants, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ block_partials, uint32_t* __restrict__ buckets) {
+    constexpr int PW = 4 * FieldWords<F>::value;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (blockIdx.x >= meta[2]) return;
+    const uint32_t g = giants[3 * blockIdx.x], b0 = giants[3 * blockIdx.x + 1], nblk = giants[3 * blockIdx.x + 2], t = threadIdx.x;
+    XYZZ<F> acc;
+    pt_set_inf(acc);
+    for (uint32_t b = t; b < nblk; b += TB) { XYZZ<F> o; pt_load(o, block_partials + (size_t)(b0 + b) * PW); acc = pt_add(acc, o); }
+    pt_store(lds + t * PW, acc);
+    __syncthreads();
+    for (int d = TB / 2; d >= 1; d >>= 1) {
+        if (t < (uint32_t)d) { XYZZ<F> o; pt_load(o, lds + (t + d) * PW); acc = pt_add(acc, o); pt_store(lds + t * PW, acc); }
+        __syncthreads();
+    }
+    if (t == 0) pt_store(buckets + (size_t)g * PW, acc);
 }
 
 // ---- bucket reduction -------------------------------------------------------------------------------------------------
@@ -140,21 +253,21 @@ k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, const uint32_t* __r
 //
 // Level 1: each lane takes G consecutive buckets:  A' = sum_j j*B_j (running sums), R' = sum_j B_j.
 template <class F> __global__ void __launch_bounds__(256)
-k_msm_reduce_seq(const uint32_t* __restrict__ buckets, uint32_t nb, uint32_t G, uint32_t groups_per_window, uint32_t total_groups,
+k_msm_reduce_seq(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ counts, uint32_t nb, uint32_t G, uint32_t groups_per_window, uint32_t total_groups,
                  uint32_t* __restrict__ outA, uint32_t* __restrict__ outR) {
     constexpr int PW = 4 * FieldWords<F>::value;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_groups) return;
     uint32_t w = t / groups_per_window, u = t % groups_per_window;
-    const uint32_t* src = buckets + ((size_t)w * nb + (size_t)u * G) * PW;
+    const size_t g0 = (size_t)w * nb + (size_t)u * G;
+    const uint32_t* src = buckets + g0 * PW;
     XYZZ<F> run, acc;
     pt_set_inf(run); pt_set_inf(acc);
     for (int j = (int)G - 1; j >= 1; j--) {
-        XYZZ<F> b; pt_load(b, src + (size_t)j * PW);
-        run = pt_add(run, b);
+        if (counts[g0 + j]) { XYZZ<F> b; pt_load(b, src + (size_t)j * PW); run = pt_add(run, b); }   // empty buckets were never written
         acc = pt_add(acc, run);
     }
-    { XYZZ<F> b; pt_load(b, src); run = pt_add(run, b); }
+    if (counts[g0]) { XYZZ<F> b; pt_load(b, src); run = pt_add(run, b); }
     pt_store(outA + (size_t)t * PW, acc);
     pt_store(outR + (size_t)t * PW, run);
 }
@@ -206,26 +319,6 @@ k_msm_reduce_block(const uint32_t* __restrict__ inA, const uint32_t* __restrict_
         pt_store(outA + o * PW, a);
         if (!final) pt_store(outR + o * PW, myR);
     }
-}
-
-// ---- bucket ordering by size (descending) so that a wave's lanes get equal trip counts ----------------------------------
-static __global__ void k_msm_size_hist(const uint32_t* __restrict__ counts, uint32_t total, uint32_t max_bin, uint32_t* __restrict__ hist) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    atomicAdd(&hist[min(counts[g], max_bin)], 1u);
-}
-// single block: descending exclusive scan over the (small) size histogram
-static __global__ void k_msm_size_scan(uint32_t* __restrict__ hist, uint32_t bins) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint32_t run = 0;
-        for (int b = (int)bins - 1; b >= 0; b--) { uint32_t v = hist[b]; hist[b] = run; run += v; }
-    }
-}
-static __global__ void k_msm_size_scatter(const uint32_t* __restrict__ counts, uint32_t total, uint32_t max_bin, uint32_t* __restrict__ hist, uint32_t* __restrict__ order) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    uint32_t pos = atomicAdd(&hist[min(counts[g], max_bin)], 1u);
-    order[pos] = g;
 }
 
 // ---- synthetic base table (zkmi_gen_geometric_bases_dev): P_i = (f*g^i mod r)*G ----------------------------------------

@@ -27,6 +27,14 @@ int msm_bls12381(int group, const void* d_bases, const void* d_scalars, size_t n
     if (group == 1) return msm_run<Fp<Bls12381Fq>>(d_bases, d_scalars, n, sb, out_jac);
     return msm_run<Fp2<Bls12381Fq>>(d_bases, d_scalars, n, sb, out_jac);
 }
+int msm_accumulate_bls12381(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job) {
+    if (group == 1) return msm_accumulate<Fp<Bls12381Fq>>(d_bases, pl, skip, job);
+    return msm_accumulate<Fp2<Bls12381Fq>>(d_bases, pl, skip, job);
+}
+int msm_fold_bls12381(int group, const MsmJob& job, uint8_t* out_jac) {
+    if (group == 1) msm_fold<Fp<Bls12381Fq>>(job, out_jac); else msm_fold<Fp2<Bls12381Fq>>(job, out_jac);
+    return ZKMI_OK;
+}
 int gen_bases_bls12381(int group, size_t n, uint64_t f, uint64_t g, void* d_out) {
     uint8_t gen[192];
     bls_generator(group, gen);

@@ -26,6 +26,14 @@ int msm_bn254(int group, const void* d_bases, const void* d_scalars, size_t n, s
     if (group == 1) return msm_run<Fp<Bn254Fq>>(d_bases, d_scalars, n, sb, out_jac);
     return msm_run<Fp2<Bn254Fq>>(d_bases, d_scalars, n, sb, out_jac);
 }
+int msm_accumulate_bn254(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job) {
+    if (group == 1) return msm_accumulate<Fp<Bn254Fq>>(d_bases, pl, skip, job);
+    return msm_accumulate<Fp2<Bn254Fq>>(d_bases, pl, skip, job);
+}
+int msm_fold_bn254(int group, const MsmJob& job, uint8_t* out_jac) {
+    if (group == 1) msm_fold<Fp<Bn254Fq>>(job, out_jac); else msm_fold<Fp2<Bn254Fq>>(job, out_jac);
+    return ZKMI_OK;
+}
 int gen_bases_bn254(int group, size_t n, uint64_t f, uint64_t g, void* d_out) {
     uint8_t gen[128];
     bn254_generator(group, gen);

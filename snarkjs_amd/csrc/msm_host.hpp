@@ -63,38 +63,42 @@ template <class F> int to_affine_host(const uint8_t* jac, uint8_t* aff) {
     return ZKMI_OK;
 }
 
-template <class F, int NW> int msm_launch_digits(const uint8_t* d_scalars, const MsmShape& sh, uint32_t* counts, uint32_t* starts, uint32_t* cursor,
-                                                uint32_t* sorted, hipStream_t st) {
-    const unsigned blocks = (unsigned)((sh.n + 255) / 256);
-    hipLaunchKernelGGL((k_msm_count<NW>), dim3(blocks), dim3(256), 0, st, d_scalars, sh, counts);
-    hipLaunchKernelGGL(k_msm_scan, dim3(sh.W), dim3(1024), 0, st, counts, starts, sh.nb);
-    hipLaunchKernelGGL((k_msm_scatter<NW>), dim3(blocks), dim3(256), 0, st, d_scalars, sh, starts, cursor, sorted);
-    return ZKMI_OK;
-}
+// ---- stage 1-3 (field independent, msm_sort.hip): signed-digit recoding + counting sort of all windows -----------
+// The plan points into the library's named scratch buffers; it stays valid until the next msm_sort on the stream.
+struct MsmPlan {
+    MsmShape sh;
+    size_t total = 0;                 // W * nb buckets
+    uint32_t cap = 0;                 // lane-group granularity (msm.cuh: k_msm_assign)
+    size_t lane_bound = 0, multi_bound = 0;
+    uint32_t *counts = nullptr, *starts = nullptr, *sorted = nullptr;
+    uint32_t *lane_g = nullptr, *lane_sub = nullptr, *meta = nullptr, *giants = nullptr;
+};
+constexpr int MSM_TB = 128, MSM_LOG_TB = 7;      // tree block: 128 lanes x 384 B (BLS12-381 G2 XYZZ) = 48 KiB of LDS
+int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan);
 
-// Full device MSM: bases (affine, device), scalars (plain integers, device) -> Jacobian point on the host.
-template <class F> int msm_run(const void* d_bases, const void* d_scalars, size_t n, size_t sb, uint8_t* out_jac) {
+// One MSM in flight: per-window sums land in a pinned host slot; msm_fold turns them into the Jacobian result.
+struct MsmJob {
+    int W = 0, c = 0;
+    uint32_t* h_win = nullptr;
+};
+constexpr int MSM_JOB_SLOTS = 8;
+constexpr size_t MSM_JOB_SLOT_BYTES = 128 * 1024;
+int msm_job_slot(int slot, MsmJob& job);
+
+// ---- stage 4-5: bucket accumulation + reduction for one base table over an existing plan ------------------------------
+// skip: the scalar with index i pairs with base (i - skip); indices < skip are ignored. This lets several MSMs share
+// one digit sort (Groth16: A, B1, B2 over the witness and C over witness[nPublic+1:], src/groth16_prove.js:85-97).
+template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job) {
     constexpr int FW = FieldWords<F>::value, PW = 4 * FW;
     Ctx& cx = ctx();
-    if (n == 0) { memset(out_jac, 0, 3 * 4 * FW); return ZKMI_OK; }
-    if (n >= (1ull << 31)) return fail(ZKMI_ERR_UNSUPPORTED, "msm: n >= 2^31");
-    if (sb == 0 || sb > 64) return fail(ZKMI_ERR_UNSUPPORTED, "msm: scalar size must be 1..64 bytes");
-    MsmShape sh;
-    sh.n = (uint32_t)n; sh.sb = (int)sb;
-    sh.c = cx.msm_c_override ? cx.msm_c_override : msm_pick_c(n);
-    sh.W = (int)((8 * sb + 1 + sh.c - 1) / sh.c);
-    sh.nb = 1u << (sh.c - 1);
-    const size_t total = (size_t)sh.W * sh.nb;
+    const MsmShape& sh = pl.sh;
+    const size_t total = pl.total;
     hipStream_t st = cx.stream;
-
-    uint32_t *counts, *sorted, *buckets, *order, *hist, *redA0, *redR0, *redA1, *redR1;
-    ZK_TRY(ws_get("msm.counts", 3 * total * 4, (void**)&counts));        // counts | starts | cursor
-    uint32_t *starts = counts + total, *cursor = starts + total;
-    ZK_TRY(ws_get("msm.sorted", (size_t)sh.W * n * 4, (void**)&sorted));
+    uint32_t *buckets, *redA0, *redR0, *redA1, *redR1, *lane_partials, *block_partials;
     ZK_TRY(ws_get("msm.buckets", total * PW * 4, (void**)&buckets));
-    ZK_TRY(ws_get("msm.order", total * 4, (void**)&order));
-    const uint32_t BINS = 1024;
-    ZK_TRY(ws_get("msm.hist", BINS * 4, (void**)&hist));
+    ZK_TRY(ws_get("msm.lane_partials", std::max<size_t>(pl.multi_bound, 1) * PW * 4, (void**)&lane_partials));
+    const size_t tree_blocks = pl.multi_bound / MSM_TB + 1;
+    ZK_TRY(ws_get("msm.block_partials", tree_blocks * PW * 4, (void**)&block_partials));
     const uint32_t G = std::min<uint32_t>(8u, sh.nb);
     const uint32_t m1 = sh.nb / G;
     ZK_TRY(ws_get("msm.redA0", (size_t)sh.W * m1 * PW * 4, (void**)&redA0));
@@ -103,24 +107,22 @@ template <class F> int msm_run(const void* d_bases, const void* d_scalars, size_
     const uint32_t m2 = (m1 + M - 1) / M;
     ZK_TRY(ws_get("msm.redA1", (size_t)sh.W * std::max(m2, 1u) * PW * 4, (void**)&redA1));
     ZK_TRY(ws_get("msm.redR1", (size_t)sh.W * std::max(m2, 1u) * PW * 4, (void**)&redR1));
-
-    ZK_HIP(hipEventRecord(cx.ev0, st));
-    ZK_HIP(hipMemsetAsync(counts, 0, 3 * total * 4, st));
-    ZK_HIP(hipMemsetAsync(hist, 0, BINS * 4, st));
-    const uint8_t* sc = (const uint8_t*)d_scalars;
-    if (sb <= 4) msm_launch_digits<F, 1>(sc, sh, counts, starts, cursor, sorted, st);
-    else if (sb <= 32) msm_launch_digits<F, 8>(sc, sh, counts, starts, cursor, sorted, st);
-    else msm_launch_digits<F, 16>(sc, sh, counts, starts, cursor, sorted, st);
-    // bucket order by size (descending)
-    const unsigned tb = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(k_msm_size_hist, dim3(tb), dim3(256), 0, st, counts, (uint32_t)total, BINS - 1, hist);
-    hipLaunchKernelGGL(k_msm_size_scan, dim3(1), dim3(64), 0, st, hist, BINS);
-    hipLaunchKernelGGL(k_msm_size_scatter, dim3(tb), dim3(256), 0, st, counts, (uint32_t)total, BINS - 1, hist, order);
-    // accumulate
-    hipLaunchKernelGGL((k_msm_accum<F>), dim3(tb), dim3(256), 0, st, (const uint32_t*)d_bases, sh, counts, starts, sorted, order, buckets);
+    if ((size_t)sh.W * PW * 4 > MSM_JOB_SLOT_BYTES) return fail(ZKMI_ERR_UNSUPPORTED, "msm: too many windows");
+    static bool tree_attr = false;
+    const size_t tree_lds = (size_t)MSM_TB * PW * 4;
+    if (!tree_attr) {
+        ZK_HIP(hipFuncSetAttribute((const void*)k_msm_tree<F, MSM_TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_msm_giant<F, MSM_TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
+        tree_attr = true;
+    }
+    hipLaunchKernelGGL((k_msm_accum<F>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_bases, sh, skip, pl.cap, pl.counts,
+                       pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials);
+    hipLaunchKernelGGL((k_msm_tree<F, MSM_TB>), dim3((unsigned)tree_blocks), dim3(MSM_TB), tree_lds, st, lane_partials, pl.lane_g, pl.counts, pl.cap, pl.meta, buckets,
+                       block_partials);
+    hipLaunchKernelGGL((k_msm_giant<F, MSM_TB>), dim3((unsigned)tree_blocks), dim3(MSM_TB), tree_lds, st, pl.giants, pl.meta, block_partials, buckets);
     // reduce: level 1 (sequential groups of G), then block levels until one point per window
     const uint32_t tg = sh.W * m1;
-    hipLaunchKernelGGL((k_msm_reduce_seq<F>), dim3((tg + 255) / 256), dim3(256), 0, st, buckets, sh.nb, G, m1, tg, redA0, redR0);
+    hipLaunchKernelGGL((k_msm_reduce_seq<F>), dim3((tg + 255) / 256), dim3(256), 0, st, buckets, pl.counts, sh.nb, G, m1, tg, redA0, redR0);
     uint32_t m = m1;
     int log_scale = ilog2_sz(G);
     uint32_t *inA = redA0, *inR = redR0, *outA = redA1, *outR = redR1;
@@ -139,17 +141,37 @@ template <class F> int msm_run(const void* d_bases, const void* d_scalars, size_
         m = blocks;
         log_scale += ilog2_sz(M);
     }
-    ZK_HIP(hipEventRecord(cx.ev1, st));
-    std::vector<uint32_t> win((size_t)sh.W * PW);
-    ZK_HIP(hipMemcpyAsync(win.data(), inA, win.size() * 4, hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipStreamSynchronize(st));
+    job.W = sh.W; job.c = sh.c;
+    ZK_HIP(hipMemcpyAsync(job.h_win, inA, (size_t)sh.W * PW * 4, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipGetLastError());
-    float ms = 0;
-    hipEventElapsedTime(&ms, cx.ev0, cx.ev1);
-    cx.last_ms = ms;
-    msm_fold_windows<F>(win.data(), sh.W, sh.c, out_jac);
     return ZKMI_OK;
 }
+// after the stream has been synchronised
+template <class F> void msm_fold(const MsmJob& job, uint8_t* out_jac) { msm_fold_windows<F>(job.h_win, job.W, job.c, out_jac); }
+
+// Full device MSM: bases (affine, device), scalars (plain integers, device) -> Jacobian point on the host.
+template <class F> int msm_run(const void* d_bases, const void* d_scalars, size_t n, size_t sb, uint8_t* out_jac) {
+    constexpr int FW = FieldWords<F>::value;
+    Ctx& cx = ctx();
+    if (n == 0) { memset(out_jac, 0, 3 * 4 * FW); return ZKMI_OK; }
+    hipStream_t st = cx.stream;
+    MsmPlan pl;
+    MsmJob job;
+    ZK_TRY(msm_job_slot(0, job));
+    ZK_HIP(hipEventRecord(cx.ev0, st));
+    ZK_TRY(msm_sort(d_scalars, n, sb, pl));
+    ZK_TRY(msm_accumulate<F>(d_bases, pl, 0, job));
+    ZK_HIP(hipEventRecord(cx.ev1, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, cx.ev0, cx.ev1) == hipSuccess) cx.last_ms = ms;
+    msm_fold<F>(job, out_jac);
+    return ZKMI_OK;
+}
+
+// non-template entry points (msm_bn254.hip / msm_bls12381.hip) for callers that must not instantiate the kernels again
+int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job);
+int msm_fold_dispatch(int curve, int group, const MsmJob& job, uint8_t* out_jac);
 
 template <class F, class FrC> int gen_bases_run(const uint8_t* gen_affine_host, size_t n, uint64_t f, uint64_t g, void* d_out) {
     constexpr int FW = FieldWords<F>::value;

@@ -1,0 +1,69 @@
+// snarkjs_amd/csrc/msm_sort.hip — field-independent front half of the device Pippenger: signed-digit recoding of the
+// scalars and a counting sort of (point index, sign) into per-(window, bucket) lists; plus bucket ordering by size.
+// One sort can feed several accumulations (msm_accumulate) when MSMs share their scalars.
+#include "msm_host.hpp"
+
+namespace zkmi {
+
+template <int NW> static int msm_launch_digits(const uint8_t* d_scalars, const MsmShape& sh, uint32_t* counts, uint32_t* starts, uint32_t* cursor,
+                                               uint32_t* sorted, hipStream_t st) {
+    const unsigned blocks = (unsigned)((sh.n + 255) / 256);
+    hipLaunchKernelGGL((k_msm_count<NW>), dim3(blocks), dim3(256), 0, st, d_scalars, sh, counts);
+    hipLaunchKernelGGL(k_msm_scan, dim3(sh.W), dim3(1024), 0, st, counts, starts, sh.nb);
+    hipLaunchKernelGGL((k_msm_scatter<NW>), dim3(blocks), dim3(256), 0, st, d_scalars, sh, starts, cursor, sorted);
+    return ZKMI_OK;
+}
+
+int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl) {
+    Ctx& cx = ctx();
+    if (n == 0 || n >= (1ull << 31)) return fail(ZKMI_ERR_UNSUPPORTED, "msm: n must be in [1, 2^31)");
+    if (sb == 0 || sb > 64) return fail(ZKMI_ERR_UNSUPPORTED, "msm: scalar size must be 1..64 bytes");
+    MsmShape& sh = pl.sh;
+    sh.n = (uint32_t)n; sh.sb = (int)sb;
+    sh.c = cx.msm_c_override ? cx.msm_c_override : msm_pick_c(n);
+    sh.W = (int)((8 * sb + 1 + sh.c - 1) / sh.c);
+    sh.nb = 1u << (sh.c - 1);
+    const size_t total = (size_t)sh.W * sh.nb;
+    pl.total = total;
+    hipStream_t st = cx.stream;
+    uint32_t *counts, *hist;
+    ZK_TRY(ws_get("msm.counts", 3 * total * 4, (void**)&counts));        // counts | starts | cursor
+    pl.counts = counts; pl.starts = counts + total;
+    uint32_t* cursor = pl.starts + total;
+    ZK_TRY(ws_get("msm.sorted", (size_t)sh.W * n * 4, (void**)&pl.sorted));
+    // lane-group schedule (k_msm_classify/_class_scan/_assign): cap = pow2ceil(2 * average bucket size) in [16, 256]
+    const size_t avg = (n + sh.nb - 1) / sh.nb;
+    uint32_t cap = 16;
+    while (cap < 2 * avg && cap < MSM_MAX_CAP) cap <<= 1;
+    pl.cap = cap;
+    pl.multi_bound = (size_t)sh.W * n / cap + 1;                          // lanes of multi-lane groups: sum 2^floor(log2(cnt/cap))
+    pl.lane_bound = total + pl.multi_bound;
+    ZK_TRY(ws_get("msm.lanes", 2 * pl.lane_bound * 4, (void**)&pl.lane_g));
+    pl.lane_sub = pl.lane_g + pl.lane_bound;
+    const size_t giant_bound = pl.multi_bound / MSM_TB + 1;
+    ZK_TRY(ws_get("msm.hist", (3 * MSM_NKEYS + 8 + 3 * giant_bound) * 4, (void**)&hist));     // hist | off | cursor | meta | giants
+    uint32_t *koff = hist + MSM_NKEYS, *kcur = koff + MSM_NKEYS;
+    pl.meta = kcur + MSM_NKEYS; pl.giants = pl.meta + 8;
+    ZK_HIP(hipMemsetAsync(counts, 0, 3 * total * 4, st));
+    ZK_HIP(hipMemsetAsync(hist, 0, (3 * MSM_NKEYS + 8) * 4, st));
+    const uint8_t* sc = (const uint8_t*)d_scalars;
+    if (sb <= 4) msm_launch_digits<1>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, st);
+    else if (sb <= 32) msm_launch_digits<8>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, st);
+    else msm_launch_digits<16>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, st);
+    const unsigned tb = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(k_msm_classify, dim3(tb), dim3(256), 0, st, pl.counts, (uint32_t)total, cap, hist);
+    hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(64), 0, st, hist, koff, pl.meta, cap);
+    hipLaunchKernelGGL(k_msm_assign, dim3(tb), dim3(256), 0, st, pl.counts, (uint32_t)total, cap, (uint32_t)MSM_LOG_TB, koff, kcur, pl.lane_g, pl.lane_sub, pl.giants, pl.meta);
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+}
+
+int msm_job_slot(int slot, MsmJob& job) {
+    Ctx& cx = ctx();
+    if (slot < 0 || slot >= MSM_JOB_SLOTS) return fail(ZKMI_ERR_INVALID, "msm: bad job slot");
+    if (!cx.pinned) ZK_HIP(hipHostMalloc((void**)&cx.pinned, MSM_JOB_SLOTS * MSM_JOB_SLOT_BYTES, hipHostMallocDefault));
+    job.h_win = (uint32_t*)(cx.pinned + (size_t)slot * MSM_JOB_SLOT_BYTES);
+    return ZKMI_OK;
+}
+
+}  // namespace zkmi

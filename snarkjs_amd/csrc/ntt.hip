@@ -13,7 +13,7 @@ typedef host::HFp<4> HE;
 struct FrRoots {
     HFr F;
     int s = 0;
-    HE w[33], wi[33];
+    HE w[33], wi[33], shift;
 };
 // Fr.w[] as ffjavascript defines it (build/snarkjs.min.js:1@185893): nqr = smallest quadratic
 // non-residue >= 2, s = 2-adicity of r-1, w[s] = nqr^((r-1)/2^s), w[i] = w[i+1]^2.
@@ -32,6 +32,7 @@ template <class C> static const FrRoots& fr_roots() {
     HE negone = F.neg(F.One()), nqr;
     for (uint64_t x = 2;; x++) { nqr = F.from_u64(x); if (F.pow(nqr, half, 4) == negone) break; }
     R.s = s;
+    R.shift = F.sqr(nqr);
     R.w[s] = F.pow(nqr, e, 4);
     for (int i = s - 1; i >= 0; i--) R.w[i] = F.sqr(R.w[i + 1]);
     for (int i = 0; i <= s; i++) R.wi[i] = F.inv(R.w[i]);
@@ -110,22 +111,39 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
     uint32_t* d_rowinc = nullptr;
     size_t rowoff[4] = {0, 0, 0, 0};
     if (first) {
-        const HFr& F = R.F;
-        HE f, g; memcpy(f.v, first, 32); memcpy(g.v, inc, 32);
         size_t tot = 0;
         for (int i = 0; i < p; i++) { rowoff[i] = tot; tot += (size_t)1 << P->l[i]; }
-        std::vector<HE> tab(tot);
-        unsigned logS = L;
-        for (int i = 0; i < p; i++) {
-            logS -= P->l[i];
-            HE b = g;
-            for (unsigned k = 0; k < logS; k++) b = F.sqr(b);          // inc^(S_i)
-            HE cur = (i == 0) ? f : F.One();
-            for (size_t j = 0; j < ((size_t)1 << P->l[i]); j++) { tab[rowoff[i] + j] = cur; cur = F.mul(cur, b); }
-        }
-        ZK_TRY(ws_get("ntt.rowinc", tot * 32, (void**)&d_rowinc));
-        ZK_HIP(hipMemcpyAsync(d_rowinc, tab.data(), tot * 32, hipMemcpyHostToDevice, st));
-        ZK_HIP(hipStreamSynchronize(st));     // `tab` is a stack-owned staging buffer
+        std::string ck((const char*)first, 32);
+        ck.append((const char*)inc, 32);
+        ck.push_back((char)curve); ck.push_back((char)L);
+        DevBuf& cb = cx.ntt_prescale[ck];
+        if (!cb.p) {                                  // tables are O(sum 2^l_i) elements: built once per (size, first, inc)
+            if (cx.ntt_prescale.size() > 64) {         // bound the cache: drop everything but the new entry
+                ZK_HIP(hipStreamSynchronize(st));
+                for (auto it = cx.ntt_prescale.begin(); it != cx.ntt_prescale.end();) {
+                    if (it->first == ck) { ++it; continue; }
+                    if (it->second.p) (void)hipFree(it->second.p);
+                    it = cx.ntt_prescale.erase(it);
+                }
+            }
+            const HFr& F = R.F;
+            HE f, g; memcpy(f.v, first, 32); memcpy(g.v, inc, 32);
+            std::vector<HE> tab(tot);
+            unsigned logS = L;
+            for (int i = 0; i < p; i++) {
+                logS -= P->l[i];
+                HE b = g;
+                for (unsigned k = 0; k < logS; k++) b = F.sqr(b);          // inc^(S_i)
+                HE cur = (i == 0) ? f : F.One();
+                for (size_t j = 0; j < ((size_t)1 << P->l[i]); j++) { tab[rowoff[i] + j] = cur; cur = F.mul(cur, b); }
+            }
+            DevBuf& nb = cx.ntt_prescale[ck];
+            ZK_HIP(hipMalloc(&nb.p, tot * 32));
+            nb.cap = tot * 32;
+            ZK_HIP(hipMemcpyAsync(nb.p, tab.data(), tot * 32, hipMemcpyHostToDevice, st));
+            ZK_HIP(hipStreamSynchronize(st));     // `tab` is a stack-owned staging buffer
+            d_rowinc = (uint32_t*)nb.p;
+        } else d_rowinc = (uint32_t*)cb.p;
     }
     // work buffer for the in-place middle passes (the caller's input is never modified)
     uint32_t* work = nullptr;
@@ -193,6 +211,13 @@ template <class C> static int apply_key_run(const void* d_in, void* d_out, size_
     hipLaunchKernelGGL((k_apply_key<C, PER>), dim3((unsigned)((n + T * PER - 1) / (T * PER))), dim3(T), 0, cx.stream, (const uint32_t*)d_in, (uint32_t*)d_out, n, d_k, d_k + 8, d_k + 16);
     ZK_HIP(hipEventRecord(cx.ev1, cx.stream));
     ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+}
+int fr_coset_inc(int curve, unsigned power, uint8_t* out32) {
+    const FrRoots& R = (curve == ZKMI_CURVE_BN128) ? fr_roots<Bn254Fr>() : fr_roots<Bls12381Fr>();
+    if ((int)power > R.s) return fail(ZKMI_ERR_UNSUPPORTED, "domain exceeds the 2-adicity of Fr");
+    const HE& v = ((int)power == R.s) ? R.shift : R.w[power + 1];
+    memcpy(out32, v.v, 32);
     return ZKMI_OK;
 }
 int apply_key_dev_dispatch(int curve, const void* d_in, void* d_out, size_t n, const uint8_t* first, const uint8_t* inc) {

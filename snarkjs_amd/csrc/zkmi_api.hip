@@ -2,6 +2,7 @@
 // marshalling and dispatch to the per-curve kernel drivers.  No CPU fallback: every compute entry point requires a
 // HIP device and fails with ZKMI_ERR_NO_DEVICE otherwise.
 #include <string.h>
+#include "msm_host.hpp"
 #include "zkmi_common.hpp"
 
 namespace zkmi {
@@ -58,6 +59,10 @@ int download_pages(const void* d_src, size_t total_bytes, uint8_t* const* out_pt
 
 int msm_bn254(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_bls12381(int group, const void*, const void*, size_t, size_t, uint8_t*);
+int msm_accumulate_bn254(int group, const void*, const MsmPlan&, uint32_t, MsmJob&);
+int msm_accumulate_bls12381(int group, const void*, const MsmPlan&, uint32_t, MsmJob&);
+int msm_fold_bn254(int group, const MsmJob&, uint8_t*);
+int msm_fold_bls12381(int group, const MsmJob&, uint8_t*);
 int gen_bases_bn254(int group, size_t, uint64_t, uint64_t, void*);
 int gen_bases_bls12381(int group, size_t, uint64_t, uint64_t, void*);
 int to_affine_bn254(int group, const uint8_t*, uint8_t*);
@@ -71,6 +76,14 @@ static int check_cg(int curve, int group) {
 int msm_dev_dispatch(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t sb, uint8_t* out) {
     ZK_TRY(check_cg(curve, group));
     return curve == ZKMI_CURVE_BN128 ? msm_bn254(group, d_bases, d_scalars, n, sb, out) : msm_bls12381(group, d_bases, d_scalars, n, sb, out);
+}
+int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job) {
+    ZK_TRY(check_cg(curve, group));
+    return curve == ZKMI_CURVE_BN128 ? msm_accumulate_bn254(group, d_bases, pl, skip, job) : msm_accumulate_bls12381(group, d_bases, pl, skip, job);
+}
+int msm_fold_dispatch(int curve, int group, const MsmJob& job, uint8_t* out_jac) {
+    ZK_TRY(check_cg(curve, group));
+    return curve == ZKMI_CURVE_BN128 ? msm_fold_bn254(group, job, out_jac) : msm_fold_bls12381(group, job, out_jac);
 }
 int gen_bases_dispatch(int curve, int group, size_t n, uint64_t f, uint64_t g, void* d_out) {
     ZK_TRY(check_cg(curve, group));

@@ -48,7 +48,10 @@ struct Ctx {
     std::map<std::string, DevBuf> ws;                       // named scratch buffers (grow-only)
     std::map<uint64_t, DevBuf> base_cache;                  // zkmi_msm base_cache_key -> resident table
     std::map<std::tuple<int, unsigned, int>, NttPlan> plans;  // (curve, log_n, inverse)
+    std::map<std::string, DevBuf> ntt_prescale;             // cached row-factor tables of fused NTT pre-scales
     std::map<void*, size_t> user_allocs;
+    std::map<uint64_t, void*> groth16;                      // zkmi_groth16 resident keys (groth16.hip)
+    uint8_t* pinned = nullptr;                              // pinned host slots for MSM window sums
 };
 Ctx& ctx();
 int require_ctx();
@@ -67,6 +70,8 @@ int apply_key_dev_dispatch(int curve, const void* d_in, void* d_out, size_t n, c
 int fr_batch_dev_dispatch(int curve, int op, const void* d_in, void* d_out, size_t n);
 int join_abc_dev_dispatch(int curve, const void* a, const void* b, const void* c, void* out, size_t n);
 int to_affine_dispatch(int curve, int group, const uint8_t* jac, uint8_t* aff);
+// inc of the Groth16 coset step: Fr.shift when power == Fr.s, else Fr.w[power+1] (src/groth16_prove.js:64), Montgomery bytes
+int fr_coset_inc(int curve, unsigned power, uint8_t* out32);
 
 inline int n8q_of(int curve) { return curve == ZKMI_CURVE_BN128 ? 32 : 48; }
 

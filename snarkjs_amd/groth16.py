@@ -1,0 +1,128 @@
+"""groth16.prove on the MI355X — host-side mirror of the reference driver (src/groth16_prove.js:28-144,
+src/groth16.js:19-22): same inputs (zkey + wtns containers), same checks and error messages, same output
+({proof, publicSignals} with decimal-string coordinates).  Everything between "sections read" and "proof points"
+runs in the HIP library (zkmi_groth16_prove, snarkjs_amd/csrc/groth16.hip).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import binfile, zkmi
+
+_BN128_Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+_BLS_Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+_R = {0: 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+      1: 52435875175126190479447740508185965837690552500527637822603658699938581184513}
+
+
+def _curve_from_q(q):
+    """src/curves.js:23-34 getCurveFromQ"""
+    if q == _BN128_Q:
+        return 0, "bn128"
+    if q == _BLS_Q:
+        return 1, "bls12381"
+    raise ValueError(f"Curve not supported: {q}")
+
+
+def _fr_random_mont(curve_id, rng=None):
+    """Fr.random() stand-in: uniform element, returned in Montgomery form. `rng(nbytes) -> bytes`."""
+    rng = rng or os.urandom
+    r = _R[curve_id]
+    v = int.from_bytes(rng(64), "little") % r
+    return np.frombuffer(((v << 256) % r).to_bytes(32, "little"), np.uint8).copy()
+
+
+def _from_mont_q(curve_id, b):
+    q = _BN128_Q if curve_id == 0 else _BLS_Q
+    n8 = 32 if curve_id == 0 else 48
+    rinv = pow(1 << (8 * n8), -1, q)
+    out = []
+    for i in range(0, len(b), n8):
+        out.append(int.from_bytes(bytes(b[i:i + n8]), "little") * rinv % q)
+    return out
+
+
+class ProvingKey:
+    """A Groth16 zkey resident on the device (base tables + CSR coefficient table)."""
+    _next = 1
+
+    def __init__(self, zkey_bytes):
+        self.zk = zk = binfile.read_groth16_zkey(zkey_bytes)
+        self.curve_id, self.curve_name = _curve_from_q(zk["q"])
+        self.key = ProvingKey._next
+        ProvingKey._next += 1
+        zkmi.init(int(os.environ.get("LOCAL_RANK", "0")) if zkmi.device_count() > 1 else 0)
+        self._keep = {k: np.ascontiguousarray(zk[k]) for k in
+                      ("coeffs", "A", "B1", "B2", "C", "H", "vk_alpha_1", "vk_beta_1", "vk_beta_2", "vk_delta_1", "vk_delta_2")}
+        p = lambda k: self._keep[k].ctypes.data
+        self.desc = zkmi.Groth16Zkey(self.curve_id, zk["nVars"], zk["nPublic"], zk["domainSize"], p("coeffs"), self._keep["coeffs"].size,
+                                     p("A"), p("B1"), p("B2"), p("C"), p("H"),
+                                     p("vk_alpha_1"), p("vk_beta_1"), p("vk_beta_2"), p("vk_delta_1"), p("vk_delta_2"))
+        zkmi.check(zkmi.lib().zkmi_groth16_load(C.byref(self.desc), self.key))
+
+    def prove_raw(self, witness, r_mont, s_mont, d_witness=None):
+        """-> (pi_a, pi_b, pi_c) affine Montgomery bytes. d_witness: device pointer of an already uploaded witness."""
+        q = 32 if self.curve_id == 0 else 48
+        pi_a, pi_b, pi_c = np.zeros(2 * q, np.uint8), np.zeros(4 * q, np.uint8), np.zeros(2 * q, np.uint8)
+        r, s = zkmi.u8(r_mont), zkmi.u8(s_mont)
+        L = zkmi.lib()
+        if d_witness is not None:
+            zkmi.check(L.zkmi_groth16_prove_dev(self.key, d_witness, zkmi.ptr(r), zkmi.ptr(s), zkmi.ptr(pi_a), zkmi.ptr(pi_b), zkmi.ptr(pi_c)))
+        else:
+            w = zkmi.u8(witness)
+            zkmi.check(L.zkmi_groth16_prove(None, self.key, zkmi.ptr(w), zkmi.ptr(r), zkmi.ptr(s), zkmi.ptr(pi_a), zkmi.ptr(pi_b), zkmi.ptr(pi_c)))
+        return pi_a, pi_b, pi_c
+
+    def stage_ms(self):
+        out = (C.c_double * 10)()
+        zkmi.check(zkmi.lib().zkmi_groth16_stage_ms(out, 10))
+        names = ["buildABC", "ntt_x6", "joinABC", "sort_witness", "msm_A", "msm_B1", "msm_B2", "msm_C", "sort_H", "msm_H"]
+        return dict(zip(names, list(out)))
+
+    def release(self):
+        if self.key:
+            zkmi.lib().zkmi_groth16_release(self.key)
+            self.key = 0
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def prove(zkey, witness_file, logger=None, options=None, r_mont=None, s_mont=None):
+    """groth16.prove(zkeyFileName, witnessFileName) — files given as bytes or paths (or a ProvingKey to reuse).
+    r_mont / s_mont: the two Fr.random() draws (:103-104) in Montgomery form, for bit-exact reproduction."""
+    def data(x):
+        if isinstance(x, (bytes, bytearray, memoryview, np.ndarray)):
+            return bytes(x)
+        with open(x, "rb") as f:
+            return f.read()
+
+    pk = zkey if isinstance(zkey, ProvingKey) else ProvingKey(data(zkey))
+    zk = pk.zk
+    wt = binfile.read_wtns(data(witness_file))
+    if zk["r"] != wt["q"]:
+        raise ValueError("Curve of the witness does not match the curve of the proving key")      # :41-43
+    if wt["nWitness"] != zk["nVars"]:
+        raise ValueError(f"Invalid witness length. Circuit: {zk['nVars']}, witness: {wt['nWitness']}")   # :45-47
+    r = r_mont if r_mont is not None else _fr_random_mont(pk.curve_id)
+    s = s_mont if s_mont is not None else _fr_random_mont(pk.curve_id)
+    pi_a, pi_b, pi_c = pk.prove_raw(wt["witness"], r, s)
+    n8q = zk["n8q"]
+    to_le = lambda vals: b"".join(int(v).to_bytes(n8q, "little") for v in vals)
+    proof, _ = binfile.proof_json(pk.curve_name, n8q, to_le(_from_mont_q(pk.curve_id, pi_a)), to_le(_from_mont_q(pk.curve_id, pi_b)),
+                                  to_le(_from_mont_q(pk.curve_id, pi_c)))
+    w = wt["witness"]
+    public = [str(int.from_bytes(bytes(w[i * 32:(i + 1) * 32]), "little")) for i in range(1, zk["nPublic"] + 1)]   # :123-128
+    if not isinstance(zkey, ProvingKey):
+        pk.release()
+    return {"proof": proof, "publicSignals": public}
+
+
+def proof_to_json(proof):
+    """JSON.stringify(proof) as snarkjs writes it (key order of src/groth16_prove.js:130-141)."""
+    return json.dumps(proof, separators=(",", ":"))

@@ -24,7 +24,7 @@ SYMBOLS = [
     "zkmi_ntt", "zkmi_ntt_dev",
     "zkmi_fr_batch_apply_key", "zkmi_fr_batch_apply_key_dev", "zkmi_fr_batch", "zkmi_fr_batch_dev",
     "zkmi_groth16_join_abc", "zkmi_groth16_join_abc_dev",
-    "zkmi_groth16_prove", "zkmi_groth16_release", "zkmi_groth16_prove_dev_timing",
+    "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_release", "zkmi_groth16_stage_ms",
     "zkmi_gen_geometric_bases_dev", "zkmi_to_affine", "zkmi_last_kernel_ms",
 ]
 
@@ -83,11 +83,11 @@ def lib():
     L.zkmi_groth16_join_abc_dev.argtypes = [C.c_int, vp, vp, vp, vp, sz]
     L.zkmi_gen_geometric_bases_dev.argtypes = [C.c_int, C.c_int, sz, C.c_uint64, C.c_uint64, vp]
     L.zkmi_to_affine.argtypes = [C.c_int, C.c_int, u8p, u8p]
-    if hasattr(L, "zkmi_groth16_prove"):
-        L.zkmi_groth16_prove.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p]
-        L.zkmi_groth16_release.argtypes = [C.c_uint64]
-    if hasattr(L, "zkmi_groth16_prove_dev_timing"):
-        L.zkmi_groth16_prove_dev_timing.argtypes = [C.POINTER(C.c_double), C.c_int]
+    L.zkmi_groth16_load.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64]
+    L.zkmi_groth16_prove.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.zkmi_groth16_prove_dev.argtypes = [C.c_uint64, vp, u8p, u8p, u8p, u8p, u8p]
+    L.zkmi_groth16_release.argtypes = [C.c_uint64]
+    L.zkmi_groth16_stage_ms.argtypes = [C.POINTER(C.c_double), C.c_int]
     _lib = L
     return L
 

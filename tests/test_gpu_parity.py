@@ -212,3 +212,39 @@ def test_join_abc(zk, name):
     n = 5000
     a, b, cc = (synth.elems(s, n) for s in (1, 2, 3))
     assert np.array_equal(cv.joinABC(a, b, cc), O.join_abc(c, a, b, cc))
+
+
+def test_groth16_golden_proof(zk, golden_dir):
+    """The seeded Groth16 proof of SURVEY.md Appendix C.3: fused device prover == the reference's proof JSON (sha256)."""
+    from snarkjs_amd import groth16
+    with open(os.path.join(golden_dir, "groth16_bn128_n1024.json")) as f:
+        g = json.load(f)
+    zkey = open(os.path.join(golden_dir, "groth16_bn128_n1024.zkey"), "rb").read()
+    wtns = open(os.path.join(golden_dir, "groth16_bn128_n1024.wtns"), "rb").read()
+    res = groth16.prove(zkey, wtns, r_mont=bytes.fromhex(g["r_mont"]), s_mont=bytes.fromhex(g["s_mont"]))
+    assert res["proof"] == g["proof"]
+    assert res["publicSignals"] == g["publicSignals"]
+    assert sha(groth16.proof_to_json(res["proof"]).encode()) == g["proof_sha256"] == "08797809c8de2c2053a925b1772af3e04c41f8c9b4c41f5b71ae5135435da44d"
+    with pytest.raises(ValueError):
+        groth16.prove(zkey, wtns[:-32])
+
+
+@pytest.mark.parametrize("name,lg", [("bn128", 12), ("bn128", 16), ("bls12381", 12)])
+def test_groth16_synthetic_vs_oracle(zk, name, lg):
+    """Synthetic zkey/wtns of SURVEY.md §8d ('fast' variant): device prover == CPU oracle, point for point."""
+    import synth_zkey
+    from snarkjs_amd import groth16, binfile
+    c = O.CURVE_ID[name]
+    zkey, wtns = synth_zkey.make(name, lg, seed=0xC0FFEE + lg)
+    r_m, s_m = O.fr_e(c, 0x1234567), O.fr_e(c, 0x7654321)
+    pk = groth16.ProvingKey(zkey)
+    w = binfile.read_wtns(wtns)["witness"]
+    got = pk.prove_raw(w, r_m, s_m)
+    want = O.groth16_prove(c, binfile.read_groth16_zkey(zkey), w, r_m, s_m)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    # proving twice with the resident key gives the same bytes (no state leaks between proofs)
+    again = pk.prove_raw(w, r_m, s_m)
+    for a, b in zip(got, again):
+        assert np.array_equal(a, b)
+    pk.release()
