@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json metric on MI355X: Groth16 proofs/s (BN254, 2^20 constraints, synthetic zkey/wtns =
+configs[1]) with G1-MSM Mscalar/s and NTT Melem/s as sub-metrics.
+
+A "step" is one whole proof: buildABC -> 3 x (iNTT, coset NTT) -> joinABC -> 5 MSMs -> blinding/toAffine, with the
+proving key AND the witness already resident in HBM when the timed region starts (zkmi_groth16_prove_dev).
+N > 1: one process per GPU (torchrun), every rank proves its own stream of proofs over a replicated key — the proof
+is the independent unit (SURVEY.md §8e "whole proofs"); no data-path collective; "scaling": "weak".
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FIELD_MUL_PEAK_G = 126.0       # measured Montgomery-mul ceiling, tools/fieldbench (profiles/r01_fieldbench.txt), Gmul/s
+
+
+def cpu_baseline(log_n_sample, log_n_full):
+    """The CPU oracle (C restatement of the reference, oracle/zk_oracle.c) on a bounded sample, rank 0, N=1 only."""
+    import oracle_lib as O
+    import synth_zkey
+    from snarkjs_amd import binfile
+    zkey, wtns = synth_zkey.make("bn128", log_n_sample, seed=0xBA5E, witness="uniform")
+    zk, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)["witness"]
+    r_m, s_m = O.fr_e(0, 0x1234567), O.fr_e(0, 0x7654321)
+    t0 = time.perf_counter()
+    ref = O.groth16_prove(0, zk, w, r_m, s_m)
+    dt = time.perf_counter() - t0
+    scale = 1 << (log_n_full - log_n_sample)
+    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": f"one full Groth16 proof at 2^{log_n_sample} constraints by oracle/zk_oracle.c (1 thread, {dt:.1f} s), "
+                      f"scaled linearly x{scale} to 2^{log_n_full}"}, (zkey, wtns, ref, r_m, s_m)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--cpu-log-n", type=int, default=14)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--witness", default="uniform", choices=["uniform", "mixed"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from snarkjs_amd import groth16, zkmi, binfile
+    import synth
+    import synth_zkey
+    zkmi.init(local_rank)
+    L = zkmi.lib()
+
+    lg = args.log_n
+    zkey, wtns = synth_zkey.make("bn128", lg, seed=0x5EED + rank, witness=args.witness)
+    pk = groth16.ProvingKey(zkey)
+    zk = pk.zk
+    w = binfile.read_wtns(wtns)["witness"]
+    d_w = zkmi.DeviceBuffer.from_host(w)
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    mont = lambda v: np.frombuffer(((v << 256) % R).to_bytes(32, "little"), np.uint8).copy()
+    r_m, s_m = mont(0x1234567), mont(0x7654321)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return pk.prove_raw(None, r_m, s_m, d_witness=d_w.ptr)
+
+    for _ in range(args.warmup):
+        step()
+    stage_acc, accum_ms = {}, {k: [] for k in range(5)}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof_pts = step()
+        for k, v in pk.stage_ms().items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+        for k in range(5):
+            accum_ms[k].append(L.zkmi_msm_accum_ms(k))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stages = {k: v / args.steps for k, v in stage_acc.items()}
+
+    out = None
+    if rank == 0:
+        # ---- sub-metrics (outside the timed region): G1 MSM and NTT at the same size, device-event time ----
+        n = 1 << lg
+        d_b = zkmi.DeviceBuffer(n * 64)
+        zkmi.check(L.zkmi_gen_geometric_bases_dev(0, 1, n, 7, 11, d_b.ptr))
+        d_s = zkmi.DeviceBuffer.from_host(synth.elems(0x5EED, n))
+        jac = np.zeros(96, np.uint8)
+        ts, ta = [], []
+        for _ in range(4):
+            zkmi.check(L.zkmi_msm_dev(0, 1, d_b.ptr, d_s.ptr, n, 32, zkmi.ptr(jac)))
+            ts.append(L.zkmi_last_kernel_ms()); ta.append(L.zkmi_msm_accum_ms(0))
+        msm_ms, msm_acc_ms = min(ts[1:]), min(ta[1:])
+        d_o = zkmi.DeviceBuffer(n * 32)
+        tn = []
+        for _ in range(5):
+            zkmi.check(L.zkmi_ntt_dev(0, d_s.ptr, d_o.ptr, lg, 0, None, None))
+            tn.append(L.zkmi_last_kernel_ms())
+        ntt_ms = min(tn[1:])
+        # ---- roofline of the dominant kernel: bucket accumulation of the G2 MSM (B2) ----
+        m = zk["nVars"]
+        acc = {k: float(np.mean(v)) for k, v in accum_ms.items()}
+        names = {0: ("k_msm_accum<Fp<Bn254Fq>> (A)", 96), 1: ("k_msm_accum<Fp<Bn254Fq>> (B1)", 96), 2: ("k_msm_accum<Fp2<Bn254Fq>> (B2)", 160),
+                 3: ("k_msm_accum<Fp<Bn254Fq>> (C)", 96), 4: ("k_msm_accum<Fp<Bn254Fq>> (H)", 96)}
+        dom = max(acc, key=lambda k: acc[k])
+        units = {0: m, 1: m, 2: m, 3: m - zk["nPublic"] - 1, 4: zk["domainSize"]}[dom]
+        alg_bytes = names[dom][1] * units                      # B/term (affine base + 32-B scalar) x terms
+        achieved = alg_bytes / (acc[dom] * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # filled from separate rocprofv3 --pmc passes
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(names[dom][0].split(" ")[0])
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": names[dom][0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "kernel_ms": round(acc[dom], 4),
+                "algorithmic_bytes": alg_bytes,
+                "note": "integer-ALU-bound (256-bit Montgomery carry chains, no MFMA): see int_alu"}
+        out = {
+            "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"BN254 Groth16 prove, 2^{lg} constraints, synthetic zkey/wtns (BASELINE configs[1]); key + witness resident in HBM",
+                       "curve": "bn128", "log_n": lg, "n_vars": m, "n_coef": int((zk['coeffs'].size - 4) // 44), "witness": args.witness,
+                       "parallelism": f"replica x{world} (one proof stream per GPU)"},
+            "submetrics": {"g1_msm_mscalar_per_s": round(n / msm_ms / 1e3, 2), "g1_msm_ms": round(msm_ms, 4), "g1_msm_accum_kernel_ms": round(msm_acc_ms, 4),
+                           "g1_msm_hbm_frac": round(96 * n / (msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                           "ntt_melem_per_s": round(n / ntt_ms / 1e3, 2), "ntt_ms": round(ntt_ms, 4),
+                           "ntt_hbm_frac": round(64 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+            "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            "accum_kernel_ms": {names[k][0]: round(v, 4) for k, v in acc.items()},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, (zk_s, wt_s, ref, rs, ss) = cpu_baseline(args.cpu_log_n, lg)
+            out["cpu_baseline"] = base
+            # the same sample through the device path must give the oracle's proof points (parity inside the bench run)
+            pk_s = groth16.ProvingKey(zk_s)
+            got = pk_s.prove_raw(binfile.read_wtns(wt_s)["witness"], rs, ss)
+            out["cpu_baseline"]["parity_on_sample"] = bool(all(np.array_equal(a, b) for a, b in zip(got, ref)))
+            pk_s.release()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,9 @@ int zkmi_release_bases(uint64_t base_cache_key);
 /* Same with bases and scalars already resident in device memory (bench.py, fused pipelines). */
 int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t scalar_bytes,
                  uint8_t* out_jacobian);
+/* Device time (ms, HIP events on the library stream) of the bucket-accumulation kernel of the last MSM that used job
+ * slot `slot`: zkmi_msm / zkmi_msm_dev use slot 0; zkmi_groth16_prove uses 0..4 = A, B1, B2, C, H. -1 if never run. */
+double zkmi_msm_accum_ms(int slot);
 /* Window width used for n terms (tuning knob; 0 restores the built-in table). */
 int zkmi_msm_set_window_bits(int c);
 
@@ -134,8 +137,9 @@ int zkmi_groth16_prove_dev(uint64_t zkey_cache_key, const void* d_witness, const
                            uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 int zkmi_groth16_release(uint64_t zkey_cache_key);
 /* Device time (ms, HIP events) of the stages of the last proof, in order: buildABC, 6 NTTs, joinABC, sort(witness),
- * MSM A, MSM B1, MSM B2, MSM C, sort(H scalars), MSM H. Writes min(n, ZKMI_GROTH16_STAGES) values. */
-#define ZKMI_GROTH16_STAGES 10
+ * bucket accumulation of MSM A, B1, B2, C, sort(H scalars), accumulation of MSM H, batched bucket reductions.
+ * Writes min(n, ZKMI_GROTH16_STAGES) values. */
+#define ZKMI_GROTH16_STAGES 11
 int zkmi_groth16_stage_ms(double* out, int n);
 
 /* ---- utilities --------------------------------------------------------------------------------------------------- */

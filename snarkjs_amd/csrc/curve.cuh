@@ -36,16 +36,27 @@ template <class C> ZK_DEV bool f_is_zero(const Fp2<C>& a) { return fp_is_zero(a.
 template <class C> ZK_DEV bool f_eq(const Fp2<C>& a, const Fp2<C>& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
 template <class C> ZK_DEV void f_set_zero(Fp2<C>& a) { a.c0 = fp_zero<C>(); a.c1 = fp_zero<C>(); }
 template <class C> ZK_DEV void f_set_one(Fp2<C>& a) { a.c0 = fp_one<C>(); a.c1 = fp_zero<C>(); }
+// Base-field product used inside Fq2 arithmetic. An Fq2 mixed addition holds 28 of them: fully inlined that is > 64 KiB
+// of straight-line code (the instruction cache two CUs share) and > 200 VGPRs; as an out-of-line call (operands and
+// result in registers) the hot loop stays cache-resident.  ZKMI_FP2_NOINLINE=0 restores full inlining.
+#ifndef ZKMI_FP2_NOINLINE
+#define ZKMI_FP2_NOINLINE 1
+#endif
+#if ZKMI_FP2_NOINLINE
+template <class C> __device__ __noinline__ Fp<C> fp2_base_mul(Fp<C> a, Fp<C> b) { return fp_mul(a, b); }
+#else
+template <class C> ZK_DEV Fp<C> fp2_base_mul(const Fp<C>& a, const Fp<C>& b) { return fp_mul(a, b); }
+#endif
 // Karatsuba: 3 base-field multiplications
 template <class C> ZK_DEV Fp2<C> f_mul(const Fp2<C>& a, const Fp2<C>& b) {
-    Fp<C> t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
-    Fp<C> t2 = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+    Fp<C> t0 = fp2_base_mul(a.c0, b.c0), t1 = fp2_base_mul(a.c1, b.c1);
+    Fp<C> t2 = fp2_base_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
     return Fp2<C>{fp_sub(t0, t1), fp_sub(fp_sub(t2, t0), t1)};
 }
 // (a0+a1)(a0-a1) + 2 a0 a1 u : 2 multiplications
 template <class C> ZK_DEV Fp2<C> f_sqr(const Fp2<C>& a) {
-    Fp<C> t = fp_mul(a.c0, a.c1);
-    return Fp2<C>{fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
+    Fp<C> t = fp2_base_mul(a.c0, a.c1);
+    return Fp2<C>{fp2_base_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
 }
 template <class C> ZK_DEV Fp2<C> f_inv(const Fp2<C>& a) {
     Fp<C> d = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));

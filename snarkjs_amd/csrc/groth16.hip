@@ -10,6 +10,7 @@
 //
 // The zkey is static per circuit: zkmi_groth16_load uploads the five base tables once and converts the coefficient
 // section into CSR form (rows = (matrix, constraint)) on the device; a proof then moves only the witness.
+#include <stdlib.h>
 #include <string.h>
 #include <memory>
 #include "msm_host.hpp"
@@ -85,7 +86,7 @@ k_build_abc(const uint32_t* __restrict__ row_start, const uint32_t* __restrict__
 }
 
 // ---- resident proving key ---------------------------------------------------------------------------------------------
-enum { ST_BUILD = 0, ST_NTT, ST_JOIN, ST_SORT_W, ST_MSM_A, ST_MSM_B1, ST_MSM_B2, ST_MSM_C, ST_SORT_H, ST_MSM_H, ST_COUNT };
+enum { ST_BUILD = 0, ST_NTT, ST_JOIN, ST_SORT_W, ST_MSM_A, ST_MSM_B1, ST_MSM_B2, ST_MSM_C, ST_SORT_H, ST_MSM_H, ST_REDUCE, ST_COUNT };
 
 struct G16Key {
     int curve = 0;
@@ -218,10 +219,10 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     ZK_HIP(hipEventRecord(K.ev[ST_JOIN], st));
     ZK_TRY(join_abc_dev_dispatch(K.curve, K.A, K.B, K.C, K.T, n));          // T = H-MSM scalars (normal form)
     ZK_HIP(hipEventRecord(K.ev[ST_SORT_W], st));
-    MsmPlan pl;
+    MsmPlan pl, plh;
     MsmJob job[5];
     for (int i = 0; i < 5; i++) ZK_TRY(msm_job_slot(i, job[i]));
-    ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl));
+    ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl, 0));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_A], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bA, pl, 0, job[0]));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_B1], st));
@@ -231,9 +232,16 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_C], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.n_public + 1, job[3]));
     ZK_HIP(hipEventRecord(K.ev[ST_SORT_H], st));
-    ZK_TRY(msm_sort(K.T, n, 32, pl));
+    ZK_TRY(msm_sort(K.T, n, 32, plh, 1));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_H], st));
-    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, pl, 0, job[4]));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, plh, 0, job[4]));
+    ZK_HIP(hipEventRecord(K.ev[ST_REDUCE], st));
+    // bucket reductions are latency-bound: all G1 jobs of one shape go through ONE set of launches
+    MsmJob* g1[4] = {&job[0], &job[1], &job[3], &job[4]};
+    if (job[4].W == job[0].W && job[4].c == job[0].c) ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 4));
+    else { ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 3)); ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1 + 3, 1)); }
+    MsmJob* g2[1] = {&job[2]};
+    ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1));
     ZK_HIP(hipEventRecord(K.ev[ST_COUNT], st));
     ZK_HIP(hipStreamSynchronize(st));
     ZK_HIP(hipGetLastError());

@@ -66,12 +66,39 @@ template <int NW, class Fn> ZK_DEV void for_each_digit(const uint32_t (&s)[NW], 
     }
 }
 
+// atomicAdd(&ctr[idx], 1) for every active lane, returning the old value, with up to two rounds of wave-level
+// aggregation: lanes that share the first pending lane's counter are served by one atomic. Skewed digit distributions
+// (real witnesses are mostly 0/1; the partially filled top window) otherwise serialise on a single L2 address.
+ZK_DEV uint32_t msm_atomic_inc(uint32_t* __restrict__ ctr, size_t idx) {
+    const uint32_t lane = __lane_id();
+    uint32_t result = 0;
+    bool done = false;
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        if (!done) {
+            const uint64_t act = __ballot(1);
+            const int leader = __ffsll((unsigned long long)act) - 1;
+            const uint32_t lo = __shfl((uint32_t)idx, leader), hi = __shfl((uint32_t)(idx >> 32), leader);
+            if (lo == (uint32_t)idx && hi == (uint32_t)(idx >> 32)) {
+                const uint64_t peers = __ballot(1);
+                const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+                uint32_t basev = 0;
+                if ((int)lane == leader) basev = atomicAdd(&ctr[idx], (uint32_t)__popcll(peers));
+                result = __shfl(basev, leader) + rank;
+                done = true;
+            }
+        }
+    }
+    if (!done) result = atomicAdd(&ctr[idx], 1u);
+    return result;
+}
+
 template <int NW> __global__ void k_msm_count(const uint8_t* __restrict__ scalars, MsmShape sh, uint32_t* __restrict__ counts) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sh.n) return;
     uint32_t s[NW];
     load_scalar<NW>(s, scalars, i, sh.sb);
-    for_each_digit<NW>(s, sh.c, sh.W, [&](int w, uint32_t mag, bool) { atomicAdd(&counts[(size_t)w * sh.nb + (mag - 1)], 1u); });
+    for_each_digit<NW>(s, sh.c, sh.W, [&](int w, uint32_t mag, bool) { msm_atomic_inc(counts, (size_t)w * sh.nb + (mag - 1)); });
 }
 
 // one block per window: starts[w][b] = exclusive prefix sum of counts[w][*]
@@ -103,7 +130,7 @@ template <int NW> __global__ void k_msm_scatter(const uint8_t* __restrict__ scal
     load_scalar<NW>(s, scalars, i, sh.sb);
     for_each_digit<NW>(s, sh.c, sh.W, [&](int w, uint32_t mag, bool neg) {
         size_t g = (size_t)w * sh.nb + (mag - 1);
-        uint32_t pos = starts[g] + atomicAdd(&cursor[g], 1u);
+        uint32_t pos = starts[g] + msm_atomic_inc(cursor, g);
         sorted[(size_t)w * sh.n + pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
     });
 }
@@ -164,7 +191,9 @@ k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, 
         giants[3 * idx] = g; giants[3 * idx + 1] = lane0 >> log_tb; giants[3 * idx + 2] = 1u << (j - log_tb);
     }
 }
-template <class F> __global__ void __launch_bounds__(256)
+// WIDE (Fq2 points): no software pipelining of the gather and at most 256 VGPRs (2 waves per SIMD) — measured 2.2x faster
+// than letting the compiler take 400+ registers (tools/maddbench.hip).
+template <class F, bool WIDE> __global__ void __launch_bounds__(256, WIDE ? 2 : 1)
 k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
             const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub, const uint32_t* __restrict__ meta,
             uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials) {
@@ -184,14 +213,31 @@ k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, uint32_t skip, uint
     const uint32_t* list = sorted + (size_t)w * sh.n + starts[g];
     XYZZ<F> acc;
     pt_set_inf(acc);
-    for (uint32_t k = lo; k < hi; k++) {
-        uint32_t e = list[k];
-        const uint32_t idx = e & 0x7fffffffu;
-        if (idx < skip) continue;
-        Affine<F> q;
-        pt_load(q, bases + (size_t)(idx - skip) * (2 * FW));
-        if (e >> 31) q.y = f_neg(q.y);
-        pt_madd(acc, q);
+    if (WIDE) {
+        for (uint32_t k = lo; k < hi; k++) {
+            const uint32_t e = list[k], idx = e & 0x7fffffffu;
+            if (idx < skip) continue;
+            Affine<F> q;
+            pt_load(q, bases + (size_t)(idx - skip) * (2 * FW));
+            if (e >> 31) q.y = f_neg(q.y);
+            pt_madd(acc, q);
+        }
+    } else {
+        // software pipeline: the gather of point k+1 (a random 64..96-byte read) is in flight during the addition of point k
+        uint32_t e_next = lo < hi ? list[lo] : 0u;
+        Affine<F> q_next;
+        if (lo < hi && (e_next & 0x7fffffffu) >= skip) pt_load(q_next, bases + (size_t)((e_next & 0x7fffffffu) - skip) * (2 * FW));
+        for (uint32_t k = lo; k < hi; k++) {
+            const uint32_t e = e_next;
+            Affine<F> q = q_next;
+            if (k + 1 < hi) {
+                e_next = list[k + 1];
+                if ((e_next & 0x7fffffffu) >= skip) pt_load(q_next, bases + (size_t)((e_next & 0x7fffffffu) - skip) * (2 * FW));
+            }
+            if ((e & 0x7fffffffu) < skip) continue;
+            if (e >> 31) q.y = f_neg(q.y);
+            pt_madd(acc, q);
+        }
     }
     if (j) pt_store(lane_partials + (size_t)lane * (4 * FW), acc);
     else pt_store(buckets + (size_t)g * (4 * FW), acc);
@@ -248,34 +294,58 @@ k_msm_giant(const uint32_t* __restrict__ giants, const uint32_t* __restrict__ me
 }
 
 // ---- bucket reduction -------------------------------------------------------------------------------------------------
-// Invariant carried through the levels (per window):  result = sum_t A_t + scale * sum_t t*R_t  + (top level) sum_t R_t,
-// where t is the index inside the window at that level. Level 0 has A = 0, R = buckets, scale = 1.
-//
-// Level 1: each lane takes G consecutive buckets:  A' = sum_j j*B_j (running sums), R' = sum_j B_j.
-template <class F> __global__ void __launch_bounds__(256)
-k_msm_reduce_seq(const uint32_t* __restrict__ buckets, const uint32_t* __restrict__ counts, uint32_t nb, uint32_t G, uint32_t groups_per_window, uint32_t total_groups,
-                 uint32_t* __restrict__ outA, uint32_t* __restrict__ outR) {
+// Per window S = sum_{b0=0}^{nb-1} (b0+1) * B_b0 (b0+1 = digit magnitude). The reference does this with a recursive halving
+// (_reduceTable, min.js:1@74634); a GPU wants the shallowest dependency chain, because one XYZZ addition is ~9 us of
+// latency for a lone wave. Write b0 = r*C + c with C = 2^cbits columns and R = 2^rbits rows (rbits + cbits = c-1):
+//     S = C * sum_r r*Row_r + sum_c c*Col_c + sum_r Row_r,     Row_r = sum_c B[r*C+c],  Col_c = sum_r B[r*C+c].
+// k_msm_rowcol forms all Row/Col sums (one wave per sum: <= C/64 sequential additions, then a 6-level butterfly);
+// k_msm_wsum turns each length-C array into (sum_t t*X_t, sum_t X_t) with a suffix scan + tree in LDS. The host applies
+// the factor C (cbits doublings) when it folds the windows.  Several MSMs of the same shape are reduced in one launch.
+constexpr int MSM_MAX_BATCH = 4;
+struct MsmReduceBatch {
+    const uint32_t* buckets[MSM_MAX_BATCH];
+    const uint32_t* counts[MSM_MAX_BATCH];
+    int njobs;
+};
+template <class F, int TBR> __global__ void __launch_bounds__(TBR)
+k_msm_rowcol(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_t cbits, uint32_t* __restrict__ out) {
     constexpr int PW = 4 * FieldWords<F>::value;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_groups) return;
-    uint32_t w = t / groups_per_window, u = t % groups_per_window;
-    const size_t g0 = (size_t)w * nb + (size_t)u * G;
-    const uint32_t* src = buckets + g0 * PW;
-    XYZZ<F> run, acc;
-    pt_set_inf(run); pt_set_inf(acc);
-    for (int j = (int)G - 1; j >= 1; j--) {
-        if (counts[g0 + j]) { XYZZ<F> b; pt_load(b, src + (size_t)j * PW); run = pt_add(run, b); }   // empty buckets were never written
-        acc = pt_add(acc, run);
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t C = 1u << cbits, R = 1u << rbits;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t gw = (size_t)blockIdx.x * (TBR / 64) + wv;                 // output index: ((job*W + w)*2 + kind)*C + i
+    const size_t n_out = (size_t)rb.njobs * W * 2 * C;
+    XYZZ<F> acc;
+    pt_set_inf(acc);
+    if (gw < n_out) {
+        const uint32_t i = (uint32_t)(gw & (C - 1)), kind = (uint32_t)(gw >> cbits) & 1u;
+        const size_t jw = gw >> (cbits + 1);
+        const uint32_t job = (uint32_t)(jw / W), w = (uint32_t)(jw % W);
+        const uint32_t* bk = rb.buckets[job];
+        const uint32_t* cn = rb.counts[job];
+        const uint32_t cnt = kind ? R : ((i < R) ? C : 0u);
+        for (uint32_t e = lane; e < cnt; e += 64) {
+            const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
+            if (cn[g]) { XYZZ<F> p; pt_load(p, bk + g * PW); acc = pt_add(acc, p); }      // empty buckets were never written
+        }
     }
-    if (counts[g0]) { XYZZ<F> b; pt_load(b, src); run = pt_add(run, b); }
-    pt_store(outA + (size_t)t * PW, acc);
-    pt_store(outR + (size_t)t * PW, run);
+    uint32_t* my = lds + (size_t)threadIdx.x * PW;
+    pt_store(my, acc);
+    __syncthreads();
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) {
+        if (lane < (uint32_t)d) { XYZZ<F> o; pt_load(o, my + (size_t)d * PW); acc = pt_add(acc, o); }
+        __syncthreads();
+        if (lane < (uint32_t)d) pt_store(my, acc);
+        __syncthreads();
+    }
+    if (lane == 0 && gw < n_out) pt_store(out + gw * PW, acc);
 }
-// Level >= 2: one block of M lanes per M consecutive (A,R) pairs of a window:
-//   A' = sum_t A_t + scale * sum_{t>=1} suffix_t(R),  R' = suffix_0(R);  if `final`: out = A' + R' (one point per window).
+// One block of M lanes per M consecutive items of an array of m_per_array points; invariant across levels:
+//   weighted = sum_t A_t + scale * sum_t t*X_t,  total = sum_t X_t   (level 0: A absent, scale 1).
 template <class F, int M> __global__ void __launch_bounds__(M)
-k_msm_reduce_block(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inR, uint32_t m_per_window, uint32_t blocks_per_window,
-                   int log_scale, int final, uint32_t* __restrict__ outA, uint32_t* __restrict__ outR) {
+k_msm_wsum(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inR, uint32_t m_per_window, uint32_t blocks_per_window,
+           int log_scale, uint32_t* __restrict__ outA, uint32_t* __restrict__ outR) {
     constexpr int PW = 4 * FieldWords<F>::value;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* sR = lds;
@@ -283,41 +353,46 @@ k_msm_reduce_block(const uint32_t* __restrict__ inA, const uint32_t* __restrict_
     const uint32_t w = blockIdx.x / blocks_per_window, blk = blockIdx.x % blocks_per_window, t = threadIdx.x;
     const uint32_t idx = blk * M + t;
     XYZZ<F> myR, myA;
+    pt_set_inf(myA);
     if (idx < m_per_window) {
         pt_load(myR, inR + ((size_t)w * m_per_window + idx) * PW);
-        pt_load(myA, inA + ((size_t)w * m_per_window + idx) * PW);
-    } else { pt_set_inf(myR); pt_set_inf(myA); }
+        if (inA) pt_load(myA, inA + ((size_t)w * m_per_window + idx) * PW);
+    } else pt_set_inf(myR);
     pt_store(sR + t * PW, myR);
     __syncthreads();
-    // inclusive suffix scan of R (Hillis-Steele)
-    for (int d = 1; d < M; d <<= 1) {
+    const uint32_t act = min((uint32_t)M, m_per_window - blk * M);
+    int MA = 1;
+    while ((uint32_t)MA < act) MA <<= 1;
+    // inclusive suffix scan of X (Hillis-Steele): afterwards lane t holds sum_{u>=t} X_u
+#pragma unroll 1
+    for (int d = 1; d < MA; d <<= 1) {
         XYZZ<F> o;
-        if (t + d < M) pt_load(o, sR + (t + d) * PW); else pt_set_inf(o);
+        if (t + d < (uint32_t)MA) pt_load(o, sR + (t + d) * PW); else pt_set_inf(o);
         __syncthreads();
         myR = pt_add(myR, o);
         pt_store(sR + t * PW, myR);
         __syncthreads();
     }
-    // X_t = suffix_t for t >= 1 (else 0); tree-sum X and A together
+    // sum_t t*X_t = sum_{t>=1} suffix_t; tree-sum it in lanes [0,MA) while lanes [MA,2MA) (if present) tree-sum the A's
     XYZZ<F> myX = myR;
     if (t == 0) pt_set_inf(myX);
     pt_store(sR + t * PW, myX);
     pt_store(sA + t * PW, myA);
     __syncthreads();
-    for (int d = M / 2; d >= 1; d >>= 1) {
-        if (t < (uint32_t)d) {
-            XYZZ<F> o; pt_load(o, sR + (t + d) * PW); myX = pt_add(myX, o); pt_store(sR + t * PW, myX);
-            XYZZ<F> p; pt_load(p, sA + (t + d) * PW); myA = pt_add(myA, p); pt_store(sA + t * PW, myA);
-        }
+#pragma unroll 1
+    for (int d = MA / 2; d >= 1; d >>= 1) {
+        if (t < (uint32_t)d) { XYZZ<F> o; pt_load(o, sR + (t + d) * PW); myX = pt_add(myX, o); }
+        if (inA && t < (uint32_t)d) { XYZZ<F> p; pt_load(p, sA + (t + d) * PW); myA = pt_add(myA, p); }
+        __syncthreads();
+        if (t < (uint32_t)d) { pt_store(sR + t * PW, myX); if (inA) pt_store(sA + t * PW, myA); }
         __syncthreads();
     }
     if (t == 0) {
         for (int k = 0; k < log_scale; k++) myX = pt_dbl(myX);
-        XYZZ<F> a = pt_add(myA, myX);
+        XYZZ<F> a = inA ? pt_add(myA, myX) : myX;
         size_t o = (size_t)w * blocks_per_window + blk;
-        if (final) a = pt_add(a, myR);          // myR of lane 0 = suffix_0 = sum of all R
         pt_store(outA + o * PW, a);
-        if (!final) pt_store(outR + o * PW, myR);
+        pt_store(outR + o * PW, myR);          // lane 0's suffix sum = total
     }
 }
 

@@ -31,6 +31,10 @@ int msm_accumulate_bls12381(int group, const void* d_bases, const MsmPlan& pl, u
     if (group == 1) return msm_accumulate<Fp<Bls12381Fq>>(d_bases, pl, skip, job);
     return msm_accumulate<Fp2<Bls12381Fq>>(d_bases, pl, skip, job);
 }
+int msm_reduce_bls12381(int group, MsmJob* const* jobs, int njobs) {
+    if (group == 1) return msm_reduce<Fp<Bls12381Fq>>(jobs, njobs);
+    return msm_reduce<Fp2<Bls12381Fq>>(jobs, njobs);
+}
 int msm_fold_bls12381(int group, const MsmJob& job, uint8_t* out_jac) {
     if (group == 1) msm_fold<Fp<Bls12381Fq>>(job, out_jac); else msm_fold<Fp2<Bls12381Fq>>(job, out_jac);
     return ZKMI_OK;

@@ -30,6 +30,10 @@ int msm_accumulate_bn254(int group, const void* d_bases, const MsmPlan& pl, uint
     if (group == 1) return msm_accumulate<Fp<Bn254Fq>>(d_bases, pl, skip, job);
     return msm_accumulate<Fp2<Bn254Fq>>(d_bases, pl, skip, job);
 }
+int msm_reduce_bn254(int group, MsmJob* const* jobs, int njobs) {
+    if (group == 1) return msm_reduce<Fp<Bn254Fq>>(jobs, njobs);
+    return msm_reduce<Fp2<Bn254Fq>>(jobs, njobs);
+}
 int msm_fold_bn254(int group, const MsmJob& job, uint8_t* out_jac) {
     if (group == 1) msm_fold<Fp<Bn254Fq>>(job, out_jac); else msm_fold<Fp2<Bn254Fq>>(job, out_jac);
     return ZKMI_OK;

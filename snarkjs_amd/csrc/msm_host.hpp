@@ -14,6 +14,7 @@ static inline int ilog2_sz(size_t n) { int l = 0; while (((size_t)1 << (l + 1)) 
 // k_msm_accum against the latency-bound bucket reduction (depth O(c)); re-tuned on MI355X.
 static inline int msm_pick_c(size_t n) {
     int lg = ilog2_sz(n ? n : 1);
+    if (lg < 62 && n > (((size_t)3) << lg) / 2) lg++;      // round to the nearest power of two (nVars is usually just below one)
     static const int T[] = {2, 2, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9, 9, 10, 11, 11, 12, 13, 13, 14, 15, 15, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
     return T[lg > 31 ? 31 : lg];
 }
@@ -25,27 +26,36 @@ template <> struct HostOf<Fp2<Bn254Fq>> { typedef host::HField2<4> FT; static FT
 template <> struct HostOf<Fp<Bls12381Fq>> { typedef host::HField<6> FT; static FT make() { return host::HField<6>::from_cfg<Bls12381Fq>(); } };
 template <> struct HostOf<Fp2<Bls12381Fq>> { typedef host::HField2<6> FT; static FT make() { return FT{host::HField<6>::from_cfg<Bls12381Fq>()}; } };
 
-// Fold W window sums (device XYZZ, little-endian words) into one Jacobian point: sum_w 2^(c·w)·P_w.
-template <class F> void msm_fold_windows(const uint32_t* win, int W, int c, uint8_t* out_jac) {
+// XYZZ (device words) -> host Jacobian with Z = ZZ*ZZZ:  X' = X*ZZ*ZZZ^2, Y' = Y*ZZ^3*ZZZ^2
+template <class F> typename host::HCurve<typename HostOf<F>::FT>::P xyzz_to_jac(const host::HCurve<typename HostOf<F>::FT>& cv, const uint32_t* p) {
     typedef typename HostOf<F>::FT FT;
     typedef typename FT::E E;
-    host::HCurve<FT> cv{HostOf<F>::make()};
-    const FT& Fh = cv.F;
     constexpr int FW = FieldWords<F>::value;
+    const FT& Fh = cv.F;
+    E X, Y, ZZ, ZZZ;
+    memcpy(&X, p, 4 * FW); memcpy(&Y, p + FW, 4 * FW); memcpy(&ZZ, p + 2 * FW, 4 * FW); memcpy(&ZZZ, p + 3 * FW, 4 * FW);
+    if (ZZ.is_zero()) return cv.zero();
+    typename host::HCurve<FT>::P q;
+    E z2 = Fh.sqr(ZZZ), zzX = Fh.mul(ZZ, z2);
+    q.X = Fh.mul(X, zzX);
+    q.Y = Fh.mul(Y, Fh.mul(Fh.sqr(ZZ), zzX));
+    q.Z = Fh.mul(ZZ, ZZZ);
+    return q;
+}
+// Fold the per-window device results into one Jacobian point. Per window w the device leaves (see msm.cuh, bucket
+// reduction): win[(2w)*PW] = WR = sum_r r*Row_r, win[(2w+1)*PW] = WC = sum_c c*Col_c and tot[(2w)*PW] = T = sum_r Row_r;
+// S_w = 2^cbits * WR + WC + T, result = sum_w 2^(c*w) * S_w (the reference also recombines windows on the host, @213360).
+template <class F> void msm_fold_windows(const uint32_t* win, const uint32_t* tot, int W, int c, int cbits, uint8_t* out_jac) {
+    typedef typename HostOf<F>::FT FT;
+    host::HCurve<FT> cv{HostOf<F>::make()};
+    constexpr int FW = FieldWords<F>::value, PW = 4 * FW;
     typename host::HCurve<FT>::P acc = cv.zero();
     for (int w = W - 1; w >= 0; w--) {
         if (!cv.is_zero(acc)) for (int k = 0; k < c; k++) acc = cv.dbl(acc);
-        E X, Y, ZZ, ZZZ;
-        const uint32_t* p = win + (size_t)w * 4 * FW;
-        memcpy(&X, p, 4 * FW); memcpy(&Y, p + FW, 4 * FW); memcpy(&ZZ, p + 2 * FW, 4 * FW); memcpy(&ZZZ, p + 3 * FW, 4 * FW);
-        if (ZZ.is_zero()) continue;
-        // XYZZ -> Jacobian with Z = ZZ·ZZZ:  X' = X·ZZ·ZZZ^2, Y' = Y·ZZ^3·ZZZ^2
-        typename host::HCurve<FT>::P q;
-        E z2 = Fh.sqr(ZZZ), zzX = Fh.mul(ZZ, z2);
-        q.X = Fh.mul(X, zzX);
-        q.Y = Fh.mul(Y, Fh.mul(Fh.sqr(ZZ), zzX));
-        q.Z = Fh.mul(ZZ, ZZZ);
-        acc = cv.add(acc, q);
+        auto wr = xyzz_to_jac<F>(cv, win + (size_t)(2 * w) * PW);
+        for (int k = 0; k < cbits && !cv.is_zero(wr); k++) wr = cv.dbl(wr);
+        auto s = cv.add(cv.add(wr, xyzz_to_jac<F>(cv, win + (size_t)(2 * w + 1) * PW)), xyzz_to_jac<F>(cv, tot + (size_t)(2 * w) * PW));
+        acc = cv.add(acc, s);
     }
     if (cv.is_zero(acc)) { memset(out_jac, 0, 3 * 4 * FW); return; }
     memcpy(out_jac, &acc.X, 4 * FW); memcpy(out_jac + 4 * FW, &acc.Y, 4 * FW); memcpy(out_jac + 8 * FW, &acc.Z, 4 * FW);
@@ -67,6 +77,7 @@ template <class F> int to_affine_host(const uint8_t* jac, uint8_t* aff) {
 // The plan points into the library's named scratch buffers; it stays valid until the next msm_sort on the stream.
 struct MsmPlan {
     MsmShape sh;
+    int slot = 0;                     // which set of plan buffers (0/1): two plans stay alive when their MSMs are reduced in one batch
     size_t total = 0;                 // W * nb buckets
     uint32_t cap = 0;                 // lane-group granularity (msm.cuh: k_msm_assign)
     size_t lane_bound = 0, multi_bound = 0;
@@ -74,40 +85,37 @@ struct MsmPlan {
     uint32_t *lane_g = nullptr, *lane_sub = nullptr, *meta = nullptr, *giants = nullptr;
 };
 constexpr int MSM_TB = 128, MSM_LOG_TB = 7;      // tree block: 128 lanes x 384 B (BLS12-381 G2 XYZZ) = 48 KiB of LDS
-int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan);
+int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan, int plan_slot = 0);
 
 // One MSM in flight: per-window sums land in a pinned host slot; msm_fold turns them into the Jacobian result.
 struct MsmJob {
-    int W = 0, c = 0;
-    uint32_t* h_win = nullptr;
+    int W = 0, c = 0, cbits = 0, slot = 0;
+    uint32_t nb = 0;
+    uint32_t* h_win = nullptr;                      // pinned host: 2W weighted sums then 2W totals (XYZZ)
+    const uint32_t *buckets = nullptr, *counts = nullptr;   // device: this job's complete buckets (between accumulate and reduce)
+    hipEvent_t acc0 = nullptr, acc1 = nullptr;      // bracket the k_msm_accum launch (bench.py roofline: live kernel time)
 };
 constexpr int MSM_JOB_SLOTS = 8;
-constexpr size_t MSM_JOB_SLOT_BYTES = 128 * 1024;
+constexpr size_t MSM_JOB_SLOT_BYTES = 512 * 1024;
 int msm_job_slot(int slot, MsmJob& job);
 
-// ---- stage 4-5: bucket accumulation + reduction for one base table over an existing plan ------------------------------
+// ---- stage 4: bucket accumulation for one base table over an existing plan ---------------------------------------------
 // skip: the scalar with index i pairs with base (i - skip); indices < skip are ignored. This lets several MSMs share
 // one digit sort (Groth16: A, B1, B2 over the witness and C over witness[nPublic+1:], src/groth16_prove.js:85-97).
+// Leaves the complete buckets of this MSM in the bucket buffer of job.slot; msm_reduce finishes the job.
 template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job) {
     constexpr int FW = FieldWords<F>::value, PW = 4 * FW;
+    constexpr bool WIDE = FW > 12;
     Ctx& cx = ctx();
     const MsmShape& sh = pl.sh;
     const size_t total = pl.total;
     hipStream_t st = cx.stream;
-    uint32_t *buckets, *redA0, *redR0, *redA1, *redR1, *lane_partials, *block_partials;
-    ZK_TRY(ws_get("msm.buckets", total * PW * 4, (void**)&buckets));
+    const std::string sfx = "." + std::to_string(job.slot);
+    uint32_t *buckets, *lane_partials, *block_partials;
+    ZK_TRY(ws_get("msm.buckets" + sfx, total * PW * 4, (void**)&buckets));
     ZK_TRY(ws_get("msm.lane_partials", std::max<size_t>(pl.multi_bound, 1) * PW * 4, (void**)&lane_partials));
     const size_t tree_blocks = pl.multi_bound / MSM_TB + 1;
     ZK_TRY(ws_get("msm.block_partials", tree_blocks * PW * 4, (void**)&block_partials));
-    const uint32_t G = std::min<uint32_t>(8u, sh.nb);
-    const uint32_t m1 = sh.nb / G;
-    ZK_TRY(ws_get("msm.redA0", (size_t)sh.W * m1 * PW * 4, (void**)&redA0));
-    ZK_TRY(ws_get("msm.redR0", (size_t)sh.W * m1 * PW * 4, (void**)&redR0));
-    constexpr int M = (PW * 4 * 2 * 256 <= 128 * 1024) ? 256 : 128;    // LDS: 2 arrays of M points
-    const uint32_t m2 = (m1 + M - 1) / M;
-    ZK_TRY(ws_get("msm.redA1", (size_t)sh.W * std::max(m2, 1u) * PW * 4, (void**)&redA1));
-    ZK_TRY(ws_get("msm.redR1", (size_t)sh.W * std::max(m2, 1u) * PW * 4, (void**)&redR1));
-    if ((size_t)sh.W * PW * 4 > MSM_JOB_SLOT_BYTES) return fail(ZKMI_ERR_UNSUPPORTED, "msm: too many windows");
     static bool tree_attr = false;
     const size_t tree_lds = (size_t)MSM_TB * PW * 4;
     if (!tree_attr) {
@@ -115,39 +123,81 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
         ZK_HIP(hipFuncSetAttribute((const void*)k_msm_giant<F, MSM_TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
         tree_attr = true;
     }
-    hipLaunchKernelGGL((k_msm_accum<F>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_bases, sh, skip, pl.cap, pl.counts,
+    if (job.acc0) ZK_HIP(hipEventRecord(job.acc0, st));
+    hipLaunchKernelGGL((k_msm_accum<F, WIDE>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_bases, sh, skip, pl.cap, pl.counts,
                        pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials);
+    if (job.acc1) ZK_HIP(hipEventRecord(job.acc1, st));
     hipLaunchKernelGGL((k_msm_tree<F, MSM_TB>), dim3((unsigned)tree_blocks), dim3(MSM_TB), tree_lds, st, lane_partials, pl.lane_g, pl.counts, pl.cap, pl.meta, buckets,
                        block_partials);
     hipLaunchKernelGGL((k_msm_giant<F, MSM_TB>), dim3((unsigned)tree_blocks), dim3(MSM_TB), tree_lds, st, pl.giants, pl.meta, block_partials, buckets);
-    // reduce: level 1 (sequential groups of G), then block levels until one point per window
-    const uint32_t tg = sh.W * m1;
-    hipLaunchKernelGGL((k_msm_reduce_seq<F>), dim3((tg + 255) / 256), dim3(256), 0, st, buckets, pl.counts, sh.nb, G, m1, tg, redA0, redR0);
-    uint32_t m = m1;
-    int log_scale = ilog2_sz(G);
-    uint32_t *inA = redA0, *inR = redR0, *outA = redA1, *outR = redR1;
-    const size_t lds_bytes = (size_t)2 * M * PW * 4;
+    job.W = sh.W; job.c = sh.c; job.nb = sh.nb; job.buckets = buckets; job.counts = pl.counts;
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+}
+
+// ---- stage 5: bucket reduction of up to MSM_MAX_BATCH accumulated jobs of the same shape, in one set of launches ------
+template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
+    constexpr int FW = FieldWords<F>::value, PW = 4 * FW;
+    Ctx& cx = ctx();
+    hipStream_t st = cx.stream;
+    if (njobs < 1 || njobs > MSM_MAX_BATCH) return fail(ZKMI_ERR_INVALID, "msm_reduce: bad batch size");
+    const int W = jobs[0]->W, c = jobs[0]->c;
+    const uint32_t nb = jobs[0]->nb;
+    MsmReduceBatch rb;
+    rb.njobs = njobs;
+    for (int i = 0; i < njobs; i++) {
+        if (jobs[i]->W != W || jobs[i]->c != c) return fail(ZKMI_ERR_INVALID, "msm_reduce: jobs of different shape");
+        rb.buckets[i] = jobs[i]->buckets; rb.counts[i] = jobs[i]->counts;
+    }
+    const uint32_t rbits = (uint32_t)(c - 1) / 2, cbits = (uint32_t)(c - 1) - rbits, C = 1u << cbits;
+    const size_t VW = (size_t)njobs * W * 2;                           // arrays of C points: (job, window, row|col)
+    constexpr int TBR = (PW * 4 * 256 <= 64 * 1024) ? 256 : 128;       // k_msm_rowcol: one wave per output
+    constexpr int M = (PW * 4 * 2 * 256 <= 128 * 1024) ? 256 : 128;    // k_msm_wsum: 2 LDS arrays of M points
+    const uint32_t m2 = (C + M - 1) / M;
+    uint32_t *rc, *a0, *r0, *a1, *r1;
+    ZK_TRY(ws_get("msm.rowcol", VW * C * PW * 4, (void**)&rc));
+    ZK_TRY(ws_get("msm.redA0", VW * m2 * PW * 4, (void**)&a0));
+    ZK_TRY(ws_get("msm.redR0", VW * m2 * PW * 4, (void**)&r0));
+    ZK_TRY(ws_get("msm.redA1", VW * PW * 4, (void**)&a1));
+    ZK_TRY(ws_get("msm.redR1", VW * PW * 4, (void**)&r1));
+    if ((size_t)W * 4 * PW * 4 > MSM_JOB_SLOT_BYTES) return fail(ZKMI_ERR_UNSUPPORTED, "msm: too many windows");
     static bool attr_set = false;
+    const size_t lds_rc = (size_t)TBR * PW * 4, lds_ws = (size_t)2 * M * PW * 4;
     if (!attr_set) {
-        ZK_HIP(hipFuncSetAttribute((const void*)k_msm_reduce_block<F, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol<F, TBR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rc));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_msm_wsum<F, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         attr_set = true;
     }
+    const size_t n_out = VW * C;
+    hipLaunchKernelGGL((k_msm_rowcol<F, TBR>), dim3((unsigned)((n_out + TBR / 64 - 1) / (TBR / 64))), dim3(TBR), lds_rc, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
+    uint32_t m = C;
+    int log_scale = 0;
+    const uint32_t *inA = nullptr, *inR = rc;
+    uint32_t *outA = a0, *outR = r0;
     for (;;) {
         const uint32_t blocks = (m + M - 1) / M;
-        const int fin = blocks == 1;
-        hipLaunchKernelGGL((k_msm_reduce_block<F, M>), dim3(sh.W * blocks), dim3(M), lds_bytes, st, inA, inR, m, blocks, log_scale, fin, outA, outR);
-        std::swap(inA, outA); std::swap(inR, outR);
-        if (fin) break;
+        hipLaunchKernelGGL((k_msm_wsum<F, M>), dim3((unsigned)(VW * blocks)), dim3(M), lds_ws, st, inA, inR, m, blocks, log_scale, outA, outR);
+        inA = outA; inR = outR;
+        if (blocks == 1) break;
+        outA = (outA == a0) ? a1 : a0; outR = (outR == r0) ? r1 : r0;
         m = blocks;
         log_scale += ilog2_sz(M);
     }
-    job.W = sh.W; job.c = sh.c;
-    ZK_HIP(hipMemcpyAsync(job.h_win, inA, (size_t)sh.W * PW * 4, hipMemcpyDeviceToHost, st));
+    for (int i = 0; i < njobs; i++) {
+        MsmJob& job = *jobs[i];
+        job.cbits = (int)cbits;
+        const size_t per = (size_t)2 * W * PW;                              // words per job in inA / inR
+        ZK_HIP(hipMemcpyAsync(job.h_win, inA + (size_t)i * per, per * 4, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipMemcpyAsync(job.h_win + per, inR + (size_t)i * per, per * 4, hipMemcpyDeviceToHost, st));
+    }
     ZK_HIP(hipGetLastError());
     return ZKMI_OK;
 }
 // after the stream has been synchronised
-template <class F> void msm_fold(const MsmJob& job, uint8_t* out_jac) { msm_fold_windows<F>(job.h_win, job.W, job.c, out_jac); }
+template <class F> void msm_fold(const MsmJob& job, uint8_t* out_jac) {
+    constexpr int PW = 4 * FieldWords<F>::value;
+    msm_fold_windows<F>(job.h_win, job.h_win + (size_t)2 * job.W * PW, job.W, job.c, job.cbits, out_jac);
+}
 
 // Full device MSM: bases (affine, device), scalars (plain integers, device) -> Jacobian point on the host.
 template <class F> int msm_run(const void* d_bases, const void* d_scalars, size_t n, size_t sb, uint8_t* out_jac) {
@@ -161,6 +211,8 @@ template <class F> int msm_run(const void* d_bases, const void* d_scalars, size_
     ZK_HIP(hipEventRecord(cx.ev0, st));
     ZK_TRY(msm_sort(d_scalars, n, sb, pl));
     ZK_TRY(msm_accumulate<F>(d_bases, pl, 0, job));
+    MsmJob* jp = &job;
+    ZK_TRY(msm_reduce<F>(&jp, 1));
     ZK_HIP(hipEventRecord(cx.ev1, st));
     ZK_HIP(hipStreamSynchronize(st));
     float ms = 0;
@@ -171,6 +223,8 @@ template <class F> int msm_run(const void* d_bases, const void* d_scalars, size_
 
 // non-template entry points (msm_bn254.hip / msm_bls12381.hip) for callers that must not instantiate the kernels again
 int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job);
+int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs);
+
 int msm_fold_dispatch(int curve, int group, const MsmJob& job, uint8_t* out_jac);
 
 template <class F, class FrC> int gen_bases_run(const uint8_t* gen_affine_host, size_t n, uint64_t f, uint64_t g, void* d_out) {

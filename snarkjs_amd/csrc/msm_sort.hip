@@ -14,8 +14,10 @@ template <int NW> static int msm_launch_digits(const uint8_t* d_scalars, const M
     return ZKMI_OK;
 }
 
-int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl) {
+int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_slot) {
     Ctx& cx = ctx();
+    pl.slot = plan_slot & 1;
+    const std::string sfx = pl.slot ? ".p1" : ".p0";
     if (n == 0 || n >= (1ull << 31)) return fail(ZKMI_ERR_UNSUPPORTED, "msm: n must be in [1, 2^31)");
     if (sb == 0 || sb > 64) return fail(ZKMI_ERR_UNSUPPORTED, "msm: scalar size must be 1..64 bytes");
     MsmShape& sh = pl.sh;
@@ -27,21 +29,25 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl) {
     pl.total = total;
     hipStream_t st = cx.stream;
     uint32_t *counts, *hist;
-    ZK_TRY(ws_get("msm.counts", 3 * total * 4, (void**)&counts));        // counts | starts | cursor
+    ZK_TRY(ws_get("msm.counts" + sfx, 3 * total * 4, (void**)&counts));        // counts | starts | cursor
     pl.counts = counts; pl.starts = counts + total;
     uint32_t* cursor = pl.starts + total;
-    ZK_TRY(ws_get("msm.sorted", (size_t)sh.W * n * 4, (void**)&pl.sorted));
-    // lane-group schedule (k_msm_classify/_class_scan/_assign): cap = pow2ceil(2 * average bucket size) in [16, 256]
+    ZK_TRY(ws_get("msm.sorted" + sfx, (size_t)sh.W * n * 4, (void**)&pl.sorted));
+    // lane-group schedule (k_msm_classify/_class_scan/_assign)
+    // cap: points per lane. Large MSMs are ALU-bound: one lane per typical bucket (cap = pow2ceil(2 * average size)) keeps
+    // the combine tree idle; small MSMs are latency-bound: shrink cap until ~250k lanes exist.
     const size_t avg = (n + sh.nb - 1) / sh.nb;
-    uint32_t cap = 16;
-    while (cap < 2 * avg && cap < MSM_MAX_CAP) cap <<= 1;
+    uint32_t cap_big = 16, cap_fill = 8;
+    while (cap_big < 2 * avg && cap_big < MSM_MAX_CAP) cap_big <<= 1;
+    while ((size_t)2 * cap_fill <= (size_t)sh.W * n / 250000 && cap_fill < MSM_MAX_CAP) cap_fill <<= 1;
+    const uint32_t cap = std::min(cap_big, cap_fill);
     pl.cap = cap;
     pl.multi_bound = (size_t)sh.W * n / cap + 1;                          // lanes of multi-lane groups: sum 2^floor(log2(cnt/cap))
     pl.lane_bound = total + pl.multi_bound;
-    ZK_TRY(ws_get("msm.lanes", 2 * pl.lane_bound * 4, (void**)&pl.lane_g));
+    ZK_TRY(ws_get("msm.lanes" + sfx, 2 * pl.lane_bound * 4, (void**)&pl.lane_g));
     pl.lane_sub = pl.lane_g + pl.lane_bound;
     const size_t giant_bound = pl.multi_bound / MSM_TB + 1;
-    ZK_TRY(ws_get("msm.hist", (3 * MSM_NKEYS + 8 + 3 * giant_bound) * 4, (void**)&hist));     // hist | off | cursor | meta | giants
+    ZK_TRY(ws_get("msm.hist" + sfx, (3 * MSM_NKEYS + 8 + 3 * giant_bound) * 4, (void**)&hist));     // hist | off | cursor | meta | giants
     uint32_t *koff = hist + MSM_NKEYS, *kcur = koff + MSM_NKEYS;
     pl.meta = kcur + MSM_NKEYS; pl.giants = pl.meta + 8;
     ZK_HIP(hipMemsetAsync(counts, 0, 3 * total * 4, st));
@@ -62,7 +68,10 @@ int msm_job_slot(int slot, MsmJob& job) {
     Ctx& cx = ctx();
     if (slot < 0 || slot >= MSM_JOB_SLOTS) return fail(ZKMI_ERR_INVALID, "msm: bad job slot");
     if (!cx.pinned) ZK_HIP(hipHostMalloc((void**)&cx.pinned, MSM_JOB_SLOTS * MSM_JOB_SLOT_BYTES, hipHostMallocDefault));
+    job.slot = slot;
     job.h_win = (uint32_t*)(cx.pinned + (size_t)slot * MSM_JOB_SLOT_BYTES);
+    if (!cx.job_ev[2 * slot]) { ZK_HIP(hipEventCreate(&cx.job_ev[2 * slot])); ZK_HIP(hipEventCreate(&cx.job_ev[2 * slot + 1])); }
+    job.acc0 = cx.job_ev[2 * slot]; job.acc1 = cx.job_ev[2 * slot + 1];
     return ZKMI_OK;
 }
 

@@ -61,6 +61,8 @@ int msm_bn254(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_bls12381(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_accumulate_bn254(int group, const void*, const MsmPlan&, uint32_t, MsmJob&);
 int msm_accumulate_bls12381(int group, const void*, const MsmPlan&, uint32_t, MsmJob&);
+int msm_reduce_bn254(int group, MsmJob* const*, int);
+int msm_reduce_bls12381(int group, MsmJob* const*, int);
 int msm_fold_bn254(int group, const MsmJob&, uint8_t*);
 int msm_fold_bls12381(int group, const MsmJob&, uint8_t*);
 int gen_bases_bn254(int group, size_t, uint64_t, uint64_t, void*);
@@ -80,6 +82,10 @@ int msm_dev_dispatch(int curve, int group, const void* d_bases, const void* d_sc
 int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job) {
     ZK_TRY(check_cg(curve, group));
     return curve == ZKMI_CURVE_BN128 ? msm_accumulate_bn254(group, d_bases, pl, skip, job) : msm_accumulate_bls12381(group, d_bases, pl, skip, job);
+}
+int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs) {
+    ZK_TRY(check_cg(curve, group));
+    return curve == ZKMI_CURVE_BN128 ? msm_reduce_bn254(group, jobs, njobs) : msm_reduce_bls12381(group, jobs, njobs);
 }
 int msm_fold_dispatch(int curve, int group, const MsmJob& job, uint8_t* out_jac) {
     ZK_TRY(check_cg(curve, group));
@@ -139,6 +145,13 @@ double zkmi_last_kernel_ms(void) {
     if (hipEventSynchronize(g_ctx.ev1) != hipSuccess) return 0.0;
     float ms = 0;
     if (hipEventElapsedTime(&ms, g_ctx.ev0, g_ctx.ev1) != hipSuccess) return g_ctx.last_ms;
+    return ms;
+}
+double zkmi_msm_accum_ms(int slot) {
+    if (!g_ctx.ready || slot < 0 || slot >= 8 || !g_ctx.job_ev[2 * slot]) return -1.0;
+    float ms = 0;
+    if (hipEventSynchronize(g_ctx.job_ev[2 * slot + 1]) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, g_ctx.job_ev[2 * slot], g_ctx.job_ev[2 * slot + 1]) != hipSuccess) return -1.0;
     return ms;
 }
 int zkmi_dev_alloc(size_t bytes, void** d_ptr) {

@@ -51,6 +51,7 @@ struct Ctx {
     std::map<std::string, DevBuf> ntt_prescale;             // cached row-factor tables of fused NTT pre-scales
     std::map<void*, size_t> user_allocs;
     std::map<uint64_t, void*> groth16;                      // zkmi_groth16 resident keys (groth16.hip)
+    hipEvent_t job_ev[16] = {};                             // per MSM job slot: events around k_msm_accum
     uint8_t* pinned = nullptr;                              // pinned host slots for MSM window sums
 };
 Ctx& ctx();

@@ -76,9 +76,9 @@ class ProvingKey:
         return pi_a, pi_b, pi_c
 
     def stage_ms(self):
-        out = (C.c_double * 10)()
-        zkmi.check(zkmi.lib().zkmi_groth16_stage_ms(out, 10))
-        names = ["buildABC", "ntt_x6", "joinABC", "sort_witness", "msm_A", "msm_B1", "msm_B2", "msm_C", "sort_H", "msm_H"]
+        out = (C.c_double * 11)()
+        zkmi.check(zkmi.lib().zkmi_groth16_stage_ms(out, 11))
+        names = ["buildABC", "ntt_x6", "joinABC", "sort_witness", "accum_A", "accum_B1", "accum_B2", "accum_C", "sort_H", "accum_H", "reduce_all"]
         return dict(zip(names, list(out)))
 
     def release(self):
