@@ -298,7 +298,7 @@ k_msm_giant(const uint32_t* __restrict__ giants, const uint32_t* __restrict__ me
 // (_reduceTable, min.js:1@74634); a GPU wants the shallowest dependency chain, because one XYZZ addition is ~9 us of
 // latency for a lone wave. Write b0 = r*C + c with C = 2^cbits columns and R = 2^rbits rows (rbits + cbits = c-1):
 //     S = C * sum_r r*Row_r + sum_c c*Col_c + sum_r Row_r,     Row_r = sum_c B[r*C+c],  Col_c = sum_r B[r*C+c].
-// k_msm_rowcol forms all Row/Col sums (one wave per sum: <= C/64 sequential additions, then a 6-level butterfly);
+// k_msm_rowcol forms all Row/Col sums (MSM_RC_L lanes per sum: sequential partial sums, then a log2(L)-level butterfly);
 // k_msm_wsum turns each length-C array into (sum_t t*X_t, sum_t X_t) with a suffix scan + tree in LDS. The host applies
 // the factor C (cbits doublings) when it folds the windows.  Several MSMs of the same shape are reduced in one launch.
 constexpr int MSM_MAX_BATCH = 4;
@@ -307,13 +307,14 @@ struct MsmReduceBatch {
     const uint32_t* counts[MSM_MAX_BATCH];
     int njobs;
 };
+constexpr int MSM_RC_L = 8;             // lanes per Row/Col sum: (cnt/L) sequential additions, then log2(L) butterfly steps
 template <class F, int TBR> __global__ void __launch_bounds__(TBR)
 k_msm_rowcol(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_t cbits, uint32_t* __restrict__ out) {
-    constexpr int PW = 4 * FieldWords<F>::value;
+    constexpr int PW = 4 * FieldWords<F>::value, L = MSM_RC_L;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t C = 1u << cbits, R = 1u << rbits;
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const size_t gw = (size_t)blockIdx.x * (TBR / 64) + wv;                 // output index: ((job*W + w)*2 + kind)*C + i
+    const uint32_t sub = threadIdx.x & (L - 1);
+    const size_t gw = (size_t)blockIdx.x * (TBR / L) + threadIdx.x / L;     // output index: ((job*W + w)*2 + kind)*C + i
     const size_t n_out = (size_t)rb.njobs * W * 2 * C;
     XYZZ<F> acc;
     pt_set_inf(acc);
@@ -324,7 +325,7 @@ k_msm_rowcol(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_
         const uint32_t* bk = rb.buckets[job];
         const uint32_t* cn = rb.counts[job];
         const uint32_t cnt = kind ? R : ((i < R) ? C : 0u);
-        for (uint32_t e = lane; e < cnt; e += 64) {
+        for (uint32_t e = sub; e < cnt; e += L) {
             const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
             if (cn[g]) { XYZZ<F> p; pt_load(p, bk + g * PW); acc = pt_add(acc, p); }      // empty buckets were never written
         }
@@ -333,13 +334,13 @@ k_msm_rowcol(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_
     pt_store(my, acc);
     __syncthreads();
 #pragma unroll 1
-    for (int d = 32; d >= 1; d >>= 1) {
-        if (lane < (uint32_t)d) { XYZZ<F> o; pt_load(o, my + (size_t)d * PW); acc = pt_add(acc, o); }
+    for (int d = L / 2; d >= 1; d >>= 1) {
+        if (sub < (uint32_t)d) { XYZZ<F> o; pt_load(o, my + (size_t)d * PW); acc = pt_add(acc, o); }
         __syncthreads();
-        if (lane < (uint32_t)d) pt_store(my, acc);
+        if (sub < (uint32_t)d) pt_store(my, acc);
         __syncthreads();
     }
-    if (lane == 0 && gw < n_out) pt_store(out + gw * PW, acc);
+    if (sub == 0 && gw < n_out) pt_store(out + gw * PW, acc);
 }
 // One block of M lanes per M consecutive items of an array of m_per_array points; invariant across levels:
 //   weighted = sum_t A_t + scale * sum_t t*X_t,  total = sum_t X_t   (level 0: A absent, scale 1).

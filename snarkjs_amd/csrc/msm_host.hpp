@@ -151,7 +151,7 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
     }
     const uint32_t rbits = (uint32_t)(c - 1) / 2, cbits = (uint32_t)(c - 1) - rbits, C = 1u << cbits;
     const size_t VW = (size_t)njobs * W * 2;                           // arrays of C points: (job, window, row|col)
-    constexpr int TBR = (PW * 4 * 256 <= 64 * 1024) ? 256 : 128;       // k_msm_rowcol: one wave per output
+    constexpr int TBR = (PW * 4 * 256 <= 64 * 1024) ? 256 : 128;       // k_msm_rowcol block (LDS: one point per lane)
     constexpr int M = (PW * 4 * 2 * 256 <= 128 * 1024) ? 256 : 128;    // k_msm_wsum: 2 LDS arrays of M points
     const uint32_t m2 = (C + M - 1) / M;
     uint32_t *rc, *a0, *r0, *a1, *r1;
@@ -169,7 +169,7 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
         attr_set = true;
     }
     const size_t n_out = VW * C;
-    hipLaunchKernelGGL((k_msm_rowcol<F, TBR>), dim3((unsigned)((n_out + TBR / 64 - 1) / (TBR / 64))), dim3(TBR), lds_rc, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
+    hipLaunchKernelGGL((k_msm_rowcol<F, TBR>), dim3((unsigned)((n_out + TBR / MSM_RC_L - 1) / (TBR / MSM_RC_L))), dim3(TBR), lds_rc, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
     uint32_t m = C;
     int log_scale = 0;
     const uint32_t *inA = nullptr, *inR = rc;
