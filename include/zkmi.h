@@ -148,6 +148,9 @@ int zkmi_groth16_stage_ms(double* out, int n);
 int zkmi_gen_geometric_bases_dev(int curve, int group, size_t n, uint64_t f, uint64_t g, void* d_out);
 /* G.toAffine on host for one Jacobian point (tiny; used by bindings to normalise results). */
 int zkmi_to_affine(int curve, int group, const uint8_t* jacobian, uint8_t* affine);
+/* G.add on host for two Jacobian points (O(1)): folds the per-GPU partial results of a sharded MSM
+ * (reference: host-side `G.add` over chunk results, min.js:1@214651). Needs no device. */
+int zkmi_point_add(int curve, int group, const uint8_t* a_jacobian, const uint8_t* b_jacobian, uint8_t* out_jacobian);
 /* Wall-clock-free device timing of the last call of each kind, in milliseconds (HIP events on the library stream). */
 double zkmi_last_kernel_ms(void);
 

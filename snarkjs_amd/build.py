@@ -52,7 +52,30 @@ def build(verbose=False, force=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    build_addon(verbose)
     return LIB
+
+
+def build_addon(verbose=False):
+    """The N-API addon (plain C): snarkjs_amd/napi/zkmi_napi.node, linked against ../libzkmi.so. Skipped (with a note) when
+    the Node headers are not installed."""
+    src = os.path.join(HERE, "napi", "zkmi_napi.c")
+    out = os.path.join(HERE, "napi", "zkmi_napi.node")
+    inc = next((d for d in ("/usr/include/node", "/usr/local/include/node") if os.path.exists(os.path.join(d, "node_api.h"))), None)
+    if inc is None:
+        if verbose:
+            print("node_api.h not found: N-API addon not built")
+        return None
+    if not _stale(out, [src, LIB, os.path.join(os.path.dirname(HERE), "include", "zkmi.h")]):
+        return out
+    cmd = ["gcc", "-O2", "-shared", "-fPIC", "-Wall", "-DNODE_GYP_MODULE_NAME=zkmi_napi", "-I" + inc, src, "-o", out,
+           "-L" + HERE, "-lzkmi", "-Wl,-rpath,$ORIGIN/.."]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"addon build failed:\n{r.stderr[-4000:]}")
+    return out
 
 
 if __name__ == "__main__":

@@ -61,6 +61,19 @@ template <class F> void msm_fold_windows(const uint32_t* win, const uint32_t* to
     memcpy(out_jac, &acc.X, 4 * FW); memcpy(out_jac + 4 * FW, &acc.Y, 4 * FW); memcpy(out_jac + 8 * FW, &acc.Z, 4 * FW);
 }
 
+// out = a + b for two Jacobian points in the C-ABI format (host, O(1)): combines per-GPU partial MSM results.
+template <class F> int point_add_host(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    typedef typename HostOf<F>::FT FT;
+    host::HCurve<FT> cv{HostOf<F>::make()};
+    constexpr int FW = FieldWords<F>::value;
+    typename host::HCurve<FT>::P p, q;
+    memcpy(&p.X, a, 4 * FW); memcpy(&p.Y, a + 4 * FW, 4 * FW); memcpy(&p.Z, a + 8 * FW, 4 * FW);
+    memcpy(&q.X, b, 4 * FW); memcpy(&q.Y, b + 4 * FW, 4 * FW); memcpy(&q.Z, b + 8 * FW, 4 * FW);
+    auto r = cv.add(p, q);
+    if (cv.is_zero(r)) { memset(out, 0, 12 * FW); return ZKMI_OK; }
+    memcpy(out, &r.X, 4 * FW); memcpy(out + 4 * FW, &r.Y, 4 * FW); memcpy(out + 8 * FW, &r.Z, 4 * FW);
+    return ZKMI_OK;
+}
 template <class F> int to_affine_host(const uint8_t* jac, uint8_t* aff) {
     typedef typename HostOf<F>::FT FT;
     host::HCurve<FT> cv{HostOf<F>::make()};

@@ -68,6 +68,8 @@ int msm_fold_bls12381(int group, const MsmJob&, uint8_t*);
 int gen_bases_bn254(int group, size_t, uint64_t, uint64_t, void*);
 int gen_bases_bls12381(int group, size_t, uint64_t, uint64_t, void*);
 int to_affine_bn254(int group, const uint8_t*, uint8_t*);
+int point_add_bn254(int group, const uint8_t*, const uint8_t*, uint8_t*);
+int point_add_bls12381(int group, const uint8_t*, const uint8_t*, uint8_t*);
 int to_affine_bls12381(int group, const uint8_t*, uint8_t*);
 
 static int check_cg(int curve, int group) {
@@ -284,5 +286,10 @@ int zkmi_gen_geometric_bases_dev(int curve, int group, size_t n, uint64_t f, uin
     return gen_bases_dispatch(curve, group, n, f, g, d_out);
 }
 int zkmi_to_affine(int curve, int group, const uint8_t* jac, uint8_t* aff) { return to_affine_dispatch(curve, group, jac, aff); }
+int zkmi_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    ZK_TRY(check_cg(curve, group));
+    if (!a || !b || !out) return fail(ZKMI_ERR_INVALID, "null argument");
+    return curve == ZKMI_CURVE_BN128 ? point_add_bn254(group, a, b, out) : point_add_bls12381(group, a, b, out);
+}
 
 }  // extern "C"

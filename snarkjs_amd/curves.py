@@ -11,7 +11,8 @@ Same names, argument meaning and error behaviour as the reference objects return
     curve.Fr.batchToMontgomery / batchFromMontgomery / batchInverse
 
 Buffers are bytes-like (the reference's Uint8Array) or a list of bytes-like pages (the reference's BigBuffer,
-min.js:1@183423); results come back as numpy uint8 arrays (or a list of them when the input was paged).
+min.js:1@183423); results come back as numpy uint8 arrays, or a list of them where the reference would return a
+BigBuffer (see _alloc_like / _alloc_like_sliced).
 All work happens in the HIP library behind include/zkmi.h; nothing here computes.
 """
 import numpy as np
@@ -43,6 +44,14 @@ def _alloc_like(buf, nbytes):
     return np.empty(nbytes, np.uint8)
 
 
+def _alloc_like_sliced(buf, nbytes):
+    """Container rule of Fr.fft / Fr.ifft / Fr.batchInverse: the reference first takes buff.slice(0, byteLength), which for a
+    BigBuffer of at most one page is a flat Uint8Array (min.js:1@183423), and returns that type."""
+    if _is_paged(buf) and nbytes > PAGE_SIZE:
+        return _alloc_like(buf, nbytes)
+    return np.empty(nbytes, np.uint8)
+
+
 def _out_pages(out):
     import ctypes as C
     bufs = out if isinstance(out, list) else [out]
@@ -64,7 +73,7 @@ class _Fr:
         if nbytes % 32 or n == 0 or (n & (n - 1)):
             raise ValueError("fft must be multiple of 2")   # reference message, min.js:1@215859
         pg = zkmi.pages_of(buf)
-        out = _alloc_like(buf, nbytes)
+        out = _alloc_like_sliced(buf, nbytes)
         op, ol, no, _keep = _out_pages(out)
         zkmi.check(zkmi.lib().zkmi_ntt(self._c, pg.pages, op, ol, no, n.bit_length() - 1, int(inverse), None, None))
         return out
@@ -88,8 +97,10 @@ class _Fr:
 
     def _batch(self, op_id, buf):
         nbytes = _byte_length(buf)
+        if nbytes % 32:
+            raise ValueError("Invalid buffer size")      # reference message (min.js:1@188677)
         pg = zkmi.pages_of(buf)
-        out = _alloc_like(buf, nbytes)
+        out = (_alloc_like_sliced if op_id == zkmi.BATCH_INVERSE else _alloc_like)(buf, nbytes)
         op, ol, no, _keep = _out_pages(out)
         zkmi.check(zkmi.lib().zkmi_fr_batch(self._c, op_id, pg.pages, op, ol, no, nbytes // 32))
         return out

@@ -1,0 +1,130 @@
+// snarkjs_amd/js/register.js — makes unmodified snarkjs run its prover hot path on the MI355X.
+//
+// snarkjs reaches all bulk arithmetic through ONE object per curve, returned by getCurveFromName / getCurveFromQ /
+// getCurveFromR (reference src/curves.js:9-53) and cached in globalThis.curve_bn128 / curve_bls12381 (bundle
+// build/snarkjs.min.js:1@240638).  register(curve) replaces the bulk entry points of that object
+//     curve.G1.multiExpAffine, curve.G2.multiExpAffine                       (min.js:1@214996)
+//     curve.Fr.fft, curve.Fr.ifft                                             (min.js:1@215859)
+//     curve.Fr.batchApplyKey / batchToMontgomery / batchFromMontgomery / batchInverse (min.js:1@211529, @188677)
+// with calls into the HIP library through the N-API addon (../napi/zkmi_napi.node -> libzkmi.so, include/zkmi.h),
+// keeping the reference's argument meaning, container rules (Uint8Array in -> Uint8Array out, BigBuffer in ->
+// BigBuffer out, inputs never mutated) and error messages.  Everything else on the curve object (element-level
+// Fr/G1/G2 ops, pairing, curve.tm, ceremony-only group FFTs) is left untouched.
+//
+// There is no silent fallback: without a HIP device register() throws.
+"use strict";
+const path = require("path");
+
+const CURVE_ID = { bn128: 0, bls12381: 1 };
+const OP = { TO_MONTGOMERY: 0, FROM_MONTGOMERY: 1, INVERSE: 2 };
+
+function loadAddon() {
+    return require(path.join(__dirname, "..", "napi", "zkmi_napi.node"));
+}
+function isBig(b) { return b && !(b instanceof Uint8Array) && Array.isArray(b.buffers) && typeof b.byteLength === "number"; }
+function isBuf(b) { return (b instanceof Uint8Array) || isBig(b); }
+// Uint8Array -> itself; BigBuffer -> its page list (ffjavascript BigBuffer.buffers)
+function pagesOf(b) { return (b instanceof Uint8Array) ? b : b.buffers; }
+// Result containers follow the reference function by function (downstream code tests `instanceof BigBuffer`, e.g.
+// src/groth16_prove.js:361): batchToMontgomery / batchFromMontgomery / batchApplyKey return the input's own type
+// (min.js:1 helper before @185893, @211529); fft / ifft / batchInverse first take `buff.slice(0, byteLength)`, which for a
+// BigBuffer of at most one page is a plain Uint8Array (BigBuffer.slice, min.js:1@183423), and return THAT type.
+const PAGE_SIZE = 1 << 30;
+function allocLike(b, byteLength) { return new b.constructor(byteLength); }
+function allocLikeSliced(b, byteLength) {
+    return (b instanceof Uint8Array || b.byteLength <= PAGE_SIZE) ? new Uint8Array(byteLength) : new b.constructor(byteLength);
+}
+function log2(n) { let l = 0; while ((1 << (l + 1)) <= n && l < 40) l++; return l; }
+
+function register(curve, options) {
+    options = options || {};
+    const addon = options.addon || loadAddon();
+    if (curve.__zkmi) return curve;
+    const cid = CURVE_ID[curve.name];
+    if (cid === undefined) throw new Error(`Curve not supported: ${curve.name}`);
+    addon.init(options.device === undefined ? 0 : options.device);      // throws when no HIP device is visible
+    const Fr = curve.Fr;
+    const orig = {};
+
+    for (const [gname, group] of [["G1", 1], ["G2", 2]]) {
+        const G = curve[gname];
+        orig[gname] = { multiExpAffine: G.multiExpAffine };
+        G.multiExpAffine = async function (buffBases, buffScalars, logger, logText) {
+            if (!isBuf(buffBases)) {
+                if (logger) logger.error(`${logText} _multiExpChunk buffBases is not Uint8Array`);
+                throw new Error(`${logText} _multiExpChunk buffBases is not Uint8Array`);
+            }
+            if (!isBuf(buffScalars)) {
+                if (logger) logger.error(`${logText} _multiExpChunk buffScalars is not Uint8Array`);
+                throw new Error(`${logText} _multiExpChunk buffScalars is not Uint8Array`);
+            }
+            const sGIn = G.F.n8 * 2;
+            const nPoints = Math.floor(buffBases.byteLength / sGIn);
+            if (nPoints == 0) return G.zero;
+            const sScalar = Math.floor(buffScalars.byteLength / nPoints);
+            if (sScalar * nPoints != buffScalars.byteLength) throw new Error("Scalar size does not match");
+            if (logger) logger.debug(`Multiexp start: ${logText}: 0/${nPoints}`);
+            const res = addon.msm(cid, group, pagesOf(buffBases), pagesOf(buffScalars), nPoints, sScalar, 0);
+            if (logger) logger.debug(`Multiexp end: ${logText}: 0/${nPoints}`);
+            return res;                                                  // Jacobian, Montgomery, 3*F.n8 bytes
+        };
+    }
+
+    orig.Fr = { fft: Fr.fft, ifft: Fr.ifft, batchApplyKey: Fr.batchApplyKey, batchToMontgomery: Fr.batchToMontgomery,
+                batchFromMontgomery: Fr.batchFromMontgomery, batchInverse: Fr.batchInverse };
+
+    async function ntt(buff, inverse, origFn, args) {
+        if (Array.isArray(buff)) return origFn.apply(Fr, args);          // array-of-elements form: not on the prove path
+        if (!isBuf(buff)) throw new Error("fft: buffer is not Uint8Array or BigBuffer");
+        const n = buff.byteLength / Fr.n8;
+        const bits = log2(n);
+        if ((1 << bits) != n) throw new Error("fft must be multiple of 2");
+        const out = allocLikeSliced(buff, buff.byteLength);
+        addon.ntt(cid, pagesOf(buff), pagesOf(out), bits, inverse ? 1 : 0, null, null);
+        return out;
+    }
+    Fr.fft = function (buff, inType, outType, logger, loggerTxt) { return ntt(buff, false, orig.Fr.fft, arguments); };
+    Fr.ifft = function (buff, inType, outType, logger, loggerTxt) { return ntt(buff, true, orig.Fr.ifft, arguments); };
+
+    Fr.batchApplyKey = async function (buff, first, inc, inType, outType) {
+        if (!isBuf(buff)) return orig.Fr.batchApplyKey.apply(Fr, arguments);
+        const out = allocLike(buff, buff.byteLength);
+        addon.applyKey(cid, pagesOf(buff), pagesOf(out), Math.floor(buff.byteLength / Fr.n8), Fr.e(first), Fr.e(inc));
+        return out;
+    };
+    function batch(op, name) {
+        return async function (buff) {
+            if (!isBuf(buff)) return orig.Fr[name].apply(Fr, arguments);
+            if (buff.byteLength % Fr.n8) throw new Error("Invalid buffer size");
+            const out = (op == OP.INVERSE ? allocLikeSliced : allocLike)(buff, buff.byteLength);
+            addon.frBatch(cid, op, pagesOf(buff), pagesOf(out), Math.floor(buff.byteLength / Fr.n8));
+            return out;
+        };
+    }
+    Fr.batchToMontgomery = batch(OP.TO_MONTGOMERY, "batchToMontgomery");
+    Fr.batchFromMontgomery = batch(OP.FROM_MONTGOMERY, "batchFromMontgomery");
+    Fr.batchInverse = batch(OP.INVERSE, "batchInverse");
+
+    curve.__zkmi = { addon, cid, orig };
+    return curve;
+}
+
+// Undo register(): restore the reference WASM entry points (used by A/B parity tests).
+function unregister(curve) {
+    if (!curve.__zkmi) return curve;
+    const o = curve.__zkmi.orig;
+    curve.G1.multiExpAffine = o.G1.multiExpAffine;
+    curve.G2.multiExpAffine = o.G2.multiExpAffine;
+    Object.assign(curve.Fr, o.Fr);
+    delete curve.__zkmi;
+    return curve;
+}
+
+// Patch both curves through snarkjs's own getter so that the cached instances are the ones patched.
+async function registerAll(snarkjs, options) {
+    const out = {};
+    for (const name of ["bn128", "bls12381"]) out[name] = register(await snarkjs.curves.getCurveFromName(name), options);
+    return out;
+}
+
+module.exports = { register, unregister, registerAll, loadAddon };

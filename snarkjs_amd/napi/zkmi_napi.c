@@ -1,0 +1,264 @@
+/*
+ * snarkjs_amd/napi/zkmi_napi.c — thin N-API (C) binding of libzkmi.so (include/zkmi.h) for Node.js.
+ *
+ * One exported function per C-ABI entry point; no arithmetic here.  Buffers cross as Uint8Array or as an array of
+ * Uint8Array pages (ffjavascript's BigBuffer.buffers, reference bundle build/snarkjs.min.js:1@183423).
+ * snarkjs_amd/js/register.js turns these into the curve.G1.multiExpAffine / curve.Fr.fft ... surface snarkjs calls.
+ *
+ * Build (snarkjs_amd/build.py):  gcc -shared -fPIC -I/usr/include/node zkmi_napi.c -o zkmi_napi.node -L.. -lzkmi
+ */
+#include <node_api.h>
+#include <stdbool.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/zkmi.h"
+
+#define MAX_PAGES 64
+
+#define NAPI_OK(call)                                                              \
+    do {                                                                           \
+        if ((call) != napi_ok) { napi_throw_error(env, NULL, "zkmi: N-API call failed: " #call); return NULL; } \
+    } while (0)
+
+static napi_value throw_zkmi(napi_env env, int rc) {
+    char msg[512];
+    const char* e = zkmi_last_error();
+    snprintf(msg, sizeof msg, "zkmi error %d: %s", rc, e ? e : "");
+    napi_throw_error(env, NULL, msg);
+    return NULL;
+}
+
+typedef struct {
+    const uint8_t* ptr[MAX_PAGES];
+    size_t len[MAX_PAGES];
+    int n;
+    size_t total;
+} pages_t;
+
+/* v: Uint8Array | Array<Uint8Array> */
+static int get_pages(napi_env env, napi_value v, pages_t* out) {
+    bool is_arr = false, is_ta = false;
+    out->n = 0; out->total = 0;
+    if (napi_is_typedarray(env, v, &is_ta) != napi_ok) return -1;
+    if (is_ta) {
+        napi_typedarray_type t; size_t len; void* data; napi_value ab; size_t off;
+        if (napi_get_typedarray_info(env, v, &t, &len, &data, &ab, &off) != napi_ok || t != napi_uint8_array) return -1;
+        out->ptr[0] = (const uint8_t*)data; out->len[0] = len; out->n = 1; out->total = len;
+        return 0;
+    }
+    if (napi_is_array(env, v, &is_arr) != napi_ok || !is_arr) return -1;
+    uint32_t k = 0;
+    if (napi_get_array_length(env, v, &k) != napi_ok || k > MAX_PAGES) return -1;
+    for (uint32_t i = 0; i < k; i++) {
+        napi_value e; napi_typedarray_type t; size_t len; void* data; napi_value ab; size_t off;
+        if (napi_get_element(env, v, i, &e) != napi_ok) return -1;
+        if (napi_get_typedarray_info(env, e, &t, &len, &data, &ab, &off) != napi_ok || t != napi_uint8_array) return -1;
+        out->ptr[i] = (const uint8_t*)data; out->len[i] = len; out->total += len;
+    }
+    out->n = (int)k;
+    return 0;
+}
+static zkmi_pages as_zk(const pages_t* p) { zkmi_pages z; z.ptr = p->ptr; z.len = p->len; z.n_pages = p->n; return z; }
+
+static int get_i32(napi_env env, napi_value v, int32_t* o) { return napi_get_value_int32(env, v, o) == napi_ok ? 0 : -1; }
+static int get_f64(napi_env env, napi_value v, double* o) { return napi_get_value_double(env, v, o) == napi_ok ? 0 : -1; }
+/* optional 32-byte element: null/undefined -> NULL */
+static int get_opt32(napi_env env, napi_value v, const uint8_t** o) {
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok) return -1;
+    if (t == napi_null || t == napi_undefined) { *o = NULL; return 0; }
+    pages_t p;
+    if (get_pages(env, v, &p) || p.n != 1 || p.len[0] != 32) return -1;
+    *o = p.ptr[0];
+    return 0;
+}
+static napi_value new_u8(napi_env env, size_t n, uint8_t** data) {
+    napi_value ab, ta;
+    void* d;
+    if (napi_create_arraybuffer(env, n, &d, &ab) != napi_ok) return NULL;
+    if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return NULL;
+    *data = (uint8_t*)d;
+    return ta;
+}
+#define ARGS(N)                                                           \
+    size_t argc = N; napi_value argv[N];                                  \
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));        \
+    if (argc < N) { napi_throw_type_error(env, NULL, "zkmi: too few arguments"); return NULL; }
+#define BAD_ARG() do { napi_throw_type_error(env, NULL, "zkmi: bad argument"); return NULL; } while (0)
+
+/* init(device) */
+static napi_value js_init(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    int32_t dev;
+    if (get_i32(env, argv[0], &dev)) BAD_ARG();
+    int rc = zkmi_init(dev);
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_device_count(napi_env env, napi_callback_info info) {
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, zkmi_device_count(), &v));
+    return v;
+}
+static napi_value js_version(napi_env env, napi_callback_info info) {
+    napi_value v;
+    NAPI_OK(napi_create_string_utf8(env, zkmi_version(), NAPI_AUTO_LENGTH, &v));
+    return v;
+}
+/* msm(curve, group, bases, scalars, n, scalarBytes, cacheKey) -> Uint8Array(3*group*n8q) */
+static napi_value js_msm(napi_env env, napi_callback_info info) {
+    ARGS(7);
+    int32_t curve, group; double n, sb, key;
+    pages_t b, s;
+    if (get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &group) || get_pages(env, argv[2], &b) || get_pages(env, argv[3], &s) ||
+        get_f64(env, argv[4], &n) || get_f64(env, argv[5], &sb) || get_f64(env, argv[6], &key)) BAD_ARG();
+    if (group != 1 && group != 2) BAD_ARG();
+    uint8_t* out;
+    napi_value res = new_u8(env, (size_t)3 * group * (curve == ZKMI_CURVE_BN128 ? 32 : 48), &out);
+    if (!res) BAD_ARG();
+    int rc = zkmi_msm(curve, group, as_zk(&b), as_zk(&s), (size_t)n, (size_t)sb, (uint64_t)key, out);
+    if (rc) return throw_zkmi(env, rc);
+    return res;
+}
+static napi_value js_release_bases(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    double key;
+    if (get_f64(env, argv[0], &key)) BAD_ARG();
+    zkmi_release_bases((uint64_t)key);
+    return NULL;
+}
+/* ntt(curve, in, out, logN, inverse, first|null, inc|null): out is preallocated by the caller (same container type) */
+static napi_value js_ntt(napi_env env, napi_callback_info info) {
+    ARGS(7);
+    int32_t curve, logn, inverse;
+    pages_t in, out;
+    const uint8_t *first, *inc;
+    if (get_i32(env, argv[0], &curve) || get_pages(env, argv[1], &in) || get_pages(env, argv[2], &out) || get_i32(env, argv[3], &logn) ||
+        get_i32(env, argv[4], &inverse) || get_opt32(env, argv[5], &first) || get_opt32(env, argv[6], &inc)) BAD_ARG();
+    int rc = zkmi_ntt(curve, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (unsigned)logn, inverse, first, inc);
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+/* frBatch(curve, op, in, out, n) */
+static napi_value js_fr_batch(napi_env env, napi_callback_info info) {
+    ARGS(5);
+    int32_t curve, op; double n;
+    pages_t in, out;
+    if (get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &op) || get_pages(env, argv[2], &in) || get_pages(env, argv[3], &out) || get_f64(env, argv[4], &n)) BAD_ARG();
+    int rc = zkmi_fr_batch(curve, op, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n);
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+/* applyKey(curve, in, out, n, first, inc) */
+static napi_value js_apply_key(napi_env env, napi_callback_info info) {
+    ARGS(6);
+    int32_t curve; double n;
+    pages_t in, out;
+    const uint8_t *first, *inc;
+    if (get_i32(env, argv[0], &curve) || get_pages(env, argv[1], &in) || get_pages(env, argv[2], &out) || get_f64(env, argv[3], &n) ||
+        get_opt32(env, argv[4], &first) || get_opt32(env, argv[5], &inc) || !first || !inc) BAD_ARG();
+    int rc = zkmi_fr_batch_apply_key(curve, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n, first, inc);
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+/* joinABC(curve, a, b, c, out, n) */
+static napi_value js_join_abc(napi_env env, napi_callback_info info) {
+    ARGS(6);
+    int32_t curve; double n;
+    pages_t a, b, c, out;
+    if (get_i32(env, argv[0], &curve) || get_pages(env, argv[1], &a) || get_pages(env, argv[2], &b) || get_pages(env, argv[3], &c) ||
+        get_pages(env, argv[4], &out) || get_f64(env, argv[5], &n)) BAD_ARG();
+    int rc = zkmi_groth16_join_abc(curve, as_zk(&a), as_zk(&b), as_zk(&c), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n);
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+/* toAffine(curve, group, jacobian) -> Uint8Array */
+static napi_value js_to_affine(napi_env env, napi_callback_info info) {
+    ARGS(3);
+    int32_t curve, group;
+    pages_t j;
+    if (get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &group) || get_pages(env, argv[2], &j) || j.n != 1) BAD_ARG();
+    const size_t q = curve == ZKMI_CURVE_BN128 ? 32 : 48;
+    if ((group != 1 && group != 2) || j.len[0] != 3 * group * q) BAD_ARG();
+    uint8_t* out;
+    napi_value res = new_u8(env, 2 * group * q, &out);
+    if (!res) BAD_ARG();
+    int rc = zkmi_to_affine(curve, group, j.ptr[0], out);
+    if (rc) return throw_zkmi(env, rc);
+    return res;
+}
+/* groth16Prove({curve,nVars,nPublic,domainSize,coeffs,A,B1,B2,C,H,alpha1,beta1,beta2,delta1,delta2} | null, key, witness, r, s)
+ *   -> {pi_a, pi_b, pi_c} (affine Montgomery bytes). Sections must be single Uint8Arrays (< 2 GiB each). */
+static int get_named_u8(napi_env env, napi_value obj, const char* name, const uint8_t** p, size_t* len) {
+    napi_value v; pages_t pg;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok || get_pages(env, v, &pg) || pg.n != 1) return -1;
+    *p = pg.ptr[0]; if (len) *len = pg.len[0];
+    return 0;
+}
+static int get_named_u32(napi_env env, napi_value obj, const char* name, uint32_t* o) {
+    napi_value v;
+    return (napi_get_named_property(env, obj, name, &v) == napi_ok && napi_get_value_uint32(env, v, o) == napi_ok) ? 0 : -1;
+}
+static napi_value js_groth16_prove(napi_env env, napi_callback_info info) {
+    ARGS(5);
+    zkmi_groth16_zkey zk, *pzk = NULL;
+    napi_valuetype t;
+    NAPI_OK(napi_typeof(env, argv[0], &t));
+    double key;
+    pages_t w;
+    const uint8_t *r, *s;
+    int curve = 0;
+    if (t == napi_object) {
+        uint32_t c;
+        memset(&zk, 0, sizeof zk);
+        if (get_named_u32(env, argv[0], "curve", &c) || get_named_u32(env, argv[0], "nVars", &zk.n_vars) || get_named_u32(env, argv[0], "nPublic", &zk.n_public) ||
+            get_named_u32(env, argv[0], "domainSize", &zk.domain_size) || get_named_u8(env, argv[0], "coeffs", &zk.coeffs, &zk.coeffs_len) ||
+            get_named_u8(env, argv[0], "A", &zk.bases_a, NULL) || get_named_u8(env, argv[0], "B1", &zk.bases_b1, NULL) || get_named_u8(env, argv[0], "B2", &zk.bases_b2, NULL) ||
+            get_named_u8(env, argv[0], "C", &zk.bases_c, NULL) || get_named_u8(env, argv[0], "H", &zk.bases_h, NULL) ||
+            get_named_u8(env, argv[0], "alpha1", &zk.vk_alpha_1, NULL) || get_named_u8(env, argv[0], "beta1", &zk.vk_beta_1, NULL) ||
+            get_named_u8(env, argv[0], "beta2", &zk.vk_beta_2, NULL) || get_named_u8(env, argv[0], "delta1", &zk.vk_delta_1, NULL) ||
+            get_named_u8(env, argv[0], "delta2", &zk.vk_delta_2, NULL)) BAD_ARG();
+        zk.curve = (int)c; curve = zk.curve; pzk = &zk;
+    }
+    if (get_f64(env, argv[1], &key) || get_pages(env, argv[2], &w) || w.n != 1 || get_opt32(env, argv[3], &r) || get_opt32(env, argv[4], &s) || !r || !s) BAD_ARG();
+    if (!pzk) {            /* key already resident: the caller passes the curve id in place of the zkey object */
+        int32_t c;
+        if (get_i32(env, argv[0], &c)) BAD_ARG();
+        curve = c;
+    }
+    const size_t q = curve == ZKMI_CURVE_BN128 ? 32 : 48;
+    uint8_t *pa, *pb, *pc;
+    napi_value va = new_u8(env, 2 * q, &pa), vb = new_u8(env, 4 * q, &pb), vc = new_u8(env, 2 * q, &pc), res;
+    if (!va || !vb || !vc) BAD_ARG();
+    int rc = zkmi_groth16_prove(pzk, (uint64_t)key, w.ptr[0], r, s, pa, pb, pc);
+    if (rc) return throw_zkmi(env, rc);
+    NAPI_OK(napi_create_object(env, &res));
+    NAPI_OK(napi_set_named_property(env, res, "pi_a", va));
+    NAPI_OK(napi_set_named_property(env, res, "pi_b", vb));
+    NAPI_OK(napi_set_named_property(env, res, "pi_c", vc));
+    return res;
+}
+static napi_value js_groth16_release(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    double key;
+    if (get_f64(env, argv[0], &key)) BAD_ARG();
+    zkmi_groth16_release((uint64_t)key);
+    return NULL;
+}
+
+static napi_value module_init(napi_env env, napi_value exports) {
+    static const struct { const char* name; napi_callback fn; } fns[] = {
+        {"init", js_init}, {"deviceCount", js_device_count}, {"version", js_version}, {"msm", js_msm}, {"releaseBases", js_release_bases},
+        {"ntt", js_ntt}, {"frBatch", js_fr_batch}, {"applyKey", js_apply_key}, {"joinABC", js_join_abc}, {"toAffine", js_to_affine},
+        {"groth16Prove", js_groth16_prove}, {"groth16Release", js_groth16_release},
+    };
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+        if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
+    }
+    return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, module_init)

@@ -25,7 +25,7 @@ SYMBOLS = [
     "zkmi_fr_batch_apply_key", "zkmi_fr_batch_apply_key_dev", "zkmi_fr_batch", "zkmi_fr_batch_dev",
     "zkmi_groth16_join_abc", "zkmi_groth16_join_abc_dev",
     "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_release", "zkmi_groth16_stage_ms",
-    "zkmi_gen_geometric_bases_dev", "zkmi_to_affine", "zkmi_last_kernel_ms",
+    "zkmi_gen_geometric_bases_dev", "zkmi_to_affine", "zkmi_point_add", "zkmi_last_kernel_ms",
 ]
 
 
@@ -85,6 +85,7 @@ def lib():
     L.zkmi_groth16_join_abc_dev.argtypes = [C.c_int, vp, vp, vp, vp, sz]
     L.zkmi_gen_geometric_bases_dev.argtypes = [C.c_int, C.c_int, sz, C.c_uint64, C.c_uint64, vp]
     L.zkmi_to_affine.argtypes = [C.c_int, C.c_int, u8p, u8p]
+    L.zkmi_point_add.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p]
     L.zkmi_groth16_load.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64]
     L.zkmi_groth16_prove.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p]
     L.zkmi_groth16_prove_dev.argtypes = [C.c_uint64, vp, u8p, u8p, u8p, u8p, u8p]

@@ -1,0 +1,87 @@
+// tests/js/register_glue.js — CPU-only check of snarkjs_amd/js/register.js against the REAL reference bundle.
+// Needs /root/reference (build container only).  The HIP addon is replaced by a MOCK whose entry points call the
+// reference's own (saved) WASM functions, so what is tested is exactly the glue: which calls snarkjs makes through the
+// patched surface, container types (Uint8Array vs BigBuffer), argument conventions and that a seeded groth16 /
+// plonk proof through the patched curve is byte-identical to the unpatched one.
+// Run:  node --harmony-optional-chaining --harmony-nullish tests/js/register_glue.js
+"use strict";
+const fs = require("fs"), path = require("path"), crypto = require("crypto");
+process.env.SINGLE = "1";
+const snarkjs = require(path.join(__dirname, "..", "..", "oracle", "ref_shim.js"));
+const { register, unregister } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "register.js"));
+const sha = (b) => crypto.createHash("sha256").update(b).digest("hex");
+const GOLD = path.join(__dirname, "..", "golden");
+let fails = 0;
+function check(name, ok) { if (!ok) { fails++; console.log("FAIL", name); } else console.log("ok  ", name); }
+
+function cat(p) { if (p instanceof Uint8Array) return p; const n = p.reduce((a, b) => a + b.length, 0), o = new Uint8Array(n); let k = 0; for (const b of p) { o.set(b, k); k += b.length; } return o; }
+function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); return; } let k = 0; for (const b of dst) { b.set(src.subarray(k, k + b.length)); k += b.length; } }
+
+(async () => {
+    const curve = await snarkjs.curves.getCurveFromName("bn128");
+    const saved = { g1: curve.G1.multiExpAffine.bind(curve.G1), g2: curve.G2.multiExpAffine.bind(curve.G2), fft: curve.Fr.fft.bind(curve.Fr), ifft: curve.Fr.ifft.bind(curve.Fr),
+                    ak: curve.Fr.batchApplyKey.bind(curve.Fr), tm: curve.Fr.batchToMontgomery.bind(curve.Fr), fm: curve.Fr.batchFromMontgomery.bind(curve.Fr), inv: curve.Fr.batchInverse.bind(curve.Fr) };
+    const calls = {};
+    const note = (k) => { calls[k] = (calls[k] || 0) + 1; };
+    // The mock is synchronous like the real addon, so it may only use the reference's SYNC element ops; bulk results are
+    // produced by running the saved async WASM functions beforehand is not possible — instead the mock records the
+    // request and the glue test drives it through `pending` promises resolved before the glue returns.
+    // (the promise that fills an output rides on the output container as __p)
+    const mock = {
+        init() { note("init"); },
+        msm(cid, group, bases, scalars, n, sb, key) { note("msm" + group); const out = new Uint8Array(96 * group); out.__p = (group == 1 ? saved.g1 : saved.g2)(cat(bases), cat(scalars)).then((r) => out.set(r)); return out; },
+        ntt(cid, inp, out, logn, inverse) { note(inverse ? "ifft" : "fft"); out.__p = (inverse ? saved.ifft : saved.fft)(cat(inp)).then((r) => spread(r, out)); },
+        applyKey(cid, inp, out, n, first, inc) { note("applyKey"); out.__p = saved.ak(cat(inp), first, inc).then((r) => spread(r, out)); },
+        frBatch(cid, op, inp, out, n) { note("batch" + op); out.__p = [saved.tm, saved.fm, saved.inv][op](cat(inp)).then((r) => spread(r, out)); },
+    };
+    register(curve, { addon: mock });
+    // the mock fills its outputs asynchronously: wrap every patched method so that it awaits that work
+    for (const [obj, names] of [[curve.G1, ["multiExpAffine"]], [curve.G2, ["multiExpAffine"]], [curve.Fr, ["fft", "ifft", "batchApplyKey", "batchToMontgomery", "batchFromMontgomery", "batchInverse"]]]) {
+        for (const nm of names) {
+            const f = obj[nm];
+            obj[nm] = async function () { const r = await f.apply(this, arguments); const c = (r instanceof Uint8Array) ? r : (r && r.buffers); if (c && c.__p) { await c.__p; delete c.__p; } return r; };
+        }
+    }
+
+    // 1. container rule: Uint8Array in -> Uint8Array out, BigBuffer in -> BigBuffer out
+    const x = new Uint8Array(1024 * 32); for (let i = 0; i < 1024; i++) x[32 * i] = i + 1;
+    const y = await curve.Fr.fft(x);
+    check("fft Uint8Array -> Uint8Array, bytes equal reference", y instanceof Uint8Array && sha(y) === sha(await saved.fft(x)));
+    let threw = false;
+    try { await curve.Fr.fft(new Uint8Array(96)); } catch (e) { threw = e.message === "fft must be multiple of 2"; }
+    check("fft error message", threw);
+    threw = false;
+    try { await curve.G1.multiExpAffine(new Uint8Array(128), new Uint8Array(63)); } catch (e) { threw = e.message === "Scalar size does not match"; }
+    check("multiExpAffine error message", threw);
+    check("multiExpAffine empty -> G1.zero", (await curve.G1.multiExpAffine(new Uint8Array(0), new Uint8Array(0))) === curve.G1.zero);
+
+    // 2. seeded Groth16 proof through the patched surface == SURVEY.md Appendix C.3 / golden fixture
+    const g = JSON.parse(fs.readFileSync(path.join(GOLD, "groth16_bn128_n1024.json")));
+    const zkey = new Uint8Array(fs.readFileSync(path.join(GOLD, "groth16_bn128_n1024.zkey")));
+    const wtns = new Uint8Array(fs.readFileSync(path.join(GOLD, "groth16_bn128_n1024.wtns")));
+    const hexb = (s) => new Uint8Array(Buffer.from(s, "hex"));
+    const draws = [hexb(g.r_mont), hexb(g.s_mont)];
+    const realRandom = curve.Fr.random;
+    curve.Fr.random = () => draws.shift();
+    for (const k of Object.keys(calls)) delete calls[k];
+    const res = await snarkjs.groth16.prove(zkey, wtns);
+    curve.Fr.random = realRandom;
+    check("groth16.prove through register.js == reference proof", sha(JSON.stringify(res.proof)) === g.proof_sha256);
+    check("bulk-op census (SURVEY.md Appendix B): 4 G1 + 1 G2 MSM, 3 ifft, 3 fft, 3 applyKey",
+          calls.msm1 === 4 && calls.msm2 === 1 && calls.ifft === 3 && calls.fft === 3 && calls.applyKey === 3);
+
+    // 3. PLONK through the patched surface still verifies (exercises batchToMontgomery / FromMontgomery / Inverse + BigBuffer ffts)
+    const pz = "/root/reference/test/circuit2/circuit.zkey", pw = "/root/reference/test/circuit2/witness.wtns";
+    if (fs.existsSync(pz)) {
+        for (const k of Object.keys(calls)) delete calls[k];
+        const zk = new Uint8Array(fs.readFileSync(pz)), wt = new Uint8Array(fs.readFileSync(pw));
+        const pr = await snarkjs.plonk.prove(zk, wt);
+        const vk = await snarkjs.zKey.exportVerificationKey(zk);
+        check("plonk.prove through register.js verifies", await snarkjs.plonk.verify(vk, pr.publicSignals, pr.proof));
+        check("plonk census: 9 MSM, batchInverse, batchFromMontgomery used", calls.msm1 === 9 && calls.batch2 >= 1 && calls.batch1 >= 9 && calls.batch0 === 3);
+    }
+    unregister(curve);
+    check("unregister restores the WASM entry points", curve.__zkmi === undefined);
+    console.log(fails ? `${fails} FAILED` : "ALL OK");
+    process.exit(fails ? 1 : 0);
+})().catch((e) => { console.log("ERROR", e); process.exit(2); });
