@@ -132,6 +132,67 @@ template <class F> ZK_DEV void pt_madd(XYZZ<F>& acc, const Affine<F>& q) {
     acc.X = X3;
     acc.ZZ = f_mul(acc.ZZ, PP); acc.ZZZ = f_mul(acc.ZZZ, PPP);
 }
+// ---- accumulator parked in LDS -----------------------------------------------------------------------------------------
+// An Fq2 XYZZ accumulator is 64 (BN254) / 96 (BLS12-381) VGPRs; together with the operands of a mixed addition the live set
+// exceeds 256 registers and the compiler spills to scratch (measured: 15 GB of scratch writes per 2^20 G2 MSM). Instead the
+// four coordinates live in LDS (transposed: dword i of lane t at i*T + t, conflict-free) and are pulled into registers only
+// while needed.  T = threads per block.
+template <class C> ZK_DEV void f_from_words(Fp<C>& v, const uint32_t* w) {
+#pragma unroll
+    for (int i = 0; i < C::N; i++) v.l[i] = w[i];
+}
+template <class C> ZK_DEV void f_to_words(uint32_t* w, const Fp<C>& v) {
+#pragma unroll
+    for (int i = 0; i < C::N; i++) w[i] = v.l[i];
+}
+template <class C> ZK_DEV void f_from_words(Fp2<C>& v, const uint32_t* w) {
+#pragma unroll
+    for (int i = 0; i < C::N; i++) { v.c0.l[i] = w[i]; v.c1.l[i] = w[C::N + i]; }
+}
+template <class C> ZK_DEV void f_to_words(uint32_t* w, const Fp2<C>& v) {
+#pragma unroll
+    for (int i = 0; i < C::N; i++) { w[i] = v.c0.l[i]; w[C::N + i] = v.c1.l[i]; }
+}
+template <class F, int T> struct LdsAcc {
+    static constexpr int FW = FieldWords<F>::value;
+    uint32_t* base;                         // &lds[threadIdx.x]
+    ZK_DEV void get(int coord, F& v) const {
+        uint32_t w[FW];
+#pragma unroll
+        for (int i = 0; i < FW; i++) w[i] = base[(coord * FW + i) * T];
+        f_from_words(v, w);
+    }
+    ZK_DEV void put(int coord, const F& v) const {
+        uint32_t w[FW];
+        f_to_words(w, v);
+#pragma unroll
+        for (int i = 0; i < FW; i++) base[(coord * FW + i) * T] = w[i];
+    }
+};
+// acc += q (q affine and not infinity); `inf` = accumulator is the point at infinity (kept in a register)
+template <class F, int T> ZK_DEV void pt_madd_lds(const LdsAcc<F, T>& A, bool& inf, const Affine<F>& q) {
+    if (inf) { F one; f_set_one(one); A.put(0, q.x); A.put(1, q.y); A.put(2, one); A.put(3, one); inf = false; return; }
+    F t, P, R;
+    A.get(2, t); P = f_mul(q.x, t);            // U2
+    A.get(0, t); P = f_sub(P, t);              // P = U2 - X
+    A.get(3, t); R = f_mul(q.y, t);            // S2
+    A.get(1, t); R = f_sub(R, t);              // R = S2 - Y
+    if (f_is_zero(P)) {
+        if (f_is_zero(R)) { XYZZ<F> d = pt_dbl_affine(q); A.put(0, d.X); A.put(1, d.Y); A.put(2, d.ZZ); A.put(3, d.ZZZ); }
+        else inf = true;
+        return;
+    }
+    F PP = f_sqr(P);
+    A.get(2, t); A.put(2, f_mul(t, PP));       // ZZ' = ZZ*PP
+    A.get(0, t);
+    F Q = f_mul(t, PP);                        // Q = X*PP
+    F PPP = f_mul(P, PP);
+    A.get(3, t); A.put(3, f_mul(t, PPP));      // ZZZ' = ZZZ*PPP
+    F X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
+    A.put(0, X3);
+    A.get(1, t);
+    A.put(1, f_sub(f_mul(R, f_sub(Q, X3)), f_mul(t, PPP)));
+}
 // full addition (EFD add-2008-s: 12M + 2S) with all special cases
 template <class F> __device__ __noinline__ XYZZ<F> pt_add(const XYZZ<F>& a, const XYZZ<F>& b) {
     if (pt_is_inf(a)) return b;

@@ -191,8 +191,8 @@ k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, 
         giants[3 * idx] = g; giants[3 * idx + 1] = lane0 >> log_tb; giants[3 * idx + 2] = 1u << (j - log_tb);
     }
 }
-// WIDE (Fq2 points): no software pipelining of the gather and at most 256 VGPRs (2 waves per SIMD) — measured 2.2x faster
-// than letting the compiler take 400+ registers (tools/maddbench.hip).
+// WIDE (Fq2 points): at most 256 VGPRs (2 waves per SIMD), accumulator parked in LDS (curve.cuh: LdsAcc), no software
+// pipelining of the gather — 2.6x the throughput of the fully inlined 400+-register version (tools/maddbench.hip).
 template <class F, bool WIDE> __global__ void __launch_bounds__(256, WIDE ? 2 : 1)
 k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
             const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub, const uint32_t* __restrict__ meta,
@@ -214,14 +214,19 @@ k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, uint32_t skip, uint
     XYZZ<F> acc;
     pt_set_inf(acc);
     if (WIDE) {
+        extern __shared__ __attribute__((aligned(16))) uint32_t lds_acc[];
+        LdsAcc<F, 256> A{lds_acc + threadIdx.x};
+        bool inf = true;
         for (uint32_t k = lo; k < hi; k++) {
             const uint32_t e = list[k], idx = e & 0x7fffffffu;
             if (idx < skip) continue;
             Affine<F> q;
             pt_load(q, bases + (size_t)(idx - skip) * (2 * FW));
+            if (pt_is_inf(q)) continue;
             if (e >> 31) q.y = f_neg(q.y);
-            pt_madd(acc, q);
+            pt_madd_lds(A, inf, q);
         }
+        if (!inf) { A.get(0, acc.X); A.get(1, acc.Y); A.get(2, acc.ZZ); A.get(3, acc.ZZZ); }
     } else {
         // software pipeline: the gather of point k+1 (a random 64..96-byte read) is in flight during the addition of point k
         uint32_t e_next = lo < hi ? list[lo] : 0u;

@@ -136,8 +136,14 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
         ZK_HIP(hipFuncSetAttribute((const void*)k_msm_giant<F, MSM_TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
         tree_attr = true;
     }
+    const size_t acc_lds = WIDE ? (size_t)PW * 256 * 4 : 0;              // WIDE: XYZZ accumulators live in LDS
+    static bool acc_attr = false;
+    if (WIDE && !acc_attr) {
+        ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum<F, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
+        acc_attr = true;
+    }
     if (job.acc0) ZK_HIP(hipEventRecord(job.acc0, st));
-    hipLaunchKernelGGL((k_msm_accum<F, WIDE>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_bases, sh, skip, pl.cap, pl.counts,
+    hipLaunchKernelGGL((k_msm_accum<F, WIDE>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), acc_lds, st, (const uint32_t*)d_bases, sh, skip, pl.cap, pl.counts,
                        pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials);
     if (job.acc1) ZK_HIP(hipEventRecord(job.acc1, st));
     hipLaunchKernelGGL((k_msm_tree<F, MSM_TB>), dim3((unsigned)tree_blocks), dim3(MSM_TB), tree_lds, st, lane_partials, pl.lane_g, pl.counts, pl.cap, pl.meta, buckets,
