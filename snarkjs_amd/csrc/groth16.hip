@@ -91,7 +91,9 @@ enum { ST_BUILD = 0, ST_NTT, ST_JOIN, ST_SORT_W, ST_MSM_A, ST_MSM_B1, ST_MSM_B2,
 struct G16Key {
     int curve = 0;
     uint32_t n_vars = 0, n_public = 0, domain = 0, power = 0, n_coef = 0;
-    void *bA = nullptr, *bB1 = nullptr, *bB2 = nullptr, *bC = nullptr, *bH = nullptr;
+    void *bA = nullptr, *bB1 = nullptr, *bB2 = nullptr, *bC = nullptr, *bH = nullptr;   // base tables; with pre-computed windows: T[k][i] = 2^(c*k) P_i
+    int cw = 0, ch = 0;               // window width of the witness-side / H-side tables (0 = plain bases, no pre-computation)
+    uint32_t c_skip = 0;              // index offset of the C bases (0 when the C table is padded to nVars entries)
     uint32_t *row_cnt = nullptr, *row_start = nullptr, *sig = nullptr, *val = nullptr;
     uint32_t *w = nullptr, *A = nullptr, *B = nullptr, *C = nullptr, *T = nullptr;
     std::vector<uint8_t> vk_alpha_1, vk_beta_1, vk_beta_2, vk_delta_1, vk_delta_2;
@@ -124,11 +126,33 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key) {
     K->n_coef = (uint32_t)((zk->coeffs_len - 4) / 44);            // buildABC1: nCoef = (byteLength-4)/sCoef (:149-150)
     const size_t q = n8q_of(zk->curve), g1 = 2 * q, g2 = 4 * q;
     const size_t m = zk->n_vars, mc = m - zk->n_public - 1;
-    ZK_TRY(upload(&K->bA, zk->bases_a, m * g1, st));
-    ZK_TRY(upload(&K->bB1, zk->bases_b1, m * g1, st));
-    ZK_TRY(upload(&K->bB2, zk->bases_b2, m * g2, st));
-    ZK_TRY(upload(&K->bC, zk->bases_c, mc * g1, st));
-    ZK_TRY(upload(&K->bH, zk->bases_h, (size_t)n * g1, st));
+    // Pre-computed window tables (msm.cuh: k_msm_precompute): the zkey is static, so every base set is expanded once into
+    // T[k][i] = 2^(c*k) * P_i. ZKMI_PRECOMP=0 keeps the plain bases (per-window bucket sets); ZKMI_PRECOMP=<c> forces c.
+    const char* pe = getenv("ZKMI_PRECOMP");
+    const int pc = pe ? atoi(pe) : -1;
+    K->cw = pc == 0 ? 0 : (pc > 0 ? pc : msm_precomp_c(m));
+    K->ch = pc == 0 ? 0 : (pc > 0 ? pc : msm_precomp_c(n));
+    auto put_table = [&](void** dst, const uint8_t* src, size_t cnt, size_t pad_front, int group, int c) -> int {
+        const size_t pb = group == 1 ? g1 : g2, tot = cnt + pad_front;
+        void* raw = nullptr;
+        ZK_HIP(hipMalloc(&raw, tot * pb ? tot * pb : 16));
+        if (pad_front) ZK_HIP(hipMemsetAsync(raw, 0, pad_front * pb, st));             // all-zero bytes = point at infinity
+        if (cnt) ZK_HIP(hipMemcpyAsync((uint8_t*)raw + pad_front * pb, src, cnt * pb, hipMemcpyHostToDevice, st));
+        if (!c) { *dst = raw; return ZKMI_OK; }
+        const int Wd = msm_digits(32, c);
+        ZK_HIP(hipMalloc(dst, (size_t)Wd * tot * pb));
+        ZK_TRY(msm_precompute_dispatch(zk->curve, group, raw, tot, c, Wd, *dst));
+        ZK_HIP(hipStreamSynchronize(st));
+        (void)hipFree(raw);
+        return ZKMI_OK;
+    };
+    ZK_TRY(put_table(&K->bA, zk->bases_a, m, 0, 1, K->cw));
+    ZK_TRY(put_table(&K->bB1, zk->bases_b1, m, 0, 1, K->cw));
+    ZK_TRY(put_table(&K->bB2, zk->bases_b2, m, 0, 2, K->cw));
+    // C pairs with witness[nPublic+1:] (:97): with tables it is padded in front so that it shares the witness indices
+    ZK_TRY(put_table(&K->bC, zk->bases_c, mc, K->cw ? m - mc : 0, 1, K->cw));
+    K->c_skip = K->cw ? 0 : (uint32_t)(m - mc);
+    ZK_TRY(put_table(&K->bH, zk->bases_h, (size_t)n, 0, 1, K->ch));
     K->vk_alpha_1.assign(zk->vk_alpha_1, zk->vk_alpha_1 + g1); K->vk_beta_1.assign(zk->vk_beta_1, zk->vk_beta_1 + g1);
     K->vk_beta_2.assign(zk->vk_beta_2, zk->vk_beta_2 + g2); K->vk_delta_1.assign(zk->vk_delta_1, zk->vk_delta_1 + g1);
     K->vk_delta_2.assign(zk->vk_delta_2, zk->vk_delta_2 + g2);
@@ -222,7 +246,7 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     MsmPlan pl, plh;
     MsmJob job[5];
     for (int i = 0; i < 5; i++) ZK_TRY(msm_job_slot(i, job[i]));
-    ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl, 0));
+    ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl, 0, K.cw));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_A], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bA, pl, 0, job[0]));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_B1], st));
@@ -230,9 +254,9 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_B2], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 2, K.bB2, pl, 0, job[2]));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_C], st));
-    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.n_public + 1, job[3]));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.c_skip, job[3]));
     ZK_HIP(hipEventRecord(K.ev[ST_SORT_H], st));
-    ZK_TRY(msm_sort(K.T, n, 32, plh, 1));
+    ZK_TRY(msm_sort(K.T, n, 32, plh, 1, K.ch));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_H], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, plh, 0, job[4]));
     ZK_HIP(hipEventRecord(K.ev[ST_REDUCE], st));

@@ -5,7 +5,7 @@
 // with the bases re-copied per window, the whole MSM is five data-parallel device stages over all windows at once:
 //
 //   1. k_msm_count    signed-digit recoding of every scalar, histogram of bucket sizes        (global atomics)
-//   2. k_msm_scan     exclusive scan of the histogram per window                              (LDS block scan)
+//   2. k_msm_scan_*   exclusive scan of the histogram (all windows, one flat list)            (LDS block scans)
 //   3. k_msm_scatter  counting-sort scatter: per bucket, the list of (point index, sign)
 //   4. k_msm_accum    one lane per bucket: gather bases, XYZZ mixed additions (the hot loop: n·W of them)
 //   5. k_msm_reduce*  per window sum_b (b+1)·B_b: lane-sequential running sums over 8 buckets, then LDS
@@ -21,9 +21,11 @@ namespace zkmi {
 struct MsmShape {
     uint32_t n;        // terms
     int c;             // window bits
-    int W;             // windows = ceil((8*scalar_bytes + 1) / c)
-    uint32_t nb;       // buckets per window = 2^(c-1)
+    int Wd;            // digit windows = ceil((8*scalar_bytes + 1) / c)
+    int W;             // bucket sets: Wd, or 1 with pre-computed window tables (all digits share one set of buckets)
+    uint32_t nb;       // buckets per set = 2^(c-1)
     int sb;            // scalar bytes
+    int precomp;       // bases are a table T[k][i] = 2^(c*k) * P_i (k < Wd, stride n): entry index = k*n + i
 };
 
 // ---- scalar access / signed-digit recoding ----------------------------------------------------------------------
@@ -73,21 +75,21 @@ ZK_DEV uint32_t msm_atomic_inc(uint32_t* __restrict__ ctr, size_t idx) {
     const uint32_t lane = __lane_id();
     uint32_t result = 0;
     bool done = false;
-#pragma unroll
-    for (int round = 0; round < 2; round++) {
-        if (!done) {
-            const uint64_t act = __ballot(1);
-            const int leader = __ffsll((unsigned long long)act) - 1;
-            const uint32_t lo = __shfl((uint32_t)idx, leader), hi = __shfl((uint32_t)(idx >> 32), leader);
-            if (lo == (uint32_t)idx && hi == (uint32_t)(idx >> 32)) {
-                const uint64_t peers = __ballot(1);
-                const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
-                uint32_t basev = 0;
-                if ((int)lane == leader) basev = atomicAdd(&ctr[idx], (uint32_t)__popcll(peers));
-                result = __shfl(basev, leader) + rank;
-                done = true;
-            }
-        }
+    // Each round serves the group of lanes that share the first pending lane's counter with ONE atomic. Rounds continue
+    // while groups are large (a hot digit: up to 8 distinct hot values per wave), and stop at the first small group —
+    // uniformly distributed digits leave after one round.
+    for (int round = 0; round < 8; round++) {
+        const uint64_t pend = __ballot(!done);
+        if (!pend) break;
+        const int leader = __ffsll((unsigned long long)pend) - 1;
+        const uint32_t lo = __shfl((uint32_t)idx, leader), hi = __shfl((uint32_t)(idx >> 32), leader);
+        const bool match = !done && lo == (uint32_t)idx && hi == (uint32_t)(idx >> 32);
+        const uint64_t peers = __ballot(match);
+        uint32_t basev = 0;
+        if (match && (int)lane == leader) basev = atomicAdd(&ctr[idx], (uint32_t)__popcll(peers));
+        basev = __shfl(basev, leader);
+        if (match) { result = basev + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)); done = true; }
+        if (__popcll(peers) < 4) break;
     }
     if (!done) result = atomicAdd(&ctr[idx], 1u);
     return result;
@@ -98,28 +100,59 @@ template <int NW> __global__ void k_msm_count(const uint8_t* __restrict__ scalar
     if (i >= sh.n) return;
     uint32_t s[NW];
     load_scalar<NW>(s, scalars, i, sh.sb);
-    for_each_digit<NW>(s, sh.c, sh.W, [&](int w, uint32_t mag, bool) { msm_atomic_inc(counts, (size_t)w * sh.nb + (mag - 1)); });
+    for_each_digit<NW>(s, sh.c, sh.Wd, [&](int w, uint32_t mag, bool) { msm_atomic_inc(counts, (sh.precomp ? (size_t)0 : (size_t)w * sh.nb) + (mag - 1)); });
 }
 
-// one block per window: starts[w][b] = exclusive prefix sum of counts[w][*]
-static __global__ void k_msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts, uint32_t nb) {
-    __shared__ uint32_t part[1024];
-    const uint32_t* cw = counts + (size_t)blockIdx.x * nb;
-    uint32_t* sw = starts + (size_t)blockIdx.x * nb;
-    const uint32_t per = (nb + blockDim.x - 1) / blockDim.x;
-    const uint32_t lo = threadIdx.x * per, hi = min(nb, lo + per);
-    uint32_t sum = 0;
-    for (uint32_t b = lo; b < hi; b++) sum += cw[b];
-    part[threadIdx.x] = sum;
+// starts[] = exclusive prefix sum of counts[] over ALL (window, bucket) pairs: the sorted lists of all buckets form one flat
+// array. Three small launches: per-chunk sums, scan of the chunk sums (one block), per-chunk scan with offset.
+constexpr uint32_t MSM_SCAN_CHUNK = 2048;      // 256 threads x 8 counters
+static __global__ void __launch_bounds__(256) k_msm_scan_sums(const uint32_t* __restrict__ counts, uint32_t total, uint32_t* __restrict__ part) {
+    __shared__ uint32_t red[256];
+    const uint32_t base = blockIdx.x * MSM_SCAN_CHUNK + threadIdx.x * 8;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (base + k < total) s += counts[base + k];
+    red[threadIdx.x] = s;
     __syncthreads();
-    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
-        uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+    for (int d = 128; d >= 1; d >>= 1) { if (threadIdx.x < (uint32_t)d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+static __global__ void __launch_bounds__(1024) k_msm_scan_top(uint32_t* __restrict__ part, uint32_t nparts) {
+    __shared__ uint32_t sh[1024];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nparts; b0 += 1024) {
+        const uint32_t i = b0 + threadIdx.x, v = i < nparts ? part[i] : 0u;
+        sh[threadIdx.x] = v;
         __syncthreads();
-        part[threadIdx.x] += v;
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            uint32_t t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nparts) part[i] = carry + sh[threadIdx.x] - v;
+        const uint32_t tot = sh[1023];
+        __syncthreads();
+        carry += tot;
+    }
+}
+static __global__ void __launch_bounds__(256) k_msm_scan_final(const uint32_t* __restrict__ counts, uint32_t total, const uint32_t* __restrict__ part, uint32_t* __restrict__ starts) {
+    __shared__ uint32_t sh[256];
+    const uint32_t base = blockIdx.x * MSM_SCAN_CHUNK + threadIdx.x * 8;
+    uint32_t c[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { c[k] = base + k < total ? counts[base + k] : 0u; s += c[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += t;
         __syncthreads();
     }
-    uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t b = lo; b < hi; b++) { sw[b] = run; run += cw[b]; }
+    uint32_t run = part[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { if (base + k < total) starts[base + k] = run; run += c[k]; }
 }
 
 template <int NW> __global__ void k_msm_scatter(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ starts,
@@ -128,10 +161,11 @@ template <int NW> __global__ void k_msm_scatter(const uint8_t* __restrict__ scal
     if (i >= sh.n) return;
     uint32_t s[NW];
     load_scalar<NW>(s, scalars, i, sh.sb);
-    for_each_digit<NW>(s, sh.c, sh.W, [&](int w, uint32_t mag, bool neg) {
-        size_t g = (size_t)w * sh.nb + (mag - 1);
-        uint32_t pos = starts[g] + msm_atomic_inc(cursor, g);
-        sorted[(size_t)w * sh.n + pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+    for_each_digit<NW>(s, sh.c, sh.Wd, [&](int w, uint32_t mag, bool neg) {
+        const size_t g = (sh.precomp ? (size_t)0 : (size_t)w * sh.nb) + (mag - 1);
+        const uint32_t pos = starts[g] + msm_atomic_inc(cursor, g);
+        const uint32_t ent = sh.precomp ? (uint32_t)w * sh.n + (uint32_t)i : (uint32_t)i;
+        sorted[pos] = ent | (neg ? 0x80000000u : 0u);
     });
 }
 
@@ -210,7 +244,7 @@ k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, uint32_t skip, uint
         lo = min(cnt, lane_sub[lane] * chunk);
         hi = min(cnt, lo + chunk);
     }
-    const uint32_t* list = sorted + (size_t)w * sh.n + starts[g];
+    const uint32_t* list = sorted + starts[g];
     XYZZ<F> acc;
     pt_set_inf(acc);
     if (WIDE) {
@@ -303,7 +337,7 @@ k_msm_giant(const uint32_t* __restrict__ giants, const uint32_t* __restrict__ me
 // (_reduceTable, min.js:1@74634); a GPU wants the shallowest dependency chain, because one XYZZ addition is ~9 us of
 // latency for a lone wave. Write b0 = r*C + c with C = 2^cbits columns and R = 2^rbits rows (rbits + cbits = c-1):
 //     S = C * sum_r r*Row_r + sum_c c*Col_c + sum_r Row_r,     Row_r = sum_c B[r*C+c],  Col_c = sum_r B[r*C+c].
-// k_msm_rowcol forms all Row/Col sums (MSM_RC_L lanes per sum: sequential partial sums, then a log2(L)-level butterfly);
+// k_msm_rowcol forms all Row/Col sums (L lanes per sum: sequential partial sums, then a log2(L)-level butterfly);
 // k_msm_wsum turns each length-C array into (sum_t t*X_t, sum_t X_t) with a suffix scan + tree in LDS. The host applies
 // the factor C (cbits doublings) when it folds the windows.  Several MSMs of the same shape are reduced in one launch.
 constexpr int MSM_MAX_BATCH = 4;
@@ -312,10 +346,9 @@ struct MsmReduceBatch {
     const uint32_t* counts[MSM_MAX_BATCH];
     int njobs;
 };
-constexpr int MSM_RC_L = 8;             // lanes per Row/Col sum: (cnt/L) sequential additions, then log2(L) butterfly steps
 template <class F, int TBR> __global__ void __launch_bounds__(TBR)
-k_msm_rowcol(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_t cbits, uint32_t* __restrict__ out) {
-    constexpr int PW = 4 * FieldWords<F>::value, L = MSM_RC_L;
+k_msm_rowcol(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_t cbits, uint32_t L, uint32_t* __restrict__ out) {
+    constexpr int PW = 4 * FieldWords<F>::value;     // L lanes per Row/Col sum (power of two <= 64): cnt/L sequential additions, then log2(L) butterfly steps
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t C = 1u << cbits, R = 1u << rbits;
     const uint32_t sub = threadIdx.x & (L - 1);
@@ -339,7 +372,7 @@ k_msm_rowcol(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_
     pt_store(my, acc);
     __syncthreads();
 #pragma unroll 1
-    for (int d = L / 2; d >= 1; d >>= 1) {
+    for (int d = (int)L / 2; d >= 1; d >>= 1) {
         if (sub < (uint32_t)d) { XYZZ<F> o; pt_load(o, my + (size_t)d * PW); acc = pt_add(acc, o); }
         __syncthreads();
         if (sub < (uint32_t)d) pt_store(my, acc);
@@ -399,6 +432,55 @@ k_msm_wsum(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ inR, u
         size_t o = (size_t)w * blocks_per_window + blk;
         pt_store(outA + o * PW, a);
         pt_store(outR + o * PW, myR);          // lane 0's suffix sum = total
+    }
+}
+
+// Alternative to k_msm_wsum when there are few arrays (pre-computed tables: one window): only PLAIN sums on the device,
+//   T_k = sum_{t : bit k of t set} X_t  (k < cbits)  and  T_cbits = sum_t X_t,
+// one block per (array, k); the host forms sum_t t*X_t = sum_k 2^k T_k by Horner (O(cbits) group operations). Depth on the
+// device = C/M sequential additions + log2(M) tree levels, with no doublings in the chain.
+template <class F, int M> __global__ void __launch_bounds__(M)
+k_msm_bitsums(const uint32_t* __restrict__ arr, uint32_t C, uint32_t cbits, uint32_t* __restrict__ out) {
+    constexpr int PW = 4 * FieldWords<F>::value;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t a = blockIdx.x / (cbits + 1), k = blockIdx.x % (cbits + 1), t = threadIdx.x;
+    XYZZ<F> acc;
+    pt_set_inf(acc);
+    for (uint32_t i = t; i < C; i += M)
+        if (k == cbits || ((i >> k) & 1u)) { XYZZ<F> p; pt_load(p, arr + ((size_t)a * C + i) * PW); acc = pt_add(acc, p); }
+    pt_store(lds + t * PW, acc);
+    __syncthreads();
+#pragma unroll 1
+    for (int d = M / 2; d >= 1; d >>= 1) {
+        if (t < (uint32_t)d) { XYZZ<F> o; pt_load(o, lds + (t + d) * PW); acc = pt_add(acc, o); pt_store(lds + t * PW, acc); }
+        __syncthreads();
+    }
+    if (t == 0) pt_store(out + (size_t)blockIdx.x * PW, acc);
+}
+
+// ---- pre-computed window tables for resident bases ------------------------------------------------------------------------
+// T[k][i] = 2^(c*k) * P_i in affine form, k < Wd. With the table every signed digit of a scalar lands in ONE set of 2^(c-1)
+// buckets, so c can grow (fewer digits per scalar => fewer mixed additions and fewer sort entries) without multiplying the
+// bucket-reduction work by the number of windows. One lane per point; one Fermat inversion per table entry (one-off per key).
+template <class F> __global__ void __launch_bounds__(256)
+k_msm_precompute(const uint32_t* __restrict__ bases, uint32_t n, int c, int Wd, uint32_t* __restrict__ table) {
+    constexpr int FW = FieldWords<F>::value;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p;
+    pt_load(p, bases + (size_t)i * 2 * FW);
+    f_store(table + (size_t)i * 2 * FW, p.x); f_store(table + (size_t)i * 2 * FW + FW, p.y);
+    const bool inf = pt_is_inf(p);
+    for (int k = 1; k < Wd; k++) {
+        uint32_t* dst = table + ((size_t)k * n + i) * 2 * FW;
+        if (!inf) {
+            XYZZ<F> q = pt_dbl_affine(p);
+            for (int d = 1; d < c; d++) q = pt_dbl(q);
+            // affine: 1/ZZ = (ZZ/ZZZ)^2 since ZZ^3 = ZZZ^2
+            F i3 = f_inv(q.ZZZ), i2 = f_sqr(f_mul(q.ZZ, i3));
+            p.x = f_mul(q.X, i2); p.y = f_mul(q.Y, i3);
+        }
+        f_store(dst, p.x); f_store(dst + FW, p.y);
     }
 }
 

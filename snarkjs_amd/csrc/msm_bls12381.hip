@@ -31,6 +31,10 @@ int msm_accumulate_bls12381(int group, const void* d_bases, const MsmPlan& pl, u
     if (group == 1) return msm_accumulate<Fp<Bls12381Fq>>(d_bases, pl, skip, job);
     return msm_accumulate<Fp2<Bls12381Fq>>(d_bases, pl, skip, job);
 }
+int msm_precompute_bls12381(int group, const void* d_bases, size_t n, int c, int Wd, void* d_table) {
+    if (group == 1) return msm_precompute<Fp<Bls12381Fq>>(d_bases, n, c, Wd, d_table);
+    return msm_precompute<Fp2<Bls12381Fq>>(d_bases, n, c, Wd, d_table);
+}
 int msm_reduce_bls12381(int group, MsmJob* const* jobs, int njobs) {
     if (group == 1) return msm_reduce<Fp<Bls12381Fq>>(jobs, njobs);
     return msm_reduce<Fp2<Bls12381Fq>>(jobs, njobs);

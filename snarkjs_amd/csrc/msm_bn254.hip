@@ -30,6 +30,10 @@ int msm_accumulate_bn254(int group, const void* d_bases, const MsmPlan& pl, uint
     if (group == 1) return msm_accumulate<Fp<Bn254Fq>>(d_bases, pl, skip, job);
     return msm_accumulate<Fp2<Bn254Fq>>(d_bases, pl, skip, job);
 }
+int msm_precompute_bn254(int group, const void* d_bases, size_t n, int c, int Wd, void* d_table) {
+    if (group == 1) return msm_precompute<Fp<Bn254Fq>>(d_bases, n, c, Wd, d_table);
+    return msm_precompute<Fp2<Bn254Fq>>(d_bases, n, c, Wd, d_table);
+}
 int msm_reduce_bn254(int group, MsmJob* const* jobs, int njobs) {
     if (group == 1) return msm_reduce<Fp<Bn254Fq>>(jobs, njobs);
     return msm_reduce<Fp2<Bn254Fq>>(jobs, njobs);

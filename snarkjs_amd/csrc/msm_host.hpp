@@ -15,7 +15,8 @@ static inline int ilog2_sz(size_t n) { int l = 0; while (((size_t)1 << (l + 1)) 
 static inline int msm_pick_c(size_t n) {
     int lg = ilog2_sz(n ? n : 1);
     if (lg < 62 && n > (((size_t)3) << lg) / 2) lg++;      // round to the nearest power of two (nVars is usually just below one)
-    static const int T[] = {2, 2, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9, 9, 10, 11, 11, 12, 13, 13, 14, 15, 15, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
+    // (17..21 use 15: see msm_precomp_c about the fill of the top digit window)
+    static const int T[] = {2, 2, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9, 9, 10, 11, 11, 12, 15, 15, 15, 15, 15, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
     return T[lg > 31 ? 31 : lg];
 }
 
@@ -98,11 +99,13 @@ struct MsmPlan {
     uint32_t *lane_g = nullptr, *lane_sub = nullptr, *meta = nullptr, *giants = nullptr;
 };
 constexpr int MSM_TB = 128, MSM_LOG_TB = 7;      // tree block: 128 lanes x 384 B (BLS12-381 G2 XYZZ) = 48 KiB of LDS
-int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan, int plan_slot = 0);
+// precomp_c != 0: the bases of every MSM run over this plan are pre-computed window tables built with that c
+int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan, int plan_slot = 0, int precomp_c = 0);
 
 // One MSM in flight: per-window sums land in a pinned host slot; msm_fold turns them into the Jacobian result.
 struct MsmJob {
     int W = 0, c = 0, cbits = 0, slot = 0;
+    int bitsums = 0;                                // h_win holds per (array, k) plain sums (k_msm_bitsums) instead of weighted sums
     uint32_t nb = 0;
     uint32_t* h_win = nullptr;                      // pinned host: 2W weighted sums then 2W totals (XYZZ)
     const uint32_t *buckets = nullptr, *counts = nullptr;   // device: this job's complete buckets (between accumulate and reduce)
@@ -175,11 +178,10 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
     const uint32_t m2 = (C + M - 1) / M;
     uint32_t *rc, *a0, *r0, *a1, *r1;
     ZK_TRY(ws_get("msm.rowcol", VW * C * PW * 4, (void**)&rc));
-    ZK_TRY(ws_get("msm.redA0", VW * m2 * PW * 4, (void**)&a0));
+    ZK_TRY(ws_get("msm.redA0", std::max<size_t>(VW * m2, VW * (cbits + 1)) * PW * 4, (void**)&a0));
     ZK_TRY(ws_get("msm.redR0", VW * m2 * PW * 4, (void**)&r0));
     ZK_TRY(ws_get("msm.redA1", VW * PW * 4, (void**)&a1));
     ZK_TRY(ws_get("msm.redR1", VW * PW * 4, (void**)&r1));
-    if ((size_t)W * 4 * PW * 4 > MSM_JOB_SLOT_BYTES) return fail(ZKMI_ERR_UNSUPPORTED, "msm: too many windows");
     static bool attr_set = false;
     const size_t lds_rc = (size_t)TBR * PW * 4, lds_ws = (size_t)2 * M * PW * 4;
     if (!attr_set) {
@@ -188,26 +190,45 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
         attr_set = true;
     }
     const size_t n_out = VW * C;
-    hipLaunchKernelGGL((k_msm_rowcol<F, TBR>), dim3((unsigned)((n_out + TBR / MSM_RC_L - 1) / (TBR / MSM_RC_L))), dim3(TBR), lds_rc, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
-    uint32_t m = C;
-    int log_scale = 0;
-    const uint32_t *inA = nullptr, *inR = rc;
-    uint32_t *outA = a0, *outR = r0;
-    for (;;) {
-        const uint32_t blocks = (m + M - 1) / M;
-        hipLaunchKernelGGL((k_msm_wsum<F, M>), dim3((unsigned)(VW * blocks)), dim3(M), lds_ws, st, inA, inR, m, blocks, log_scale, outA, outR);
-        inA = outA; inR = outR;
-        if (blocks == 1) break;
-        outA = (outA == a0) ? a1 : a0; outR = (outR == r0) ? r1 : r0;
-        m = blocks;
-        log_scale += ilog2_sz(M);
+    // lanes per row/column sum: ~16 sequential additions per lane, between 8 and 64 lanes
+    uint32_t L = 8;
+    while (L < 64 && (C / L) > 16) L <<= 1;
+    hipLaunchKernelGGL((k_msm_rowcol<F, TBR>), dim3((unsigned)((n_out + TBR / L - 1) / (TBR / L))), dim3(TBR), lds_rc, st, rb, (uint32_t)W, nb, rbits, cbits, L, rc);
+    const bool bitsums = VW * (cbits + 1) <= 256;            // few arrays (pre-computed tables): plain sums only, host does the weighting
+    const uint32_t* resA = nullptr;
+    const uint32_t* resR = nullptr;
+    size_t perA = 0;                                         // words per job in resA
+    if (bitsums) {
+        constexpr int MB = (PW * 4 * 256 <= 64 * 1024) ? 256 : 128;
+        static bool battr = false;
+        if (!battr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_bitsums<F, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MB * PW * 4))); battr = true; }
+        hipLaunchKernelGGL((k_msm_bitsums<F, MB>), dim3((unsigned)(VW * (cbits + 1))), dim3(MB), (size_t)MB * PW * 4, st, rc, C, cbits, a0);
+        resA = a0;
+        perA = (size_t)2 * W * (cbits + 1) * PW;
+    } else {
+        uint32_t m = C;
+        int log_scale = 0;
+        const uint32_t *inA = nullptr, *inR = rc;
+        uint32_t *outA = a0, *outR = r0;
+        for (;;) {
+            const uint32_t blocks = (m + M - 1) / M;
+            hipLaunchKernelGGL((k_msm_wsum<F, M>), dim3((unsigned)(VW * blocks)), dim3(M), lds_ws, st, inA, inR, m, blocks, log_scale, outA, outR);
+            inA = outA; inR = outR;
+            if (blocks == 1) break;
+            outA = (outA == a0) ? a1 : a0; outR = (outR == r0) ? r1 : r0;
+            m = blocks;
+            log_scale += ilog2_sz(M);
+        }
+        resA = inA; resR = inR;
+        perA = (size_t)2 * W * PW;
     }
     for (int i = 0; i < njobs; i++) {
         MsmJob& job = *jobs[i];
         job.cbits = (int)cbits;
-        const size_t per = (size_t)2 * W * PW;                              // words per job in inA / inR
-        ZK_HIP(hipMemcpyAsync(job.h_win, inA + (size_t)i * per, per * 4, hipMemcpyDeviceToHost, st));
-        ZK_HIP(hipMemcpyAsync(job.h_win + per, inR + (size_t)i * per, per * 4, hipMemcpyDeviceToHost, st));
+        job.bitsums = bitsums ? 1 : 0;
+        if (perA * 4 * 2 > MSM_JOB_SLOT_BYTES) return fail(ZKMI_ERR_UNSUPPORTED, "msm: too many windows");
+        ZK_HIP(hipMemcpyAsync(job.h_win, resA + (size_t)i * perA, perA * 4, hipMemcpyDeviceToHost, st));
+        if (!bitsums) ZK_HIP(hipMemcpyAsync(job.h_win + perA, resR + (size_t)i * perA, perA * 4, hipMemcpyDeviceToHost, st));
     }
     ZK_HIP(hipGetLastError());
     return ZKMI_OK;
@@ -215,7 +236,26 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
 // after the stream has been synchronised
 template <class F> void msm_fold(const MsmJob& job, uint8_t* out_jac) {
     constexpr int PW = 4 * FieldWords<F>::value;
-    msm_fold_windows<F>(job.h_win, job.h_win + (size_t)2 * job.W * PW, job.W, job.c, job.cbits, out_jac);
+    if (!job.bitsums) { msm_fold_windows<F>(job.h_win, job.h_win + (size_t)2 * job.W * PW, job.W, job.c, job.cbits, out_jac); return; }
+    // plain bit sums -> weighted sums by Horner on the host, laid out as msm_fold_windows expects
+    typedef typename HostOf<F>::FT FT;
+    host::HCurve<FT> cv{HostOf<F>::make()};
+    const int nb1 = job.cbits + 1;
+    std::vector<uint32_t> win((size_t)2 * job.W * PW), tot((size_t)2 * job.W * PW);
+    auto put = [&](uint32_t* dst, const typename host::HCurve<FT>::P& p) {      // Jacobian -> XYZZ words (ZZ = Z^2, ZZZ = Z^3)
+        constexpr int FW = FieldWords<F>::value;
+        if (cv.is_zero(p)) { memset(dst, 0, PW * 4); return; }
+        auto z2 = cv.F.sqr(p.Z), z3 = cv.F.mul(z2, p.Z);
+        memcpy(dst, &p.X, 4 * FW); memcpy(dst + FW, &p.Y, 4 * FW); memcpy(dst + 2 * FW, &z2, 4 * FW); memcpy(dst + 3 * FW, &z3, 4 * FW);
+    };
+    for (int a = 0; a < 2 * job.W; a++) {
+        const uint32_t* src = job.h_win + (size_t)a * nb1 * PW;
+        auto acc = cv.zero();
+        for (int k = job.cbits - 1; k >= 0; k--) { if (!cv.is_zero(acc)) acc = cv.dbl(acc); acc = cv.add(acc, xyzz_to_jac<F>(cv, src + (size_t)k * PW)); }
+        put(win.data() + (size_t)a * PW, acc);
+        memcpy(tot.data() + (size_t)a * PW, src + (size_t)job.cbits * PW, PW * 4);
+    }
+    msm_fold_windows<F>(win.data(), tot.data(), job.W, job.c, job.cbits, out_jac);
 }
 
 // Full device MSM: bases (affine, device), scalars (plain integers, device) -> Jacobian point on the host.
@@ -239,6 +279,26 @@ template <class F> int msm_run(const void* d_bases, const void* d_scalars, size_
     msm_fold<F>(job, out_jac);
     return ZKMI_OK;
 }
+
+// Window width and digit count of a pre-computed table for n resident bases and sb-byte scalars
+static inline int msm_precomp_c(size_t n) {
+    int lg = ilog2_sz(n ? n : 1);
+    if (lg < 62 && n > (((size_t)3) << lg) / 2) lg++;
+    int c = std::max(8, std::min(21, lg));
+    // 254/255-bit scalars: keep the top digit window well filled (a 2..7-bit top window funnels millions of scalars into a
+    // handful of buckets and serialises the sort's atomics): for large n snap to c in {15, 16, 17, 20}
+    if (lg >= 14) { static const int snap[] = {15, 15, 16, 17, 17, 20, 20, 20}; c = snap[std::min(std::max(c, 14), 21) - 14]; }
+    return c;
+}
+static inline int msm_digits(size_t sb, int c) { return (int)((8 * sb + 1 + c - 1) / c); }
+// d_table: Wd * n affine points (device). Built once per resident base set.
+template <class F> int msm_precompute(const void* d_bases, size_t n, int c, int Wd, void* d_table) {
+    Ctx& cx = ctx();
+    hipLaunchKernelGGL((k_msm_precompute<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cx.stream, (const uint32_t*)d_bases, (uint32_t)n, c, Wd, (uint32_t*)d_table);
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+}
+int msm_precompute_dispatch(int curve, int group, const void* d_bases, size_t n, int c, int Wd, void* d_table);
 
 // non-template entry points (msm_bn254.hip / msm_bls12381.hip) for callers that must not instantiate the kernels again
 int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job);

@@ -6,15 +6,18 @@
 namespace zkmi {
 
 template <int NW> static int msm_launch_digits(const uint8_t* d_scalars, const MsmShape& sh, uint32_t* counts, uint32_t* starts, uint32_t* cursor,
-                                               uint32_t* sorted, hipStream_t st) {
+                                               uint32_t* sorted, uint32_t* part, hipStream_t st) {
     const unsigned blocks = (unsigned)((sh.n + 255) / 256);
     hipLaunchKernelGGL((k_msm_count<NW>), dim3(blocks), dim3(256), 0, st, d_scalars, sh, counts);
-    hipLaunchKernelGGL(k_msm_scan, dim3(sh.W), dim3(1024), 0, st, counts, starts, sh.nb);
+    const uint32_t total = (uint32_t)sh.W * sh.nb, nparts = (total + MSM_SCAN_CHUNK - 1) / MSM_SCAN_CHUNK;
+    hipLaunchKernelGGL(k_msm_scan_sums, dim3(nparts), dim3(256), 0, st, counts, total, part);
+    hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, st, part, nparts);
+    hipLaunchKernelGGL(k_msm_scan_final, dim3(nparts), dim3(256), 0, st, counts, total, part, starts);
     hipLaunchKernelGGL((k_msm_scatter<NW>), dim3(blocks), dim3(256), 0, st, d_scalars, sh, starts, cursor, sorted);
     return ZKMI_OK;
 }
 
-int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_slot) {
+int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_slot, int precomp_c) {
     Ctx& cx = ctx();
     pl.slot = plan_slot & 1;
     const std::string sfx = pl.slot ? ".p1" : ".p0";
@@ -22,9 +25,12 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     if (sb == 0 || sb > 64) return fail(ZKMI_ERR_UNSUPPORTED, "msm: scalar size must be 1..64 bytes");
     MsmShape& sh = pl.sh;
     sh.n = (uint32_t)n; sh.sb = (int)sb;
-    sh.c = cx.msm_c_override ? cx.msm_c_override : msm_pick_c(n);
-    sh.W = (int)((8 * sb + 1 + sh.c - 1) / sh.c);
+    sh.precomp = precomp_c ? 1 : 0;
+    sh.c = precomp_c ? precomp_c : (cx.msm_c_override ? cx.msm_c_override : msm_pick_c(n));
+    sh.Wd = msm_digits(sb, sh.c);
+    sh.W = sh.precomp ? 1 : sh.Wd;
     sh.nb = 1u << (sh.c - 1);
+    if (sh.precomp && (size_t)sh.Wd * n >= (1ull << 31)) return fail(ZKMI_ERR_UNSUPPORTED, "msm: pre-computed table too large for 31-bit indices");
     const size_t total = (size_t)sh.W * sh.nb;
     pl.total = total;
     hipStream_t st = cx.stream;
@@ -32,17 +38,17 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     ZK_TRY(ws_get("msm.counts" + sfx, 3 * total * 4, (void**)&counts));        // counts | starts | cursor
     pl.counts = counts; pl.starts = counts + total;
     uint32_t* cursor = pl.starts + total;
-    ZK_TRY(ws_get("msm.sorted" + sfx, (size_t)sh.W * n * 4, (void**)&pl.sorted));
+    ZK_TRY(ws_get("msm.sorted" + sfx, (size_t)sh.Wd * n * 4, (void**)&pl.sorted));
     // lane-group schedule (k_msm_classify/_class_scan/_assign)
     // cap: points per lane. Large MSMs are ALU-bound: one lane per typical bucket (cap = pow2ceil(2 * average size)) keeps
     // the combine tree idle; small MSMs are latency-bound: shrink cap until ~250k lanes exist.
-    const size_t avg = (n + sh.nb - 1) / sh.nb;
+    const size_t avg = ((size_t)(sh.precomp ? sh.Wd : 1) * n + sh.nb - 1) / sh.nb;
     uint32_t cap_big = 16, cap_fill = 8;
     while (cap_big < 2 * avg && cap_big < MSM_MAX_CAP) cap_big <<= 1;
-    while ((size_t)2 * cap_fill <= (size_t)sh.W * n / 250000 && cap_fill < MSM_MAX_CAP) cap_fill <<= 1;
+    while ((size_t)2 * cap_fill <= (size_t)sh.Wd * n / 250000 && cap_fill < MSM_MAX_CAP) cap_fill <<= 1;
     const uint32_t cap = std::min(cap_big, cap_fill);
     pl.cap = cap;
-    pl.multi_bound = (size_t)sh.W * n / cap + 1;                          // lanes of multi-lane groups: sum 2^floor(log2(cnt/cap))
+    pl.multi_bound = (size_t)sh.Wd * n / cap + 1;                          // lanes of multi-lane groups: sum 2^floor(log2(cnt/cap))
     pl.lane_bound = total + pl.multi_bound;
     ZK_TRY(ws_get("msm.lanes" + sfx, 2 * pl.lane_bound * 4, (void**)&pl.lane_g));
     pl.lane_sub = pl.lane_g + pl.lane_bound;
@@ -53,9 +59,11 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     ZK_HIP(hipMemsetAsync(counts, 0, 3 * total * 4, st));
     ZK_HIP(hipMemsetAsync(hist, 0, (3 * MSM_NKEYS + 8) * 4, st));
     const uint8_t* sc = (const uint8_t*)d_scalars;
-    if (sb <= 4) msm_launch_digits<1>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, st);
-    else if (sb <= 32) msm_launch_digits<8>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, st);
-    else msm_launch_digits<16>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, st);
+    uint32_t* part;
+    ZK_TRY(ws_get("msm.scanpart" + sfx, (total / MSM_SCAN_CHUNK + 2) * 4, (void**)&part));
+    if (sb <= 4) msm_launch_digits<1>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, st);
+    else if (sb <= 32) msm_launch_digits<8>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, st);
+    else msm_launch_digits<16>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, st);
     const unsigned tb = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(k_msm_classify, dim3(tb), dim3(256), 0, st, pl.counts, (uint32_t)total, cap, hist);
     hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(64), 0, st, hist, koff, pl.meta, cap);

@@ -62,6 +62,8 @@ int msm_bls12381(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_accumulate_bn254(int group, const void*, const MsmPlan&, uint32_t, MsmJob&);
 int msm_accumulate_bls12381(int group, const void*, const MsmPlan&, uint32_t, MsmJob&);
 int msm_reduce_bn254(int group, MsmJob* const*, int);
+int msm_precompute_bn254(int group, const void*, size_t, int, int, void*);
+int msm_precompute_bls12381(int group, const void*, size_t, int, int, void*);
 int msm_reduce_bls12381(int group, MsmJob* const*, int);
 int msm_fold_bn254(int group, const MsmJob&, uint8_t*);
 int msm_fold_bls12381(int group, const MsmJob&, uint8_t*);
@@ -84,6 +86,10 @@ int msm_dev_dispatch(int curve, int group, const void* d_bases, const void* d_sc
 int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job) {
     ZK_TRY(check_cg(curve, group));
     return curve == ZKMI_CURVE_BN128 ? msm_accumulate_bn254(group, d_bases, pl, skip, job) : msm_accumulate_bls12381(group, d_bases, pl, skip, job);
+}
+int msm_precompute_dispatch(int curve, int group, const void* d_bases, size_t n, int c, int Wd, void* d_table) {
+    ZK_TRY(check_cg(curve, group));
+    return curve == ZKMI_CURVE_BN128 ? msm_precompute_bn254(group, d_bases, n, c, Wd, d_table) : msm_precompute_bls12381(group, d_bases, n, c, Wd, d_table);
 }
 int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs) {
     ZK_TRY(check_cg(curve, group));
