@@ -32,7 +32,7 @@ def cpu_baseline(log_n_sample, log_n_full):
     import oracle_lib as O
     import synth_zkey
     from snarkjs_amd import binfile
-    zkey, wtns = synth_zkey.make("bn128", log_n_sample, seed=0xBA5E, witness="uniform")
+    zkey, wtns = synth_zkey.make("bn128", log_n_sample, seed=0xBA5E, witness="uniform")    # cpu baseline is quoted on the BN254 workload
     zk, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)["witness"]
     r_m, s_m = O.fr_e(0, 0x1234567), O.fr_e(0, 0x7654321)
     t0 = time.perf_counter()
@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--cpu-log-n", type=int, default=14)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--witness", default="uniform", choices=["uniform", "mixed"])
+    ap.add_argument("--curve", default="bn128", choices=["bn128", "bls12381"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -74,12 +75,14 @@ def main():
     L = zkmi.lib()
 
     lg = args.log_n
-    zkey, wtns = synth_zkey.make("bn128", lg, seed=0x5EED + rank, witness=args.witness)
+    zkey, wtns = synth_zkey.make(args.curve, lg, seed=0x5EED + rank, witness=args.witness)
+    cid = 0 if args.curve == "bn128" else 1
+    q8 = 32 if cid == 0 else 48
     pk = groth16.ProvingKey(zkey)
     zk = pk.zk
     w = binfile.read_wtns(wtns)["witness"]
     d_w = zkmi.DeviceBuffer.from_host(w)
-    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    R = synth_zkey.PRIMES[args.curve][2]
     mont = lambda v: np.frombuffer(((v << 256) % R).to_bytes(32, "little"), np.uint8).copy()
     r_m, s_m = mont(0x1234567), mont(0x7654321)
 
@@ -114,26 +117,28 @@ def main():
     if rank == 0:
         # ---- sub-metrics (outside the timed region): G1 MSM and NTT at the same size, device-event time ----
         n = 1 << lg
-        d_b = zkmi.DeviceBuffer(n * 64)
-        zkmi.check(L.zkmi_gen_geometric_bases_dev(0, 1, n, 7, 11, d_b.ptr))
+        d_b = zkmi.DeviceBuffer(n * 2 * q8)
+        zkmi.check(L.zkmi_gen_geometric_bases_dev(cid, 1, n, 7, 11, d_b.ptr))
         d_s = zkmi.DeviceBuffer.from_host(synth.elems(0x5EED, n))
-        jac = np.zeros(96, np.uint8)
+        jac = np.zeros(3 * q8, np.uint8)
         ts, ta = [], []
         for _ in range(4):
-            zkmi.check(L.zkmi_msm_dev(0, 1, d_b.ptr, d_s.ptr, n, 32, zkmi.ptr(jac)))
+            zkmi.check(L.zkmi_msm_dev(cid, 1, d_b.ptr, d_s.ptr, n, 32, zkmi.ptr(jac)))
             ts.append(L.zkmi_last_kernel_ms()); ta.append(L.zkmi_msm_accum_ms(0))
         msm_ms, msm_acc_ms = min(ts[1:]), min(ta[1:])
         d_o = zkmi.DeviceBuffer(n * 32)
         tn = []
         for _ in range(5):
-            zkmi.check(L.zkmi_ntt_dev(0, d_s.ptr, d_o.ptr, lg, 0, None, None))
+            zkmi.check(L.zkmi_ntt_dev(cid, d_s.ptr, d_o.ptr, lg, 0, None, None))
             tn.append(L.zkmi_last_kernel_ms())
         ntt_ms = min(tn[1:])
         # ---- roofline of the dominant kernel: bucket accumulation of the G2 MSM (B2) ----
         m = zk["nVars"]
         acc = {k: float(np.mean(v)) for k, v in accum_ms.items()}
-        names = {0: ("k_msm_accum<Fp<Bn254Fq>> (A)", 96), 1: ("k_msm_accum<Fp<Bn254Fq>> (B1)", 96), 2: ("k_msm_accum<Fp2<Bn254Fq>> (B2)", 160),
-                 3: ("k_msm_accum<Fp<Bn254Fq>> (C)", 96), 4: ("k_msm_accum<Fp<Bn254Fq>> (H)", 96)}
+        fq = "Bn254Fq" if cid == 0 else "Bls12381Fq"
+        b1, b2 = 2 * q8 + 32, 4 * q8 + 32                     # affine base + 32-byte scalar per term
+        names = {0: (f"k_msm_accum<Fp<{fq}>> (A)", b1), 1: (f"k_msm_accum<Fp<{fq}>> (B1)", b1), 2: (f"k_msm_accum<Fp2<{fq}>> (B2)", b2),
+                 3: (f"k_msm_accum<Fp<{fq}>> (C)", b1), 4: (f"k_msm_accum<Fp<{fq}>> (H)", b1)}
         dom = max(acc, key=lambda k: acc[k])
         units = {0: m, 1: m, 2: m, 3: m - zk["nPublic"] - 1, 4: zk["domainSize"]}[dom]
         alg_bytes = names[dom][1] * units                      # B/term (affine base + 32-B scalar) x terms
@@ -153,11 +158,11 @@ def main():
             "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"BN254 Groth16 prove, 2^{lg} constraints, synthetic zkey/wtns (BASELINE configs[1]); key + witness resident in HBM",
-                       "curve": "bn128", "log_n": lg, "n_vars": m, "n_coef": int((zk['coeffs'].size - 4) // 44), "witness": args.witness,
+            "config": {"workload": f"{'BN254' if cid == 0 else 'BLS12-381'} Groth16 prove, 2^{lg} constraints, synthetic zkey/wtns (BASELINE configs[{1 if (cid == 0 and lg == 20) else (2 if cid == 0 else 4)}]); key + witness resident in HBM",
+                       "curve": args.curve, "log_n": lg, "n_vars": m, "n_coef": int((zk['coeffs'].size - 4) // 44), "witness": args.witness,
                        "parallelism": f"replica x{world} (one proof stream per GPU)"},
             "submetrics": {"g1_msm_mscalar_per_s": round(n / msm_ms / 1e3, 2), "g1_msm_ms": round(msm_ms, 4), "g1_msm_accum_kernel_ms": round(msm_acc_ms, 4),
-                           "g1_msm_hbm_frac": round(96 * n / (msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                           "g1_msm_hbm_frac": round((2 * q8 + 32) * n / (msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                            "ntt_melem_per_s": round(n / ntt_ms / 1e3, 2), "ntt_ms": round(ntt_ms, 4),
                            "ntt_hbm_frac": round(64 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},

@@ -193,7 +193,25 @@ template <class F, int T> ZK_DEV void pt_madd_lds(const LdsAcc<F, T>& A, bool& i
     A.get(1, t);
     A.put(1, f_sub(f_mul(R, f_sub(Q, X3)), f_mul(t, PPP)));
 }
-// full addition (EFD add-2008-s: 12M + 2S) with all special cases
+// full addition (EFD add-2008-s: 12M + 2S) with all special cases; inlined flavour for throughput-bound loops
+template <class F> ZK_DEV XYZZ<F> pt_add_inl(const XYZZ<F>& a, const XYZZ<F>& b) {
+    if (pt_is_inf(a)) return b;
+    if (pt_is_inf(b)) return a;
+    F U1 = f_mul(a.X, b.ZZ), U2 = f_mul(b.X, a.ZZ), S1 = f_mul(a.Y, b.ZZZ), S2 = f_mul(b.Y, a.ZZZ);
+    F P = f_sub(U2, U1), R = f_sub(S2, S1);
+    if (f_is_zero(P)) {
+        if (f_is_zero(R)) return pt_dbl(a);
+        XYZZ<F> z; pt_set_inf(z); return z;
+    }
+    XYZZ<F> r;
+    F PP = f_sqr(P), PPP = f_mul(P, PP), Q = f_mul(U1, PP);
+    r.X = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
+    r.Y = f_sub(f_mul(R, f_sub(Q, r.X)), f_mul(S1, PPP));
+    r.ZZ = f_mul(f_mul(a.ZZ, b.ZZ), PP);
+    r.ZZZ = f_mul(f_mul(a.ZZZ, b.ZZZ), PPP);
+    return r;
+}
+// out-of-line flavour for latency-bound code (LDS trees, scans): keeps code size and compile time bounded
 template <class F> __device__ __noinline__ XYZZ<F> pt_add(const XYZZ<F>& a, const XYZZ<F>& b) {
     if (pt_is_inf(a)) return b;
     if (pt_is_inf(b)) return a;

@@ -346,39 +346,42 @@ struct MsmReduceBatch {
     const uint32_t* counts[MSM_MAX_BATCH];
     int njobs;
 };
-template <class F, int TBR> __global__ void __launch_bounds__(TBR)
+// Stage 1 of the Row/Col sums: L lanes per sum, each adds its share (cnt/L strided elements) and writes ONE partial — every
+// lane does useful additions (a butterfly inside the wave would run at full wave cost with 32, 16, 8 ... lanes active).
+// k_msm_fold then reduces the L partials of each sum K at a time.
+template <class F> __global__ void __launch_bounds__(256)
 k_msm_rowcol(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_t cbits, uint32_t L, uint32_t* __restrict__ out) {
-    constexpr int PW = 4 * FieldWords<F>::value;     // L lanes per Row/Col sum (power of two <= 64): cnt/L sequential additions, then log2(L) butterfly steps
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr int PW = 4 * FieldWords<F>::value;
     const uint32_t C = 1u << cbits, R = 1u << rbits;
-    const uint32_t sub = threadIdx.x & (L - 1);
-    const size_t gw = (size_t)blockIdx.x * (TBR / L) + threadIdx.x / L;     // output index: ((job*W + w)*2 + kind)*C + i
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sub = (uint32_t)(tid & (L - 1));
+    const size_t gw = tid / L;                                              // sum index: ((job*W + w)*2 + kind)*C + i
     const size_t n_out = (size_t)rb.njobs * W * 2 * C;
+    if (gw >= n_out) return;
     XYZZ<F> acc;
     pt_set_inf(acc);
-    if (gw < n_out) {
-        const uint32_t i = (uint32_t)(gw & (C - 1)), kind = (uint32_t)(gw >> cbits) & 1u;
-        const size_t jw = gw >> (cbits + 1);
-        const uint32_t job = (uint32_t)(jw / W), w = (uint32_t)(jw % W);
-        const uint32_t* bk = rb.buckets[job];
-        const uint32_t* cn = rb.counts[job];
-        const uint32_t cnt = kind ? R : ((i < R) ? C : 0u);
-        for (uint32_t e = sub; e < cnt; e += L) {
-            const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
-            if (cn[g]) { XYZZ<F> p; pt_load(p, bk + g * PW); acc = pt_add(acc, p); }      // empty buckets were never written
-        }
+    const uint32_t i = (uint32_t)(gw & (C - 1)), kind = (uint32_t)(gw >> cbits) & 1u;
+    const size_t jw = gw >> (cbits + 1);
+    const uint32_t job = (uint32_t)(jw / W), w = (uint32_t)(jw % W);
+    const uint32_t* bk = rb.buckets[job];
+    const uint32_t* cn = rb.counts[job];
+    const uint32_t cnt = kind ? R : ((i < R) ? C : 0u);
+    for (uint32_t e = sub; e < cnt; e += L) {
+        const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
+        if (cn[g]) { XYZZ<F> p; pt_load(p, bk + g * PW); acc = pt_add(acc, p); }      // empty buckets were never written
     }
-    uint32_t* my = lds + (size_t)threadIdx.x * PW;
-    pt_store(my, acc);
-    __syncthreads();
-#pragma unroll 1
-    for (int d = (int)L / 2; d >= 1; d >>= 1) {
-        if (sub < (uint32_t)d) { XYZZ<F> o; pt_load(o, my + (size_t)d * PW); acc = pt_add(acc, o); }
-        __syncthreads();
-        if (sub < (uint32_t)d) pt_store(my, acc);
-        __syncthreads();
-    }
-    if (sub == 0 && gw < n_out) pt_store(out + gw * PW, acc);
+    pt_store(out + tid * PW, acc);
+}
+// out[i] = sum_{k<K} in[i*K + k]
+template <class F> __global__ void __launch_bounds__(256)
+k_msm_fold(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n_out, uint32_t K) {
+    constexpr int PW = 4 * FieldWords<F>::value;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    XYZZ<F> acc;
+    pt_load(acc, in + i * K * PW);
+    for (uint32_t k = 1; k < K; k++) { XYZZ<F> p; pt_load(p, in + (i * K + k) * PW); acc = pt_add(acc, p); }
+    pt_store(out + i * PW, acc);
 }
 // One block of M lanes per M consecutive items of an array of m_per_array points; invariant across levels:
 //   weighted = sum_t A_t + scale * sum_t t*X_t,  total = sum_t X_t   (level 0: A absent, scale 1).

@@ -173,7 +173,6 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
     }
     const uint32_t rbits = (uint32_t)(c - 1) / 2, cbits = (uint32_t)(c - 1) - rbits, C = 1u << cbits;
     const size_t VW = (size_t)njobs * W * 2;                           // arrays of C points: (job, window, row|col)
-    constexpr int TBR = (PW * 4 * 256 <= 64 * 1024) ? 256 : 128;       // k_msm_rowcol block (LDS: one point per lane)
     constexpr int M = (PW * 4 * 2 * 256 <= 128 * 1024) ? 256 : 128;    // k_msm_wsum: 2 LDS arrays of M points
     const uint32_t m2 = (C + M - 1) / M;
     uint32_t *rc, *a0, *r0, *a1, *r1;
@@ -183,17 +182,34 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
     ZK_TRY(ws_get("msm.redA1", VW * PW * 4, (void**)&a1));
     ZK_TRY(ws_get("msm.redR1", VW * PW * 4, (void**)&r1));
     static bool attr_set = false;
-    const size_t lds_rc = (size_t)TBR * PW * 4, lds_ws = (size_t)2 * M * PW * 4;
+    const size_t lds_ws = (size_t)2 * M * PW * 4;
     if (!attr_set) {
-        ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol<F, TBR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rc));
         ZK_HIP(hipFuncSetAttribute((const void*)k_msm_wsum<F, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
         attr_set = true;
     }
     const size_t n_out = VW * C;
-    // lanes per row/column sum: ~16 sequential additions per lane, between 8 and 64 lanes
-    uint32_t L = 8;
-    while (L < 64 && (C / L) > 16) L <<= 1;
-    hipLaunchKernelGGL((k_msm_rowcol<F, TBR>), dim3((unsigned)((n_out + TBR / L - 1) / (TBR / L))), dim3(TBR), lds_rc, st, rb, (uint32_t)W, nb, rbits, cbits, L, rc);
+    // Row/Col sums in stages: L lanes per sum (~16 additions each), then folds of 8 partials at a time
+    // (Fq2 additions are ~50 us of latency each and the total work is small: spread wider and fold 4 at a time)
+    constexpr bool WIDE_R = FW > 12;
+    const uint32_t seq = WIDE_R ? 4 : 16, maxL = WIDE_R ? 256 : 64, foldK = WIDE_R ? 4 : 8;
+    uint32_t L = 1;
+    while (L < maxL && (C / L) > seq) L <<= 1;
+    uint32_t *p0, *p1;
+    ZK_TRY(ws_get("msm.rcpart0", n_out * L * PW * 4, (void**)&p0));
+    ZK_TRY(ws_get("msm.rcpart1", std::max<size_t>(n_out * L / 4, 1) * PW * 4, (void**)&p1));
+    {
+        uint32_t* dst = L == 1 ? rc : p0;
+        hipLaunchKernelGGL((k_msm_rowcol<F>), dim3((unsigned)((n_out * L + 255) / 256)), dim3(256), 0, st, rb, (uint32_t)W, nb, rbits, cbits, L, dst);
+        uint32_t parts = L;
+        const uint32_t* src = dst;
+        while (parts > 1) {
+            const uint32_t K = std::min<uint32_t>(parts, foldK);
+            parts /= K;
+            uint32_t* d2 = parts == 1 ? rc : (src == p0 ? p1 : p0);
+            hipLaunchKernelGGL((k_msm_fold<F>), dim3((unsigned)((n_out * parts + 255) / 256)), dim3(256), 0, st, src, d2, n_out * parts, K);
+            src = d2;
+        }
+    }
     const bool bitsums = VW * (cbits + 1) <= 256;            // few arrays (pre-computed tables): plain sums only, host does the weighting
     const uint32_t* resA = nullptr;
     const uint32_t* resR = nullptr;
