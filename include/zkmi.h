@@ -65,6 +65,9 @@ int zkmi_dev_alloc(size_t bytes, void** d_ptr);
 int zkmi_dev_free(void* d_ptr);
 int zkmi_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int zkmi_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+/* stream-ordered device-to-device copy / fill on the library stream */
+int zkmi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes);
+int zkmi_memset_dev(void* d_dst, int value, size_t bytes);
 
 /* ---- G.multiExpAffine ------------------------------------------------------------------------------------------- */
 /* curve.G1.multiExpAffine / curve.G2.multiExpAffine (min.js:1@214996 -> @214651 -> _multiExpChunk @213360; kernel
@@ -141,6 +144,45 @@ int zkmi_groth16_release(uint64_t zkey_cache_key);
  * Writes min(n, ZKMI_GROTH16_STAGES) values. */
 #define ZKMI_GROTH16_STAGES 11
 int zkmi_groth16_stage_ms(double* out, int n);
+
+/* ---- PLONK prover: the per-element loops of src/plonk_prove.js and src/polynomial/polynomial.js as device kernels ---------
+ * (SURVEY.md 8a rows a10-a12). All buffers are DEVICE pointers to Montgomery Fr elements; 32-byte constants are host
+ * pointers (Montgomery). Polynomial lengths are in elements. */
+/* Fr.w[i] (min.js:1@185893), needs no device */
+int zkmi_fr_root(int curve, unsigned i, uint8_t* out32);
+/* computeWirePolynomials gather (plonk_prove.js:267-283): A/B/C[i] = getWitness(map[i]) for i < n_constraints, 0 up to domain.
+ * d_witness: n_witness elements (normal form, witness[0] already zeroed, :94-96); d_internal: the n_additions internal
+ * signals (:174-204); maps are u32 arrays. Output is in the witness's (normal) form: run batchToMontgomery next (:285-287). */
+int zkmi_plonk_gather_wires_dev(int curve, const void* d_witness, uint32_t n_witness, const void* d_internal, uint32_t n_additions,
+                                const void* d_map_a, const void* d_map_b, const void* d_map_c, uint32_t n_constraints, uint32_t domain,
+                                void* d_a, void* d_b, void* d_c);
+/* computeZ (plonk_prove.js:361-455): grand-product evaluations Z[0..domain) from the wire buffers (Montgomery) and the 4n
+ * sigma evaluations (sampled at stride 4). Fails with "Copy constraints does not match" if Z[0] != 1. w_n = Fr.w[power]. */
+int zkmi_plonk_compute_z_dev(int curve, const void* d_a, const void* d_b, const void* d_c, const void* d_s1e, const void* d_s2e,
+                             const void* d_s3e, uint32_t domain, const uint8_t* beta, const uint8_t* gamma, const uint8_t* k1,
+                             const uint8_t* k2, const uint8_t* w_n, void* d_z);
+/* computeT (plonk_prove.js:516-628 with MulZ.mul2/mul4, mul_z.js:49-148): T and Tz over the 4n extended evaluation points.
+ * lagrange = zkey section 13 on the device (per public input: n coefficients then 4n evaluations); pub_a = buffers.A. */
+typedef struct zkmi_plonk_evals {
+    const void *a, *b, *c, *z, *qm, *ql, *qr, *qo, *qc, *s1, *s2, *s3;     /* 4n evaluations each */
+    const void* lagrange;
+    const void* pub_a;
+} zkmi_plonk_evals;
+int zkmi_plonk_compute_t_dev(int curve, const zkmi_plonk_evals* ev, uint32_t domain, uint32_t n_public, const uint8_t* blind11 /* b1..b11 */,
+                             const uint8_t* beta, const uint8_t* gamma, const uint8_t* alpha, const uint8_t* k1, const uint8_t* k2,
+                             const uint8_t* w_n, const uint8_t* w_4n, const uint8_t* w_2, void* d_t, void* d_tz);
+/* Polynomial.add / sub with optional blinding value (polynomial.js:218-276): y[i] = y[i] +/- k*x[i], i < nx (k NULL = 1) */
+int zkmi_poly_axpy_dev(int curve, void* d_y, const void* d_x, size_t nx, const uint8_t* k, int subtract);
+/* Polynomial.mulScalar (:278-284) */
+int zkmi_poly_scale_dev(int curve, void* d_p, size_t n, const uint8_t* k);
+/* Polynomial.evaluate (Horner, :174-184) as a parallel reduction; out = 32 bytes (host) */
+int zkmi_poly_evaluate_dev(int curve, const void* d_p, size_t n, const uint8_t* x, uint8_t* out);
+/* *all_zero = 1 iff p[0..n) are all zero (degree checks, plonk_prove.js:298-306, :645-647) */
+int zkmi_poly_is_zero_dev(int curve, const void* d_p, size_t n, int* all_zero);
+/* Polynomial.divZh(domainSize, extensions) (:592-615), in place; "Polynomial is not divisible" on a non-zero tail */
+int zkmi_poly_div_zh_dev(int curve, void* d_p, size_t len, uint32_t domain, uint32_t extensions);
+/* Polynomial.divByZerofier(n, beta) (:617-674), in place; n = 1 only (PLONK openings; FFLONK's n > 1 is not built yet) */
+int zkmi_poly_div_by_zerofier_dev(int curve, void* d_p, size_t len, uint32_t n, const uint8_t* beta);
 
 /* ---- utilities --------------------------------------------------------------------------------------------------- */
 /* Synthetic base table of SURVEY.md §8d: P_i = (f*g^i mod r)*G written to device memory as affine Montgomery points

@@ -160,11 +160,48 @@ async function groth16Golden() {
     console.log('groth16 golden done: proof sha', sha(JSON.stringify(proof)), 'verify', ok);
 }
 
+// Seeded PLONK fixtures: plonk.setup on two circuits of the reference's test tree with the same seeded ptau, then a seeded
+// plonk.prove whose 11 blinding draws (src/plonk_prove.js:224-227) and Fiat-Shamir challenges are recorded.
+async function plonkGolden() {
+    const curve = await snarkjs.curves.getCurveFromName('bn128');
+    const mem = () => ({ type: 'mem' });
+    const p0 = mem(), p1 = mem(), pf = mem();
+    await snarkjs.powersOfTau.newAccumulator(curve, 12, p0);
+    await snarkjs.powersOfTau.contribute(p0, p1, 'C1', 'Entropy1');
+    await snarkjs.powersOfTau.preparePhase2(p1, pf);
+    const cases = [['plonk_bn128_small', '/root/reference/test/plonk_circuit/', JSON.parse(fs.readFileSync('/root/reference/test/plonk_circuit/input.json'))],
+                   ['plonk_bn128_n2048', '/root/reference/test/groth16/', { a: 11, b: 2 }]];
+    for (const [tag, T, input] of cases) {
+        const z = mem(), w = mem();
+        await snarkjs.plonk.setup(new Uint8Array(fs.readFileSync(T + 'circuit.r1cs')), pf, z);
+        await snarkjs.wtns.calculate(input, new Uint8Array(fs.readFileSync(T + 'circuit.wasm')), w);
+        const rnd = [], Fr = curve.Fr, census = {};
+        const origRandom = Fr.random.bind(Fr); Fr.random = () => { const v = origRandom(); rnd.push(hex(v)); return v; };
+        const undo = [];
+        for (const [obj, nm] of [[Fr, 'fft'], [Fr, 'ifft'], [Fr, 'batchToMontgomery'], [Fr, 'batchFromMontgomery'], [Fr, 'batchInverse'], [curve.G1, 'multiExpAffine']]) {
+            const o = obj[nm]; undo.push([obj, nm, o]);
+            obj[nm] = async function (...a) { census[nm] = (census[nm] || 0) + 1; return o.apply(obj, a); };
+        }
+        const { proof, publicSignals } = await snarkjs.plonk.prove(z.data, w.data);
+        for (const [o, nm, f] of undo) o[nm] = f; Fr.random = origRandom;
+        const vk = await snarkjs.zKey.exportVerificationKey(z.data);
+        const ok = await snarkjs.plonk.verify(vk, publicSignals, proof);
+        if (!ok) throw new Error('golden plonk proof does not verify');
+        fs.writeFileSync(path.join(OUT, `${tag}.zkey`), z.data);
+        fs.writeFileSync(path.join(OUT, `${tag}.wtns`), w.data);
+        fs.writeFileSync(path.join(OUT, `${tag}.json`), JSON.stringify({
+            zkey_sha256: sha(z.data), wtns_sha256: sha(w.data), proof_sha256: sha(JSON.stringify(proof)), blinding_mont: rnd, proof, publicSignals,
+            verified: ok, vk, census }, null, 1));
+        console.log(tag, 'plonk golden done: zkey', z.data.length, 'bytes, proof sha', sha(JSON.stringify(proof)), 'verify', ok);
+    }
+}
+
 (async () => {
     fs.mkdirSync(OUT, { recursive: true });
     const what = process.argv[2] || 'all';
     if (what === 'all' || what === 'bn128') await kernelVectors('bn128', 'bn128');
     if (what === 'all' || what === 'bls12381') await kernelVectors('bls12381', 'bls12381');
     if (what === 'all' || what === 'groth16') await groth16Golden();
+    if (what === 'all' || what === 'plonk') await plonkGolden();
     process.exit(0);
 })().catch(e => { console.error(e); process.exit(1); });

@@ -213,6 +213,12 @@ template <class C> static int apply_key_run(const void* d_in, void* d_out, size_
     ZK_HIP(hipGetLastError());
     return ZKMI_OK;
 }
+int fr_root(int curve, unsigned i, uint8_t* out32) {
+    const FrRoots& R = (curve == ZKMI_CURVE_BN128) ? fr_roots<Bn254Fr>() : fr_roots<Bls12381Fr>();
+    if ((int)i > R.s) return fail(ZKMI_ERR_INVALID, "root index exceeds the 2-adicity of Fr");
+    memcpy(out32, R.w[i].v, 32);
+    return ZKMI_OK;
+}
 int fr_coset_inc(int curve, unsigned power, uint8_t* out32) {
     const FrRoots& R = (curve == ZKMI_CURVE_BN128) ? fr_roots<Bn254Fr>() : fr_roots<Bls12381Fr>();
     if ((int)power > R.s) return fail(ZKMI_ERR_UNSUPPORTED, "domain exceeds the 2-adicity of Fr");

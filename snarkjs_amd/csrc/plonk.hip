@@ -1,0 +1,536 @@
+// snarkjs_amd/csrc/plonk.hip — device kernels for the per-element loops of the PLONK prover.
+//
+// In the reference these are single-threaded JavaScript loops calling Fr.mul / Fr.add on 32-byte slices
+// (src/plonk_prove.js, src/mul_z.js, src/polynomial/polynomial.js); here each is a data-parallel kernel over Fr:
+//   computeWirePolynomials gather  (plonk_prove.js:267-283)   k_plonk_gather
+//   computeZ                       (plonk_prove.js:361-455)   k_plonk_z_factors + multiplicative scan + batch inverse
+//   computeT + MulZ.mul2/mul4      (plonk_prove.js:516-628, mul_z.js:49-148)   k_plonk_t   (one lane per evaluation point)
+//   Polynomial.add/sub/mulScalar   (polynomial.js:218-284)    k_poly_axpy / k_poly_scale
+//   Polynomial.evaluate (Horner)   (polynomial.js:174-184)    k_poly_eval_partial + k_poly_sum   (parallel reduction)
+//   Polynomial.divZh               (polynomial.js:592-615)    k_poly_div_zh          (stride-n recurrence, one lane per residue)
+//   Polynomial.divByZerofier(1,b)  (polynomial.js:617-674)    power weighting + additive scan (the linear recurrence
+//                                                              q_i = (q_{i-1} - c_i)/b  solved as a prefix sum)
+// All buffers are device pointers to little-endian Montgomery Fr elements, the reference's own representation.
+#include <string.h>
+#include <algorithm>
+#include <type_traits>
+#include "host_field.hpp"
+#include "ntt.cuh"
+#include "zkmi_common.hpp"
+
+namespace zkmi {
+
+typedef host::HField<4> HFr;
+typedef host::HFp<4> HE;
+
+// base^e = lo[e & (2^lb - 1)] * hi[e >> lb]
+struct PowTab {
+    const uint32_t* lo;
+    const uint32_t* hi;
+    uint32_t lb;
+};
+template <class C> ZK_DEV Fp<C> pow_tab(const PowTab& t, uint64_t e) {
+    Fp<C> a = fp_load<C>(t.lo + (size_t)(e & ((1ull << t.lb) - 1)) * C::N);
+    Fp<C> b = fp_load<C>(t.hi + (size_t)(e >> t.lb) * C::N);
+    return fp_mul(a, b);
+}
+// host: table for exponents < 2^log_count, into the named scratch buffer
+static int build_pow_tab(const HFr& F, const HE& base, unsigned log_count, const char* name, PowTab* out) {
+    Ctx& cx = ctx();
+    const unsigned lb = (log_count + 1) / 2, hb = log_count - lb;
+    const size_t nlo = (size_t)1 << lb, nhi = (size_t)1 << hb;
+    std::vector<HE> t(nlo + nhi);
+    t[0] = F.One();
+    for (size_t i = 1; i < nlo; i++) t[i] = F.mul(t[i - 1], base);
+    const HE step = F.mul(t[nlo - 1], base);
+    t[nlo] = F.One();
+    for (size_t i = 1; i < nhi; i++) t[nlo + i] = F.mul(t[nlo + i - 1], step);
+    uint32_t* d;
+    ZK_TRY(ws_get(name, t.size() * 32, (void**)&d));
+    ZK_HIP(hipMemcpyAsync(d, t.data(), t.size() * 32, hipMemcpyHostToDevice, cx.stream));
+    ZK_HIP(hipStreamSynchronize(cx.stream));              // `t` is a stack-owned staging buffer
+    out->lo = d; out->hi = d + nlo * 8; out->lb = lb;
+    return ZKMI_OK;
+}
+static inline unsigned clog2(size_t n) { unsigned l = 0; while (((size_t)1 << l) < n) l++; return l; }
+
+// ---- scans over Fr (multiplicative or additive), 3 launches: chunk totals, scan of totals, chunk scan with offset -----------
+constexpr int SCAN_T = 256, SCAN_K = 8, SCAN_CHUNK = SCAN_T * SCAN_K;
+template <class C, bool MUL> ZK_DEV Fp<C> scan_op(const Fp<C>& a, const Fp<C>& b) { return MUL ? fp_mul(a, b) : fp_add(a, b); }
+template <class C, bool MUL> ZK_DEV Fp<C> scan_id() { return MUL ? fp_one<C>() : fp_zero<C>(); }
+
+// block-wide inclusive scan of one value per thread (Hillis-Steele in LDS); returns the inclusive value of this thread
+template <class C, bool MUL> ZK_DEV Fp<C> block_scan(Fp<C> v, uint32_t* lds) {
+    const uint32_t t = threadIdx.x;
+    fp_store<C>(lds + t * 8, v);
+    __syncthreads();
+    for (int d = 1; d < SCAN_T; d <<= 1) {
+        Fp<C> o = t >= (uint32_t)d ? fp_load<C>(lds + (t - d) * 8) : scan_id<C, MUL>();
+        __syncthreads();
+        v = scan_op<C, MUL>(o, v);
+        fp_store<C>(lds + t * 8, v);
+        __syncthreads();
+    }
+    return v;
+}
+template <class C, bool MUL> __global__ void __launch_bounds__(SCAN_T)
+k_scan_totals(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[SCAN_T * 8];
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_K;
+    Fp<C> acc = scan_id<C, MUL>();
+    for (int k = 0; k < SCAN_K; k++) if (base + k < n) acc = scan_op<C, MUL>(acc, fp_load<C>(in + (base + k) * 8));
+    Fp<C> inc = block_scan<C, MUL>(acc, lds);
+    if (threadIdx.x == SCAN_T - 1) fp_store<C>(part + (size_t)blockIdx.x * 8, inc);
+}
+// exclusive scan of the chunk totals by ONE block
+template <class C, bool MUL> __global__ void __launch_bounds__(SCAN_T)
+k_scan_parts(uint32_t* __restrict__ part, uint32_t nparts) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[SCAN_T * 8];
+    __shared__ __attribute__((aligned(16))) uint32_t carry_s[8];
+    Fp<C> carry = scan_id<C, MUL>();
+    for (uint32_t b0 = 0; b0 < nparts; b0 += SCAN_T) {
+        const uint32_t i = b0 + threadIdx.x;
+        Fp<C> v = i < nparts ? fp_load<C>(part + (size_t)i * 8) : scan_id<C, MUL>();
+        Fp<C> inc = block_scan<C, MUL>(v, lds);
+        // exclusive = carry op (inclusive of the previous thread)
+        Fp<C> prev = threadIdx.x ? fp_load<C>(lds + (threadIdx.x - 1) * 8) : scan_id<C, MUL>();
+        if (i < nparts) fp_store<C>(part + (size_t)i * 8, scan_op<C, MUL>(carry, prev));
+        if (threadIdx.x == SCAN_T - 1) fp_store<C>(carry_s, scan_op<C, MUL>(carry, inc));
+        __syncthreads();
+        carry = fp_load<C>(carry_s);
+        __syncthreads();
+    }
+}
+// out[i] = inclusive scan up to i (in place allowed)
+template <class C, bool MUL> __global__ void __launch_bounds__(SCAN_T)
+k_scan_final(const uint32_t* __restrict__ in, size_t n, const uint32_t* __restrict__ part, uint32_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[SCAN_T * 8];
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_K;
+    Fp<C> v[SCAN_K];
+    Fp<C> acc = scan_id<C, MUL>();
+    for (int k = 0; k < SCAN_K; k++) {
+        v[k] = base + k < n ? fp_load<C>(in + (base + k) * 8) : scan_id<C, MUL>();
+        acc = scan_op<C, MUL>(acc, v[k]);
+    }
+    block_scan<C, MUL>(acc, lds);
+    Fp<C> run = scan_op<C, MUL>(fp_load<C>(part + (size_t)blockIdx.x * 8), threadIdx.x ? fp_load<C>(lds + (threadIdx.x - 1) * 8) : scan_id<C, MUL>());
+    for (int k = 0; k < SCAN_K; k++) {
+        run = scan_op<C, MUL>(run, v[k]);
+        if (base + k < n) fp_store<C>(out + (base + k) * 8, run);
+    }
+}
+template <class C, bool MUL> static int scan_inclusive(const uint32_t* in, size_t n, uint32_t* out) {
+    Ctx& cx = ctx();
+    if (!n) return ZKMI_OK;
+    const uint32_t nparts = (uint32_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    uint32_t* part;
+    ZK_TRY(ws_get("plonk.scanpart", (size_t)nparts * 32, (void**)&part));
+    hipLaunchKernelGGL((k_scan_totals<C, MUL>), dim3(nparts), dim3(SCAN_T), 0, cx.stream, in, n, part);
+    hipLaunchKernelGGL((k_scan_parts<C, MUL>), dim3(1), dim3(SCAN_T), 0, cx.stream, part, nparts);
+    hipLaunchKernelGGL((k_scan_final<C, MUL>), dim3(nparts), dim3(SCAN_T), 0, cx.stream, in, n, part, out);
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+}
+
+// ---- wires ---------------------------------------------------------------------------------------------------------------
+template <class C> __global__ void k_plonk_gather(const uint32_t* __restrict__ wit, uint32_t n_wit, const uint32_t* __restrict__ internal, uint32_t n_add,
+                                                 const uint32_t* __restrict__ ma, const uint32_t* __restrict__ mb, const uint32_t* __restrict__ mc,
+                                                 uint32_t n_constraints, uint32_t domain, uint32_t* __restrict__ A, uint32_t* __restrict__ B, uint32_t* __restrict__ Cc) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= domain) return;
+    const uint32_t* maps[3] = {ma, mb, mc};
+    uint32_t* outs[3] = {A, B, Cc};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        Fp<C> v = fp_zero<C>();
+        if (i < n_constraints) {
+            const uint32_t id = maps[k][i];                              // getWitness (:207-215)
+            if (id < n_wit) v = fp_load<C>(wit + (size_t)id * 8);
+            else if (id < n_wit + n_add) v = fp_load<C>(internal + (size_t)(id - n_wit) * 8);
+        }
+        fp_store<C>(outs[k] + (size_t)i * 8, v);
+    }
+}
+
+// ---- computeZ -------------------------------------------------------------------------------------------------------------
+// constants block (device): [0] beta [1] gamma [2] k1 [3] k2 [4] alpha [5] alpha^2 [6] w_n [7..17] b1..b11 [18..21] Z1 [22..25] Z2 [26..29] Z3 [30] one
+enum { PK_BETA = 0, PK_GAMMA, PK_K1, PK_K2, PK_ALPHA, PK_ALPHA2, PK_WN, PK_B1, PK_Z1 = PK_B1 + 11, PK_Z2 = PK_Z1 + 4, PK_Z3 = PK_Z2 + 4, PK_ONE = PK_Z3 + 4, PK_COUNT };
+template <class C> ZK_DEV Fp<C> kc(const uint32_t* k, int i) { return fp_load<C>(k + (size_t)i * 8); }
+
+template <class C> __global__ void __launch_bounds__(256)
+k_plonk_z_factors(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, const uint32_t* __restrict__ Cc, const uint32_t* __restrict__ s1, const uint32_t* __restrict__ s2,
+                  const uint32_t* __restrict__ s3, uint32_t domain, const uint32_t* __restrict__ k, PowTab wt, uint32_t* __restrict__ num, uint32_t* __restrict__ den) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= domain) return;
+    const Fp<C> beta = kc<C>(k, PK_BETA), gamma = kc<C>(k, PK_GAMMA);
+    const Fp<C> a = fp_load<C>(A + (size_t)i * 8), b = fp_load<C>(B + (size_t)i * 8), c = fp_load<C>(Cc + (size_t)i * 8);
+    const Fp<C> betaw = fp_mul(beta, pow_tab<C>(wt, i));
+    Fp<C> n1 = fp_add(fp_add(a, betaw), gamma);
+    Fp<C> n2 = fp_add(fp_add(b, fp_mul(kc<C>(k, PK_K1), betaw)), gamma);
+    Fp<C> n3 = fp_add(fp_add(c, fp_mul(kc<C>(k, PK_K2), betaw)), gamma);
+    fp_store<C>(num + (size_t)i * 8, fp_mul(n1, fp_mul(n2, n3)));
+    Fp<C> d1 = fp_add(fp_add(a, fp_mul(fp_load<C>(s1 + (size_t)i * 4 * 8), beta)), gamma);      // sigma evaluations sampled at stride 4 (:401-408)
+    Fp<C> d2 = fp_add(fp_add(b, fp_mul(fp_load<C>(s2 + (size_t)i * 4 * 8), beta)), gamma);
+    Fp<C> d3 = fp_add(fp_add(c, fp_mul(fp_load<C>(s3 + (size_t)i * 4 * 8), beta)), gamma);
+    fp_store<C>(den + (size_t)i * 8, fp_mul(d1, fp_mul(d2, d3)));
+}
+// Z[i] = P_num[i] * inv(P_den[i]) with P[i] = prod_{j<i} (exclusive) and P[0] = total product; incN/incD = inclusive scans, invD = 1/incD
+template <class C> __global__ void k_plonk_z_finish(const uint32_t* __restrict__ incN, const uint32_t* __restrict__ invD, uint32_t domain, uint32_t* __restrict__ Z) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= domain) return;
+    const uint32_t j = i ? i - 1 : domain - 1;
+    fp_store<C>(Z + (size_t)i * 8, fp_mul(fp_load<C>(incN + (size_t)j * 8), fp_load<C>(invD + (size_t)j * 8)));
+}
+
+// ---- computeT ---------------------------------------------------------------------------------------------------------------
+struct PlonkTArgs {
+    const uint32_t *a, *b, *c, *z, *qm, *ql, *qr, *qo, *qc, *s1, *s2, *s3;     // 4n evaluations each
+    const uint32_t* lagrange;     // section 13 on the device: per public input 5n elements (n coefficients, 4n evaluations)
+    const uint32_t* pub_a;        // buffers.A (Montgomery): A[j], j < nPublic
+    const uint32_t* k;            // constants block
+    uint32_t domain, n_public;
+    uint32_t *t, *tz;
+};
+template <class C> struct MulZ {
+    Fp<C> Z1, Z2, Z3;
+    bool p;
+    // mul_z.js:49-71
+    ZK_DEV void mul2(const Fp<C>& a, const Fp<C>& b, const Fp<C>& ap, const Fp<C>& bp, Fp<C>& r, Fp<C>& rz) const {
+        r = fp_mul(a, b);
+        rz = fp_add(fp_mul(a, bp), fp_mul(ap, b));
+        if (p) rz = fp_add(rz, fp_mul(Z1, fp_mul(ap, bp)));
+    }
+    // mul_z.js:103-148
+    ZK_DEV void mul4(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d, const Fp<C>& ap, const Fp<C>& bp, const Fp<C>& cp, const Fp<C>& dp, Fp<C>& r, Fp<C>& rz) const {
+        const Fp<C> a_b = fp_mul(a, b), a_bp = fp_mul(a, bp), ap_b = fp_mul(ap, b), ap_bp = fp_mul(ap, bp);
+        const Fp<C> c_d = fp_mul(c, d), c_dp = fp_mul(c, dp), cp_d = fp_mul(cp, d), cp_dp = fp_mul(cp, dp);
+        r = fp_mul(a_b, c_d);
+        Fp<C> a0 = fp_add(fp_add(fp_mul(ap_b, c_d), fp_mul(a_bp, c_d)), fp_add(fp_mul(a_b, cp_d), fp_mul(a_b, c_dp)));
+        rz = a0;
+        if (p) {
+            Fp<C> a1 = fp_add(fp_add(fp_add(fp_mul(ap_bp, c_d), fp_mul(ap_b, cp_d)), fp_add(fp_mul(ap_b, c_dp), fp_mul(a_bp, cp_d))), fp_add(fp_mul(a_bp, c_dp), fp_mul(a_b, cp_dp)));
+            Fp<C> a2 = fp_add(fp_add(fp_mul(a_bp, cp_dp), fp_mul(ap_b, cp_dp)), fp_add(fp_mul(ap_bp, c_dp), fp_mul(ap_bp, cp_d)));
+            Fp<C> a3 = fp_mul(ap_bp, cp_dp);
+            rz = fp_add(fp_add(rz, fp_mul(Z1, a1)), fp_add(fp_mul(Z2, a2), fp_mul(Z3, a3)));
+        }
+    }
+};
+template <class C> __global__ void __launch_bounds__(256)
+k_plonk_t(PlonkTArgs g, PowTab w4) {
+    const uint32_t n4 = 4 * g.domain;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    auto ld = [&](const uint32_t* p, size_t idx) { return fp_load<C>(p + idx * 8); };
+    const uint32_t* k = g.k;
+    const Fp<C> w = pow_tab<C>(w4, i);                                     // w = Fr.w[power+2]^i
+    const Fp<C> a = ld(g.a, i), b = ld(g.b, i), c = ld(g.c, i), z = ld(g.z, i);
+    const Fp<C> zw = ld(g.z, (n4 + 4 + i) % n4);
+    const Fp<C> beta = kc<C>(k, PK_BETA), gamma = kc<C>(k, PK_GAMMA), alpha = kc<C>(k, PK_ALPHA), alpha2 = kc<C>(k, PK_ALPHA2);
+    auto bl = [&](int j) { return kc<C>(k, PK_B1 + j - 1); };              // challenges.b[j]
+    const Fp<C> ap = fp_add(bl(2), fp_mul(bl(1), w)), bp = fp_add(bl(4), fp_mul(bl(3), w)), cp = fp_add(bl(6), fp_mul(bl(5), w));
+    const Fp<C> w2 = fp_sqr(w);
+    const Fp<C> zp = fp_add(fp_add(fp_mul(bl(7), w2), fp_mul(bl(8), w)), bl(9));
+    const Fp<C> wW = fp_mul(w, kc<C>(k, PK_WN)), wW2 = fp_sqr(wW);
+    const Fp<C> zWp = fp_add(fp_add(fp_mul(bl(7), wW2), fp_mul(bl(8), wW)), bl(9));
+    Fp<C> pi = fp_zero<C>();
+    for (uint32_t j = 0; j < g.n_public; j++)
+        pi = fp_sub(pi, fp_mul(ld(g.lagrange, (size_t)j * 5 * g.domain + g.domain + i), ld(g.pub_a, j)));
+    MulZ<C> mz;
+    mz.p = (i & 3) != 0;
+    mz.Z1 = kc<C>(k, PK_Z1 + (i & 3)); mz.Z2 = kc<C>(k, PK_Z2 + (i & 3)); mz.Z3 = kc<C>(k, PK_Z3 + (i & 3));
+    // e1 := a b qM + a qL + b qR + c qO + PI + qC
+    Fp<C> e1, e1z;
+    mz.mul2(a, b, ap, bp, e1, e1z);
+    const Fp<C> qm = ld(g.qm, i), ql = ld(g.ql, i), qr = ld(g.qr, i), qo = ld(g.qo, i);
+    e1 = fp_mul(e1, qm); e1z = fp_mul(e1z, qm);
+    e1 = fp_add(e1, fp_mul(a, ql)); e1z = fp_add(e1z, fp_mul(ap, ql));
+    e1 = fp_add(e1, fp_mul(b, qr)); e1z = fp_add(e1z, fp_mul(bp, qr));
+    e1 = fp_add(e1, fp_mul(c, qo)); e1z = fp_add(e1z, fp_mul(cp, qo));
+    e1 = fp_add(fp_add(e1, pi), ld(g.qc, i));
+    // e2 := alpha (a + beta X + gamma)(b + beta k1 X + gamma)(c + beta k2 X + gamma) z
+    const Fp<C> betaw = fp_mul(beta, w);
+    Fp<C> e2, e2z;
+    mz.mul4(fp_add(fp_add(a, betaw), gamma), fp_add(fp_add(b, fp_mul(betaw, kc<C>(k, PK_K1))), gamma), fp_add(fp_add(c, fp_mul(betaw, kc<C>(k, PK_K2))), gamma), z, ap, bp, cp, zp, e2, e2z);
+    e2 = fp_mul(e2, alpha); e2z = fp_mul(e2z, alpha);
+    // e3 := alpha (a + beta s1 + gamma)(b + beta s2 + gamma)(c + beta s3 + gamma) z(Xw)
+    Fp<C> e3, e3z;
+    mz.mul4(fp_add(fp_add(a, fp_mul(beta, ld(g.s1, i))), gamma), fp_add(fp_add(b, fp_mul(beta, ld(g.s2, i))), gamma), fp_add(fp_add(c, fp_mul(beta, ld(g.s3, i))), gamma), zw, ap, bp, cp, zWp,
+            e3, e3z);
+    e3 = fp_mul(e3, alpha); e3z = fp_mul(e3z, alpha);
+    // e4 := alpha^2 (z - 1) L1
+    const Fp<C> l1 = ld(g.lagrange, (size_t)g.domain + i);
+    const Fp<C> e4 = fp_mul(fp_mul(fp_sub(z, kc<C>(k, PK_ONE)), l1), alpha2);
+    const Fp<C> e4z = fp_mul(fp_mul(zp, l1), alpha2);
+    fp_store<C>(g.t + (size_t)i * 8, fp_add(fp_sub(fp_add(e1, e2), e3), e4));
+    fp_store<C>(g.tz + (size_t)i * 8, fp_add(fp_sub(fp_add(e1z, e2z), e3z), e4z));
+}
+
+// ---- polynomial ops ---------------------------------------------------------------------------------------------------------
+// y[i] = y[i] +/- (k ? k*x[i] : x[i]),  i < nx
+template <class C> __global__ void k_poly_axpy(uint32_t* __restrict__ y, const uint32_t* __restrict__ x, size_t nx, const uint32_t* __restrict__ k, int subtract) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nx) return;
+    Fp<C> b = fp_load<C>(x + i * 8);
+    if (k) b = fp_mul(b, fp_load<C>(k));
+    const Fp<C> a = fp_load<C>(y + i * 8);
+    fp_store<C>(y + i * 8, subtract ? fp_sub(a, b) : fp_add(a, b));
+}
+template <class C> __global__ void k_poly_scale(uint32_t* __restrict__ p, size_t n, const uint32_t* __restrict__ k) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fp_store<C>(p + i * 8, fp_mul(fp_load<C>(p + i * 8), fp_load<C>(k)));
+}
+static __global__ void k_poly_any_nonzero(const uint32_t* __restrict__ p, size_t n_words, uint32_t* __restrict__ flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words && p[i]) atomicOr(flag, 1u);
+}
+// divZh: c[i] <- -c[i] (i < n); c[i] <- c[i-n] - c[i] (i >= n, using the UPDATED c[i-n]); one lane per residue class.
+// bad: set when a coefficient that must vanish (i > n*(ext-1) - ext) does not.
+template <class C> __global__ void k_poly_div_zh(uint32_t* __restrict__ c, size_t len, uint32_t n, uint32_t ext, uint32_t* __restrict__ bad) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || j >= len) return;
+    Fp<C> prev = fp_neg(fp_load<C>(c + (size_t)j * 8));
+    fp_store<C>(c + (size_t)j * 8, prev);
+    for (size_t i = (size_t)j + n; i < len; i += n) {
+        prev = fp_sub(prev, fp_load<C>(c + i * 8));
+        fp_store<C>(c + i * 8, prev);
+        if (i > (size_t)n * (ext - 1) - ext && !fp_is_zero(prev)) atomicAdd(bad, 1u);
+    }
+}
+// Horner by chunks: partial[b] = sum over the block's coefficients c_i x^i
+constexpr int EV_K = 16;
+template <class C> __global__ void __launch_bounds__(256)
+k_poly_eval_partial(const uint32_t* __restrict__ c, size_t n, const uint32_t* __restrict__ x, PowTab xt, uint32_t* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[256 * 8];
+    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * EV_K;
+    const Fp<C> xv = fp_load<C>(x);
+    Fp<C> acc = fp_zero<C>();
+    for (int k = EV_K - 1; k >= 0; k--) { acc = fp_mul(acc, xv); if (base + k < n) acc = fp_add(acc, fp_load<C>(c + (base + k) * 8)); }
+    if (base < n) acc = fp_mul(acc, pow_tab<C>(xt, base)); else acc = fp_zero<C>();
+    fp_store<C>(lds + threadIdx.x * 8, acc);
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (threadIdx.x < (uint32_t)d) { acc = fp_add(acc, fp_load<C>(lds + (threadIdx.x + d) * 8)); fp_store<C>(lds + threadIdx.x * 8, acc); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fp_store<C>(part + (size_t)blockIdx.x * 8, acc);
+}
+template <class C> __global__ void __launch_bounds__(256) k_poly_sum(const uint32_t* __restrict__ part, uint32_t np, uint32_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[256 * 8];
+    Fp<C> acc = fp_zero<C>();
+    for (uint32_t i = threadIdx.x; i < np; i += 256) acc = fp_add(acc, fp_load<C>(part + (size_t)i * 8));
+    fp_store<C>(lds + threadIdx.x * 8, acc);
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (threadIdx.x < (uint32_t)d) { acc = fp_add(acc, fp_load<C>(lds + (threadIdx.x + d) * 8)); fp_store<C>(lds + threadIdx.x * 8, acc); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fp_store<C>(out, acc);
+}
+// divByZerofier(1, beta): u_i = -c_i * beta^i * (1/beta); S = inclusive prefix sums of u; q_i = S_i * (1/beta)^i
+template <class C> __global__ void k_dz_weight(const uint32_t* __restrict__ c, size_t n, PowTab bt, const uint32_t* __restrict__ inv_beta, uint32_t* __restrict__ u) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fp_store<C>(u + i * 8, fp_neg(fp_mul(fp_mul(fp_load<C>(c + i * 8), pow_tab<C>(bt, i)), fp_load<C>(inv_beta))));
+}
+template <class C> __global__ void k_dz_unweight(const uint32_t* __restrict__ s, size_t n, PowTab it, uint32_t* __restrict__ q) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fp_store<C>(q + i * 8, fp_mul(fp_load<C>(s + i * 8), pow_tab<C>(it, i)));
+}
+
+// ---- host drivers (templated on the Fr configuration) -----------------------------------------------------------------------------
+template <class C> struct PlonkOps {
+    static HFr F() { return HFr::from_cfg<C>(); }
+    static HE he(const uint8_t* p) { HE e; memcpy(e.v, p, 32); return e; }
+
+    static int gather(const void* w, uint32_t nw, const void* in, uint32_t na, const void* ma, const void* mb, const void* mc, uint32_t ncon, uint32_t dom, void* A, void* B, void* Cc) {
+        hipLaunchKernelGGL((k_plonk_gather<C>), dim3((dom + 255) / 256), dim3(256), 0, ctx().stream, (const uint32_t*)w, nw, (const uint32_t*)in, na, (const uint32_t*)ma, (const uint32_t*)mb,
+                           (const uint32_t*)mc, ncon, dom, (uint32_t*)A, (uint32_t*)B, (uint32_t*)Cc);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int upload_consts(const std::vector<HE>& v, const char* name, uint32_t** d) {
+        ZK_TRY(ws_get(name, v.size() * 32, (void**)d));
+        ZK_HIP(hipMemcpyAsync(*d, v.data(), v.size() * 32, hipMemcpyHostToDevice, ctx().stream));
+        ZK_HIP(hipStreamSynchronize(ctx().stream));
+        return ZKMI_OK;
+    }
+    static int compute_z(const void* A, const void* B, const void* Cc, const void* s1, const void* s2, const void* s3, uint32_t dom, const uint8_t* beta, const uint8_t* gamma, const uint8_t* k1,
+                         const uint8_t* k2, const uint8_t* w_n, void* Z) {
+        Ctx& cx = ctx();
+        const HFr Fh = F();
+        std::vector<HE> kv(PK_COUNT, Fh.zero());
+        kv[PK_BETA] = he(beta); kv[PK_GAMMA] = he(gamma); kv[PK_K1] = he(k1); kv[PK_K2] = he(k2);
+        uint32_t* dk;
+        ZK_TRY(upload_consts(kv, "plonk.kz", &dk));
+        PowTab wt;
+        ZK_TRY(build_pow_tab(Fh, he(w_n), clog2(dom), "plonk.powz", &wt));
+        uint32_t *num, *den;
+        ZK_TRY(ws_get("plonk.znum", (size_t)dom * 32, (void**)&num));
+        ZK_TRY(ws_get("plonk.zden", (size_t)dom * 32, (void**)&den));
+        const unsigned blocks = (dom + 255) / 256;
+        hipLaunchKernelGGL((k_plonk_z_factors<C>), dim3(blocks), dim3(256), 0, cx.stream, (const uint32_t*)A, (const uint32_t*)B, (const uint32_t*)Cc, (const uint32_t*)s1, (const uint32_t*)s2,
+                           (const uint32_t*)s3, dom, dk, wt, num, den);
+        ZK_TRY((scan_inclusive<C, true>(num, dom, num)));
+        ZK_TRY((scan_inclusive<C, true>(den, dom, den)));
+        ZK_TRY(fr_batch_dev_dispatch(std::is_same<C, Bn254Fr>::value ? ZKMI_CURVE_BN128 : ZKMI_CURVE_BLS12381, ZKMI_BATCH_INVERSE, den, den, dom));   // Fr.batchInverse (:420)
+        hipLaunchKernelGGL((k_plonk_z_finish<C>), dim3(blocks), dim3(256), 0, cx.stream, num, den, dom, (uint32_t*)Z);
+        HE z0;
+        ZK_HIP(hipMemcpyAsync(z0.v, Z, 32, hipMemcpyDeviceToHost, cx.stream));
+        ZK_HIP(hipStreamSynchronize(cx.stream));
+        ZK_HIP(hipGetLastError());
+        if (!(z0 == Fh.One())) return fail(ZKMI_ERR_INVALID, "Copy constraints does not match");     // :437-439
+        return ZKMI_OK;
+    }
+    static int compute_t(const zkmi_plonk_evals* ev, uint32_t dom, uint32_t n_public, const uint8_t* blind, const uint8_t* beta, const uint8_t* gamma, const uint8_t* alpha, const uint8_t* k1,
+                         const uint8_t* k2, const uint8_t* w_n, const uint8_t* w_4n, const uint8_t* w_2, void* T, void* Tz) {
+        Ctx& cx = ctx();
+        const HFr Fh = F();
+        std::vector<HE> kv(PK_COUNT, Fh.zero());
+        kv[PK_BETA] = he(beta); kv[PK_GAMMA] = he(gamma); kv[PK_K1] = he(k1); kv[PK_K2] = he(k2); kv[PK_ALPHA] = he(alpha); kv[PK_ALPHA2] = Fh.sqr(he(alpha)); kv[PK_WN] = he(w_n);
+        for (int j = 0; j < 11; j++) kv[PK_B1 + j] = he(blind + 32 * j);
+        kv[PK_ONE] = Fh.One();
+        // MulZ constants (mul_z.js:21-47), w2 = Fr.w[2]
+        const HE w2 = he(w_2), one = Fh.One(), two = Fh.from_u64(2), m1 = Fh.neg(one), m2 = Fh.neg(two);
+        kv[PK_Z1 + 1] = Fh.add(m1, w2); kv[PK_Z1 + 2] = m2; kv[PK_Z1 + 3] = Fh.sub(m1, w2);
+        kv[PK_Z2 + 1] = Fh.mul(m2, w2); kv[PK_Z2 + 2] = Fh.from_u64(4); kv[PK_Z2 + 3] = Fh.neg(Fh.mul(m2, w2));
+        kv[PK_Z3 + 1] = Fh.add(two, Fh.mul(two, w2)); kv[PK_Z3 + 2] = Fh.neg(Fh.from_u64(8)); kv[PK_Z3 + 3] = Fh.sub(two, Fh.mul(two, w2));
+        uint32_t* dk;
+        ZK_TRY(upload_consts(kv, "plonk.kt", &dk));
+        PowTab w4;
+        ZK_TRY(build_pow_tab(Fh, he(w_4n), clog2((size_t)4 * dom), "plonk.powt", &w4));
+        PlonkTArgs g;
+        g.a = (const uint32_t*)ev->a; g.b = (const uint32_t*)ev->b; g.c = (const uint32_t*)ev->c; g.z = (const uint32_t*)ev->z;
+        g.qm = (const uint32_t*)ev->qm; g.ql = (const uint32_t*)ev->ql; g.qr = (const uint32_t*)ev->qr; g.qo = (const uint32_t*)ev->qo; g.qc = (const uint32_t*)ev->qc;
+        g.s1 = (const uint32_t*)ev->s1; g.s2 = (const uint32_t*)ev->s2; g.s3 = (const uint32_t*)ev->s3;
+        g.lagrange = (const uint32_t*)ev->lagrange; g.pub_a = (const uint32_t*)ev->pub_a; g.k = dk;
+        g.domain = dom; g.n_public = n_public; g.t = (uint32_t*)T; g.tz = (uint32_t*)Tz;
+        hipLaunchKernelGGL((k_plonk_t<C>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int axpy(void* y, const void* x, size_t nx, const uint8_t* k, int subtract) {
+        if (!nx) return ZKMI_OK;
+        uint32_t* dk = nullptr;
+        if (k) { std::vector<HE> kv(1, he(k)); ZK_TRY(upload_consts(kv, "plonk.kaxpy", &dk)); }
+        hipLaunchKernelGGL((k_poly_axpy<C>), dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, ctx().stream, (uint32_t*)y, (const uint32_t*)x, nx, dk, subtract);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int scale(void* p, size_t n, const uint8_t* k) {
+        if (!n) return ZKMI_OK;
+        uint32_t* dk;
+        std::vector<HE> kv(1, he(k));
+        ZK_TRY(upload_consts(kv, "plonk.kaxpy", &dk));
+        hipLaunchKernelGGL((k_poly_scale<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, (uint32_t*)p, n, dk);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int evaluate(const void* p, size_t n, const uint8_t* x, uint8_t* out) {
+        Ctx& cx = ctx();
+        const HFr Fh = F();
+        if (!n) { memset(out, 0, 32); return ZKMI_OK; }
+        uint32_t* dx;
+        std::vector<HE> kv(1, he(x));
+        ZK_TRY(upload_consts(kv, "plonk.kev", &dx));
+        PowTab xt;
+        ZK_TRY(build_pow_tab(Fh, he(x), std::max(1u, clog2(n)), "plonk.powe", &xt));
+        const uint32_t np = (uint32_t)((n + 256 * EV_K - 1) / (256 * EV_K));
+        uint32_t* part;
+        ZK_TRY(ws_get("plonk.evpart", ((size_t)np + 1) * 32, (void**)&part));
+        hipLaunchKernelGGL((k_poly_eval_partial<C>), dim3(np), dim3(256), 0, cx.stream, (const uint32_t*)p, n, dx, xt, part);
+        hipLaunchKernelGGL((k_poly_sum<C>), dim3(1), dim3(256), 0, cx.stream, part, np, part + (size_t)np * 8);
+        ZK_HIP(hipMemcpyAsync(out, part + (size_t)np * 8, 32, hipMemcpyDeviceToHost, cx.stream));
+        ZK_HIP(hipStreamSynchronize(cx.stream));
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int div_zh(void* p, size_t len, uint32_t dom, uint32_t ext) {
+        Ctx& cx = ctx();
+        uint32_t* bad;
+        ZK_TRY(ws_get("plonk.bad", 16, (void**)&bad));
+        ZK_HIP(hipMemsetAsync(bad, 0, 16, cx.stream));
+        hipLaunchKernelGGL((k_poly_div_zh<C>), dim3((dom + 255) / 256), dim3(256), 0, cx.stream, (uint32_t*)p, len, dom, ext, bad);
+        uint32_t nbad = 0;
+        ZK_HIP(hipMemcpyAsync(&nbad, bad, 4, hipMemcpyDeviceToHost, cx.stream));
+        ZK_HIP(hipStreamSynchronize(cx.stream));
+        ZK_HIP(hipGetLastError());
+        if (nbad) return fail(ZKMI_ERR_INVALID, "Polynomial is not divisible");            // polynomial.js:607-611
+        return ZKMI_OK;
+    }
+    static int div_by_zerofier(void* p, size_t len, uint32_t n, const uint8_t* beta) {
+        Ctx& cx = ctx();
+        if (n != 1) return fail(ZKMI_ERR_UNSUPPORTED, "divByZerofier: only n = 1 (PLONK openings) is implemented on the device");
+        if (!len) return ZKMI_OK;
+        const HFr Fh = F();
+        const HE b = he(beta), ib = Fh.inv(b);
+        PowTab bt, it;
+        ZK_TRY(build_pow_tab(Fh, b, std::max(1u, clog2(len)), "plonk.powb", &bt));
+        ZK_TRY(build_pow_tab(Fh, ib, std::max(1u, clog2(len)), "plonk.powib", &it));
+        uint32_t *dib, *u;
+        std::vector<HE> kv(1, ib);
+        ZK_TRY(upload_consts(kv, "plonk.kib", &dib));
+        ZK_TRY(ws_get("plonk.dzu", len * 32, (void**)&u));
+        const unsigned blocks = (unsigned)((len + 255) / 256);
+        hipLaunchKernelGGL((k_dz_weight<C>), dim3(blocks), dim3(256), 0, cx.stream, (const uint32_t*)p, len, bt, dib, u);
+        ZK_TRY((scan_inclusive<C, false>(u, len, u)));
+        hipLaunchKernelGGL((k_dz_unweight<C>), dim3(blocks), dim3(256), 0, cx.stream, u, len, it, (uint32_t*)p);
+        HE last;
+        ZK_HIP(hipMemcpyAsync(last.v, (uint8_t*)p + (len - 1) * 32, 32, hipMemcpyDeviceToHost, cx.stream));
+        ZK_HIP(hipStreamSynchronize(cx.stream));
+        ZK_HIP(hipGetLastError());
+        if (!last.is_zero()) return fail(ZKMI_ERR_INVALID, "Polynomial is not divisible");   // polynomial.js:665-669
+        return ZKMI_OK;
+    }
+};
+
+}  // namespace zkmi
+
+using namespace zkmi;
+#define PLONK_DISPATCH(curve, call)                                                     \
+    do {                                                                                \
+        ZK_TRY(require_ctx());                                                          \
+        if ((curve) == ZKMI_CURVE_BN128) return PlonkOps<Bn254Fr>::call;                \
+        if ((curve) == ZKMI_CURVE_BLS12381) return PlonkOps<Bls12381Fr>::call;          \
+        return fail(ZKMI_ERR_INVALID, "unknown curve");                                 \
+    } while (0)
+
+extern "C" {
+
+int zkmi_plonk_gather_wires_dev(int curve, const void* d_witness, uint32_t n_witness, const void* d_internal, uint32_t n_additions, const void* d_map_a, const void* d_map_b,
+                                const void* d_map_c, uint32_t n_constraints, uint32_t domain, void* d_a, void* d_b, void* d_c) {
+    PLONK_DISPATCH(curve, gather(d_witness, n_witness, d_internal, n_additions, d_map_a, d_map_b, d_map_c, n_constraints, domain, d_a, d_b, d_c));
+}
+int zkmi_plonk_compute_z_dev(int curve, const void* d_a, const void* d_b, const void* d_c, const void* d_s1e, const void* d_s2e, const void* d_s3e, uint32_t domain, const uint8_t* beta,
+                             const uint8_t* gamma, const uint8_t* k1, const uint8_t* k2, const uint8_t* w_n, void* d_z) {
+    PLONK_DISPATCH(curve, compute_z(d_a, d_b, d_c, d_s1e, d_s2e, d_s3e, domain, beta, gamma, k1, k2, w_n, d_z));
+}
+int zkmi_plonk_compute_t_dev(int curve, const zkmi_plonk_evals* ev, uint32_t domain, uint32_t n_public, const uint8_t* blind11, const uint8_t* beta, const uint8_t* gamma,
+                             const uint8_t* alpha, const uint8_t* k1, const uint8_t* k2, const uint8_t* w_n, const uint8_t* w_4n, const uint8_t* w_2, void* d_t, void* d_tz) {
+    if (!ev) return fail(ZKMI_ERR_INVALID, "null evaluations");
+    PLONK_DISPATCH(curve, compute_t(ev, domain, n_public, blind11, beta, gamma, alpha, k1, k2, w_n, w_4n, w_2, d_t, d_tz));
+}
+int zkmi_poly_axpy_dev(int curve, void* d_y, const void* d_x, size_t nx, const uint8_t* k, int subtract) { PLONK_DISPATCH(curve, axpy(d_y, d_x, nx, k, subtract)); }
+int zkmi_poly_scale_dev(int curve, void* d_p, size_t n, const uint8_t* k) { PLONK_DISPATCH(curve, scale(d_p, n, k)); }
+int zkmi_poly_evaluate_dev(int curve, const void* d_p, size_t n, const uint8_t* x, uint8_t* out) { PLONK_DISPATCH(curve, evaluate(d_p, n, x, out)); }
+int zkmi_poly_is_zero_dev(int curve, const void* d_p, size_t n, int* all_zero) {
+    ZK_TRY(require_ctx());
+    (void)curve;
+    if (!all_zero) return fail(ZKMI_ERR_INVALID, "null argument");
+    *all_zero = 1;
+    if (!n) return ZKMI_OK;
+    uint32_t* flag;
+    ZK_TRY(ws_get("plonk.bad", 16, (void**)&flag));
+    ZK_HIP(hipMemsetAsync(flag, 0, 16, ctx().stream));
+    hipLaunchKernelGGL(k_poly_any_nonzero, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, ctx().stream, (const uint32_t*)d_p, n * 8, flag);
+    uint32_t f = 0;
+    ZK_HIP(hipMemcpyAsync(&f, flag, 4, hipMemcpyDeviceToHost, ctx().stream));
+    ZK_HIP(hipStreamSynchronize(ctx().stream));
+    *all_zero = f ? 0 : 1;
+    return ZKMI_OK;
+}
+int zkmi_poly_div_zh_dev(int curve, void* d_p, size_t len, uint32_t domain, uint32_t extensions) { PLONK_DISPATCH(curve, div_zh(d_p, len, domain, extensions)); }
+int zkmi_poly_div_by_zerofier_dev(int curve, void* d_p, size_t len, uint32_t n, const uint8_t* beta) { PLONK_DISPATCH(curve, div_by_zerofier(d_p, len, n, beta)); }
+
+}  // extern "C"

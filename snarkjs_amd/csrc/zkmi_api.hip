@@ -188,6 +188,16 @@ int zkmi_memcpy_d2h(void* h, const void* d, size_t bytes) {
     return ZKMI_OK;
 }
 
+int zkmi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes) {
+    ZK_TRY(require_ctx());
+    if (bytes) ZK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, g_ctx.stream));
+    return ZKMI_OK;
+}
+int zkmi_memset_dev(void* d_dst, int value, size_t bytes) {
+    ZK_TRY(require_ctx());
+    if (bytes) ZK_HIP(hipMemsetAsync(d_dst, value, bytes, g_ctx.stream));
+    return ZKMI_OK;
+}
 int zkmi_msm_set_window_bits(int c) {
     if (c < 0 || c > 20) return fail(ZKMI_ERR_INVALID, "window bits must be 0 (auto) or 1..20");
     g_ctx.msm_c_override = c;
@@ -292,6 +302,11 @@ int zkmi_gen_geometric_bases_dev(int curve, int group, size_t n, uint64_t f, uin
     return gen_bases_dispatch(curve, group, n, f, g, d_out);
 }
 int zkmi_to_affine(int curve, int group, const uint8_t* jac, uint8_t* aff) { return to_affine_dispatch(curve, group, jac, aff); }
+int zkmi_fr_root(int curve, unsigned i, uint8_t* out32) {
+    if (curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381) return fail(ZKMI_ERR_INVALID, "unknown curve");
+    if (!out32) return fail(ZKMI_ERR_INVALID, "null argument");
+    return fr_root(curve, i, out32);
+}
 int zkmi_point_add(int curve, int group, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     ZK_TRY(check_cg(curve, group));
     if (!a || !b || !out) return fail(ZKMI_ERR_INVALID, "null argument");

@@ -73,6 +73,7 @@ int join_abc_dev_dispatch(int curve, const void* a, const void* b, const void* c
 int to_affine_dispatch(int curve, int group, const uint8_t* jac, uint8_t* aff);
 // inc of the Groth16 coset step: Fr.shift when power == Fr.s, else Fr.w[power+1] (src/groth16_prove.js:64), Montgomery bytes
 int fr_coset_inc(int curve, unsigned power, uint8_t* out32);
+int fr_root(int curve, unsigned i, uint8_t* out32);      // Fr.w[i], Montgomery bytes
 
 inline int n8q_of(int curve) { return curve == ZKMI_CURVE_BN128 ? 32 : 48; }
 

@@ -1,0 +1,420 @@
+"""plonk.prove on the MI355X — host-side mirror of the reference driver (src/plonk_prove.js:47-888, src/plonk.js).
+
+Same inputs (plonk zkey + wtns containers), same checks and error messages, same output ({proof, publicSignals} with
+decimal strings in the reference's key order).  Every O(n) step runs in the HIP library and the data stays in device
+memory between rounds; what remains on the host is what the reference also does with O(1) work: the Keccak-256
+Fiat-Shamir transcript (src/Keccak256Transcript.js), challenge arithmetic, blinding of a few coefficients, proof
+assembly — and calculateAdditions (:174-204), a data-dependent sequential chain.
+
+    round 1  gather wires -> batchToMontgomery -> 3 iNTT(n) + 3 NTT(4n) -> 3 MSM           zkmi_plonk_gather_wires_dev, zkmi_ntt_dev, zkmi_msm_dev
+    round 2  computeZ (factors, 2 product scans, batch inverse) -> iNTT, NTT(4n), MSM       zkmi_plonk_compute_z_dev
+    round 3  computeT over 4n points (MulZ) -> 2 iNTT(4n), divZh, split -> 3 MSM            zkmi_plonk_compute_t_dev, zkmi_poly_div_zh_dev
+    round 4  6 Horner evaluations                                                            zkmi_poly_evaluate_dev
+    round 5  linearisation R (axpy chain), 2 x divByZerofier -> 2 MSM                        zkmi_poly_axpy_dev, zkmi_poly_div_by_zerofier_dev
+"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+from . import zkmi
+from .groth16 import _curve_from_q, _R
+
+_Q = {0: 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+      1: 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab}
+
+# ---- Keccak-256 (original padding 0x01, as @noble/hashes keccak_256 used by src/Keccak256Transcript.js) ----------------------
+_KRC = (0x1, 0x8082, 0x800000000000808A, 0x8000000080008000, 0x808B, 0x80000001, 0x8000000080008081, 0x8000000000008009, 0x8A, 0x88,
+        0x80008009, 0x8000000A, 0x8000808B, 0x800000000000008B, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002,
+        0x8000000000000080, 0x800A, 0x800000008000000A, 0x8000000080008081, 0x8000000000008080, 0x80000001, 0x8000000080008008)
+_KROT = (0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14)   # flat index x + 5y
+_MASK = (1 << 64) - 1
+
+
+def _permute(s):
+    for rc in _KRC:
+        c = [s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20] for x in range(5)]
+        for x in range(5):
+            t = c[(x + 4) % 5] ^ (((c[(x + 1) % 5] << 1) | (c[(x + 1) % 5] >> 63)) & _MASK)
+            for y in range(0, 25, 5):
+                s[x + y] ^= t
+        b = [0] * 25
+        for x in range(5):
+            for y in range(5):
+                v, r = s[x + 5 * y], _KROT[x + 5 * y]
+                b[y + 5 * ((2 * x + 3 * y) % 5)] = ((v << r) | (v >> (64 - r))) & _MASK if r else v
+        for y in range(0, 25, 5):
+            for x in range(5):
+                s[x + y] = b[x + y] ^ (~b[(x + 1) % 5 + y] & _MASK & b[(x + 2) % 5 + y])
+        s[0] ^= rc
+
+
+def keccak256(data):
+    rate = 136
+    msg = bytearray(data)
+    msg.append(0x01)
+    msg.extend(b"\x00" * ((-len(msg)) % rate))
+    msg[-1] |= 0x80
+    st = [0] * 25
+    for off in range(0, len(msg), rate):
+        for i in range(rate // 8):
+            st[i] ^= int.from_bytes(msg[off + 8 * i:off + 8 * i + 8], "little")
+        _permute(st)
+    return b"".join(st[i].to_bytes(8, "little") for i in range(4))
+
+
+class _Field:
+    """Fr / Fq conversions for one curve: Montgomery little-endian bytes <-> Python ints (normal form)."""
+
+    def __init__(self, cid):
+        self.cid, self.r, self.q = cid, _R[cid], _Q[cid]
+        self.n8q = 32 if cid == 0 else 48
+        self.Rr, self.Rq = pow(2, 256, self.r), pow(2, 8 * self.n8q, self.q)
+        self.Rri, self.Rqi = pow(self.Rr, -1, self.r), pow(self.Rq, -1, self.q)
+
+    def mont(self, v):        # int -> 32 Montgomery bytes (numpy)
+        return np.frombuffer((v % self.r * self.Rr % self.r).to_bytes(32, "little"), np.uint8).copy()
+
+    def unmont(self, b):      # 32 Montgomery bytes -> int
+        return int.from_bytes(bytes(b), "little") * self.Rri % self.r
+
+    def unmont_q(self, b):
+        return int.from_bytes(bytes(b), "little") * self.Rqi % self.q
+
+    def root(self, i):
+        out = np.zeros(32, np.uint8)
+        zkmi.check(zkmi.lib().zkmi_fr_root(self.cid, i, zkmi.ptr(out)))
+        return out
+
+
+class _Poly:
+    """Coefficients (or evaluations) of `n` Montgomery Fr elements in device memory (the reference's Polynomial / Evaluations)."""
+
+    def __init__(self, fld, n, zero=True):
+        self.f, self.n = fld, n
+        self.buf = zkmi.DeviceBuffer(max(n, 1) * 32)
+        if zero:
+            zkmi.check(zkmi.lib().zkmi_memset_dev(self.buf.ptr, 0, n * 32))
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    def at(self, i):
+        return self.buf.ptr + 32 * i
+
+    def copy_from(self, src_ptr, count, dst_off=0):
+        zkmi.check(zkmi.lib().zkmi_memcpy_d2d(self.at(dst_off), src_ptr, count * 32))
+        return self
+
+    def get(self, i):                     # getCoef -> int
+        out = np.empty(32, np.uint8)
+        zkmi.check(zkmi.lib().zkmi_memcpy_d2h(zkmi.ptr(out), self.at(i), 32))
+        return self.f.unmont(out)
+
+    def set(self, i, v):                  # setCoef
+        b = self.f.mont(v)
+        zkmi.check(zkmi.lib().zkmi_memcpy_h2d(self.at(i), zkmi.ptr(b), 32))
+
+    def axpy(self, other, k=None, sub=False, count=None):
+        """this.add(polynomial, blindingValue) / this.sub (polynomial.js:218-276); the caller sizes `self` to the max length"""
+        cnt = other.n if count is None else count
+        assert cnt <= self.n
+        kb = None if k is None else zkmi.ptr(self.f.mont(k))
+        zkmi.check(zkmi.lib().zkmi_poly_axpy_dev(self.f.cid, self.ptr, other.ptr, cnt, kb, int(sub)))
+
+    def scale(self, k):
+        zkmi.check(zkmi.lib().zkmi_poly_scale_dev(self.f.cid, self.ptr, self.n, zkmi.ptr(self.f.mont(k))))
+
+    def add_scalar(self, v):
+        self.set(0, (self.get(0) + v) % self.f.r)
+
+    def evaluate(self, x):
+        out = np.empty(32, np.uint8)
+        zkmi.check(zkmi.lib().zkmi_poly_evaluate_dev(self.f.cid, self.ptr, self.n, zkmi.ptr(self.f.mont(x)), zkmi.ptr(out)))
+        return self.f.unmont(out)
+
+    def tail_is_zero(self, start):
+        z = C.c_int(1)
+        zkmi.check(zkmi.lib().zkmi_poly_is_zero_dev(self.f.cid, self.at(start), self.n - start, C.byref(z)))
+        return bool(z.value)
+
+    def blinded(self, factors):
+        """blindCoefficients (polynomial.js:68-93): length grows by len(factors)"""
+        out = _Poly(self.f, self.n + len(factors))
+        out.copy_from(self.ptr, self.n)
+        for i, fct in enumerate(factors):
+            out.set(self.n + i, (out.get(self.n + i) + fct) % self.f.r)
+            out.set(i, (out.get(i) - fct) % self.f.r)
+        return out
+
+    def ntt(self, inverse, out=None):
+        out = out or _Poly(self.f, self.n, zero=False)
+        zkmi.check(zkmi.lib().zkmi_ntt_dev(self.f.cid, self.ptr, out.ptr, self.n.bit_length() - 1, int(inverse), None, None))
+        return out
+
+    def extended_evals(self, ext):
+        """Evaluations.fromPolynomial(p, 4): zero-pad to ext*n coefficients, then fft (evaluations.js:30-37)"""
+        e = _Poly(self.f, self.n * ext)
+        e.copy_from(self.ptr, self.n)
+        return e.ntt(False, out=e)
+
+    def free(self):
+        self.buf.free()
+
+
+class PlonkKey:
+    """A PLONK zkey resident on the device (selector / permutation sections, Lagrange evaluations, SRS points)."""
+
+    def __init__(self, zkey_bytes):
+        data = bytes(zkey_bytes)
+        s = self.sections = {}
+        nsec = struct.unpack_from("<I", data, 8)[0]
+        off = 12
+        for _ in range(nsec):
+            t, ln = struct.unpack_from("<IQ", data, off)
+            off += 12
+            s[t] = (off, ln)
+            off += ln
+        if struct.unpack_from("<I", data, s[1][0])[0] != 2:
+            raise ValueError("zkey file is not plonk")                                   # plonk_prove.js:60-62
+        off = s[2][0]
+        n8q = struct.unpack_from("<I", data, off)[0]
+        q = int.from_bytes(data[off + 4:off + 4 + n8q], "little"); off += 4 + n8q
+        n8r = struct.unpack_from("<I", data, off)[0]
+        self.r = int.from_bytes(data[off + 4:off + 4 + n8r], "little"); off += 4 + n8r
+        self.curve_id, self.curve_name = _curve_from_q(q)
+        self.f = f = _Field(self.curve_id)
+        self.nVars, self.nPublic, self.n, self.nAdditions, self.nConstraints = struct.unpack_from("<IIIII", data, off); off += 20
+        self.power = self.n.bit_length() - 1
+        self.k1, self.k2 = f.unmont(data[off:off + 32]), f.unmont(data[off + 32:off + 64]); off += 64
+        self.commit = {}
+        for nm in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):                       # src/zkey_utils.js:283-290
+            self.commit[nm] = (f.unmont_q(data[off:off + n8q]), f.unmont_q(data[off + n8q:off + 2 * n8q])); off += 2 * n8q
+        zkmi.init(int(os.environ.get("LOCAL_RANK", "0")) if zkmi.device_count() > 1 else 0)
+        self.additions = data[s[3][0]:s[3][0] + s[3][1]]
+        self.dev = {t: zkmi.DeviceBuffer.from_host(np.frombuffer(data, np.uint8, s[t][1], s[t][0])) for t in (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14) if s[t][1]}
+
+    def sec(self, t, elem_off=0):
+        return self.dev[t].ptr + 32 * elem_off
+
+    def release(self):
+        for b in self.dev.values():
+            b.free()
+        self.dev = {}
+
+
+class _Transcript:
+    def __init__(self, f):
+        self.f, self.parts = f, []
+
+    def reset(self):
+        self.parts = []
+
+    def point(self, p):                                  # addPolCommitment -> G1.toRprUncompressed: x, y big-endian normal form
+        self.parts.append(p[0].to_bytes(self.f.n8q, "big") + p[1].to_bytes(self.f.n8q, "big"))
+
+    def scalar(self, v):                                 # addScalar -> Fr.toRprBE
+        self.parts.append(v.to_bytes(32, "big"))
+
+    def challenge(self):
+        if not self.parts:
+            raise ValueError("Keccak256Transcript: No data to generate a transcript")
+        return int.from_bytes(keccak256(b"".join(self.parts)), "big") % self.f.r
+
+
+def _commit(key, poly):
+    """Polynomial.multiExponentiation (polynomial.js:970-977): batchFromMontgomery, G1.multiExpAffine over PTau[0:len], toAffine"""
+    f, L = key.f, zkmi.lib()
+    sc = zkmi.DeviceBuffer(poly.n * 32)
+    zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_FROM_MONTGOMERY, poly.ptr, sc.ptr, poly.n))
+    jac = np.zeros(3 * f.n8q, np.uint8)
+    zkmi.check(L.zkmi_msm_dev(f.cid, 1, key.sec(14), sc.ptr, poly.n, 32, zkmi.ptr(jac)))
+    sc.free()
+    aff = np.zeros(2 * f.n8q, np.uint8)
+    zkmi.check(L.zkmi_to_affine(f.cid, 1, zkmi.ptr(jac), zkmi.ptr(aff)))
+    return (f.unmont_q(aff[:f.n8q]), f.unmont_q(aff[f.n8q:]))
+
+
+def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
+    """plonk.prove(zkeyFileName, witnessFileName). blinding_mont: the 11 Fr.random() draws (:224-227) as Montgomery bytes,
+    for bit-exact reproduction; default = fresh randomness."""
+    def data(x):
+        if isinstance(x, (bytes, bytearray, memoryview, np.ndarray)):
+            return bytes(x)
+        with open(x, "rb") as fh:
+            return fh.read()
+
+    key = zkey if isinstance(zkey, PlonkKey) else PlonkKey(data(zkey))
+    f, L, r, n, power = key.f, zkmi.lib(), key.f.r, key.n, key.power
+    wt = data(witness_file)
+    ws = {}
+    off = 12
+    for _ in range(struct.unpack_from("<I", wt, 8)[0]):
+        t, ln = struct.unpack_from("<IQ", wt, off)
+        ws[t] = (off + 12, ln)
+        off += 12 + ln
+    n8 = struct.unpack_from("<I", wt, ws[1][0])[0]
+    wq = int.from_bytes(wt[ws[1][0] + 4:ws[1][0] + 4 + n8], "little")
+    n_witness = struct.unpack_from("<I", wt, ws[1][0] + 4 + n8)[0]
+    if key.r != wq:
+        raise ValueError("Curve of the witness does not match the curve of the proving key")
+    if n_witness != key.nVars - key.nAdditions:
+        raise ValueError(f"Invalid witness length. Circuit: {key.nVars}, witness: {n_witness}, {key.nAdditions}")
+    wit = np.frombuffer(wt, np.uint8, n_witness * 32, ws[2][0]).copy()
+    public = [int.from_bytes(bytes(wit[32 * i:32 * i + 32]), "little") for i in range(1, key.nPublic + 1)]
+    wit[:32] = 0                                                                          # :94-96
+    if blinding_mont is None:
+        b = [0] + [int.from_bytes(os.urandom(64), "little") % r for _ in range(11)]
+    else:
+        b = [0] + [f.unmont(x) for x in blinding_mont]
+
+    # calculateAdditions (:174-204): each internal signal may depend on earlier ones — sequential, on the host
+    internal = []
+    nW = key.nVars - key.nAdditions
+
+    def get_witness(idx):
+        if idx < nW:
+            return int.from_bytes(bytes(wit[32 * idx:32 * idx + 32]), "little")
+        return internal[idx - nW] if idx < key.nVars else 0
+    for i in range(key.nAdditions):
+        o = 72 * i
+        s1, s2 = struct.unpack_from("<II", key.additions, o)
+        f1, f2 = f.unmont(key.additions[o + 8:o + 40]), f.unmont(key.additions[o + 40:o + 72])
+        internal.append((f1 * get_witness(s1) + f2 * get_witness(s2)) % r)
+    d_wit = zkmi.DeviceBuffer.from_host(wit)
+    d_int = zkmi.DeviceBuffer.from_host(np.frombuffer(b"".join(v.to_bytes(32, "little") for v in internal) or bytes(32), np.uint8))
+
+    tr = _Transcript(f)
+    pts, evs = {}, {}
+    w_n, w_4n, w_2 = f.root(power), f.root(power + 2), f.root(2)
+    mont = f.mont
+
+    # ---- ROUND 1 (:222-313)
+    A, B, Cw = _Poly(f, n, False), _Poly(f, n, False), _Poly(f, n, False)
+    zkmi.check(L.zkmi_plonk_gather_wires_dev(f.cid, d_wit.ptr, nW, d_int.ptr, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n,
+                                             A.ptr, B.ptr, Cw.ptr))
+    for p in (A, B, Cw):
+        zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_TO_MONTGOMERY, p.ptr, p.ptr, n))
+    pA, pB, pC = A.ntt(True), B.ntt(True), Cw.ntt(True)
+    eA, eB, eC = pA.extended_evals(4), pB.extended_evals(4), pC.extended_evals(4)
+    pA, pB, pC = pA.blinded([b[2], b[1]]), pB.blinded([b[4], b[3]]), pC.blinded([b[6], b[5]])
+    for nm, p in (("A", pA), ("B", pB), ("C", pC)):
+        pts[nm] = _commit(key, p)
+
+    # ---- ROUND 2 (:315-455)
+    tr.reset()
+    for nm in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):
+        tr.point(key.commit[nm])
+    for i in range(key.nPublic):
+        tr.scalar(A.get(i))
+    for nm in ("A", "B", "C"):
+        tr.point(pts[nm])
+    beta = tr.challenge()
+    tr.reset(); tr.scalar(beta)
+    gamma = tr.challenge()
+    Zb = _Poly(f, n, False)
+    zkmi.check(L.zkmi_plonk_compute_z_dev(f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), n, zkmi.ptr(mont(beta)),
+                                          zkmi.ptr(mont(gamma)), zkmi.ptr(mont(key.k1)), zkmi.ptr(mont(key.k2)), zkmi.ptr(w_n), Zb.ptr))
+    pZ = Zb.ntt(True)
+    eZ = pZ.extended_evals(4)
+    pZ = pZ.blinded([b[9], b[8], b[7]])
+    pts["Z"] = _commit(key, pZ)
+
+    # ---- ROUND 3 (:457-684)
+    tr.reset(); tr.scalar(beta); tr.scalar(gamma); tr.point(pts["Z"])
+    alpha = tr.challenge()
+    ev = zkmi.PlonkEvals(eA.ptr, eB.ptr, eC.ptr, eZ.ptr, key.sec(7, n), key.sec(8, n), key.sec(9, n), key.sec(10, n), key.sec(11, n),
+                         key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), key.sec(13), A.ptr)
+    T, Tz = _Poly(f, 4 * n, False), _Poly(f, 4 * n, False)
+    blind = np.concatenate([mont(b[i]) for i in range(1, 12)])
+    zkmi.check(L.zkmi_plonk_compute_t_dev(f.cid, C.byref(ev), n, key.nPublic, zkmi.ptr(blind), zkmi.ptr(mont(beta)), zkmi.ptr(mont(gamma)), zkmi.ptr(mont(alpha)),
+                                          zkmi.ptr(mont(key.k1)), zkmi.ptr(mont(key.k2)), zkmi.ptr(w_n), zkmi.ptr(w_4n), zkmi.ptr(w_2), T.ptr, Tz.ptr))
+    pT = T.ntt(True, out=T)
+    zkmi.check(L.zkmi_poly_div_zh_dev(f.cid, pT.ptr, 4 * n, n, 4))
+    pTz = Tz.ntt(True, out=Tz)
+    pT.axpy(pTz)
+    if not pT.tail_is_zero(3 * n + 6):
+        raise ValueError("T Polynomial is not well calculated")                          # :645-647
+    T1 = _Poly(f, n + 1).copy_from(pT.at(0), n)
+    T2 = _Poly(f, n + 1).copy_from(pT.at(n), n)
+    T3 = _Poly(f, n + 6).copy_from(pT.at(2 * n), n + 6)
+    T1.set(n, b[10])
+    T2.set(0, (T2.get(0) - b[10]) % r); T2.set(n, b[11])
+    T3.set(0, (T3.get(0) - b[11]) % r)
+    for nm, p in (("T1", T1), ("T2", T2), ("T3", T3)):
+        pts[nm] = _commit(key, p)
+
+    # ---- ROUND 4 (:686-708)
+    tr.reset(); tr.scalar(alpha)
+    for nm in ("T1", "T2", "T3"):
+        tr.point(pts[nm])
+    xi = tr.challenge()
+    xiw = xi * f.unmont(w_n) % r
+    S1c = _Poly(f, n, False).copy_from(key.sec(12, 0), n)
+    S2c = _Poly(f, n, False).copy_from(key.sec(12, 5 * n), n)
+    S3c = _Poly(f, n, False).copy_from(key.sec(12, 10 * n), n)
+    evs["eval_a"], evs["eval_b"], evs["eval_c"] = pA.evaluate(xi), pB.evaluate(xi), pC.evaluate(xi)
+    evs["eval_s1"], evs["eval_s2"], evs["eval_zw"] = S1c.evaluate(xi), S2c.evaluate(xi), pZ.evaluate(xiw)
+
+    # ---- ROUND 5 (:710-888)
+    tr.reset(); tr.scalar(xi)
+    for k in ("eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw"):
+        tr.scalar(evs[k])
+    v = [0, tr.challenge()]
+    for i in range(2, 6):
+        v.append(v[i - 1] * v[1] % r)
+    xin = pow(xi, n, r)
+    zh = (xin - 1) % r
+    wv = f.unmont(w_n)
+    Lg, ww = [0], 1
+    for i in range(1, max(1, key.nPublic) + 1):
+        Lg.append(ww * zh % r * pow(n * (xi - ww) % r, -1, r) % r)
+        ww = ww * wv % r
+    eval_l1 = (xin - 1) * pow(n * (xi - 1) % r, -1, r) % r
+    eval_pi = 0
+    for i, pub in enumerate(public):
+        eval_pi = (eval_pi - pub * Lg[i + 1]) % r
+    ea, eb, ec, es1, es2, ezw = (evs[k] for k in ("eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw"))
+    alpha2, betaxi = alpha * alpha % r, beta * xi % r
+    e2 = (ea + betaxi + gamma) * (eb + betaxi * key.k1 + gamma) % r * (ec + betaxi * key.k2 + gamma) % r * alpha % r
+    e3 = (ea + beta * es1 + gamma) * (eb + beta * es2 + gamma) % r * ezw % r * alpha % r
+    e4 = eval_l1 * alpha2 % r
+    Rp = _Poly(f, n + 6)
+    q_coef = lambda t: _Poly(f, n, False).copy_from(key.sec(t, 0), n)
+    for t, k in ((7, ea * eb % r), (8, ea), (9, eb), (10, ec), (11, None)):
+        qp = q_coef(t)
+        Rp.axpy(qp, k)
+        qp.free()
+    Rp.axpy(pZ, e2)
+    Rp.axpy(S3c, e3 * beta % r, sub=True)
+    Rp.axpy(pZ, e4)
+    tmp = _Poly(f, n + 6).copy_from(T3.ptr, n + 6)
+    tmp.scale(xin * xin % r)
+    tmp.axpy(T2, xin)
+    tmp.axpy(T1)
+    tmp.scale(zh)
+    Rp.axpy(tmp, sub=True)
+    Rp.add_scalar((eval_pi - e3 * (ec + gamma) - e4) % r)
+    Wxi = _Poly(f, n + 6)
+    Wxi.axpy(Rp)
+    for p, k in ((pA, v[1]), (pB, v[2]), (pC, v[3]), (S1c, v[4]), (S2c, v[5])):
+        Wxi.axpy(p, k)
+    Wxi.add_scalar(-(v[1] * ea + v[2] * eb + v[3] * ec + v[4] * es1 + v[5] * es2) % r)
+    zkmi.check(L.zkmi_poly_div_by_zerofier_dev(f.cid, Wxi.ptr, Wxi.n, 1, zkmi.ptr(mont(xi))))
+    Wxiw = _Poly(f, pZ.n, False).copy_from(pZ.ptr, pZ.n)
+    Wxiw.add_scalar(-ezw % r)
+    zkmi.check(L.zkmi_poly_div_by_zerofier_dev(f.cid, Wxiw.ptr, Wxiw.n, 1, zkmi.ptr(mont(xiw))))
+    pts["Wxi"], pts["Wxiw"] = _commit(key, Wxi), _commit(key, Wxiw)
+
+    proof = {}
+    for nm in ("A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"):                       # src/proof.js:61-83 (insertion order)
+        proof[nm] = [str(pts[nm][0]), str(pts[nm][1]), "1"]
+    for k in ("eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw"):
+        proof[k] = str(evs[k])
+    proof["protocol"] = "plonk"
+    proof["curve"] = key.curve_name
+    if not isinstance(zkey, PlonkKey):
+        key.release()
+    return {"proof": proof, "publicSignals": [str(p) for p in public]}

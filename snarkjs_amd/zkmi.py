@@ -19,13 +19,15 @@ ERR_NO_DEVICE = 1
 # every symbol include/zkmi.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "zkmi_init", "zkmi_device_count", "zkmi_last_error", "zkmi_version", "zkmi_set_stream", "zkmi_synchronize",
-    "zkmi_dev_alloc", "zkmi_dev_free", "zkmi_memcpy_h2d", "zkmi_memcpy_d2h",
+    "zkmi_dev_alloc", "zkmi_dev_free", "zkmi_memcpy_h2d", "zkmi_memcpy_d2h", "zkmi_memcpy_d2d", "zkmi_memset_dev",
     "zkmi_msm", "zkmi_release_bases", "zkmi_msm_dev", "zkmi_msm_set_window_bits", "zkmi_msm_accum_ms",
     "zkmi_ntt", "zkmi_ntt_dev",
     "zkmi_fr_batch_apply_key", "zkmi_fr_batch_apply_key_dev", "zkmi_fr_batch", "zkmi_fr_batch_dev",
     "zkmi_groth16_join_abc", "zkmi_groth16_join_abc_dev",
     "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_release", "zkmi_groth16_stage_ms",
-    "zkmi_gen_geometric_bases_dev", "zkmi_to_affine", "zkmi_point_add", "zkmi_last_kernel_ms",
+    "zkmi_gen_geometric_bases_dev", "zkmi_to_affine", "zkmi_point_add", "zkmi_fr_root",
+    "zkmi_plonk_gather_wires_dev", "zkmi_plonk_compute_z_dev", "zkmi_plonk_compute_t_dev", "zkmi_poly_axpy_dev", "zkmi_poly_scale_dev",
+    "zkmi_poly_evaluate_dev", "zkmi_poly_is_zero_dev", "zkmi_poly_div_zh_dev", "zkmi_poly_div_by_zerofier_dev", "zkmi_last_kernel_ms",
 ]
 
 
@@ -37,6 +39,10 @@ class ZkmiError(RuntimeError):
 
 class Pages(C.Structure):
     _fields_ = [("ptr", C.POINTER(C.c_void_p)), ("len", C.POINTER(C.c_size_t)), ("n_pages", C.c_int)]
+
+
+class PlonkEvals(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("a", "b", "c", "z", "qm", "ql", "qr", "qo", "qc", "s1", "s2", "s3", "lagrange", "pub_a")]
 
 
 class Groth16Zkey(C.Structure):
@@ -69,6 +75,8 @@ def lib():
     L.zkmi_dev_free.argtypes = [vp]
     L.zkmi_memcpy_h2d.argtypes = [vp, vp, sz]
     L.zkmi_memcpy_d2h.argtypes = [vp, vp, sz]
+    L.zkmi_memcpy_d2d.argtypes = [vp, vp, sz]
+    L.zkmi_memset_dev.argtypes = [vp, C.c_int, sz]
     L.zkmi_msm.argtypes = [C.c_int, C.c_int, Pages, Pages, sz, sz, C.c_uint64, u8p]
     L.zkmi_release_bases.argtypes = [C.c_uint64]
     L.zkmi_msm_dev.argtypes = [C.c_int, C.c_int, vp, vp, sz, sz, u8p]
@@ -86,6 +94,17 @@ def lib():
     L.zkmi_gen_geometric_bases_dev.argtypes = [C.c_int, C.c_int, sz, C.c_uint64, C.c_uint64, vp]
     L.zkmi_to_affine.argtypes = [C.c_int, C.c_int, u8p, u8p]
     L.zkmi_point_add.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p]
+    L.zkmi_fr_root.argtypes = [C.c_int, C.c_uint, u8p]
+    u32 = C.c_uint32
+    L.zkmi_plonk_gather_wires_dev.argtypes = [C.c_int, vp, u32, vp, u32, vp, vp, vp, u32, u32, vp, vp, vp]
+    L.zkmi_plonk_compute_z_dev.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, u32, u8p, u8p, u8p, u8p, u8p, vp]
+    L.zkmi_plonk_compute_t_dev.argtypes = [C.c_int, C.POINTER(PlonkEvals), u32, u32, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p, vp, vp]
+    L.zkmi_poly_axpy_dev.argtypes = [C.c_int, vp, vp, sz, u8p, C.c_int]
+    L.zkmi_poly_scale_dev.argtypes = [C.c_int, vp, sz, u8p]
+    L.zkmi_poly_evaluate_dev.argtypes = [C.c_int, vp, sz, u8p, u8p]
+    L.zkmi_poly_is_zero_dev.argtypes = [C.c_int, vp, sz, C.POINTER(C.c_int)]
+    L.zkmi_poly_div_zh_dev.argtypes = [C.c_int, vp, sz, u32, u32]
+    L.zkmi_poly_div_by_zerofier_dev.argtypes = [C.c_int, vp, sz, u32, u8p]
     L.zkmi_groth16_load.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64]
     L.zkmi_groth16_prove.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p]
     L.zkmi_groth16_prove_dev.argtypes = [C.c_uint64, vp, u8p, u8p, u8p, u8p, u8p]

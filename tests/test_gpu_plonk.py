@@ -1,0 +1,163 @@
+"""GPU parity of the PLONK rows: device polynomial kernels vs the Python restatement
+(oracle/plonk_oracle.py) on seeded inputs, and the full device prover vs the seeded proofs of the reference."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import plonk_oracle as P
+import synth
+
+
+def test_product_keccak_matches_oracle_and_known_answers():
+    from snarkjs_amd import plonk
+    assert plonk.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    for k in (1, 3, 64, 135, 136, 137, 271, 272, 273, 1000):
+        m = bytes((7 * i + k) & 255 for i in range(k))
+        assert plonk.keccak256(m) == P.keccak256(m), k
+
+
+@pytest.fixture(scope="module")
+def env():
+    from snarkjs_amd import zkmi, plonk
+    zkmi.init(0)
+    return zkmi, plonk, plonk._Field(0), P.Ctx()
+
+
+def _dev(zkmi, cx, vals):
+    return zkmi.DeviceBuffer.from_host(np.frombuffer(cx.to_mont(vals), np.uint8))
+
+
+def _host(cx, buf, n):
+    return cx.from_mont(buf.to_host(n * 32))
+
+
+def _rand(seed, n, r):
+    return [synth.to_int(b) % r for b in synth.elems(seed, n).reshape(n, 32)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 7, 256, 2048, 2049, 5000, 70001])
+def test_poly_ops_vs_oracle(env, n):
+    zkmi, plonk, f, cx = env
+    L, r = zkmi.lib(), cx.r
+    a, b = _rand(1000 + n, n, r), _rand(2000 + n, n, r)
+    k, x = _rand(3, 2, r)
+    mont = lambda v: zkmi.ptr(f.mont(v))
+    # axpy / scale (polynomial.js:218-284)
+    for sub in (0, 1):
+        for kk in (None, k):
+            da, db = _dev(zkmi, cx, a), _dev(zkmi, cx, b)
+            zkmi.check(L.zkmi_poly_axpy_dev(0, da.ptr, db.ptr, n, None if kk is None else mont(kk), sub))
+            assert _host(cx, da, n) == P.poly_add(a, b, r, kk, -1 if sub else 1)
+    da = _dev(zkmi, cx, a)
+    zkmi.check(L.zkmi_poly_scale_dev(0, da.ptr, n, mont(k)))
+    assert _host(cx, da, n) == [v * k % r for v in a]
+    # evaluate (Horner, :174-184)
+    out = np.zeros(32, np.uint8)
+    da = _dev(zkmi, cx, a)
+    zkmi.check(L.zkmi_poly_evaluate_dev(0, da.ptr, n, mont(x), zkmi.ptr(out)))
+    assert f.unmont(out) == P.evaluate(a, x, r)
+    # divByZerofier(1, beta) (:617-674): build an exactly divisible polynomial p = q * (X - beta)
+    if n >= 2:
+        q = a[:n - 1]
+        p = [0] * n
+        for i, c in enumerate(q):
+            p[i] = (p[i] - x * c) % r
+            p[i + 1] = (p[i + 1] + c) % r
+        want = P.div_by_zerofier(p, 1, x, r)
+        assert want[:n - 1] == q and want[n - 1] == 0
+        dp = _dev(zkmi, cx, p)
+        zkmi.check(L.zkmi_poly_div_by_zerofier_dev(0, dp.ptr, n, 1, mont(x)))
+        assert _host(cx, dp, n) == want
+        p[0] = (p[0] + 1) % r                       # not divisible any more
+        dp = _dev(zkmi, cx, p)
+        assert L.zkmi_poly_div_by_zerofier_dev(0, dp.ptr, n, 1, mont(x)) != 0
+        assert b"not divisible" in L.zkmi_last_error()
+    z = C.c_int(0)
+    dz = _dev(zkmi, cx, [0] * n)
+    zkmi.check(L.zkmi_poly_is_zero_dev(0, dz.ptr, n, C.byref(z)))
+    assert z.value == 1
+    zkmi.check(L.zkmi_poly_is_zero_dev(0, da.ptr, n, C.byref(z)))
+    assert z.value == (0 if any(a) else 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dom", [8, 256, 4096])
+def test_div_zh_vs_oracle(env, dom):
+    zkmi, plonk, f, cx = env
+    L, r = zkmi.lib(), cx.r
+    # t = q * (X^dom - 1) with deg q < 3*dom - dom... as in computeT: length 4*dom, quotient degree < 3*dom + 6 - ... keep it exact
+    q = _rand(77 + dom, 3 * dom - 4, r) + [0] * (dom + 4)
+    t = [0] * (4 * dom)
+    for i, c in enumerate(q[:3 * dom - 4]):
+        t[i] = (t[i] - c) % r
+        t[i + dom] = (t[i + dom] + c) % r
+    want = P.div_zh(t, dom, 4, r)
+    assert want == q
+    dt = _dev(zkmi, cx, t)
+    zkmi.check(L.zkmi_poly_div_zh_dev(0, dt.ptr, 4 * dom, dom, 4))
+    assert _host(cx, dt, 4 * dom) == want
+    t[4 * dom - 1] = 5
+    dt = _dev(zkmi, cx, t)
+    assert L.zkmi_poly_div_zh_dev(0, dt.ptr, 4 * dom, dom, 4) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["plonk_bn128_small", "plonk_bn128_n2048"])
+def test_plonk_stages_and_golden_proof(env, golden_dir, tag):
+    """Device prover == the reference's seeded proof (sha256 of the proof JSON)."""
+    zkmi, plonk, f, cx = env
+    with open(os.path.join(golden_dir, f"{tag}.json")) as fh:
+        g = json.load(fh)
+    zkey = open(os.path.join(golden_dir, f"{tag}.zkey"), "rb").read()
+    wtns = open(os.path.join(golden_dir, f"{tag}.wtns"), "rb").read()
+    blind = [bytes.fromhex(x) for x in g["blinding_mont"]]
+    res = plonk.prove(zkey, wtns, blinding_mont=blind)
+    assert res["publicSignals"] == g["publicSignals"]
+    assert res["proof"] == g["proof"]
+    assert hashlib.sha256(json.dumps(res["proof"], separators=(",", ":")).encode()).hexdigest() == g["proof_sha256"]
+    with pytest.raises(ValueError):
+        plonk.prove(zkey, wtns[:-32])
+    # a resident key proves twice with different blinding; both verify the same public signals and differ as proofs
+    key = plonk.PlonkKey(zkey)
+    p1 = plonk.prove(key, wtns, blinding_mont=blind)
+    p2 = plonk.prove(key, wtns)
+    key.release()
+    assert p1["proof"] == g["proof"] and p2["proof"] != g["proof"] and p2["publicSignals"] == g["publicSignals"]
+
+
+@pytest.mark.gpu
+def test_compute_z_and_t_stages_vs_oracle(env, golden_dir):
+    """computeZ / computeT kernels against the oracle's intermediate arrays on the n = 2048 fixture."""
+    zkmi, plonk, f, cx = env
+    L = zkmi.lib()
+    tag = "plonk_bn128_n2048"
+    with open(os.path.join(golden_dir, f"{tag}.json")) as fh:
+        g = json.load(fh)
+    zkey = open(os.path.join(golden_dir, f"{tag}.zkey"), "rb").read()
+    wtns = open(os.path.join(golden_dir, f"{tag}.wtns"), "rb").read()
+    st = {}
+    P.plonk_prove(zkey, wtns, [bytes.fromhex(x) for x in g["blinding_mont"]], stages=st)
+    key = plonk.PlonkKey(zkey)
+    n = key.n
+    mont = lambda v: zkmi.ptr(f.mont(v))
+    dA, dB, dC = (_dev(zkmi, cx, st[k]) for k in ("A", "B", "C"))
+    dZ = zkmi.DeviceBuffer(n * 32)
+    zkmi.check(L.zkmi_plonk_compute_z_dev(0, dA.ptr, dB.ptr, dC.ptr, key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), n, mont(st["beta"]), mont(st["gamma"]),
+                                          mont(key.k1), mont(key.k2), zkmi.ptr(f.root(key.power)), dZ.ptr))
+    assert _host(cx, dZ, n) == st["Zb"]
+    keep = [_dev(zkmi, cx, st[k]) for k in ("eA", "eB", "eC", "eZ")]
+    ev = zkmi.PlonkEvals(keep[0].ptr, keep[1].ptr, keep[2].ptr, keep[3].ptr, key.sec(7, n), key.sec(8, n), key.sec(9, n), key.sec(10, n), key.sec(11, n),
+                         key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), key.sec(13), dA.ptr)
+    dT, dTz = zkmi.DeviceBuffer(4 * n * 32), zkmi.DeviceBuffer(4 * n * 32)
+    blind = np.concatenate([np.frombuffer(bytes.fromhex(x), np.uint8) for x in g["blinding_mont"]])
+    zkmi.check(L.zkmi_plonk_compute_t_dev(0, C.byref(ev), n, key.nPublic, zkmi.ptr(blind), mont(st["beta"]), mont(st["gamma"]), mont(st["alpha"]), mont(key.k1), mont(key.k2),
+                                          zkmi.ptr(f.root(key.power)), zkmi.ptr(f.root(key.power + 2)), zkmi.ptr(f.root(2)), dT.ptr, dTz.ptr))
+    assert _host(cx, dT, 4 * n) == st["T"]
+    assert _host(cx, dTz, 4 * n) == st["Tz"]
+    key.release()
