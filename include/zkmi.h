@@ -84,6 +84,12 @@ int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalar
 /* Device time (ms, HIP events on the library stream) of the bucket-accumulation kernel of the last MSM that used job
  * slot `slot`: zkmi_msm / zkmi_msm_dev use slot 0; zkmi_groth16_prove uses 0..4 = A, B1, B2, C, H. -1 if never run. */
 double zkmi_msm_accum_ms(int slot);
+/* Resident bases with pre-computed window tables T[k][i] = 2^(c*k) * P_i (static per zkey / SRS: src/groth16_prove.js:84-100,
+ * src/polynomial/polynomial.js:970-977 slices the same PTau for every commitment). Build once from n device-resident affine
+ * points; each MSM then uses the first k <= n bases with k scalars of at most 32 bytes. */
+int zkmi_msm_table_build(int curve, int group, const void* d_bases, size_t n, uint64_t* handle);
+int zkmi_msm_table_dev(uint64_t handle, const void* d_scalars, size_t k, size_t scalar_bytes, uint8_t* out_jacobian);
+int zkmi_msm_table_release(uint64_t handle);
 /* Window width used for n terms (tuning knob; 0 restores the built-in table). */
 int zkmi_msm_set_window_bits(int c);
 

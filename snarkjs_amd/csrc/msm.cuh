@@ -25,7 +25,8 @@ struct MsmShape {
     int W;             // bucket sets: Wd, or 1 with pre-computed window tables (all digits share one set of buckets)
     uint32_t nb;       // buckets per set = 2^(c-1)
     int sb;            // scalar bytes
-    int precomp;       // bases are a table T[k][i] = 2^(c*k) * P_i (k < Wd, stride n): entry index = k*n + i
+    int precomp;       // bases are a table T[k][i] = 2^(c*k) * P_i (k < Wd): entry index = k*stride + i
+    uint32_t stride;   // points per table row (>= n: an MSM may use a prefix of the resident bases)
 };
 
 // ---- scalar access / signed-digit recoding ----------------------------------------------------------------------
@@ -164,7 +165,7 @@ template <int NW> __global__ void k_msm_scatter(const uint8_t* __restrict__ scal
     for_each_digit<NW>(s, sh.c, sh.Wd, [&](int w, uint32_t mag, bool neg) {
         const size_t g = (sh.precomp ? (size_t)0 : (size_t)w * sh.nb) + (mag - 1);
         const uint32_t pos = starts[g] + msm_atomic_inc(cursor, g);
-        const uint32_t ent = sh.precomp ? (uint32_t)w * sh.n + (uint32_t)i : (uint32_t)i;
+        const uint32_t ent = sh.precomp ? (uint32_t)w * sh.stride + (uint32_t)i : (uint32_t)i;
         sorted[pos] = ent | (neg ? 0x80000000u : 0u);
     });
 }

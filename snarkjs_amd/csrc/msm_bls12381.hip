@@ -35,6 +35,10 @@ int msm_precompute_bls12381(int group, const void* d_bases, size_t n, int c, int
     if (group == 1) return msm_precompute<Fp<Bls12381Fq>>(d_bases, n, c, Wd, d_table);
     return msm_precompute<Fp2<Bls12381Fq>>(d_bases, n, c, Wd, d_table);
 }
+int msm_table_bls12381(int group, const void* d_table, size_t stride, int c, const void* d_scalars, size_t k, size_t sb, uint8_t* out) {
+    if (group == 1) return msm_run_table<Fp<Bls12381Fq>>(d_table, stride, c, d_scalars, k, sb, out);
+    return msm_run_table<Fp2<Bls12381Fq>>(d_table, stride, c, d_scalars, k, sb, out);
+}
 int msm_reduce_bls12381(int group, MsmJob* const* jobs, int njobs) {
     if (group == 1) return msm_reduce<Fp<Bls12381Fq>>(jobs, njobs);
     return msm_reduce<Fp2<Bls12381Fq>>(jobs, njobs);

@@ -100,7 +100,7 @@ struct MsmPlan {
 };
 constexpr int MSM_TB = 128, MSM_LOG_TB = 7;      // tree block: 128 lanes x 384 B (BLS12-381 G2 XYZZ) = 48 KiB of LDS
 // precomp_c != 0: the bases of every MSM run over this plan are pre-computed window tables built with that c
-int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan, int plan_slot = 0, int precomp_c = 0);
+int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan, int plan_slot = 0, int precomp_c = 0, size_t table_stride = 0);
 
 // One MSM in flight: per-window sums land in a pinned host slot; msm_fold turns them into the Jacobian result.
 struct MsmJob {
@@ -315,12 +315,36 @@ template <class F> int msm_precompute(const void* d_bases, size_t n, int c, int 
     return ZKMI_OK;
 }
 int msm_precompute_dispatch(int curve, int group, const void* d_bases, size_t n, int c, int Wd, void* d_table);
+// MSM of the first k scalars against a pre-computed table (stride points per row, window width c)
+template <class F> int msm_run_table(const void* d_table, size_t stride, int c, const void* d_scalars, size_t k, size_t sb, uint8_t* out_jac);
+int msm_table_dispatch(int curve, int group, const void* d_table, size_t stride, int c, const void* d_scalars, size_t k, size_t sb, uint8_t* out_jac);
 
 // non-template entry points (msm_bn254.hip / msm_bls12381.hip) for callers that must not instantiate the kernels again
 int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job);
 int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs);
 
 int msm_fold_dispatch(int curve, int group, const MsmJob& job, uint8_t* out_jac);
+
+template <class F> int msm_run_table(const void* d_table, size_t stride, int c, const void* d_scalars, size_t k, size_t sb, uint8_t* out_jac) {
+    constexpr int FW = FieldWords<F>::value;
+    Ctx& cx = ctx();
+    if (k == 0) { memset(out_jac, 0, 3 * 4 * FW); return ZKMI_OK; }
+    hipStream_t st = cx.stream;
+    MsmPlan pl;
+    MsmJob job;
+    ZK_TRY(msm_job_slot(0, job));
+    ZK_HIP(hipEventRecord(cx.ev0, st));
+    ZK_TRY(msm_sort(d_scalars, k, sb, pl, 0, c, stride));
+    ZK_TRY(msm_accumulate<F>(d_table, pl, 0, job));
+    MsmJob* jp = &job;
+    ZK_TRY(msm_reduce<F>(&jp, 1));
+    ZK_HIP(hipEventRecord(cx.ev1, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, cx.ev0, cx.ev1) == hipSuccess) cx.last_ms = ms;
+    msm_fold<F>(job, out_jac);
+    return ZKMI_OK;
+}
 
 template <class F, class FrC> int gen_bases_run(const uint8_t* gen_affine_host, size_t n, uint64_t f, uint64_t g, void* d_out) {
     constexpr int FW = FieldWords<F>::value;

@@ -17,7 +17,7 @@ template <int NW> static int msm_launch_digits(const uint8_t* d_scalars, const M
     return ZKMI_OK;
 }
 
-int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_slot, int precomp_c) {
+int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_slot, int precomp_c, size_t table_stride) {
     Ctx& cx = ctx();
     pl.slot = plan_slot & 1;
     const std::string sfx = pl.slot ? ".p1" : ".p0";
@@ -29,8 +29,9 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     sh.c = precomp_c ? precomp_c : (cx.msm_c_override ? cx.msm_c_override : msm_pick_c(n));
     sh.Wd = msm_digits(sb, sh.c);
     sh.W = sh.precomp ? 1 : sh.Wd;
+    sh.stride = (uint32_t)(table_stride ? table_stride : n);
     sh.nb = 1u << (sh.c - 1);
-    if (sh.precomp && (size_t)sh.Wd * n >= (1ull << 31)) return fail(ZKMI_ERR_UNSUPPORTED, "msm: pre-computed table too large for 31-bit indices");
+    if (sh.precomp && (size_t)sh.Wd * sh.stride >= (1ull << 31)) return fail(ZKMI_ERR_UNSUPPORTED, "msm: pre-computed table too large for 31-bit indices");
     const size_t total = (size_t)sh.W * sh.nb;
     pl.total = total;
     hipStream_t st = cx.stream;

@@ -64,6 +64,8 @@ int msm_accumulate_bls12381(int group, const void*, const MsmPlan&, uint32_t, Ms
 int msm_reduce_bn254(int group, MsmJob* const*, int);
 int msm_precompute_bn254(int group, const void*, size_t, int, int, void*);
 int msm_precompute_bls12381(int group, const void*, size_t, int, int, void*);
+int msm_table_bn254(int group, const void*, size_t, int, const void*, size_t, size_t, uint8_t*);
+int msm_table_bls12381(int group, const void*, size_t, int, const void*, size_t, size_t, uint8_t*);
 int msm_reduce_bls12381(int group, MsmJob* const*, int);
 int msm_fold_bn254(int group, const MsmJob&, uint8_t*);
 int msm_fold_bls12381(int group, const MsmJob&, uint8_t*);
@@ -90,6 +92,10 @@ int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const Msm
 int msm_precompute_dispatch(int curve, int group, const void* d_bases, size_t n, int c, int Wd, void* d_table) {
     ZK_TRY(check_cg(curve, group));
     return curve == ZKMI_CURVE_BN128 ? msm_precompute_bn254(group, d_bases, n, c, Wd, d_table) : msm_precompute_bls12381(group, d_bases, n, c, Wd, d_table);
+}
+int msm_table_dispatch(int curve, int group, const void* d_table, size_t stride, int c, const void* d_scalars, size_t k, size_t sb, uint8_t* out) {
+    ZK_TRY(check_cg(curve, group));
+    return curve == ZKMI_CURVE_BN128 ? msm_table_bn254(group, d_table, stride, c, d_scalars, k, sb, out) : msm_table_bls12381(group, d_table, stride, c, d_scalars, k, sb, out);
 }
 int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs) {
     ZK_TRY(check_cg(curve, group));
@@ -162,17 +168,31 @@ double zkmi_msm_accum_ms(int slot) {
     if (hipEventElapsedTime(&ms, g_ctx.job_ev[2 * slot], g_ctx.job_ev[2 * slot + 1]) != hipSuccess) return -1.0;
     return ms;
 }
+// Device buffers handed to the host are pooled by size: a prover allocates and drops the same few sizes every proof, and
+// hipMalloc / hipFree are synchronous and slow (and the first touch of fresh VRAM costs milliseconds of page-table set-up).
 int zkmi_dev_alloc(size_t bytes, void** d_ptr) {
     ZK_TRY(require_ctx());
-    ZK_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    if (!bytes) bytes = 1;
+    auto it = g_ctx.pool.find(bytes);
+    if (it != g_ctx.pool.end() && !it->second.empty()) {
+        *d_ptr = it->second.back();
+        it->second.pop_back();
+        g_ctx.pool_bytes -= bytes;
+    } else ZK_HIP(hipMalloc(d_ptr, bytes));
     g_ctx.user_allocs[*d_ptr] = bytes;
     return ZKMI_OK;
 }
 int zkmi_dev_free(void* d_ptr) {
     ZK_TRY(require_ctx());
     if (!d_ptr) return ZKMI_OK;
-    g_ctx.user_allocs.erase(d_ptr);
-    ZK_HIP(hipFree(d_ptr));
+    auto it = g_ctx.user_allocs.find(d_ptr);
+    if (it == g_ctx.user_allocs.end()) return fail(ZKMI_ERR_INVALID, "zkmi_dev_free: not a zkmi_dev_alloc pointer");
+    const size_t bytes = it->second;
+    g_ctx.user_allocs.erase(it);
+    if (g_ctx.pool_bytes + bytes <= g_ctx.pool_limit) {          // stream-ordered reuse: all library work runs on one stream
+        g_ctx.pool[bytes].push_back(d_ptr);
+        g_ctx.pool_bytes += bytes;
+    } else ZK_HIP(hipFree(d_ptr));
     return ZKMI_OK;
 }
 int zkmi_memcpy_h2d(void* d, const void* h, size_t bytes) {
@@ -233,6 +253,49 @@ int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t 
     ZK_TRY(ws_get("api.scalars", n * scalar_bytes, &d_s));
     ZK_TRY(upload_pages(scalars, n * scalar_bytes, d_s));
     return msm_dev_dispatch(curve, group, d_b, d_s, n, scalar_bytes, out);
+}
+// ---- resident base tables --------------------------------------------------------------------------------------------------
+struct MsmTable { void* p = nullptr; size_t n = 0; int c = 0, Wd = 0, curve = 0, group = 0; };
+static std::map<uint64_t, MsmTable> g_tables;
+static uint64_t g_next_table = 1;
+static int table_build(int curve, int group, const void* d_bases, size_t n, MsmTable& t) {
+    const size_t pb = (size_t)2 * group * n8q_of(curve);
+    t.curve = curve; t.group = group; t.n = n;
+    t.c = msm_precomp_c(n);
+    t.Wd = msm_digits(32, t.c);
+    if ((size_t)t.Wd * n >= (1ull << 31)) return fail(ZKMI_ERR_UNSUPPORTED, "msm table: too many points");
+    ZK_HIP(hipMalloc(&t.p, (size_t)t.Wd * n * pb));
+    ZK_TRY(msm_precompute_dispatch(curve, group, d_bases, n, t.c, t.Wd, t.p));
+    ZK_HIP(hipStreamSynchronize(g_ctx.stream));
+    return ZKMI_OK;
+}
+int zkmi_msm_table_build(int curve, int group, const void* d_bases, size_t n, uint64_t* handle) {
+    ZK_TRY(require_ctx());
+    ZK_TRY(check_cg(curve, group));
+    if (!handle || !d_bases || !n) return fail(ZKMI_ERR_INVALID, "msm_table_build: bad argument");
+    MsmTable t;
+    ZK_TRY(table_build(curve, group, d_bases, n, t));
+    *handle = g_next_table++;
+    g_tables[*handle] = t;
+    return ZKMI_OK;
+}
+int zkmi_msm_table_dev(uint64_t handle, const void* d_scalars, size_t k, size_t scalar_bytes, uint8_t* out) {
+    ZK_TRY(require_ctx());
+    auto it = g_tables.find(handle);
+    if (it == g_tables.end()) return fail(ZKMI_ERR_INVALID, "msm_table_dev: unknown table");
+    const MsmTable& t = it->second;
+    if (!out) return fail(ZKMI_ERR_INVALID, "null output");
+    if (k > t.n) return fail(ZKMI_ERR_INVALID, "msm_table_dev: more scalars than resident bases");
+    if (scalar_bytes == 0 || scalar_bytes > 32) return fail(ZKMI_ERR_UNSUPPORTED, "msm_table_dev: tables are built for scalars of at most 32 bytes");
+    return msm_table_dispatch(t.curve, t.group, t.p, t.n, t.c, d_scalars, k, scalar_bytes, out);
+}
+int zkmi_msm_table_release(uint64_t handle) {
+    auto it = g_tables.find(handle);
+    if (it == g_tables.end()) return ZKMI_OK;
+    if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+    if (it->second.p) (void)hipFree(it->second.p);
+    g_tables.erase(it);
+    return ZKMI_OK;
 }
 int zkmi_release_bases(uint64_t key) {
     auto it = g_ctx.base_cache.find(key);

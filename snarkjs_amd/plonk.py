@@ -195,6 +195,10 @@ class PlonkKey:
         zkmi.init(int(os.environ.get("LOCAL_RANK", "0")) if zkmi.device_count() > 1 else 0)
         self.additions = data[s[3][0]:s[3][0] + s[3][1]]
         self.dev = {t: zkmi.DeviceBuffer.from_host(np.frombuffer(data, np.uint8, s[t][1], s[t][0])) for t in (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14) if s[t][1]}
+        # the SRS is static: pre-computed window tables for the nine commitments of every proof (all use a prefix of PTau)
+        self.n_ptau = s[14][1] // (2 * f.n8q)
+        self.ptau_table = C.c_uint64(0)
+        zkmi.check(zkmi.lib().zkmi_msm_table_build(self.curve_id, 1, self.dev[14].ptr, self.n_ptau, C.byref(self.ptau_table)))
 
     def sec(self, t, elem_off=0):
         return self.dev[t].ptr + 32 * elem_off
@@ -203,6 +207,9 @@ class PlonkKey:
         for b in self.dev.values():
             b.free()
         self.dev = {}
+        if self.ptau_table.value:
+            zkmi.lib().zkmi_msm_table_release(self.ptau_table)
+            self.ptau_table = C.c_uint64(0)
 
 
 class _Transcript:
@@ -230,7 +237,7 @@ def _commit(key, poly):
     sc = zkmi.DeviceBuffer(poly.n * 32)
     zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_FROM_MONTGOMERY, poly.ptr, sc.ptr, poly.n))
     jac = np.zeros(3 * f.n8q, np.uint8)
-    zkmi.check(L.zkmi_msm_dev(f.cid, 1, key.sec(14), sc.ptr, poly.n, 32, zkmi.ptr(jac)))
+    zkmi.check(L.zkmi_msm_table_dev(key.ptau_table, sc.ptr, poly.n, 32, zkmi.ptr(jac)))
     sc.free()
     aff = np.zeros(2 * f.n8q, np.uint8)
     zkmi.check(L.zkmi_to_affine(f.cid, 1, zkmi.ptr(jac), zkmi.ptr(aff)))

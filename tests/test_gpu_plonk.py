@@ -161,3 +161,23 @@ def test_compute_z_and_t_stages_vs_oracle(env, golden_dir):
     assert _host(cx, dT, 4 * n) == st["T"]
     assert _host(cx, dTz, 4 * n) == st["Tz"]
     key.release()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lg", [4, 10, 13])
+def test_synthetic_plonk_key_device_vs_oracle(env, lg):
+    """A synthetic but VALID key (tests/synth_plonk.py): the device prover must accept it (copy-constraint and divisibility
+    checks) and agree with the Python restatement coefficient for coefficient (proof equality)."""
+    import synth_plonk
+    zkmi, plonk, f, cx = env
+    zkey, wtns = synth_plonk.make("bn128", lg, seed=lg)
+    blind = [bytes(f.mont(1000 + 17 * i)) for i in range(11)]
+    got = plonk.prove(zkey, wtns, blinding_mont=blind)
+    want_proof, want_pub = P.plonk_prove(zkey, wtns, blind)
+    assert got["publicSignals"] == want_pub and got["proof"] == want_proof
+    # a corrupted witness must be rejected by the copy-constraint check, like the reference does (:437-439)
+    bad = bytearray(wtns)
+    bad[-32] ^= 1
+    with pytest.raises(Exception) as ei:
+        plonk.prove(zkey, bytes(bad), blinding_mont=blind)
+    assert "Copy constraints does not match" in str(ei.value) or "not divisible" in str(ei.value)
