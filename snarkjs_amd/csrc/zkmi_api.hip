@@ -223,41 +223,11 @@ int zkmi_msm_set_window_bits(int c) {
     g_ctx.msm_c_override = c;
     return ZKMI_OK;
 }
-int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t scalar_bytes, uint8_t* out) {
-    ZK_TRY(require_ctx());
-    if (!out) return fail(ZKMI_ERR_INVALID, "null output");
-    return msm_dev_dispatch(curve, group, d_bases, d_scalars, n, scalar_bytes, out);
-}
-int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t n, size_t scalar_bytes, uint64_t key, uint8_t* out) {
-    ZK_TRY(require_ctx());
-    ZK_TRY(check_cg(curve, group));
-    if (!out) return fail(ZKMI_ERR_INVALID, "null output");
-    const size_t pb = (size_t)2 * group * n8q_of(curve);
-    if (n == 0) { memset(out, 0, 3 * group * n8q_of(curve)); return ZKMI_OK; }
-    if (pages_total(scalars) != n * scalar_bytes) return fail(ZKMI_ERR_INVALID, "Scalar size does not match");
-    void *d_b = nullptr, *d_s = nullptr;
-    if (key) {
-        DevBuf& b = g_ctx.base_cache[key];
-        if (b.cap != n * pb) {
-            if (b.p) ZK_HIP(hipFree(b.p));
-            b.p = nullptr; b.cap = 0;
-            ZK_HIP(hipMalloc(&b.p, n * pb));
-            b.cap = n * pb;
-            ZK_TRY(upload_pages(bases, n * pb, b.p));
-        }
-        d_b = b.p;
-    } else {
-        ZK_TRY(ws_get("api.bases", n * pb, &d_b));
-        ZK_TRY(upload_pages(bases, n * pb, d_b));
-    }
-    ZK_TRY(ws_get("api.scalars", n * scalar_bytes, &d_s));
-    ZK_TRY(upload_pages(scalars, n * scalar_bytes, d_s));
-    return msm_dev_dispatch(curve, group, d_b, d_s, n, scalar_bytes, out);
-}
 // ---- resident base tables --------------------------------------------------------------------------------------------------
 struct MsmTable { void* p = nullptr; size_t n = 0; int c = 0, Wd = 0, curve = 0, group = 0; };
 static std::map<uint64_t, MsmTable> g_tables;
 static uint64_t g_next_table = 1;
+static std::map<uint64_t, MsmTable> g_key_tables;      // zkmi_msm base_cache_key -> resident table
 static int table_build(int curve, int group, const void* d_bases, size_t n, MsmTable& t) {
     const size_t pb = (size_t)2 * group * n8q_of(curve);
     t.curve = curve; t.group = group; t.n = n;
@@ -297,11 +267,47 @@ int zkmi_msm_table_release(uint64_t handle) {
     g_tables.erase(it);
     return ZKMI_OK;
 }
+int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t scalar_bytes, uint8_t* out) {
+    ZK_TRY(require_ctx());
+    if (!out) return fail(ZKMI_ERR_INVALID, "null output");
+    return msm_dev_dispatch(curve, group, d_bases, d_scalars, n, scalar_bytes, out);
+}
+int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t n, size_t scalar_bytes, uint64_t key, uint8_t* out) {
+    ZK_TRY(require_ctx());
+    ZK_TRY(check_cg(curve, group));
+    if (!out) return fail(ZKMI_ERR_INVALID, "null output");
+    const size_t pb = (size_t)2 * group * n8q_of(curve);
+    if (n == 0) { memset(out, 0, 3 * group * n8q_of(curve)); return ZKMI_OK; }
+    if (pages_total(scalars) != n * scalar_bytes) return fail(ZKMI_ERR_INVALID, "Scalar size does not match");
+    void *d_b = nullptr, *d_s = nullptr;
+    ZK_TRY(ws_get("api.scalars", n * scalar_bytes, &d_s));
+    ZK_TRY(upload_pages(scalars, n * scalar_bytes, d_s));
+    if (key) {
+        // resident bases: uploaded once, expanded into pre-computed window tables (zkey sections / SRS are static)
+        MsmTable& t = g_key_tables[key];
+        if (t.n != n || t.curve != curve || t.group != group) {
+            if (t.p) { ZK_HIP(hipStreamSynchronize(g_ctx.stream)); (void)hipFree(t.p); t = MsmTable(); }
+            void* raw = nullptr;
+            ZK_HIP(hipMalloc(&raw, n * pb));
+            ZK_TRY(upload_pages(bases, n * pb, raw));
+            int rc = table_build(curve, group, raw, n, t);
+            (void)hipFree(raw);
+            if (rc) { g_key_tables.erase(key); return rc; }
+        }
+        if (scalar_bytes <= 32) return msm_table_dispatch(curve, group, t.p, t.n, t.c, d_s, n, scalar_bytes, out);
+        d_b = t.p;                                   // wider scalars: row 0 of the table is the plain base array
+    } else {
+        ZK_TRY(ws_get("api.bases", n * pb, &d_b));
+        ZK_TRY(upload_pages(bases, n * pb, d_b));
+    }
+    return msm_dev_dispatch(curve, group, d_b, d_s, n, scalar_bytes, out);
+}
 int zkmi_release_bases(uint64_t key) {
-    auto it = g_ctx.base_cache.find(key);
-    if (it == g_ctx.base_cache.end()) return ZKMI_OK;
-    if (it->second.p) ZK_HIP(hipFree(it->second.p));
-    g_ctx.base_cache.erase(it);
+    auto it = g_key_tables.find(key);
+    if (it == g_key_tables.end()) return ZKMI_OK;
+    if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+    if (it->second.p) (void)hipFree(it->second.p);
+    g_key_tables.erase(it);
     return ZKMI_OK;
 }
 

@@ -46,7 +46,6 @@ struct Ctx {
     double last_ms = 0.0;
     int msm_c_override = 0;
     std::map<std::string, DevBuf> ws;                       // named scratch buffers (grow-only)
-    std::map<uint64_t, DevBuf> base_cache;                  // zkmi_msm base_cache_key -> resident table
     std::map<std::tuple<int, unsigned, int>, NttPlan> plans;  // (curve, log_n, inverse)
     std::map<std::string, DevBuf> ntt_prescale;             // cached row-factor tables of fused NTT pre-scales
     std::map<void*, size_t> user_allocs;

@@ -170,7 +170,7 @@ class Curve:
 _curves = {}
 
 
-def get_curve_from_name(name, device=0):
+def get_curve_from_name(name, device=None):
     """src/curves.js:36-53 getCurveFromName; the curve object is cached like globalThis.curve_bn128."""
     zkmi.init(device)
     key = "bn128" if zkmi.CURVE_ID.get(name.lower(), -1) == 0 else name.lower()
@@ -179,7 +179,7 @@ def get_curve_from_name(name, device=0):
     return _curves[key]
 
 
-def get_curve_from_r(r, device=0):
+def get_curve_from_r(r, device=None):
     """src/curves.js:9-21 getCurveFromR."""
     if r == 21888242871839275222246405745257275088548364400416034343698204186575808495617:
         return get_curve_from_name("bn128", device)

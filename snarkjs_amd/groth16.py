@@ -53,7 +53,7 @@ class ProvingKey:
         self.curve_id, self.curve_name = _curve_from_q(zk["q"])
         self.key = ProvingKey._next
         ProvingKey._next += 1
-        zkmi.init(int(os.environ.get("LOCAL_RANK", "0")) if zkmi.device_count() > 1 else 0)
+        zkmi.init()
         self._keep = {k: np.ascontiguousarray(zk[k]) for k in
                       ("coeffs", "A", "B1", "B2", "C", "H", "vk_alpha_1", "vk_beta_1", "vk_beta_2", "vk_delta_1", "vk_delta_2")}
         p = lambda k: self._keep[k].ctypes.data

@@ -192,7 +192,7 @@ class PlonkKey:
         self.commit = {}
         for nm in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):                       # src/zkey_utils.js:283-290
             self.commit[nm] = (f.unmont_q(data[off:off + n8q]), f.unmont_q(data[off + n8q:off + 2 * n8q])); off += 2 * n8q
-        zkmi.init(int(os.environ.get("LOCAL_RANK", "0")) if zkmi.device_count() > 1 else 0)
+        zkmi.init()
         self.additions = data[s[3][0]:s[3][0] + s[3][1]]
         self.dev = {t: zkmi.DeviceBuffer.from_host(np.frombuffer(data, np.uint8, s[t][1], s[t][0])) for t in (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14) if s[t][1]}
         # the SRS is static: pre-computed window tables for the nine commitments of every proof (all use a prefix of PTau)

@@ -122,8 +122,19 @@ def check(rc):
         raise ZkmiError(rc, lib().zkmi_last_error().decode(errors="replace"))
 
 
-def init(device=0):
+_device = None
+
+
+def init(device=None):
+    """Bind this process to one GPU (one process per GPU). device=None: keep the current binding, or bind to LOCAL_RANK
+    (torchrun) / device 0 on first use."""
+    global _device
+    if device is None:
+        if _device is not None:
+            return
+        device = int(os.environ.get("LOCAL_RANK", "0")) if lib().zkmi_device_count() > 1 else 0
     check(lib().zkmi_init(device))
+    _device = device
 
 
 def device_count():

@@ -41,6 +41,11 @@ for (const [tag, cid] of [["bn128", 0], ["bls12381", 1]]) {
     for (const g of [1, 2]) {
         const jac = addon.msm(cid, g, raw(tag, `g${g}_bases`), x, 1024, 32, 0);
         check(`${tag} G${g}.multiExpAffine`, jac.length === 3 * g * n8q && eq(addon.toAffine(cid, g, jac), raw(tag, `g${g}_msm_affine`)));
+        // resident bases (pre-computed window tables under a cache key): first call builds, second call reuses
+        const key = 1000 + 10 * cid + g;
+        const j1 = addon.msm(cid, g, raw(tag, `g${g}_bases`), x, 1024, 32, key), j2 = addon.msm(cid, g, raw(tag, `g${g}_bases`), x, 1024, 32, key);
+        check(`${tag} G${g}.multiExpAffine (resident tables)`, eq(addon.toAffine(cid, g, j1), raw(tag, `g${g}_msm_affine`)) && eq(addon.toAffine(cid, g, j2), raw(tag, `g${g}_msm_affine`)));
+        addon.releaseBases(key);
     }
     let threw = false;
     try { addon.msm(cid, 1, raw(tag, "g1_bases"), x.subarray(0, 1024 * 32 - 1), 1024, 32, 0); } catch (e) { threw = /Scalar size does not match/.test(e.message); }

@@ -23,7 +23,7 @@ from synth_zkey import PRIMES, _binfile
 
 def make(name, lg, seed=7, tau=0x1F3D5B79):
     from snarkjs_amd import zkmi
-    zkmi.init(0)
+    zkmi.init()
     L = zkmi.lib()
     cid = 0 if name == "bn128" else 1
     q8, q, r = PRIMES[name]

@@ -33,7 +33,7 @@ def _tables(name, n1, n2, use_device):
     q8 = PRIMES[name][0]
     if use_device:
         from snarkjs_amd import zkmi
-        zkmi.init(0)
+        zkmi.init()
         out = []
         for group, n in ((1, n1), (2, n2)):
             d = zkmi.DeviceBuffer(n * 2 * group * q8)

@@ -250,3 +250,26 @@ def test_groth16_synthetic_vs_oracle(zk, name, lg):
     for a, b in zip(got, again):
         assert np.array_equal(a, b)
     pk.release()
+
+
+@pytest.mark.parametrize("name,group,lg", [("bn128", 1, 14), ("bn128", 2, 12), ("bls12381", 1, 12)])
+def test_msm_resident_tables(zk, name, group, lg):
+    """zkmi_msm_table_*: pre-computed window tables; MSMs over a PREFIX of the resident bases (PLONK commits with PTau[0:k])."""
+    import ctypes as C
+    from snarkjs_amd import zkmi
+    c, L = O.CURVE_ID[name], zkmi.lib()
+    n = 1 << lg
+    q8 = O.n8q(c)
+    bases = O.geom_bases(c, group, n)
+    d_b = zkmi.DeviceBuffer.from_host(bases)
+    h = C.c_uint64(0)
+    zkmi.check(L.zkmi_msm_table_build(c, group, d_b.ptr, n, C.byref(h)))
+    for k, sb, seed in ((n, 32, 1), (n - 5, 32, 2), (1, 32, 3), (777, 4, 4)):
+        sc = synth.witness_like(0x7AB1E + seed, k) if sb == 32 else synth.elems(9, (k * sb + 31) // 32 + 1)[:k * sb]
+        d_s = zkmi.DeviceBuffer.from_host(sc)
+        out = np.zeros(3 * group * q8, np.uint8)
+        zkmi.check(L.zkmi_msm_table_dev(h, d_s.ptr, k, sb, zkmi.ptr(out)))
+        want = O.to_affine(c, group, O.msm(c, group, bases[:k * 2 * group * q8], sc, k, sb))
+        assert np.array_equal(O.to_affine(c, group, out), want), (k, sb)
+    assert L.zkmi_msm_table_dev(h, d_s.ptr, n + 1, 32, zkmi.ptr(out)) != 0
+    zkmi.check(L.zkmi_msm_table_release(h))
