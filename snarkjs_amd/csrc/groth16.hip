@@ -86,7 +86,7 @@ k_build_abc(const uint32_t* __restrict__ row_start, const uint32_t* __restrict__
 }
 
 // ---- resident proving key ---------------------------------------------------------------------------------------------
-enum { ST_BUILD = 0, ST_NTT, ST_JOIN, ST_SORT_W, ST_MSM_A, ST_MSM_B1, ST_MSM_B2, ST_MSM_C, ST_SORT_H, ST_MSM_H, ST_REDUCE, ST_COUNT };
+enum { ST_BUILD = 0, ST_NTT, ST_JOIN, ST_SORT_W, ST_MSM_B2, ST_MSM_A, ST_MSM_B1, ST_MSM_C, ST_SORT_H, ST_MSM_H, ST_REDUCE, ST_COUNT };
 
 struct G16Key {
     int curve = 0;
@@ -247,12 +247,23 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     MsmJob job[5];
     for (int i = 0; i < 5; i++) ZK_TRY(msm_job_slot(i, job[i]));
     ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl, 0, K.cw));
+    // The G2 MSM goes first: its bucket reduction is pure latency (~50 us per Fq2 point addition, little parallel work), so it
+    // runs on the auxiliary stream underneath the G1 accumulations (ZKMI_OVERLAP=0 keeps everything on one stream).
+    static const bool ov = !(getenv("ZKMI_OVERLAP") && atoi(getenv("ZKMI_OVERLAP")) == 0);
+    MsmJob* g2[1] = {&job[2]};
+    ZK_HIP(hipEventRecord(K.ev[ST_MSM_B2], st));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 2, K.bB2, pl, 0, job[2]));
+    if (ov) {
+        ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 0, true));        // njobs = 0: only creates the auxiliary stream
+        ZK_HIP(hipEventRecord(cx.aux_ev[0], st));
+        ZK_HIP(hipStreamWaitEvent(cx.aux_stream, cx.aux_ev[0], 0));
+        ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1, true));
+        ZK_HIP(hipEventRecord(cx.aux_ev[1], cx.aux_stream));
+    }
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_A], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bA, pl, 0, job[0]));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_B1], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bB1, pl, 0, job[1]));
-    ZK_HIP(hipEventRecord(K.ev[ST_MSM_B2], st));
-    ZK_TRY(msm_accumulate_dispatch(K.curve, 2, K.bB2, pl, 0, job[2]));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_C], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.c_skip, job[3]));
     ZK_HIP(hipEventRecord(K.ev[ST_SORT_H], st));
@@ -264,10 +275,10 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     MsmJob* g1[4] = {&job[0], &job[1], &job[3], &job[4]};
     if (job[4].W == job[0].W && job[4].c == job[0].c) ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 4));
     else { ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 3)); ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1 + 3, 1)); }
-    MsmJob* g2[1] = {&job[2]};
-    ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1));
+    if (!ov) ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1));
     ZK_HIP(hipEventRecord(K.ev[ST_COUNT], st));
     ZK_HIP(hipStreamSynchronize(st));
+    if (ov) ZK_HIP(hipStreamSynchronize(cx.aux_stream));
     ZK_HIP(hipGetLastError());
     for (int i = 0; i < ST_COUNT; i++) { float ms = 0; if (hipEventElapsedTime(&ms, K.ev[i], K.ev[i + 1]) == hipSuccess) K.stage_ms[i] = ms; }
     uint8_t jA[144], jB1[144], jB2[288], jC[144], jH[144];

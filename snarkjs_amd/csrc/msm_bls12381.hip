@@ -39,9 +39,9 @@ int msm_table_bls12381(int group, const void* d_table, size_t stride, int c, con
     if (group == 1) return msm_run_table<Fp<Bls12381Fq>>(d_table, stride, c, d_scalars, k, sb, out);
     return msm_run_table<Fp2<Bls12381Fq>>(d_table, stride, c, d_scalars, k, sb, out);
 }
-int msm_reduce_bls12381(int group, MsmJob* const* jobs, int njobs) {
-    if (group == 1) return msm_reduce<Fp<Bls12381Fq>>(jobs, njobs);
-    return msm_reduce<Fp2<Bls12381Fq>>(jobs, njobs);
+int msm_reduce_bls12381(int group, MsmJob* const* jobs, int njobs, bool aux) {
+    if (group == 1) return msm_reduce<Fp<Bls12381Fq>>(jobs, njobs, aux);
+    return msm_reduce<Fp2<Bls12381Fq>>(jobs, njobs, aux);
 }
 int msm_fold_bls12381(int group, const MsmJob& job, uint8_t* out_jac) {
     if (group == 1) msm_fold<Fp<Bls12381Fq>>(job, out_jac); else msm_fold<Fp2<Bls12381Fq>>(job, out_jac);

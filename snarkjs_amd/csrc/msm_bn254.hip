@@ -38,9 +38,9 @@ int msm_table_bn254(int group, const void* d_table, size_t stride, int c, const 
     if (group == 1) return msm_run_table<Fp<Bn254Fq>>(d_table, stride, c, d_scalars, k, sb, out);
     return msm_run_table<Fp2<Bn254Fq>>(d_table, stride, c, d_scalars, k, sb, out);
 }
-int msm_reduce_bn254(int group, MsmJob* const* jobs, int njobs) {
-    if (group == 1) return msm_reduce<Fp<Bn254Fq>>(jobs, njobs);
-    return msm_reduce<Fp2<Bn254Fq>>(jobs, njobs);
+int msm_reduce_bn254(int group, MsmJob* const* jobs, int njobs, bool aux) {
+    if (group == 1) return msm_reduce<Fp<Bn254Fq>>(jobs, njobs, aux);
+    return msm_reduce<Fp2<Bn254Fq>>(jobs, njobs, aux);
 }
 int msm_fold_bn254(int group, const MsmJob& job, uint8_t* out_jac) {
     if (group == 1) msm_fold<Fp<Bn254Fq>>(job, out_jac); else msm_fold<Fp2<Bn254Fq>>(job, out_jac);

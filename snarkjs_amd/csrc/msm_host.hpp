@@ -158,10 +158,13 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
 }
 
 // ---- stage 5: bucket reduction of up to MSM_MAX_BATCH accumulated jobs of the same shape, in one set of launches ------
-template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
+// aux: run on the library's auxiliary stream with its own scratch buffers (a latency-bound reduction can then overlap the
+// throughput-bound accumulations of other MSMs); the caller orders the streams with events.
+template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = false) {
     constexpr int FW = FieldWords<F>::value, PW = 4 * FW;
     Ctx& cx = ctx();
-    hipStream_t st = cx.stream;
+    hipStream_t st = aux ? cx.aux_stream : cx.stream;
+    const std::string ax = aux ? ".aux" : "";
     if (njobs < 1 || njobs > MSM_MAX_BATCH) return fail(ZKMI_ERR_INVALID, "msm_reduce: bad batch size");
     const int W = jobs[0]->W, c = jobs[0]->c;
     const uint32_t nb = jobs[0]->nb;
@@ -176,11 +179,11 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
     constexpr int M = (PW * 4 * 2 * 256 <= 128 * 1024) ? 256 : 128;    // k_msm_wsum: 2 LDS arrays of M points
     const uint32_t m2 = (C + M - 1) / M;
     uint32_t *rc, *a0, *r0, *a1, *r1;
-    ZK_TRY(ws_get("msm.rowcol", VW * C * PW * 4, (void**)&rc));
-    ZK_TRY(ws_get("msm.redA0", std::max<size_t>(VW * m2, VW * (cbits + 1)) * PW * 4, (void**)&a0));
-    ZK_TRY(ws_get("msm.redR0", VW * m2 * PW * 4, (void**)&r0));
-    ZK_TRY(ws_get("msm.redA1", VW * PW * 4, (void**)&a1));
-    ZK_TRY(ws_get("msm.redR1", VW * PW * 4, (void**)&r1));
+    ZK_TRY(ws_get("msm.rowcol" + ax, VW * C * PW * 4, (void**)&rc));
+    ZK_TRY(ws_get("msm.redA0" + ax, std::max<size_t>(VW * m2, VW * (cbits + 1)) * PW * 4, (void**)&a0));
+    ZK_TRY(ws_get("msm.redR0" + ax, VW * m2 * PW * 4, (void**)&r0));
+    ZK_TRY(ws_get("msm.redA1" + ax, VW * PW * 4, (void**)&a1));
+    ZK_TRY(ws_get("msm.redR1" + ax, VW * PW * 4, (void**)&r1));
     static bool attr_set = false;
     const size_t lds_ws = (size_t)2 * M * PW * 4;
     if (!attr_set) {
@@ -195,8 +198,8 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs) {
     uint32_t L = 1;
     while (L < maxL && (C / L) > seq) L <<= 1;
     uint32_t *p0, *p1;
-    ZK_TRY(ws_get("msm.rcpart0", n_out * L * PW * 4, (void**)&p0));
-    ZK_TRY(ws_get("msm.rcpart1", std::max<size_t>(n_out * L / 4, 1) * PW * 4, (void**)&p1));
+    ZK_TRY(ws_get("msm.rcpart0" + ax, n_out * L * PW * 4, (void**)&p0));
+    ZK_TRY(ws_get("msm.rcpart1" + ax, std::max<size_t>(n_out * L / 4, 1) * PW * 4, (void**)&p1));
     {
         uint32_t* dst = L == 1 ? rc : p0;
         hipLaunchKernelGGL((k_msm_rowcol<F>), dim3((unsigned)((n_out * L + 255) / 256)), dim3(256), 0, st, rb, (uint32_t)W, nb, rbits, cbits, L, dst);
@@ -321,7 +324,7 @@ int msm_table_dispatch(int curve, int group, const void* d_table, size_t stride,
 
 // non-template entry points (msm_bn254.hip / msm_bls12381.hip) for callers that must not instantiate the kernels again
 int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job);
-int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs);
+int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs, bool aux = false);
 
 int msm_fold_dispatch(int curve, int group, const MsmJob& job, uint8_t* out_jac);
 

@@ -61,12 +61,12 @@ int msm_bn254(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_bls12381(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_accumulate_bn254(int group, const void*, const MsmPlan&, uint32_t, MsmJob&);
 int msm_accumulate_bls12381(int group, const void*, const MsmPlan&, uint32_t, MsmJob&);
-int msm_reduce_bn254(int group, MsmJob* const*, int);
+int msm_reduce_bn254(int group, MsmJob* const*, int, bool);
 int msm_precompute_bn254(int group, const void*, size_t, int, int, void*);
 int msm_precompute_bls12381(int group, const void*, size_t, int, int, void*);
 int msm_table_bn254(int group, const void*, size_t, int, const void*, size_t, size_t, uint8_t*);
 int msm_table_bls12381(int group, const void*, size_t, int, const void*, size_t, size_t, uint8_t*);
-int msm_reduce_bls12381(int group, MsmJob* const*, int);
+int msm_reduce_bls12381(int group, MsmJob* const*, int, bool);
 int msm_fold_bn254(int group, const MsmJob&, uint8_t*);
 int msm_fold_bls12381(int group, const MsmJob&, uint8_t*);
 int gen_bases_bn254(int group, size_t, uint64_t, uint64_t, void*);
@@ -97,9 +97,15 @@ int msm_table_dispatch(int curve, int group, const void* d_table, size_t stride,
     ZK_TRY(check_cg(curve, group));
     return curve == ZKMI_CURVE_BN128 ? msm_table_bn254(group, d_table, stride, c, d_scalars, k, sb, out) : msm_table_bls12381(group, d_table, stride, c, d_scalars, k, sb, out);
 }
-int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs) {
+int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs, bool aux) {
     ZK_TRY(check_cg(curve, group));
-    return curve == ZKMI_CURVE_BN128 ? msm_reduce_bn254(group, jobs, njobs) : msm_reduce_bls12381(group, jobs, njobs);
+    if (aux && !g_ctx.aux_stream) {
+        ZK_HIP(hipStreamCreateWithFlags(&g_ctx.aux_stream, hipStreamNonBlocking));
+        ZK_HIP(hipEventCreateWithFlags(&g_ctx.aux_ev[0], hipEventDisableTiming));
+        ZK_HIP(hipEventCreateWithFlags(&g_ctx.aux_ev[1], hipEventDisableTiming));
+    }
+    if (njobs == 0) return ZKMI_OK;                               // only makes sure the auxiliary stream exists
+    return curve == ZKMI_CURVE_BN128 ? msm_reduce_bn254(group, jobs, njobs, aux) : msm_reduce_bls12381(group, jobs, njobs, aux);
 }
 int msm_fold_dispatch(int curve, int group, const MsmJob& job, uint8_t* out_jac) {
     ZK_TRY(check_cg(curve, group));

@@ -52,6 +52,8 @@ struct Ctx {
     std::map<size_t, std::vector<void*>> pool;              // freed zkmi_dev_alloc blocks by size
     size_t pool_bytes = 0, pool_limit = (size_t)96 << 30;
     std::map<uint64_t, void*> groth16;                      // zkmi_groth16 resident keys (groth16.hip)
+    hipStream_t aux_stream = nullptr;                       // second stream for latency-bound reductions (groth16.hip)
+    hipEvent_t aux_ev[2] = {};
     hipEvent_t job_ev[16] = {};                             // per MSM job slot: events around k_msm_accum
     uint8_t* pinned = nullptr;                              // pinned host slots for MSM window sums
 };
