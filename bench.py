@@ -195,6 +195,19 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "kernel_ms": round(acc[dom], 4),
                 "algorithmic_bytes": alg_bytes,
                 "note": "integer-ALU-bound (256-bit Montgomery carry chains, no MFMA): see int_alu"}
+        # the resource that actually binds: field multiplications. Digits per scalar with the resident pre-computed tables
+        # (msm_host.hpp: msm_precomp_c); every digit is one mixed addition = 8M+2S, x3 base-field products per Fq2 product (G2).
+        lgv = max(1, units).bit_length() - 1
+        if units > (3 << lgv) // 2:
+            lgv += 1
+        cpre = max(8, min(21, lgv))
+        if lgv >= 14:
+            cpre = [15, 15, 16, 17, 17, 20, 20, 20][min(max(cpre, 14), 21) - 14]
+        digits = -(-257 // cpre)
+        fmuls = digits * units * 10 * (3 if dom == 2 else 1)
+        int_alu = {"unit": "Gmul/s", "field_muls_upper_bound": fmuls, "achieved": round(fmuls / (acc[dom] * 1e-3) / 1e9, 1), "peak": FIELD_MUL_PEAK_G,
+                   "frac": round(fmuls / (acc[dom] * 1e-3) / 1e9 / FIELD_MUL_PEAK_G, 4),
+                   "note": "peak = measured Montgomery-multiply ceiling of the chip (tools/fieldbench, profiles/r01_fieldbench.txt); zero digits and infinity bases are counted, so achieved is an upper bound"}
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -209,6 +222,7 @@ def main():
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "accum_kernel_ms": {names[k][0]: round(v, 4) for k, v in acc.items()},
             "roofline": roof,
+            "int_alu": int_alu,
         }
         if world == 1 and not args.no_cpu_baseline:
             base, (zk_s, wt_s, ref, rs, ss) = cpu_baseline(args.cpu_log_n, lg)
