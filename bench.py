@@ -103,7 +103,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ZKMI_FORCE_DIST"):      # ZKMI_FORCE_DIST: exercise the RCCL path with a single rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -153,6 +153,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stages = {k: v / args.steps for k, v in stage_acc.items()}
+
+    # ---- one large G1 MSM sharded by base-index range over the ranks (north star: "G1 MSM shards across the GPUs ... final
+    # RCCL reduce"): every rank runs the device Pippenger on its slice, one all_gather of the partial points, local fold.
+    sharded = None
+    if dist is not None:
+        from snarkjs_amd import distributed as D
+        n_tot = 1 << (lg + 2)
+        lo, hi = D.shard_range(n_tot, rank, world)
+        k = hi - lo
+        d_bs = zkmi.DeviceBuffer(max(k, 1) * 2 * q8)
+        zkmi.check(L.zkmi_gen_geometric_bases_dev(cid, 1, max(k, 1), 7 + rank, 11, d_bs.ptr))
+        d_ss = zkmi.DeviceBuffer.from_host(synth.elems(0xD157 + rank, max(k, 1)))
+
+        class _Cv:
+            id = cid
+            G1 = G2 = None
+
+        def shard_msm(_b, _s):
+            o = np.zeros(3 * q8, np.uint8)
+            if k:
+                zkmi.check(L.zkmi_msm_dev(cid, 1, d_bs.ptr, d_ss.ptr, k, 32, zkmi.ptr(o)))
+            return o
+        D.msm_sharded(_Cv, 1, None, None, compute=shard_msm)
+        barrier()
+        ts = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            D.msm_sharded(_Cv, 1, None, None, compute=shard_msm)
+        barrier()
+        tsh = torch.tensor([time.perf_counter() - ts], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
+        sharded = {"terms": n_tot, "ms": round(float(tsh.item()) / reps * 1e3, 3), "mscalar_per_s": round(n_tot * reps / float(tsh.item()) / 1e6, 2),
+                   "exchange": "all_gather of %d x %d-byte partial points + host fold" % (world, 3 * q8)}
+        d_bs.free(); d_ss.free()
 
     out = None
     if rank == 0:
@@ -220,6 +254,7 @@ def main():
                            "ntt_melem_per_s": round(n / ntt_ms / 1e3, 2), "ntt_ms": round(ntt_ms, 4),
                            "ntt_hbm_frac": round(64 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            "g1_msm_sharded": sharded,
             "accum_kernel_ms": {names[k][0]: round(v, 4) for k, v in acc.items()},
             "roofline": roof,
             "int_alu": int_alu,
