@@ -146,7 +146,7 @@ int zkmi_groth16_prove_dev(uint64_t zkey_cache_key, const void* d_witness, const
                            uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 int zkmi_groth16_release(uint64_t zkey_cache_key);
 /* Device time (ms, HIP events) of the stages of the last proof, in order: buildABC, 6 NTTs, joinABC, sort(witness),
- * bucket accumulation of MSM B2, A, B1, C, sort(H scalars), accumulation of MSM H, batched G1 bucket reductions (the B2
+ * bucket accumulation of MSM B2, B1 (+ the second witness sort), A, C, sort(H scalars), accumulation of MSM H, batched G1 bucket reductions (the B2
  * reduction runs on a second stream underneath the G1 accumulations).
  * Writes min(n, ZKMI_GROTH16_STAGES) values. */
 #define ZKMI_GROTH16_STAGES 11

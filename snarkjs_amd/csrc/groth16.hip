@@ -86,12 +86,15 @@ k_build_abc(const uint32_t* __restrict__ row_start, const uint32_t* __restrict__
 }
 
 // ---- resident proving key ---------------------------------------------------------------------------------------------
-enum { ST_BUILD = 0, ST_NTT, ST_JOIN, ST_SORT_W, ST_MSM_B2, ST_MSM_A, ST_MSM_B1, ST_MSM_C, ST_SORT_H, ST_MSM_H, ST_REDUCE, ST_COUNT };
+enum { ST_BUILD = 0, ST_NTT, ST_JOIN, ST_SORT_W, ST_MSM_B2, ST_MSM_B1, ST_MSM_A, ST_MSM_C, ST_SORT_H, ST_MSM_H, ST_REDUCE, ST_COUNT };
 
 struct G16Key {
     int curve = 0;
     uint32_t n_vars = 0, n_public = 0, domain = 0, power = 0, n_coef = 0;
     void *bA = nullptr, *bB1 = nullptr, *bB2 = nullptr, *bC = nullptr, *bH = nullptr;   // base tables; with pre-computed windows: T[k][i] = 2^(c*k) P_i
+    uint32_t* drop_b = nullptr;       // scalars whose B1 AND B2 bases are both at infinity: left out of the sort that feeds B1/B2
+    double b_density = 1.0;           // fraction of witness entries that survive drop_b
+    uint32_t* mask[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // infinity bitmaps of bA, bB1, bB2, bC, bH (one bit per table entry)
     int cw = 0, ch = 0;               // window width of the witness-side / H-side tables (0 = plain bases, no pre-computation)
     uint32_t c_skip = 0;              // index offset of the C bases (0 when the C table is padded to nVars entries)
     uint32_t *row_cnt = nullptr, *row_start = nullptr, *sig = nullptr, *val = nullptr;
@@ -100,7 +103,7 @@ struct G16Key {
     hipEvent_t ev[ST_COUNT + 1] = {};
     double stage_ms[ST_COUNT] = {};
     void release() {
-        void* ptrs[] = {bA, bB1, bB2, bC, bH, row_cnt, row_start, sig, val, w, A, B, C, T};
+        void* ptrs[] = {bA, bB1, bB2, bC, bH, row_cnt, row_start, sig, val, w, A, B, C, T, mask[0], mask[1], mask[2], mask[3], mask[4], drop_b};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     }
@@ -132,27 +135,45 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key) {
     const int pc = pe ? atoi(pe) : -1;
     K->cw = pc == 0 ? 0 : (pc > 0 ? pc : msm_precomp_c(m));
     K->ch = pc == 0 ? 0 : (pc > 0 ? pc : msm_precomp_c(n));
-    auto put_table = [&](void** dst, const uint8_t* src, size_t cnt, size_t pad_front, int group, int c) -> int {
+    auto put_table = [&](void** dst, uint32_t** mask, const uint8_t* src, size_t cnt, size_t pad_front, int group, int c) -> int {
         const size_t pb = group == 1 ? g1 : g2, tot = cnt + pad_front;
         void* raw = nullptr;
         ZK_HIP(hipMalloc(&raw, tot * pb ? tot * pb : 16));
         if (pad_front) ZK_HIP(hipMemsetAsync(raw, 0, pad_front * pb, st));             // all-zero bytes = point at infinity
         if (cnt) ZK_HIP(hipMemcpyAsync((uint8_t*)raw + pad_front * pb, src, cnt * pb, hipMemcpyHostToDevice, st));
-        if (!c) { *dst = raw; return ZKMI_OK; }
-        const int Wd = msm_digits(32, c);
-        ZK_HIP(hipMalloc(dst, (size_t)Wd * tot * pb));
-        ZK_TRY(msm_precompute_dispatch(zk->curve, group, raw, tot, c, Wd, *dst));
+        const int Wd = c ? msm_digits(32, c) : 1;
+        if (!c) *dst = raw;
+        else {
+            ZK_HIP(hipMalloc(dst, (size_t)Wd * tot * pb));
+            ZK_TRY(msm_precompute_dispatch(zk->curve, group, raw, tot, c, Wd, *dst));
+        }
+        ZK_HIP(hipMalloc((void**)mask, (((size_t)Wd * tot + 31) / 32) * 4 + 16));
+        ZK_TRY(msm_infmask_dispatch(zk->curve, group, *dst, (size_t)Wd * tot, *mask));
         ZK_HIP(hipStreamSynchronize(st));
-        (void)hipFree(raw);
+        if (c) (void)hipFree(raw);
         return ZKMI_OK;
     };
-    ZK_TRY(put_table(&K->bA, zk->bases_a, m, 0, 1, K->cw));
-    ZK_TRY(put_table(&K->bB1, zk->bases_b1, m, 0, 1, K->cw));
-    ZK_TRY(put_table(&K->bB2, zk->bases_b2, m, 0, 2, K->cw));
+    ZK_TRY(put_table(&K->bA, &K->mask[0], zk->bases_a, m, 0, 1, K->cw));
+    ZK_TRY(put_table(&K->bB1, &K->mask[1], zk->bases_b1, m, 0, 1, K->cw));
+    ZK_TRY(put_table(&K->bB2, &K->mask[2], zk->bases_b2, m, 0, 2, K->cw));
     // C pairs with witness[nPublic+1:] (:97): with tables it is padded in front so that it shares the witness indices
-    ZK_TRY(put_table(&K->bC, zk->bases_c, mc, K->cw ? m - mc : 0, 1, K->cw));
+    ZK_TRY(put_table(&K->bC, &K->mask[3], zk->bases_c, mc, K->cw ? m - mc : 0, 1, K->cw));
     K->c_skip = K->cw ? 0 : (uint32_t)(m - mc);
-    ZK_TRY(put_table(&K->bH, zk->bases_h, (size_t)n, 0, 1, K->ch));
+    ZK_TRY(put_table(&K->bH, &K->mask[4], zk->bases_h, (size_t)n, 0, 1, K->ch));
+    {   // B is sparse in real circuits (a signal absent from the B matrix has the point at infinity in BOTH B1 and B2, section
+        // layout src/zkey_utils.js:183-193): those witness entries are dropped from the digit sort that feeds the B MSMs
+        const size_t words = (m + 31) / 32;
+        std::vector<uint32_t> h1(words), h2(words);
+        ZK_HIP(hipMemcpyAsync(h1.data(), K->mask[1], words * 4, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipMemcpyAsync(h2.data(), K->mask[2], words * 4, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+        size_t dropped = 0;
+        for (size_t i = 0; i < words; i++) { h1[i] &= h2[i]; dropped += (size_t)__builtin_popcount(h1[i]); }
+        K->b_density = 1.0 - (double)dropped / (double)m;
+        ZK_HIP(hipMalloc((void**)&K->drop_b, words * 4 + 16));
+        ZK_HIP(hipMemcpyAsync(K->drop_b, h1.data(), words * 4, hipMemcpyHostToDevice, st));
+        ZK_HIP(hipStreamSynchronize(st));
+    }
     K->vk_alpha_1.assign(zk->vk_alpha_1, zk->vk_alpha_1 + g1); K->vk_beta_1.assign(zk->vk_beta_1, zk->vk_beta_1 + g1);
     K->vk_beta_2.assign(zk->vk_beta_2, zk->vk_beta_2 + g2); K->vk_delta_1.assign(zk->vk_delta_1, zk->vk_delta_1 + g1);
     K->vk_delta_2.assign(zk->vk_delta_2, zk->vk_delta_2 + g2);
@@ -246,13 +267,18 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     MsmPlan pl, plh;
     MsmJob job[5];
     for (int i = 0; i < 5; i++) ZK_TRY(msm_job_slot(i, job[i]));
-    ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl, 0, K.cw));
+    // Two digit sorts of the witness: one without the entries whose B bases are at infinity (feeds B2 and B1), one complete
+    // (feeds A and C). The second sort pays for itself once ~10 % of the B bases are at infinity.
+    const bool split_b = K.b_density < 0.9;
+    MsmPlan plb;
+    ZK_TRY(msm_sort(d_witness, K.n_vars, 32, split_b ? plb : pl, split_b ? 2 : 0, K.cw, 0, split_b ? K.drop_b : nullptr));
+    const MsmPlan& pB = split_b ? plb : pl;
     // The G2 MSM goes first: its bucket reduction is pure latency (~50 us per Fq2 point addition, little parallel work), so it
     // runs on the auxiliary stream underneath the G1 accumulations (ZKMI_OVERLAP=0 keeps everything on one stream).
     static const bool ov = !(getenv("ZKMI_OVERLAP") && atoi(getenv("ZKMI_OVERLAP")) == 0);
     MsmJob* g2[1] = {&job[2]};
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_B2], st));
-    ZK_TRY(msm_accumulate_dispatch(K.curve, 2, K.bB2, pl, 0, job[2]));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 2, K.bB2, pB, 0, job[2], K.mask[2]));
     if (ov) {
         ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 0, true));        // njobs = 0: only creates the auxiliary stream
         ZK_HIP(hipEventRecord(cx.aux_ev[0], st));
@@ -260,16 +286,17 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
         ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1, true));
         ZK_HIP(hipEventRecord(cx.aux_ev[1], cx.aux_stream));
     }
-    ZK_HIP(hipEventRecord(K.ev[ST_MSM_A], st));
-    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bA, pl, 0, job[0]));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_B1], st));
-    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bB1, pl, 0, job[1]));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bB1, pB, 0, job[1], K.mask[1]));
+    if (split_b) ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl, 0, K.cw));
+    ZK_HIP(hipEventRecord(K.ev[ST_MSM_A], st));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bA, pl, 0, job[0], K.mask[0]));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_C], st));
-    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.c_skip, job[3]));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.c_skip, job[3], K.mask[3]));
     ZK_HIP(hipEventRecord(K.ev[ST_SORT_H], st));
     ZK_TRY(msm_sort(K.T, n, 32, plh, 1, K.ch));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_H], st));
-    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, plh, 0, job[4]));
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, plh, 0, job[4], K.mask[4]));
     ZK_HIP(hipEventRecord(K.ev[ST_REDUCE], st));
     // bucket reductions are latency-bound: all G1 jobs of one shape go through ONE set of launches
     MsmJob* g1[4] = {&job[0], &job[1], &job[3], &job[4]};

@@ -96,9 +96,11 @@ ZK_DEV uint32_t msm_atomic_inc(uint32_t* __restrict__ ctr, size_t idx) {
     return result;
 }
 
-template <int NW> __global__ void k_msm_count(const uint8_t* __restrict__ scalars, MsmShape sh, uint32_t* __restrict__ counts) {
+// dropmask (optional): bit i set = scalar i is dropped (its base is the point at infinity in every MSM run over this plan)
+template <int NW> __global__ void k_msm_count(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ dropmask, uint32_t* __restrict__ counts) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sh.n) return;
+    if (dropmask && ((dropmask[i >> 5] >> (i & 31)) & 1u)) return;
     uint32_t s[NW];
     load_scalar<NW>(s, scalars, i, sh.sb);
     for_each_digit<NW>(s, sh.c, sh.Wd, [&](int w, uint32_t mag, bool) { msm_atomic_inc(counts, (sh.precomp ? (size_t)0 : (size_t)w * sh.nb) + (mag - 1)); });
@@ -156,10 +158,11 @@ static __global__ void __launch_bounds__(256) k_msm_scan_final(const uint32_t* _
     for (int k = 0; k < 8; k++) { if (base + k < total) starts[base + k] = run; run += c[k]; }
 }
 
-template <int NW> __global__ void k_msm_scatter(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ starts,
+template <int NW> __global__ void k_msm_scatter(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ dropmask, const uint32_t* __restrict__ starts,
                                                uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sh.n) return;
+    if (dropmask && ((dropmask[i >> 5] >> (i & 31)) & 1u)) return;
     uint32_t s[NW];
     load_scalar<NW>(s, scalars, i, sh.sb);
     for_each_digit<NW>(s, sh.c, sh.Wd, [&](int w, uint32_t mag, bool neg) {
@@ -229,7 +232,7 @@ k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, 
 // WIDE (Fq2 points): at most 256 VGPRs (2 waves per SIMD), accumulator parked in LDS (curve.cuh: LdsAcc), no software
 // pipelining of the gather — 2.6x the throughput of the fully inlined 400+-register version (tools/maddbench.hip).
 template <class F, bool WIDE> __global__ void __launch_bounds__(256, WIDE ? 2 : 1)
-k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
+k_msm_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ infmask, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
             const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub, const uint32_t* __restrict__ meta,
             uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials) {
     constexpr int FW = FieldWords<F>::value;
@@ -248,33 +251,49 @@ k_msm_accum(const uint32_t* __restrict__ bases, MsmShape sh, uint32_t skip, uint
     const uint32_t* list = sorted + starts[g];
     XYZZ<F> acc;
     pt_set_inf(acc);
+    // Next usable entry of this lane's list: skips indices below `skip` and bases at infinity (zkey sections B1/B2 are mostly
+    // infinity for real circuits) in a cheap private loop, so that every lane arrives at the mixed addition with a real point —
+    // a lane that merely `continue`d would idle for the whole addition of its 63 neighbours. infmask: one bit per table entry
+    // (resident tables), else the point itself is inspected.
+    uint32_t k = lo;
+    auto fetch = [&](uint32_t& e_out, Affine<F>& q_out) -> bool {
+        while (k < hi) {
+            const uint32_t e = list[k++];
+            uint32_t idx = e & 0x7fffffffu;
+            if (idx < skip) continue;
+            idx -= skip;
+            if (infmask) {
+                if ((infmask[idx >> 5] >> (idx & 31)) & 1u) continue;
+                pt_load(q_out, bases + (size_t)idx * (2 * FW));
+            } else {
+                pt_load(q_out, bases + (size_t)idx * (2 * FW));
+                if (pt_is_inf(q_out)) continue;
+            }
+            e_out = e;
+            return true;
+        }
+        return false;
+    };
     if (WIDE) {
         extern __shared__ __attribute__((aligned(16))) uint32_t lds_acc[];
         LdsAcc<F, 256> A{lds_acc + threadIdx.x};
         bool inf = true;
-        for (uint32_t k = lo; k < hi; k++) {
-            const uint32_t e = list[k], idx = e & 0x7fffffffu;
-            if (idx < skip) continue;
-            Affine<F> q;
-            pt_load(q, bases + (size_t)(idx - skip) * (2 * FW));
-            if (pt_is_inf(q)) continue;
+        uint32_t e;
+        Affine<F> q;
+        while (fetch(e, q)) {
             if (e >> 31) q.y = f_neg(q.y);
             pt_madd_lds(A, inf, q);
         }
         if (!inf) { A.get(0, acc.X); A.get(1, acc.Y); A.get(2, acc.ZZ); A.get(3, acc.ZZZ); }
     } else {
-        // software pipeline: the gather of point k+1 (a random 64..96-byte read) is in flight during the addition of point k
-        uint32_t e_next = lo < hi ? list[lo] : 0u;
+        // software pipeline: the gather of the next point (a random 64..96-byte read) is in flight during the current addition
+        uint32_t e_next = 0;
         Affine<F> q_next;
-        if (lo < hi && (e_next & 0x7fffffffu) >= skip) pt_load(q_next, bases + (size_t)((e_next & 0x7fffffffu) - skip) * (2 * FW));
-        for (uint32_t k = lo; k < hi; k++) {
+        bool have = fetch(e_next, q_next);
+        while (have) {
             const uint32_t e = e_next;
             Affine<F> q = q_next;
-            if (k + 1 < hi) {
-                e_next = list[k + 1];
-                if ((e_next & 0x7fffffffu) >= skip) pt_load(q_next, bases + (size_t)((e_next & 0x7fffffffu) - skip) * (2 * FW));
-            }
-            if ((e & 0x7fffffffu) < skip) continue;
+            have = fetch(e_next, q_next);
             if (e >> 31) q.y = f_neg(q.y);
             pt_madd(acc, q);
         }
@@ -460,6 +479,16 @@ k_msm_bitsums(const uint32_t* __restrict__ arr, uint32_t C, uint32_t cbits, uint
         __syncthreads();
     }
     if (t == 0) pt_store(out + (size_t)blockIdx.x * PW, acc);
+}
+
+// one bit per point of a resident base array / table: 1 = point at infinity (mask must be zeroed first)
+template <class F> __global__ void k_msm_infmask(const uint32_t* __restrict__ pts, size_t n, uint32_t* __restrict__ mask) {
+    constexpr int FW = FieldWords<F>::value;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p;
+    pt_load(p, pts + i * 2 * FW);
+    if (pt_is_inf(p)) atomicOr(&mask[i >> 5], 1u << (i & 31));
 }
 
 // ---- pre-computed window tables for resident bases ------------------------------------------------------------------------

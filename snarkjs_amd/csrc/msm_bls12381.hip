@@ -27,9 +27,13 @@ int msm_bls12381(int group, const void* d_bases, const void* d_scalars, size_t n
     if (group == 1) return msm_run<Fp<Bls12381Fq>>(d_bases, d_scalars, n, sb, out_jac);
     return msm_run<Fp2<Bls12381Fq>>(d_bases, d_scalars, n, sb, out_jac);
 }
-int msm_accumulate_bls12381(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job) {
-    if (group == 1) return msm_accumulate<Fp<Bls12381Fq>>(d_bases, pl, skip, job);
-    return msm_accumulate<Fp2<Bls12381Fq>>(d_bases, pl, skip, job);
+int msm_accumulate_bls12381(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask) {
+    if (group == 1) return msm_accumulate<Fp<Bls12381Fq>>(d_bases, pl, skip, job, d_infmask);
+    return msm_accumulate<Fp2<Bls12381Fq>>(d_bases, pl, skip, job, d_infmask);
+}
+int msm_infmask_bls12381(int group, const void* d_points, size_t n, uint32_t* d_mask) {
+    if (group == 1) return msm_infmask<Fp<Bls12381Fq>>(d_points, n, d_mask);
+    return msm_infmask<Fp2<Bls12381Fq>>(d_points, n, d_mask);
 }
 int msm_precompute_bls12381(int group, const void* d_bases, size_t n, int c, int Wd, void* d_table) {
     if (group == 1) return msm_precompute<Fp<Bls12381Fq>>(d_bases, n, c, Wd, d_table);

@@ -26,9 +26,13 @@ int msm_bn254(int group, const void* d_bases, const void* d_scalars, size_t n, s
     if (group == 1) return msm_run<Fp<Bn254Fq>>(d_bases, d_scalars, n, sb, out_jac);
     return msm_run<Fp2<Bn254Fq>>(d_bases, d_scalars, n, sb, out_jac);
 }
-int msm_accumulate_bn254(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job) {
-    if (group == 1) return msm_accumulate<Fp<Bn254Fq>>(d_bases, pl, skip, job);
-    return msm_accumulate<Fp2<Bn254Fq>>(d_bases, pl, skip, job);
+int msm_accumulate_bn254(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask) {
+    if (group == 1) return msm_accumulate<Fp<Bn254Fq>>(d_bases, pl, skip, job, d_infmask);
+    return msm_accumulate<Fp2<Bn254Fq>>(d_bases, pl, skip, job, d_infmask);
+}
+int msm_infmask_bn254(int group, const void* d_points, size_t n, uint32_t* d_mask) {
+    if (group == 1) return msm_infmask<Fp<Bn254Fq>>(d_points, n, d_mask);
+    return msm_infmask<Fp2<Bn254Fq>>(d_points, n, d_mask);
 }
 int msm_precompute_bn254(int group, const void* d_bases, size_t n, int c, int Wd, void* d_table) {
     if (group == 1) return msm_precompute<Fp<Bn254Fq>>(d_bases, n, c, Wd, d_table);

@@ -100,7 +100,8 @@ struct MsmPlan {
 };
 constexpr int MSM_TB = 128, MSM_LOG_TB = 7;      // tree block: 128 lanes x 384 B (BLS12-381 G2 XYZZ) = 48 KiB of LDS
 // precomp_c != 0: the bases of every MSM run over this plan are pre-computed window tables built with that c
-int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan, int plan_slot = 0, int precomp_c = 0, size_t table_stride = 0);
+// d_dropmask: optional bitmap over the scalars; set bits are left out of the lists (bases at infinity)
+int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan, int plan_slot = 0, int precomp_c = 0, size_t table_stride = 0, const uint32_t* d_dropmask = nullptr);
 
 // One MSM in flight: per-window sums land in a pinned host slot; msm_fold turns them into the Jacobian result.
 struct MsmJob {
@@ -119,7 +120,7 @@ int msm_job_slot(int slot, MsmJob& job);
 // skip: the scalar with index i pairs with base (i - skip); indices < skip are ignored. This lets several MSMs share
 // one digit sort (Groth16: A, B1, B2 over the witness and C over witness[nPublic+1:], src/groth16_prove.js:85-97).
 // Leaves the complete buckets of this MSM in the bucket buffer of job.slot; msm_reduce finishes the job.
-template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job) {
+template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask = nullptr) {
     constexpr int FW = FieldWords<F>::value, PW = 4 * FW;
     constexpr bool WIDE = FW > 12;
     Ctx& cx = ctx();
@@ -146,7 +147,7 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
         acc_attr = true;
     }
     if (job.acc0) ZK_HIP(hipEventRecord(job.acc0, st));
-    hipLaunchKernelGGL((k_msm_accum<F, WIDE>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), acc_lds, st, (const uint32_t*)d_bases, sh, skip, pl.cap, pl.counts,
+    hipLaunchKernelGGL((k_msm_accum<F, WIDE>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), acc_lds, st, (const uint32_t*)d_bases, d_infmask, sh, skip, pl.cap, pl.counts,
                        pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials);
     if (job.acc1) ZK_HIP(hipEventRecord(job.acc1, st));
     hipLaunchKernelGGL((k_msm_tree<F, MSM_TB>), dim3((unsigned)tree_blocks), dim3(MSM_TB), tree_lds, st, lane_partials, pl.lane_g, pl.counts, pl.cap, pl.meta, buckets,
@@ -318,12 +319,21 @@ template <class F> int msm_precompute(const void* d_bases, size_t n, int c, int 
     return ZKMI_OK;
 }
 int msm_precompute_dispatch(int curve, int group, const void* d_bases, size_t n, int c, int Wd, void* d_table);
+template <class F> int msm_infmask(const void* d_points, size_t n, uint32_t* d_mask) {
+    Ctx& cx = ctx();
+    ZK_HIP(hipMemsetAsync(d_mask, 0, ((n + 31) / 32) * 4, cx.stream));
+    if (n) hipLaunchKernelGGL((k_msm_infmask<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cx.stream, (const uint32_t*)d_points, n, d_mask);
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+}
 // MSM of the first k scalars against a pre-computed table (stride points per row, window width c)
 template <class F> int msm_run_table(const void* d_table, size_t stride, int c, const void* d_scalars, size_t k, size_t sb, uint8_t* out_jac);
 int msm_table_dispatch(int curve, int group, const void* d_table, size_t stride, int c, const void* d_scalars, size_t k, size_t sb, uint8_t* out_jac);
 
 // non-template entry points (msm_bn254.hip / msm_bls12381.hip) for callers that must not instantiate the kernels again
-int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job);
+int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask = nullptr);
+// d_mask: ceil(n/32) words, zeroed by the callee; bit i = point i is the point at infinity
+int msm_infmask_dispatch(int curve, int group, const void* d_points, size_t n, uint32_t* d_mask);
 int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs, bool aux = false);
 
 int msm_fold_dispatch(int curve, int group, const MsmJob& job, uint8_t* out_jac);

@@ -6,21 +6,21 @@
 namespace zkmi {
 
 template <int NW> static int msm_launch_digits(const uint8_t* d_scalars, const MsmShape& sh, uint32_t* counts, uint32_t* starts, uint32_t* cursor,
-                                               uint32_t* sorted, uint32_t* part, hipStream_t st) {
+                                               uint32_t* sorted, uint32_t* part, const uint32_t* dropmask, hipStream_t st) {
     const unsigned blocks = (unsigned)((sh.n + 255) / 256);
-    hipLaunchKernelGGL((k_msm_count<NW>), dim3(blocks), dim3(256), 0, st, d_scalars, sh, counts);
+    hipLaunchKernelGGL((k_msm_count<NW>), dim3(blocks), dim3(256), 0, st, d_scalars, sh, dropmask, counts);
     const uint32_t total = (uint32_t)sh.W * sh.nb, nparts = (total + MSM_SCAN_CHUNK - 1) / MSM_SCAN_CHUNK;
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(nparts), dim3(256), 0, st, counts, total, part);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, st, part, nparts);
     hipLaunchKernelGGL(k_msm_scan_final, dim3(nparts), dim3(256), 0, st, counts, total, part, starts);
-    hipLaunchKernelGGL((k_msm_scatter<NW>), dim3(blocks), dim3(256), 0, st, d_scalars, sh, starts, cursor, sorted);
+    hipLaunchKernelGGL((k_msm_scatter<NW>), dim3(blocks), dim3(256), 0, st, d_scalars, sh, dropmask, starts, cursor, sorted);
     return ZKMI_OK;
 }
 
-int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_slot, int precomp_c, size_t table_stride) {
+int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_slot, int precomp_c, size_t table_stride, const uint32_t* d_dropmask) {
     Ctx& cx = ctx();
-    pl.slot = plan_slot & 1;
-    const std::string sfx = pl.slot ? ".p1" : ".p0";
+    pl.slot = plan_slot;
+    const std::string sfx = ".p" + std::to_string(plan_slot);
     if (n == 0 || n >= (1ull << 31)) return fail(ZKMI_ERR_UNSUPPORTED, "msm: n must be in [1, 2^31)");
     if (sb == 0 || sb > 64) return fail(ZKMI_ERR_UNSUPPORTED, "msm: scalar size must be 1..64 bytes");
     MsmShape& sh = pl.sh;
@@ -62,9 +62,9 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     const uint8_t* sc = (const uint8_t*)d_scalars;
     uint32_t* part;
     ZK_TRY(ws_get("msm.scanpart" + sfx, (total / MSM_SCAN_CHUNK + 2) * 4, (void**)&part));
-    if (sb <= 4) msm_launch_digits<1>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, st);
-    else if (sb <= 32) msm_launch_digits<8>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, st);
-    else msm_launch_digits<16>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, st);
+    if (sb <= 4) msm_launch_digits<1>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, d_dropmask, st);
+    else if (sb <= 32) msm_launch_digits<8>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, d_dropmask, st);
+    else msm_launch_digits<16>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, d_dropmask, st);
     const unsigned tb = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(k_msm_classify, dim3(tb), dim3(256), 0, st, pl.counts, (uint32_t)total, cap, hist);
     hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(64), 0, st, hist, koff, pl.meta, cap);

@@ -78,7 +78,7 @@ class ProvingKey:
     def stage_ms(self):
         out = (C.c_double * 11)()
         zkmi.check(zkmi.lib().zkmi_groth16_stage_ms(out, 11))
-        names = ["buildABC", "ntt_x6", "joinABC", "sort_witness", "accum_B2", "accum_A", "accum_B1", "accum_C", "sort_H", "accum_H", "reduce_g1"]
+        names = ["buildABC", "ntt_x6", "joinABC", "sort_witness_B", "accum_B2", "accum_B1+sort_witness", "accum_A", "accum_C", "sort_H", "accum_H", "reduce_g1"]
         return dict(zip(names, list(out)))
 
     def release(self):
