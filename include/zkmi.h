@@ -188,8 +188,11 @@ int zkmi_poly_evaluate_dev(int curve, const void* d_p, size_t n, const uint8_t* 
 int zkmi_poly_is_zero_dev(int curve, const void* d_p, size_t n, int* all_zero);
 /* Polynomial.divZh(domainSize, extensions) (:592-615), in place; "Polynomial is not divisible" on a non-zero tail */
 int zkmi_poly_div_zh_dev(int curve, void* d_p, size_t len, uint32_t domain, uint32_t extensions);
-/* Polynomial.divByZerofier(n, beta) (:617-674), in place; n = 1 only (PLONK openings; FFLONK's n > 1 is not built yet) */
+/* Polynomial.divByZerofier(n, beta) (:617-674): division by X^n - beta, in place (PLONK openings use n = 1, FFLONK n > 1) */
 int zkmi_poly_div_by_zerofier_dev(int curve, void* d_p, size_t len, uint32_t n, const uint8_t* beta);
+/* CPolynomial.getPolynomial (src/polynomial/cpolynomial.js:53-73): out[i*n + j] = P_j[i] for i < lens[j] (d_polys[j] may be
+ * NULL), zero elsewhere; n <= 16 component polynomials; out_len elements are written. */
+int zkmi_cpoly_interleave_dev(int curve, const void* const* d_polys, const size_t* lens, int n, void* d_out, size_t out_len);
 
 /* ---- utilities --------------------------------------------------------------------------------------------------- */
 /* Synthetic base table of SURVEY.md §8d: P_i = (f*g^i mod r)*G written to device memory as affine Montgomery points

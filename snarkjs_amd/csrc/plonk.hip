@@ -328,15 +328,40 @@ template <class C> __global__ void __launch_bounds__(256) k_poly_sum(const uint3
     if (threadIdx.x == 0) fp_store<C>(out, acc);
 }
 // divByZerofier(1, beta): u_i = -c_i * beta^i * (1/beta); S = inclusive prefix sums of u; q_i = S_i * (1/beta)^i
-template <class C> __global__ void k_dz_weight(const uint32_t* __restrict__ c, size_t n, PowTab bt, const uint32_t* __restrict__ inv_beta, uint32_t* __restrict__ u) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    fp_store<C>(u + i * 8, fp_neg(fp_mul(fp_mul(fp_load<C>(c + i * 8), pow_tab<C>(bt, i)), fp_load<C>(inv_beta))));
+// (chain k of residue `off` modulo `stride`: element index off + k*stride; stride = 1 for the PLONK openings)
+template <class C> __global__ void k_dz_weight(const uint32_t* __restrict__ c, size_t m, size_t off, size_t stride, PowTab bt, const uint32_t* __restrict__ inv_beta, uint32_t* __restrict__ u) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    fp_store<C>(u + k * 8, fp_neg(fp_mul(fp_mul(fp_load<C>(c + (off + k * stride) * 8), pow_tab<C>(bt, k)), fp_load<C>(inv_beta))));
 }
-template <class C> __global__ void k_dz_unweight(const uint32_t* __restrict__ s, size_t n, PowTab it, uint32_t* __restrict__ q) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    fp_store<C>(q + i * 8, fp_mul(fp_load<C>(s + i * 8), pow_tab<C>(it, i)));
+template <class C> __global__ void k_dz_unweight(const uint32_t* __restrict__ s, size_t m, size_t off, size_t stride, PowTab it, uint32_t* __restrict__ q) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    fp_store<C>(q + (off + k * stride) * 8, fp_mul(fp_load<C>(s + k * 8), pow_tab<C>(it, k)));
+}
+// many short chains (n large): one lane per residue, sequential along the chain; bad != 0 if a coefficient that must vanish does not
+template <class C> __global__ void k_dz_chain(uint32_t* __restrict__ c, size_t len, uint32_t n, const uint32_t* __restrict__ inv_beta, uint32_t* __restrict__ bad) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || r >= len) return;
+    const Fp<C> ib = fp_load<C>(inv_beta);
+    Fp<C> prev = fp_neg(fp_mul(ib, fp_load<C>(c + (size_t)r * 8)));
+    fp_store<C>(c + (size_t)r * 8, prev);
+    for (size_t i = (size_t)r + n; i < len; i += n) {
+        prev = fp_mul(ib, fp_sub(prev, fp_load<C>(c + i * 8)));
+        fp_store<C>(c + i * 8, prev);
+        if (i + n + 1 > len && !fp_is_zero(prev)) atomicAdd(bad, 1u);           // i > len - n - 1
+    }
+}
+// CPolynomial.getPolynomial (cpolynomial.js:53-73): out[i*n + j] = P_j[i], i < len_j
+struct InterleaveArgs { const uint32_t* p[16]; uint32_t len[16]; uint32_t n; };
+template <class C> __global__ void k_cpoly_interleave(InterleaveArgs a, uint32_t* __restrict__ out, size_t out_len) {
+    size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= out_len) return;
+    const uint32_t j = (uint32_t)(o % a.n);
+    const size_t i = o / a.n;
+    Fp<C> v = fp_zero<C>();
+    if (a.p[j] && i < a.len[j]) v = fp_load<C>(a.p[j] + i * 8);
+    fp_store<C>(out + o * 8, v);
 }
 
 // ---- host drivers (templated on the Fr configuration) -----------------------------------------------------------------------------
@@ -461,26 +486,55 @@ template <class C> struct PlonkOps {
     }
     static int div_by_zerofier(void* p, size_t len, uint32_t n, const uint8_t* beta) {
         Ctx& cx = ctx();
-        if (n != 1) return fail(ZKMI_ERR_UNSUPPORTED, "divByZerofier: only n = 1 (PLONK openings) is implemented on the device");
+        if (n == 0) return fail(ZKMI_ERR_INVALID, "divByZerofier: n must be positive");
         if (!len) return ZKMI_OK;
         const HFr Fh = F();
         const HE b = he(beta), ib = Fh.inv(b);
-        PowTab bt, it;
-        ZK_TRY(build_pow_tab(Fh, b, std::max(1u, clog2(len)), "plonk.powb", &bt));
-        ZK_TRY(build_pow_tab(Fh, ib, std::max(1u, clog2(len)), "plonk.powib", &it));
-        uint32_t *dib, *u;
+        uint32_t *dib, *bad;
         std::vector<HE> kv(1, ib);
         ZK_TRY(upload_consts(kv, "plonk.kib", &dib));
-        ZK_TRY(ws_get("plonk.dzu", len * 32, (void**)&u));
-        const unsigned blocks = (unsigned)((len + 255) / 256);
-        hipLaunchKernelGGL((k_dz_weight<C>), dim3(blocks), dim3(256), 0, cx.stream, (const uint32_t*)p, len, bt, dib, u);
-        ZK_TRY((scan_inclusive<C, false>(u, len, u)));
-        hipLaunchKernelGGL((k_dz_unweight<C>), dim3(blocks), dim3(256), 0, cx.stream, u, len, it, (uint32_t*)p);
-        HE last;
-        ZK_HIP(hipMemcpyAsync(last.v, (uint8_t*)p + (len - 1) * 32, 32, hipMemcpyDeviceToHost, cx.stream));
+        const size_t chain = (len + n - 1) / n;                    // longest chain
+        if (n >= 64 || chain <= 64) {
+            // many short chains: one lane per residue class
+            ZK_TRY(ws_get("plonk.bad", 16, (void**)&bad));
+            ZK_HIP(hipMemsetAsync(bad, 0, 16, cx.stream));
+            hipLaunchKernelGGL((k_dz_chain<C>), dim3((n + 255) / 256), dim3(256), 0, cx.stream, (uint32_t*)p, len, n, dib, bad);
+            uint32_t nbad = 0;
+            ZK_HIP(hipMemcpyAsync(&nbad, bad, 4, hipMemcpyDeviceToHost, cx.stream));
+            ZK_HIP(hipStreamSynchronize(cx.stream));
+            ZK_HIP(hipGetLastError());
+            if (nbad) return fail(ZKMI_ERR_INVALID, "Polynomial is not divisible");
+            return ZKMI_OK;
+        }
+        // few long chains: each residue class r is the linear recurrence q_k = (q_{k-1} - c_k)/beta, solved as a prefix sum
+        PowTab bt, it;
+        ZK_TRY(build_pow_tab(Fh, b, std::max(1u, clog2(chain)), "plonk.powb", &bt));
+        ZK_TRY(build_pow_tab(Fh, ib, std::max(1u, clog2(chain)), "plonk.powib", &it));
+        uint32_t* u;
+        ZK_TRY(ws_get("plonk.dzu", chain * 32, (void**)&u));
+        for (uint32_t r = 0; r < n && r < len; r++) {
+            const size_t m = (len - r + n - 1) / n;
+            const unsigned blocks = (unsigned)((m + 255) / 256);
+            hipLaunchKernelGGL((k_dz_weight<C>), dim3(blocks), dim3(256), 0, cx.stream, (const uint32_t*)p, m, (size_t)r, (size_t)n, bt, dib, u);
+            ZK_TRY((scan_inclusive<C, false>(u, m, u)));
+            hipLaunchKernelGGL((k_dz_unweight<C>), dim3(blocks), dim3(256), 0, cx.stream, u, m, (size_t)r, (size_t)n, it, (uint32_t*)p);
+        }
+        // the n highest coefficients must vanish (polynomial.js:665-669)
+        const size_t tail = std::min<size_t>(n, len);
+        std::vector<HE> last(tail);
+        ZK_HIP(hipMemcpyAsync(last.data(), (uint8_t*)p + (len - tail) * 32, tail * 32, hipMemcpyDeviceToHost, cx.stream));
         ZK_HIP(hipStreamSynchronize(cx.stream));
         ZK_HIP(hipGetLastError());
-        if (!last.is_zero()) return fail(ZKMI_ERR_INVALID, "Polynomial is not divisible");   // polynomial.js:665-669
+        for (const HE& e : last) if (!e.is_zero()) return fail(ZKMI_ERR_INVALID, "Polynomial is not divisible");
+        return ZKMI_OK;
+    }
+    static int interleave(const void* const* polys, const size_t* lens, int n, void* out, size_t out_len) {
+        if (n < 1 || n > 16) return fail(ZKMI_ERR_UNSUPPORTED, "CPolynomial: 1..16 component polynomials");
+        InterleaveArgs a;
+        a.n = (uint32_t)n;
+        for (int j = 0; j < 16; j++) { a.p[j] = j < n ? (const uint32_t*)polys[j] : nullptr; a.len[j] = j < n ? (uint32_t)lens[j] : 0; }
+        if (out_len) hipLaunchKernelGGL((k_cpoly_interleave<C>), dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx().stream, a, (uint32_t*)out, out_len);
+        ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
 };
@@ -532,5 +586,9 @@ int zkmi_poly_is_zero_dev(int curve, const void* d_p, size_t n, int* all_zero) {
 }
 int zkmi_poly_div_zh_dev(int curve, void* d_p, size_t len, uint32_t domain, uint32_t extensions) { PLONK_DISPATCH(curve, div_zh(d_p, len, domain, extensions)); }
 int zkmi_poly_div_by_zerofier_dev(int curve, void* d_p, size_t len, uint32_t n, const uint8_t* beta) { PLONK_DISPATCH(curve, div_by_zerofier(d_p, len, n, beta)); }
+int zkmi_cpoly_interleave_dev(int curve, const void* const* d_polys, const size_t* lens, int n, void* d_out, size_t out_len) {
+    if (!d_polys || !lens) return fail(ZKMI_ERR_INVALID, "null argument");
+    PLONK_DISPATCH(curve, interleave(d_polys, lens, n, d_out, out_len));
+}
 
 }  // extern "C"

@@ -27,7 +27,7 @@ SYMBOLS = [
     "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_release", "zkmi_groth16_stage_ms",
     "zkmi_gen_geometric_bases_dev", "zkmi_to_affine", "zkmi_point_add", "zkmi_fr_root",
     "zkmi_plonk_gather_wires_dev", "zkmi_plonk_compute_z_dev", "zkmi_plonk_compute_t_dev", "zkmi_poly_axpy_dev", "zkmi_poly_scale_dev",
-    "zkmi_poly_evaluate_dev", "zkmi_poly_is_zero_dev", "zkmi_poly_div_zh_dev", "zkmi_poly_div_by_zerofier_dev", "zkmi_last_kernel_ms",
+    "zkmi_poly_evaluate_dev", "zkmi_poly_is_zero_dev", "zkmi_poly_div_zh_dev", "zkmi_cpoly_interleave_dev", "zkmi_poly_div_by_zerofier_dev", "zkmi_last_kernel_ms",
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
     L.zkmi_poly_is_zero_dev.argtypes = [C.c_int, vp, sz, C.POINTER(C.c_int)]
     L.zkmi_poly_div_zh_dev.argtypes = [C.c_int, vp, sz, u32, u32]
     L.zkmi_poly_div_by_zerofier_dev.argtypes = [C.c_int, vp, sz, u32, u8p]
+    L.zkmi_cpoly_interleave_dev.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(sz), C.c_int, vp, sz]
     L.zkmi_groth16_load.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64]
     L.zkmi_groth16_prove.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p]
     L.zkmi_groth16_prove_dev.argtypes = [C.c_uint64, vp, u8p, u8p, u8p, u8p, u8p]

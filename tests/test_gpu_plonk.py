@@ -181,3 +181,45 @@ def test_synthetic_plonk_key_device_vs_oracle(env, lg):
     with pytest.raises(Exception) as ei:
         plonk.prove(zkey, bytes(bad), blinding_mont=blind)
     assert "Copy constraints does not match" in str(ei.value) or "not divisible" in str(ei.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,length", [(2, 4096), (3, 1000), (8, 70000), (64, 5000), (200, 1000), (4, 8)])
+def test_div_by_zerofier_general_n(env, n, length):
+    """divByZerofier(n, beta) for n > 1 (FFLONK's use, polynomial.js:617-674): p = q * (X^n - beta)"""
+    zkmi, plonk, f, cx = env
+    L, r = zkmi.lib(), cx.r
+    beta = _rand(5, 1, r)[0]
+    q = _rand(100 + n, length - n, r)
+    p = [0] * length
+    for i, c in enumerate(q):
+        p[i] = (p[i] - beta * c) % r
+        p[i + n] = (p[i + n] + c) % r
+    want = P.div_by_zerofier(p, n, beta, r)
+    assert want[:length - n] == q and not any(want[length - n:])
+    dp = _dev(zkmi, cx, p)
+    zkmi.check(L.zkmi_poly_div_by_zerofier_dev(0, dp.ptr, length, n, zkmi.ptr(f.mont(beta))))
+    assert _host(cx, dp, length) == want
+    p[1] = (p[1] + 3) % r
+    dp = _dev(zkmi, cx, p)
+    assert L.zkmi_poly_div_by_zerofier_dev(0, dp.ptr, length, n, zkmi.ptr(f.mont(beta))) != 0
+
+
+@pytest.mark.gpu
+def test_cpoly_interleave(env):
+    """CPolynomial.getPolynomial (cpolynomial.js:53-73)"""
+    zkmi, plonk, f, cx = env
+    L, r = zkmi.lib(), cx.r
+    polys = [_rand(40 + j, ln, r) if ln else None for j, ln in enumerate((100, 0, 37, 100))]
+    n, out_len = 4, 512
+    bufs = [_dev(zkmi, cx, p) if p else None for p in polys]
+    ptrs = (C.c_void_p * n)(*[b.ptr if b else None for b in bufs])
+    lens = (C.c_size_t * n)(*[len(p) if p else 0 for p in polys])
+    out = zkmi.DeviceBuffer(out_len * 32)
+    zkmi.check(L.zkmi_cpoly_interleave_dev(0, ptrs, lens, n, out.ptr, out_len))
+    want = [0] * out_len
+    for j, p in enumerate(polys):
+        for i, c in enumerate(p or []):
+            if i * n + j < out_len:
+                want[i * n + j] = c
+    assert _host(cx, out, out_len) == want
