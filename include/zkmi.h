@@ -89,6 +89,10 @@ double zkmi_msm_accum_ms(int slot);
  * points; each MSM then uses the first k <= n bases with k scalars of at most 32 bytes. */
 int zkmi_msm_table_build(int curve, int group, const void* d_bases, size_t n, uint64_t* handle);
 int zkmi_msm_table_dev(uint64_t handle, const void* d_scalars, size_t k, size_t scalar_bytes, uint8_t* out_jacobian);
+/* up to 4 independent MSMs against one table in a single call (PLONK commits A,B,C / T1,T2,T3 / Wxi,Wxiw per round): their
+ * latency-bound bucket reductions share one set of launches. out_jacobians: count x 3*group*n8q bytes. */
+int zkmi_msm_table_multi_dev(uint64_t handle, const void* const* d_scalars, const size_t* ks, int count, size_t scalar_bytes,
+                             uint8_t* out_jacobians);
 int zkmi_msm_table_release(uint64_t handle);
 /* Window width used for n terms (tuning knob; 0 restores the built-in table). */
 int zkmi_msm_set_window_bits(int c);

@@ -329,6 +329,9 @@ template <class F> int msm_infmask(const void* d_points, size_t n, uint32_t* d_m
 // MSM of the first k scalars against a pre-computed table (stride points per row, window width c)
 template <class F> int msm_run_table(const void* d_table, size_t stride, int c, const void* d_scalars, size_t k, size_t sb, uint8_t* out_jac);
 int msm_table_dispatch(int curve, int group, const void* d_table, size_t stride, int c, const void* d_scalars, size_t k, size_t sb, uint8_t* out_jac);
+// Several MSMs against the same table (independent scalar vectors): one sort + accumulation each, ONE batched bucket reduction
+int msm_table_multi_dispatch(int curve, int group, const void* d_table, size_t stride, int c, const void* const* d_scalars, const size_t* ks, int count, size_t sb,
+                             uint8_t* out_jacs);
 
 // non-template entry points (msm_bn254.hip / msm_bls12381.hip) for callers that must not instantiate the kernels again
 int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask = nullptr);
@@ -356,6 +359,35 @@ template <class F> int msm_run_table(const void* d_table, size_t stride, int c, 
     float ms = 0;
     if (hipEventElapsedTime(&ms, cx.ev0, cx.ev1) == hipSuccess) cx.last_ms = ms;
     msm_fold<F>(job, out_jac);
+    return ZKMI_OK;
+}
+
+template <class F> int msm_run_table_multi(const void* d_table, size_t stride, int c, const void* const* d_scalars, const size_t* ks, int count, size_t sb, uint8_t* out_jacs) {
+    constexpr int FW = FieldWords<F>::value;
+    Ctx& cx = ctx();
+    if (count < 1 || count > MSM_MAX_BATCH) return fail(ZKMI_ERR_INVALID, "msm_table_multi: 1..4 MSMs per call");
+    hipStream_t st = cx.stream;
+    MsmPlan pl[MSM_MAX_BATCH];
+    MsmJob job[MSM_MAX_BATCH];
+    MsmJob* jp[MSM_MAX_BATCH];
+    int live = 0;
+    ZK_HIP(hipEventRecord(cx.ev0, st));
+    for (int i = 0; i < count; i++) {
+        if (ks[i] == 0) continue;
+        ZK_TRY(msm_job_slot(i, job[i]));
+        ZK_TRY(msm_sort(d_scalars[i], ks[i], sb, pl[i], i, c, stride));
+        ZK_TRY(msm_accumulate<F>(d_table, pl[i], 0, job[i]));
+        jp[live++] = &job[i];
+    }
+    if (live) ZK_TRY(msm_reduce<F>(jp, live));
+    ZK_HIP(hipEventRecord(cx.ev1, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, cx.ev0, cx.ev1) == hipSuccess) cx.last_ms = ms;
+    for (int i = 0; i < count; i++) {
+        if (ks[i] == 0) memset(out_jacs + (size_t)i * 12 * FW, 0, 12 * FW);
+        else msm_fold<F>(job[i], out_jacs + (size_t)i * 12 * FW);
+    }
     return ZKMI_OK;
 }
 

@@ -68,6 +68,8 @@ int msm_precompute_bn254(int group, const void*, size_t, int, int, void*);
 int msm_precompute_bls12381(int group, const void*, size_t, int, int, void*);
 int msm_table_bn254(int group, const void*, size_t, int, const void*, size_t, size_t, uint8_t*);
 int msm_table_bls12381(int group, const void*, size_t, int, const void*, size_t, size_t, uint8_t*);
+int msm_table_multi_bn254(int group, const void*, size_t, int, const void* const*, const size_t*, int, size_t, uint8_t*);
+int msm_table_multi_bls12381(int group, const void*, size_t, int, const void* const*, const size_t*, int, size_t, uint8_t*);
 int msm_reduce_bls12381(int group, MsmJob* const*, int, bool);
 int msm_fold_bn254(int group, const MsmJob&, uint8_t*);
 int msm_fold_bls12381(int group, const MsmJob&, uint8_t*);
@@ -270,6 +272,17 @@ int zkmi_msm_table_dev(uint64_t handle, const void* d_scalars, size_t k, size_t 
     if (k > t.n) return fail(ZKMI_ERR_INVALID, "msm_table_dev: more scalars than resident bases");
     if (scalar_bytes == 0 || scalar_bytes > 32) return fail(ZKMI_ERR_UNSUPPORTED, "msm_table_dev: tables are built for scalars of at most 32 bytes");
     return msm_table_dispatch(t.curve, t.group, t.p, t.n, t.c, d_scalars, k, scalar_bytes, out);
+}
+int zkmi_msm_table_multi_dev(uint64_t handle, const void* const* d_scalars, const size_t* ks, int count, size_t scalar_bytes, uint8_t* out_jacobians) {
+    ZK_TRY(require_ctx());
+    auto it = g_tables.find(handle);
+    if (it == g_tables.end()) return fail(ZKMI_ERR_INVALID, "msm_table_multi_dev: unknown table");
+    const MsmTable& t = it->second;
+    if (!d_scalars || !ks || !out_jacobians) return fail(ZKMI_ERR_INVALID, "null argument");
+    if (scalar_bytes == 0 || scalar_bytes > 32) return fail(ZKMI_ERR_UNSUPPORTED, "msm_table_multi_dev: tables are built for scalars of at most 32 bytes");
+    for (int i = 0; i < count; i++) if (ks[i] > t.n) return fail(ZKMI_ERR_INVALID, "msm_table_multi_dev: more scalars than resident bases");
+    return t.curve == ZKMI_CURVE_BN128 ? msm_table_multi_bn254(t.group, t.p, t.n, t.c, d_scalars, ks, count, scalar_bytes, out_jacobians)
+                                       : msm_table_multi_bls12381(t.group, t.p, t.n, t.c, d_scalars, ks, count, scalar_bytes, out_jacobians);
 }
 int zkmi_msm_table_release(uint64_t handle) {
     auto it = g_tables.find(handle);

@@ -231,17 +231,25 @@ class _Transcript:
         return int.from_bytes(keccak256(b"".join(self.parts)), "big") % self.f.r
 
 
-def _commit(key, poly):
-    """Polynomial.multiExponentiation (polynomial.js:970-977): batchFromMontgomery, G1.multiExpAffine over PTau[0:len], toAffine"""
-    f, L = key.f, zkmi.lib()
-    sc = zkmi.DeviceBuffer(poly.n * 32)
-    zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_FROM_MONTGOMERY, poly.ptr, sc.ptr, poly.n))
-    jac = np.zeros(3 * f.n8q, np.uint8)
-    zkmi.check(L.zkmi_msm_table_dev(key.ptau_table, sc.ptr, poly.n, 32, zkmi.ptr(jac)))
-    sc.free()
-    aff = np.zeros(2 * f.n8q, np.uint8)
-    zkmi.check(L.zkmi_to_affine(f.cid, 1, zkmi.ptr(jac), zkmi.ptr(aff)))
-    return (f.unmont_q(aff[:f.n8q]), f.unmont_q(aff[f.n8q:]))
+def _commit(key, *polys):
+    """Polynomial.multiExponentiation (polynomial.js:970-977) for the commitments of one round: batchFromMontgomery,
+    G1.multiExpAffine over PTau[0:len] (resident table; the bucket reductions of the round share one set of launches), toAffine."""
+    f, L, cnt = key.f, zkmi.lib(), len(polys)
+    scs = [zkmi.DeviceBuffer(p.n * 32) for p in polys]
+    for p, sc in zip(polys, scs):
+        zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_FROM_MONTGOMERY, p.ptr, sc.ptr, p.n))
+    jac = np.zeros(cnt * 3 * f.n8q, np.uint8)
+    ptrs = (C.c_void_p * cnt)(*[sc.ptr for sc in scs])
+    ks = (C.c_size_t * cnt)(*[p.n for p in polys])
+    zkmi.check(L.zkmi_msm_table_multi_dev(key.ptau_table, ptrs, ks, cnt, 32, zkmi.ptr(jac)))
+    out = []
+    for i in range(cnt):
+        aff = np.zeros(2 * f.n8q, np.uint8)
+        zkmi.check(L.zkmi_to_affine(f.cid, 1, zkmi.ptr(jac[i * 3 * f.n8q:(i + 1) * 3 * f.n8q].copy()), zkmi.ptr(aff)))
+        out.append((f.unmont_q(aff[:f.n8q]), f.unmont_q(aff[f.n8q:])))
+    for sc in scs:
+        sc.free()
+    return out
 
 
 def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
@@ -307,8 +315,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     pA, pB, pC = A.ntt(True), B.ntt(True), Cw.ntt(True)
     eA, eB, eC = pA.extended_evals(4), pB.extended_evals(4), pC.extended_evals(4)
     pA, pB, pC = pA.blinded([b[2], b[1]]), pB.blinded([b[4], b[3]]), pC.blinded([b[6], b[5]])
-    for nm, p in (("A", pA), ("B", pB), ("C", pC)):
-        pts[nm] = _commit(key, p)
+    pts["A"], pts["B"], pts["C"] = _commit(key, pA, pB, pC)
 
     # ---- ROUND 2 (:315-455)
     tr.reset()
@@ -327,7 +334,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     pZ = Zb.ntt(True)
     eZ = pZ.extended_evals(4)
     pZ = pZ.blinded([b[9], b[8], b[7]])
-    pts["Z"] = _commit(key, pZ)
+    pts["Z"], = _commit(key, pZ)
 
     # ---- ROUND 3 (:457-684)
     tr.reset(); tr.scalar(beta); tr.scalar(gamma); tr.point(pts["Z"])
@@ -350,8 +357,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     T1.set(n, b[10])
     T2.set(0, (T2.get(0) - b[10]) % r); T2.set(n, b[11])
     T3.set(0, (T3.get(0) - b[11]) % r)
-    for nm, p in (("T1", T1), ("T2", T2), ("T3", T3)):
-        pts[nm] = _commit(key, p)
+    pts["T1"], pts["T2"], pts["T3"] = _commit(key, T1, T2, T3)
 
     # ---- ROUND 4 (:686-708)
     tr.reset(); tr.scalar(alpha)
@@ -413,7 +419,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     Wxiw = _Poly(f, pZ.n, False).copy_from(pZ.ptr, pZ.n)
     Wxiw.add_scalar(-ezw % r)
     zkmi.check(L.zkmi_poly_div_by_zerofier_dev(f.cid, Wxiw.ptr, Wxiw.n, 1, zkmi.ptr(mont(xiw))))
-    pts["Wxi"], pts["Wxiw"] = _commit(key, Wxi), _commit(key, Wxiw)
+    pts["Wxi"], pts["Wxiw"] = _commit(key, Wxi, Wxiw)
 
     proof = {}
     for nm in ("A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"):                       # src/proof.js:61-83 (insertion order)
