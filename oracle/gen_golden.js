@@ -196,6 +196,52 @@ async function plonkGolden() {
     }
 }
 
+// Seeded FFLONK fixtures: fflonk.setup on two circuits of the reference's test tree with a seeded ptau (only tauG1/tauG2 are read,
+// src/fflonk_setup.js:430-438), then a seeded fflonk.prove whose 9 blinding draws (src/fflonk_prove.js:321-324) are recorded.
+async function fflonkGolden() {
+    const curve = await snarkjs.curves.getCurveFromName('bn128');
+    const mem = () => ({ type: 'mem' });
+    const p0 = mem(), p1 = mem(), pf = mem();
+    await snarkjs.powersOfTau.newAccumulator(curve, 12, p0);
+    await snarkjs.powersOfTau.contribute(p0, p1, 'C1', 'Entropy1');
+    await snarkjs.powersOfTau.preparePhase2(p1, pf);
+    const cases = [['fflonk_bn128_small', '/root/reference/test/plonk_circuit/', JSON.parse(fs.readFileSync('/root/reference/test/plonk_circuit/input.json'))],
+                   ['fflonk_bn128_n256', '/root/reference/test/fflonk/', JSON.parse(fs.readFileSync('/root/reference/test/fflonk/witness.json'))]];
+    for (const [tag, T, input] of cases) {
+        const z = mem(), w = mem();
+        await snarkjs.fflonk.setup(new Uint8Array(fs.readFileSync(T + 'circuit.r1cs')), pf, z);
+        if (tag === 'fflonk_bn128_n256') {
+            // test/fflonk/circuit.wasm does not belong to circuit.r1cs (it yields 14 signals); the witness of Multiplier(100)
+            // (circuit.circom) is computed here directly: signals = [1, c, a, b, int[0..98]], c = int[99]
+            const r = curve.Fr.p, a = BigInt(input.a), b = BigInt(input.b), ints = [(a * a + b) % r];
+            for (let i = 1; i < 100; i++) ints.push((ints[i - 1] * ints[i - 1] + b) % r);
+            const sig = [1n, ints[99], a, b].concat(ints.slice(0, 99));
+            const le = (v, n) => { const o = new Uint8Array(n); for (let i = 0; i < n; i++) { o[i] = Number(v & 255n); v >>= 8n; } return o; };
+            const u32 = (v) => le(BigInt(v), 4), u64 = (v) => le(BigInt(v), 8);
+            const hdrS = Buffer.concat([u32(32), le(r, 32), u32(sig.length)]), dataS = Buffer.concat(sig.map((v) => le(v, 32)));
+            w.data = new Uint8Array(Buffer.concat([Buffer.from('wtns'), u32(2), u32(2), u32(1), u64(hdrS.length), hdrS, u32(2), u64(dataS.length), dataS]));
+        } else await snarkjs.wtns.calculate(input, new Uint8Array(fs.readFileSync(T + 'circuit.wasm')), w);
+        const rnd = [], Fr = curve.Fr, census = {};
+        const origRandom = Fr.random.bind(Fr); Fr.random = () => { const v = origRandom(); rnd.push(hex(v)); return v; };
+        const undo = [];
+        for (const [obj, nm] of [[Fr, 'fft'], [Fr, 'ifft'], [Fr, 'batchToMontgomery'], [Fr, 'batchFromMontgomery'], [Fr, 'batchInverse'], [curve.G1, 'multiExpAffine']]) {
+            const o = obj[nm]; undo.push([obj, nm, o]);
+            obj[nm] = async function (...a) { census[nm] = (census[nm] || 0) + 1; return o.apply(obj, a); };
+        }
+        const { proof, publicSignals } = await snarkjs.fflonk.prove(z.data, w.data);
+        for (const [o, nm, f] of undo) o[nm] = f; Fr.random = origRandom;
+        const vk = await snarkjs.zKey.exportVerificationKey(z.data);
+        const ok = await snarkjs.fflonk.verify(vk, publicSignals, proof);
+        if (!ok) throw new Error('golden fflonk proof does not verify');
+        fs.writeFileSync(path.join(OUT, `${tag}.zkey`), z.data);
+        fs.writeFileSync(path.join(OUT, `${tag}.wtns`), w.data);
+        fs.writeFileSync(path.join(OUT, `${tag}.json`), JSON.stringify({
+            zkey_sha256: sha(z.data), wtns_sha256: sha(w.data), proof_sha256: sha(JSON.stringify(proof)), blinding_mont: rnd, proof, publicSignals,
+            verified: ok, vk, census }, null, 1));
+        console.log(tag, 'fflonk golden done: zkey', z.data.length, 'bytes, proof sha', sha(JSON.stringify(proof)), 'verify', ok);
+    }
+}
+
 (async () => {
     fs.mkdirSync(OUT, { recursive: true });
     const what = process.argv[2] || 'all';
@@ -203,5 +249,6 @@ async function plonkGolden() {
     if (what === 'all' || what === 'bls12381') await kernelVectors('bls12381', 'bls12381');
     if (what === 'all' || what === 'groth16') await groth16Golden();
     if (what === 'all' || what === 'plonk') await plonkGolden();
+    if (what === 'all' || what === 'fflonk') await fflonkGolden();
     process.exit(0);
 })().catch(e => { console.error(e); process.exit(1); });
