@@ -182,6 +182,16 @@ typedef struct zkmi_plonk_evals {
 int zkmi_plonk_compute_t_dev(int curve, const zkmi_plonk_evals* ev, uint32_t domain, uint32_t n_public, const uint8_t* blind11 /* b1..b11 */,
                              const uint8_t* beta, const uint8_t* gamma, const uint8_t* alpha, const uint8_t* k1, const uint8_t* k2,
                              const uint8_t* w_n, const uint8_t* w_4n, const uint8_t* w_2, void* d_t, void* d_tz);
+/* FFLONK quotient numerators (src/fflonk_prove.js): T0 (:415-504) over 4n points from a,b,c,ql,qr,qm,qo,qc,lagrange,pub_a of
+ * `ev`; T1 / T1z (:667-718) over 2n points from the 4n evaluations of z and the Lagrange section (b789 = b7,b8,b9; w_2n =
+ * Fr.w[power+1]); T2 / T2z (:720-815) over 4n points from a,b,c,z,s1,s2,s3 of `ev`. */
+int zkmi_fflonk_t0_dev(int curve, const zkmi_plonk_evals* ev, uint32_t domain, uint32_t n_public, void* d_t0);
+int zkmi_fflonk_t1_dev(int curve, const void* d_z4, const void* d_lagrange, uint32_t domain, const uint8_t* b789, const uint8_t* w_2n,
+                       void* d_t1, void* d_t1z);
+int zkmi_fflonk_t2_dev(int curve, const zkmi_plonk_evals* ev, uint32_t domain, const uint8_t* b789, const uint8_t* beta, const uint8_t* gamma,
+                       const uint8_t* k1, const uint8_t* k2, const uint8_t* w_n, const uint8_t* w_4n, void* d_t2, void* d_t2z);
+/* Polynomial.degree (polynomial.js:163-172): highest index of a non-zero coefficient, 0 if none */
+int zkmi_poly_degree_dev(int curve, const void* d_p, size_t n, size_t* degree);
 /* Polynomial.add / sub with optional blinding value (polynomial.js:218-276): y[i] = y[i] +/- k*x[i], i < nx (k NULL = 1) */
 int zkmi_poly_axpy_dev(int curve, void* d_y, const void* d_x, size_t nx, const uint8_t* k, int subtract);
 /* Polynomial.mulScalar (:278-284) */

@@ -265,6 +265,63 @@ k_plonk_t(PlonkTArgs g, PowTab w4) {
     fp_store<C>(g.tz + (size_t)i * 8, fp_add(fp_sub(fp_add(e1z, e2z), e3z), e4z));
 }
 
+// ---- FFLONK quotient numerators (src/fflonk_prove.js) ------------------------------------------------------------------------
+// T0 (:415-504): q_L a + q_R b + q_M a b + q_O c + q_C + PI over the 4n extended points
+struct FflonkT0Args { const uint32_t *a, *b, *c, *ql, *qr, *qm, *qo, *qc, *lagrange, *pub_a; uint32_t domain, n_public; uint32_t* t0; };
+template <class C> __global__ void __launch_bounds__(256) k_fflonk_t0(FflonkT0Args g) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * g.domain) return;
+    auto ld = [&](const uint32_t* p, size_t idx) { return fp_load<C>(p + idx * 8); };
+    const Fp<C> a = ld(g.a, i), b = ld(g.b, i), c = ld(g.c, i);
+    Fp<C> pi = fp_zero<C>();
+    for (uint32_t j = 0; j < g.n_public; j++) pi = fp_sub(pi, fp_mul(ld(g.lagrange, (size_t)j * 5 * g.domain + g.domain + i), ld(g.pub_a, j)));
+    const Fp<C> e1 = fp_mul(a, ld(g.ql, i)), e2 = fp_mul(b, ld(g.qr, i)), e3 = fp_mul(fp_mul(a, b), ld(g.qm, i)), e4 = fp_mul(c, ld(g.qo, i));
+    fp_store<C>(g.t0 + (size_t)i * 8, fp_add(e1, fp_add(e2, fp_add(e3, fp_add(e4, fp_add(ld(g.qc, i), pi))))));
+}
+// T1 (:667-718): (z - 1) L_1 and z' L_1 over 2n points (every second extended evaluation); k: [0..2] = b7, b8, b9, [3] = one
+template <class C> __global__ void __launch_bounds__(256)
+k_fflonk_t1(const uint32_t* __restrict__ z4, const uint32_t* __restrict__ lagrange, uint32_t domain, const uint32_t* __restrict__ k, PowTab w2n, uint32_t* __restrict__ t1, uint32_t* __restrict__ t1z) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * domain) return;
+    const Fp<C> om = pow_tab<C>(w2n, i), om2 = fp_sqr(om);
+    const Fp<C> z = fp_load<C>(z4 + (size_t)2 * i * 8);
+    const Fp<C> zp = fp_add(fp_add(fp_mul(kc<C>(k, 0), om2), fp_mul(kc<C>(k, 1), om)), kc<C>(k, 2));
+    const Fp<C> l1 = fp_load<C>(lagrange + ((size_t)domain + 2 * i) * 8);
+    fp_store<C>(t1 + (size_t)i * 8, fp_mul(fp_sub(z, kc<C>(k, 3)), l1));
+    fp_store<C>(t1z + (size_t)i * 8, fp_mul(zp, l1));
+}
+// T2 (:720-815): permutation argument numerator and its blinding part over 4n points;
+// k: [0] beta [1] gamma [2] k1 [3] k2 [4] w_n [5..7] b7, b8, b9
+struct FflonkT2Args { const uint32_t *a, *b, *c, *z, *s1, *s2, *s3, *k; uint32_t domain; uint32_t *t2, *t2z; };
+template <class C> __global__ void __launch_bounds__(256) k_fflonk_t2(FflonkT2Args g, PowTab w4) {
+    const uint32_t n4 = 4 * g.domain;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    auto ld = [&](const uint32_t* p, size_t idx) { return fp_load<C>(p + idx * 8); };
+    const uint32_t* k = g.k;
+    const Fp<C> om = pow_tab<C>(w4, i), om2 = fp_sqr(om), omW = fp_mul(om, kc<C>(k, 4)), omW2 = fp_sqr(omW);
+    const Fp<C> a = ld(g.a, i), b = ld(g.b, i), c = ld(g.c, i), z = ld(g.z, i), zW = ld(g.z, (n4 + 4 + i) % n4);
+    const Fp<C> beta = kc<C>(k, 0), gamma = kc<C>(k, 1);
+    const Fp<C> zp = fp_add(fp_add(fp_mul(kc<C>(k, 5), om2), fp_mul(kc<C>(k, 6), om)), kc<C>(k, 7));
+    const Fp<C> zWp = fp_add(fp_add(fp_mul(kc<C>(k, 5), omW2), fp_mul(kc<C>(k, 6), omW)), kc<C>(k, 7));
+    const Fp<C> betaX = fp_mul(beta, om);
+    const Fp<C> e11 = fp_add(fp_add(a, betaX), gamma), e12 = fp_add(fp_add(b, fp_mul(betaX, kc<C>(k, 2))), gamma), e13 = fp_add(fp_add(c, fp_mul(betaX, kc<C>(k, 3))), gamma);
+    const Fp<C> p1 = fp_mul(fp_mul(e11, e12), e13);
+    const Fp<C> e21 = fp_add(fp_add(a, fp_mul(beta, ld(g.s1, i))), gamma), e22 = fp_add(fp_add(b, fp_mul(beta, ld(g.s2, i))), gamma), e23 = fp_add(fp_add(c, fp_mul(beta, ld(g.s3, i))), gamma);
+    const Fp<C> p2 = fp_mul(fp_mul(e21, e22), e23);
+    fp_store<C>(g.t2 + (size_t)i * 8, fp_sub(fp_mul(p1, z), fp_mul(p2, zW)));
+    fp_store<C>(g.t2z + (size_t)i * 8, fp_sub(fp_mul(p1, zp), fp_mul(p2, zWp)));
+}
+// highest index of a non-zero element (0 when all vanish): Polynomial.degree (polynomial.js:163-172)
+static __global__ void k_poly_degree(const uint32_t* __restrict__ p, size_t n, unsigned long long* __restrict__ deg) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o |= p[i * 8 + k];
+    if (o) atomicMax(deg, (unsigned long long)i);
+}
+
 // ---- polynomial ops ---------------------------------------------------------------------------------------------------------
 // y[i] = y[i] +/- (k ? k*x[i] : x[i]),  i < nx
 template <class C> __global__ void k_poly_axpy(uint32_t* __restrict__ y, const uint32_t* __restrict__ x, size_t nx, const uint32_t* __restrict__ k, int subtract) {
@@ -435,6 +492,41 @@ template <class C> struct PlonkOps {
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
+    static int fflonk_t0(const zkmi_plonk_evals* ev, uint32_t dom, uint32_t n_public, void* t0) {
+        FflonkT0Args g;
+        g.a = (const uint32_t*)ev->a; g.b = (const uint32_t*)ev->b; g.c = (const uint32_t*)ev->c;
+        g.ql = (const uint32_t*)ev->ql; g.qr = (const uint32_t*)ev->qr; g.qm = (const uint32_t*)ev->qm; g.qo = (const uint32_t*)ev->qo; g.qc = (const uint32_t*)ev->qc;
+        g.lagrange = (const uint32_t*)ev->lagrange; g.pub_a = (const uint32_t*)ev->pub_a; g.domain = dom; g.n_public = n_public; g.t0 = (uint32_t*)t0;
+        hipLaunchKernelGGL((k_fflonk_t0<C>), dim3((4 * dom + 255) / 256), dim3(256), 0, ctx().stream, g);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int fflonk_t1(const void* z4, const void* lagrange, uint32_t dom, const uint8_t* b789, const uint8_t* w_2n, void* t1, void* t1z) {
+        const HFr Fh = F();
+        std::vector<HE> kv = {he(b789), he(b789 + 32), he(b789 + 64), Fh.One()};
+        uint32_t* dk;
+        ZK_TRY(upload_consts(kv, "plonk.kt1", &dk));
+        PowTab w2;
+        ZK_TRY(build_pow_tab(Fh, he(w_2n), clog2((size_t)2 * dom), "plonk.powt1", &w2));
+        hipLaunchKernelGGL((k_fflonk_t1<C>), dim3((2 * dom + 255) / 256), dim3(256), 0, ctx().stream, (const uint32_t*)z4, (const uint32_t*)lagrange, dom, dk, w2, (uint32_t*)t1, (uint32_t*)t1z);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int fflonk_t2(const zkmi_plonk_evals* ev, uint32_t dom, const uint8_t* b789, const uint8_t* beta, const uint8_t* gamma, const uint8_t* k1, const uint8_t* k2, const uint8_t* w_n,
+                         const uint8_t* w_4n, void* t2, void* t2z) {
+        const HFr Fh = F();
+        std::vector<HE> kv = {he(beta), he(gamma), he(k1), he(k2), he(w_n), he(b789), he(b789 + 32), he(b789 + 64)};
+        uint32_t* dk;
+        ZK_TRY(upload_consts(kv, "plonk.kt2", &dk));
+        PowTab w4;
+        ZK_TRY(build_pow_tab(Fh, he(w_4n), clog2((size_t)4 * dom), "plonk.powt", &w4));
+        FflonkT2Args g;
+        g.a = (const uint32_t*)ev->a; g.b = (const uint32_t*)ev->b; g.c = (const uint32_t*)ev->c; g.z = (const uint32_t*)ev->z;
+        g.s1 = (const uint32_t*)ev->s1; g.s2 = (const uint32_t*)ev->s2; g.s3 = (const uint32_t*)ev->s3; g.k = dk; g.domain = dom; g.t2 = (uint32_t*)t2; g.t2z = (uint32_t*)t2z;
+        hipLaunchKernelGGL((k_fflonk_t2<C>), dim3((4 * dom + 255) / 256), dim3(256), 0, ctx().stream, g, w4);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
     static int axpy(void* y, const void* x, size_t nx, const uint8_t* k, int subtract) {
         if (!nx) return ZKMI_OK;
         uint32_t* dk = nullptr;
@@ -583,6 +675,34 @@ int zkmi_poly_is_zero_dev(int curve, const void* d_p, size_t n, int* all_zero) {
     ZK_HIP(hipStreamSynchronize(ctx().stream));
     *all_zero = f ? 0 : 1;
     return ZKMI_OK;
+}
+int zkmi_poly_degree_dev(int curve, const void* d_p, size_t n, size_t* degree) {
+    ZK_TRY(require_ctx());
+    (void)curve;
+    if (!degree) return fail(ZKMI_ERR_INVALID, "null argument");
+    *degree = 0;
+    if (!n) return ZKMI_OK;
+    unsigned long long* d;
+    ZK_TRY(ws_get("plonk.bad", 16, (void**)&d));
+    ZK_HIP(hipMemsetAsync(d, 0, 16, ctx().stream));
+    hipLaunchKernelGGL(k_poly_degree, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, (const uint32_t*)d_p, n, d);
+    unsigned long long h = 0;
+    ZK_HIP(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx().stream));
+    ZK_HIP(hipStreamSynchronize(ctx().stream));
+    *degree = (size_t)h;
+    return ZKMI_OK;
+}
+int zkmi_fflonk_t0_dev(int curve, const zkmi_plonk_evals* ev, uint32_t domain, uint32_t n_public, void* d_t0) {
+    if (!ev) return fail(ZKMI_ERR_INVALID, "null evaluations");
+    PLONK_DISPATCH(curve, fflonk_t0(ev, domain, n_public, d_t0));
+}
+int zkmi_fflonk_t1_dev(int curve, const void* d_z4, const void* d_lagrange, uint32_t domain, const uint8_t* b789, const uint8_t* w_2n, void* d_t1, void* d_t1z) {
+    PLONK_DISPATCH(curve, fflonk_t1(d_z4, d_lagrange, domain, b789, w_2n, d_t1, d_t1z));
+}
+int zkmi_fflonk_t2_dev(int curve, const zkmi_plonk_evals* ev, uint32_t domain, const uint8_t* b789, const uint8_t* beta, const uint8_t* gamma, const uint8_t* k1, const uint8_t* k2,
+                       const uint8_t* w_n, const uint8_t* w_4n, void* d_t2, void* d_t2z) {
+    if (!ev) return fail(ZKMI_ERR_INVALID, "null evaluations");
+    PLONK_DISPATCH(curve, fflonk_t2(ev, domain, b789, beta, gamma, k1, k2, w_n, w_4n, d_t2, d_t2z));
 }
 int zkmi_poly_div_zh_dev(int curve, void* d_p, size_t len, uint32_t domain, uint32_t extensions) { PLONK_DISPATCH(curve, div_zh(d_p, len, domain, extensions)); }
 int zkmi_poly_div_by_zerofier_dev(int curve, void* d_p, size_t len, uint32_t n, const uint8_t* beta) { PLONK_DISPATCH(curve, div_by_zerofier(d_p, len, n, beta)); }

@@ -223,3 +223,82 @@ def test_cpoly_interleave(env):
             if i * n + j < out_len:
                 want[i * n + j] = c
     assert _host(cx, out, out_len) == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,deg", [(1, 0), (1000, 999), (1000, 17), (70000, 65536), (4096, 0), (300, None)])
+def test_poly_degree(env, n, deg):
+    """Polynomial.degree (polynomial.js:165-172): index of the highest non-zero coefficient, 0 for the zero polynomial"""
+    zkmi, plonk, f, cx = env
+    p = [0] * n
+    if deg is not None:
+        for i, v in enumerate(_rand(9, deg + 1, cx.r)):
+            p[i] = v
+        p[deg] = p[deg] or 1
+    d, dp = C.c_size_t(77), _dev(zkmi, cx, p)
+    zkmi.check(zkmi.lib().zkmi_poly_degree_dev(0, dp.ptr, n, C.byref(d)))
+    assert d.value == (deg or 0) == P.degree(p)
+
+
+@pytest.mark.gpu
+def test_fflonk_quotient_kernels_vs_oracle(env, golden_dir):
+    """k_fflonk_t0/t1/t2 over the extended evaluation points == the restatement's T0, T1, T1z, T2, T2z (fflonk_prove.js:415-815)"""
+    import fflonk_oracle as FF
+    zkmi, plonk, f, cx = env
+    L = zkmi.lib()
+    tag = "fflonk_bn128_n256"
+    g = json.load(open(os.path.join(golden_dir, f"{tag}.json")))
+    zkey = open(os.path.join(golden_dir, f"{tag}.zkey"), "rb").read()
+    wtns = open(os.path.join(golden_dir, f"{tag}.wtns"), "rb").read()
+    blind = [bytes.fromhex(x) for x in g["blinding_mont"]]
+    st = {}
+    FF.fflonk_prove(zkey, wtns, blind, stages=st)
+    from snarkjs_amd import fflonk
+    key = fflonk.FflonkKey(zkey)
+    n = key.n
+    dv = {k: _dev(zkmi, cx, st[k]) for k in ("A", "eA", "eB", "eC", "eZ")}
+    ev = zkmi.PlonkEvals(dv["eA"].ptr, dv["eB"].ptr, dv["eC"].ptr, dv["eZ"].ptr, key.sec(9, n), key.sec(7, n), key.sec(8, n), key.sec(10, n), key.sec(11, n),
+                         key.sec(12, n), key.sec(13, n), key.sec(14, n), key.sec(15), dv["A"].ptr)
+    t0 = zkmi.DeviceBuffer(4 * n * 32)
+    zkmi.check(L.zkmi_fflonk_t0_dev(0, C.byref(ev), n, key.nPublic, t0.ptr))
+    assert _host(cx, t0, 4 * n) == st["T0"]
+    b = [f.unmont(x) for x in blind]
+    b789 = np.concatenate([f.mont(b[6]), f.mont(b[7]), f.mont(b[8])])
+    t1, t1z = zkmi.DeviceBuffer(2 * n * 32), zkmi.DeviceBuffer(2 * n * 32)
+    zkmi.check(L.zkmi_fflonk_t1_dev(0, dv["eZ"].ptr, key.sec(15), n, zkmi.ptr(b789), zkmi.ptr(f.root(key.power + 1)), t1.ptr, t1z.ptr))
+    assert _host(cx, t1, 2 * n) == st["T1"] and _host(cx, t1z, 2 * n) == st["T1z"]
+    t2, t2z = zkmi.DeviceBuffer(4 * n * 32), zkmi.DeviceBuffer(4 * n * 32)
+    mp = lambda v: zkmi.ptr(f.mont(v))
+    zkmi.check(L.zkmi_fflonk_t2_dev(0, C.byref(ev), n, zkmi.ptr(b789), mp(st["beta"]), mp(st["gamma"]), mp(key.k1), mp(key.k2), zkmi.ptr(f.root(key.power)),
+                                    zkmi.ptr(f.root(key.power + 2)), t2.ptr, t2z.ptr))
+    assert _host(cx, t2, 4 * n) == st["T2"] and _host(cx, t2z, 4 * n) == st["T2z"]
+    key.release()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["fflonk_bn128_small", "fflonk_bn128_n256"])
+def test_fflonk_golden_proof(env, golden_dir, tag):
+    """Device FFLONK prover == the reference's seeded proof (sha256 of the proof JSON), and == the oracle on fresh blinding."""
+    import fflonk_oracle as FF
+    from snarkjs_amd import fflonk
+    zkmi, plonk, f, cx = env
+    g = json.load(open(os.path.join(golden_dir, f"{tag}.json")))
+    zkey = open(os.path.join(golden_dir, f"{tag}.zkey"), "rb").read()
+    wtns = open(os.path.join(golden_dir, f"{tag}.wtns"), "rb").read()
+    blind = [bytes.fromhex(x) for x in g["blinding_mont"]]
+    res = fflonk.prove(zkey, wtns, blinding_mont=blind)
+    assert res["publicSignals"] == g["publicSignals"]
+    assert res["proof"] == g["proof"]
+    assert hashlib.sha256(json.dumps(res["proof"], separators=(",", ":")).encode()).hexdigest() == g["proof_sha256"]
+    with pytest.raises(ValueError):
+        fflonk.prove(zkey, wtns[:-32])
+    with pytest.raises(ValueError):
+        fflonk.prove(open(os.path.join(golden_dir, "plonk_bn128_small.zkey"), "rb").read(), wtns)
+    key = fflonk.FflonkKey(zkey)
+    blind2 = [bytes(f.mont(v)) for v in _rand(31, 9, cx.r)]
+    p2 = fflonk.prove(key, wtns, blinding_mont=blind2)
+    want, _ = FF.fflonk_prove(zkey, wtns, blind2)
+    assert p2["proof"] == want and p2["proof"] != g["proof"]
+    p3 = fflonk.prove(key, wtns)
+    key.release()
+    assert p3["publicSignals"] == g["publicSignals"] and p3["proof"]["polynomials"]["C1"] != g["proof"]["polynomials"]["C1"]
