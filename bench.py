@@ -48,10 +48,15 @@ def bench_plonk(args, rank, world, dist, torch):
     """BASELINE configs[3]: BN254 PLONK prove at 2^log_n constraints on a synthetic VALID key (tests/synth_plonk.py); one proof
     stream per GPU. The key is resident; each proof uploads its witness (32 MB at 2^20) — the reference reads it from a file."""
     import synth_plonk
-    from snarkjs_amd import plonk
+    from snarkjs_amd import fflonk, plonk
     lg = args.log_n
-    zkey, wtns = synth_plonk.make("bn128", lg, seed=3 + rank)
-    key = plonk.PlonkKey(zkey)
+    proto = args.workload
+    if proto == "fflonk":               # not a BASELINE config; same kernels, MSMs over 8n / 16n coefficients (SURVEY.md 2 row 5)
+        zkey, wtns = synth_plonk.make_fflonk(lg, seed=3 + rank)
+        key, plonk = fflonk.FflonkKey(zkey), fflonk
+    else:
+        zkey, wtns = synth_plonk.make("bn128", lg, seed=3 + rank)
+        key = plonk.PlonkKey(zkey)
 
     def barrier():
         if dist is not None:
@@ -71,10 +76,10 @@ def bench_plonk(args, rank, world, dist, torch):
         elapsed = float(t.item())
     if rank == 0:
         print(json.dumps({
-            "metric": "plonk_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+            "metric": f"{proto}_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"BN254 PLONK prove, 2^{lg} constraints, synthetic valid key (BASELINE configs[3]); key resident, witness uploaded per proof",
+            "config": {"workload": f"BN254 {proto.upper()} prove, 2^{lg} constraints, synthetic valid key" + (" (BASELINE configs[3])" if proto == "plonk" else "") + "; key resident, witness uploaded per proof",
                        "curve": "bn128", "log_n": lg, "parallelism": f"replica x{world}"},
             "public_signal": res["publicSignals"][0][:24] + "..."}), flush=True)
     if dist is not None:
@@ -92,7 +97,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--witness", default="uniform", choices=["uniform", "mixed"])
     ap.add_argument("--curve", default="bn128", choices=["bn128", "bls12381"])
-    ap.add_argument("--workload", default="groth16", choices=["groth16", "plonk"], help="plonk = BASELINE configs[3] (not the default metric)")
+    ap.add_argument("--workload", default="groth16", choices=["groth16", "plonk", "fflonk"], help="plonk = BASELINE configs[3] (not the default metric)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,7 +119,7 @@ def main():
     L = zkmi.lib()
 
     lg = args.log_n
-    if args.workload == "plonk":
+    if args.workload in ("plonk", "fflonk"):
         return bench_plonk(args, rank, world, dist, torch)
     zkey, wtns = synth_zkey.make(args.curve, lg, seed=0x5EED + rank, witness=args.witness)
     cid = 0 if args.curve == "bn128" else 1

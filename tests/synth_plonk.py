@@ -21,7 +21,8 @@ import numpy as np
 from synth_zkey import PRIMES, _binfile
 
 
-def make(name, lg, seed=7, tau=0x1F3D5B79):
+def _pieces(name, lg, seed, tau, n_srs, free_rows=0):
+    """everything both PLONK-family key layouts share: witness, signal maps, selector / sigma / Lagrange sections, SRS, commit()"""
     from snarkjs_amd import zkmi
     zkmi.init()
     L = zkmi.lib()
@@ -54,6 +55,8 @@ def make(name, lg, seed=7, tau=0x1F3D5B79):
     # ---- permutation: positions p = col*n + row, grouped by signal id, sigma = next position in the cycle
     sig = np.zeros((3, n), np.int64)
     sig[0, :nc], sig[1, :nc], sig[2, :nc] = map_a, map_b, map_c
+    for j in range(free_rows):                    # FFLONK: the last two rows carry blinding values, sigma = identity there (fflonk_setup.js:357-361)
+        sig[:, n - 1 - j] = -1 - 3 * j - np.arange(3)
     flat = sig.reshape(-1)
     order = np.argsort(flat, kind="stable")
     nxt = np.empty(3 * n, np.int64)
@@ -87,8 +90,8 @@ def make(name, lg, seed=7, tau=0x1F3D5B79):
         return d_out.to_host().tobytes() + d4.to_host().tobytes()
 
     # SRS: [tau^i] G1 (geometric table with f = 1, g = tau), and [tau] G2
-    d_srs = zkmi.DeviceBuffer((n + 6) * 2 * q8)
-    zkmi.check(L.zkmi_gen_geometric_bases_dev(cid, 1, n + 6, 1, tau, d_srs.ptr))
+    d_srs = zkmi.DeviceBuffer(n_srs * 2 * q8)
+    zkmi.check(L.zkmi_gen_geometric_bases_dev(cid, 1, n_srs, 1, tau, d_srs.ptr))
     d_g2 = zkmi.DeviceBuffer(2 * 4 * q8)
     zkmi.check(L.zkmi_gen_geometric_bases_dev(cid, 2, 2, 1, tau, d_g2.ptr))
     x2 = d_g2.to_host()[4 * q8:]
@@ -112,20 +115,65 @@ def make(name, lg, seed=7, tau=0x1F3D5B79):
                       (10, "Qo", const_rows(zero_m, mone_m)), (11, "Qc", const_rows(zero_m, zero_m))):
         secs[t] = section(ev)
         commits[nm] = commit()
-    sig_sec = b""
     for k, nm in enumerate(("S1", "S2", "S3")):
-        sig_sec += section(sigma_ev[k].reshape(-1))
+        secs[nm] = section(sigma_ev[k].reshape(-1))
         commits[nm] = commit()
-    secs[12] = sig_sec
     e0 = np.zeros((n, 32), np.uint8)
     e0[0] = np.frombuffer(one_m, np.uint8)
     secs[13] = section(e0.reshape(-1))            # Lagrange L_1 (nPublic = 1)
+    srs = d_srs.to_host().tobytes()
+
+    def commit_coefs(coef_bytes):                 # [p(tau)]_1 for any coefficient vector no longer than the SRS
+        k = len(coef_bytes) // 32
+        dc, ds = zkmi.DeviceBuffer.from_host(np.frombuffer(coef_bytes, np.uint8)), zkmi.DeviceBuffer(k * 32)
+        zkmi.check(L.zkmi_fr_batch_dev(cid, 1, dc.ptr, ds.ptr, k))
+        jac, aff = np.zeros(3 * q8, np.uint8), np.zeros(2 * q8, np.uint8)
+        zkmi.check(L.zkmi_msm_dev(cid, 1, d_srs.ptr, ds.ptr, k, 32, zkmi.ptr(jac)))
+        zkmi.check(L.zkmi_to_affine(cid, 1, zkmi.ptr(jac), zkmi.ptr(aff)))
+        dc.free(); ds.free()
+        return aff.tobytes()
+    out = dict(q8=q8, q=q, r=r, n=n, nc=nc, n_vars=n_vars, wt=wt, maps=(map_a, map_b, map_c), secs=secs, commits=commits, x2=x2.tobytes(), srs=srs,
+               k1=k1, k2=k2, mont=mont, commit_coefs=commit_coefs, free=lambda: [b.free() for b in (d_in, d_out, d4, d_srs, d_g2, d_sc)])
+    return out
+
+
+def make(name, lg, seed=7, tau=0x1F3D5B79):
+    """PLONK zkey (protocol id 2, src/zkey_utils.js:261-299) + wtns"""
+    P = _pieces(name, lg, seed, tau, (1 << lg) + 6)
+    q8, q, r, n, nc, secs, commits, mont = P["q8"], P["q"], P["r"], P["n"], P["nc"], P["secs"], P["commits"], P["mont"]
+    map_a, map_b, map_c = P["maps"]
     hdr = (struct.pack("<I", q8) + q.to_bytes(q8, "little") + struct.pack("<I", 32) + r.to_bytes(32, "little")
-           + struct.pack("<IIIII", n_vars, 1, n, 0, nc) + mont(k1) + mont(k2)
-           + b"".join(commits[nm] for nm in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3")) + x2.tobytes())
+           + struct.pack("<IIIII", P["n_vars"], 1, n, 0, nc) + mont(P["k1"]) + mont(P["k2"])
+           + b"".join(commits[nm] for nm in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3")) + P["x2"])
     zkey = _binfile(b"zkey", [(1, struct.pack("<I", 2)), (2, hdr), (3, b""), (4, map_a.astype("<u4").tobytes()), (5, map_b.astype("<u4").tobytes()),
-                              (6, map_c.astype("<u4").tobytes()), (7, secs[7]), (8, secs[8]), (9, secs[9]), (10, secs[10]), (11, secs[11]), (12, secs[12]),
-                              (13, secs[13]), (14, d_srs.to_host().tobytes())])
-    for b in (d_in, d_out, d4, d_srs, d_g2, d_sc):
-        b.free()
-    return zkey, wt
+                              (6, map_c.astype("<u4").tobytes()), (7, secs[7]), (8, secs[8]), (9, secs[9]), (10, secs[10]), (11, secs[11]),
+                              (12, secs["S1"] + secs["S2"] + secs["S3"]), (13, secs[13]), (14, P["srs"])])
+    P["free"]()
+    return zkey, P["wt"]
+
+
+def make_fflonk(lg, seed=7, tau=0x1F3D5B79):
+    """FFLONK zkey (protocol id 10; src/fflonk_setup.js:213-500, src/zkey_utils.js:301-339) + wtns for the same circuit. BN254 only
+    (the reference hard-codes w3 / wr for that field, fflonk_setup.js:525-547)."""
+    n = 1 << lg
+    P = _pieces("bn128", lg, seed, tau, 9 * n + 18, free_rows=2)
+    q8, q, r, nc, secs, mont = P["q8"], P["q"], P["r"], P["nc"], P["secs"], P["mont"]
+    map_a, map_b, map_c = P["maps"]
+    coef = lambda key: np.frombuffer(secs[key][:n * 32], np.uint8).reshape(n, 32)
+    # C0(X) = QL(X^8) + X QR(X^8) + X^2 QO(X^8) + X^3 QM(X^8) + X^4 QC(X^8) + X^5 S1(X^8) + X^6 S2(X^8) + X^7 S3(X^8)   (:441-458)
+    c0 = np.stack([coef(k) for k in (8, 9, 10, 7, 11, "S1", "S2", "S3")], axis=1).reshape(-1).tobytes()
+    w3 = pow(31624, 3648040478639879203707734290876212514758060733402672390616367364429301415936 // 3, r)   # computeW3 (:525-533)
+    w4, w8 = (np.zeros(32, np.uint8) for _ in range(2))
+    from snarkjs_amd import zkmi
+    zkmi.check(zkmi.lib().zkmi_fr_root(0, 2, zkmi.ptr(w4)))
+    zkmi.check(zkmi.lib().zkmi_fr_root(0, 3, zkmi.ptr(w8)))
+    wr = pow(467799165886069610036046866799264026481344299079011762026774533774345988080, 2 ** (28 - lg), r)
+    hdr = (struct.pack("<I", q8) + q.to_bytes(q8, "little") + struct.pack("<I", 32) + r.to_bytes(32, "little")
+           + struct.pack("<IIIII", P["n_vars"], 1, n, 0, nc) + mont(P["k1"]) + mont(P["k2"]) + mont(w3) + w4.tobytes() + w8.tobytes() + mont(wr)
+           + P["x2"] + P["commit_coefs"](c0))
+    # FFLONK section ids (src/fflonk_constants.js): 7 QL, 8 QR, 9 QM, 10 QO, 11 QC, 12-14 sigma, 15 Lagrange, 16 PTau, 17 C0
+    zkey = _binfile(b"zkey", [(1, struct.pack("<I", 10)), (2, hdr), (3, b""), (4, map_a.astype("<u4").tobytes()), (5, map_b.astype("<u4").tobytes()),
+                              (6, map_c.astype("<u4").tobytes()), (7, secs[8]), (8, secs[9]), (9, secs[7]), (10, secs[10]), (11, secs[11]),
+                              (12, secs["S1"]), (13, secs["S2"]), (14, secs["S3"]), (15, secs[13]), (16, P["srs"]), (17, c0)])
+    P["free"]()
+    return zkey, P["wt"]

