@@ -273,3 +273,55 @@ def test_msm_resident_tables(zk, name, group, lg):
         assert np.array_equal(O.to_affine(c, group, out), want), (k, sb)
     assert L.zkmi_msm_table_dev(h, d_s.ptr, n + 1, 32, zkmi.ptr(out)) != 0
     zkmi.check(L.zkmi_msm_table_release(h))
+
+
+@pytest.mark.parametrize("name,lg", [("bn128", 20), ("bls12381", 20)])
+def test_groth16_full_size_closed_form(zk, name, lg):
+    """BASELINE configs[1] at its full size (2^20 constraints), checked through a size-independent property: every base of the
+    synthetic key is a known multiple of the generator (7*11^i*G, tests/synth_zkey.py), so each proof point has a closed-form
+    discrete log — pi_a = a*G1, pi_b = b*G2, pi_c = c*G1 with a, b, c from O(n) field sums over the witness and the quotient
+    evaluations h (src/groth16_prove.js:103-128).  h comes from the CPU restatement's buildABC / NTT chain / joinABC; the five
+    2^20-term MSMs are never run on the CPU."""
+    import synth_zkey
+    from snarkjs_amd import groth16, binfile
+    c = O.CURVE_ID[name]
+    r = synth_zkey.PRIMES[name][2]
+    n_public = 2
+    zkey, wtns = synth_zkey.make(name, lg, seed=0xBEEF + lg, n_public=n_public)
+    zk_ = binfile.read_groth16_zkey(zkey)
+    w = binfile.read_wtns(wtns)["witness"]
+    n, m = zk_["domainSize"], zk_["nVars"]
+    r_m, s_m = O.fr_e(c, 0x1234567), O.fr_e(c, 0x7654321)
+    pk = groth16.ProvingKey(zkey)
+    pi_a, pi_b, pi_c = pk.prove_raw(w, r_m, s_m)
+    pk.release()
+    # h = odd-coset evaluations of (A*B - C) (:62-83)
+    A, B, Cc = O.build_abc(c, zk_["coeffs"], w, m, n)
+    one, inc = O.fr_one(c), O.fr_w(c, lg + 1)
+    A, B, Cc = (O.ntt(c, O.apply_key(c, O.ntt(c, x, inverse=True), one, inc)) for x in (A, B, Cc))
+    h = np.frombuffer(O.join_abc(c, A, B, Cc), "<u8").reshape(n, 4)      # joinABC already leaves normal form (:362)
+    wv = np.frombuffer(w, "<u8").reshape(m, 4)
+    to_int = lambda row: int(row[0]) | int(row[1]) << 64 | int(row[2]) << 128 | int(row[3]) << 192
+    rr, ss = 0x1234567, 0x7654321
+    d = lambda i: 7 * pow(11, i, r) % r                       # discrete log of T[i]
+    sa = sb = sc = sh = 0
+    g = 7                                                     # 7 * 11^i
+    for i in range(m):
+        wi = to_int(wv[i])
+        sa += wi * g
+        if i % 3 != 1:
+            sb += wi * g
+        if i > n_public:
+            sc += wi * g                                      # C_j = T1[2 + j], j = i - nPublic - 1: shift applied below
+        g = g * 11 % r
+    g = 7
+    for i in range(n):
+        sh += to_int(h[i]) * g
+        g = g * 11 % r
+    a = (d(5) + sa + rr * d(7)) % r                           # alpha1 = T1[5], A_i = T1[i], delta1 = T1[7]
+    b = (d(1) + sb + ss * d(2)) % r                           # beta2 = T2[1], B2_i = T2[i], delta2 = T2[2]
+    b1 = (d(6) + sb * 11 + ss * d(7)) % r                     # beta1 = T1[6], B1_i = T1[i + 1]
+    cc = (sc * pow(11, 2 - n_public - 1, r) + sh * pow(11, 3, r) + ss * a + rr * b1 - rr * ss % r * d(7)) % r
+    assert np.array_equal(pi_a, O.to_affine(c, 1, O.generator_mul(c, 1, a)))
+    assert np.array_equal(pi_b, O.to_affine(c, 2, O.generator_mul(c, 2, b)))
+    assert np.array_equal(pi_c, O.to_affine(c, 1, O.generator_mul(c, 1, cc)))
