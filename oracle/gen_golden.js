@@ -185,13 +185,17 @@ async function plonkGolden() {
         const { proof, publicSignals } = await snarkjs.plonk.prove(z.data, w.data);
         for (const [o, nm, f] of undo) o[nm] = f; Fr.random = origRandom;
         const vk = await snarkjs.zKey.exportVerificationKey(z.data);
-        const ok = await snarkjs.plonk.verify(vk, publicSignals, proof);
+        // the verifier's own intermediate values (src/plonk_verify.js:62-105 logs them at debug level): they pin the restatement
+        // oracle/plonk_verify_oracle.py up to, but excluding, the final pairing
+        const verify_trace = [];
+        const vlog = { debug: (m) => verify_trace.push(m), info() {}, warn() {}, error() {} };
+        const ok = await snarkjs.plonk.verify(vk, publicSignals, proof, vlog);
         if (!ok) throw new Error('golden plonk proof does not verify');
         fs.writeFileSync(path.join(OUT, `${tag}.zkey`), z.data);
         fs.writeFileSync(path.join(OUT, `${tag}.wtns`), w.data);
         fs.writeFileSync(path.join(OUT, `${tag}.json`), JSON.stringify({
             zkey_sha256: sha(z.data), wtns_sha256: sha(w.data), proof_sha256: sha(JSON.stringify(proof)), blinding_mont: rnd, proof, publicSignals,
-            verified: ok, vk, census }, null, 1));
+            verified: ok, vk, verify_trace, census }, null, 1));
         console.log(tag, 'plonk golden done: zkey', z.data.length, 'bytes, proof sha', sha(JSON.stringify(proof)), 'verify', ok);
     }
 }

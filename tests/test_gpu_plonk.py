@@ -341,3 +341,24 @@ def test_synthetic_fflonk_2p16_self_consistent(env):
     for k in ("ql", "qr", "qm", "qo", "qc", "s1", "s2", "s3"):      # circuit-only evaluations depend on xi only through the transcript
         assert p1["proof"]["evaluations"][k] != "0" or k in ("qr", "qc")
     assert p1["proof"]["polynomials"]["C1"] != p2["proof"]["polynomials"]["C1"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lg", [12, 20])
+def test_plonk_full_size_proof_verifies(env, lg):
+    """BASELINE configs[3] at its full size (2^20 constraints): the device proof VERIFIES.  The verifier is the restatement of
+    src/plonk_verify.js pinned to the reference's own verifier trace (test_plonk_verifier_trace); the synthetic key has a known
+    toy tau, so the final pairing is the G1 identity B1 == tau * A1 (oracle/plonk_verify_oracle.py)."""
+    import plonk_verify_oracle as V
+    import synth_plonk
+    zkmi, plonk, f, cx = env
+    tau = 0x1F3D5B79
+    zkey, wtns = synth_plonk.make("bn128", lg, seed=11, tau=tau)
+    res = plonk.prove(zkey, wtns)
+    vk = V.vk_from_zkey(zkey)
+    assert V.verify_known_tau(vk, res["publicSignals"], res["proof"], tau)
+    # soundness of the check itself: a wrong tau, a tampered evaluation and a tampered public signal must all be rejected
+    assert not V.verify_known_tau(vk, res["publicSignals"], res["proof"], tau + 1)
+    bad = dict(res["proof"]); bad["eval_a"] = str((int(bad["eval_a"]) + 1) % cx.r)
+    assert not V.verify_known_tau(vk, res["publicSignals"], bad, tau)
+    assert not V.verify_known_tau(vk, [str((int(res["publicSignals"][0]) + 1) % cx.r)], res["proof"], tau)

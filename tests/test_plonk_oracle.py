@@ -44,3 +44,30 @@ def test_fflonk_golden_proof(golden_dir, tag):
     assert public == g["publicSignals"]
     assert proof == g["proof"]
     assert hashlib.sha256(json.dumps(proof, separators=(",", ":")).encode()).hexdigest() == g["proof_sha256"]
+
+
+@pytest.mark.parametrize("tag", ["plonk_bn128_small", "plonk_bn128_n2048"])
+def test_plonk_verifier_trace(golden_dir, tag):
+    """The verifier restatement (oracle/plonk_verify_oracle.py) reproduces every intermediate value the reference's plonk.verify
+    logs for its own seeded proofs (challenges, L_i(xi), PI(xi), r0 and the points D, F, E)."""
+    import re
+    import plonk_verify_oracle as V
+    g, zkey, wtns = load(golden_dir, tag)
+    val = V.verifier_values(g["vk"], g["publicSignals"], g["proof"])
+    want = {}
+    for line in g["verify_trace"]:
+        m = re.match(r"(\w+)(?:\(xi\))?[:=] ?(.*)", line)
+        want.setdefault(m.group(1), []).append(m.group(2))
+    sc = lambda s: int(s, 16)
+    pt = lambda s: tuple(int(x, 16) for x in re.findall(r"[0-9a-f]+", s))
+    for k in ("beta", "gamma", "alpha", "xi", "u", "r0"):
+        assert val[k] == sc(want[k][0]), k
+    assert val["v"][1:] == [sc(x) for x in want["v"]]
+    assert val["L"][1:] == [sc(want[f"L{i}"][0]) for i in range(1, len(val["L"]))]
+    assert val["pi"] == sc(want["PI"][0])
+    for k in ("D", "F", "E"):
+        assert val[k] == pt(want[k][0]), k
+    # the verification key the reference exported == the one read from the zkey header
+    vk = V.vk_from_zkey(zkey)
+    for k, v in vk.items():
+        assert g["vk"][k] == v or str(g["vk"][k]) == str(v), k
