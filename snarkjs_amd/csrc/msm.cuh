@@ -173,6 +173,141 @@ template <int NW> __global__ void k_msm_scatter(const uint8_t* __restrict__ scal
     });
 }
 
+// ---- two-level LDS radix partition (large MSMs) -----------------------------------------------------------------------
+// The counting sort above issues one GLOBAL atomic per (scalar, digit) twice (count, scatter): 2 x 13.6M atomics per 2^20-term MSM
+// with window tables, ~1.3 ms. For large inputs the same lists are built with LDS atomics only, in two passes over the flat key
+// g = window*nb + (mag-1) (window = 0 with tables):
+//   level 1  partition by g >> 11: per-block LDS histograms (k_rsort_hist1), one flat scan, block-local ranking (k_rsort_scatter1)
+//            into an intermediate array of (entry, g & 2047) pairs;
+//   level 2  every partition is cut into chunks of <= RSORT_CHUNK pairs (k_rsort_chunks); per-chunk LDS histogram over the 2048
+//            low keys (k_rsort_hist2), per-partition scan over chunks and bins (k_rsort_scan2: this also produces counts[] and
+//            starts[]), per-chunk ranking into the final lists (k_rsort_scatter2).
+// Any distribution works: a partition that receives most of the entries (real witnesses: digit 1 of window 0) simply gets many
+// chunks. The order inside a bucket is arbitrary (as with the atomic version); bucket sums do not depend on it.
+constexpr int RSORT_LOW_BITS = 11;
+constexpr uint32_t RSORT_BINS = 1u << RSORT_LOW_BITS;
+constexpr uint32_t RSORT_TILE = 1024;            // scalars per level-1 block (256 threads x 4)
+constexpr uint32_t RSORT_CHUNK = 8192;           // pairs per level-2 block
+constexpr uint32_t RSORT_MAX_PARTS = 4096;
+
+template <int NW, class Fn> ZK_DEV void rsort_tile_digits(const uint8_t* __restrict__ scalars, const MsmShape& sh, const uint32_t* __restrict__ dropmask, Fn f) {
+#pragma unroll 1
+    for (uint32_t j = 0; j < RSORT_TILE / 256; j++) {
+        const size_t i = (size_t)blockIdx.x * RSORT_TILE + j * 256 + threadIdx.x;
+        if (i >= sh.n) break;
+        if (dropmask && ((dropmask[i >> 5] >> (i & 31)) & 1u)) continue;
+        uint32_t s[NW];
+        load_scalar<NW>(s, scalars, i, sh.sb);
+        for_each_digit<NW>(s, sh.c, sh.Wd, [&](int w, uint32_t mag, bool neg) {
+            const uint32_t g = (sh.precomp ? 0u : (uint32_t)w * sh.nb) + (mag - 1);
+            const uint32_t ent = (sh.precomp ? (uint32_t)w * sh.stride + (uint32_t)i : (uint32_t)i) | (neg ? 0x80000000u : 0u);
+            f(g, ent);
+        });
+    }
+}
+// bh[p * nblk + blk] = entries of block blk that fall into partition p
+template <int NW> __global__ void __launch_bounds__(256)
+k_rsort_hist1(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ dropmask, uint32_t nparts, uint32_t* __restrict__ bh) {
+    __shared__ uint32_t h[RSORT_MAX_PARTS];
+    for (uint32_t p = threadIdx.x; p < nparts; p += 256) h[p] = 0;
+    __syncthreads();
+    rsort_tile_digits<NW>(scalars, sh, dropmask, [&](uint32_t g, uint32_t) { atomicAdd(&h[g >> RSORT_LOW_BITS], 1u); });
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < nparts; p += 256) bh[(size_t)p * gridDim.x + blockIdx.x] = h[p];
+}
+template <int NW> __global__ void __launch_bounds__(256)
+k_rsort_scatter1(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ dropmask, uint32_t nparts, const uint32_t* __restrict__ bhoff, uint2* __restrict__ tmp) {
+    __shared__ uint32_t cur[RSORT_MAX_PARTS];
+    for (uint32_t p = threadIdx.x; p < nparts; p += 256) cur[p] = bhoff[(size_t)p * gridDim.x + blockIdx.x];
+    __syncthreads();
+    rsort_tile_digits<NW>(scalars, sh, dropmask, [&](uint32_t g, uint32_t ent) {
+        const uint32_t pos = atomicAdd(&cur[g >> RSORT_LOW_BITS], 1u);
+        tmp[pos] = make_uint2(ent, g & (RSORT_BINS - 1));
+    });
+}
+// chunk table: chunks[3k..3k+2] = (partition, first pair, number of pairs); meta[0] = number of chunks. One block.
+static __global__ void __launch_bounds__(1024)
+k_rsort_chunks(const uint32_t* __restrict__ bhoff, uint32_t nparts, uint32_t nblk, uint32_t* __restrict__ pchunk0, uint32_t* __restrict__ chunks, uint32_t* __restrict__ meta) {
+    __shared__ uint32_t sc[1024];
+    uint32_t carry = 0;
+    for (uint32_t p0 = 0; p0 < nparts; p0 += 1024) {
+        const uint32_t p = p0 + threadIdx.x;
+        uint32_t start = 0, size = 0;
+        if (p < nparts) { start = bhoff[(size_t)p * nblk]; size = bhoff[(size_t)(p + 1) * nblk] - start; }
+        const uint32_t nch = (size + RSORT_CHUNK - 1) / RSORT_CHUNK;
+        sc[threadIdx.x] = nch;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            uint32_t t = threadIdx.x >= d ? sc[threadIdx.x - d] : 0u;
+            __syncthreads();
+            sc[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t c0 = carry + sc[threadIdx.x] - nch;
+        if (p < nparts) {
+            pchunk0[p] = c0;
+            for (uint32_t k = 0; k < nch; k++) {
+                chunks[3 * (c0 + k)] = p; chunks[3 * (c0 + k) + 1] = start + k * RSORT_CHUNK;
+                chunks[3 * (c0 + k) + 2] = min(RSORT_CHUNK, size - k * RSORT_CHUNK);
+            }
+        }
+        const uint32_t tot = sc[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { pchunk0[nparts] = carry; meta[0] = carry; }
+}
+static __global__ void __launch_bounds__(256)
+k_rsort_hist2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ chunks, const uint32_t* __restrict__ meta, uint32_t* __restrict__ h2) {
+    if (blockIdx.x >= meta[0]) return;
+    __shared__ uint32_t h[RSORT_BINS];
+    for (uint32_t b = threadIdx.x; b < RSORT_BINS; b += 256) h[b] = 0;
+    __syncthreads();
+    const uint32_t first = chunks[3 * blockIdx.x + 1], len = chunks[3 * blockIdx.x + 2];
+    for (uint32_t j = threadIdx.x; j < len; j += 256) atomicAdd(&h[tmp[first + j].y], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < RSORT_BINS; b += 256) h2[(size_t)blockIdx.x * RSORT_BINS + b] = h[b];
+}
+// one block per partition: h2[chunk][bin] <- exclusive prefix over the partition's chunks; counts / starts of the partition's buckets
+static __global__ void __launch_bounds__(1024)
+k_rsort_scan2(const uint32_t* __restrict__ bhoff, uint32_t nblk, const uint32_t* __restrict__ pchunk0, uint32_t* __restrict__ h2, uint32_t* __restrict__ counts, uint32_t* __restrict__ starts) {
+    __shared__ uint32_t sc[1024];
+    const uint32_t p = blockIdx.x, c0 = pchunk0[p], c1 = pchunk0[p + 1];
+    const uint32_t b0 = 2 * threadIdx.x;                 // two adjacent bins per thread
+    uint32_t r0 = 0, r1 = 0;
+    for (uint32_t k = c0; k < c1; k++) {
+        uint2* q = reinterpret_cast<uint2*>(h2 + (size_t)k * RSORT_BINS + b0);
+        const uint2 t = *q;
+        *q = make_uint2(r0, r1);
+        r0 += t.x; r1 += t.y;
+    }
+    sc[threadIdx.x] = r0 + r1;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t t = threadIdx.x >= d ? sc[threadIdx.x - d] : 0u;
+        __syncthreads();
+        sc[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const uint32_t base = bhoff[(size_t)p * nblk] + sc[threadIdx.x] - (r0 + r1);
+    const size_t g = (size_t)p * RSORT_BINS + b0;
+    counts[g] = r0; counts[g + 1] = r1;
+    starts[g] = base; starts[g + 1] = base + r0;
+}
+static __global__ void __launch_bounds__(256)
+k_rsort_scatter2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ chunks, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ h2,
+                 const uint32_t* __restrict__ starts, uint32_t* __restrict__ sorted) {
+    if (blockIdx.x >= meta[0]) return;
+    __shared__ uint32_t cur[RSORT_BINS];
+    const uint32_t p = chunks[3 * blockIdx.x], first = chunks[3 * blockIdx.x + 1], len = chunks[3 * blockIdx.x + 2];
+    for (uint32_t b = threadIdx.x; b < RSORT_BINS; b += 256) cur[b] = starts[(size_t)p * RSORT_BINS + b] + h2[(size_t)blockIdx.x * RSORT_BINS + b];
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < len; j += 256) {
+        const uint2 e = tmp[first + j];
+        sorted[atomicAdd(&cur[e.y], 1u)] = e.x;
+    }
+}
+
 // ---- bucket accumulation: load-balanced lane groups ---------------------------------------------------------------
 // A bucket with cnt points gets L lanes: L = 1 while cnt < 2*cap, else L = 2^j with j = floor(log2(cnt/cap)) (so every
 // lane adds < 2*cap points).  Buckets are ordered by a key (descending): multi-lane groups first (largest first, so a

@@ -17,6 +17,40 @@ template <int NW> static int msm_launch_digits(const uint8_t* d_scalars, const M
     return ZKMI_OK;
 }
 
+// Two-level LDS radix partition (msm.cuh: k_rsort_*): same outputs (counts, starts, sorted) without global atomics.
+template <int NW> static int msm_launch_digits_radix(const uint8_t* d_scalars, const MsmShape& sh, uint32_t* counts, uint32_t* starts, uint32_t* sorted,
+                                                     const uint32_t* dropmask, hipStream_t st) {
+    const uint32_t total = (uint32_t)sh.W * sh.nb, P = total >> RSORT_LOW_BITS;
+    const uint32_t nblk = (uint32_t)((sh.n + RSORT_TILE - 1) / RSORT_TILE);
+    const size_t nbh = (size_t)P * nblk + 1, emax = (size_t)sh.Wd * sh.n, nch_max = emax / RSORT_CHUNK + P + 1;
+    uint32_t *bh, *part, *ck, *h2;
+    uint2* tmp;
+    ZK_TRY(ws_get("msm.rs_bh", 2 * nbh * 4, (void**)&bh));
+    uint32_t* bhoff = bh + nbh;
+    const uint32_t nsp = (uint32_t)((nbh + MSM_SCAN_CHUNK - 1) / MSM_SCAN_CHUNK);
+    ZK_TRY(ws_get("msm.rs_part", ((size_t)nsp + 2) * 4, (void**)&part));
+    ZK_TRY(ws_get("msm.rs_tmp", emax * 8, (void**)&tmp));
+    ZK_TRY(ws_get("msm.rs_chunks", (3 * nch_max + P + 2 + 4) * 4, (void**)&ck));
+    uint32_t *pchunk0 = ck + 3 * nch_max, *meta = pchunk0 + P + 2;
+    ZK_TRY(ws_get("msm.rs_h2", nch_max * RSORT_BINS * 4, (void**)&h2));
+    ZK_HIP(hipMemsetAsync(bh + nbh - 1, 0, 4, st));
+    hipLaunchKernelGGL((k_rsort_hist1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, bh);
+    hipLaunchKernelGGL(k_msm_scan_sums, dim3(nsp), dim3(256), 0, st, bh, (uint32_t)nbh, part);
+    hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, st, part, nsp);
+    hipLaunchKernelGGL(k_msm_scan_final, dim3(nsp), dim3(256), 0, st, bh, (uint32_t)nbh, part, bhoff);
+    hipLaunchKernelGGL((k_rsort_scatter1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, bhoff, tmp);
+    hipLaunchKernelGGL(k_rsort_chunks, dim3(1), dim3(1024), 0, st, bhoff, P, nblk, pchunk0, ck, meta);
+    hipLaunchKernelGGL(k_rsort_hist2, dim3((unsigned)nch_max), dim3(256), 0, st, tmp, ck, meta, h2);
+    hipLaunchKernelGGL(k_rsort_scan2, dim3(P), dim3(1024), 0, st, bhoff, nblk, pchunk0, h2, counts, starts);
+    hipLaunchKernelGGL(k_rsort_scatter2, dim3((unsigned)nch_max), dim3(256), 0, st, tmp, ck, meta, h2, starts, sorted);
+    return ZKMI_OK;
+}
+static bool msm_use_radix(const MsmShape& sh) {
+    static const bool on = !(getenv("ZKMI_RSORT") && atoi(getenv("ZKMI_RSORT")) == 0);
+    const size_t total = (size_t)sh.W * sh.nb;
+    return on && sh.c > RSORT_LOW_BITS && (total >> RSORT_LOW_BITS) <= RSORT_MAX_PARTS && (size_t)sh.Wd * sh.n >= (1u << 17);
+}
+
 int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_slot, int precomp_c, size_t table_stride, const uint32_t* d_dropmask) {
     Ctx& cx = ctx();
     pl.slot = plan_slot;
@@ -57,14 +91,20 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     ZK_TRY(ws_get("msm.hist" + sfx, (3 * MSM_NKEYS + 8 + 3 * giant_bound) * 4, (void**)&hist));     // hist | off | cursor | meta | giants
     uint32_t *koff = hist + MSM_NKEYS, *kcur = koff + MSM_NKEYS;
     pl.meta = kcur + MSM_NKEYS; pl.giants = pl.meta + 8;
-    ZK_HIP(hipMemsetAsync(counts, 0, 3 * total * 4, st));
     ZK_HIP(hipMemsetAsync(hist, 0, (3 * MSM_NKEYS + 8) * 4, st));
     const uint8_t* sc = (const uint8_t*)d_scalars;
     uint32_t* part;
     ZK_TRY(ws_get("msm.scanpart" + sfx, (total / MSM_SCAN_CHUNK + 2) * 4, (void**)&part));
+    if (msm_use_radix(sh)) {
+        if (sb <= 4) { ZK_TRY(msm_launch_digits_radix<1>(sc, sh, pl.counts, pl.starts, pl.sorted, d_dropmask, st)); }
+        else if (sb <= 32) { ZK_TRY(msm_launch_digits_radix<8>(sc, sh, pl.counts, pl.starts, pl.sorted, d_dropmask, st)); }
+        else { ZK_TRY(msm_launch_digits_radix<16>(sc, sh, pl.counts, pl.starts, pl.sorted, d_dropmask, st)); }
+    } else {
+    ZK_HIP(hipMemsetAsync(counts, 0, 3 * total * 4, st));
     if (sb <= 4) msm_launch_digits<1>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, d_dropmask, st);
     else if (sb <= 32) msm_launch_digits<8>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, d_dropmask, st);
     else msm_launch_digits<16>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, d_dropmask, st);
+    }
     const unsigned tb = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(k_msm_classify, dim3(tb), dim3(256), 0, st, pl.counts, (uint32_t)total, cap, hist);
     hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(64), 0, st, hist, koff, pl.meta, cap);
