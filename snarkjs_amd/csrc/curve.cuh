@@ -42,19 +42,28 @@ template <class C> ZK_DEV void f_set_one(Fp2<C>& a) { a.c0 = fp_one<C>(); a.c1 =
 #ifndef ZKMI_FP2_NOINLINE
 #define ZKMI_FP2_NOINLINE 1
 #endif
-#if ZKMI_FP2_NOINLINE
+#if ZKMI_FP2_NOINLINE == 1
 template <class C> __device__ __noinline__ Fp<C> fp2_base_mul(Fp<C> a, Fp<C> b) { return fp_mul(a, b); }
 #else
 template <class C> ZK_DEV Fp<C> fp2_base_mul(const Fp<C>& a, const Fp<C>& b) { return fp_mul(a, b); }
 #endif
+#if ZKMI_FP2_NOINLINE == 2
+// the call boundary sits at the Fq2 operation: 32 argument registers in, 16 out, the Karatsuba partial products never live
+// across a call (the caller's live set across any call of a mixed addition is <= 4 Fq2 values: fits the callee-saved VGPRs)
+#define ZK_FP2_OP __device__ __noinline__
+#define ZK_FP2_ARG(T) T
+#else
+#define ZK_FP2_OP ZK_DEV
+#define ZK_FP2_ARG(T) const T&
+#endif
 // Karatsuba: 3 base-field multiplications
-template <class C> ZK_DEV Fp2<C> f_mul(const Fp2<C>& a, const Fp2<C>& b) {
+template <class C> ZK_FP2_OP Fp2<C> f_mul(ZK_FP2_ARG(Fp2<C>) a, ZK_FP2_ARG(Fp2<C>) b) {
     Fp<C> t0 = fp2_base_mul(a.c0, b.c0), t1 = fp2_base_mul(a.c1, b.c1);
     Fp<C> t2 = fp2_base_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
     return Fp2<C>{fp_sub(t0, t1), fp_sub(fp_sub(t2, t0), t1)};
 }
 // (a0+a1)(a0-a1) + 2 a0 a1 u : 2 multiplications
-template <class C> ZK_DEV Fp2<C> f_sqr(const Fp2<C>& a) {
+template <class C> ZK_FP2_OP Fp2<C> f_sqr(ZK_FP2_ARG(Fp2<C>) a) {
     Fp<C> t = fp2_base_mul(a.c0, a.c1);
     return Fp2<C>{fp2_base_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
 }

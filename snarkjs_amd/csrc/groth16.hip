@@ -249,6 +249,32 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     const uint32_t n = K.domain;
     const host::HField<4> Fr = host::HField<4>::from_cfg<FrC>();
     const uint32_t* w = (const uint32_t*)d_witness;
+    // The three digit sorts (witness without the B-infinity entries, witness, H scalars) are LDS/latency-bound; the NTT chain and
+    // the bucket accumulations are ALU-bound. With ZKMI_OVERLAP (default) the sorts run on the auxiliary stream underneath them
+    // and the main stream only waits on their events. ZKMI_OVERLAP=0 keeps everything on one stream.
+    static const bool ov = !(getenv("ZKMI_OVERLAP") && atoi(getenv("ZKMI_OVERLAP")) == 0);
+    MsmPlan pl, plh, plb;
+    MsmJob job[5];
+    for (int i = 0; i < 5; i++) ZK_TRY(msm_job_slot(i, job[i]));
+    // Two digit sorts of the witness: one without the entries whose B bases are at infinity (feeds B2 and B1), one complete
+    // (feeds A and C). The second sort pays for itself once ~10 % of the B bases are at infinity.
+    const bool split_b = K.b_density < 0.9;
+    MsmJob* g2[1] = {&job[2]};
+    hipStream_t aux = nullptr;
+    if (ov) {
+        ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 0, true));        // njobs = 0: only creates the auxiliary stream
+        aux = cx.aux_stream;
+        if (!cx.sort_ev[0]) for (int i = 0; i < 5; i++) ZK_HIP(hipEventCreateWithFlags(&cx.sort_ev[i], hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(cx.sort_ev[0], st));                   // the witness upload (if any) is ordered before this point
+        ZK_HIP(hipStreamWaitEvent(aux, cx.sort_ev[0], 0));
+        cx.stream = aux;
+        int rc = msm_sort(d_witness, K.n_vars, 32, split_b ? plb : pl, split_b ? 2 : 0, K.cw, 0, split_b ? K.drop_b : nullptr);
+        if (!rc) rc = hipEventRecord(cx.sort_ev[1], aux) == hipSuccess ? 0 : fail(ZKMI_ERR_HIP, "hipEventRecord");
+        if (!rc && split_b) rc = msm_sort(d_witness, K.n_vars, 32, pl, 0, K.cw);
+        if (!rc) rc = hipEventRecord(cx.sort_ev[2], aux) == hipSuccess ? 0 : fail(ZKMI_ERR_HIP, "hipEventRecord");
+        cx.stream = st;
+        ZK_TRY(rc);
+    }
     ZK_HIP(hipEventRecord(K.ev[ST_BUILD], st));
     hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, w, n, K.A, K.B, K.C);
     ZK_HIP(hipEventRecord(K.ev[ST_NTT], st));
@@ -264,37 +290,38 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     ZK_HIP(hipEventRecord(K.ev[ST_JOIN], st));
     ZK_TRY(join_abc_dev_dispatch(K.curve, K.A, K.B, K.C, K.T, n));          // T = H-MSM scalars (normal form)
     ZK_HIP(hipEventRecord(K.ev[ST_SORT_W], st));
-    MsmPlan pl, plh;
-    MsmJob job[5];
-    for (int i = 0; i < 5; i++) ZK_TRY(msm_job_slot(i, job[i]));
-    // Two digit sorts of the witness: one without the entries whose B bases are at infinity (feeds B2 and B1), one complete
-    // (feeds A and C). The second sort pays for itself once ~10 % of the B bases are at infinity.
-    const bool split_b = K.b_density < 0.9;
-    MsmPlan plb;
-    ZK_TRY(msm_sort(d_witness, K.n_vars, 32, split_b ? plb : pl, split_b ? 2 : 0, K.cw, 0, split_b ? K.drop_b : nullptr));
+    if (ov) {
+        ZK_HIP(hipEventRecord(cx.sort_ev[3], st));
+        ZK_HIP(hipStreamWaitEvent(aux, cx.sort_ev[3], 0));
+        cx.stream = aux;
+        int rc = msm_sort(K.T, n, 32, plh, 1, K.ch);
+        if (!rc) rc = hipEventRecord(cx.sort_ev[4], aux) == hipSuccess ? 0 : fail(ZKMI_ERR_HIP, "hipEventRecord");
+        cx.stream = st;
+        ZK_TRY(rc);
+        ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[1], 0));
+    } else ZK_TRY(msm_sort(d_witness, K.n_vars, 32, split_b ? plb : pl, split_b ? 2 : 0, K.cw, 0, split_b ? K.drop_b : nullptr));
     const MsmPlan& pB = split_b ? plb : pl;
     // The G2 MSM goes first: its bucket reduction is pure latency (~50 us per Fq2 point addition, little parallel work), so it
-    // runs on the auxiliary stream underneath the G1 accumulations (ZKMI_OVERLAP=0 keeps everything on one stream).
-    static const bool ov = !(getenv("ZKMI_OVERLAP") && atoi(getenv("ZKMI_OVERLAP")) == 0);
-    MsmJob* g2[1] = {&job[2]};
+    // also runs on the auxiliary stream, underneath the G1 accumulations.
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_B2], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 2, K.bB2, pB, 0, job[2], K.mask[2]));
     if (ov) {
-        ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 0, true));        // njobs = 0: only creates the auxiliary stream
         ZK_HIP(hipEventRecord(cx.aux_ev[0], st));
-        ZK_HIP(hipStreamWaitEvent(cx.aux_stream, cx.aux_ev[0], 0));
+        ZK_HIP(hipStreamWaitEvent(aux, cx.aux_ev[0], 0));
         ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1, true));
-        ZK_HIP(hipEventRecord(cx.aux_ev[1], cx.aux_stream));
+        ZK_HIP(hipEventRecord(cx.aux_ev[1], aux));
     }
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_B1], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bB1, pB, 0, job[1], K.mask[1]));
-    if (split_b) ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl, 0, K.cw));
+    if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[2], 0));
+    else if (split_b) ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl, 0, K.cw));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_A], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bA, pl, 0, job[0], K.mask[0]));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_C], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.c_skip, job[3], K.mask[3]));
     ZK_HIP(hipEventRecord(K.ev[ST_SORT_H], st));
-    ZK_TRY(msm_sort(K.T, n, 32, plh, 1, K.ch));
+    if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[4], 0));
+    else ZK_TRY(msm_sort(K.T, n, 32, plh, 1, K.ch));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_H], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, plh, 0, job[4], K.mask[4]));
     ZK_HIP(hipEventRecord(K.ev[ST_REDUCE], st));
@@ -305,13 +332,14 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     if (!ov) ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1));
     ZK_HIP(hipEventRecord(K.ev[ST_COUNT], st));
     ZK_HIP(hipStreamSynchronize(st));
-    if (ov) ZK_HIP(hipStreamSynchronize(cx.aux_stream));
     ZK_HIP(hipGetLastError());
     for (int i = 0; i < ST_COUNT; i++) { float ms = 0; if (hipEventElapsedTime(&ms, K.ev[i], K.ev[i + 1]) == hipSuccess) K.stage_ms[i] = ms; }
+    // the host folds of the G1 jobs run while the G2 reduction may still be finishing on the auxiliary stream
     uint8_t jA[144], jB1[144], jB2[288], jC[144], jH[144];
     ZK_TRY(msm_fold_dispatch(K.curve, 1, job[0], jA)); ZK_TRY(msm_fold_dispatch(K.curve, 1, job[1], jB1));
-    ZK_TRY(msm_fold_dispatch(K.curve, 2, job[2], jB2)); ZK_TRY(msm_fold_dispatch(K.curve, 1, job[3], jC));
-    ZK_TRY(msm_fold_dispatch(K.curve, 1, job[4], jH));
+    ZK_TRY(msm_fold_dispatch(K.curve, 1, job[3], jC)); ZK_TRY(msm_fold_dispatch(K.curve, 1, job[4], jH));
+    if (ov) ZK_HIP(hipStreamSynchronize(cx.aux_stream));
+    ZK_TRY(msm_fold_dispatch(K.curve, 2, job[2], jB2));
     if (K.curve == ZKMI_CURVE_BN128) g16_finish<Fp<Bn254Fq>, Fp2<Bn254Fq>, Bn254Fr>(K, jA, jB1, jB2, jC, jH, r_mont, s_mont, pi_a, pi_b, pi_c);
     else g16_finish<Fp<Bls12381Fq>, Fp2<Bls12381Fq>, Bls12381Fr>(K, jA, jB1, jB2, jC, jH, r_mont, s_mont, pi_a, pi_b, pi_c);
     return ZKMI_OK;

@@ -444,47 +444,56 @@ k_msm_tree(const uint32_t* __restrict__ lane_partials, const uint32_t* __restric
     constexpr int PW = 4 * FieldWords<F>::value;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t jmax_s;
-    const uint32_t t = threadIdx.x, lane = blockIdx.x * TB + t, multi = meta[1];
-    if (blockIdx.x * TB >= multi) return;
-    XYZZ<F> acc;
-    uint32_t j = 0, g = 0;
-    if (lane < multi) {
-        g = lane_g[lane];
-        j = msm_key_lanes_log(msm_key(counts[g], cap), cap);
-        pt_load(acc, lane_partials + (size_t)lane * PW);
-    } else pt_set_inf(acc);
-    if (t == 0) jmax_s = j;
-    pt_store(lds + t * PW, acc);
-    __syncthreads();
-    constexpr uint32_t LOG_TB = (TB == 256) ? 8 : (TB == 128 ? 7 : 6);
-    const uint32_t steps = min(jmax_s, LOG_TB);
-    for (uint32_t s = 0; s < steps; s++) {
-        const bool act = ((t & ((2u << s) - 1)) == 0) && (s < j);
-        if (act) { XYZZ<F> o; pt_load(o, lds + (t + (1u << s)) * PW); acc = pt_add(acc, o); }
+    // persistent blocks: the grid is a fixed few hundred blocks that stride over the tree blocks actually in use (none at all for
+    // uniformly distributed scalars) — a grid sized for the worst case costs ~100 us of wave launches with scratch set-up
+    const uint32_t t = threadIdx.x, multi = meta[1];
+    for (uint32_t blk = blockIdx.x; blk * TB < multi; blk += gridDim.x) {
+        const uint32_t lane = blk * TB + t;
+        XYZZ<F> acc;
+        uint32_t j = 0, g = 0;
+        if (lane < multi) {
+            g = lane_g[lane];
+            j = msm_key_lanes_log(msm_key(counts[g], cap), cap);
+            pt_load(acc, lane_partials + (size_t)lane * PW);
+        } else pt_set_inf(acc);
+        if (t == 0) jmax_s = j;
+        pt_store(lds + t * PW, acc);
         __syncthreads();
-        if (act) pt_store(lds + t * PW, acc);
+        constexpr uint32_t LOG_TB = (TB == 256) ? 8 : (TB == 128 ? 7 : 6);
+        const uint32_t steps = min(jmax_s, LOG_TB);
+        for (uint32_t s = 0; s < steps; s++) {
+            const bool act = ((t & ((2u << s) - 1)) == 0) && (s < j);
+            if (act) { XYZZ<F> o; pt_load(o, lds + (t + (1u << s)) * PW); acc = pt_add(acc, o); }
+            __syncthreads();
+            if (act) pt_store(lds + t * PW, acc);
+            __syncthreads();
+        }
+        if (lane < multi) {
+            if (j <= LOG_TB) { if ((t & ((1u << j) - 1)) == 0) pt_store(buckets + (size_t)g * PW, acc); }
+            else if (t == 0) pt_store(block_partials + (size_t)blk * PW, acc);
+        }
         __syncthreads();
     }
-    if (lane >= multi) return;
-    if (j <= LOG_TB) { if ((t & ((1u << j) - 1)) == 0) pt_store(buckets + (size_t)g * PW, acc); }
-    else if (t == 0) pt_store(block_partials + (size_t)blockIdx.x * PW, acc);
 }
 template <class F, int TB> __global__ void __launch_bounds__(TB)
 k_msm_giant(const uint32_t* __restrict__ giants, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ block_partials, uint32_t* __restrict__ buckets) {
     constexpr int PW = 4 * FieldWords<F>::value;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    if (blockIdx.x >= meta[2]) return;
-    const uint32_t g = giants[3 * blockIdx.x], b0 = giants[3 * blockIdx.x + 1], nblk = giants[3 * blockIdx.x + 2], t = threadIdx.x;
-    XYZZ<F> acc;
-    pt_set_inf(acc);
-    for (uint32_t b = t; b < nblk; b += TB) { XYZZ<F> o; pt_load(o, block_partials + (size_t)(b0 + b) * PW); acc = pt_add(acc, o); }
-    pt_store(lds + t * PW, acc);
-    __syncthreads();
-    for (int d = TB / 2; d >= 1; d >>= 1) {
-        if (t < (uint32_t)d) { XYZZ<F> o; pt_load(o, lds + (t + d) * PW); acc = pt_add(acc, o); pt_store(lds + t * PW, acc); }
+    const uint32_t t = threadIdx.x, ngiants = meta[2];
+    for (uint32_t gi = blockIdx.x; gi < ngiants; gi += gridDim.x) {
+        const uint32_t g = giants[3 * gi], b0 = giants[3 * gi + 1], nblk = giants[3 * gi + 2];
+        XYZZ<F> acc;
+        pt_set_inf(acc);
+        for (uint32_t b = t; b < nblk; b += TB) { XYZZ<F> o; pt_load(o, block_partials + (size_t)(b0 + b) * PW); acc = pt_add(acc, o); }
+        pt_store(lds + t * PW, acc);
+        __syncthreads();
+        for (int d = TB / 2; d >= 1; d >>= 1) {
+            if (t < (uint32_t)d) { XYZZ<F> o; pt_load(o, lds + (t + d) * PW); acc = pt_add(acc, o); pt_store(lds + t * PW, acc); }
+            __syncthreads();
+        }
+        if (t == 0) pt_store(buckets + (size_t)g * PW, acc);
         __syncthreads();
     }
-    if (t == 0) pt_store(buckets + (size_t)g * PW, acc);
 }
 
 // ---- bucket reduction -------------------------------------------------------------------------------------------------

@@ -150,9 +150,9 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
     hipLaunchKernelGGL((k_msm_accum<F, WIDE>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), acc_lds, st, (const uint32_t*)d_bases, d_infmask, sh, skip, pl.cap, pl.counts,
                        pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials);
     if (job.acc1) ZK_HIP(hipEventRecord(job.acc1, st));
-    hipLaunchKernelGGL((k_msm_tree<F, MSM_TB>), dim3((unsigned)tree_blocks), dim3(MSM_TB), tree_lds, st, lane_partials, pl.lane_g, pl.counts, pl.cap, pl.meta, buckets,
+    hipLaunchKernelGGL((k_msm_tree<F, MSM_TB>), dim3((unsigned)std::min<size_t>(tree_blocks, 512)), dim3(MSM_TB), tree_lds, st, lane_partials, pl.lane_g, pl.counts, pl.cap, pl.meta, buckets,
                        block_partials);
-    hipLaunchKernelGGL((k_msm_giant<F, MSM_TB>), dim3((unsigned)tree_blocks), dim3(MSM_TB), tree_lds, st, pl.giants, pl.meta, block_partials, buckets);
+    hipLaunchKernelGGL((k_msm_giant<F, MSM_TB>), dim3((unsigned)std::min<size_t>(tree_blocks, 256)), dim3(MSM_TB), tree_lds, st, pl.giants, pl.meta, block_partials, buckets);
     job.W = sh.W; job.c = sh.c; job.nb = sh.nb; job.buckets = buckets; job.counts = pl.counts;
     ZK_HIP(hipGetLastError());
     return ZKMI_OK;

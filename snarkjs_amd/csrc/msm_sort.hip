@@ -81,7 +81,8 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     uint32_t cap_big = 16, cap_fill = 8;
     while (cap_big < 2 * avg && cap_big < MSM_MAX_CAP) cap_big <<= 1;
     while ((size_t)2 * cap_fill <= (size_t)sh.Wd * n / 250000 && cap_fill < MSM_MAX_CAP) cap_fill <<= 1;
-    const uint32_t cap = std::min(cap_big, cap_fill);
+    static const int cap_env = getenv("ZKMI_CAP") ? atoi(getenv("ZKMI_CAP")) : 0;
+    const uint32_t cap = cap_env ? (uint32_t)cap_env : std::min(cap_big, cap_fill);
     pl.cap = cap;
     pl.multi_bound = (size_t)sh.Wd * n / cap + 1;                          // lanes of multi-lane groups: sum 2^floor(log2(cnt/cap))
     pl.lane_bound = total + pl.multi_bound;

@@ -108,7 +108,11 @@ int msm_table_dispatch(int curve, int group, const void* d_table, size_t stride,
 int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs, bool aux) {
     ZK_TRY(check_cg(curve, group));
     if (aux && !g_ctx.aux_stream) {
-        ZK_HIP(hipStreamCreateWithFlags(&g_ctx.aux_stream, hipStreamNonBlocking));
+        // highest priority: the auxiliary stream carries latency-bound work (few waves, long dependency chains) that must not
+        // queue behind the main stream's throughput-bound kernels for wave slots
+        int prio_least = 0, prio_greatest = 0;
+        ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        ZK_HIP(hipStreamCreateWithPriority(&g_ctx.aux_stream, hipStreamNonBlocking, getenv("ZKMI_AUX_PRIO") ? atoi(getenv("ZKMI_AUX_PRIO")) : prio_greatest));
         ZK_HIP(hipEventCreateWithFlags(&g_ctx.aux_ev[0], hipEventDisableTiming));
         ZK_HIP(hipEventCreateWithFlags(&g_ctx.aux_ev[1], hipEventDisableTiming));
     }

@@ -54,6 +54,7 @@ struct Ctx {
     std::map<uint64_t, void*> groth16;                      // zkmi_groth16 resident keys (groth16.hip)
     hipStream_t aux_stream = nullptr;                       // second stream for latency-bound reductions (groth16.hip)
     hipEvent_t aux_ev[2] = {};
+    hipEvent_t sort_ev[5] = {};                             // groth16.hip: digit sorts on the auxiliary stream (start, B, witness, join, H)
     hipEvent_t job_ev[16] = {};                             // per MSM job slot: events around k_msm_accum
     uint8_t* pinned = nullptr;                              // pinned host slots for MSM window sums
 };

@@ -325,3 +325,49 @@ def test_groth16_full_size_closed_form(zk, name, lg):
     assert np.array_equal(pi_a, O.to_affine(c, 1, O.generator_mul(c, 1, a)))
     assert np.array_equal(pi_b, O.to_affine(c, 2, O.generator_mul(c, 2, b)))
     assert np.array_equal(pi_c, O.to_affine(c, 1, O.generator_mul(c, 1, cc)))
+
+
+@pytest.mark.parametrize("dist", ["equal", "zero", "ones", "witness", "two_values", "max"])
+@pytest.mark.parametrize("tables", [False, True])
+def test_msm_sort_skewed_distributions(zk, dist, tables):
+    """The LDS radix partition of the digit sort (msm.cuh: k_rsort_*) under distributions that send most entries to a handful of
+    buckets (real witnesses are mostly 0/1), with and without window tables; closed-form check on the geometric bases, n = 2^18."""
+    import ctypes as C
+    from snarkjs_amd import zkmi
+    c, group, lg = 0, 1, 18
+    n = 1 << lg
+    r = synth_r = int(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bn128_kernel_vectors.json")))["r"])
+    L = zkmi.lib()
+    d_b = zkmi.DeviceBuffer(n * 64)
+    zkmi.check(L.zkmi_gen_geometric_bases_dev(c, group, n, 7, 11, d_b.ptr))
+    full = synth.elems(0xD157, n).reshape(n, 32).copy()
+    if dist == "equal":
+        full[:] = full[0]
+    elif dist == "zero":
+        full[:] = 0
+    elif dist == "ones":
+        full[:] = 0; full[:, 0] = 1
+    elif dist == "witness":
+        full = synth.witness_like(0xD158, n).reshape(n, 32).copy()
+    elif dist == "two_values":
+        full[::2] = full[0]; full[1::2] = full[1]
+    elif dist == "max":
+        full[:] = 0xFF                                     # 2^256 - 1: scalars >= r are not reduced (SURVEY.md 8a a1)
+    sc = np.ascontiguousarray(full.reshape(-1))
+    d_s = zkmi.DeviceBuffer.from_host(sc)
+    out = np.zeros(96, np.uint8)
+    if tables:
+        h = C.c_uint64(0)
+        zkmi.check(L.zkmi_msm_table_build(c, group, d_b.ptr, n, C.byref(h)))
+        zkmi.check(L.zkmi_msm_table_dev(h, d_s.ptr, n, 32, zkmi.ptr(out)))
+        zkmi.check(L.zkmi_msm_table_release(h))
+    else:
+        zkmi.check(L.zkmi_msm_dev(c, group, d_b.ptr, d_s.ptr, n, 32, zkmi.ptr(out)))
+    s = full.view("<u8").astype(object)
+    k, f = 0, 7
+    for i in range(n):
+        v = int(s[i, 0]) | int(s[i, 1]) << 64 | int(s[i, 2]) << 128 | int(s[i, 3]) << 192
+        k = (k + v * f) % r
+        f = f * 11 % r
+    want = O.to_affine(c, group, O.generator_mul(c, group, k))
+    assert np.array_equal(O.to_affine(c, group, out), want)

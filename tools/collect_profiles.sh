@@ -12,6 +12,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 600 python bench.py --workload plonk --log-n 20 --steps 5 --warmup 1 > $O/bench_plonk_2p20.json 2>/dev/null
 timeout 600 python bench.py --curve bls12381 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_bls12381_2p20.json 2>/dev/null
+timeout 300 python bench.py --workload fflonk --log-n 18 --steps 5 --warmup 1 > $O/bench_fflonk_2p18.json 2>/dev/null
 timeout 900 python bench.py --log-n 24 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_bn128_2p24.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_plonk -o plonk -- python bench.py --workload plonk --log-n 20 --steps 3 --warmup 1 > /dev/null 2>&1
 cat $O/bench.json

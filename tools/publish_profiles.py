@@ -4,7 +4,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
 for f, t in (("bench.json", f"{tag}_bench.json"), ("bench_plonk_2p20.json", f"{tag}_bench_plonk_2p20.json"), ("bench_bls12381_2p20.json", f"{tag}_bench_bls12381_2p20.json"),
-             ("bench_bn128_2p24.json", f"{tag}_bench_bn128_2p24.json"), ("stats/bench_kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"),
+             ("bench_bn128_2p24.json", f"{tag}_bench_bn128_2p24.json"), ("bench_fflonk_2p18.json", f"{tag}_bench_fflonk_2p18.json"), ("stats/bench_kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"),
              ("stats_plonk/plonk_kernel_stats.csv", f"{tag}_plonk_kernel_stats.csv")):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, t))
