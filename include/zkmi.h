@@ -192,10 +192,18 @@ int zkmi_fflonk_t2_dev(int curve, const zkmi_plonk_evals* ev, uint32_t domain, c
                        const uint8_t* k1, const uint8_t* k2, const uint8_t* w_n, const uint8_t* w_4n, void* d_t2, void* d_t2z);
 /* Polynomial.degree (polynomial.js:163-172): highest index of a non-zero coefficient, 0 if none */
 int zkmi_poly_degree_dev(int curve, const void* d_p, size_t n, size_t* degree);
+/* Keccak-256 with the original 0x01 padding (@noble/hashes keccak_256 as used by src/Keccak256Transcript.js:18-62); host only,
+ * needs no device: the Fiat-Shamir transcript of the PLONK / FFLONK provers */
+int zkmi_keccak256(const uint8_t* data, size_t len, uint8_t* out32);
 /* Polynomial.add / sub with optional blinding value (polynomial.js:218-276): y[i] = y[i] +/- k*x[i], i < nx (k NULL = 1) */
 int zkmi_poly_axpy_dev(int curve, void* d_y, const void* d_x, size_t nx, const uint8_t* k, int subtract);
 /* Polynomial.mulScalar (:278-284) */
 int zkmi_poly_scale_dev(int curve, void* d_p, size_t n, const uint8_t* k);
+/* blindCoefficients (polynomial.js:68-93) on a buffer of n + count elements whose tail is zero: p[n+i] += f_i, p[i] -= f_i.
+ * factors: count x 32 bytes (host, Montgomery), count <= 32. No host synchronisation. */
+int zkmi_poly_blind_dev(int curve, void* d_p, size_t n, const uint8_t* factors, int count);
+/* addScalar (polynomial.js:286-290): p[0] += value. No host synchronisation. */
+int zkmi_poly_add_scalar_dev(int curve, void* d_p, const uint8_t* value);
 /* Polynomial.evaluate (Horner, :174-184) as a parallel reduction; out = 32 bytes (host) */
 int zkmi_poly_evaluate_dev(int curve, const void* d_p, size_t n, const uint8_t* x, uint8_t* out);
 /* *all_zero = 1 iff p[0..n) are all zero (degree checks, plonk_prove.js:298-306, :645-647) */

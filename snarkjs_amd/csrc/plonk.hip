@@ -35,20 +35,28 @@ template <class C> ZK_DEV Fp<C> pow_tab(const PowTab& t, uint64_t e) {
     return fp_mul(a, b);
 }
 // host: table for exponents < 2^log_count, into the named scratch buffer
+// The bases are roots of unity of the key's domain: the same few tables are asked for by every proof, so they are cached by name
+// (the named scratch buffer keeps the device copy; the cache remembers which base / size it was built for).
+struct PowTabKey { HE base; unsigned log_count; uint32_t* d; };
+static std::map<std::string, PowTabKey>& pow_tab_cache() { static std::map<std::string, PowTabKey> m; return m; }
 static int build_pow_tab(const HFr& F, const HE& base, unsigned log_count, const char* name, PowTab* out) {
     Ctx& cx = ctx();
     const unsigned lb = (log_count + 1) / 2, hb = log_count - lb;
     const size_t nlo = (size_t)1 << lb, nhi = (size_t)1 << hb;
-    std::vector<HE> t(nlo + nhi);
-    t[0] = F.One();
-    for (size_t i = 1; i < nlo; i++) t[i] = F.mul(t[i - 1], base);
-    const HE step = F.mul(t[nlo - 1], base);
-    t[nlo] = F.One();
-    for (size_t i = 1; i < nhi; i++) t[nlo + i] = F.mul(t[nlo + i - 1], step);
     uint32_t* d;
-    ZK_TRY(ws_get(name, t.size() * 32, (void**)&d));
-    ZK_HIP(hipMemcpyAsync(d, t.data(), t.size() * 32, hipMemcpyHostToDevice, cx.stream));
-    ZK_HIP(hipStreamSynchronize(cx.stream));              // `t` is a stack-owned staging buffer
+    ZK_TRY(ws_get(name, (nlo + nhi) * 32, (void**)&d));
+    auto it = pow_tab_cache().find(name);
+    if (it == pow_tab_cache().end() || !(it->second.base == base) || it->second.log_count != log_count || it->second.d != d) {
+        std::vector<HE> t(nlo + nhi);
+        t[0] = F.One();
+        for (size_t i = 1; i < nlo; i++) t[i] = F.mul(t[i - 1], base);
+        const HE step = F.mul(t[nlo - 1], base);
+        t[nlo] = F.One();
+        for (size_t i = 1; i < nhi; i++) t[nlo + i] = F.mul(t[nlo + i - 1], step);
+        ZK_HIP(hipMemcpyAsync(d, t.data(), t.size() * 32, hipMemcpyHostToDevice, cx.stream));
+        ZK_HIP(hipStreamSynchronize(cx.stream));              // `t` is a stack-owned staging buffer
+        pow_tab_cache()[name] = PowTabKey{base, log_count, d};
+    }
     out->lo = d; out->hi = d + nlo * 8; out->lb = lb;
     return ZKMI_OK;
 }
@@ -215,8 +223,7 @@ template <class C> struct MulZ {
         }
     }
 };
-template <class C> __global__ void __launch_bounds__(256)
-k_plonk_t(PlonkTArgs g, PowTab w4) {
+template <class C> ZK_DEV void plonk_t_body(const PlonkTArgs& g, const PowTab& w4) {
     const uint32_t n4 = 4 * g.domain;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
@@ -264,6 +271,8 @@ k_plonk_t(PlonkTArgs g, PowTab w4) {
     fp_store<C>(g.t + (size_t)i * 8, fp_add(fp_sub(fp_add(e1, e2), e3), e4));
     fp_store<C>(g.tz + (size_t)i * 8, fp_add(fp_sub(fp_add(e1z, e2z), e3z), e4z));
 }
+template <class C> __global__ void __launch_bounds__(256) k_plonk_t(PlonkTArgs g, PowTab w4) { plonk_t_body<C>(g, w4); }
+template <class C, int MINBLK> __global__ void __launch_bounds__(256, MINBLK) k_plonk_t_occ(PlonkTArgs g, PowTab w4) { plonk_t_body<C>(g, w4); }
 
 // ---- FFLONK quotient numerators (src/fflonk_prove.js) ------------------------------------------------------------------------
 // T0 (:415-504): q_L a + q_R b + q_M a b + q_O c + q_C + PI over the 4n extended points
@@ -324,6 +333,14 @@ static __global__ void k_poly_degree(const uint32_t* __restrict__ p, size_t n, u
 
 // ---- polynomial ops ---------------------------------------------------------------------------------------------------------
 // y[i] = y[i] +/- (k ? k*x[i] : x[i]),  i < nx
+// blindCoefficients (polynomial.js:68-93): p[n+i] += f_i, p[i] -= f_i;  addScalar (:286-290): p[0] += f_0 (n = 0, sub = 0)
+template <class C> __global__ void k_poly_blind(uint32_t* __restrict__ p, size_t n, const uint32_t* __restrict__ f, int count, int sub) {
+    const int i = threadIdx.x;
+    if (i >= count) return;
+    const Fp<C> v = fp_load<C>(f + (size_t)i * 8);
+    fp_store<C>(p + (n + i) * 8, fp_add(fp_load<C>(p + (n + i) * 8), v));
+    if (sub) fp_store<C>(p + (size_t)i * 8, fp_sub(fp_load<C>(p + (size_t)i * 8), v));
+}
 template <class C> __global__ void k_poly_axpy(uint32_t* __restrict__ y, const uint32_t* __restrict__ x, size_t nx, const uint32_t* __restrict__ k, int subtract) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nx) return;
@@ -432,10 +449,30 @@ template <class C> struct PlonkOps {
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
+    // Per-call constants (challenges, blinding factors) go through a ring of pinned host / device slots: the copy is truly
+    // asynchronous and the host never waits for the stream. A slot is reused only after the work that was queued up to the NEXT
+    // upload has completed (event recorded at that point), i.e. after the kernels that read it.
+    static constexpr int RING = 64, SLOT_BYTES = 2048;
+    struct ConstRing { uint8_t* h = nullptr; uint8_t* d = nullptr; hipEvent_t ev[RING] = {}; bool used[RING] = {}; int next = 0, prev = -1; };
+    static ConstRing& ring() { static ConstRing r; return r; }
     static int upload_consts(const std::vector<HE>& v, const char* name, uint32_t** d) {
-        ZK_TRY(ws_get(name, v.size() * 32, (void**)d));
-        ZK_HIP(hipMemcpyAsync(*d, v.data(), v.size() * 32, hipMemcpyHostToDevice, ctx().stream));
-        ZK_HIP(hipStreamSynchronize(ctx().stream));
+        (void)name;
+        ConstRing& r = ring();
+        hipStream_t st = ctx().stream;
+        if (v.size() * 32 > (size_t)SLOT_BYTES) return fail(ZKMI_ERR_INVALID, "plonk: constants block too large");
+        if (!r.h) {
+            ZK_HIP(hipHostMalloc((void**)&r.h, (size_t)RING * SLOT_BYTES, hipHostMallocDefault));
+            ZK_HIP(hipMalloc((void**)&r.d, (size_t)RING * SLOT_BYTES));
+            for (int i = 0; i < RING; i++) ZK_HIP(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+        }
+        if (r.prev >= 0) { ZK_HIP(hipEventRecord(r.ev[r.prev], st)); r.used[r.prev] = true; }
+        const int slot = r.next;
+        r.next = (r.next + 1) % RING;
+        if (r.used[slot]) ZK_HIP(hipEventSynchronize(r.ev[slot]));
+        memcpy(r.h + (size_t)slot * SLOT_BYTES, v.data(), v.size() * 32);
+        ZK_HIP(hipMemcpyAsync(r.d + (size_t)slot * SLOT_BYTES, r.h + (size_t)slot * SLOT_BYTES, v.size() * 32, hipMemcpyHostToDevice, st));
+        r.prev = slot;
+        *d = (uint32_t*)(r.d + (size_t)slot * SLOT_BYTES);
         return ZKMI_OK;
     }
     static int compute_z(const void* A, const void* B, const void* Cc, const void* s1, const void* s2, const void* s3, uint32_t dom, const uint8_t* beta, const uint8_t* gamma, const uint8_t* k1,
@@ -488,7 +525,11 @@ template <class C> struct PlonkOps {
         g.s1 = (const uint32_t*)ev->s1; g.s2 = (const uint32_t*)ev->s2; g.s3 = (const uint32_t*)ev->s3;
         g.lagrange = (const uint32_t*)ev->lagrange; g.pub_a = (const uint32_t*)ev->pub_a; g.k = dk;
         g.domain = dom; g.n_public = n_public; g.t = (uint32_t*)T; g.tz = (uint32_t*)Tz;
-        hipLaunchKernelGGL((k_plonk_t<C>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        static const int occ = getenv("ZKMI_PLONK_T_OCC") ? atoi(getenv("ZKMI_PLONK_T_OCC")) : 3;   // 3 waves/SIMD: 4.6 ms at 2^20 (default bounds: 6.0 ms)
+        if (occ == 2) hipLaunchKernelGGL((k_plonk_t_occ<C, 2>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        else if (occ == 3) hipLaunchKernelGGL((k_plonk_t_occ<C, 3>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        else if (occ == 4) hipLaunchKernelGGL((k_plonk_t_occ<C, 1>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        else hipLaunchKernelGGL((k_plonk_t<C>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
@@ -532,6 +573,17 @@ template <class C> struct PlonkOps {
         uint32_t* dk = nullptr;
         if (k) { std::vector<HE> kv(1, he(k)); ZK_TRY(upload_consts(kv, "plonk.kaxpy", &dk)); }
         hipLaunchKernelGGL((k_poly_axpy<C>), dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, ctx().stream, (uint32_t*)y, (const uint32_t*)x, nx, dk, subtract);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int blind(void* p, size_t n, const uint8_t* factors, int count, int sub) {
+        if (count < 1 || count > 32) return fail(ZKMI_ERR_INVALID, "poly_blind: 1..32 factors");
+        if (sub && n < (size_t)count) return fail(ZKMI_ERR_INVALID, "poly_blind: polynomial shorter than the blinding factors");
+        std::vector<HE> kv(count);
+        for (int i = 0; i < count; i++) kv[i] = he(factors + 32 * i);
+        uint32_t* dk;
+        ZK_TRY(upload_consts(kv, "plonk.kblind", &dk));
+        hipLaunchKernelGGL((k_poly_blind<C>), dim3(1), dim3(64), 0, ctx().stream, (uint32_t*)p, n, dk, count, sub);
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
@@ -642,7 +694,59 @@ using namespace zkmi;
         return fail(ZKMI_ERR_INVALID, "unknown curve");                                 \
     } while (0)
 
+// ---- Keccak-256 (host): the Fiat-Shamir transcript of src/Keccak256Transcript.js (@noble/hashes keccak_256: original 0x01 padding,
+// rate 136) — a few hundred bytes per challenge, so it stays on the host like in the reference
+static void keccak_f1600(uint64_t st[25]) {
+    static const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull, 0x0000000080000001ull,
+                                    0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+                                    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull,
+                                    0x000000000000800aull, 0x800000008000000aull, 0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    static const int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    for (int round = 0; round < 24; round++) {
+        uint64_t bc[5];
+        for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
+        for (int i = 0; i < 5; i++) {
+            const uint64_t t = bc[(i + 4) % 5] ^ ((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63));
+            for (int j = 0; j < 25; j += 5) st[j + i] ^= t;
+        }
+        uint64_t t = st[1];
+        for (int i = 0; i < 24; i++) {
+            const int j = PIL[i];
+            const uint64_t b = st[j];
+            st[j] = (t << ROT[i]) | (t >> (64 - ROT[i]));
+            t = b;
+        }
+        for (int j = 0; j < 25; j += 5) {
+            for (int i = 0; i < 5; i++) bc[i] = st[j + i];
+            for (int i = 0; i < 5; i++) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+        }
+        st[0] ^= RC[round];
+    }
+}
+
 extern "C" {
+
+int zkmi_keccak256(const uint8_t* data, size_t len, uint8_t* out32) {
+    if ((!data && len) || !out32) return fail(ZKMI_ERR_INVALID, "keccak256: null argument");
+    constexpr size_t RATE = 136;
+    uint64_t st[25] = {0};
+    uint8_t block[RATE];
+    size_t off = 0;
+    for (;;) {
+        const size_t take = std::min(RATE, len - off);
+        const bool last = take < RATE;
+        memset(block, 0, RATE);
+        if (take) memcpy(block, data + off, take);
+        if (last) { block[take] ^= 0x01; block[RATE - 1] ^= 0x80; }
+        for (size_t i = 0; i < RATE / 8; i++) { uint64_t v; memcpy(&v, block + 8 * i, 8); st[i] ^= v; }
+        keccak_f1600(st);
+        off += take;
+        if (last) break;
+    }
+    memcpy(out32, st, 32);
+    return ZKMI_OK;
+}
 
 int zkmi_plonk_gather_wires_dev(int curve, const void* d_witness, uint32_t n_witness, const void* d_internal, uint32_t n_additions, const void* d_map_a, const void* d_map_b,
                                 const void* d_map_c, uint32_t n_constraints, uint32_t domain, void* d_a, void* d_b, void* d_c) {
@@ -659,6 +763,8 @@ int zkmi_plonk_compute_t_dev(int curve, const zkmi_plonk_evals* ev, uint32_t dom
 }
 int zkmi_poly_axpy_dev(int curve, void* d_y, const void* d_x, size_t nx, const uint8_t* k, int subtract) { PLONK_DISPATCH(curve, axpy(d_y, d_x, nx, k, subtract)); }
 int zkmi_poly_scale_dev(int curve, void* d_p, size_t n, const uint8_t* k) { PLONK_DISPATCH(curve, scale(d_p, n, k)); }
+int zkmi_poly_blind_dev(int curve, void* d_p, size_t n, const uint8_t* factors, int count) { PLONK_DISPATCH(curve, blind(d_p, n, factors, count, 1)); }
+int zkmi_poly_add_scalar_dev(int curve, void* d_p, const uint8_t* value) { PLONK_DISPATCH(curve, blind(d_p, 0, value, 1, 0)); }
 int zkmi_poly_evaluate_dev(int curve, const void* d_p, size_t n, const uint8_t* x, uint8_t* out) { PLONK_DISPATCH(curve, evaluate(d_p, n, x, out)); }
 int zkmi_poly_is_zero_dev(int curve, const void* d_p, size_t n, int* all_zero) {
     ZK_TRY(require_ctx());

@@ -25,43 +25,11 @@ _Q = {0: 21888242871839275222246405745257275088696311157297823662689037894645226
       1: 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab}
 
 # ---- Keccak-256 (original padding 0x01, as @noble/hashes keccak_256 used by src/Keccak256Transcript.js) ----------------------
-_KRC = (0x1, 0x8082, 0x800000000000808A, 0x8000000080008000, 0x808B, 0x80000001, 0x8000000080008081, 0x8000000000008009, 0x8A, 0x88,
-        0x80008009, 0x8000000A, 0x8000808B, 0x800000000000008B, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002,
-        0x8000000000000080, 0x800A, 0x800000008000000A, 0x8000000080008081, 0x8000000000008080, 0x80000001, 0x8000000080008008)
-_KROT = (0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14)   # flat index x + 5y
-_MASK = (1 << 64) - 1
-
-
-def _permute(s):
-    for rc in _KRC:
-        c = [s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20] for x in range(5)]
-        for x in range(5):
-            t = c[(x + 4) % 5] ^ (((c[(x + 1) % 5] << 1) | (c[(x + 1) % 5] >> 63)) & _MASK)
-            for y in range(0, 25, 5):
-                s[x + y] ^= t
-        b = [0] * 25
-        for x in range(5):
-            for y in range(5):
-                v, r = s[x + 5 * y], _KROT[x + 5 * y]
-                b[y + 5 * ((2 * x + 3 * y) % 5)] = ((v << r) | (v >> (64 - r))) & _MASK if r else v
-        for y in range(0, 25, 5):
-            for x in range(5):
-                s[x + y] = b[x + y] ^ (~b[(x + 1) % 5 + y] & _MASK & b[(x + 2) % 5 + y])
-        s[0] ^= rc
-
-
 def keccak256(data):
-    rate = 136
-    msg = bytearray(data)
-    msg.append(0x01)
-    msg.extend(b"\x00" * ((-len(msg)) % rate))
-    msg[-1] |= 0x80
-    st = [0] * 25
-    for off in range(0, len(msg), rate):
-        for i in range(rate // 8):
-            st[i] ^= int.from_bytes(msg[off + 8 * i:off + 8 * i + 8], "little")
-        _permute(st)
-    return b"".join(st[i].to_bytes(8, "little") for i in range(4))
+    """host routine of the library (csrc/plonk.hip: zkmi_keccak256); needs no device"""
+    data, out = bytes(data), C.create_string_buffer(32)
+    zkmi.check(zkmi.lib().zkmi_keccak256(data, len(data), out))
+    return out.raw
 
 
 class _Field:
@@ -128,7 +96,7 @@ class _Poly:
         zkmi.check(zkmi.lib().zkmi_poly_scale_dev(self.f.cid, self.ptr, self.n, zkmi.ptr(self.f.mont(k))))
 
     def add_scalar(self, v):
-        self.set(0, (self.get(0) + v) % self.f.r)
+        zkmi.check(zkmi.lib().zkmi_poly_add_scalar_dev(self.f.cid, self.ptr, zkmi.ptr(self.f.mont(v))))
 
     def evaluate(self, x):
         out = np.empty(32, np.uint8)
@@ -144,9 +112,8 @@ class _Poly:
         """blindCoefficients (polynomial.js:68-93): length grows by len(factors)"""
         out = _Poly(self.f, self.n + len(factors))
         out.copy_from(self.ptr, self.n)
-        for i, fct in enumerate(factors):
-            out.set(self.n + i, (out.get(self.n + i) + fct) % self.f.r)
-            out.set(i, (out.get(i) - fct) % self.f.r)
+        fb = np.concatenate([self.f.mont(fct) for fct in factors])
+        zkmi.check(zkmi.lib().zkmi_poly_blind_dev(self.f.cid, out.ptr, self.n, zkmi.ptr(fb), len(factors)))
         return out
 
     def ntt(self, inverse, out=None):

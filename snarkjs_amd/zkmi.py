@@ -27,7 +27,7 @@ SYMBOLS = [
     "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_release", "zkmi_groth16_stage_ms",
     "zkmi_gen_geometric_bases_dev", "zkmi_to_affine", "zkmi_point_add", "zkmi_fr_root",
     "zkmi_plonk_gather_wires_dev", "zkmi_plonk_compute_z_dev", "zkmi_plonk_compute_t_dev", "zkmi_fflonk_t0_dev", "zkmi_fflonk_t1_dev",
-    "zkmi_fflonk_t2_dev", "zkmi_poly_degree_dev", "zkmi_poly_axpy_dev", "zkmi_poly_scale_dev",
+    "zkmi_fflonk_t2_dev", "zkmi_poly_degree_dev", "zkmi_keccak256", "zkmi_poly_blind_dev", "zkmi_poly_add_scalar_dev", "zkmi_poly_axpy_dev", "zkmi_poly_scale_dev",
     "zkmi_poly_evaluate_dev", "zkmi_poly_is_zero_dev", "zkmi_poly_div_zh_dev", "zkmi_cpoly_interleave_dev", "zkmi_poly_div_by_zerofier_dev", "zkmi_last_kernel_ms",
 ]
 
@@ -108,6 +108,9 @@ def lib():
     L.zkmi_fflonk_t1_dev.argtypes = [C.c_int, vp, vp, u32, u8p, u8p, vp, vp]
     L.zkmi_fflonk_t2_dev.argtypes = [C.c_int, C.POINTER(PlonkEvals), u32, u8p, u8p, u8p, u8p, u8p, u8p, u8p, vp, vp]
     L.zkmi_poly_degree_dev.argtypes = [C.c_int, vp, sz, C.POINTER(sz)]
+    L.zkmi_keccak256.argtypes = [C.c_char_p, sz, C.c_char_p]
+    L.zkmi_poly_blind_dev.argtypes = [C.c_int, vp, sz, vp, C.c_int]
+    L.zkmi_poly_add_scalar_dev.argtypes = [C.c_int, vp, vp]
     L.zkmi_poly_axpy_dev.argtypes = [C.c_int, vp, vp, sz, u8p, C.c_int]
     L.zkmi_poly_scale_dev.argtypes = [C.c_int, vp, sz, u8p]
     L.zkmi_poly_evaluate_dev.argtypes = [C.c_int, vp, sz, u8p, u8p]
