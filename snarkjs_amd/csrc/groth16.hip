@@ -323,11 +323,16 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[4], 0));
     else ZK_TRY(msm_sort(K.T, n, 32, plh, 1, K.ch));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_H], st));
-    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, plh, 0, job[4], K.mask[4]));
+    // pi_c only needs C + H (:115): when both MSMs have the same bucket shape, H is accumulated into C's buckets and the two share
+    // one bucket reduction (ZKMI_MERGE_CH=0 keeps them apart)
+    static const bool merge_env = !(getenv("ZKMI_MERGE_CH") && atoi(getenv("ZKMI_MERGE_CH")) == 0);
+    const bool merge_ch = merge_env && K.ch == K.cw && plh.sh.W == pl.sh.W && plh.sh.nb == pl.sh.nb;
+    ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, plh, 0, job[4], K.mask[4], merge_ch ? &job[3] : nullptr));
     ZK_HIP(hipEventRecord(K.ev[ST_REDUCE], st));
     // bucket reductions are latency-bound: all G1 jobs of one shape go through ONE set of launches
     MsmJob* g1[4] = {&job[0], &job[1], &job[3], &job[4]};
-    if (job[4].W == job[0].W && job[4].c == job[0].c) ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 4));
+    if (merge_ch) ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 3));
+    else if (job[4].W == job[0].W && job[4].c == job[0].c) ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 4));
     else { ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 3)); ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1 + 3, 1)); }
     if (!ov) ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1));
     ZK_HIP(hipEventRecord(K.ev[ST_COUNT], st));

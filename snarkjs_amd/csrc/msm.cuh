@@ -366,10 +366,10 @@ k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, 
 }
 // WIDE (Fq2 points): at most 256 VGPRs (2 waves per SIMD), accumulator parked in LDS (curve.cuh: LdsAcc), no software
 // pipelining of the gather — 2.6x the throughput of the fully inlined 400+-register version (tools/maddbench.hip).
-template <class F, bool WIDE> __global__ void __launch_bounds__(256, WIDE ? 2 : 1)
+template <class F, bool WIDE, bool MERGE> __global__ void __launch_bounds__(256, WIDE ? 2 : 1)
 k_msm_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ infmask, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
             const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub, const uint32_t* __restrict__ meta,
-            uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials) {
+            uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials, const uint32_t* __restrict__ prev_counts) {
     constexpr int FW = FieldWords<F>::value;
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= meta[0]) return;
@@ -386,6 +386,10 @@ k_msm_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ inf
     const uint32_t* list = sorted + starts[g];
     XYZZ<F> acc;
     pt_set_inf(acc);
+    // merge mode (prev_counts != nullptr): the bucket array already holds the buckets of another MSM of the same shape whose
+    // result is only ever needed added to this one (Groth16: C and H) — the first lane of each bucket continues from that value,
+    // so the two MSMs share ONE bucket reduction
+    if (MERGE && !WIDE) { if (prev_counts[g] && (!j || lane_sub[lane] == 0)) pt_load(acc, buckets + (size_t)g * (4 * FW)); }
     // Next usable entry of this lane's list: skips indices below `skip` and bases at infinity (zkey sections B1/B2 are mostly
     // infinity for real circuits) in a cheap private loop, so that every lane arrives at the mixed addition with a real point —
     // a lane that merely `continue`d would idle for the whole addition of its 63 neighbours. infmask: one bit per table entry
@@ -435,6 +439,10 @@ k_msm_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ inf
     }
     if (j) pt_store(lane_partials + (size_t)lane * (4 * FW), acc);
     else pt_store(buckets + (size_t)g * (4 * FW), acc);
+}
+static __global__ void k_msm_counts_add(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t total, uint32_t* __restrict__ out) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < total) out[g] = (a[g] || b[g]) ? 1u : 0u;
 }
 // Combine the lane partials of multi-lane groups (they occupy lanes [0, meta[1])): LDS tree inside each block of TB
 // lanes; groups wider than a block leave one partial per block for k_msm_giant.

@@ -27,9 +27,9 @@ int msm_bls12381(int group, const void* d_bases, const void* d_scalars, size_t n
     if (group == 1) return msm_run<Fp<Bls12381Fq>>(d_bases, d_scalars, n, sb, out_jac);
     return msm_run<Fp2<Bls12381Fq>>(d_bases, d_scalars, n, sb, out_jac);
 }
-int msm_accumulate_bls12381(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask) {
-    if (group == 1) return msm_accumulate<Fp<Bls12381Fq>>(d_bases, pl, skip, job, d_infmask);
-    return msm_accumulate<Fp2<Bls12381Fq>>(d_bases, pl, skip, job, d_infmask);
+int msm_accumulate_bls12381(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask, MsmJob* into) {
+    if (group == 1) return msm_accumulate<Fp<Bls12381Fq>>(d_bases, pl, skip, job, d_infmask, into);
+    return msm_accumulate<Fp2<Bls12381Fq>>(d_bases, pl, skip, job, d_infmask, into);
 }
 int msm_infmask_bls12381(int group, const void* d_points, size_t n, uint32_t* d_mask) {
     if (group == 1) return msm_infmask<Fp<Bls12381Fq>>(d_points, n, d_mask);

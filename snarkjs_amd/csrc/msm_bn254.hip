@@ -26,9 +26,9 @@ int msm_bn254(int group, const void* d_bases, const void* d_scalars, size_t n, s
     if (group == 1) return msm_run<Fp<Bn254Fq>>(d_bases, d_scalars, n, sb, out_jac);
     return msm_run<Fp2<Bn254Fq>>(d_bases, d_scalars, n, sb, out_jac);
 }
-int msm_accumulate_bn254(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask) {
-    if (group == 1) return msm_accumulate<Fp<Bn254Fq>>(d_bases, pl, skip, job, d_infmask);
-    return msm_accumulate<Fp2<Bn254Fq>>(d_bases, pl, skip, job, d_infmask);
+int msm_accumulate_bn254(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask, MsmJob* into) {
+    if (group == 1) return msm_accumulate<Fp<Bn254Fq>>(d_bases, pl, skip, job, d_infmask, into);
+    return msm_accumulate<Fp2<Bn254Fq>>(d_bases, pl, skip, job, d_infmask, into);
 }
 int msm_infmask_bn254(int group, const void* d_points, size_t n, uint32_t* d_mask) {
     if (group == 1) return msm_infmask<Fp<Bn254Fq>>(d_points, n, d_mask);

@@ -106,6 +106,7 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan, int plan
 // One MSM in flight: per-window sums land in a pinned host slot; msm_fold turns them into the Jacobian result.
 struct MsmJob {
     int W = 0, c = 0, cbits = 0, slot = 0;
+    bool merged = false;                            // accumulated into another job's buckets (msm_accumulate `into`)
     int bitsums = 0;                                // h_win holds per (array, k) plain sums (k_msm_bitsums) instead of weighted sums
     uint32_t nb = 0;
     uint32_t* h_win = nullptr;                      // pinned host: 2W weighted sums then 2W totals (XYZZ)
@@ -120,7 +121,9 @@ int msm_job_slot(int slot, MsmJob& job);
 // skip: the scalar with index i pairs with base (i - skip); indices < skip are ignored. This lets several MSMs share
 // one digit sort (Groth16: A, B1, B2 over the witness and C over witness[nPublic+1:], src/groth16_prove.js:85-97).
 // Leaves the complete buckets of this MSM in the bucket buffer of job.slot; msm_reduce finishes the job.
-template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask = nullptr) {
+// into (optional): an already accumulated job of the same shape; this MSM's points are added into ITS buckets (the two results are
+// only needed as a sum) and `job` is marked merged: msm_reduce skips it and msm_fold returns the point at infinity for it.
+template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask = nullptr, MsmJob* into = nullptr) {
     constexpr int FW = FieldWords<F>::value, PW = 4 * FW;
     constexpr bool WIDE = FW > 12;
     Ctx& cx = ctx();
@@ -129,7 +132,13 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
     hipStream_t st = cx.stream;
     const std::string sfx = "." + std::to_string(job.slot);
     uint32_t *buckets, *lane_partials, *block_partials;
-    ZK_TRY(ws_get("msm.buckets" + sfx, total * PW * 4, (void**)&buckets));
+    const uint32_t* prev_counts = nullptr;
+    if (into) {
+        if (WIDE) return fail(ZKMI_ERR_UNSUPPORTED, "msm_accumulate: merge mode is implemented for G1 only");
+        if (into->W != sh.W || into->c != sh.c || into->nb != sh.nb || !into->buckets) return fail(ZKMI_ERR_INVALID, "msm_accumulate: merge target of a different shape");
+        buckets = const_cast<uint32_t*>(into->buckets);
+        prev_counts = into->counts;
+    } else ZK_TRY(ws_get("msm.buckets" + sfx, total * PW * 4, (void**)&buckets));
     ZK_TRY(ws_get("msm.lane_partials", std::max<size_t>(pl.multi_bound, 1) * PW * 4, (void**)&lane_partials));
     const size_t tree_blocks = pl.multi_bound / MSM_TB + 1;
     ZK_TRY(ws_get("msm.block_partials", tree_blocks * PW * 4, (void**)&block_partials));
@@ -143,17 +152,31 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
     const size_t acc_lds = WIDE ? (size_t)PW * 256 * 4 : 0;              // WIDE: XYZZ accumulators live in LDS
     static bool acc_attr = false;
     if (WIDE && !acc_attr) {
-        ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum<F, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum<F, WIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
         acc_attr = true;
     }
     if (job.acc0) ZK_HIP(hipEventRecord(job.acc0, st));
-    hipLaunchKernelGGL((k_msm_accum<F, WIDE>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), acc_lds, st, (const uint32_t*)d_bases, d_infmask, sh, skip, pl.cap, pl.counts,
-                       pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials);
+    bool launched = false;
+    if constexpr (!WIDE) if (into) {
+        launched = true;
+        hipLaunchKernelGGL((k_msm_accum<F, false, true>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_bases, d_infmask, sh, skip, pl.cap, pl.counts,
+                           pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);
+    }
+    if (!launched)
+        hipLaunchKernelGGL((k_msm_accum<F, WIDE, false>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), acc_lds, st, (const uint32_t*)d_bases, d_infmask, sh, skip, pl.cap, pl.counts,
+                           pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);
     if (job.acc1) ZK_HIP(hipEventRecord(job.acc1, st));
     hipLaunchKernelGGL((k_msm_tree<F, MSM_TB>), dim3((unsigned)std::min<size_t>(tree_blocks, 512)), dim3(MSM_TB), tree_lds, st, lane_partials, pl.lane_g, pl.counts, pl.cap, pl.meta, buckets,
                        block_partials);
     hipLaunchKernelGGL((k_msm_giant<F, MSM_TB>), dim3((unsigned)std::min<size_t>(tree_blocks, 256)), dim3(MSM_TB), tree_lds, st, pl.giants, pl.meta, block_partials, buckets);
     job.W = sh.W; job.c = sh.c; job.nb = sh.nb; job.buckets = buckets; job.counts = pl.counts;
+    job.merged = into != nullptr;
+    if (into) {
+        uint32_t* cmb;
+        ZK_TRY(ws_get("msm.cmbcounts." + std::to_string(into->slot), total * 4, (void**)&cmb));
+        hipLaunchKernelGGL(k_msm_counts_add, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, prev_counts, pl.counts, (uint32_t)total, cmb);
+        into->counts = cmb;
+    }
     ZK_HIP(hipGetLastError());
     return ZKMI_OK;
 }
@@ -256,6 +279,7 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
 // after the stream has been synchronised
 template <class F> void msm_fold(const MsmJob& job, uint8_t* out_jac) {
     constexpr int PW = 4 * FieldWords<F>::value;
+    if (job.merged) { memset(out_jac, 0, 3 * PW); return; }              // its points are inside the merge target's result
     if (!job.bitsums) { msm_fold_windows<F>(job.h_win, job.h_win + (size_t)2 * job.W * PW, job.W, job.c, job.cbits, out_jac); return; }
     // plain bit sums -> weighted sums by Horner on the host, laid out as msm_fold_windows expects
     typedef typename HostOf<F>::FT FT;
@@ -334,7 +358,7 @@ int msm_table_multi_dispatch(int curve, int group, const void* d_table, size_t s
                              uint8_t* out_jacs);
 
 // non-template entry points (msm_bn254.hip / msm_bls12381.hip) for callers that must not instantiate the kernels again
-int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask = nullptr);
+int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask = nullptr, MsmJob* into = nullptr);
 // d_mask: ceil(n/32) words, zeroed by the callee; bit i = point i is the point at infinity
 int msm_infmask_dispatch(int curve, int group, const void* d_points, size_t n, uint32_t* d_mask);
 int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs, bool aux = false);

@@ -526,9 +526,7 @@ template <class C> struct PlonkOps {
         g.lagrange = (const uint32_t*)ev->lagrange; g.pub_a = (const uint32_t*)ev->pub_a; g.k = dk;
         g.domain = dom; g.n_public = n_public; g.t = (uint32_t*)T; g.tz = (uint32_t*)Tz;
         static const int occ = getenv("ZKMI_PLONK_T_OCC") ? atoi(getenv("ZKMI_PLONK_T_OCC")) : 3;   // 3 waves/SIMD: 4.6 ms at 2^20 (default bounds: 6.0 ms)
-        if (occ == 2) hipLaunchKernelGGL((k_plonk_t_occ<C, 2>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
-        else if (occ == 3) hipLaunchKernelGGL((k_plonk_t_occ<C, 3>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
-        else if (occ == 4) hipLaunchKernelGGL((k_plonk_t_occ<C, 1>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        if (occ == 3) hipLaunchKernelGGL((k_plonk_t_occ<C, 3>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
         else hipLaunchKernelGGL((k_plonk_t<C>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;

@@ -59,8 +59,8 @@ int download_pages(const void* d_src, size_t total_bytes, uint8_t* const* out_pt
 
 int msm_bn254(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_bls12381(int group, const void*, const void*, size_t, size_t, uint8_t*);
-int msm_accumulate_bn254(int group, const void*, const MsmPlan&, uint32_t, MsmJob&, const uint32_t*);
-int msm_accumulate_bls12381(int group, const void*, const MsmPlan&, uint32_t, MsmJob&, const uint32_t*);
+int msm_accumulate_bn254(int group, const void*, const MsmPlan&, uint32_t, MsmJob&, const uint32_t*, MsmJob*);
+int msm_accumulate_bls12381(int group, const void*, const MsmPlan&, uint32_t, MsmJob&, const uint32_t*, MsmJob*);
 int msm_infmask_bn254(int group, const void*, size_t, uint32_t*);
 int msm_infmask_bls12381(int group, const void*, size_t, uint32_t*);
 int msm_reduce_bn254(int group, MsmJob* const*, int, bool);
@@ -89,9 +89,9 @@ int msm_dev_dispatch(int curve, int group, const void* d_bases, const void* d_sc
     ZK_TRY(check_cg(curve, group));
     return curve == ZKMI_CURVE_BN128 ? msm_bn254(group, d_bases, d_scalars, n, sb, out) : msm_bls12381(group, d_bases, d_scalars, n, sb, out);
 }
-int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask) {
+int msm_accumulate_dispatch(int curve, int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask, MsmJob* into) {
     ZK_TRY(check_cg(curve, group));
-    return curve == ZKMI_CURVE_BN128 ? msm_accumulate_bn254(group, d_bases, pl, skip, job, d_infmask) : msm_accumulate_bls12381(group, d_bases, pl, skip, job, d_infmask);
+    return curve == ZKMI_CURVE_BN128 ? msm_accumulate_bn254(group, d_bases, pl, skip, job, d_infmask, into) : msm_accumulate_bls12381(group, d_bases, pl, skip, job, d_infmask, into);
 }
 int msm_infmask_dispatch(int curve, int group, const void* d_points, size_t n, uint32_t* d_mask) {
     ZK_TRY(check_cg(curve, group));
