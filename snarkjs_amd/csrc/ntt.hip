@@ -57,7 +57,8 @@ template <class C> static int get_plan(int curve, unsigned L, int inverse, NttPl
     P.log_n = L;
     if (L <= (unsigned)NTT_TILE_LOG) { P.n_pass = 1; P.l[0] = L; }
     else {
-        P.n_pass = (int)((L + 7) / 8);
+        static const unsigned maxbits = getenv("ZKMI_NTT_DIGIT") ? (unsigned)atoi(getenv("ZKMI_NTT_DIGIT")) : 8u;
+        P.n_pass = (int)((L + maxbits - 1) / maxbits);
         unsigned rem = L;
         for (int i = 0; i < P.n_pass; i++) { unsigned li = (rem + (P.n_pass - i) - 1) / (P.n_pass - i); P.l[i] = li; rem -= li; }
     }
@@ -150,8 +151,8 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
     if (p > 1) ZK_TRY(ws_get("ntt.work", n * 32, (void**)&work));
     static bool attr = false;
     if (!attr) {
-        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_strided<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_last<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_strided<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_last<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
     ZK_HIP(hipEventRecord(cx.ev0, st));

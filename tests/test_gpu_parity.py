@@ -371,3 +371,27 @@ def test_msm_sort_skewed_distributions(zk, dist, tables):
         f = f * 11 % r
     want = O.to_affine(c, group, O.generator_mul(c, group, k))
     assert np.array_equal(O.to_affine(c, group, out), want)
+
+
+@pytest.mark.parametrize("name,sb,lg", [("bn128", 4, 17), ("bn128", 48, 15), ("bls12381", 4, 16), ("bn128", 33, 15)])
+def test_msm_scalar_widths_large(zk, name, sb, lg):
+    """Scalar widths other than 32 bytes on the large-input (LDS radix) sort path: 4-byte scalars (src/powersoftau_verify.js:371),
+    48-byte and odd-width scalars; values >= r are not reduced by the reference, the group does it. Closed form on geometric bases."""
+    from snarkjs_amd import zkmi
+    c, L = O.CURVE_ID[name], zkmi.lib()
+    n = 1 << lg
+    r = int(json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"{name}_kernel_vectors.json")))["r"])
+    q8 = O.n8q(c)
+    d_b = zkmi.DeviceBuffer(n * 2 * q8)
+    zkmi.check(L.zkmi_gen_geometric_bases_dev(c, 1, n, 7, 11, d_b.ptr))
+    raw = synth.elems(0xABC + sb, (n * sb + 31) // 32 + 1)[:n * sb].copy()
+    raw[sb - 1::sb] |= 0x80                                      # top bit set: exercises the carry out of the last signed window
+    d_s = zkmi.DeviceBuffer.from_host(raw)
+    out = np.zeros(3 * q8, np.uint8)
+    zkmi.check(L.zkmi_msm_dev(c, 1, d_b.ptr, d_s.ptr, n, sb, zkmi.ptr(out)))
+    k, f = 0, 7
+    rb = raw.tobytes()
+    for i in range(n):
+        k = (k + int.from_bytes(rb[i * sb:(i + 1) * sb], "little") * f) % r
+        f = f * 11 % r
+    assert np.array_equal(O.to_affine(c, 1, out), O.to_affine(c, 1, O.generator_mul(c, 1, k)))
