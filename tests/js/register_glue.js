@@ -80,6 +80,29 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
         check("plonk.prove through register.js verifies", await snarkjs.plonk.verify(vk, pr.publicSignals, pr.proof));
         check("plonk census: 9 MSM, batchInverse, batchFromMontgomery used", calls.msm1 === 9 && calls.batch2 >= 1 && calls.batch1 >= 9 && calls.batch0 === 3);
     }
+    // 4. setup-side callers (SURVEY.md 8 f3): plonk.setup / fflonk.setup reach the bulk ops through the same patched methods
+    //    (src/plonk_setup.js:322-330,395-403; src/fflonk_setup.js via Polynomial.to4T / multiExponentiation) — the zkey written
+    //    through the patched surface must equal the unpatched one byte for byte. A small seeded ptau is made with the originals.
+    const r1cs = "/root/reference/test/plonk_circuit/circuit.r1cs";
+    if (fs.existsSync(r1cs)) {
+        const mem = () => ({ type: "mem" });
+        const mkPtau = async () => { const p0 = mem(), p1 = mem(), pf = mem(); await snarkjs.powersOfTau.newAccumulator(curve, 7, p0); await snarkjs.powersOfTau.contribute(p0, p1, "C1", "Entropy1"); await snarkjs.powersOfTau.preparePhase2(p1, pf); return pf; };
+        const rb = new Uint8Array(fs.readFileSync(r1cs));
+        for (const k of Object.keys(calls)) delete calls[k];
+        const ptau = await mkPtau();                       // ceremony code also runs through the patched curve (G1/G2 group FFTs stay WASM)
+        const zPatched = mem(), fPatched = mem();
+        await snarkjs.plonk.setup(rb, ptau, zPatched);
+        const setupCalls = Object.assign({}, calls);
+        await snarkjs.fflonk.setup(rb, ptau, fPatched);
+        unregister(curve);
+        const zPlain = mem(), fPlain = mem();
+        await snarkjs.plonk.setup(rb, ptau, zPlain);
+        await snarkjs.fflonk.setup(rb, ptau, fPlain);
+        check("plonk.setup through register.js writes the same zkey", sha(zPatched.data) === sha(zPlain.data));
+        check("fflonk.setup through register.js writes the same zkey", sha(fPatched.data) === sha(fPlain.data));
+        check("plonk.setup census: 8 MSMs (Qm..S3), ifft + fft(4n) per selector / sigma / Lagrange", setupCalls.msm1 === 8 && setupCalls.ifft >= 9 && setupCalls.fft >= 9);
+        register(curve, { addon: mock });
+    }
     unregister(curve);
     check("unregister restores the WASM entry points", curve.__zkmi === undefined);
     console.log(fails ? `${fails} FAILED` : "ALL OK");
