@@ -364,6 +364,10 @@ k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, 
         giants[3 * idx] = g; giants[3 * idx + 1] = lane0 >> log_tb; giants[3 * idx + 2] = 1u << (j - log_tb);
     }
 }
+// Threads per accumulation block. The LDS-parked Fq2 accumulators cost 4*FW words per lane: 256 B (BN254: 2 blocks of 256 lanes
+// per CU) but 384 B for BLS12-381, where a 256-lane block would own 96 KiB and run alone on its CU (1 wave per SIMD) — 128-lane
+// blocks fit three per CU.
+template <class F> struct MsmAccumBlock { static constexpr int value = (FieldWords<F>::value > 16) ? 128 : 256; };
 // WIDE (Fq2 points): at most 256 VGPRs (2 waves per SIMD), accumulator parked in LDS (curve.cuh: LdsAcc), no software
 // pipelining of the gather — 2.6x the throughput of the fully inlined 400+-register version (tools/maddbench.hip).
 template <class F, bool WIDE, bool MERGE> __global__ void __launch_bounds__(256, WIDE ? 2 : 1)
@@ -415,7 +419,7 @@ k_msm_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ inf
     };
     if (WIDE) {
         extern __shared__ __attribute__((aligned(16))) uint32_t lds_acc[];
-        LdsAcc<F, 256> A{lds_acc + threadIdx.x};
+        LdsAcc<F, MsmAccumBlock<F>::value> A{lds_acc + threadIdx.x};
         bool inf = true;
         uint32_t e;
         Affine<F> q;

@@ -149,7 +149,8 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
         ZK_HIP(hipFuncSetAttribute((const void*)k_msm_giant<F, MSM_TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_lds));
         tree_attr = true;
     }
-    const size_t acc_lds = WIDE ? (size_t)PW * 256 * 4 : 0;              // WIDE: XYZZ accumulators live in LDS
+    constexpr unsigned AT = WIDE ? MsmAccumBlock<F>::value : 256;      // threads per accumulation block
+    const size_t acc_lds = WIDE ? (size_t)PW * AT * 4 : 0;              // WIDE: XYZZ accumulators live in LDS
     static bool acc_attr = false;
     if (WIDE && !acc_attr) {
         ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum<F, WIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
@@ -163,7 +164,7 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
                            pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);
     }
     if (!launched)
-        hipLaunchKernelGGL((k_msm_accum<F, WIDE, false>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), acc_lds, st, (const uint32_t*)d_bases, d_infmask, sh, skip, pl.cap, pl.counts,
+        hipLaunchKernelGGL((k_msm_accum<F, WIDE, false>), dim3((unsigned)((pl.lane_bound + AT - 1) / AT)), dim3(AT), acc_lds, st, (const uint32_t*)d_bases, d_infmask, sh, skip, pl.cap, pl.counts,
                            pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);
     if (job.acc1) ZK_HIP(hipEventRecord(job.acc1, st));
     hipLaunchKernelGGL((k_msm_tree<F, MSM_TB>), dim3((unsigned)std::min<size_t>(tree_blocks, 512)), dim3(MSM_TB), tree_lds, st, lane_partials, pl.lane_g, pl.counts, pl.cap, pl.meta, buckets,
