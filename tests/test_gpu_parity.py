@@ -395,3 +395,37 @@ def test_msm_scalar_widths_large(zk, name, sb, lg):
         k = (k + int.from_bytes(rb[i * sb:(i + 1) * sb], "little") * f) % r
         f = f * 11 % r
     assert np.array_equal(O.to_affine(c, 1, out), O.to_affine(c, 1, O.generator_mul(c, 1, k)))
+
+
+def test_soak_many_proofs_same_key(zk):
+    """200 Groth16 proofs + 40 PLONK proofs back to back on resident keys: identical bytes every time (event / constant-ring / plan
+    buffer reuse across proofs) and no growth of device memory after the first proofs."""
+    import ctypes
+    import synth_plonk
+    import synth_zkey
+    from snarkjs_amd import groth16, binfile, plonk
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        fr, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(tot)) == 0
+        return fr.value
+    zkey, wtns = synth_zkey.make("bn128", 14, seed=77)
+    pk = groth16.ProvingKey(zkey)
+    w = binfile.read_wtns(wtns)["witness"]
+    r_m, s_m = O.fr_e(0, 11), O.fr_e(0, 13)
+    first = [bytes(x) for x in pk.prove_raw(w, r_m, s_m)]
+    pk.prove_raw(w, r_m, s_m)
+    free0 = free_bytes()
+    for _ in range(200):
+        assert [bytes(x) for x in pk.prove_raw(w, r_m, s_m)] == first
+    pzkey, pwtns = synth_plonk.make("bn128", 12, seed=5)
+    key = plonk.PlonkKey(pzkey)
+    f = plonk._Field(0)
+    blind = [bytes(f.mont(900 + i)) for i in range(11)]
+    p0 = plonk.prove(key, pwtns, blinding_mont=blind)
+    for _ in range(40):
+        assert plonk.prove(key, pwtns, blinding_mont=blind) == p0
+    key.release()
+    pk.release()
+    assert free_bytes() >= free0 - (64 << 20)
