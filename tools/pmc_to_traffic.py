@@ -18,7 +18,8 @@ def agg(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("zkmi::", "")
-        k = re.sub(r",\s*(true|false|\d+)>$", ">", k)          # drop trailing non-type template args
+        while re.search(r",\s*(true|false|\d+)>$", k):
+            k = re.sub(r",\s*(true|false|\d+)>$", ">", k)      # drop trailing non-type template args
         acc[k][0] += 1
         acc[k][1] += float(r["Counter_Value"])
     return {k: v[1] / v[0] for k, v in acc.items()}
