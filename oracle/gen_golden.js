@@ -235,13 +235,20 @@ async function fflonkGolden() {
         const { proof, publicSignals } = await snarkjs.fflonk.prove(z.data, w.data);
         for (const [o, nm, f] of undo) o[nm] = f; Fr.random = origRandom;
         const vk = await snarkjs.zKey.exportVerificationKey(z.data);
-        const ok = await snarkjs.fflonk.verify(vk, publicSignals, proof);
+        // the two G1 arguments of the verifier's final pairing (src/fflonk_verify.js:529-541: pairingEq(-A1, [1]_2, W2, [x]_2)) and its
+        // challenges pin the restatement oracle/fflonk_verify_oracle.py up to, but excluding, the pairing itself
+        const verify_trace = [], pairing_inputs = [];
+        const origPairingEq = curve.pairingEq.bind(curve);
+        curve.pairingEq = async (...a) => { for (const k of [0, 2]) { const o = curve.G1.toObject(curve.G1.toAffine(a[k])); pairing_inputs.push([o[0].toString(), o[1].toString()]); } return origPairingEq(...a); };
+        const vlog = { debug() {}, info: (m) => { if (/challenges\./.test(m)) verify_trace.push(m); }, warn() {}, error() {} };
+        const ok = await snarkjs.fflonk.verify(vk, publicSignals, proof, vlog);
+        curve.pairingEq = origPairingEq;
         if (!ok) throw new Error('golden fflonk proof does not verify');
         fs.writeFileSync(path.join(OUT, `${tag}.zkey`), z.data);
         fs.writeFileSync(path.join(OUT, `${tag}.wtns`), w.data);
         fs.writeFileSync(path.join(OUT, `${tag}.json`), JSON.stringify({
             zkey_sha256: sha(z.data), wtns_sha256: sha(w.data), proof_sha256: sha(JSON.stringify(proof)), blinding_mont: rnd, proof, publicSignals,
-            verified: ok, vk, census }, null, 1));
+            verified: ok, vk, verify_trace, pairing_inputs, census }, null, 1));
         console.log(tag, 'fflonk golden done: zkey', z.data.length, 'bytes, proof sha', sha(JSON.stringify(proof)), 'verify', ok);
     }
 }

@@ -71,3 +71,22 @@ def test_plonk_verifier_trace(golden_dir, tag):
     vk = V.vk_from_zkey(zkey)
     for k, v in vk.items():
         assert g["vk"][k] == v or str(g["vk"][k]) == str(v), k
+
+
+@pytest.mark.parametrize("tag", ["fflonk_bn128_small", "fflonk_bn128_n256"])
+def test_fflonk_verifier_trace(golden_dir, tag):
+    """The FFLONK verifier restatement reproduces the challenges the reference's fflonk.verify logs and the two G1 points it hands
+    to the final pairing (-A1 and W2) for the reference's own seeded proofs."""
+    import re
+    import fflonk_verify_oracle as V
+    g, zkey, wtns = load(golden_dir, tag)
+    val = V.verifier_values(g["vk"], g["publicSignals"], g["proof"])
+    for line in g["verify_trace"]:
+        m = re.search(r"challenges\.(\w+):\s+(\d+)", line)
+        assert val[m.group(1)] == int(m.group(2)), m.group(1)
+    neg_a1, b1 = (tuple(int(x) for x in p) for p in g["pairing_inputs"])
+    assert val["A1"] == (neg_a1[0], (V.Ctx().q - neg_a1[1]) % V.Ctx().q)
+    assert val["B1"] == b1
+    vk = V.vk_from_zkey(zkey)
+    for k, v in vk.items():
+        assert str(g["vk"][k]) == str(v) or g["vk"][k] == v, k
