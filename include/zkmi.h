@@ -149,6 +149,16 @@ int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t zkey_cache_key, c
 int zkmi_groth16_prove_dev(uint64_t zkey_cache_key, const void* d_witness, const uint8_t* r_mont, const uint8_t* s_mont,
                            uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 int zkmi_groth16_release(uint64_t zkey_cache_key);
+/* Multi-GPU proof (BASELINE configs[2]: MSMs sharded across the GPUs of a node). Every rank loads the shard of the
+ * key that holds the witness-side bases of the variables [var_lo, var_hi) (sections 5-8) and the H bases [h_lo, h_hi) (section 9);
+ * the section pointers of `zkey` are those of the FULL sections, the library slices them. zkmi_groth16_sums_dev runs the device
+ * part of a proof on the FULL witness (buildABC, NTT chain, joinABC are replicated: they need no exchange) and returns this
+ * shard's five partial MSM sums  jA | jB1 | jB2 | jC | jH  (Jacobian, 3*n8q bytes each, jB2 6*n8q: 7*3*n8q bytes in total).
+ * The caller adds the sums of all ranks (one all-gather of < 1 KB per rank + zkmi_point_add) and zkmi_groth16_finish applies the
+ * blinding and toAffine (:103-132, host, O(1)). With the full key, sums + finish == zkmi_groth16_prove_dev. */
+int zkmi_groth16_load_shard(const zkmi_groth16_zkey* zkey, uint64_t zkey_cache_key, uint32_t var_lo, uint32_t var_hi, uint32_t h_lo, uint32_t h_hi);
+int zkmi_groth16_sums_dev(uint64_t zkey_cache_key, const void* d_witness, uint8_t* sums);
+int zkmi_groth16_finish(uint64_t zkey_cache_key, const uint8_t* sums, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 /* Device time (ms, HIP events) of the stages of the last proof, in order: buildABC, 6 NTTs, joinABC, sort(witness),
  * bucket accumulation of MSM B2, B1 (+ the second witness sort), A, C, sort(H scalars), accumulation of MSM H, batched G1 bucket reductions (the B2
  * reduction runs on a second stream underneath the G1 accumulations).

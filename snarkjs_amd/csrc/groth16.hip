@@ -97,6 +97,10 @@ struct G16Key {
     uint32_t* mask[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // infinity bitmaps of bA, bB1, bB2, bC, bH (one bit per table entry)
     int cw = 0, ch = 0;               // window width of the witness-side / H-side tables (0 = plain bases, no pre-computation)
     uint32_t c_skip = 0;              // index offset of the C bases (0 when the C table is padded to nVars entries)
+    // shard of the key held by this device (multi-GPU: MSMs split by base-index range): witness-side bases of the
+    // variables [v_lo, v_lo + v_cnt) and H bases [h_lo, h_lo + h_cnt); the full key has v_lo = h_lo = 0, v_cnt = nVars, h_cnt = n
+    uint32_t v_lo = 0, v_cnt = 0, h_lo = 0, h_cnt = 0;
+    bool full() const { return v_lo == 0 && h_lo == 0 && v_cnt == n_vars && h_cnt == domain; }
     uint32_t *row_cnt = nullptr, *row_start = nullptr, *sig = nullptr, *val = nullptr;
     uint32_t *w = nullptr, *A = nullptr, *B = nullptr, *C = nullptr, *T = nullptr;
     std::vector<uint8_t> vk_alpha_1, vk_beta_1, vk_beta_2, vk_delta_1, vk_delta_2;
@@ -115,7 +119,7 @@ static int upload(void** d, const uint8_t* h, size_t bytes, hipStream_t st) {
     return ZKMI_OK;
 }
 
-static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key) {
+static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, uint32_t v_hi, uint32_t h_lo, uint32_t h_hi) {
     Ctx& cx = ctx();
     hipStream_t st = cx.stream;
     if (zk->curve != ZKMI_CURVE_BN128 && zk->curve != ZKMI_CURVE_BLS12381) return fail(ZKMI_ERR_INVALID, "unknown curve");
@@ -128,13 +132,18 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key) {
     K->power = (uint32_t)ilog2_sz(n);
     K->n_coef = (uint32_t)((zk->coeffs_len - 4) / 44);            // buildABC1: nCoef = (byteLength-4)/sCoef (:149-150)
     const size_t q = n8q_of(zk->curve), g1 = 2 * q, g2 = 4 * q;
-    const size_t m = zk->n_vars, mc = m - zk->n_public - 1;
+    if (v_lo >= v_hi || v_hi > zk->n_vars || h_lo >= h_hi || h_hi > n) return fail(ZKMI_ERR_INVALID, "groth16: empty or out-of-range key shard");
+    K->v_lo = v_lo; K->v_cnt = v_hi - v_lo; K->h_lo = h_lo; K->h_cnt = h_hi - h_lo;
+    // m = witness-side bases held here; C pairs with witness[nPublic+1:] (:97): c_front = entries of this range that precede it
+    const size_t m = K->v_cnt, first_c = (size_t)zk->n_public + 1;
+    const size_t c_front = first_c > v_lo ? std::min<size_t>(first_c - v_lo, m) : 0, mc = m - c_front;
+    const size_t c_src0 = (v_lo > first_c ? v_lo - first_c : 0);
     // Pre-computed window tables (msm.cuh: k_msm_precompute): the zkey is static, so every base set is expanded once into
     // T[k][i] = 2^(c*k) * P_i. ZKMI_PRECOMP=0 keeps the plain bases (per-window bucket sets); ZKMI_PRECOMP=<c> forces c.
     const char* pe = getenv("ZKMI_PRECOMP");
     const int pc = pe ? atoi(pe) : -1;
     K->cw = pc == 0 ? 0 : (pc > 0 ? pc : msm_precomp_c(m));
-    K->ch = pc == 0 ? 0 : (pc > 0 ? pc : msm_precomp_c(n));
+    K->ch = pc == 0 ? 0 : (pc > 0 ? pc : msm_precomp_c(K->h_cnt));
     auto put_table = [&](void** dst, uint32_t** mask, const uint8_t* src, size_t cnt, size_t pad_front, int group, int c) -> int {
         const size_t pb = group == 1 ? g1 : g2, tot = cnt + pad_front;
         void* raw = nullptr;
@@ -153,13 +162,13 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key) {
         if (c) (void)hipFree(raw);
         return ZKMI_OK;
     };
-    ZK_TRY(put_table(&K->bA, &K->mask[0], zk->bases_a, m, 0, 1, K->cw));
-    ZK_TRY(put_table(&K->bB1, &K->mask[1], zk->bases_b1, m, 0, 1, K->cw));
-    ZK_TRY(put_table(&K->bB2, &K->mask[2], zk->bases_b2, m, 0, 2, K->cw));
-    // C pairs with witness[nPublic+1:] (:97): with tables it is padded in front so that it shares the witness indices
-    ZK_TRY(put_table(&K->bC, &K->mask[3], zk->bases_c, mc, K->cw ? m - mc : 0, 1, K->cw));
-    K->c_skip = K->cw ? 0 : (uint32_t)(m - mc);
-    ZK_TRY(put_table(&K->bH, &K->mask[4], zk->bases_h, (size_t)n, 0, 1, K->ch));
+    ZK_TRY(put_table(&K->bA, &K->mask[0], zk->bases_a + (size_t)v_lo * g1, m, 0, 1, K->cw));
+    ZK_TRY(put_table(&K->bB1, &K->mask[1], zk->bases_b1 + (size_t)v_lo * g1, m, 0, 1, K->cw));
+    ZK_TRY(put_table(&K->bB2, &K->mask[2], zk->bases_b2 + (size_t)v_lo * g2, m, 0, 2, K->cw));
+    // with tables C is padded in front so that it shares the witness indices of this range
+    ZK_TRY(put_table(&K->bC, &K->mask[3], zk->bases_c + c_src0 * g1, mc, K->cw ? c_front : 0, 1, K->cw));
+    K->c_skip = K->cw ? 0 : (uint32_t)c_front;
+    ZK_TRY(put_table(&K->bH, &K->mask[4], zk->bases_h + (size_t)h_lo * g1, (size_t)K->h_cnt, 0, 1, K->ch));
     {   // B is sparse in real circuits (a signal absent from the B matrix has the point at infinity in BOTH B1 and B2, section
         // layout src/zkey_utils.js:183-193): those witness entries are dropped from the digit sort that feeds the B MSMs
         const size_t words = (m + 31) / 32;
@@ -199,7 +208,7 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key) {
     ZK_HIP(hipGetLastError());
     (void)hipFree(raw); (void)hipFree(cursor);
     if (nbad) { K->release(); return fail(ZKMI_ERR_INVALID, "groth16: coefficient record out of range (matrix > 1, constraint >= domain or signal >= nVars)"); }
-    ZK_HIP(hipMalloc((void**)&K->w, m * 32));
+    ZK_HIP(hipMalloc((void**)&K->w, (size_t)zk->n_vars * 32));
     for (uint32_t** p : {&K->A, &K->B, &K->C, &K->T}) ZK_HIP(hipMalloc((void**)p, (size_t)n * 32));
     for (auto& e : K->ev) ZK_HIP(hipEventCreate(&e));
     auto it = cx.groth16.find(key);
@@ -243,12 +252,17 @@ static void g16_finish(const G16Key& K, const uint8_t* jA, const uint8_t* jB1, c
     c1.to_affine(pc, x1, y1); memcpy(pi_c, &x1, B1); memcpy(pi_c + B1, &y1, B1);
 }
 
-template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+// The device part of one proof: the five MSM results of THIS key (shard) as Jacobian points jA | jB1 | jB2 | jC | jH
+// (3*n8q bytes each, 6*n8q for jB2). With the full key they are the MSMs of src/groth16_prove.js:85-101; with a shard they are
+// partial sums over its base-index range, to be added across devices before g16_finish.
+template <class FrC> static int g16_sums_dev(G16Key& K, const void* d_witness, uint8_t* jA, uint8_t* jB1, uint8_t* jB2, uint8_t* jC, uint8_t* jH) {
     Ctx& cx = ctx();
     hipStream_t st = cx.stream;
     const uint32_t n = K.domain;
     const host::HField<4> Fr = host::HField<4>::from_cfg<FrC>();
     const uint32_t* w = (const uint32_t*)d_witness;
+    const uint8_t* w_sh = (const uint8_t*)d_witness + (size_t)K.v_lo * 32;       // scalars of this shard's witness-side bases
+    const uint8_t* h_sh = (const uint8_t*)K.T + (size_t)K.h_lo * 32;
     // The three digit sorts (witness without the B-infinity entries, witness, H scalars) are LDS/latency-bound; the NTT chain and
     // the bucket accumulations are ALU-bound. With ZKMI_OVERLAP (default) the sorts run on the auxiliary stream underneath them
     // and the main stream only waits on their events. ZKMI_OVERLAP=0 keeps everything on one stream.
@@ -268,9 +282,9 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
         ZK_HIP(hipEventRecord(cx.sort_ev[0], st));                   // the witness upload (if any) is ordered before this point
         ZK_HIP(hipStreamWaitEvent(aux, cx.sort_ev[0], 0));
         cx.stream = aux;
-        int rc = msm_sort(d_witness, K.n_vars, 32, split_b ? plb : pl, split_b ? 2 : 0, K.cw, 0, split_b ? K.drop_b : nullptr);
+        int rc = msm_sort(w_sh, K.v_cnt, 32, split_b ? plb : pl, split_b ? 2 : 0, K.cw, 0, split_b ? K.drop_b : nullptr);
         if (!rc) rc = hipEventRecord(cx.sort_ev[1], aux) == hipSuccess ? 0 : fail(ZKMI_ERR_HIP, "hipEventRecord");
-        if (!rc && split_b) rc = msm_sort(d_witness, K.n_vars, 32, pl, 0, K.cw);
+        if (!rc && split_b) rc = msm_sort(w_sh, K.v_cnt, 32, pl, 0, K.cw);
         if (!rc) rc = hipEventRecord(cx.sort_ev[2], aux) == hipSuccess ? 0 : fail(ZKMI_ERR_HIP, "hipEventRecord");
         cx.stream = st;
         ZK_TRY(rc);
@@ -294,12 +308,12 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
         ZK_HIP(hipEventRecord(cx.sort_ev[3], st));
         ZK_HIP(hipStreamWaitEvent(aux, cx.sort_ev[3], 0));
         cx.stream = aux;
-        int rc = msm_sort(K.T, n, 32, plh, 1, K.ch);
+        int rc = msm_sort(h_sh, K.h_cnt, 32, plh, 1, K.ch);
         if (!rc) rc = hipEventRecord(cx.sort_ev[4], aux) == hipSuccess ? 0 : fail(ZKMI_ERR_HIP, "hipEventRecord");
         cx.stream = st;
         ZK_TRY(rc);
         ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[1], 0));
-    } else ZK_TRY(msm_sort(d_witness, K.n_vars, 32, split_b ? plb : pl, split_b ? 2 : 0, K.cw, 0, split_b ? K.drop_b : nullptr));
+    } else ZK_TRY(msm_sort(w_sh, K.v_cnt, 32, split_b ? plb : pl, split_b ? 2 : 0, K.cw, 0, split_b ? K.drop_b : nullptr));
     const MsmPlan& pB = split_b ? plb : pl;
     // The G2 MSM goes first: its bucket reduction is pure latency (~50 us per Fq2 point addition, little parallel work), so it
     // also runs on the auxiliary stream, underneath the G1 accumulations.
@@ -314,14 +328,14 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_B1], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bB1, pB, 0, job[1], K.mask[1]));
     if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[2], 0));
-    else if (split_b) ZK_TRY(msm_sort(d_witness, K.n_vars, 32, pl, 0, K.cw));
+    else if (split_b) ZK_TRY(msm_sort(w_sh, K.v_cnt, 32, pl, 0, K.cw));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_A], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bA, pl, 0, job[0], K.mask[0]));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_C], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.c_skip, job[3], K.mask[3]));
     ZK_HIP(hipEventRecord(K.ev[ST_SORT_H], st));
     if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[4], 0));
-    else ZK_TRY(msm_sort(K.T, n, 32, plh, 1, K.ch));
+    else ZK_TRY(msm_sort(h_sh, K.h_cnt, 32, plh, 1, K.ch));
     ZK_HIP(hipEventRecord(K.ev[ST_MSM_H], st));
     // pi_c only needs C + H (:115): when both MSMs have the same bucket shape, H is accumulated into C's buckets and the two share
     // one bucket reduction (ZKMI_MERGE_CH=0 keeps them apart)
@@ -340,13 +354,22 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     ZK_HIP(hipGetLastError());
     for (int i = 0; i < ST_COUNT; i++) { float ms = 0; if (hipEventElapsedTime(&ms, K.ev[i], K.ev[i + 1]) == hipSuccess) K.stage_ms[i] = ms; }
     // the host folds of the G1 jobs run while the G2 reduction may still be finishing on the auxiliary stream
-    uint8_t jA[144], jB1[144], jB2[288], jC[144], jH[144];
     ZK_TRY(msm_fold_dispatch(K.curve, 1, job[0], jA)); ZK_TRY(msm_fold_dispatch(K.curve, 1, job[1], jB1));
     ZK_TRY(msm_fold_dispatch(K.curve, 1, job[3], jC)); ZK_TRY(msm_fold_dispatch(K.curve, 1, job[4], jH));
     if (ov) ZK_HIP(hipStreamSynchronize(cx.aux_stream));
     ZK_TRY(msm_fold_dispatch(K.curve, 2, job[2], jB2));
+    return ZKMI_OK;
+}
+static void g16_finish_dispatch(const G16Key& K, const uint8_t* jA, const uint8_t* jB1, const uint8_t* jB2, const uint8_t* jC, const uint8_t* jH, const uint8_t* r_mont,
+                                const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
     if (K.curve == ZKMI_CURVE_BN128) g16_finish<Fp<Bn254Fq>, Fp2<Bn254Fq>, Bn254Fr>(K, jA, jB1, jB2, jC, jH, r_mont, s_mont, pi_a, pi_b, pi_c);
     else g16_finish<Fp<Bls12381Fq>, Fp2<Bls12381Fq>, Bls12381Fr>(K, jA, jB1, jB2, jC, jH, r_mont, s_mont, pi_a, pi_b, pi_c);
+}
+template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+    if (!K.full()) return fail(ZKMI_ERR_INVALID, "groth16_prove: the key is a shard (use zkmi_groth16_sums_dev + zkmi_groth16_finish)");
+    uint8_t jA[144], jB1[144], jB2[288], jC[144], jH[144];
+    ZK_TRY(g16_sums_dev<FrC>(K, d_witness, jA, jB1, jB2, jC, jH));
+    g16_finish_dispatch(K, jA, jB1, jB2, jC, jH, r_mont, s_mont, pi_a, pi_b, pi_c);
     return ZKMI_OK;
 }
 
@@ -365,7 +388,31 @@ extern "C" {
 int zkmi_groth16_load(const zkmi_groth16_zkey* zkey, uint64_t key) {
     ZK_TRY(require_ctx());
     if (!zkey || !key) return fail(ZKMI_ERR_INVALID, "groth16_load: null zkey or key 0");
-    return g16_load(zkey, key);
+    return g16_load(zkey, key, 0, zkey->n_vars, 0, zkey->domain_size);
+}
+int zkmi_groth16_load_shard(const zkmi_groth16_zkey* zkey, uint64_t key, uint32_t var_lo, uint32_t var_hi, uint32_t h_lo, uint32_t h_hi) {
+    ZK_TRY(require_ctx());
+    if (!zkey || !key) return fail(ZKMI_ERR_INVALID, "groth16_load_shard: null zkey or key 0");
+    return g16_load(zkey, key, var_lo, var_hi, h_lo, h_hi);
+}
+int zkmi_groth16_sums_dev(uint64_t key, const void* d_witness, uint8_t* sums) {
+    ZK_TRY(require_ctx());
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_sums_dev: key not loaded");
+    if (!d_witness || !sums) return fail(ZKMI_ERR_INVALID, "groth16_sums_dev: null argument");
+    g_last_key = key;
+    const size_t j1 = 3 * (size_t)n8q_of(K->curve);
+    uint8_t *jA = sums, *jB1 = sums + j1, *jB2 = sums + 2 * j1, *jC = sums + 4 * j1, *jH = sums + 5 * j1;
+    if (K->curve == ZKMI_CURVE_BN128) return g16_sums_dev<Bn254Fr>(*K, d_witness, jA, jB1, jB2, jC, jH);
+    return g16_sums_dev<Bls12381Fr>(*K, d_witness, jA, jB1, jB2, jC, jH);
+}
+int zkmi_groth16_finish(uint64_t key, const uint8_t* sums, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_finish: key not loaded");
+    if (!sums || !r_mont || !s_mont || !pi_a || !pi_b || !pi_c) return fail(ZKMI_ERR_INVALID, "groth16_finish: null argument");
+    const size_t j1 = 3 * (size_t)n8q_of(K->curve);
+    g16_finish_dispatch(*K, sums, sums + j1, sums + 2 * j1, sums + 4 * j1, sums + 5 * j1, r_mont, s_mont, pi_a, pi_b, pi_c);
+    return ZKMI_OK;
 }
 int zkmi_groth16_release(uint64_t key) {
     auto it = ctx().groth16.find(key);
@@ -392,7 +439,7 @@ int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_
     const uint64_t k = key ? key : 0xffffffffffffffffull;          // key 0: load, prove, release
     if (!g16_find(k) || !key) {
         if (!zkey) return fail(ZKMI_ERR_INVALID, "groth16_prove: key not loaded and no zkey given");
-        ZK_TRY(g16_load(zkey, k));
+        ZK_TRY(g16_load(zkey, k, 0, zkey->n_vars, 0, zkey->domain_size));
     }
     G16Key* K = g16_find(k);
     ZK_HIP(hipMemcpyAsync(K->w, witness, (size_t)K->n_vars * 32, hipMemcpyHostToDevice, ctx().stream));

@@ -53,3 +53,24 @@ def msm_sharded(curve, group_id, local_bases, local_scalars, process_group=None,
     fn = compute or G.multiExpAffine
     part = np.ascontiguousarray(fn(local_bases, local_scalars), dtype=np.uint8)
     return fold_points(curve.id, group_id, all_gather_bytes(part, process_group))
+
+
+def fold_groth16_sums(curve_id, all_sums):
+    """Add the per-rank MSM sums of a sharded Groth16 proof (ProvingKey.sums_raw: jA | jB1 | jB2 | jC | jH) point by point."""
+    q = 32 if curve_id == 0 else 48
+    j1 = 3 * q
+    cuts = [(0, j1, 1), (j1, 2 * j1, 1), (2 * j1, 4 * j1, 2), (4 * j1, 5 * j1, 1), (5 * j1, 6 * j1, 1)]
+    out = np.zeros(7 * j1, np.uint8)
+    for a, b, grp in cuts:
+        out[a:b] = fold_points(curve_id, grp, [np.ascontiguousarray(s[a:b]) for s in all_sums])
+    return out
+
+
+def groth16_prove_sharded(pk, witness, r_mont, s_mont, process_group=None, d_witness=None):
+    """One Groth16 proof with the five MSMs split by base-index range over the ranks of `process_group` (BASELINE configs[2]).
+
+    pk: ProvingKey(zkey, shard=(rank, world)) on every rank; witness: the FULL witness on every rank (buildABC / NTT chain /
+    joinABC are replicated — they need no exchange); r_mont, s_mont: the same blinding draws on every rank. ONE all_gather of
+    the 7*3*n8q-byte partial sums, folded in rank order, so every rank returns the identical (pi_a, pi_b, pi_c)."""
+    part = pk.sums_raw(witness, d_witness=d_witness)
+    return pk.finish_raw(fold_groth16_sums(pk.curve_id, all_gather_bytes(part, process_group)), r_mont, s_mont)

@@ -48,7 +48,9 @@ class ProvingKey:
     """A Groth16 zkey resident on the device (base tables + CSR coefficient table)."""
     _next = 1
 
-    def __init__(self, zkey_bytes):
+    def __init__(self, zkey_bytes, shard=None):
+        """shard = (rank, world): keep only this rank's index range of the five base sections on the device (multi-GPU proofs,
+        BASELINE configs[2]); prove with snarkjs_amd.distributed.groth16_prove_sharded. Default: the whole key."""
         self.zk = zk = binfile.read_groth16_zkey(zkey_bytes)
         self.curve_id, self.curve_name = _curve_from_q(zk["q"])
         self.key = ProvingKey._next
@@ -60,7 +62,35 @@ class ProvingKey:
         self.desc = zkmi.Groth16Zkey(self.curve_id, zk["nVars"], zk["nPublic"], zk["domainSize"], p("coeffs"), self._keep["coeffs"].size,
                                      p("A"), p("B1"), p("B2"), p("C"), p("H"),
                                      p("vk_alpha_1"), p("vk_beta_1"), p("vk_beta_2"), p("vk_delta_1"), p("vk_delta_2"))
-        zkmi.check(zkmi.lib().zkmi_groth16_load(C.byref(self.desc), self.key))
+        self.shard = shard
+        if shard is None:
+            zkmi.check(zkmi.lib().zkmi_groth16_load(C.byref(self.desc), self.key))
+        else:
+            from .distributed import shard_range
+            rank, world = shard
+            (v_lo, v_hi), (h_lo, h_hi) = shard_range(zk["nVars"], rank, world), shard_range(zk["domainSize"], rank, world)
+            zkmi.check(zkmi.lib().zkmi_groth16_load_shard(C.byref(self.desc), self.key, v_lo, v_hi, h_lo, h_hi))
+
+    def sums_raw(self, witness, d_witness=None):
+        """The five MSM sums of this key (shard) for `witness` (full witness): jA | jB1 | jB2 | jC | jH Jacobian bytes."""
+        q = 32 if self.curve_id == 0 else 48
+        sums = np.zeros(7 * 3 * q, np.uint8)
+        buf = None
+        if d_witness is None:
+            buf = zkmi.DeviceBuffer.from_host(zkmi.u8(witness))
+            d_witness = buf.ptr
+        zkmi.check(zkmi.lib().zkmi_groth16_sums_dev(self.key, d_witness, zkmi.ptr(sums)))
+        if buf is not None:
+            buf.free()
+        return sums
+
+    def finish_raw(self, sums, r_mont, s_mont):
+        """blinding + toAffine (src/groth16_prove.js:103-132) of complete MSM sums -> (pi_a, pi_b, pi_c) affine Montgomery bytes"""
+        q = 32 if self.curve_id == 0 else 48
+        pi_a, pi_b, pi_c = np.zeros(2 * q, np.uint8), np.zeros(4 * q, np.uint8), np.zeros(2 * q, np.uint8)
+        r, s, sums = zkmi.u8(r_mont), zkmi.u8(s_mont), zkmi.u8(sums)
+        zkmi.check(zkmi.lib().zkmi_groth16_finish(self.key, zkmi.ptr(sums), zkmi.ptr(r), zkmi.ptr(s), zkmi.ptr(pi_a), zkmi.ptr(pi_b), zkmi.ptr(pi_c)))
+        return pi_a, pi_b, pi_c
 
     def prove_raw(self, witness, r_mont, s_mont, d_witness=None):
         """-> (pi_a, pi_b, pi_c) affine Montgomery bytes. d_witness: device pointer of an already uploaded witness."""

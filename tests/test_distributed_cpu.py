@@ -42,6 +42,34 @@ def _worker(rank, world, port, n, out_dir):
         want = O.to_affine(O.BN128, group, O.msm(O.BN128, group, bases, scalars, m))
         assert np.array_equal(O.to_affine(O.BN128, group, res), want)
         np.save(os.path.join(out_dir, f"r{rank}_g{group}.npy"), res)
+    # sharded Groth16 (BASELINE configs[2]): per-rank MSM sums over the rank's base-index ranges (stubbed with the oracle), ONE
+    # all_gather of the 672-byte sum blocks, fold -> every rank holds the five complete MSM results of src/groth16_prove.js:85-101
+    import synth_zkey
+    from snarkjs_amd import binfile
+    zkey, wtns = synth_zkey.make("bn128", 6, seed=9, use_device=False)
+    zk = binfile.read_groth16_zkey(zkey)
+    w = binfile.read_wtns(wtns)["witness"]
+    m, npub, dom = zk["nVars"], zk["nPublic"], zk["domainSize"]
+    A, B, Cc = O.build_abc(O.BN128, zk["coeffs"], w, m, dom)
+    one, inc = O.fr_one(O.BN128), O.fr_w(O.BN128, 7)
+    A, B, Cc = (O.ntt(O.BN128, O.apply_key(O.BN128, O.ntt(O.BN128, x, inverse=True), one, inc)) for x in (A, B, Cc))
+    h = O.join_abc(O.BN128, A, B, Cc)
+
+    def sums(v_lo, v_hi, h_lo, h_hi):
+        c_lo, c_hi = max(v_lo, npub + 1), max(v_hi, npub + 1)
+        sl = lambda arr, lo, hi, pb: np.ascontiguousarray(arr[lo * pb:hi * pb])
+        msm = lambda grp, bases, sc, k: O.msm(O.BN128, grp, bases, sc, k) if k else np.zeros(96 * grp, np.uint8)
+        return np.concatenate([msm(1, sl(zk["A"], v_lo, v_hi, 64), sl(w, v_lo, v_hi, 32), v_hi - v_lo),
+                               msm(1, sl(zk["B1"], v_lo, v_hi, 64), sl(w, v_lo, v_hi, 32), v_hi - v_lo),
+                               msm(2, sl(zk["B2"], v_lo, v_hi, 128), sl(w, v_lo, v_hi, 32), v_hi - v_lo),
+                               msm(1, sl(zk["C"], c_lo - npub - 1, c_hi - npub - 1, 64), sl(w, c_lo, c_hi, 32), c_hi - c_lo),
+                               msm(1, sl(zk["H"], h_lo, h_hi, 64), sl(h, h_lo, h_hi, 32), h_hi - h_lo)])
+    (v_lo, v_hi), (h_lo, h_hi) = D.shard_range(m, rank, world), D.shard_range(dom, rank, world)
+    total = D.fold_groth16_sums(O.BN128, D.all_gather_bytes(sums(v_lo, v_hi, h_lo, h_hi)))
+    want = sums(0, m, 0, dom)
+    for (a, b, grp) in ((0, 96, 1), (96, 192, 1), (192, 384, 2), (384, 480, 1), (480, 576, 1)):
+        assert np.array_equal(O.to_affine(O.BN128, grp, total[a:b]), O.to_affine(O.BN128, grp, want[a:b])), (a, b)
+    np.save(os.path.join(out_dir, f"r{rank}_g16.npy"), total)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,5 +93,5 @@ def test_shard_range_covers_everything():
 
 def test_sharded_msm_gloo_world2(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), 600, str(tmp_path)), nprocs=2, join=True)
-    for g in (1, 2):       # every rank holds the same bytes (fold in rank order)
+    for g in (1, 2, 16):       # every rank holds the same bytes (fold in rank order)
         assert np.array_equal(np.load(tmp_path / f"r0_g{g}.npy"), np.load(tmp_path / f"r1_g{g}.npy"))

@@ -429,3 +429,36 @@ def test_soak_many_proofs_same_key(zk):
     key.release()
     pk.release()
     assert free_bytes() >= free0 - (64 << 20)
+
+
+@pytest.mark.parametrize("name,lg,world", [("bn128", 12, 3), ("bn128", 16, 8), ("bls12381", 12, 2), ("bn128", 10, 1)])
+def test_groth16_sharded_equals_single_device(zk, name, lg, world):
+    """BASELINE configs[2] (MSMs sharded across the GPUs of a node by base-index range): the `world` key shards are loaded one after
+    the other on this one GPU, their partial MSM sums are folded as the ranks would after the all_gather, and the finished proof
+    must equal the single-device proof bit for bit (and the CPU oracle's at the small sizes)."""
+    import synth_zkey
+    from snarkjs_amd import groth16, binfile
+    from snarkjs_amd import distributed as D
+    c = O.CURVE_ID[name]
+    zkey, wtns = synth_zkey.make(name, lg, seed=0x5A4D + lg, n_public=3)
+    w = binfile.read_wtns(wtns)["witness"]
+    r_m, s_m = O.fr_e(c, 0xAAA1), O.fr_e(c, 0xBBB2)
+    full = groth16.ProvingKey(zkey)
+    want = [bytes(x) for x in full.prove_raw(w, r_m, s_m)]
+    # sums + finish on the full key is the same thing as prove
+    assert [bytes(x) for x in full.finish_raw(full.sums_raw(w), r_m, s_m)] == want
+    full.release()
+    parts = []
+    for rank in range(world):
+        pk = groth16.ProvingKey(zkey, shard=(rank, world))
+        parts.append(pk.sums_raw(w))
+        if world > 1:
+            with pytest.raises(Exception):
+                pk.prove_raw(w, r_m, s_m)                  # a shard cannot finish a proof on its own
+        last = pk if rank == world - 1 else pk.release()
+    got = [bytes(x) for x in last.finish_raw(D.fold_groth16_sums(c, parts), r_m, s_m)]
+    last.release()
+    assert got == want
+    if lg <= 12:
+        ref = O.groth16_prove(c, binfile.read_groth16_zkey(zkey), w, r_m, s_m)
+        assert got == [bytes(x) for x in ref]
