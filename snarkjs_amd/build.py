@@ -69,7 +69,7 @@ def build_addon(verbose=False):
     if not _stale(out, [src, LIB, os.path.join(os.path.dirname(HERE), "include", "zkmi.h")]):
         return out
     cmd = ["gcc", "-O2", "-shared", "-fPIC", "-Wall", "-DNODE_GYP_MODULE_NAME=zkmi_napi", "-I" + inc, src, "-o", out,
-           "-L" + HERE, "-lzkmi", "-Wl,-rpath,$ORIGIN/.."]
+           "-L" + HERE, "-lzkmi", "-ldl", "-Wl,-rpath,$ORIGIN/.."]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

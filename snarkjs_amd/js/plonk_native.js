@@ -1,0 +1,298 @@
+// snarkjs_amd/js/plonk_native.js — plonk.prove on the MI355X from Node.js (opt-in fused driver, SURVEY.md §8 f2).
+//
+// Same inputs and outputs as the reference driver (src/plonk_prove.js:47-888: zkey + wtns bytes in, {proof, publicSignals} out,
+// same checks and error messages); every O(n) step runs in libzkmi on device-resident polynomials, reached through the addon's
+// generic `call(name, ...)` binding of the C-ABI (napi/zkmi_napi.c).  This file is the JavaScript twin of snarkjs_amd/plonk.py
+// (which the pytest parity suite drives): the reference's Polynomial / Evaluations objects become handles on device buffers and
+// each of their methods one C entry point.  The host keeps what is O(1) in the reference too: the Keccak transcript
+// (zkmi_keccak256), challenges, a handful of field operations (BigInt), and calculateAdditions (a sequential chain).
+//
+//   const { prove } = require("snarkjs_amd/js/plonk_native.js");
+//   const { proof, publicSignals } = prove(zkeyBytes, wtnsBytes);          // synchronous; throws without a GPU (no fallback)
+"use strict";
+const path = require("path");
+const crypto = require("crypto");
+const addon = require(path.join(__dirname, "..", "napi", "zkmi_napi.node"));
+const call = (name, ...a) => addon.call(name, ...a);
+
+const R_BN = 21888242871839275222246405745257275088548364400416034343698204186575808495617n;
+const Q_BN = 21888242871839275222246405745257275088696311157297823662689037894645226208583n;
+const R_BLS = 52435875175126190479447740508185965837690552500527637822603658699938581184513n;
+const Q_BLS = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaabn;
+
+const mod = (a, m) => { const x = a % m; return x < 0n ? x + m : x; };
+function modinv(a, m) {
+    let [r0, r1, s0, s1] = [mod(a, m), m, 1n, 0n];
+    while (r1 !== 0n) { const q = r0 / r1; [r0, r1] = [r1, r0 - q * r1]; [s0, s1] = [s1, s0 - q * s1]; }
+    if (r0 !== 1n) throw new Error("not invertible");
+    return mod(s0, m);
+}
+function modpow(b, e, m) { let r = 1n; b = mod(b, m); while (e > 0n) { if (e & 1n) r = r * b % m; b = b * b % m; e >>= 1n; } return r; }
+function toLE(v, n) { const o = new Uint8Array(n); for (let i = 0; i < n; i++) { o[i] = Number(v & 0xffn); v >>= 8n; } return o; }
+function fromLE(b) { let v = 0n; for (let i = b.length - 1; i >= 0; i--) v = (v << 8n) | BigInt(b[i]); return v; }
+function toBE(v, n) { return toLE(v, n).reverse(); }
+function fromBE(b) { let v = 0n; for (let i = 0; i < b.length; i++) v = (v << 8n) | BigInt(b[i]); return v; }
+
+class Field {
+    constructor(cid) {
+        this.cid = cid; this.r = cid === 0 ? R_BN : R_BLS; this.q = cid === 0 ? Q_BN : Q_BLS; this.n8q = cid === 0 ? 32 : 48;
+        this.Rr = mod(1n << 256n, this.r); this.Rri = modinv(this.Rr, this.r);
+        this.Rqi = modinv(mod(1n << BigInt(8 * this.n8q), this.q), this.q);
+    }
+    mont(v) { return toLE(mod(v, this.r) * this.Rr % this.r, 32); }                 // BigInt -> 32 Montgomery bytes
+    unmont(b) { return fromLE(b) * this.Rri % this.r; }
+    unmontQ(b) { return fromLE(b) * this.Rqi % this.q; }
+    root(i) { const o = new Uint8Array(32); call("zkmi_fr_root", this.cid, i, o); return o; }
+}
+
+// ---- device memory ------------------------------------------------------------------------------------------------------
+function devAlloc(bytes) {
+    const out = new Uint8Array(8);
+    call("zkmi_dev_alloc", Math.max(bytes, 32), out);
+    return Number(new DataView(out.buffer).getBigUint64(0, true));
+}
+const devFree = (p) => { if (p) call("zkmi_dev_free", p); };
+function devFrom(host) { const p = devAlloc(host.length); if (host.length) call("zkmi_memcpy_h2d", p, host, host.length); return p; }
+
+// the reference's Polynomial / Evaluations: n Montgomery Fr elements in device memory
+class Poly {
+    constructor(f, n, zero = true) { this.f = f; this.n = n; this.ptr = devAlloc(n * 32); if (zero) call("zkmi_memset_dev", this.ptr, 0, n * 32); }
+    at(i) { return this.ptr + 32 * i; }
+    copyFrom(src, count, dstOff = 0) { call("zkmi_memcpy_d2d", this.at(dstOff), src, count * 32); return this; }
+    get(i) { const o = new Uint8Array(32); call("zkmi_memcpy_d2h", o, this.at(i), 32); return this.f.unmont(o); }
+    set(i, v) { call("zkmi_memcpy_h2d", this.at(i), this.f.mont(v), 32); }
+    axpy(other, k = null, sub = false) { call("zkmi_poly_axpy_dev", this.f.cid, this.ptr, other.ptr, other.n, k === null ? null : this.f.mont(k), sub ? 1 : 0); }
+    scale(k) { call("zkmi_poly_scale_dev", this.f.cid, this.ptr, this.n, this.f.mont(k)); }
+    addScalar(v) { call("zkmi_poly_add_scalar_dev", this.f.cid, this.ptr, this.f.mont(v)); }
+    evaluate(x) { const o = new Uint8Array(32); call("zkmi_poly_evaluate_dev", this.f.cid, this.ptr, this.n, this.f.mont(x), o); return this.f.unmont(o); }
+    tailIsZero(start) { const z = new Int32Array(1); call("zkmi_poly_is_zero_dev", this.f.cid, this.at(start), this.n - start, z); return z[0] === 1; }
+    blinded(factors) {                                                   // blindCoefficients (polynomial.js:68-93)
+        const out = new Poly(this.f, this.n + factors.length).copyFrom(this.ptr, this.n);
+        const fb = new Uint8Array(32 * factors.length);
+        factors.forEach((x, i) => fb.set(this.f.mont(x), 32 * i));
+        call("zkmi_poly_blind_dev", this.f.cid, out.ptr, this.n, fb, factors.length);
+        return out;
+    }
+    ntt(inverse, out = null) { out = out || new Poly(this.f, this.n, false); call("zkmi_ntt_dev", this.f.cid, this.ptr, out.ptr, Math.log2(this.n), inverse ? 1 : 0, null, null); return out; }
+    extendedEvals(ext) { const e = new Poly(this.f, this.n * ext).copyFrom(this.ptr, this.n); return e.ntt(false, e); }   // Evaluations.fromPolynomial
+    free() { devFree(this.ptr); this.ptr = 0; }
+}
+
+function readSections(data) {
+    const dv = new DataView(data.buffer, data.byteOffset, data.byteLength), s = {};
+    let off = 12;
+    for (let i = 0, k = dv.getUint32(8, true); i < k; i++) {
+        const t = dv.getUint32(off, true), ln = Number(dv.getBigUint64(off + 4, true));
+        s[t] = [off + 12, ln];
+        off += 12 + ln;
+    }
+    return { dv, s };
+}
+
+// A PLONK zkey resident on the device (src/zkey_utils.js:261-299)
+class PlonkKey {
+    constructor(zkey) {
+        const data = zkey instanceof Uint8Array ? zkey : new Uint8Array(zkey);
+        const { dv, s } = readSections(data);
+        if (dv.getUint32(s[1][0], true) !== 2) throw new Error("zkey file is not plonk");                  // plonk_prove.js:60-62
+        let off = s[2][0];
+        const n8q = dv.getUint32(off, true), q = fromLE(data.subarray(off + 4, off + 4 + n8q)); off += 4 + n8q;
+        const n8r = dv.getUint32(off, true); this.r = fromLE(data.subarray(off + 4, off + 4 + n8r)); off += 4 + n8r;
+        if (q === Q_BN) { this.curveId = 0; this.curveName = "bn128"; } else if (q === Q_BLS) { this.curveId = 1; this.curveName = "bls12381"; } else throw new Error(`Curve not supported: ${q}`);
+        const f = this.f = new Field(this.curveId);
+        this.nVars = dv.getUint32(off, true); this.nPublic = dv.getUint32(off + 4, true); this.n = dv.getUint32(off + 8, true);
+        this.nAdditions = dv.getUint32(off + 12, true); this.nConstraints = dv.getUint32(off + 16, true); off += 20;
+        this.power = Math.log2(this.n);
+        this.k1 = f.unmont(data.subarray(off, off + 32)); this.k2 = f.unmont(data.subarray(off + 32, off + 64)); off += 64;
+        this.commit = {};
+        for (const nm of ["Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"]) { this.commit[nm] = [f.unmontQ(data.subarray(off, off + n8q)), f.unmontQ(data.subarray(off + n8q, off + 2 * n8q))]; off += 2 * n8q; }
+        addon.init(0);
+        this.additions = data.subarray(s[3][0], s[3][0] + s[3][1]);
+        this.dev = {};
+        for (let t = 4; t <= 14; t++) if (s[t] && s[t][1]) this.dev[t] = devFrom(data.subarray(s[t][0], s[t][0] + s[t][1]));
+        this.nPtau = s[14][1] / (2 * n8q);
+        const h = new Uint8Array(8);
+        call("zkmi_msm_table_build", this.curveId, 1, this.dev[14], this.nPtau, h);     // the SRS is static: window tables, built once
+        this.ptauTable = Number(new DataView(h.buffer).getBigUint64(0, true));
+    }
+    sec(t, elemOff = 0) { return this.dev[t] + 32 * elemOff; }
+    release() { for (const t of Object.keys(this.dev)) devFree(this.dev[t]); this.dev = {}; if (this.ptauTable) { call("zkmi_msm_table_release", this.ptauTable); this.ptauTable = 0; } }
+}
+
+class Transcript {                                          // src/Keccak256Transcript.js
+    constructor(f) { this.f = f; this.parts = []; }
+    reset() { this.parts = []; }
+    point(p) { this.parts.push(toBE(p[0], this.f.n8q), toBE(p[1], this.f.n8q)); }
+    scalar(v) { this.parts.push(toBE(v, 32)); }
+    challenge() {
+        if (!this.parts.length) throw new Error("Keccak256Transcript: No data to generate a transcript");
+        const msg = Buffer.concat(this.parts.map((x) => Buffer.from(x))), out = new Uint8Array(32);
+        call("zkmi_keccak256", new Uint8Array(msg.buffer, msg.byteOffset, msg.length), msg.length, out);
+        return fromBE(out) % this.f.r;
+    }
+}
+
+// Polynomial.multiExponentiation (polynomial.js:970-977) for the commitments of one round
+function commit(key, polys) {
+    const f = key.f, cnt = polys.length;
+    const scs = polys.map((p) => { const sc = devAlloc(p.n * 32); call("zkmi_fr_batch_dev", f.cid, 1, p.ptr, sc, p.n); return sc; });     // batchFromMontgomery
+    const jac = new Uint8Array(cnt * 3 * f.n8q), ptrs = new BigUint64Array(cnt), ks = new BigUint64Array(cnt);
+    polys.forEach((p, i) => { ptrs[i] = BigInt(scs[i]); ks[i] = BigInt(p.n); });
+    call("zkmi_msm_table_multi_dev", key.ptauTable, ptrs, ks, cnt, 32, jac);
+    const out = [];
+    for (let i = 0; i < cnt; i++) {
+        const aff = new Uint8Array(2 * f.n8q);
+        call("zkmi_to_affine", f.cid, 1, jac.slice(i * 3 * f.n8q, (i + 1) * 3 * f.n8q), aff);
+        out.push([f.unmontQ(aff.subarray(0, f.n8q)), f.unmontQ(aff.subarray(f.n8q))]);
+    }
+    scs.forEach(devFree);
+    return out;
+}
+
+// plonk.prove(zkey, wtns[, blindingMont]): blindingMont = the 11 Fr.random() draws (:224-227) as 32-byte Montgomery values, for
+// bit-exact reproduction of a reference proof; default = fresh randomness.
+function prove(zkey, wtns, blindingMont = null) {
+    const key = zkey instanceof PlonkKey ? zkey : new PlonkKey(zkey);
+    const polys = [];
+    const P = (n, zero = true) => { const p = new Poly(key.f, n, zero); polys.push(p); return p; };
+    const track = (p) => { polys.push(p); return p; };
+    try {
+        return proveWith(key, wtns instanceof Uint8Array ? wtns : new Uint8Array(wtns), blindingMont, P, track);
+    } finally {
+        polys.forEach((p) => p.free());
+        if (!(zkey instanceof PlonkKey)) key.release();
+    }
+}
+
+function proveWith(key, wt, blindingMont, P, track) {
+    const f = key.f, r = f.r, n = key.n, power = key.power;
+    const { dv, s: ws } = readSections(wt);
+    const n8 = dv.getUint32(ws[1][0], true), wq = fromLE(wt.subarray(ws[1][0] + 4, ws[1][0] + 4 + n8)), nWitness = dv.getUint32(ws[1][0] + 4 + n8, true);
+    if (key.r !== wq) throw new Error("Curve of the witness does not match the curve of the proving key");
+    if (nWitness !== key.nVars - key.nAdditions) throw new Error(`Invalid witness length. Circuit: ${key.nVars}, witness: ${nWitness}, ${key.nAdditions}`);
+    if (ws[2][1] < nWitness * 32 || ws[2][0] + nWitness * 32 > wt.length) throw new Error("Invalid witness length: the wtns data section is shorter than its header says");
+    const wit = wt.slice(ws[2][0], ws[2][0] + nWitness * 32);
+    const pub = [];
+    for (let i = 1; i <= key.nPublic; i++) pub.push(fromLE(wit.subarray(32 * i, 32 * i + 32)));
+    wit.fill(0, 0, 32);                                                                                     // :94-96
+    const b = [0n];
+    for (let i = 0; i < 11; i++) b.push(blindingMont ? f.unmont(blindingMont[i]) : fromLE(crypto.randomBytes(64)) % r);
+
+    // calculateAdditions (:174-204): sequential, on the host
+    const internal = [], nW = key.nVars - key.nAdditions;
+    const getWitness = (idx) => idx < nW ? fromLE(wit.subarray(32 * idx, 32 * idx + 32)) : (idx < key.nVars ? internal[idx - nW] : 0n);
+    const adv = new DataView(key.additions.buffer, key.additions.byteOffset, key.additions.byteLength);
+    for (let i = 0; i < key.nAdditions; i++) {
+        const o = 72 * i, s1 = adv.getUint32(o, true), s2 = adv.getUint32(o + 4, true);
+        const f1 = f.unmont(key.additions.subarray(o + 8, o + 40)), f2 = f.unmont(key.additions.subarray(o + 40, o + 72));
+        internal.push((f1 * getWitness(s1) + f2 * getWitness(s2)) % r);
+    }
+    const dWit = devFrom(wit), intBytes = new Uint8Array(Math.max(32, 32 * internal.length));
+    internal.forEach((v, i) => intBytes.set(toLE(v, 32), 32 * i));
+    const dInt = devFrom(intBytes);
+    try {
+        const tr = new Transcript(f), pts = {}, evs = {};
+        const wN = f.root(power), w4N = f.root(power + 2), w2 = f.root(2), mont = (v) => f.mont(v);
+
+        // ---- ROUND 1 (:222-313)
+        const A = P(n, false), B = P(n, false), Cw = P(n, false);
+        call("zkmi_plonk_gather_wires_dev", f.cid, dWit, nW, dInt, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n, A.ptr, B.ptr, Cw.ptr);
+        for (const p of [A, B, Cw]) call("zkmi_fr_batch_dev", f.cid, 0, p.ptr, p.ptr, n);                  // batchToMontgomery
+        let pA = track(A.ntt(true)), pB = track(B.ntt(true)), pC = track(Cw.ntt(true));
+        const eA = track(pA.extendedEvals(4)), eB = track(pB.extendedEvals(4)), eC = track(pC.extendedEvals(4));
+        pA = track(pA.blinded([b[2], b[1]])); pB = track(pB.blinded([b[4], b[3]])); pC = track(pC.blinded([b[6], b[5]]));
+        [pts.A, pts.B, pts.C] = commit(key, [pA, pB, pC]);
+
+        // ---- ROUND 2 (:315-455)
+        tr.reset();
+        for (const nm of ["Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"]) tr.point(key.commit[nm]);
+        for (let i = 0; i < key.nPublic; i++) tr.scalar(A.get(i));
+        for (const nm of ["A", "B", "C"]) tr.point(pts[nm]);
+        const beta = tr.challenge();
+        tr.reset(); tr.scalar(beta);
+        const gamma = tr.challenge();
+        const Zb = P(n, false);
+        call("zkmi_plonk_compute_z_dev", f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), n, mont(beta), mont(gamma), mont(key.k1), mont(key.k2), wN, Zb.ptr);
+        let pZ = track(Zb.ntt(true));
+        const eZ = track(pZ.extendedEvals(4));
+        pZ = track(pZ.blinded([b[9], b[8], b[7]]));
+        [pts.Z] = commit(key, [pZ]);
+
+        // ---- ROUND 3 (:457-684)
+        tr.reset(); tr.scalar(beta); tr.scalar(gamma); tr.point(pts.Z);
+        const alpha = tr.challenge();
+        const ev = new BigUint64Array([eA.ptr, eB.ptr, eC.ptr, eZ.ptr, key.sec(7, n), key.sec(8, n), key.sec(9, n), key.sec(10, n), key.sec(11, n),
+                                       key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), key.sec(13), A.ptr].map(BigInt));      // zkmi_plonk_evals
+        const T = P(4 * n, false), Tz = P(4 * n, false), blind = new Uint8Array(11 * 32);
+        for (let i = 1; i <= 11; i++) blind.set(mont(b[i]), 32 * (i - 1));
+        call("zkmi_plonk_compute_t_dev", f.cid, ev, n, key.nPublic, blind, mont(beta), mont(gamma), mont(alpha), mont(key.k1), mont(key.k2), wN, w4N, w2, T.ptr, Tz.ptr);
+        const pT = T.ntt(true, T);
+        call("zkmi_poly_div_zh_dev", f.cid, pT.ptr, 4 * n, n, 4);
+        const pTz = Tz.ntt(true, Tz);
+        pT.axpy(pTz);
+        if (!pT.tailIsZero(3 * n + 6)) throw new Error("T Polynomial is not well calculated");            // :645-647
+        const T1 = P(n + 1).copyFrom(pT.at(0), n), T2 = P(n + 1).copyFrom(pT.at(n), n), T3 = P(n + 6).copyFrom(pT.at(2 * n), n + 6);
+        T1.set(n, b[10]);
+        T2.set(0, mod(T2.get(0) - b[10], r)); T2.set(n, b[11]);
+        T3.set(0, mod(T3.get(0) - b[11], r));
+        [pts.T1, pts.T2, pts.T3] = commit(key, [T1, T2, T3]);
+
+        // ---- ROUND 4 (:686-708)
+        tr.reset(); tr.scalar(alpha);
+        for (const nm of ["T1", "T2", "T3"]) tr.point(pts[nm]);
+        const xi = tr.challenge(), wv = f.unmont(wN), xiw = xi * wv % r;
+        const S1c = P(n, false).copyFrom(key.sec(12, 0), n), S2c = P(n, false).copyFrom(key.sec(12, 5 * n), n), S3c = P(n, false).copyFrom(key.sec(12, 10 * n), n);
+        evs.eval_a = pA.evaluate(xi); evs.eval_b = pB.evaluate(xi); evs.eval_c = pC.evaluate(xi);
+        evs.eval_s1 = S1c.evaluate(xi); evs.eval_s2 = S2c.evaluate(xi); evs.eval_zw = pZ.evaluate(xiw);
+
+        // ---- ROUND 5 (:710-888)
+        tr.reset(); tr.scalar(xi);
+        for (const k of ["eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw"]) tr.scalar(evs[k]);
+        const v = [0n, tr.challenge()];
+        for (let i = 2; i < 6; i++) v.push(v[i - 1] * v[1] % r);
+        const xin = modpow(xi, BigInt(n), r), zh = mod(xin - 1n, r), N = BigInt(n);
+        const Lg = [0n];
+        let ww = 1n;
+        for (let i = 1; i <= Math.max(1, key.nPublic); i++) { Lg.push(ww * zh % r * modinv(N * mod(xi - ww, r) % r, r) % r); ww = ww * wv % r; }
+        const evalL1 = mod(xin - 1n, r) * modinv(N * mod(xi - 1n, r) % r, r) % r;
+        let evalPi = 0n;
+        pub.forEach((p, i) => { evalPi = mod(evalPi - p * Lg[i + 1], r); });
+        const { eval_a: ea, eval_b: eb, eval_c: ec, eval_s1: es1, eval_s2: es2, eval_zw: ezw } = evs;
+        const alpha2 = alpha * alpha % r, betaxi = beta * xi % r;
+        const e2 = (ea + betaxi + gamma) * (eb + betaxi * key.k1 + gamma) % r * (ec + betaxi * key.k2 + gamma) % r * alpha % r;
+        const e3 = (ea + beta * es1 + gamma) * (eb + beta * es2 + gamma) % r * ezw % r * alpha % r;
+        const e4 = evalL1 * alpha2 % r;
+        const Rp = P(n + 6);
+        for (const [t, k] of [[7, ea * eb % r], [8, ea], [9, eb], [10, ec], [11, null]]) { const qp = new Poly(f, n, false).copyFrom(key.sec(t, 0), n); Rp.axpy(qp, k); qp.free(); }
+        Rp.axpy(pZ, e2);
+        Rp.axpy(S3c, e3 * beta % r, true);
+        Rp.axpy(pZ, e4);
+        const tmp = P(n + 6).copyFrom(T3.ptr, n + 6);
+        tmp.scale(xin * xin % r);
+        tmp.axpy(T2, xin);
+        tmp.axpy(T1);
+        tmp.scale(zh);
+        Rp.axpy(tmp, null, true);
+        Rp.addScalar(mod(evalPi - e3 * mod(ec + gamma, r) - e4, r));
+        const Wxi = P(n + 6);
+        Wxi.axpy(Rp);
+        for (const [p, k] of [[pA, v[1]], [pB, v[2]], [pC, v[3]], [S1c, v[4]], [S2c, v[5]]]) Wxi.axpy(p, k);
+        Wxi.addScalar(mod(-(v[1] * ea + v[2] * eb + v[3] * ec + v[4] * es1 + v[5] * es2), r));
+        call("zkmi_poly_div_by_zerofier_dev", f.cid, Wxi.ptr, Wxi.n, 1, mont(xi));
+        const Wxiw = P(pZ.n, false).copyFrom(pZ.ptr, pZ.n);
+        Wxiw.addScalar(mod(-ezw, r));
+        call("zkmi_poly_div_by_zerofier_dev", f.cid, Wxiw.ptr, Wxiw.n, 1, mont(xiw));
+        [pts.Wxi, pts.Wxiw] = commit(key, [Wxi, Wxiw]);
+
+        const proof = {};
+        for (const nm of ["A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"]) proof[nm] = [pts[nm][0].toString(), pts[nm][1].toString(), "1"];   // src/proof.js:61-83
+        for (const k of ["eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw"]) proof[k] = evs[k].toString();
+        proof.protocol = "plonk";
+        proof.curve = key.curveName;
+        return { proof, publicSignals: pub.map((p) => p.toString()) };
+    } finally {
+        devFree(dWit); devFree(dInt);
+    }
+}
+
+module.exports = { prove, PlonkKey };

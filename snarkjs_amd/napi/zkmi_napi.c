@@ -7,6 +7,8 @@
  *
  * Build (snarkjs_amd/build.py):  gcc -shared -fPIC -I/usr/include/node zkmi_napi.c -o zkmi_napi.node -L.. -lzkmi
  */
+#define _GNU_SOURCE
+#include <dlfcn.h>
 #include <node_api.h>
 #include <stdbool.h>
 #include <stdint.h>
@@ -248,11 +250,55 @@ static napi_value js_groth16_release(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* call(name, ...args) -> 0 — generic binding of any `int zkmi_*(...)` entry point of include/zkmi.h whose parameters are all
+ * integers or pointers (every *_dev function is): numbers pass as 64-bit integers (device pointers fit a double's 53 bits),
+ * typed arrays as their data pointer, null/undefined as NULL. Used by js/plonk_native.js, which drives the device-resident
+ * PLONK prover from Node the way snarkjs_amd/plonk.py does from Python. Throws Error(zkmi_last_error()) on a non-zero return. */
+typedef int (*zk_fn16)(uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t,
+                       uintptr_t, uintptr_t, uintptr_t, uintptr_t);
+static void* zk_lib_handle(void) {
+    static void* h = NULL;
+    if (!h) {
+        Dl_info di;
+        if (dladdr((void*)&zkmi_init, &di) && di.dli_fname) h = dlopen(di.dli_fname, RTLD_NOW | RTLD_NOLOAD);
+    }
+    return h;
+}
+static napi_value js_call(napi_env env, napi_callback_info info) {
+    size_t argc = 17; napi_value argv[17];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 1) { napi_throw_type_error(env, NULL, "zkmi.call: function name expected"); return NULL; }
+    char name[96]; size_t nl = 0;
+    if (napi_get_value_string_utf8(env, argv[0], name, sizeof name, &nl) != napi_ok || strncmp(name, "zkmi_", 5)) BAD_ARG();
+    void* h = zk_lib_handle();
+    zk_fn16 fn = h ? (zk_fn16)dlsym(h, name) : NULL;
+    if (!fn) { napi_throw_error(env, NULL, "zkmi.call: no such entry point"); return NULL; }
+    uintptr_t a[16] = {0};
+    for (size_t i = 1; i < argc && i <= 16; i++) {
+        napi_valuetype t;
+        NAPI_OK(napi_typeof(env, argv[i], &t));
+        if (t == napi_number) { double d; NAPI_OK(napi_get_value_double(env, argv[i], &d)); a[i - 1] = (uintptr_t)(int64_t)d; }
+        else if (t == napi_null || t == napi_undefined) a[i - 1] = 0;
+        else {
+            bool is_ta = false;
+            if (napi_is_typedarray(env, argv[i], &is_ta) != napi_ok || !is_ta) BAD_ARG();
+            napi_typedarray_type tt; size_t len; void* data; napi_value ab; size_t off;
+            NAPI_OK(napi_get_typedarray_info(env, argv[i], &tt, &len, &data, &ab, &off));
+            a[i - 1] = (uintptr_t)data;
+        }
+    }
+    int rc = fn(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
+    if (rc) return throw_zkmi(env, rc);
+    napi_value z;
+    NAPI_OK(napi_create_int32(env, 0, &z));
+    return z;
+}
+
 static napi_value module_init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"init", js_init}, {"deviceCount", js_device_count}, {"version", js_version}, {"msm", js_msm}, {"releaseBases", js_release_bases},
         {"ntt", js_ntt}, {"frBatch", js_fr_batch}, {"applyKey", js_apply_key}, {"joinABC", js_join_abc}, {"toAffine", js_to_affine},
-        {"groth16Prove", js_groth16_prove}, {"groth16Release", js_groth16_release},
+        {"groth16Prove", js_groth16_prove}, {"groth16Release", js_groth16_release}, {"call", js_call},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -21,7 +21,7 @@ FLAGS = ["--harmony-optional-chaining", "--harmony-nullish"]
 @need_node
 def test_addon_exports_and_no_silent_fallback():
     js = ("const a=require(%r);const want=['init','deviceCount','version','msm','releaseBases','ntt','frBatch','applyKey','joinABC','toAffine',"
-          "'groth16Prove','groth16Release'];for(const k of want) if(typeof a[k]!=='function'){console.log('missing',k);process.exit(3)}"
+          "'groth16Prove','groth16Release','call'];for(const k of want) if(typeof a[k]!=='function'){console.log('missing',k);process.exit(3)}"
           "if(a.deviceCount()==0){try{a.init(0);console.log('init did not throw');process.exit(4)}catch(e){if(!/no HIP device/.test(e.message)){console.log(e.message);process.exit(5)}}}"
           "console.log('ok')") % ADDON
     r = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=120)
@@ -40,3 +40,24 @@ def test_register_glue_against_reference_bundle():
 def test_addon_against_golden_vectors_on_gpu():
     r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "addon_golden.js")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@need_node
+def test_node_fused_plonk_prover_on_gpu():
+    """snarkjs_amd/js/plonk_native.js (device-resident PLONK prover driven from Node) == the reference's seeded proofs"""
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "plonk_native_golden.js")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@need_node
+def test_node_fused_plonk_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    js = ("const {prove}=require(%r);const fs=require('fs');try{prove(new Uint8Array(fs.readFileSync(%r)),new Uint8Array(fs.readFileSync(%r)));console.log('no throw');process.exit(3)}"
+          "catch(e){if(!/no HIP device/.test(e.message)){console.log(e.message);process.exit(4)}console.log('ok')}") % (
+        os.path.join(ROOT, "snarkjs_amd", "js", "plonk_native.js"), os.path.join(ROOT, "tests", "golden", "plonk_bn128_small.zkey"),
+        os.path.join(ROOT, "tests", "golden", "plonk_bn128_small.wtns"))
+    r = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
