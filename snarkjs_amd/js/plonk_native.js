@@ -295,4 +295,5 @@ function proveWith(key, wt, blindingMont, P, track) {
     }
 }
 
-module.exports = { prove, PlonkKey };
+module.exports = { prove, PlonkKey,
+                   _internals: { addon, call, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN } };

@@ -50,6 +50,14 @@ def test_node_fused_plonk_prover_on_gpu():
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.gpu
+@need_node
+def test_node_fused_fflonk_prover_on_gpu():
+    """snarkjs_amd/js/fflonk_native.js == the reference's seeded FFLONK proofs"""
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "fflonk_native_golden.js")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @need_node
 def test_node_fused_plonk_fails_loudly_without_device():
     import torch
