@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--cpu-log-n", type=int, default=14)
+    ap.add_argument("--cpu-log-n", type=int, default=17, help="size of the CPU-baseline sample (2^17: about 15 s of single-thread oracle time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--witness", default="uniform", choices=["uniform", "mixed"])
     ap.add_argument("--curve", default="bn128", choices=["bn128", "bls12381"])
