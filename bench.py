@@ -274,11 +274,12 @@ def main():
         cpre = max(8, min(21, lgv))
         if lgv >= 14:
             cpre = [15, 15, 16, 17, 17, 20, 20, 20][min(max(cpre, 14), 21) - 14]
-        digits = -(-257 // cpre)
-        fmuls = digits * units * 10 * (3 if dom == 2 else 1)
-        int_alu = {"unit": "Gmul/s", "field_muls_upper_bound": fmuls, "achieved": round(fmuls / (acc[dom] * 1e-3) / 1e9, 1), "peak": FIELD_MUL_PEAK_G,
+        digits = -(-254 // cpre) if cid == 0 else -(-255 // cpre)      # non-zero signed digits of a uniform < r scalar (top digits beyond the field size are zero)
+        density = (2.0 / 3.0) if dom in (1, 2) else 1.0             # tests/synth_zkey.py: every third B1 / B2 base is the point at infinity (dropped before the sort)
+        fmuls = int(digits * units * density * (28 if dom == 2 else 10))    # 8M + 2S; in Fq2 a product is 3, a square 2 base-field products
+        int_alu = {"unit": "Gmul/s", "field_muls": fmuls, "achieved": round(fmuls / (acc[dom] * 1e-3) / 1e9, 1), "peak": FIELD_MUL_PEAK_G,
                    "frac": round(fmuls / (acc[dom] * 1e-3) / 1e9 / FIELD_MUL_PEAK_G, 4),
-                   "note": "peak = measured Montgomery-multiply ceiling of the chip (tools/fieldbench, profiles/r01_fieldbench.txt); zero digits and infinity bases are counted, so achieved is an upper bound"}
+                   "note": "field multiplications of the mixed additions of this launch (digits x non-infinity terms x 10 in G1 / 28 in G2; the Fq2 kernel's ~70 additions per mixed addition are not counted) / launch time; peak = measured Montgomery-multiply ceiling of the chip (tools/fieldbench, profiles/r01_fieldbench.txt)"}
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
