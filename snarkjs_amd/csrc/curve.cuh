@@ -59,13 +59,13 @@ template <class C> ZK_DEV Fp<C> fp2_base_mul(const Fp<C>& a, const Fp<C>& b) { r
 // Karatsuba: 3 base-field multiplications
 template <class C> ZK_FP2_OP Fp2<C> f_mul(ZK_FP2_ARG(Fp2<C>) a, ZK_FP2_ARG(Fp2<C>) b) {
     Fp<C> t0 = fp2_base_mul(a.c0, b.c0), t1 = fp2_base_mul(a.c1, b.c1);
-    Fp<C> t2 = fp2_base_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+    Fp<C> t2 = fp2_base_mul(fp_add_noreduce(a.c0, a.c1), fp_add_noreduce(b.c0, b.c1));
     return Fp2<C>{fp_sub(t0, t1), fp_sub(fp_sub(t2, t0), t1)};
 }
 // (a0+a1)(a0-a1) + 2 a0 a1 u : 2 multiplications
 template <class C> ZK_FP2_OP Fp2<C> f_sqr(ZK_FP2_ARG(Fp2<C>) a) {
     Fp<C> t = fp2_base_mul(a.c0, a.c1);
-    return Fp2<C>{fp2_base_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
+    return Fp2<C>{fp2_base_mul(fp_add_noreduce(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
 }
 template <class C> ZK_DEV Fp2<C> f_inv(const Fp2<C>& a) {
     Fp<C> d = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));

@@ -168,6 +168,17 @@ template <class C> ZK_DEV Fp<C> fp_add(const Fp<C>& a, const Fp<C>& b) {
     fp_cond_sub_p<C>(r, t, (uint32_t)c);
     return r;
 }
+// a + b without the final correction: for reduced inputs the sum is < 2p < R/2. Only valid as an operand of fp_mul (the Montgomery
+// product of operands < 2p is still < 2p before its own correction because 4p < R for every modulus here) — used for the operand
+// sums of the Karatsuba Fq2 product.
+template <class C> ZK_DEV Fp<C> fp_add_noreduce(const Fp<C>& a, const Fp<C>& b) {
+    static_assert(C::p(C::N - 1) < 0x40000000u, "fp_add_noreduce needs 4p < R");
+    Fp<C> r;
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; i++) r.l[i] = __builtin_addc(a.l[i], b.l[i], c, &c);
+    return r;
+}
 template <class C> ZK_DEV Fp<C> fp_sub(const Fp<C>& a, const Fp<C>& b) {
     uint32_t t[C::N];
     unsigned bw = 0;
