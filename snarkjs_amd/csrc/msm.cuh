@@ -2,17 +2,19 @@
 //
 // Replaces ffjavascript's engine_multiexp (window tasks over Web Workers, build/snarkjs.min.js:1@213360/@214651)
 // and wasmcurves' g1m_/g2m_multiexpAffine_chunk (@75966): instead of one 2^c-bucket pass per (chunk, window) task
-// with the bases re-copied per window, the whole MSM is five data-parallel device stages over all windows at once:
+// with the bases re-copied per window, the whole MSM is a few data-parallel device stages over all windows at once:
 //
-//   1. k_msm_count    signed-digit recoding of every scalar, histogram of bucket sizes        (global atomics)
-//   2. k_msm_scan_*   exclusive scan of the histogram (all windows, one flat list)            (LDS block scans)
-//   3. k_msm_scatter  counting-sort scatter: per bucket, the list of (point index, sign)
-//   4. k_msm_accum    one lane per bucket: gather bases, XYZZ mixed additions (the hot loop: n·W of them)
-//   5. k_msm_reduce*  per window sum_b (b+1)·B_b: lane-sequential running sums over 8 buckets, then LDS
-//                     suffix-scan + tree levels (depth O(log) instead of the reference's recursive _reduceTable)
+//   1. digit sort     signed-digit recoding of every scalar and, per (window, bucket), the list of (point index, sign):
+//                     k_rsort_* (two-level LDS radix partition, large inputs) or k_msm_count/_scan/_scatter (counting sort with
+//                     wave-aggregated global atomics, small inputs)
+//   2. schedule       k_msm_classify/_class_scan/_assign: load-balanced lane groups (big buckets get 2^j lanes)
+//   3. k_msm_accum    gather bases, XYZZ mixed additions (the hot loop: one per non-zero digit), then k_msm_tree/_giant for the
+//                     lane partials of multi-lane buckets; with resident bases the gather reads pre-computed window tables
+//                     T[k][i] = 2^(c k) P_i (k_msm_precompute) and all digits share ONE set of 2^(c-1) buckets
+//   4. reduction      sum_b (b+1) B_b in 2-D form: k_msm_rowcol + k_msm_fold (row / column sums), then k_msm_wsum or k_msm_bitsums
 //
-// The W per-window points go back to the host, which folds them with c doublings per window (the reference also
-// does this step on the host, @213360).  Signed digits halve the bucket count: 2^(c-1) buckets per window.
+// The per-window (or per-bit) sums go back to the host, which folds them with a few doublings (the reference also recombines
+// windows on the host, @213360).  Signed digits halve the bucket count: 2^(c-1) buckets per window.
 #pragma once
 #include "curve.cuh"
 
