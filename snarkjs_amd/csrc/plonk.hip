@@ -271,8 +271,9 @@ template <class C> ZK_DEV void plonk_t_body(const PlonkTArgs& g, const PowTab& w
     fp_store<C>(g.t + (size_t)i * 8, fp_add(fp_sub(fp_add(e1, e2), e3), e4));
     fp_store<C>(g.tz + (size_t)i * 8, fp_add(fp_sub(fp_add(e1z, e2z), e3z), e4z));
 }
-template <class C> __global__ void __launch_bounds__(256) k_plonk_t(PlonkTArgs g, PowTab w4) { plonk_t_body<C>(g, w4); }
-template <class C, int MINBLK> __global__ void __launch_bounds__(256, MINBLK) k_plonk_t_occ(PlonkTArgs g, PowTab w4) { plonk_t_body<C>(g, w4); }
+// 3 workgroups per CU (168 VGPRs, some scratch): 3.7 ms at 2^20; the compiler's default allocation (256 VGPRs + 146 AGPRs, 1 wave
+// per SIMD) takes 5.5 ms
+template <class C> __global__ void __launch_bounds__(256, 3) k_plonk_t(PlonkTArgs g, PowTab w4) { plonk_t_body<C>(g, w4); }
 
 // ---- FFLONK quotient numerators (src/fflonk_prove.js) ------------------------------------------------------------------------
 // T0 (:415-504): q_L a + q_R b + q_M a b + q_O c + q_C + PI over the 4n extended points
@@ -525,9 +526,7 @@ template <class C> struct PlonkOps {
         g.s1 = (const uint32_t*)ev->s1; g.s2 = (const uint32_t*)ev->s2; g.s3 = (const uint32_t*)ev->s3;
         g.lagrange = (const uint32_t*)ev->lagrange; g.pub_a = (const uint32_t*)ev->pub_a; g.k = dk;
         g.domain = dom; g.n_public = n_public; g.t = (uint32_t*)T; g.tz = (uint32_t*)Tz;
-        static const int occ = getenv("ZKMI_PLONK_T_OCC") ? atoi(getenv("ZKMI_PLONK_T_OCC")) : 3;   // 3 waves/SIMD: 4.6 ms at 2^20 (default bounds: 6.0 ms)
-        if (occ == 3) hipLaunchKernelGGL((k_plonk_t_occ<C, 3>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
-        else hipLaunchKernelGGL((k_plonk_t<C>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        hipLaunchKernelGGL((k_plonk_t<C>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
