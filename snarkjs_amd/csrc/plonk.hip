@@ -223,57 +223,64 @@ template <class C> struct MulZ {
         }
     }
 };
-template <class C> ZK_DEV void plonk_t_body(const PlonkTArgs& g, const PowTab& w4) {
+// One lane per extended evaluation point. The numerator is a sum of four terms with little in common besides the wire values, and
+// the live set of all four together exceeds 256 VGPRs (1 wave per SIMD: 5.5 ms at 2^20, or 3.7 ms with scratch at 3 waves), so it is
+// evaluated in three launches that accumulate into t / tz:  PART 0: e1 + e4 (store),  PART 1: += e2,  PART 2: -= e3.
+template <class C, int PART> __global__ void __launch_bounds__(256, 2) k_plonk_t(PlonkTArgs g, PowTab w4) {
     const uint32_t n4 = 4 * g.domain;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     auto ld = [&](const uint32_t* p, size_t idx) { return fp_load<C>(p + idx * 8); };
     const uint32_t* k = g.k;
     const Fp<C> w = pow_tab<C>(w4, i);                                     // w = Fr.w[power+2]^i
-    const Fp<C> a = ld(g.a, i), b = ld(g.b, i), c = ld(g.c, i), z = ld(g.z, i);
-    const Fp<C> zw = ld(g.z, (n4 + 4 + i) % n4);
-    const Fp<C> beta = kc<C>(k, PK_BETA), gamma = kc<C>(k, PK_GAMMA), alpha = kc<C>(k, PK_ALPHA), alpha2 = kc<C>(k, PK_ALPHA2);
     auto bl = [&](int j) { return kc<C>(k, PK_B1 + j - 1); };              // challenges.b[j]
+    const Fp<C> a = ld(g.a, i), b = ld(g.b, i), c = ld(g.c, i);
     const Fp<C> ap = fp_add(bl(2), fp_mul(bl(1), w)), bp = fp_add(bl(4), fp_mul(bl(3), w)), cp = fp_add(bl(6), fp_mul(bl(5), w));
-    const Fp<C> w2 = fp_sqr(w);
-    const Fp<C> zp = fp_add(fp_add(fp_mul(bl(7), w2), fp_mul(bl(8), w)), bl(9));
-    const Fp<C> wW = fp_mul(w, kc<C>(k, PK_WN)), wW2 = fp_sqr(wW);
-    const Fp<C> zWp = fp_add(fp_add(fp_mul(bl(7), wW2), fp_mul(bl(8), wW)), bl(9));
-    Fp<C> pi = fp_zero<C>();
-    for (uint32_t j = 0; j < g.n_public; j++)
-        pi = fp_sub(pi, fp_mul(ld(g.lagrange, (size_t)j * 5 * g.domain + g.domain + i), ld(g.pub_a, j)));
     MulZ<C> mz;
     mz.p = (i & 3) != 0;
     mz.Z1 = kc<C>(k, PK_Z1 + (i & 3)); mz.Z2 = kc<C>(k, PK_Z2 + (i & 3)); mz.Z3 = kc<C>(k, PK_Z3 + (i & 3));
-    // e1 := a b qM + a qL + b qR + c qO + PI + qC
-    Fp<C> e1, e1z;
-    mz.mul2(a, b, ap, bp, e1, e1z);
-    const Fp<C> qm = ld(g.qm, i), ql = ld(g.ql, i), qr = ld(g.qr, i), qo = ld(g.qo, i);
-    e1 = fp_mul(e1, qm); e1z = fp_mul(e1z, qm);
-    e1 = fp_add(e1, fp_mul(a, ql)); e1z = fp_add(e1z, fp_mul(ap, ql));
-    e1 = fp_add(e1, fp_mul(b, qr)); e1z = fp_add(e1z, fp_mul(bp, qr));
-    e1 = fp_add(e1, fp_mul(c, qo)); e1z = fp_add(e1z, fp_mul(cp, qo));
-    e1 = fp_add(fp_add(e1, pi), ld(g.qc, i));
-    // e2 := alpha (a + beta X + gamma)(b + beta k1 X + gamma)(c + beta k2 X + gamma) z
-    const Fp<C> betaw = fp_mul(beta, w);
-    Fp<C> e2, e2z;
-    mz.mul4(fp_add(fp_add(a, betaw), gamma), fp_add(fp_add(b, fp_mul(betaw, kc<C>(k, PK_K1))), gamma), fp_add(fp_add(c, fp_mul(betaw, kc<C>(k, PK_K2))), gamma), z, ap, bp, cp, zp, e2, e2z);
-    e2 = fp_mul(e2, alpha); e2z = fp_mul(e2z, alpha);
-    // e3 := alpha (a + beta s1 + gamma)(b + beta s2 + gamma)(c + beta s3 + gamma) z(Xw)
-    Fp<C> e3, e3z;
-    mz.mul4(fp_add(fp_add(a, fp_mul(beta, ld(g.s1, i))), gamma), fp_add(fp_add(b, fp_mul(beta, ld(g.s2, i))), gamma), fp_add(fp_add(c, fp_mul(beta, ld(g.s3, i))), gamma), zw, ap, bp, cp, zWp,
-            e3, e3z);
-    e3 = fp_mul(e3, alpha); e3z = fp_mul(e3z, alpha);
-    // e4 := alpha^2 (z - 1) L1
-    const Fp<C> l1 = ld(g.lagrange, (size_t)g.domain + i);
-    const Fp<C> e4 = fp_mul(fp_mul(fp_sub(z, kc<C>(k, PK_ONE)), l1), alpha2);
-    const Fp<C> e4z = fp_mul(fp_mul(zp, l1), alpha2);
-    fp_store<C>(g.t + (size_t)i * 8, fp_add(fp_sub(fp_add(e1, e2), e3), e4));
-    fp_store<C>(g.tz + (size_t)i * 8, fp_add(fp_sub(fp_add(e1z, e2z), e3z), e4z));
+    uint32_t* pt = g.t + (size_t)i * 8;
+    uint32_t* ptz = g.tz + (size_t)i * 8;
+    if constexpr (PART == 0) {
+        // e1 := a b qM + a qL + b qR + c qO + PI + qC ;  e4 := alpha^2 (z - 1) L1
+        Fp<C> pi = fp_zero<C>();
+        for (uint32_t j = 0; j < g.n_public; j++)
+            pi = fp_sub(pi, fp_mul(ld(g.lagrange, (size_t)j * 5 * g.domain + g.domain + i), ld(g.pub_a, j)));
+        Fp<C> e1, e1z;
+        mz.mul2(a, b, ap, bp, e1, e1z);
+        const Fp<C> qm = ld(g.qm, i), ql = ld(g.ql, i), qr = ld(g.qr, i), qo = ld(g.qo, i);
+        e1 = fp_mul(e1, qm); e1z = fp_mul(e1z, qm);
+        e1 = fp_add(e1, fp_mul(a, ql)); e1z = fp_add(e1z, fp_mul(ap, ql));
+        e1 = fp_add(e1, fp_mul(b, qr)); e1z = fp_add(e1z, fp_mul(bp, qr));
+        e1 = fp_add(e1, fp_mul(c, qo)); e1z = fp_add(e1z, fp_mul(cp, qo));
+        e1 = fp_add(fp_add(e1, pi), ld(g.qc, i));
+        const Fp<C> z = ld(g.z, i), alpha2 = kc<C>(k, PK_ALPHA2);
+        const Fp<C> zp = fp_add(fp_add(fp_mul(bl(7), fp_sqr(w)), fp_mul(bl(8), w)), bl(9));
+        const Fp<C> l1 = ld(g.lagrange, (size_t)g.domain + i);
+        fp_store<C>(pt, fp_add(e1, fp_mul(fp_mul(fp_sub(z, kc<C>(k, PK_ONE)), l1), alpha2)));
+        fp_store<C>(ptz, fp_add(e1z, fp_mul(fp_mul(zp, l1), alpha2)));
+    } else {
+        const Fp<C> beta = kc<C>(k, PK_BETA), gamma = kc<C>(k, PK_GAMMA), alpha = kc<C>(k, PK_ALPHA);
+        Fp<C> e, ez;
+        if constexpr (PART == 1) {
+            // e2 := alpha (a + beta X + gamma)(b + beta k1 X + gamma)(c + beta k2 X + gamma) z
+            const Fp<C> zp = fp_add(fp_add(fp_mul(bl(7), fp_sqr(w)), fp_mul(bl(8), w)), bl(9));
+            const Fp<C> betaw = fp_mul(beta, w);
+            mz.mul4(fp_add(fp_add(a, betaw), gamma), fp_add(fp_add(b, fp_mul(betaw, kc<C>(k, PK_K1))), gamma), fp_add(fp_add(c, fp_mul(betaw, kc<C>(k, PK_K2))), gamma), ld(g.z, i), ap, bp,
+                    cp, zp, e, ez);
+            fp_store<C>(pt, fp_add(fp_load<C>(pt), fp_mul(e, alpha)));
+            fp_store<C>(ptz, fp_add(fp_load<C>(ptz), fp_mul(ez, alpha)));
+        } else {
+            // e3 := alpha (a + beta s1 + gamma)(b + beta s2 + gamma)(c + beta s3 + gamma) z(Xw)
+            const Fp<C> wW = fp_mul(w, kc<C>(k, PK_WN));
+            const Fp<C> zWp = fp_add(fp_add(fp_mul(bl(7), fp_sqr(wW)), fp_mul(bl(8), wW)), bl(9));
+            mz.mul4(fp_add(fp_add(a, fp_mul(beta, ld(g.s1, i))), gamma), fp_add(fp_add(b, fp_mul(beta, ld(g.s2, i))), gamma), fp_add(fp_add(c, fp_mul(beta, ld(g.s3, i))), gamma),
+                    ld(g.z, (n4 + 4 + i) % n4), ap, bp, cp, zWp, e, ez);
+            fp_store<C>(pt, fp_sub(fp_load<C>(pt), fp_mul(e, alpha)));
+            fp_store<C>(ptz, fp_sub(fp_load<C>(ptz), fp_mul(ez, alpha)));
+        }
+    }
 }
-// 3 workgroups per CU (168 VGPRs, some scratch): 3.7 ms at 2^20; the compiler's default allocation (256 VGPRs + 146 AGPRs, 1 wave
-// per SIMD) takes 5.5 ms
-template <class C> __global__ void __launch_bounds__(256, 3) k_plonk_t(PlonkTArgs g, PowTab w4) { plonk_t_body<C>(g, w4); }
 
 // ---- FFLONK quotient numerators (src/fflonk_prove.js) ------------------------------------------------------------------------
 // T0 (:415-504): q_L a + q_R b + q_M a b + q_O c + q_C + PI over the 4n extended points
@@ -526,7 +533,9 @@ template <class C> struct PlonkOps {
         g.s1 = (const uint32_t*)ev->s1; g.s2 = (const uint32_t*)ev->s2; g.s3 = (const uint32_t*)ev->s3;
         g.lagrange = (const uint32_t*)ev->lagrange; g.pub_a = (const uint32_t*)ev->pub_a; g.k = dk;
         g.domain = dom; g.n_public = n_public; g.t = (uint32_t*)T; g.tz = (uint32_t*)Tz;
-        hipLaunchKernelGGL((k_plonk_t<C>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        hipLaunchKernelGGL((k_plonk_t<C, 0>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        hipLaunchKernelGGL((k_plonk_t<C, 1>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        hipLaunchKernelGGL((k_plonk_t<C, 2>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
