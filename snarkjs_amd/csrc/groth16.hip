@@ -104,6 +104,7 @@ struct G16Key {
     uint32_t *row_cnt = nullptr, *row_start = nullptr, *sig = nullptr, *val = nullptr;
     uint32_t *w = nullptr, *A = nullptr, *B = nullptr, *C = nullptr, *T = nullptr;
     std::vector<uint8_t> vk_alpha_1, vk_beta_1, vk_beta_2, vk_delta_1, vk_delta_2;
+    mutable std::vector<uint8_t> fb_delta1, fb_delta2;   // host fixed-base tables of delta (g16_finish), built on first use
     hipEvent_t ev[ST_COUNT + 1] = {};
     double stage_ms[ST_COUNT] = {};
     void release() {
@@ -218,6 +219,26 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
 }
 
 // ---- host epilogue: blinding + toAffine (src/groth16_prove.js:103-132) -------------------------------------------------
+// delta_1 is multiplied by r, s and -rs and delta_2 by s in every proof (:107-120): 8-bit fixed-base tables T[w][d] = d 2^(8w) delta
+// (32 x 255 Jacobian points, built once per key) turn each of those 256-bit scalar multiplications into 32 point additions.
+template <class CV> static void fixed_base_build(const CV& cv, const typename CV::P& base, std::vector<uint8_t>& blob) {
+    typedef typename CV::P P;
+    blob.resize((size_t)32 * 255 * sizeof(P));
+    P* t = reinterpret_cast<P*>(blob.data());
+    P b = base;
+    for (int w = 0; w < 32; w++) {
+        t[w * 255] = b;
+        for (int d = 1; d < 255; d++) t[w * 255 + d] = cv.add(t[w * 255 + d - 1], b);
+        for (int k = 0; k < 8; k++) b = cv.dbl(b);
+    }
+}
+template <class CV> static typename CV::P fixed_base_mul(const CV& cv, const std::vector<uint8_t>& blob, const uint8_t* k32) {
+    typedef typename CV::P P;
+    const P* t = reinterpret_cast<const P*>(blob.data());
+    P acc = cv.zero();
+    for (int w = 0; w < 32; w++) if (k32[w]) acc = cv.add(acc, t[w * 255 + k32[w] - 1]);
+    return acc;
+}
 template <class G1F, class G2F, class FrC>
 static void g16_finish(const G16Key& K, const uint8_t* jA, const uint8_t* jB1, const uint8_t* jB2, const uint8_t* jC, const uint8_t* jH,
                        const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
@@ -239,13 +260,24 @@ static void g16_finish(const G16Key& K, const uint8_t* jA, const uint8_t* jB1, c
     bits(r, rb); bits(s, sb); bits(Fr.neg(Fr.mul(r, s)), rsb);
     auto alpha1 = af1(K.vk_alpha_1), beta1 = af1(K.vk_beta_1), delta1 = af1(K.vk_delta_1);
     auto beta2 = af2(K.vk_beta_2), delta2 = af2(K.vk_delta_2);
-    auto pa = c1.add(c1.add(ld1(jA), alpha1), c1.mul_bits(delta1, rb, 256));                   // :106-107
-    auto pb = c2.add(c2.add(ld2(jB2), beta2), c2.mul_bits(delta2, sb, 256));                   // :109-110
-    auto pb1 = c1.add(c1.add(ld1(jB1), beta1), c1.mul_bits(delta1, sb, 256));                  // :112-113
+    if (K.fb_delta1.empty()) { fixed_base_build(c1, delta1, K.fb_delta1); fixed_base_build(c2, delta2, K.fb_delta2); }
+    auto pa = c1.add(c1.add(ld1(jA), alpha1), fixed_base_mul(c1, K.fb_delta1, rb));            // :106-107
+    auto pb = c2.add(c2.add(ld2(jB2), beta2), fixed_base_mul(c2, K.fb_delta2, sb));            // :109-110
+    auto pb1 = c1.add(c1.add(ld1(jB1), beta1), fixed_base_mul(c1, K.fb_delta1, sb));           // :112-113
     auto pc = c1.add(ld1(jC), ld1(jH));                                                        // :115
-    pc = c1.add(pc, c1.mul_bits(pa, sb, 256));                                                 // :118
-    pc = c1.add(pc, c1.mul_bits(pb1, rb, 256));                                                // :119
-    pc = c1.add(pc, c1.mul_bits(delta1, rsb, 256));                                            // :120
+    {   // s*pi_a + r*pib1 (:118-119) in one double-and-add pass (Shamir): one set of doublings for both scalars
+        const auto both = c1.add(pa, pb1);
+        auto acc = c1.zero();
+        for (int i = 255; i >= 0; i--) {
+            acc = c1.dbl(acc);
+            const int bs = (sb[i / 8] >> (i % 8)) & 1, br = (rb[i / 8] >> (i % 8)) & 1;
+            if (bs && br) acc = c1.add(acc, both);
+            else if (bs) acc = c1.add(acc, pa);
+            else if (br) acc = c1.add(acc, pb1);
+        }
+        pc = c1.add(pc, acc);
+    }
+    pc = c1.add(pc, fixed_base_mul(c1, K.fb_delta1, rsb));                                     // :120
     typename F1::E x1, y1; typename F2::E x2, y2;
     c1.to_affine(pa, x1, y1); memcpy(pi_a, &x1, B1); memcpy(pi_a + B1, &y1, B1);               // :130-132
     c2.to_affine(pb, x2, y2); memcpy(pi_b, &x2, B2); memcpy(pi_b + B2, &y2, B2);
