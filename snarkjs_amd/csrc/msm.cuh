@@ -546,7 +546,10 @@ k_msm_rowcol(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_
     const uint32_t cnt = kind ? R : ((i < R) ? C : 0u);
     for (uint32_t e = sub; e < cnt; e += L) {
         const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
-        if (cn[g]) { XYZZ<F> p; pt_load(p, bk + g * PW); acc = pt_add(acc, p); }      // empty buckets were never written
+        if (cn[g]) {                                                                    // empty buckets were never written
+            XYZZ<F> p; pt_load(p, bk + g * PW);
+            if constexpr (FieldWords<F>::value <= 12) acc = pt_add_inl(acc, p); else acc = pt_add(acc, p);     // G1: throughput-bound, inline
+        }
     }
     pt_store(out + tid * PW, acc);
 }
@@ -558,7 +561,10 @@ k_msm_fold(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n
     if (i >= n_out) return;
     XYZZ<F> acc;
     pt_load(acc, in + i * K * PW);
-    for (uint32_t k = 1; k < K; k++) { XYZZ<F> p; pt_load(p, in + (i * K + k) * PW); acc = pt_add(acc, p); }
+    for (uint32_t k = 1; k < K; k++) {
+        XYZZ<F> p; pt_load(p, in + (i * K + k) * PW);
+        if constexpr (FieldWords<F>::value <= 12) acc = pt_add_inl(acc, p); else acc = pt_add(acc, p);
+    }
     pt_store(out + i * PW, acc);
 }
 // One block of M lanes per M consecutive items of an array of m_per_array points; invariant across levels:

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkmi.so")
+LIB_PATH = os.environ.get("ZKMI_LIB", os.path.join(_HERE, "libzkmi.so"))
 
 BN128, BLS12381 = 0, 1
 CURVE_ID = {"bn128": 0, "bn254": 0, "bls12381": 1}
