@@ -4,7 +4,7 @@
 // round trips through postMessage, build/snarkjs.min.js:1@215859/@216834) and wasmcurves' frm_fftMix/_fftJoin/_fftFinal
 // (@103755).  Same function:  X[k] = sum_j x[j] w^(jk),  w = Fr.w[log n],  natural order in and out, inverse scaled
 // by 1/n — but computed in p = ceil(log n / 8) passes over HBM; each pass is a 2^l-point decimation-in-frequency
-// transform of 1024-element tiles held in LDS (Stockham-style: the digit transposition that makes the output
+// transform of 512-element tiles held in LDS (Stockham-style: the digit transposition that makes the output
 // natural-order is folded into the last pass, there is no separate bit-reversal pass).
 //
 // Index algebra (n = N1·N2·…·Np, Ni = 2^li):  j = sum_i j_i·S_i with S_i = prod_{m>i} N_m (j_1 most significant),
@@ -22,10 +22,11 @@ namespace zkmi {
 
 constexpr int NTT_MAX_PASSES = 4;
 #ifndef ZKMI_NTT_TILE_LOG
-#define ZKMI_NTT_TILE_LOG 10
+#define ZKMI_NTT_TILE_LOG 9
 #endif
-// 1024 elements = 32 KiB of LDS per workgroup -> 4 workgroups (4 waves per SIMD) per CU: the butterflies are latency-bound
-// carry chains, occupancy matters more than tile size (2^20: 0.163 ms; 2048-element tiles, 2 workgroups per CU: 0.180 ms)
+// 512 elements = 16 KiB of LDS per workgroup -> 8 workgroups (8 waves per SIMD) per CU: the butterflies are latency-bound carry
+// chains, occupancy matters more than tile size (2^20 transform: 0.150 ms; 1024-element tiles 0.163 ms; 2048-element tiles 0.180 ms;
+// A/B on one box, PLONK's 2^22 transforms unchanged)
 constexpr int NTT_TILE_LOG = ZKMI_NTT_TILE_LOG;
 constexpr int NTT_THREADS = 256;
 
