@@ -202,6 +202,52 @@ template <class F, int T> ZK_DEV void pt_madd_lds(const LdsAcc<F, T>& A, bool& i
     A.get(1, t);
     A.put(1, f_sub(f_mul(R, f_sub(Q, X3)), f_mul(t, PPP)));
 }
+// Doubling of an LDS-parked accumulator in place (EFD dbl-2008-s-1, a = 0): the rare equal-points branch of pt_add_lds.
+template <class F, int T> ZK_DEV void pt_dbl_lds(const LdsAcc<F, T>& A) {
+    F t, U, V, Wv, S, M;
+    A.get(1, t); U = f_dbl(t); V = f_sqr(U); Wv = f_mul(U, V);
+    F YW = f_mul(Wv, t);                        // W*Y
+    A.get(0, t); S = f_mul(t, V);
+    t = f_sqr(t); M = f_add(f_dbl(t), t);
+    F X3 = f_sub(f_sqr(M), f_dbl(S));
+    A.put(0, X3);
+    A.put(1, f_sub(f_mul(M, f_sub(S, X3)), YW));
+    A.get(2, t); A.put(2, f_mul(V, t));
+    A.get(3, t); A.put(3, f_mul(Wv, t));
+}
+// acc (LDS-parked) += p for a general XYZZ point p whose coordinates are fetched on demand: ld(coord, F&) with coord 0..3 =
+// X, Y, ZZ, ZZZ (from global memory or from another lane's LDS accumulator). EFD add-2008-s, 12M + 2S, all special cases.
+// Neither operand ever sits in registers as a whole: the live set stays within 256 VGPRs with no scratch — the by-reference
+// pt_add below keeps both Fq2 points plus the result in a scratch frame (768 B per lane), which made every Fq2 addition of the
+// bucket reduction ~300 us of latency.
+template <class F, int T, class Ld> ZK_DEV void pt_add_lds(const LdsAcc<F, T>& A, bool& inf, Ld ld) {
+    F t, u;
+    ld(2, u);                                   // ZZ2
+    if (f_is_zero(u)) return;                   // p = infinity
+    if (inf) {
+        A.put(2, u);
+        ld(0, t); A.put(0, t); ld(1, t); A.put(1, t); ld(3, t); A.put(3, t);
+        inf = false;
+        return;
+    }
+    F P, R, U1, S1;
+    A.get(0, t); U1 = f_mul(t, u);              // U1 = X1*ZZ2
+    A.get(2, t); ld(0, u); P = f_sub(f_mul(u, t), U1);      // P = X2*ZZ1 - U1
+    A.get(1, t); ld(3, u); S1 = f_mul(t, u);    // S1 = Y1*ZZZ2
+    A.get(3, t); ld(1, u); R = f_sub(f_mul(u, t), S1);      // R = Y2*ZZZ1 - S1
+    if (f_is_zero(P)) {
+        if (f_is_zero(R)) pt_dbl_lds(A); else inf = true;
+        return;
+    }
+    F PP = f_sqr(P);
+    A.get(2, t); ld(2, u); A.put(2, f_mul(f_mul(t, u), PP));      // ZZ3 = ZZ1*ZZ2*PP
+    F Q = f_mul(U1, PP);
+    F PPP = f_mul(P, PP);
+    A.get(3, t); ld(3, u); A.put(3, f_mul(f_mul(t, u), PPP));     // ZZZ3 = ZZZ1*ZZZ2*PPP
+    F X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
+    A.put(0, X3);
+    A.put(1, f_sub(f_mul(R, f_sub(Q, X3)), f_mul(S1, PPP)));
+}
 // full addition (EFD add-2008-s: 12M + 2S) with all special cases; inlined flavour for throughput-bound loops
 template <class F> ZK_DEV XYZZ<F> pt_add_inl(const XYZZ<F>& a, const XYZZ<F>& b) {
     if (pt_is_inf(a)) return b;

@@ -567,6 +567,100 @@ k_msm_fold(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n
     }
     pt_store(out + i * PW, acc);
 }
+// ---- row/column sums, one WAVE per sum (no fold launches) ---------------------------------------------------------------
+// The 64 lanes of a wave each add a strided share of the sum's buckets (C/64 or R/64 sequential additions), then the wave's 64
+// partials are combined by a 6-level tree through LDS inside the same launch. Depth for c = 20: 16 + 6 point additions in ONE
+// launch instead of 4 + 3 + 3 + 3 + 3 spread over five (k_msm_rowcol + four k_msm_fold). Fq2 points: the accumulator of every
+// lane is parked in LDS and the other operand is streamed coordinate by coordinate (curve.cuh: pt_add_lds) — no scratch frames,
+// 2 waves per SIMD; Fq points: accumulator in registers, tree operands through LDS.
+template <class F, int T> ZK_DEV void lds_tree_sum(const LdsAcc<F, T>& A, bool& inf, uint32_t* inf_s, uint32_t t, uint32_t group) {
+    for (uint32_t d = 1; d < group; d <<= 1) {
+        inf_s[t] = inf ? 1u : 0u;
+        __syncthreads();
+        if ((t & (2 * d - 1)) == 0 && !inf_s[t + d]) {
+            const LdsAcc<F, T> Pn{A.base + d};
+            pt_add_lds(A, inf, [&](int coord, F& v) { Pn.get(coord, v); });
+        }
+        __syncthreads();
+    }
+}
+template <class F, int T> ZK_DEV void lds_acc_store(const LdsAcc<F, T>& A, bool inf, uint32_t* dst) {
+    constexpr int FW = FieldWords<F>::value;
+    if (inf) {
+#pragma unroll
+        for (int i = 0; i < FW; i++) reinterpret_cast<uint4*>(dst)[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    F v;
+#pragma unroll
+    for (int cdn = 0; cdn < 4; cdn++) { A.get(cdn, v); f_store(dst + cdn * FW, v); }
+}
+template <class F> struct MsmRcBlock { static constexpr int value = (FieldWords<F>::value > 12) ? MsmAccumBlock<F>::value : 256; };
+template <class F> __global__ void __launch_bounds__(MsmRcBlock<F>::value, (FieldWords<F>::value > 12) ? 2 : 1)
+k_msm_rowcol_wave(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_t cbits, uint32_t* __restrict__ out) {
+    constexpr int FW = FieldWords<F>::value, PW = 4 * FW;
+    constexpr bool WIDE = FW > 12;
+    constexpr int T = MsmRcBlock<F>::value;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ uint32_t inf_s[T];
+    const uint32_t C = 1u << cbits, R = 1u << rbits;
+    const uint32_t t = threadIdx.x, sub = t & 63u;
+    const size_t gw = (size_t)blockIdx.x * (T / 64) + (t >> 6);            // sum index: ((job*W + w)*2 + kind)*C + i
+    const size_t n_out = (size_t)rb.njobs * W * 2 * C;
+    const bool valid = gw < n_out;
+    const uint32_t i = (uint32_t)(gw & (C - 1)), kind = (uint32_t)(gw >> cbits) & 1u;
+    const size_t jw = gw >> (cbits + 1);
+    const uint32_t job = valid ? (uint32_t)(jw / W) : 0u, w = (uint32_t)(jw % W);
+    const uint32_t* bk = rb.buckets[job];
+    const uint32_t* cn = rb.counts[job];
+    const uint32_t cnt = !valid ? 0u : (kind ? R : ((i < R) ? C : 0u));
+    if constexpr (WIDE) {
+        const LdsAcc<F, T> A{lds + t};
+        bool inf = true;
+        for (uint32_t e = sub; e < cnt; e += 64) {
+            const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
+            if (cn[g]) {                                                                // empty buckets were never written
+                const uint32_t* p = bk + g * PW;
+                pt_add_lds(A, inf, [&](int coord, F& v) { f_load(v, p + coord * FW); });
+            }
+        }
+        lds_tree_sum(A, inf, inf_s, t, 64);
+        if (valid && sub == 0) lds_acc_store(A, inf, out + gw * PW);
+    } else {
+        XYZZ<F> acc;
+        pt_set_inf(acc);
+        for (uint32_t e = sub; e < cnt; e += 64) {
+            const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
+            if (cn[g]) { XYZZ<F> p; pt_load(p, bk + g * PW); acc = pt_add_inl(acc, p); }
+        }
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            pt_store(lds + t * PW, acc);
+            __syncthreads();
+            if ((t & (2 * d - 1)) == 0) { XYZZ<F> o; pt_load(o, lds + (t + d) * PW); acc = pt_add_inl(acc, o); }
+            __syncthreads();
+        }
+        if (valid && sub == 0) pt_store(out + gw * PW, acc);
+    }
+}
+// k_msm_bitsums for Fq2 points with LDS-parked accumulators (see k_msm_rowcol_wave): one block per (array, k)
+template <class F> __global__ void __launch_bounds__(MsmAccumBlock<F>::value, 2)
+k_msm_bitsums_lds(const uint32_t* __restrict__ arr, uint32_t C, uint32_t cbits, uint32_t* __restrict__ out) {
+    constexpr int FW = FieldWords<F>::value, PW = 4 * FW;
+    constexpr int T = MsmAccumBlock<F>::value;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ uint32_t inf_s[T];
+    const uint32_t a = blockIdx.x / (cbits + 1), k = blockIdx.x % (cbits + 1), t = threadIdx.x;
+    const LdsAcc<F, T> A{lds + t};
+    bool inf = true;
+    for (uint32_t i = t; i < C; i += T)
+        if (k == cbits || ((i >> k) & 1u)) {
+            const uint32_t* p = arr + ((size_t)a * C + i) * PW;
+            pt_add_lds(A, inf, [&](int coord, F& v) { f_load(v, p + coord * FW); });
+        }
+    lds_tree_sum(A, inf, inf_s, t, (uint32_t)T);
+    if (t == 0) lds_acc_store(A, inf, out + (size_t)blockIdx.x * PW);
+}
+
 // One block of M lanes per M consecutive items of an array of m_per_array points; invariant across levels:
 //   weighted = sum_t A_t + scale * sum_t t*X_t,  total = sum_t X_t   (level 0: A absent, scale 1).
 template <class F, int M> __global__ void __launch_bounds__(M)

@@ -1,5 +1,6 @@
 // snarkjs_amd/csrc/msm_host.hpp — host driver of the device Pippenger (launch sequence + final window fold).
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include "host_field.hpp"
@@ -222,6 +223,17 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
     const uint32_t seq = WIDE_R ? 4 : 16, maxL = WIDE_R ? 256 : 64, foldK = WIDE_R ? 4 : 8;
     uint32_t L = 1;
     while (L < maxL && (C / L) > seq) L <<= 1;
+    // one wave per sum with the fold inside the launch (k_msm_rowcol_wave) whenever every sum has >= 64 buckets;
+    // ZKMI_ROWCOL_WAVE=0 keeps the staged k_msm_rowcol + k_msm_fold sequence
+    static const bool wave_env = !(getenv("ZKMI_ROWCOL_WAVE") && atoi(getenv("ZKMI_ROWCOL_WAVE")) == 0);
+    const bool wave_rc = wave_env && rbits >= 6 && cbits >= 6;
+    if (wave_rc) {
+        constexpr int T = MsmRcBlock<F>::value;
+        const size_t lds_rc = (size_t)T * PW * 4;
+        static bool rc_attr = false;
+        if (!rc_attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rc)); rc_attr = true; }
+        hipLaunchKernelGGL((k_msm_rowcol_wave<F>), dim3((unsigned)((n_out + T / 64 - 1) / (T / 64))), dim3(T), lds_rc, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
+    } else {
     uint32_t *p0, *p1;
     ZK_TRY(ws_get("msm.rcpart0" + ax, n_out * L * PW * 4, (void**)&p0));
     ZK_TRY(ws_get("msm.rcpart1" + ax, std::max<size_t>(n_out * L / 4, 1) * PW * 4, (void**)&p1));
@@ -238,6 +250,7 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
             src = d2;
         }
     }
+    }
     const bool bitsums = VW * (cbits + 1) <= 256;            // few arrays (pre-computed tables): plain sums only, host does the weighting
     const uint32_t* resA = nullptr;
     const uint32_t* resR = nullptr;
@@ -246,6 +259,13 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
         constexpr int MB = (PW * 4 * 256 <= 64 * 1024) ? 256 : 128;
         static bool battr = false;
         if (!battr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_bitsums<F, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MB * PW * 4))); battr = true; }
+        if constexpr (WIDE_R) {
+            constexpr int TB = MsmAccumBlock<F>::value;
+            static bool blattr = false;
+            if (!blattr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_bitsums_lds<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TB * PW * 4))); blattr = true; }
+            if (wave_env) hipLaunchKernelGGL((k_msm_bitsums_lds<F>), dim3((unsigned)(VW * (cbits + 1))), dim3(TB), (size_t)TB * PW * 4, st, rc, C, cbits, a0);
+            else hipLaunchKernelGGL((k_msm_bitsums<F, MB>), dim3((unsigned)(VW * (cbits + 1))), dim3(MB), (size_t)MB * PW * 4, st, rc, C, cbits, a0);
+        } else
         hipLaunchKernelGGL((k_msm_bitsums<F, MB>), dim3((unsigned)(VW * (cbits + 1))), dim3(MB), (size_t)MB * PW * 4, st, rc, C, cbits, a0);
         resA = a0;
         perA = (size_t)2 * W * (cbits + 1) * PW;
