@@ -17,38 +17,106 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FIELD_MUL_PEAK_G = 126.0       # measured Montgomery-mul ceiling, tools/fieldbench (profiles/r01_fieldbench.txt), Gmul/s
+# measured Montgomery-multiply ceilings of the chip (tools/fieldbench, profiles/r01_fieldbench.txt), Gmul/s: 256-bit (BN254 Fq)
+# and 384-bit (BLS12-381 Fq) moduli
+FIELD_MUL_PEAK_G = {"bn128": 126.0, "bls12381": 58.6}
 
 
-def cpu_baseline(log_n_sample, log_n_full):
-    """The CPU oracle (C restatement of the reference, oracle/zk_oracle.c) on a bounded sample, rank 0, N=1 only."""
+def _oracle():
+    """The CPU oracle is test infrastructure: only this cpu_baseline leg of bench.py touches it (after the timed region)."""
+    t = os.path.join(ROOT, "tests")
+    if t not in sys.path:
+        sys.path.insert(0, t)
     import oracle_lib as O
-    import synth_zkey
+    return O
+
+
+def relaunch_if_needed(args):
+    """`python bench.py --gpus N` starts its own N ranks (one process per GPU over RCCL) when it was not already started by
+    torch.distributed.run; a world size that does not match --gpus is refused rather than reported under a wrong n_gpus."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" in os.environ or "LOCAL_RANK" in os.environ:
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line with the wrong n_gpus")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def reference_wasm_baseline():
+    """The reference's own WASM + worker-thread path, measured in the BUILD container by tools/ref_wasm_baseline.py (the bundle cannot
+    travel to the GPU box) and committed under profiles/: quoted next to the live C port, never as `value`."""
+    f = os.path.join(ROOT, "profiles", "r02_ref_wasm_baseline.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    return {"where": f"build container, {d['host']['cpus']} cpus ({d['host']['model']}), Node {d['runs'][0]['node']}; NOT this box",
+            "runs": [{k: r[k] for k in ("log_n", "threads", "ms_per_proof", "proofs_per_s")} for r in d["runs"]], "source": "profiles/r02_ref_wasm_baseline.json"}
+
+
+def cpu_baseline(args, zkey, wtns, log_n_full):
+    """The CPU oracle (C restatement of the reference, oracle/zk_oracle.c, OpenMP over the reference's own task split: MSM windows, NTT
+    butterflies) on a bounded sample, rank 0, N=1 only. Sample = the bench's own key when the host has >= 16 threads (one whole proof
+    at full size), else a 2^18 key of the same recipe scaled linearly."""
+    O = _oracle()
     from snarkjs_amd import binfile
-    zkey, wtns = synth_zkey.make("bn128", log_n_sample, seed=0xBA5E, witness="uniform")    # cpu baseline is quoted on the BN254 workload
+    from snarkjs_amd.workloads import synth_zkey
+    threads = O.threads()
+    lg = args.cpu_log_n if args.cpu_log_n else (log_n_full if threads >= 16 else min(18, log_n_full))
+    if lg != log_n_full:
+        zkey, wtns = synth_zkey.make("bn128", lg, seed=0xBA5E, witness="uniform", b_zero_every=args.b_zero_every)
     zk, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)["witness"]
     r_m, s_m = O.fr_e(0, 0x1234567), O.fr_e(0, 0x7654321)
     t0 = time.perf_counter()
     ref = O.groth16_prove(0, zk, w, r_m, s_m)
     dt = time.perf_counter() - t0
-    scale = 1 << (log_n_full - log_n_sample)
-    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": f"one full Groth16 proof at 2^{log_n_sample} constraints by oracle/zk_oracle.c (1 thread, {dt:.1f} s), "
-                      f"scaled linearly x{scale} to 2^{log_n_full}"}, (zkey, wtns, ref, r_m, s_m)
+    scale = 1 << (log_n_full - lg)
+    base = {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": threads, "kind": "port",
+            "sample": f"one full Groth16 proof at 2^{lg} constraints by oracle/zk_oracle.c ({threads} OpenMP threads, {dt:.1f} s wall)"
+                      + (f", scaled linearly x{scale} to 2^{log_n_full} (optimistic: NTT is n log n)" if scale > 1 else ", no scaling"),
+            "reference_wasm": reference_wasm_baseline()}
+    return base, (zkey, wtns, ref, r_m, s_m)
+
+
+def napi_wall(zkey, wtns, reps=5):
+    """Wall time through the N-API addon with host buffers (SURVEY.md 8d timing protocol): tools/napi_wall.js under Node."""
+    import shutil
+    import subprocess
+    import tempfile
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "snarkjs_amd", "napi", "zkmi_napi.node")
+    if node is None or not os.path.exists(addon):
+        return {"skipped": "node or the built addon is missing"}
+    with tempfile.TemporaryDirectory() as td:
+        zf, wf = os.path.join(td, "k.zkey"), os.path.join(td, "k.wtns")
+        open(zf, "wb").write(zkey)
+        open(wf, "wb").write(wtns)
+        r = subprocess.run([node, os.path.join(ROOT, "tools", "napi_wall.js"), zf, wf, str(reps)], capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def bench_plonk(args, rank, world, dist, torch):
-    """BASELINE configs[3]: BN254 PLONK prove at 2^log_n constraints on a synthetic VALID key (tests/synth_plonk.py); one proof
+    """BASELINE configs[3]: BN254 PLONK prove at 2^log_n constraints on a synthetic VALID key (snarkjs_amd/workloads/synth_plonk.py); one proof
     stream per GPU. The key is resident; each proof uploads its witness (32 MB at 2^20) — the reference reads it from a file."""
-    import synth_plonk
-    from snarkjs_amd import fflonk, plonk
+    from snarkjs_amd.workloads import synth_plonk
+    from snarkjs_amd import fflonk, plonk, zkmi
     lg = args.log_n
     proto = args.workload
     if proto == "fflonk":               # not a BASELINE config; same kernels, MSMs over 8n / 16n coefficients (SURVEY.md 2 row 5)
@@ -75,13 +143,46 @@ def bench_plonk(args, rank, world, dist, torch):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        print(json.dumps({
+        n = 1 << lg
+        # dominant kernel of a PLONK proof: the bucket accumulations of the commitments (G1 MSMs against the resident SRS table);
+        # job slot 0 holds the last one (n + O(1) terms). Live HIP-event time around that launch on the library stream.
+        acc_ms = zkmi.lib().zkmi_msm_accum_ms(0)
+        alg = 96 * n                                            # 64-byte affine base + 32-byte scalar per term
+        roof = None
+        if acc_ms and acc_ms > 0:
+            roof = {"bound": "hbm", "kernel": "k_msm_accum<Fp<Bn254Fq>> (last commitment, n terms)", "achieved": round(alg / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(alg / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms": round(acc_ms, 4), "algorithmic_bytes": alg,
+                    "note": "integer-ALU-bound (256-bit Montgomery carry chains, no MFMA); traffic: no PMC pass for this workload"}
+        out = {
             "metric": f"{proto}_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"BN254 {proto.upper()} prove, 2^{lg} constraints, synthetic valid key" + (" (BASELINE configs[3])" if proto == "plonk" else "") + "; key resident, witness uploaded per proof",
                        "curve": "bn128", "log_n": lg, "parallelism": f"replica x{world}"},
-            "public_signal": res["publicSignals"][0][:24] + "..."}), flush=True)
+            "roofline": roof,
+            "public_signal": res["publicSignals"][0][:24] + "..."}
+        if world == 1 and not args.no_cpu_baseline and proto == "plonk":
+            # CPU port: the Python restatement of src/plonk_prove.js (oracle/plonk_oracle.py, pure-Python field loops, 1 thread) on a
+            # small valid key, scaled linearly — the reference's own PLONK prover spends most of its time in single-threaded JS loops too
+            t = os.path.join(ROOT, "tests")
+            if t not in sys.path:
+                sys.path.insert(0, t)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import plonk_oracle
+            slg = 8
+            zk_s, wt_s = synth_plonk.make("bn128", slg, seed=3)
+            f = plonk._Field(0)
+            blind = [bytes(f.mont(900 + i)) for i in range(11)]
+            t0 = time.perf_counter()
+            ref_proof, _ = plonk_oracle.plonk_prove(zk_s, wt_s, blind)
+            dt = time.perf_counter() - t0
+            key_s = plonk.PlonkKey(zk_s)
+            got = plonk.prove(key_s, wt_s, blinding_mont=blind)
+            key_s.release()
+            out["cpu_baseline"] = {"value": 1.0 / (dt * (1 << (lg - slg))), "unit": "proofs/s", "cores": 1, "kind": "port",
+                                   "sample": f"one PLONK proof at 2^{slg} constraints by oracle/plonk_oracle.py (pure Python, 1 thread, {dt:.1f} s), scaled linearly x{1 << (lg - slg)}",
+                                   "parity_on_sample": bool(got["proof"] == ref_proof)}
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -93,12 +194,16 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--cpu-log-n", type=int, default=17, help="size of the CPU-baseline sample (2^17: about 15 s of single-thread oracle time)")
+    ap.add_argument("--cpu-log-n", type=int, default=0, help="size of the CPU-baseline sample (0 = auto: the bench's own key with >= 16 host threads, else 2^18)")
+    ap.add_argument("--b-zero-every", type=int, default=0, help="k: every k-th B1/B2 base is the point at infinity (B density 1 - 1/k); 0 = dense B sections (SURVEY.md 8d recipe)")
+    ap.add_argument("--no-napi-wall", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2], help="proofs in flight per GPU (2: the tail of proof k overlaps the front of proof k+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--witness", default="uniform", choices=["uniform", "mixed"])
     ap.add_argument("--curve", default="bn128", choices=["bn128", "bls12381"])
     ap.add_argument("--workload", default="groth16", choices=["groth16", "plonk", "fflonk"], help="plonk = BASELINE configs[3] (not the default metric)")
     args = ap.parse_args()
+    relaunch_if_needed(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -113,15 +218,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from snarkjs_amd import groth16, zkmi, binfile
-    import synth
-    import synth_zkey
+    from snarkjs_amd.workloads import synth, synth_zkey
     zkmi.init(local_rank)
     L = zkmi.lib()
 
     lg = args.log_n
     if args.workload in ("plonk", "fflonk"):
         return bench_plonk(args, rank, world, dist, torch)
-    zkey, wtns = synth_zkey.make(args.curve, lg, seed=0x5EED + rank, witness=args.witness)
+    zkey, wtns = synth_zkey.make(args.curve, lg, seed=0x5EED + rank, witness=args.witness, b_zero_every=args.b_zero_every)
     cid = 0 if args.curve == "bn128" else 1
     q8 = 32 if cid == 0 else 48
     pk = groth16.ProvingKey(zkey)
@@ -142,17 +246,36 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.pipeline == 2:                                   # size the second slot's buffers outside the timed region
+        pk.submit(d_w.ptr, 1)
+        pk.collect(1, r_m, s_m)
     stage_acc, accum_ms = {}, {k: [] for k in range(5)}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        proof_pts = step()
-        for k, v in pk.stage_ms().items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
-        for k in range(5):
-            accum_ms[k].append(L.zkmi_msm_accum_ms(k))
+    if args.pipeline == 1:
+        for _ in range(args.steps):
+            proof_pts = step()
+    else:
+        # EXACTLY args.steps whole proofs, two in flight: proof i is enqueued before proof i-1 is collected; every proof is
+        # collected (folded, blinded, normalised) inside the timed region
+        for i in range(args.steps):
+            pk.submit(d_w.ptr, i & 1)
+            if i:
+                proof_pts = pk.collect((i - 1) & 1, r_m, s_m)
+        proof_pts = pk.collect((args.steps - 1) & 1, r_m, s_m)
     barrier()
     elapsed = time.perf_counter() - t0
+    # stage / kernel times and single-proof latency: a few serial proofs after the timed region
+    lat = []
+    for _ in range(4):
+        tl = time.perf_counter()
+        serial_pts = step()
+        lat.append(time.perf_counter() - tl)
+        for k, v in pk.stage_ms().items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v / 4 * args.steps
+        for k in range(5):
+            accum_ms[k].append(L.zkmi_msm_accum_ms(k))
+    assert all(np.array_equal(a, b) for a, b in zip(serial_pts, proof_pts)), "pipelined and serial proofs differ"
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -197,7 +320,7 @@ def main():
         if rank == 0:
             zkey0, wtns0 = zkey, wtns
         else:
-            zkey0, wtns0 = synth_zkey.make(args.curve, lg, seed=0x5EED, witness=args.witness)
+            zkey0, wtns0 = synth_zkey.make(args.curve, lg, seed=0x5EED, witness=args.witness, b_zero_every=args.b_zero_every)
         pks = groth16.ProvingKey(zkey0, shard=(rank, world))
         d_w0 = zkmi.DeviceBuffer.from_host(binfile.read_wtns(wtns0)["witness"])
         for _ in range(2):
@@ -255,11 +378,16 @@ def main():
         units = {0: m, 1: m, 2: m, 3: m - zk["nPublic"] - 1, 4: zk["domainSize"]}[dom]
         alg_bytes = names[dom][1] * units                      # B/term (affine base + 32-B scalar) x terms
         achieved = alg_bytes / (acc[dom] * 1e-3) / 1e9
+        # HBM bytes of that launch from separate rocprofv3 --pmc passes of THIS workload (tools/pmc_to_traffic.py tags the file);
+        # a file collected on another workload (size / curve / B density) is not used: traffic stays null
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # filled from separate rocprofv3 --pmc passes
+        wl_tag = f"groth16:{args.curve}:2^{lg}:b_zero_every={args.b_zero_every}:{args.witness}"
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(names[dom][0].split(" ")[0])
+                pj = json.load(open(tf))
+                if pj.get("__workload__") == wl_tag:
+                    traffic = pj.get(names[dom][0].split(" ")[0])
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "kernel": names[dom][0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -275,18 +403,22 @@ def main():
         if lgv >= 14:
             cpre = [15, 15, 16, 17, 17, 20, 20, 20][min(max(cpre, 14), 21) - 14]
         digits = -(-254 // cpre) if cid == 0 else -(-255 // cpre)      # non-zero signed digits of a uniform < r scalar (top digits beyond the field size are zero)
-        density = (2.0 / 3.0) if dom in (1, 2) else 1.0             # tests/synth_zkey.py: every third B1 / B2 base is the point at infinity (dropped before the sort)
+        bze = args.b_zero_every
+        density = (1.0 - 1.0 / bze) if (bze and dom in (1, 2)) else 1.0     # workloads/synth_zkey.py: every bze-th B1 / B2 base is the point at infinity (dropped before the sort)
         fmuls = int(digits * units * density * (28 if dom == 2 else 10))    # 8M + 2S; in Fq2 a product is 3, a square 2 base-field products
-        int_alu = {"unit": "Gmul/s", "field_muls": fmuls, "achieved": round(fmuls / (acc[dom] * 1e-3) / 1e9, 1), "peak": FIELD_MUL_PEAK_G,
-                   "frac": round(fmuls / (acc[dom] * 1e-3) / 1e9 / FIELD_MUL_PEAK_G, 4),
-                   "note": "field multiplications of the mixed additions of this launch (digits x non-infinity terms x 10 in G1 / 28 in G2; the Fq2 kernel's ~70 additions per mixed addition are not counted) / launch time; peak = measured Montgomery-multiply ceiling of the chip (tools/fieldbench, profiles/r01_fieldbench.txt)"}
+        int_alu = {"unit": "Gmul/s", "field_muls": fmuls, "achieved": round(fmuls / (acc[dom] * 1e-3) / 1e9, 1), "peak": FIELD_MUL_PEAK_G[args.curve],
+                   "frac": round(fmuls / (acc[dom] * 1e-3) / 1e9 / FIELD_MUL_PEAK_G[args.curve], 4),
+                   "note": "field multiplications of the mixed additions of this launch (digits x non-infinity terms x 10 in G1 / 28 in G2; the Fq2 kernel's ~70 additions per mixed addition are not counted) / launch time; peak = measured Montgomery-multiply ceiling of the chip for this curve's base field (tools/fieldbench, profiles/r01_fieldbench.txt: 256-bit 126, 384-bit 58.6 Gmul/s)"}
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{'BN254' if cid == 0 else 'BLS12-381'} Groth16 prove, 2^{lg} constraints, synthetic zkey/wtns (BASELINE configs[{1 if (cid == 0 and lg == 20) else (2 if cid == 0 else 4)}]); key + witness resident in HBM",
-                       "curve": args.curve, "log_n": lg, "n_vars": m, "n_coef": int((zk['coeffs'].size - 4) // 44), "witness": args.witness,
-                       "parallelism": f"replica x{world} (one proof stream per GPU)"},
+            "pipeline_depth": args.pipeline, "latency_ms_single_proof": round(float(np.median(lat)) * 1e3, 3),
+            "config": {"workload": f"{'BN254' if cid == 0 else 'BLS12-381'} Groth16 prove, 2^{lg} constraints, synthetic zkey/wtns (BASELINE configs[{1 if (cid == 0 and lg == 20) else (2 if cid == 0 else 4)}]), "
+                                   f"B density {1.0 if not args.b_zero_every else round(1 - 1 / args.b_zero_every, 3)} ({'every section dense, SURVEY 8d recipe' if not args.b_zero_every else f'every {args.b_zero_every}-th B1/B2 base at infinity'}), "
+                                   f"{args.witness} witness; key + witness resident in HBM",
+                       "curve": args.curve, "log_n": lg, "n_vars": m, "n_coef": int((zk['coeffs'].size - 4) // 44), "witness": args.witness, "b_density": 1.0 if not args.b_zero_every else round(1 - 1 / args.b_zero_every, 4),
+                       "parallelism": f"replica x{world} (one proof stream per GPU, {args.pipeline} proof(s) in flight)"},
             "submetrics": {"g1_msm_mscalar_per_s": round(n / msm_ms / 1e3, 2), "g1_msm_ms": round(msm_ms, 4),
                            "g1_msm_resident_tables_mscalar_per_s": round(n / msm_tab_ms / 1e3, 2), "g1_msm_resident_tables_ms": round(msm_tab_ms, 4), "g1_msm_accum_kernel_ms": round(msm_acc_ms, 4),
                            "g1_msm_hbm_frac": round((2 * q8 + 32) * n / (msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
@@ -298,8 +430,11 @@ def main():
             "roofline": roof,
             "int_alu": int_alu,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            base, (zk_s, wt_s, ref, rs, ss) = cpu_baseline(args.cpu_log_n, lg)
+        if world == 1 and not args.no_napi_wall:
+            # SURVEY.md 8d timing protocol: wall time THROUGH the N-API call with host buffers (H2D of inputs, D2H of results inside)
+            out["wall_through_napi"] = napi_wall(zkey, wtns)
+        if world == 1 and not args.no_cpu_baseline and args.curve == "bn128":
+            base, (zk_s, wt_s, ref, rs, ss) = cpu_baseline(args, zkey, wtns, lg)
             out["cpu_baseline"] = base
             # the same sample through the device path must give the oracle's proof points (parity inside the bench run)
             pk_s = groth16.ProvingKey(zk_s)

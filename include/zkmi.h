@@ -72,12 +72,18 @@ int zkmi_memset_dev(void* d_dst, int value, size_t bytes);
 /* ---- G.multiExpAffine ------------------------------------------------------------------------------------------- */
 /* curve.G1.multiExpAffine / curve.G2.multiExpAffine (min.js:1@214996 -> @214651 -> _multiExpChunk @213360; kernel
  * g1m_/g2m_multiexpAffine_chunk @75966).  group = 1 | 2.  n bases of 2*group*n8q bytes, n scalars of scalar_bytes.
- * base_cache_key != 0: the base table is uploaded once and kept resident under that key (zkey sections are static
- * per circuit, src/groth16_prove.js:84-100); release with zkmi_release_bases.
+ * base_cache_key != 0 ALLOWS the library to keep these bases resident (zkey sections / SRS slices are static per circuit,
+ * src/groth16_prove.js:84-100); its value carries no identity. The cache is content-addressed: the library hashes the whole base
+ * buffer on every call (128 bits per 64 KiB chunk), so a buffer that differs anywhere never re-uses another buffer's table. The
+ * pre-computed window table of a buffer is built on its SECOND sight, an MSM over a prefix of a resident buffer re-uses its
+ * table, tables that cannot fit are never built (plain bases instead), and least-recently-used tables are evicted under a
+ * byte budget (env ZKMI_BASE_CACHE_BYTES, default 64 GiB). zkmi_release_bases drops every cached table.
  * out_jacobian: 3*group*n8q bytes. */
 int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t n, size_t scalar_bytes,
              uint64_t base_cache_key, uint8_t* out_jacobian);
 int zkmi_release_bases(uint64_t base_cache_key);
+/* resident tables / their bytes / buffers seen once (no table yet) — for tests and diagnostics; any pointer may be NULL */
+int zkmi_base_cache_stats(uint64_t* n_tables, uint64_t* table_bytes, uint64_t* n_seen);
 /* Same with bases and scalars already resident in device memory (bench.py, fused pipelines). */
 int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t scalar_bytes,
                  uint8_t* out_jacobian);
@@ -138,16 +144,30 @@ typedef struct zkmi_groth16_zkey {
     const uint8_t* coeffs; size_t coeffs_len;
     const uint8_t *bases_a, *bases_b1, *bases_b2, *bases_c, *bases_h;
     const uint8_t *vk_alpha_1, *vk_beta_1, *vk_beta_2, *vk_delta_1, *vk_delta_2;
+    /* byte lengths of sections 5, 6, 7, 8, 9 as found in the file: checked against nVars / nPublic / domainSize of the header before
+     * anything is read (a truncated or malformed zkey fails with ZKMI_ERR_INVALID instead of reading past the caller's buffers; the
+     * reference gets the same protection from bounds-checked JS buffers). The vk_* points are 2*n8q (G1) / 4*n8q (G2) bytes. */
+    size_t bases_a_len, bases_b1_len, bases_b2_len, bases_c_len, bases_h_len;
 } zkmi_groth16_zkey;
 /* Upload the proving key under `zkey_cache_key` (!= 0): base tables + CSR form of the coefficient section. */
 int zkmi_groth16_load(const zkmi_groth16_zkey* zkey, uint64_t zkey_cache_key);
-/* One proof. zkey_cache_key != 0: the key is loaded on first use (zkey may be NULL afterwards) and stays resident;
- * zkey_cache_key == 0: load, prove, release. `witness` is a HOST pointer (n_vars x 32 B, normal form). */
-int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t zkey_cache_key, const uint8_t* witness,
+/* One proof. zkey_cache_key != 0: the key is loaded on first use (zkey may be NULL afterwards) and stays resident; a descriptor
+ * given together with an already resident key must describe the same circuit (curve, nVars, nPublic, domainSize, nCoef), else the
+ * call fails with ZKMI_ERR_INVALID — release the key first to replace it. zkey_cache_key == 0: load, prove, release.
+ * `witness` is a HOST pointer to wtns section 2 (normal form), witness_len its byte length: must be n_vars x 32
+ * ("Invalid witness length", src/groth16_prove.js:45-47). */
+int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t zkey_cache_key, const uint8_t* witness, size_t witness_len,
                        const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 /* Same with the witness already in device memory and the key loaded (bench.py: inputs resident in HBM). */
 int zkmi_groth16_prove_dev(uint64_t zkey_cache_key, const void* d_witness, const uint8_t* r_mont, const uint8_t* s_mont,
                            uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
+/* Two proofs in flight on one GPU (throughput mode): zkmi_groth16_submit_dev enqueues the whole device part of a proof into
+ * pipeline slot 0 or 1 and returns at once; zkmi_groth16_collect waits for that slot, folds the window sums and applies the
+ * blinding + toAffine. While proof k sits in its latency-bound tail (bucket reductions: few waves, long dependency chains; result
+ * copies; host folds) the throughput-bound front of proof k+1 (buildABC, NTTs, accumulations) already runs. Each slot owns its
+ * streams, scratch and work buffers; d_witness must stay valid until the slot is collected. prove_dev == submit(0) + collect(0). */
+int zkmi_groth16_submit_dev(uint64_t zkey_cache_key, const void* d_witness, int slot);
+int zkmi_groth16_collect(uint64_t zkey_cache_key, int slot, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 int zkmi_groth16_release(uint64_t zkey_cache_key);
 /* Multi-GPU proof (BASELINE configs[2]: MSMs sharded across the GPUs of a node). Every rank loads the shard of the
  * key that holds the witness-side bases of the variables [var_lo, var_hi) (sections 5-8) and the H bases [h_lo, h_hi) (section 9);

@@ -160,6 +160,60 @@ async function groth16Golden() {
     console.log('groth16 golden done: proof sha', sha(JSON.stringify(proof)), 'verify', ok);
 }
 
+// The reference has no BLS12-381 fixture or test of any kind (SURVEY.md 8c/8d). Recipe of SURVEY.md 8d: the Multiplier(n) chain of
+// test/groth16/circuit.circom written directly in the r1cs binary format with prime = BLS12-381 r (x_0 = a*a + b, x_i = x_{i-1}^2 + b;
+// public output c = x_{n-1}, public input a), its witness from a BigInt loop, then the same seeded in-memory ceremony as above on
+// getCurveFromName("bls12381"): powersOfTau -> newZKey -> contribute -> groth16.prove -> verify.
+function multiplierR1cs(r, n) {
+    const le = (v, k) => { const o = Buffer.alloc(k); let x = BigInt(v); for (let i = 0; i < k; i++) { o[i] = Number(x & 255n); x >>= 8n; } return o; };
+    const u32 = (v) => le(v, 4), u64 = (v) => le(v, 8);
+    const nWires = n + 3;                                      // [1, c = x_{n-1}, a, b, x_0 .. x_{n-2}]
+    const wireOf = (i) => (i == n - 1) ? 1 : 4 + i;            // wire of x_i
+    const lc = (terms) => Buffer.concat([u32(terms.length)].concat(terms.map(([w, v]) => Buffer.concat([u32(w), le(v, 32)]))));
+    const cons = [];
+    for (let i = 0; i < n; i++) {
+        const prev = i == 0 ? 2 : wireOf(i - 1);
+        cons.push(lc([[prev, 1n]]), lc([[prev, 1n]]), lc([[3, r - 1n], [wireOf(i), 1n]]));      // x_{i-1} * x_{i-1} = x_i - b
+    }
+    const hdr = Buffer.concat([u32(32), le(r, 32), u32(nWires), u32(1), u32(1), u32(1), u64(nWires), u32(n)]);
+    const cs = Buffer.concat(cons), map = Buffer.concat(Array.from({ length: nWires }, (_, i) => u64(i)));
+    const sec = (t, b) => Buffer.concat([u32(t), u64(b.length), b]);
+    return new Uint8Array(Buffer.concat([Buffer.from('r1cs'), u32(1), u32(3), sec(1, hdr), sec(2, cs), sec(3, map)]));
+}
+function multiplierWtns(r, n, a, b) {
+    const le = (v, k) => { const o = Buffer.alloc(k); let x = BigInt(v); for (let i = 0; i < k; i++) { o[i] = Number(x & 255n); x >>= 8n; } return o; };
+    const xs = [(a * a + b) % r];
+    for (let i = 1; i < n; i++) xs.push((xs[i - 1] * xs[i - 1] + b) % r);
+    const sig = [1n, xs[n - 1], a, b].concat(xs.slice(0, n - 1));
+    const hdrS = Buffer.concat([le(32, 4), le(r, 32), le(sig.length, 4)]), dataS = Buffer.concat(sig.map((v) => le(v, 32)));
+    return new Uint8Array(Buffer.concat([Buffer.from('wtns'), le(2, 4), le(2, 4), le(1, 4), le(hdrS.length, 8), hdrS, le(2, 4), le(dataS.length, 8), dataS]));
+}
+async function groth16GoldenBls() {
+    const curve = await snarkjs.curves.getCurveFromName('bls12381');
+    const r = curve.Fr.p, n = 1000;
+    const mem = () => ({ type: 'mem' });
+    const p0 = mem(), p1 = mem(), pf = mem(), z0 = mem(), z1 = mem();
+    await snarkjs.powersOfTau.newAccumulator(curve, 11, p0);
+    await snarkjs.powersOfTau.contribute(p0, p1, 'C1', 'Entropy1');
+    await snarkjs.powersOfTau.preparePhase2(p1, pf);
+    await snarkjs.zKey.newZKey(multiplierR1cs(r, n), pf, z0);
+    await snarkjs.zKey.contribute(z0, z1, 'p2_C1', 'pa_Entropy1');
+    const w = { data: multiplierWtns(r, n, 11n, 2n) };
+    const rnd = [], Fr = curve.Fr;
+    const origRandom = Fr.random.bind(Fr); Fr.random = () => { const v = origRandom(); rnd.push(hex(v)); return v; };
+    const { proof, publicSignals } = await snarkjs.groth16.prove(z1.data, w.data);
+    Fr.random = origRandom;
+    const vk = await snarkjs.zKey.exportVerificationKey(z1.data);
+    const ok = await snarkjs.groth16.verify(vk, publicSignals, proof);
+    if (!ok) throw new Error('golden BLS12-381 groth16 proof does not verify');
+    fs.writeFileSync(path.join(OUT, 'groth16_bls12381_n1024.zkey'), z1.data);
+    fs.writeFileSync(path.join(OUT, 'groth16_bls12381_n1024.wtns'), w.data);
+    fs.writeFileSync(path.join(OUT, 'groth16_bls12381_n1024.json'), JSON.stringify({
+        zkey_sha256: sha(z1.data), wtns_sha256: sha(w.data), proof_sha256: sha(JSON.stringify(proof)),
+        r_mont: rnd[0], s_mont: rnd[1], n_random_calls: rnd.length, proof, publicSignals, verified: ok, vk }, null, 1));
+    console.log('groth16 BLS12-381 golden done: zkey', z1.data.length, 'bytes, proof sha', sha(JSON.stringify(proof)), 'verify', ok);
+}
+
 // Seeded PLONK fixtures: plonk.setup on two circuits of the reference's test tree with the same seeded ptau, then a seeded
 // plonk.prove whose 11 blinding draws (src/plonk_prove.js:224-227) and Fiat-Shamir challenges are recorded.
 async function plonkGolden() {
@@ -259,6 +313,7 @@ async function fflonkGolden() {
     if (what === 'all' || what === 'bn128') await kernelVectors('bn128', 'bn128');
     if (what === 'all' || what === 'bls12381') await kernelVectors('bls12381', 'bls12381');
     if (what === 'all' || what === 'groth16') await groth16Golden();
+    if (what === 'all' || what === 'groth16bls') await groth16GoldenBls();
     if (what === 'all' || what === 'plonk') await plonkGolden();
     if (what === 'all' || what === 'fflonk') await fflonkGolden();
     process.exit(0);

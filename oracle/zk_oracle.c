@@ -316,9 +316,16 @@ int orc_fr_batch_inverse(int curve, const uint8_t *in, uint8_t *out, size_t n) {
 /* Fr.batchApplyKey(buf, first, inc) (min.js:1@211529, kernel frm_batchApplyKey @128060): out[i] = in[i]·first·inc^i.
  * first/inc are M elements. */
 int orc_fr_batch_apply_key(int curve, const uint8_t *in, uint8_t *out, size_t n, const uint8_t *first, const uint8_t *inc) {
-    curve_t *C = get_curve(curve); u64 x[MAXL], y[MAXL], t[MAXL], k[MAXL];
-    memcpy(t, first, 32); memcpy(k, inc, 32);
-    for (size_t i = 0; i < n; i++) { memcpy(x, in + 32 * i, 32); fe_mul(&C->Fr, y, x, t); memcpy(out + 32 * i, y, 32); fe_mul(&C->Fr, t, t, k); }
+    curve_t *C = get_curve(curve); u64 f0[MAXL], k[MAXL];
+    memcpy(f0, first, 32); memcpy(k, inc, 32);
+    const size_t CH = 4096;
+    #pragma omp parallel for schedule(static)
+    for (size_t c0 = 0; c0 < n; c0 += CH) {
+        u64 x[MAXL], y[MAXL], t[MAXL], e[1] = {(u64)c0};
+        fe_pow(&C->Fr, t, k, e, 1); fe_mul(&C->Fr, t, t, f0);                 /* first * inc^c0 */
+        size_t hi = c0 + CH < n ? c0 + CH : n;
+        for (size_t i = c0; i < hi; i++) { memcpy(x, in + 32 * i, 32); fe_mul(&C->Fr, y, x, t); memcpy(out + 32 * i, y, 32); fe_mul(&C->Fr, t, t, k); }
+    }
     return 0;
 }
 /* Fr.fft / Fr.ifft (min.js:1@215859 driver; kernels frm_fftMix/_fftJoin/_fftFinal @103755):
@@ -329,27 +336,40 @@ int orc_fr_ntt(int curve, const uint8_t *in, uint8_t *out, unsigned log_n, int i
     if ((int)log_n > C->s) return -1;
     size_t n = (size_t)1 << log_n;
     u64 (*a)[4] = malloc(n * 32);
+    #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; i++) {
         size_t r = 0; for (unsigned b = 0; b < log_n; b++) r |= ((i >> b) & 1) << (log_n - 1 - b);
         memcpy(a[r], in + 32 * i, 32);
     }
-    for (unsigned st = 1; st <= log_n; st++) {
-        size_t h = (size_t)1 << (st - 1);
-        const u64 *wst = inverse ? C->wi[st] : C->w[st];
-        u64 (*tw)[4] = malloc(h * 32);
-        memcpy(tw[0], F->one, 32);
-        for (size_t j = 1; j < h; j++) fe_mul(F, tw[j], tw[j - 1], wst);
-        for (size_t blk = 0; blk < n; blk += 2 * h)
-            for (size_t j = 0; j < h; j++) {
-                u64 t[MAXL], u[MAXL];
-                fe_mul(F, t, a[blk + j + h], tw[j]); memcpy(u, a[blk + j], 32);
-                fe_add(F, a[blk + j], u, t); fe_sub(F, a[blk + j + h], u, t);
-            }
-        free(tw);
+    /* one table of the n/2 powers of w = Fr.w[log_n]: stage st uses every (n/2h)-th entry (w_st = w^(n/2h)) */
+    size_t half = n > 1 ? n / 2 : 1;
+    u64 (*tw)[4] = malloc(half * 32);
+    {
+        const u64 *wn = inverse ? C->wi[log_n] : C->w[log_n];
+        const size_t CH = 4096;
+        #pragma omp parallel for schedule(static)
+        for (size_t c0 = 0; c0 < half; c0 += CH) {
+            u64 e[1] = {(u64)c0};
+            fe_pow(F, tw[c0], wn, e, 1);
+            size_t hi = c0 + CH < half ? c0 + CH : half;
+            for (size_t j = c0 + 1; j < hi; j++) fe_mul(F, tw[j], tw[j - 1], wn);
+        }
     }
+    for (unsigned st = 1; st <= log_n; st++) {
+        const size_t h = (size_t)1 << (st - 1), stride = half / h;
+        #pragma omp parallel for schedule(static)
+        for (size_t idx = 0; idx < half; idx++) {
+            const size_t j = idx & (h - 1), lo = ((idx >> (st - 1)) << st) + j;
+            u64 t[MAXL], u[MAXL];
+            fe_mul(F, t, a[lo + h], tw[j * stride]); memcpy(u, a[lo], 32);
+            fe_add(F, a[lo], u, t); fe_sub(F, a[lo + h], u, t);
+        }
+    }
+    free(tw);
     if (inverse) {
         u64 nn[MAXL] = {(u64)n}, ni[MAXL];
         fe_to_mont(F, ni, nn); fe_inv(F, ni, ni);
+        #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < n; i++) fe_mul(F, a[i], a[i], ni);
     }
     memcpy(out, a, n * 32); free(a);
@@ -392,13 +412,18 @@ int orc_msm(int curve, int group, const uint8_t *bases, const uint8_t *scalars, 
     u64 res[3 * MAXE]; pt_zero(&E, res);
     if (n) {
         int c = PT_SIZES[ilog2(n)], nwin = (8 * sb - 1) / c + 1;
-        for (int w = nwin - 1; w >= 0; w--) {
-            u64 part[3 * MAXE];
+        u64 (*parts)[3 * MAXE] = malloc((size_t)nwin * sizeof(*parts));
+        /* the window sums are independent (the reference hands them to its workers as separate tasks, @213360) */
+        #pragma omp parallel for schedule(dynamic, 1)
+        for (int w = 0; w < nwin; w++) {
             int len = 8 * sb - w * c; if (len > c) len = c;
-            msm_window(&E, part, bases, scalars, n, sb, w * c, len);
-            if (!pt_is_zero(&E, res)) for (int k = 0; k < c; k++) pt_double(&E, res, res);
-            pt_add(&E, res, res, part);
+            msm_window(&E, parts[w], bases, scalars, n, sb, w * c, len);
         }
+        for (int w = nwin - 1; w >= 0; w--) {
+            if (!pt_is_zero(&E, res)) for (int k = 0; k < c; k++) pt_double(&E, res, res);
+            pt_add(&E, res, res, parts[w]);
+        }
+        free(parts);
     }
     if (pt_is_zero(&E, res)) memset(out, 0, 8 * 3 * L); else memcpy(out, res, 8 * 3 * L);
     return 0;
@@ -475,6 +500,7 @@ int orc_groth16_build_abc(int curve, const uint8_t *coeffs, size_t coeffs_len, c
         memcpy(cf, rec + 12, 32); memcpy(w, witness + 32 * (size_t)s, 32); memcpy(acc, ob[m] + 32 * (size_t)c, 32);
         fe_mul(F, t, cf, w); fe_add(F, acc, acc, t); memcpy(ob[m] + 32 * (size_t)c, acc, 32);
     }
+    #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < domain; i++) {
         u64 a[MAXL], b[MAXL], c[MAXL];
         memcpy(a, outA + 32 * i, 32); memcpy(b, outB + 32 * i, 32); fe_mul(F, c, a, b); memcpy(outC + 32 * i, c, 32);
@@ -485,6 +511,7 @@ int orc_groth16_build_abc(int curve, const uint8_t *coeffs, size_t coeffs_len, c
  * then frm_batchFromMontgomery → normal form (these are the H-MSM scalars). */
 int orc_groth16_join_abc(int curve, const uint8_t *A, const uint8_t *B, const uint8_t *Cc, size_t n, uint8_t *out) {
     curve_t *C = get_curve(curve); const fld *F = &C->Fr;
+    #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; i++) {
         u64 a[MAXL], b[MAXL], c[MAXL], t[MAXL];
         memcpy(a, A + 32 * i, 32); memcpy(b, B + 32 * i, 32); memcpy(c, Cc + 32 * i, 32);
@@ -560,3 +587,45 @@ int orc_fq_from_mont(int curve, const uint8_t *in, uint8_t *out, size_t n) {
     for (size_t i = 0; i < n; i++) { memcpy(x, in + nb * i, nb); fe_from_mont(&C->Fq, y, x); memcpy(out + nb * i, y, nb); }
     return 0;
 }
+
+/* ---- helpers of the full-size closed-form checks (tests/test_gpu_parity.py) ------------------------------------------
+ * sum_i s_i * f * g^i mod r over the entries with (i % skip_mod) != skip_rem (skip_mod = 0: all entries); s_i are plain
+ * little-endian integers of sb <= 32 bytes (not reduced), result in normal form (32 bytes LE). These are the discrete logs
+ * of MSM results over the geometric base table P_i = f*g^i*G. */
+int orc_fr_geom_dot(int curve, const uint8_t *scalars, size_t n, int sb, u64 f, u64 g, unsigned skip_mod, unsigned skip_rem, uint8_t *out) {
+    curve_t *C = get_curve(curve); const fld *F = &C->Fr;
+    if (sb < 1 || sb > 32) return -1;
+    u64 fm[MAXL] = {f}, gm[MAXL] = {g};
+    fe_to_mont(F, fm, fm); fe_to_mont(F, gm, gm);
+    const size_t CH = 8192, nch = (n + CH - 1) / CH;
+    u64 (*part)[4] = calloc(nch ? nch : 1, 32);
+    #pragma omp parallel for schedule(static)
+    for (size_t ci = 0; ci < nch; ci++) {
+        const size_t c0 = ci * CH, hi = c0 + CH < n ? c0 + CH : n;
+        u64 t[MAXL], x[MAXL], acc[MAXL] = {0}, e[1] = {(u64)c0};
+        fe_pow(F, t, gm, e, 1); fe_mul(F, t, t, fm);
+        for (size_t i = c0; i < hi; i++) {
+            if (!(skip_mod && (i % skip_mod) == skip_rem)) {
+                memset(x, 0, sizeof x); memcpy(x, scalars + i * (size_t)sb, (size_t)sb);
+                fe_to_mont(F, x, x);                   /* any 256-bit integer -> its residue in M form */
+                fe_mul(F, x, x, t); fe_add(F, acc, acc, x);
+            }
+            fe_mul(F, t, t, gm);
+        }
+        memcpy(part[ci], acc, 32);
+    }
+    u64 acc[MAXL] = {0};
+    for (size_t ci = 0; ci < nch; ci++) fe_add(F, acc, acc, part[ci]);
+    free(part);
+    fe_from_mont(F, acc, acc);
+    memcpy(out, acc, 32);
+    return 0;
+}
+#ifdef _OPENMP
+#include <omp.h>
+int orc_threads(void) { return omp_get_max_threads(); }
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+int orc_threads(void) { return 1; }
+void orc_set_threads(int n) { (void)n; }
+#endif

@@ -102,18 +102,43 @@ struct G16Key {
     uint32_t v_lo = 0, v_cnt = 0, h_lo = 0, h_cnt = 0;
     bool full() const { return v_lo == 0 && h_lo == 0 && v_cnt == n_vars && h_cnt == domain; }
     uint32_t *row_cnt = nullptr, *row_start = nullptr, *sig = nullptr, *val = nullptr;
-    uint32_t *w = nullptr, *A = nullptr, *B = nullptr, *C = nullptr, *T = nullptr;
+    // per pipeline slot (two proofs may be in flight, zkmi_groth16_submit_dev): work buffers, stage events, the MSM jobs of the
+    // proof in flight. Slot 1 is allocated on first use.
+    struct Work {
+        uint32_t *w = nullptr, *A = nullptr, *B = nullptr, *C = nullptr, *T = nullptr;
+        hipEvent_t ev[ST_COUNT + 1] = {};
+        MsmJob job[5];
+        bool in_flight = false, ov = false;
+    } wk[2];
     std::vector<uint8_t> vk_alpha_1, vk_beta_1, vk_beta_2, vk_delta_1, vk_delta_2;
     mutable std::vector<uint8_t> fb_delta1, fb_delta2;   // host fixed-base tables of delta (g16_finish), built on first use
-    hipEvent_t ev[ST_COUNT + 1] = {};
     double stage_ms[ST_COUNT] = {};
     void release() {
-        void* ptrs[] = {bA, bB1, bB2, bC, bH, row_cnt, row_start, sig, val, w, A, B, C, T, mask[0], mask[1], mask[2], mask[3], mask[4], drop_b};
-        for (void* p : ptrs) if (p) (void)hipFree(p);
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        void** ptrs[] = {&bA, &bB1, &bB2, &bC, &bH, (void**)&row_cnt, (void**)&row_start, (void**)&sig, (void**)&val, (void**)&mask[0], (void**)&mask[1], (void**)&mask[2],
+                         (void**)&mask[3], (void**)&mask[4], (void**)&drop_b, (void**)&wk[0].w, (void**)&wk[0].A, (void**)&wk[0].B, (void**)&wk[0].C, (void**)&wk[0].T,
+                         (void**)&wk[1].w, (void**)&wk[1].A, (void**)&wk[1].B, (void**)&wk[1].C, (void**)&wk[1].T};
+        for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        for (auto& wkk : wk) for (auto& e : wkk.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
+    ~G16Key() { release(); }          // every early return of g16_load (ZK_TRY / ZK_HIP after make_unique) frees what was allocated so far
+    G16Key() = default;
+    G16Key(const G16Key&) = delete;
+    G16Key& operator=(const G16Key&) = delete;
+};
+// frees a temporary device allocation on every exit path
+struct DevTmp {
+    void* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
 };
 
+static int g16_work_alloc(G16Key& K, int slot) {
+    G16Key::Work& W = K.wk[slot];
+    if (W.A) return ZKMI_OK;
+    ZK_HIP(hipMalloc((void**)&W.w, (size_t)K.n_vars * 32));
+    for (uint32_t** p : {&W.A, &W.B, &W.C, &W.T}) ZK_HIP(hipMalloc((void**)p, (size_t)K.domain * 32));
+    for (auto& e : W.ev) ZK_HIP(hipEventCreate(&e));
+    return ZKMI_OK;
+}
 static int upload(void** d, const uint8_t* h, size_t bytes, hipStream_t st) {
     ZK_HIP(hipMalloc(d, bytes ? bytes : 16));
     if (bytes) ZK_HIP(hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, st));
@@ -133,6 +158,17 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
     K->power = (uint32_t)ilog2_sz(n);
     K->n_coef = (uint32_t)((zk->coeffs_len - 4) / 44);            // buildABC1: nCoef = (byteLength-4)/sCoef (:149-150)
     const size_t q = n8q_of(zk->curve), g1 = 2 * q, g2 = 4 * q;
+    {   // section lengths against the header (src/zkey_utils.js:183-205: nVars points in sections 5-7, nVars-nPublic-1 in 8, domainSize in 9)
+        const size_t nv = zk->n_vars, nc = nv - zk->n_public - 1;
+        if (!zk->coeffs || !zk->bases_a || !zk->bases_b1 || !zk->bases_b2 || !zk->bases_c || !zk->bases_h || !zk->vk_alpha_1 || !zk->vk_beta_1 || !zk->vk_beta_2 ||
+            !zk->vk_delta_1 || !zk->vk_delta_2)
+            return fail(ZKMI_ERR_INVALID, "groth16: null section pointer");
+        if (zk->bases_a_len < nv * g1 || zk->bases_b1_len < nv * g1 || zk->bases_b2_len < nv * g2 || zk->bases_c_len < nc * g1 || zk->bases_h_len < (size_t)n * g1)
+            return fail(ZKMI_ERR_INVALID, "groth16: a base section is shorter than nVars / nPublic / domainSize of the header require");
+        uint32_t n_coef_hdr = 0;
+        memcpy(&n_coef_hdr, zk->coeffs, 4);
+        if ((size_t)n_coef_hdr != (zk->coeffs_len - 4) / 44) return fail(ZKMI_ERR_INVALID, "groth16: coefficient count does not match the section length");
+    }
     if (v_lo >= v_hi || v_hi > zk->n_vars || h_lo >= h_hi || h_hi > n) return fail(ZKMI_ERR_INVALID, "groth16: empty or out-of-range key shard");
     K->v_lo = v_lo; K->v_cnt = v_hi - v_lo; K->h_lo = h_lo; K->h_cnt = h_hi - h_lo;
     // m = witness-side bases held here; C pairs with witness[nPublic+1:] (:97): c_front = entries of this range that precede it
@@ -147,12 +183,13 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
     K->ch = pc == 0 ? 0 : (pc > 0 ? pc : msm_precomp_c(K->h_cnt));
     auto put_table = [&](void** dst, uint32_t** mask, const uint8_t* src, size_t cnt, size_t pad_front, int group, int c) -> int {
         const size_t pb = group == 1 ? g1 : g2, tot = cnt + pad_front;
-        void* raw = nullptr;
-        ZK_HIP(hipMalloc(&raw, tot * pb ? tot * pb : 16));
+        DevTmp tmp;
+        ZK_HIP(hipMalloc(&tmp.p, tot * pb ? tot * pb : 16));
+        void* raw = tmp.p;
         if (pad_front) ZK_HIP(hipMemsetAsync(raw, 0, pad_front * pb, st));             // all-zero bytes = point at infinity
         if (cnt) ZK_HIP(hipMemcpyAsync((uint8_t*)raw + pad_front * pb, src, cnt * pb, hipMemcpyHostToDevice, st));
         const int Wd = c ? msm_digits(32, c) : 1;
-        if (!c) *dst = raw;
+        if (!c) { *dst = raw; tmp.p = nullptr; }
         else {
             ZK_HIP(hipMalloc(dst, (size_t)Wd * tot * pb));
             ZK_TRY(msm_precompute_dispatch(zk->curve, group, raw, tot, c, Wd, *dst));
@@ -160,8 +197,7 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
         ZK_HIP(hipMalloc((void**)mask, (((size_t)Wd * tot + 31) / 32) * 4 + 16));
         ZK_TRY(msm_infmask_dispatch(zk->curve, group, *dst, (size_t)Wd * tot, *mask));
         ZK_HIP(hipStreamSynchronize(st));
-        if (c) (void)hipFree(raw);
-        return ZKMI_OK;
+        return ZKMI_OK;                                    // ~DevTmp frees the plain copy when a table was built from it
     };
     ZK_TRY(put_table(&K->bA, &K->mask[0], zk->bases_a + (size_t)v_lo * g1, m, 0, 1, K->cw));
     ZK_TRY(put_table(&K->bB1, &K->mask[1], zk->bases_b1 + (size_t)v_lo * g1, m, 0, 1, K->cw));
@@ -188,12 +224,13 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
     K->vk_beta_2.assign(zk->vk_beta_2, zk->vk_beta_2 + g2); K->vk_delta_1.assign(zk->vk_delta_1, zk->vk_delta_1 + g1);
     K->vk_delta_2.assign(zk->vk_delta_2, zk->vk_delta_2 + g2);
     // CSR conversion of the coefficient section, on the device
-    void* raw = nullptr;
-    ZK_TRY(upload(&raw, zk->coeffs, zk->coeffs_len, st));
+    DevTmp raw_t, cursor_t;
+    ZK_TRY(upload(&raw_t.p, zk->coeffs, zk->coeffs_len, st));
+    void* raw = raw_t.p;
     const size_t rows = 2 * (size_t)n;
-    uint32_t* cursor = nullptr;
     ZK_HIP(hipMalloc((void**)&K->row_cnt, rows * 4)); ZK_HIP(hipMalloc((void**)&K->row_start, rows * 4));
-    ZK_HIP(hipMalloc((void**)&cursor, rows * 4 + 16));
+    ZK_HIP(hipMalloc(&cursor_t.p, rows * 4 + 16));
+    uint32_t* cursor = (uint32_t*)cursor_t.p;
     ZK_HIP(hipMalloc((void**)&K->sig, std::max<size_t>(K->n_coef, 1) * 4)); ZK_HIP(hipMalloc((void**)&K->val, std::max<size_t>(K->n_coef, 1) * 32));
     ZK_HIP(hipMemsetAsync(K->row_cnt, 0, rows * 4, st)); ZK_HIP(hipMemsetAsync(cursor, 0, rows * 4 + 16, st));
     uint32_t* bad = cursor + rows;
@@ -207,13 +244,10 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
     ZK_HIP(hipMemcpyAsync(&nbad, bad, 4, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     ZK_HIP(hipGetLastError());
-    (void)hipFree(raw); (void)hipFree(cursor);
-    if (nbad) { K->release(); return fail(ZKMI_ERR_INVALID, "groth16: coefficient record out of range (matrix > 1, constraint >= domain or signal >= nVars)"); }
-    ZK_HIP(hipMalloc((void**)&K->w, (size_t)zk->n_vars * 32));
-    for (uint32_t** p : {&K->A, &K->B, &K->C, &K->T}) ZK_HIP(hipMalloc((void**)p, (size_t)n * 32));
-    for (auto& e : K->ev) ZK_HIP(hipEventCreate(&e));
+    if (nbad) { return fail(ZKMI_ERR_INVALID, "groth16: coefficient record out of range (matrix > 1, constraint >= domain or signal >= nVars)"); }
+    ZK_TRY(g16_work_alloc(*K, 0));
     auto it = cx.groth16.find(key);
-    if (it != cx.groth16.end()) { ((G16Key*)it->second)->release(); delete (G16Key*)it->second; }
+    if (it != cx.groth16.end()) delete (G16Key*)it->second;
     cx.groth16[key] = K.release();
     return ZKMI_OK;
 }
@@ -287,21 +321,26 @@ static void g16_finish(const G16Key& K, const uint8_t* jA, const uint8_t* jB1, c
 // The device part of one proof: the five MSM results of THIS key (shard) as Jacobian points jA | jB1 | jB2 | jC | jH
 // (3*n8q bytes each, 6*n8q for jB2). With the full key they are the MSMs of src/groth16_prove.js:85-101; with a shard they are
 // partial sums over its base-index range, to be added across devices before g16_finish.
-template <class FrC> static int g16_sums_dev(G16Key& K, const void* d_witness, uint8_t* jA, uint8_t* jB1, uint8_t* jB2, uint8_t* jC, uint8_t* jH) {
+// g16_enqueue puts the whole device part of a proof on the streams of the ACTIVE pipeline slot and returns without waiting;
+// g16_complete waits for that slot and folds the window sums on the host.
+template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness) {
     Ctx& cx = ctx();
+    ZK_TRY(g16_work_alloc(K, cx.pipe));
+    G16Key::Work& Wk = K.wk[cx.pipe];
+    if (Wk.in_flight) return fail(ZKMI_ERR_INVALID, "groth16: this pipeline slot already holds a proof in flight (collect it first)");
     hipStream_t st = cx.stream;
     const uint32_t n = K.domain;
     const host::HField<4> Fr = host::HField<4>::from_cfg<FrC>();
     const uint32_t* w = (const uint32_t*)d_witness;
     const uint8_t* w_sh = (const uint8_t*)d_witness + (size_t)K.v_lo * 32;       // scalars of this shard's witness-side bases
-    const uint8_t* h_sh = (const uint8_t*)K.T + (size_t)K.h_lo * 32;
+    const uint8_t* h_sh = (const uint8_t*)Wk.T + (size_t)K.h_lo * 32;
     // The three digit sorts (witness without the B-infinity entries, witness, H scalars) are LDS/latency-bound; the NTT chain and
     // the bucket accumulations are ALU-bound. With ZKMI_OVERLAP (default) the sorts run on the auxiliary stream underneath them
     // and the main stream only waits on their events. ZKMI_OVERLAP=0 keeps everything on one stream.
     static const bool ov = !(getenv("ZKMI_OVERLAP") && atoi(getenv("ZKMI_OVERLAP")) == 0);
     MsmPlan pl, plh, plb;
-    MsmJob job[5];
-    for (int i = 0; i < 5; i++) ZK_TRY(msm_job_slot(i, job[i]));
+    MsmJob* job = Wk.job;
+    for (int i = 0; i < 5; i++) { job[i] = MsmJob(); ZK_TRY(msm_job_slot(i, job[i])); }
     // Two digit sorts of the witness: one without the entries whose B bases are at infinity (feeds B2 and B1), one complete
     // (feeds A and C). The second sort pays for itself once ~10 % of the B bases are at infinity.
     const bool split_b = K.b_density < 0.9;
@@ -321,21 +360,21 @@ template <class FrC> static int g16_sums_dev(G16Key& K, const void* d_witness, u
         cx.stream = st;
         ZK_TRY(rc);
     }
-    ZK_HIP(hipEventRecord(K.ev[ST_BUILD], st));
-    hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, w, n, K.A, K.B, K.C);
-    ZK_HIP(hipEventRecord(K.ev[ST_NTT], st));
+    ZK_HIP(hipEventRecord(Wk.ev[ST_BUILD], st));
+    hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, w, n, Wk.A, Wk.B, Wk.C);
+    ZK_HIP(hipEventRecord(Wk.ev[ST_NTT], st));
     // inc = power == Fr.s ? Fr.shift : Fr.w[power+1] (:64); Fr.shift = nqr^2 — both come from the NTT module's root table
     uint8_t one[32], inc[32];
     memcpy(one, Fr.one, 32);
     ZK_TRY(fr_coset_inc(K.curve, K.power, inc));
-    uint32_t* bufs[3] = {K.A, K.B, K.C};
+    uint32_t* bufs[3] = {Wk.A, Wk.B, Wk.C};
     for (int k = 0; k < 3; k++) {
-        ZK_TRY(ntt_dev_dispatch(K.curve, bufs[k], K.T, K.power, 1, nullptr, nullptr));
-        ZK_TRY(ntt_dev_dispatch(K.curve, K.T, bufs[k], K.power, 0, one, inc));
+        ZK_TRY(ntt_dev_dispatch(K.curve, bufs[k], Wk.T, K.power, 1, nullptr, nullptr));
+        ZK_TRY(ntt_dev_dispatch(K.curve, Wk.T, bufs[k], K.power, 0, one, inc));
     }
-    ZK_HIP(hipEventRecord(K.ev[ST_JOIN], st));
-    ZK_TRY(join_abc_dev_dispatch(K.curve, K.A, K.B, K.C, K.T, n));          // T = H-MSM scalars (normal form)
-    ZK_HIP(hipEventRecord(K.ev[ST_SORT_W], st));
+    ZK_HIP(hipEventRecord(Wk.ev[ST_JOIN], st));
+    ZK_TRY(join_abc_dev_dispatch(K.curve, Wk.A, Wk.B, Wk.C, Wk.T, n));          // T = H-MSM scalars (normal form)
+    ZK_HIP(hipEventRecord(Wk.ev[ST_SORT_W], st));
     if (ov) {
         ZK_HIP(hipEventRecord(cx.sort_ev[3], st));
         ZK_HIP(hipStreamWaitEvent(aux, cx.sort_ev[3], 0));
@@ -349,7 +388,7 @@ template <class FrC> static int g16_sums_dev(G16Key& K, const void* d_witness, u
     const MsmPlan& pB = split_b ? plb : pl;
     // The G2 MSM goes first: its bucket reduction is pure latency (~50 us per Fq2 point addition, little parallel work), so it
     // also runs on the auxiliary stream, underneath the G1 accumulations.
-    ZK_HIP(hipEventRecord(K.ev[ST_MSM_B2], st));
+    ZK_HIP(hipEventRecord(Wk.ev[ST_MSM_B2], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 2, K.bB2, pB, 0, job[2], K.mask[2]));
     if (ov) {
         ZK_HIP(hipEventRecord(cx.aux_ev[0], st));
@@ -357,40 +396,54 @@ template <class FrC> static int g16_sums_dev(G16Key& K, const void* d_witness, u
         ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1, true));
         ZK_HIP(hipEventRecord(cx.aux_ev[1], aux));
     }
-    ZK_HIP(hipEventRecord(K.ev[ST_MSM_B1], st));
+    ZK_HIP(hipEventRecord(Wk.ev[ST_MSM_B1], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bB1, pB, 0, job[1], K.mask[1]));
     if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[2], 0));
     else if (split_b) ZK_TRY(msm_sort(w_sh, K.v_cnt, 32, pl, 0, K.cw));
-    ZK_HIP(hipEventRecord(K.ev[ST_MSM_A], st));
+    ZK_HIP(hipEventRecord(Wk.ev[ST_MSM_A], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bA, pl, 0, job[0], K.mask[0]));
-    ZK_HIP(hipEventRecord(K.ev[ST_MSM_C], st));
+    ZK_HIP(hipEventRecord(Wk.ev[ST_MSM_C], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.c_skip, job[3], K.mask[3]));
-    ZK_HIP(hipEventRecord(K.ev[ST_SORT_H], st));
+    ZK_HIP(hipEventRecord(Wk.ev[ST_SORT_H], st));
     if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[4], 0));
     else ZK_TRY(msm_sort(h_sh, K.h_cnt, 32, plh, 1, K.ch));
-    ZK_HIP(hipEventRecord(K.ev[ST_MSM_H], st));
+    ZK_HIP(hipEventRecord(Wk.ev[ST_MSM_H], st));
     // pi_c only needs C + H (:115): when both MSMs have the same bucket shape, H is accumulated into C's buckets and the two share
     // one bucket reduction (ZKMI_MERGE_CH=0 keeps them apart)
     static const bool merge_env = !(getenv("ZKMI_MERGE_CH") && atoi(getenv("ZKMI_MERGE_CH")) == 0);
     const bool merge_ch = merge_env && K.ch == K.cw && plh.sh.W == pl.sh.W && plh.sh.nb == pl.sh.nb;
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, plh, 0, job[4], K.mask[4], merge_ch ? &job[3] : nullptr));
-    ZK_HIP(hipEventRecord(K.ev[ST_REDUCE], st));
+    ZK_HIP(hipEventRecord(Wk.ev[ST_REDUCE], st));
     // bucket reductions are latency-bound: all G1 jobs of one shape go through ONE set of launches
     MsmJob* g1[4] = {&job[0], &job[1], &job[3], &job[4]};
     if (merge_ch) ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 3));
     else if (job[4].W == job[0].W && job[4].c == job[0].c) ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 4));
     else { ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1, 3)); ZK_TRY(msm_reduce_dispatch(K.curve, 1, g1 + 3, 1)); }
     if (!ov) ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1));
-    ZK_HIP(hipEventRecord(K.ev[ST_COUNT], st));
-    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipEventRecord(Wk.ev[ST_COUNT], st));
     ZK_HIP(hipGetLastError());
-    for (int i = 0; i < ST_COUNT; i++) { float ms = 0; if (hipEventElapsedTime(&ms, K.ev[i], K.ev[i + 1]) == hipSuccess) K.stage_ms[i] = ms; }
+    Wk.in_flight = true; Wk.ov = ov;
+    return ZKMI_OK;
+}
+template <class FrC> static int g16_complete(G16Key& K, uint8_t* jA, uint8_t* jB1, uint8_t* jB2, uint8_t* jC, uint8_t* jH) {
+    Ctx& cx = ctx();
+    G16Key::Work& Wk = K.wk[cx.pipe];
+    if (!Wk.in_flight) return fail(ZKMI_ERR_INVALID, "groth16: no proof in flight in this pipeline slot");
+    Wk.in_flight = false;
+    MsmJob* job = Wk.job;
+    ZK_HIP(hipStreamSynchronize(cx.stream));
+    ZK_HIP(hipGetLastError());
+    for (int i = 0; i < ST_COUNT; i++) { float ms = 0; if (hipEventElapsedTime(&ms, Wk.ev[i], Wk.ev[i + 1]) == hipSuccess) K.stage_ms[i] = ms; }
     // the host folds of the G1 jobs run while the G2 reduction may still be finishing on the auxiliary stream
     ZK_TRY(msm_fold_dispatch(K.curve, 1, job[0], jA)); ZK_TRY(msm_fold_dispatch(K.curve, 1, job[1], jB1));
     ZK_TRY(msm_fold_dispatch(K.curve, 1, job[3], jC)); ZK_TRY(msm_fold_dispatch(K.curve, 1, job[4], jH));
-    if (ov) ZK_HIP(hipStreamSynchronize(cx.aux_stream));
+    if (Wk.ov) ZK_HIP(hipStreamSynchronize(cx.aux_stream));
     ZK_TRY(msm_fold_dispatch(K.curve, 2, job[2], jB2));
     return ZKMI_OK;
+}
+template <class FrC> static int g16_sums_dev(G16Key& K, const void* d_witness, uint8_t* jA, uint8_t* jB1, uint8_t* jB2, uint8_t* jC, uint8_t* jH) {
+    ZK_TRY(g16_enqueue<FrC>(K, d_witness));
+    return g16_complete<FrC>(K, jA, jB1, jB2, jC, jH);
 }
 static void g16_finish_dispatch(const G16Key& K, const uint8_t* jA, const uint8_t* jB1, const uint8_t* jB2, const uint8_t* jC, const uint8_t* jH, const uint8_t* r_mont,
                                 const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
@@ -449,8 +502,7 @@ int zkmi_groth16_finish(uint64_t key, const uint8_t* sums, const uint8_t* r_mont
 int zkmi_groth16_release(uint64_t key) {
     auto it = ctx().groth16.find(key);
     if (it == ctx().groth16.end()) return ZKMI_OK;
-    if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
-    ((G16Key*)it->second)->release();
+    if (ctx().ready) (void)hipDeviceSynchronize();            // both pipeline slots, main and auxiliary streams
     delete (G16Key*)it->second;
     ctx().groth16.erase(it);
     return ZKMI_OK;
@@ -464,7 +516,32 @@ int zkmi_groth16_prove_dev(uint64_t key, const void* d_witness, const uint8_t* r
     if (K->curve == ZKMI_CURVE_BN128) return g16_prove_dev<Bn254Fr>(*K, d_witness, r_mont, s_mont, pi_a, pi_b, pi_c);
     return g16_prove_dev<Bls12381Fr>(*K, d_witness, r_mont, s_mont, pi_a, pi_b, pi_c);
 }
-int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_t* witness, const uint8_t* r_mont, const uint8_t* s_mont,
+int zkmi_groth16_submit_dev(uint64_t key, const void* d_witness, int slot) {
+    ZK_TRY(require_ctx());
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_submit_dev: key not loaded");
+    if (!K->full()) return fail(ZKMI_ERR_INVALID, "groth16_submit_dev: the key is a shard");
+    if (!d_witness) return fail(ZKMI_ERR_INVALID, "groth16_submit_dev: null witness");
+    ZK_TRY(select_pipe(slot));
+    g_last_key = key;
+    int rc = K->curve == ZKMI_CURVE_BN128 ? g16_enqueue<Bn254Fr>(*K, d_witness) : g16_enqueue<Bls12381Fr>(*K, d_witness);
+    int rc2 = select_pipe(0);
+    return rc ? rc : rc2;
+}
+int zkmi_groth16_collect(uint64_t key, int slot, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+    ZK_TRY(require_ctx());
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_collect: key not loaded");
+    if (!r_mont || !s_mont || !pi_a || !pi_b || !pi_c) return fail(ZKMI_ERR_INVALID, "groth16_collect: null argument");
+    ZK_TRY(select_pipe(slot));
+    uint8_t jA[144], jB1[144], jB2[288], jC[144], jH[144];
+    int rc = K->curve == ZKMI_CURVE_BN128 ? g16_complete<Bn254Fr>(*K, jA, jB1, jB2, jC, jH) : g16_complete<Bls12381Fr>(*K, jA, jB1, jB2, jC, jH);
+    int rc2 = select_pipe(0);
+    if (rc || rc2) return rc ? rc : rc2;
+    g16_finish_dispatch(*K, jA, jB1, jB2, jC, jH, r_mont, s_mont, pi_a, pi_b, pi_c);
+    return ZKMI_OK;
+}
+int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_t* witness, size_t witness_len, const uint8_t* r_mont, const uint8_t* s_mont,
                        uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
     ZK_TRY(require_ctx());
     if (!witness) return fail(ZKMI_ERR_INVALID, "groth16_prove: null witness");
@@ -472,10 +549,23 @@ int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_
     if (!g16_find(k) || !key) {
         if (!zkey) return fail(ZKMI_ERR_INVALID, "groth16_prove: key not loaded and no zkey given");
         ZK_TRY(g16_load(zkey, k, 0, zkey->n_vars, 0, zkey->domain_size));
+    } else if (zkey) {
+        // a descriptor next to a resident key must describe the same circuit: a caller that re-uses key numbers for different
+        // zkeys would otherwise get a proof for the FIRST circuit with rc 0
+        const G16Key* R = g16_find(k);
+        if (R->curve != zkey->curve || R->n_vars != zkey->n_vars || R->n_public != zkey->n_public || R->domain != zkey->domain_size ||
+            zkey->coeffs_len < 4 || (size_t)R->n_coef != (zkey->coeffs_len - 4) / 44)
+            return fail(ZKMI_ERR_INVALID, "groth16_prove: the resident key under this cache key belongs to a different circuit (release it first)");
     }
     G16Key* K = g16_find(k);
-    ZK_HIP(hipMemcpyAsync(K->w, witness, (size_t)K->n_vars * 32, hipMemcpyHostToDevice, ctx().stream));
-    int rc = zkmi_groth16_prove_dev(k, K->w, r_mont, s_mont, pi_a, pi_b, pi_c);
+    if (witness_len != (size_t)K->n_vars * 32) {
+        const std::string msg = "Invalid witness length. Circuit: " + std::to_string(K->n_vars) + ", witness: " + std::to_string(witness_len / 32);
+        if (!key) zkmi_groth16_release(k);
+        return fail(ZKMI_ERR_INVALID, msg);
+    }
+    ZK_TRY(select_pipe(0));
+    ZK_HIP(hipMemcpyAsync(K->wk[0].w, witness, (size_t)K->n_vars * 32, hipMemcpyHostToDevice, ctx().stream));
+    int rc = zkmi_groth16_prove_dev(k, K->wk[0].w, r_mont, s_mont, pi_a, pi_b, pi_c);
     if (!key) zkmi_groth16_release(k);
     return rc;
 }

@@ -2,6 +2,8 @@
 // marshalling and dispatch to the per-curve kernel drivers.  No CPU fallback: every compute entry point requires a
 // HIP device and fails with ZKMI_ERR_NO_DEVICE otherwise.
 #include <string.h>
+#include <thread>
+#include <algorithm>
 #include "msm_host.hpp"
 #include "zkmi_common.hpp"
 
@@ -19,8 +21,27 @@ int require_ctx() {
     return zkmi_init(0);
 }
 
+int select_pipe(int p) {
+    Ctx& cx = g_ctx;
+    if (p < 0 || p > 1) return fail(ZKMI_ERR_INVALID, "pipeline slot must be 0 or 1");
+    if (p == cx.pipe) return ZKMI_OK;
+    PipeRes& cur = cx.saved[cx.pipe];
+    cur.init = true; cur.own_stream = cx.own_stream; cur.stream = cx.stream; cur.aux_stream = cx.aux_stream; cur.pinned = cx.pinned;
+    memcpy(cur.aux_ev, cx.aux_ev, sizeof cur.aux_ev); memcpy(cur.sort_ev, cx.sort_ev, sizeof cur.sort_ev); memcpy(cur.job_ev, cx.job_ev, sizeof cur.job_ev);
+    PipeRes& nx = cx.saved[p];
+    if (!nx.init) {
+        ZK_HIP(hipStreamCreateWithFlags(&nx.own_stream, hipStreamNonBlocking));
+        nx.stream = nx.own_stream;
+        nx.init = true;
+    }
+    cx.own_stream = nx.own_stream; cx.stream = nx.stream; cx.aux_stream = nx.aux_stream; cx.pinned = nx.pinned;
+    memcpy(cx.aux_ev, nx.aux_ev, sizeof nx.aux_ev); memcpy(cx.sort_ev, nx.sort_ev, sizeof nx.sort_ev); memcpy(cx.job_ev, nx.job_ev, sizeof nx.job_ev);
+    cx.pipe = p;
+    return ZKMI_OK;
+}
+
 int ws_get(const std::string& name, size_t bytes, void** out) {
-    DevBuf& b = g_ctx.ws[name];
+    DevBuf& b = g_ctx.ws[g_ctx.pipe ? "P1:" + name : name];
     if (b.cap < bytes) {
         if (b.p) { ZK_HIP(hipStreamSynchronize(g_ctx.stream)); ZK_HIP(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
         size_t cap = bytes + bytes / 8 + 256;
@@ -245,7 +266,6 @@ int zkmi_msm_set_window_bits(int c) {
 struct MsmTable { void* p = nullptr; size_t n = 0; int c = 0, Wd = 0, curve = 0, group = 0; };
 static std::map<uint64_t, MsmTable> g_tables;
 static uint64_t g_next_table = 1;
-static std::map<uint64_t, MsmTable> g_key_tables;      // zkmi_msm base_cache_key -> resident table
 static int table_build(int curve, int group, const void* d_bases, size_t n, MsmTable& t) {
     const size_t pb = (size_t)2 * group * n8q_of(curve);
     t.curve = curve; t.group = group; t.n = n;
@@ -301,6 +321,113 @@ int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalar
     if (!out) return fail(ZKMI_ERR_INVALID, "null output");
     return msm_dev_dispatch(curve, group, d_bases, d_scalars, n, scalar_bytes, out);
 }
+// ---- content-addressed cache of resident base tables behind zkmi_msm ---------------------------------------------------------
+// zkey sections and SRS slices are static, so the same bytes come back on every proof; their pre-computed window tables stay on
+// the device. The cache is keyed by the CONTENT of the base buffer — a 128-bit hash of every 64 KiB chunk, computed by the
+// library on each call (host threads, a few GB/s per thread) — never by a caller-supplied fingerprint: two buffers that differ in one
+// interior point cannot share a table. Policy:
+//   * 1st sight of a buffer: plain MSM, only its chunk hashes are remembered; 2nd sight: the table is built (a one-proof CLI run
+//     never pays k_msm_precompute); an MSM over a PREFIX of a resident buffer (PLONK's PTau.slice(0, n+2..n+6)) re-uses its table,
+//     and building a table drops resident tables that are prefixes of it;
+//   * tables that would not fit (Wd*n >= 2^31 entries, or more bytes than the budget) are never built: plain bases every time;
+//   * least-recently-used tables are freed when the resident bytes exceed the budget (ZKMI_BASE_CACHE_BYTES, default 64 GiB).
+constexpr size_t BC_CHUNK = 64 * 1024;
+struct BcHash { uint64_t a = 0, b = 0; bool operator==(const BcHash& o) const { return a == o.a && b == o.b; } bool operator!=(const BcHash& o) const { return !(*this == o); } };
+static BcHash bc_hash_bytes(const uint8_t* p, size_t len) {
+    uint64_t h[4] = {0x9e3779b97f4a7c15ull ^ len, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull, 0x27d4eb2f165667c5ull};
+    size_t i = 0;
+    for (; i + 32 <= len; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ w[k]) * 0xff51afd7ed558ccdull; h[k] ^= h[k] >> 29; }
+    }
+    for (; i < len; i++) { h[i & 3] = (h[i & 3] ^ p[i]) * 0x100000001b3ull; }
+    BcHash r;
+    r.a = (h[0] ^ (h[1] << 1 | h[1] >> 63)) * 0xc4ceb9fe1a85ec53ull + h[2];
+    r.b = (h[2] ^ (h[3] << 7 | h[3] >> 57)) * 0xff51afd7ed558ccdull + h[0] + (h[1] >> 3);
+    r.a ^= r.a >> 31; r.b ^= r.b >> 33;
+    return r;
+}
+// chunk hashes of the first `total` bytes of a paged buffer (a chunk may straddle pages: gathered through a bounce buffer)
+static void bc_chunk_hashes(const zkmi_pages& pg, size_t total, std::vector<BcHash>& out) {
+    const size_t nch = (total + BC_CHUNK - 1) / BC_CHUNK;
+    out.assign(nch, BcHash());
+    std::vector<size_t> start((size_t)pg.n_pages + 1, 0);
+    for (int i = 0; i < pg.n_pages; i++) start[i + 1] = start[i] + pg.len[i];
+    auto work = [&](size_t c0, size_t c1) {
+        std::vector<uint8_t> bounce;
+        int page = 0;
+        for (size_t c = c0; c < c1; c++) {
+            const size_t off = c * BC_CHUNK, len = std::min(BC_CHUNK, total - off);
+            while (page + 1 < pg.n_pages && start[page + 1] <= off) page++;
+            if (off + len <= start[page + 1]) out[c] = bc_hash_bytes(pg.ptr[page] + (off - start[page]), len);
+            else {
+                bounce.resize(len);
+                size_t done = 0;
+                for (int q = page; q < pg.n_pages && done < len; q++) {
+                    const size_t o = off + done - start[q], k = std::min(len - done, pg.len[q] - o);
+                    memcpy(bounce.data() + done, pg.ptr[q] + o, k);
+                    done += k;
+                }
+                out[c] = bc_hash_bytes(bounce.data(), len);
+            }
+        }
+    };
+    unsigned nt = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+    if (nch < 64) nt = 1;
+    if (nt == 1) { work(0, nch); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, nch * t / nt, nch * (t + 1) / nt);
+    for (auto& x : th) x.join();
+}
+struct BcEntry {
+    int curve = 0, group = 0;
+    size_t n = 0;                       // points hashed (and resident, when table.p)
+    std::vector<BcHash> chunks;         // per 64 KiB of base bytes; the last one may cover a partial chunk
+    MsmTable table;                     // table.p == nullptr: seen, not resident
+    bool no_table = false;              // would exceed the limits: never build
+    uint64_t last_use = 0, uses = 0;
+    size_t bytes() const { return table.p ? (size_t)table.Wd * table.n * 2 * table.group * n8q_of(table.curve) : 0; }
+};
+static std::vector<BcEntry> g_bc;
+static uint64_t g_bc_clock = 0;
+static size_t bc_budget() {
+    static const size_t v = [] { const char* e = getenv("ZKMI_BASE_CACHE_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)64 << 30); }();
+    return v;
+}
+static size_t bc_resident_bytes() { size_t t = 0; for (auto& e : g_bc) t += e.bytes(); return t; }
+static void bc_free(BcEntry& e) {
+    if (e.table.p) { if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream); (void)hipFree(e.table.p); e.table = MsmTable(); }
+}
+// does the resident entry e hold, as a prefix, exactly the `total` bytes whose chunk hashes are `q`? Whole chunks are compared by
+// hash; a trailing partial chunk of the query is compared byte for byte against row 0 of the table (the plain bases).
+static int bc_prefix_match(const BcEntry& e, const zkmi_pages& pg, size_t total, const std::vector<BcHash>& q, bool* match) {
+    *match = false;
+    const size_t pb = (size_t)2 * e.group * n8q_of(e.curve), ebytes = e.n * pb;
+    if (total > ebytes) return ZKMI_OK;
+    const size_t full = total / BC_CHUNK, tail = total - full * BC_CHUNK;
+    for (size_t c = 0; c < full; c++) if (q[c] != e.chunks[c]) return ZKMI_OK;
+    if (tail) {
+        if (total == ebytes) { if (q[full] != e.chunks[full]) return ZKMI_OK; }
+        else {
+            if (!e.table.p) return ZKMI_OK;                  // nothing to compare the partial chunk with
+            std::vector<uint8_t> dev(tail), host(tail);
+            ZK_HIP(hipMemcpy(dev.data(), (const uint8_t*)e.table.p + full * BC_CHUNK, tail, hipMemcpyDeviceToHost));
+            size_t off = full * BC_CHUNK, done = 0, base = 0;
+            for (int i = 0; i < pg.n_pages && done < tail; i++) {
+                if (off + done < base + pg.len[i]) {
+                    const size_t o = off + done - base, k = std::min(tail - done, pg.len[i] - o);
+                    memcpy(host.data() + done, pg.ptr[i] + o, k);
+                    done += k;
+                }
+                base += pg.len[i];
+            }
+            if (memcmp(dev.data(), host.data(), tail)) return ZKMI_OK;
+        }
+    }
+    *match = true;
+    return ZKMI_OK;
+}
 int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t n, size_t scalar_bytes, uint64_t key, uint8_t* out) {
     ZK_TRY(require_ctx());
     ZK_TRY(check_cg(curve, group));
@@ -308,35 +435,88 @@ int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t 
     const size_t pb = (size_t)2 * group * n8q_of(curve);
     if (n == 0) { memset(out, 0, 3 * group * n8q_of(curve)); return ZKMI_OK; }
     if (pages_total(scalars) != n * scalar_bytes) return fail(ZKMI_ERR_INVALID, "Scalar size does not match");
+    if (pages_total(bases) < n * pb) return fail(ZKMI_ERR_INVALID, "input buffer shorter than n elements");
     void *d_b = nullptr, *d_s = nullptr;
     ZK_TRY(ws_get("api.scalars", n * scalar_bytes, &d_s));
     ZK_TRY(upload_pages(scalars, n * scalar_bytes, d_s));
-    if (key) {
-        // resident bases: uploaded once, expanded into pre-computed window tables (zkey sections / SRS are static)
-        MsmTable& t = g_key_tables[key];
-        if (t.n != n || t.curve != curve || t.group != group) {
-            if (t.p) { ZK_HIP(hipStreamSynchronize(g_ctx.stream)); (void)hipFree(t.p); t = MsmTable(); }
-            void* raw = nullptr;
-            ZK_HIP(hipMalloc(&raw, n * pb));
-            ZK_TRY(upload_pages(bases, n * pb, raw));
-            int rc = table_build(curve, group, raw, n, t);
-            (void)hipFree(raw);
-            if (rc) { g_key_tables.erase(key); return rc; }
+    if (key && scalar_bytes <= 32) {
+        std::vector<BcHash> q;
+        bc_chunk_hashes(bases, n * pb, q);
+        BcEntry* hit = nullptr;                      // resident table that holds these bases as a prefix
+        BcEntry* seen = nullptr;                     // exact buffer seen before, no table yet
+        for (auto& e : g_bc) {
+            if (e.curve != curve || e.group != group || e.chunks.empty()) continue;
+            if (e.chunks[0] != q[0] && e.n * pb >= BC_CHUNK && n * pb >= BC_CHUNK) continue;          // different first 64 KiB
+            if (e.table.p) { bool m = false; ZK_TRY(bc_prefix_match(e, bases, n * pb, q, &m)); if (m) { hit = &e; break; } }
+            else if (e.n == n && e.chunks == q) seen = &e;
         }
-        if (scalar_bytes <= 32) return msm_table_dispatch(curve, group, t.p, t.n, t.c, d_s, n, scalar_bytes, out);
-        d_b = t.p;                                   // wider scalars: row 0 of the table is the plain base array
-    } else {
-        ZK_TRY(ws_get("api.bases", n * pb, &d_b));
-        ZK_TRY(upload_pages(bases, n * pb, d_b));
+        if (!hit && seen && !seen->no_table) {
+            // 2nd sight: build the table, unless it cannot exist
+            MsmTable t;
+            const int c = msm_precomp_c(n), Wd = msm_digits(32, c);
+            const size_t tbytes = (size_t)Wd * n * pb;
+            if ((size_t)Wd * n >= (1ull << 31) || tbytes > bc_budget()) seen->no_table = true;
+            else {
+                // make room: least recently used first
+                while (bc_resident_bytes() + tbytes > bc_budget()) {
+                    BcEntry* lru = nullptr;
+                    for (auto& e : g_bc) if (e.table.p && (!lru || e.last_use < lru->last_use)) lru = &e;
+                    if (!lru) break;
+                    bc_free(*lru);
+                }
+                void* raw = nullptr;
+                ZK_HIP(hipMalloc(&raw, n * pb));
+                int rc = upload_pages(bases, n * pb, raw);
+                if (!rc) rc = table_build(curve, group, raw, n, t);
+                (void)hipFree(raw);
+                if (rc == ZKMI_OK) {
+                    seen->table = t;
+                    hit = seen;
+                    // resident tables that are prefixes of the new one are redundant now
+                    for (auto& e : g_bc)
+                        if (&e != seen && e.table.p && e.curve == curve && e.group == group && e.n < n) {
+                            bool pre = e.chunks.size() <= q.size();
+                            const size_t full = e.n * pb / BC_CHUNK;
+                            for (size_t k = 0; pre && k < full; k++) pre = e.chunks[k] == q[k];
+                            if (pre && (e.n * pb) % BC_CHUNK == 0) bc_free(e);
+                        }
+                } else if (t.p) (void)hipFree(t.p);
+                // a failed build (out of device memory) falls through to the plain path
+            }
+        }
+        if (!hit && !seen) {
+            BcEntry e;
+            e.curve = curve; e.group = group; e.n = n; e.chunks = q;
+            if (g_bc.size() >= 256) {                // bound the bookkeeping: forget the oldest entry that holds no table
+                size_t victim = g_bc.size();
+                for (size_t i = 0; i < g_bc.size(); i++) if (!g_bc[i].table.p && (victim == g_bc.size() || g_bc[i].last_use < g_bc[victim].last_use)) victim = i;
+                if (victim < g_bc.size()) g_bc.erase(g_bc.begin() + victim);
+            }
+            g_bc.push_back(std::move(e));
+            seen = &g_bc.back();
+        }
+        BcEntry* used = hit ? hit : seen;
+        used->last_use = ++g_bc_clock; used->uses++;
+        if (hit) return msm_table_dispatch(curve, group, hit->table.p, hit->table.n, hit->table.c, d_s, n, scalar_bytes, out);
     }
+    ZK_TRY(ws_get("api.bases", n * pb, &d_b));
+    ZK_TRY(upload_pages(bases, n * pb, d_b));
     return msm_dev_dispatch(curve, group, d_b, d_s, n, scalar_bytes, out);
 }
+// key != 0 / 0: both drop every cached base table (the cache is content-addressed; per-key release has no meaning any more)
 int zkmi_release_bases(uint64_t key) {
-    auto it = g_key_tables.find(key);
-    if (it == g_key_tables.end()) return ZKMI_OK;
-    if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
-    if (it->second.p) (void)hipFree(it->second.p);
-    g_key_tables.erase(it);
+    (void)key;
+    for (auto& e : g_bc) bc_free(e);
+    g_bc.clear();
+    return ZKMI_OK;
+}
+// introspection for tests: resident tables, their bytes, remembered (table-less) buffers
+int zkmi_base_cache_stats(uint64_t* n_tables, uint64_t* table_bytes, uint64_t* n_seen) {
+    uint64_t t = 0, s = 0;
+    for (auto& e : g_bc) { if (e.table.p) t++; else s++; }
+    if (n_tables) *n_tables = t;
+    if (table_bytes) *table_bytes = bc_resident_bytes();
+    if (n_seen) *n_seen = s;
     return ZKMI_OK;
 }
 

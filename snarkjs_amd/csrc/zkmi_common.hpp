@@ -38,8 +38,21 @@ struct NttPlan {
     uint32_t* LT[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
+// Per-pipeline-slot resources. Two Groth16 proofs can be in flight (zkmi_groth16_submit_dev / _collect): the latency-bound tail of
+// proof k (bucket reductions, result copies, host folds) then runs underneath the throughput-bound front of proof k+1. Each slot
+// owns its streams, events, pinned result slots and — through ws_get, which prefixes buffer names with the slot — its scratch
+// buffers. select_pipe() swaps the slot's resources into the Ctx fields the kernel drivers use.
+struct PipeRes {
+    bool init = false;
+    hipStream_t own_stream = nullptr, stream = nullptr, aux_stream = nullptr;
+    hipEvent_t aux_ev[2] = {}, sort_ev[5] = {}, job_ev[16] = {};
+    uint8_t* pinned = nullptr;
+};
+
 struct Ctx {
     bool ready = false;
+    int pipe = 0;                                           // active pipeline slot (0 | 1)
+    PipeRes saved[2];
     int device = -1;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -60,6 +73,7 @@ struct Ctx {
 };
 Ctx& ctx();
 int require_ctx();
+int select_pipe(int p);                                     // make pipeline slot p (0 | 1) the active one
 // scratch buffer `name` with at least `bytes` capacity (contents undefined)
 int ws_get(const std::string& name, size_t bytes, void** out);
 

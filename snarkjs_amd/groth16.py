@@ -61,7 +61,12 @@ class ProvingKey:
         p = lambda k: self._keep[k].ctypes.data
         self.desc = zkmi.Groth16Zkey(self.curve_id, zk["nVars"], zk["nPublic"], zk["domainSize"], p("coeffs"), self._keep["coeffs"].size,
                                      p("A"), p("B1"), p("B2"), p("C"), p("H"),
-                                     p("vk_alpha_1"), p("vk_beta_1"), p("vk_beta_2"), p("vk_delta_1"), p("vk_delta_2"))
+                                     p("vk_alpha_1"), p("vk_beta_1"), p("vk_beta_2"), p("vk_delta_1"), p("vk_delta_2"),
+                                     *(self._keep[k].size for k in ("A", "B1", "B2", "C", "H")))
+        q8 = zk["n8q"]
+        for k, cnt, g in (("A", zk["nVars"], 2), ("B1", zk["nVars"], 2), ("B2", zk["nVars"], 4), ("C", zk["nVars"] - zk["nPublic"] - 1, 2), ("H", zk["domainSize"], 2)):
+            if self._keep[k].size < cnt * g * q8:          # the library checks again (ZKMI_ERR_INVALID)
+                raise ValueError(f"zkey section {k} is shorter than the header requires ({self._keep[k].size} < {cnt * g * q8} bytes)")
         self.shard = shard
         if shard is None:
             zkmi.check(zkmi.lib().zkmi_groth16_load(C.byref(self.desc), self.key))
@@ -102,7 +107,19 @@ class ProvingKey:
             zkmi.check(L.zkmi_groth16_prove_dev(self.key, d_witness, zkmi.ptr(r), zkmi.ptr(s), zkmi.ptr(pi_a), zkmi.ptr(pi_b), zkmi.ptr(pi_c)))
         else:
             w = zkmi.u8(witness)
-            zkmi.check(L.zkmi_groth16_prove(None, self.key, zkmi.ptr(w), zkmi.ptr(r), zkmi.ptr(s), zkmi.ptr(pi_a), zkmi.ptr(pi_b), zkmi.ptr(pi_c)))
+            zkmi.check(L.zkmi_groth16_prove(None, self.key, zkmi.ptr(w), w.size, zkmi.ptr(r), zkmi.ptr(s), zkmi.ptr(pi_a), zkmi.ptr(pi_b), zkmi.ptr(pi_c)))
+        return pi_a, pi_b, pi_c
+
+    def submit(self, d_witness, slot=0):
+        """Enqueue the device part of a proof into pipeline slot 0 | 1 (witness already in device memory); returns at once."""
+        zkmi.check(zkmi.lib().zkmi_groth16_submit_dev(self.key, d_witness, slot))
+
+    def collect(self, slot, r_mont, s_mont):
+        """Wait for the proof in `slot`, fold and blind it -> (pi_a, pi_b, pi_c) affine Montgomery bytes."""
+        q = 32 if self.curve_id == 0 else 48
+        pi_a, pi_b, pi_c = np.zeros(2 * q, np.uint8), np.zeros(4 * q, np.uint8), np.zeros(2 * q, np.uint8)
+        r, s = zkmi.u8(r_mont), zkmi.u8(s_mont)
+        zkmi.check(zkmi.lib().zkmi_groth16_collect(self.key, slot, zkmi.ptr(r), zkmi.ptr(s), zkmi.ptr(pi_a), zkmi.ptr(pi_b), zkmi.ptr(pi_c)))
         return pi_a, pi_b, pi_c
 
     def stage_ms(self):

@@ -22,12 +22,16 @@ function sections(data, magic) {                           // @iden3/binfileutil
     return out;
 }
 
+// Resident Groth16 keys live in a process-global native map: the key numbers are allocated module-wide, so that two provers in
+// one process can never address each other's zkey (the library additionally refuses a descriptor that does not match the
+// resident key's circuit).
+let nextKey = 1;
+
 // prover = makeProver(snarkjs, options) ; proof = await prover.prove(zkeyBytes, wtnsBytes)
 function makeProver(snarkjs, options) {
     options = options || {};
     const addon = options.addon || loadAddon();
     addon.init(options.device === undefined ? 0 : options.device);
-    let nextKey = 1;
     const resident = new Map();                              // zkey Uint8Array -> cache key (base tables stay on the device)
 
     async function prove(zkeyBytes, wtnsBytes) {
@@ -46,15 +50,19 @@ function makeProver(snarkjs, options) {
         const nWitness = wh.getUint32(4 + wh.getUint32(0, true), true);
         if (nWitness != nVars) throw new Error(`Invalid witness length. Circuit: ${nVars}, witness: ${nWitness}`);
         const witness = ws[2][0];
+        if (witness.byteLength != nVars * n8r) throw new Error(`Invalid witness length. Circuit: ${nVars}, witness: ${witness.byteLength / n8r}`);
+        for (const [sec, cnt, g] of [[5, nVars, 2], [6, nVars, 2], [7, nVars, 4], [8, nVars - nPublic - 1, 2], [9, domainSize, 2]])
+            if (!zs[sec] || zs[sec][0].byteLength < cnt * g * n8q) throw new Error(`zkey section ${sec} is shorter than its header requires`);
         let key = resident.get(zkeyBytes), desc = curve.name == "bn128" ? 0 : 1;
-        if (!key) {
+        const fresh = !key;
+        if (fresh) {
             key = nextKey++;
-            resident.set(zkeyBytes, key);
             desc = { curve: desc, nVars, nPublic, domainSize, coeffs: zs[4][0], A: zs[5][0], B1: zs[6][0], B2: zs[7][0], C: zs[8][0], H: zs[9][0],
                      alpha1, beta1, beta2, delta1, delta2 };
         }
         const r = curve.Fr.random(), s = curve.Fr.random();           // src/groth16_prove.js:103-104
         const res = addon.groth16Prove(desc, key, witness, r, s);
+        if (fresh) resident.set(zkeyBytes, key);                      // only a key that actually loaded is remembered
         const proof = {
             pi_a: curve.G1.toObject(res.pi_a), pi_b: curve.G2.toObject(res.pi_b), pi_c: curve.G1.toObject(res.pi_c),
             protocol: "groth16", curve: curve.name,

@@ -34,18 +34,10 @@ function allocLike(b, byteLength) { return new b.constructor(byteLength); }
 function allocLikeSliced(b, byteLength) {
     return (b instanceof Uint8Array || b.byteLength <= PAGE_SIZE) ? new Uint8Array(byteLength) : new b.constructor(byteLength);
 }
-// 52-bit fingerprint of a base buffer (length + four 16-byte samples): zkey sections and SRS slices are static, so the
-// same bytes come back on every proof and the library keeps their pre-computed window tables resident under this key.
-function fingerprint(pages, byteLength) {
-    const first = (pages instanceof Uint8Array) ? pages : pages[0];
-    const last = (pages instanceof Uint8Array) ? pages : pages[pages.length - 1];
-    let h1 = 0x811c9dc5 ^ (byteLength >>> 0), h2 = 0x9e3779b9 ^ Math.floor(byteLength / 4294967296);
-    const mix = (buf, off) => {
-        for (let i = 0; i < 16 && off + i < buf.length; i++) { h1 = Math.imul(h1 ^ buf[off + i], 0x01000193) >>> 0; h2 = Math.imul(h2 + buf[off + i], 0x85ebca6b) >>> 0; h2 ^= h2 >>> 13; }
-    };
-    mix(first, 0); mix(first, Math.max(0, (first.length >> 1) & ~15)); mix(last, Math.max(0, last.length - 64)); mix(last, Math.max(0, last.length - 16));
-    return (h2 & 0xfffff) * 4294967296 + h1 + 1;               // 1 .. 2^52, exactly representable as a double
-}
+// Resident bases: the last argument of addon.msm only ALLOWS the library to keep a base buffer's pre-computed window tables on the
+// device. Identity is established by the library itself from the full content of the buffer (include/zkmi.h: zkmi_msm) — never
+// by a fingerprint computed here — and a table is only built the second time the same bytes are seen, under an LRU byte budget.
+const CACHE_ALLOWED = 1;
 function log2(n) { let l = 0; while ((1 << (l + 1)) <= n && l < 40) l++; return l; }
 
 function register(curve, options) {
@@ -58,6 +50,7 @@ function register(curve, options) {
     const Fr = curve.Fr;
     const orig = {};
     const cacheBases = options.cacheBases !== false;      // keep base tables resident between calls (static zkey sections)
+    const cacheMinPoints = options.cacheMinPoints === undefined ? 4096 : options.cacheMinPoints;
 
     for (const [gname, group] of [["G1", 1], ["G2", 2]]) {
         const G = curve[gname];
@@ -77,7 +70,7 @@ function register(curve, options) {
             const sScalar = Math.floor(buffScalars.byteLength / nPoints);
             if (sScalar * nPoints != buffScalars.byteLength) throw new Error("Scalar size does not match");
             if (logger) logger.debug(`Multiexp start: ${logText}: 0/${nPoints}`);
-            const key = (cacheBases && nPoints >= 4096) ? fingerprint(pagesOf(buffBases), buffBases.byteLength) : 0;
+            const key = (cacheBases && nPoints >= cacheMinPoints) ? CACHE_ALLOWED : 0;
             const res = addon.msm(cid, group, pagesOf(buffBases), pagesOf(buffScalars), nPoints, sScalar, key);
             if (logger) logger.debug(`Multiexp end: ${logText}: 0/${nPoints}`);
             return res;                                                  // Jacobian, Montgomery, 3*F.n8 bytes

@@ -217,8 +217,9 @@ static napi_value js_groth16_prove(napi_env env, napi_callback_info info) {
         memset(&zk, 0, sizeof zk);
         if (get_named_u32(env, argv[0], "curve", &c) || get_named_u32(env, argv[0], "nVars", &zk.n_vars) || get_named_u32(env, argv[0], "nPublic", &zk.n_public) ||
             get_named_u32(env, argv[0], "domainSize", &zk.domain_size) || get_named_u8(env, argv[0], "coeffs", &zk.coeffs, &zk.coeffs_len) ||
-            get_named_u8(env, argv[0], "A", &zk.bases_a, NULL) || get_named_u8(env, argv[0], "B1", &zk.bases_b1, NULL) || get_named_u8(env, argv[0], "B2", &zk.bases_b2, NULL) ||
-            get_named_u8(env, argv[0], "C", &zk.bases_c, NULL) || get_named_u8(env, argv[0], "H", &zk.bases_h, NULL) ||
+            get_named_u8(env, argv[0], "A", &zk.bases_a, &zk.bases_a_len) || get_named_u8(env, argv[0], "B1", &zk.bases_b1, &zk.bases_b1_len) ||
+            get_named_u8(env, argv[0], "B2", &zk.bases_b2, &zk.bases_b2_len) || get_named_u8(env, argv[0], "C", &zk.bases_c, &zk.bases_c_len) ||
+            get_named_u8(env, argv[0], "H", &zk.bases_h, &zk.bases_h_len) ||
             get_named_u8(env, argv[0], "alpha1", &zk.vk_alpha_1, NULL) || get_named_u8(env, argv[0], "beta1", &zk.vk_beta_1, NULL) ||
             get_named_u8(env, argv[0], "beta2", &zk.vk_beta_2, NULL) || get_named_u8(env, argv[0], "delta1", &zk.vk_delta_1, NULL) ||
             get_named_u8(env, argv[0], "delta2", &zk.vk_delta_2, NULL)) BAD_ARG();
@@ -234,7 +235,12 @@ static napi_value js_groth16_prove(napi_env env, napi_callback_info info) {
     uint8_t *pa, *pb, *pc;
     napi_value va = new_u8(env, 2 * q, &pa), vb = new_u8(env, 4 * q, &pb), vc = new_u8(env, 2 * q, &pc), res;
     if (!va || !vb || !vc) BAD_ARG();
-    int rc = zkmi_groth16_prove(pzk, (uint64_t)key, w.ptr[0], r, s, pa, pb, pc);
+    if (pzk) {             /* header points: 2*n8q (G1) / 4*n8q (G2) bytes each */
+        size_t l1, l2, l3, l4, l5; const uint8_t* d;
+        if (get_named_u8(env, argv[0], "alpha1", &d, &l1) || get_named_u8(env, argv[0], "beta1", &d, &l2) || get_named_u8(env, argv[0], "beta2", &d, &l3) ||
+            get_named_u8(env, argv[0], "delta1", &d, &l4) || get_named_u8(env, argv[0], "delta2", &d, &l5) || l1 < 2 * q || l2 < 2 * q || l3 < 4 * q || l4 < 2 * q || l5 < 4 * q) BAD_ARG();
+    }
+    int rc = zkmi_groth16_prove(pzk, (uint64_t)key, w.ptr[0], w.len[0], r, s, pa, pb, pc);
     if (rc) return throw_zkmi(env, rc);
     NAPI_OK(napi_create_object(env, &res));
     NAPI_OK(napi_set_named_property(env, res, "pi_a", va));

@@ -1,0 +1,98 @@
+"""Synthetic Groth16 proving key + witness (the "fast" variant): structurally valid zkey / wtns
+containers of any size whose proof does not verify (random bases) but is bit-comparable between implementations.
+
+Layout follows src/zkey_utils.js:229-259 (header) / :20-45 (sections) and src/wtns_utils.js:62-72.
+Bases come from the geometric table P_i = 7*11^i*G (device generator zkmi_gen_geometric_bases_dev, itself checked
+against the oracle in test_gpu_parity.py::test_msm_closed_form_large) or, without a GPU, a caller-supplied generator.
+"""
+import struct
+
+import numpy as np
+
+from . import synth
+
+PRIMES = {
+    "bn128": (32, 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+              21888242871839275222246405745257275088548364400416034343698204186575808495617),
+    "bls12381": (48, 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+                 52435875175126190479447740508185965837690552500527637822603658699938581184513),
+}
+
+
+def _section(typ, payload):
+    return struct.pack("<IQ", typ, len(payload)) + payload
+
+
+def _binfile(magic, sections):
+    body = b"".join(_section(t, p) for t, p in sections)
+    return magic + struct.pack("<II", 1, len(sections)) + body
+
+
+def _tables(name, n1, n2, tables):
+    """[G1 table of n1 points, G2 table of n2 points], P_i = 7*11^i*G affine Montgomery. tables: optional callable
+    (curve_id, group, n) -> bytes for hosts without a GPU (tests/synth_zkey.py passes the CPU oracle's generator)."""
+    cid = 0 if name == "bn128" else 1
+    q8 = PRIMES[name][0]
+    if tables is not None:
+        return [tables(cid, 1, n1), tables(cid, 2, n2)]
+    from .. import zkmi
+    zkmi.init()
+    out = []
+    for group, n in ((1, n1), (2, n2)):
+        d = zkmi.DeviceBuffer(n * 2 * group * q8)
+        zkmi.check(zkmi.lib().zkmi_gen_geometric_bases_dev(cid, group, n, 7, 11, d.ptr))
+        out.append(d.to_host())
+        d.free()
+    return out
+
+
+def make(name, lg, seed=1, n_public=2, witness="mixed", tables=None, coef_per_row=1, b_zero_every=3):
+    """-> (zkey_bytes, wtns_bytes). domain n = 2^lg, nVars m = n - 5 (min 4).
+    b_zero_every = k: every k-th B1/B2 base (i % k == 1) is the point at infinity, as for signals absent from the B matrix of a real
+    circuit (B density 1 - 1/k); 0 = dense B sections (SURVEY.md 8d recipe: every section filled from the geometric table)."""
+    q8, q, r = PRIMES[name]
+    n = 1 << lg
+    m = max(n - 5, n_public + 2)
+    mc = m - n_public - 1
+    T1, T2 = _tables(name, max(m + 1, n + 3, 8), max(m, 4), tables)
+    g1, g2 = 2 * q8, 4 * q8
+    T1 = T1.reshape(-1, g1)
+    T2 = T2.reshape(-1, g2)
+    A = T1[0:m].copy()
+    B1 = T1[1:m + 1].copy()
+    B2 = T2[0:m].copy()
+    if b_zero_every:
+        z = np.arange(m) % b_zero_every == 1          # real keys hold the point at infinity for signals absent from B
+        B1[z] = 0
+        B2[z] = 0
+    Cb = T1[2:2 + mc].copy()
+    H = T1[3:3 + n].copy()
+    # coefficients (section 4): two records per constraint + one long row + the public-input binding rows
+    cs = np.arange(n - 1, dtype=np.uint64)
+    recs = []
+    for k in range(coef_per_row):
+        recs.append((np.zeros(n - 1, np.uint32), cs, 1 + (cs * (2 * k + 1) + k) % (m - 1)))
+        recs.append((np.ones(n - 1, np.uint32), cs, 1 + (7 * cs + 3 + 5 * k) % (m - 1)))
+    long_row = min(50, m)
+    recs.append((np.zeros(long_row, np.uint32), np.zeros(long_row, np.uint64), np.arange(long_row, dtype=np.uint64) % m))
+    pub = np.arange(n_public + 1, dtype=np.uint64)
+    recs.append((np.zeros(n_public + 1, np.uint32), (n - 1 - pub) % n, pub))       # src/zkey_new.js:290-300 analogue
+    mm = np.concatenate([x[0] for x in recs]).astype("<u4")
+    cc = np.concatenate([x[1] for x in recs]).astype("<u4")
+    ss = np.concatenate([x[2] for x in recs]).astype("<u4")
+    ncoef = mm.size
+    rec = np.zeros(ncoef, dtype=[("m", "<u4"), ("c", "<u4"), ("s", "<u4"), ("v", "u1", 32)])
+    rec["m"], rec["c"], rec["s"] = mm, cc, ss
+    rec["v"] = synth.elems(seed ^ 0x5151, ncoef).reshape(ncoef, 32)     # any residue < r is a valid (v*R^2) encoding
+    coeffs = struct.pack("<I", ncoef) + rec.tobytes()
+    le = lambda v, k: int(v).to_bytes(k, "little")
+    hdr = (struct.pack("<I", q8) + le(q, q8) + struct.pack("<I", 32) + le(r, 32) + struct.pack("<III", m, n_public, n)
+           + T1[5].tobytes() + T1[6].tobytes() + T2[1].tobytes() + T2[3].tobytes() + T1[7].tobytes() + T2[2].tobytes())
+    ic = T1[8:8 + n_public + 1].tobytes() if T1.shape[0] >= 9 + n_public else bytes((n_public + 1) * g1)
+    zkey = _binfile(b"zkey", [(1, struct.pack("<I", 1)), (2, hdr), (3, ic), (4, coeffs), (5, A.tobytes()), (6, B1.tobytes()),
+                              (7, B2.tobytes()), (8, Cb.tobytes()), (9, H.tobytes())])
+    w = (synth.witness_like(seed, m) if witness == "mixed" else synth.elems(seed, m)).copy()
+    w[:32] = 0
+    w[0] = 1
+    wt = _binfile(b"wtns", [(1, struct.pack("<I", 32) + le(r, 32) + struct.pack("<I", m)), (2, w.tobytes())])
+    return zkey, wt

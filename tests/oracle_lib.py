@@ -136,6 +136,22 @@ def geom_bases(curve, group, n):
     return out
 
 
+def geom_dot(curve, scalars, n, sb=32, f=7, g=11, skip_mod=0, skip_rem=0) -> int:
+    """sum_i s_i * f * g^i mod r over entries with i % skip_mod != skip_rem (oracle/zk_oracle.c: orc_fr_geom_dot)."""
+    scalars = _u8(scalars)
+    out = np.zeros(32, np.uint8)
+    assert lib().orc_fr_geom_dot(curve, _p(scalars), C.c_size_t(n), sb, C.c_uint64(f), C.c_uint64(g), skip_mod, skip_rem, _p(out)) == 0
+    return int.from_bytes(out.tobytes(), "little")
+
+
+def threads():
+    return lib().orc_threads()
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
 def fq_from_mont(curve, x):
     x = _u8(x)
     out = np.empty_like(x)

@@ -179,6 +179,57 @@ def test_msm_edge_cases(zk):
     assert isinstance(out, list) and np.array_equal(np.concatenate(out), O.to_mont(c, x))
 
 
+def test_msm_base_cache_is_content_addressed(zk):
+    """The resident-base cache behind zkmi_msm (drop-in path: zkey sections / SRS slices stay on the device) must never serve a
+    stale table: it is keyed by the full content of the base buffer. Two buffers that differ in ONE interior point give different
+    (correct) results; a table is built on the second sight only; an MSM over a prefix of a resident buffer (PLONK's
+    PTau.slice(0, k)) re-uses its table; paged input hashes like flat input; the byte budget evicts."""
+    import ctypes as C
+    from snarkjs_amd import zkmi
+    L = zkmi.lib()
+    c, cv = O.BN128, curve_of(zk, "bn128")
+    n = 20000                                             # 1.28 MB of bases: 20 chunks of 64 KiB, the last one partial
+
+    def stats():
+        a, b, s_ = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        zkmi.check(L.zkmi_base_cache_stats(C.byref(a), C.byref(b), C.byref(s_)))
+        return a.value, b.value, s_.value
+    zkmi.check(L.zkmi_release_bases(0))
+    B = O.geom_bases(c, 1, n)
+    sc = synth.elems(0xCAC4E, n)
+    want = O.to_affine(c, 1, O.msm(c, 1, B, sc, n))
+    aff = lambda j: O.to_affine(c, 1, j)
+    assert np.array_equal(aff(cv.G1.multiExpAffine(B, sc, cache_key=1)), want) and stats() == (0, 0, 1)        # 1st sight: remembered only
+    assert np.array_equal(aff(cv.G1.multiExpAffine(B, sc, cache_key=1)), want) and stats()[0] == 1             # 2nd sight: table built
+    assert np.array_equal(aff(cv.G1.multiExpAffine(B, sc, cache_key=1)), want) and stats()[0] == 1             # 3rd: table used
+    # one interior point replaced (same length, same first / middle / last bytes): must NOT hit the resident table
+    B2 = B.copy()
+    i = 7777
+    B2[i * 64:(i + 1) * 64] = B[(i + 1) * 64:(i + 2) * 64]
+    want2 = O.to_affine(c, 1, O.msm(c, 1, B2, sc, n))
+    assert not np.array_equal(want, want2)
+    for _ in range(3):
+        assert np.array_equal(aff(cv.G1.multiExpAffine(B2, sc, cache_key=1)), want2)
+    assert stats()[0] == 2
+    assert np.array_equal(aff(cv.G1.multiExpAffine(B, sc, cache_key=1)), want)
+    # prefixes of a resident buffer re-use its table (chunk-aligned and not), paged input included
+    for k in (n - 3, 16384, 5000):
+        wk = O.to_affine(c, 1, O.msm(c, 1, B[:k * 64], sc[:k * 32], k))
+        before = stats()
+        assert np.array_equal(aff(cv.G1.multiExpAffine(B[:k * 64].copy(), sc[:k * 32], cache_key=1)), wk)
+        assert np.array_equal(aff(cv.G1.multiExpAffine([B[:64 * 1234].copy(), B[64 * 1234:k * 64].copy()], sc[:k * 32], cache_key=1)), wk)
+        assert stats() == before                          # no new table, no new entry
+    # a prefix of the MODIFIED buffer that includes the modified point must come out as the modified result
+    k = 9000
+    wk2 = O.to_affine(c, 1, O.msm(c, 1, B2[:k * 64], sc[:k * 32], k))
+    assert np.array_equal(aff(cv.G1.multiExpAffine(B2[:k * 64].copy(), sc[:k * 32], cache_key=1)), wk2)
+    # without the permission bit nothing is cached
+    zkmi.check(L.zkmi_release_bases(0))
+    for _ in range(3):
+        assert np.array_equal(aff(cv.G1.multiExpAffine(B, sc)), want)
+    assert stats() == (0, 0, 0)
+
+
 @pytest.mark.parametrize("name,group,lg", [("bn128", 1, 16), ("bn128", 1, 20), ("bn128", 2, 16), ("bls12381", 1, 16), ("bls12381", 2, 14)])
 def test_msm_closed_form_large(zk, name, group, lg):
     """SURVEY.md §8d: bases P_i = 7·11^i·G generated on the device, uniform 253-bit scalars;
@@ -216,19 +267,97 @@ def test_join_abc(zk, name):
     assert np.array_equal(cv.joinABC(a, b, cc), O.join_abc(c, a, b, cc))
 
 
-def test_groth16_golden_proof(zk, golden_dir):
-    """The seeded Groth16 proof of SURVEY.md Appendix C.3: fused device prover == the reference's proof JSON (sha256)."""
+@pytest.mark.parametrize("tag,sha_proof", [("groth16_bn128_n1024", "08797809c8de2c2053a925b1772af3e04c41f8c9b4c41f5b71ae5135435da44d"),
+                                           ("groth16_bls12381_n1024", "955b9f3652e544aac16a90fd1ce6b8660701a7eb20e71fa7681ced22f0acd5eb")])
+def test_groth16_golden_proof(zk, golden_dir, tag, sha_proof):
+    """The seeded Groth16 proofs generated by the reference itself (oracle/gen_golden.js): BN254 = SURVEY.md Appendix C.3, BLS12-381 =
+    the Multiplier(1000) r1cs of SURVEY.md 8d over the BLS12-381 scalar field (the reference's own verifier accepted both). The fused
+    device prover must emit the same proof JSON (sha256)."""
     from snarkjs_amd import groth16
-    with open(os.path.join(golden_dir, "groth16_bn128_n1024.json")) as f:
+    with open(os.path.join(golden_dir, tag + ".json")) as f:
         g = json.load(f)
-    zkey = open(os.path.join(golden_dir, "groth16_bn128_n1024.zkey"), "rb").read()
-    wtns = open(os.path.join(golden_dir, "groth16_bn128_n1024.wtns"), "rb").read()
+    zkey = open(os.path.join(golden_dir, tag + ".zkey"), "rb").read()
+    wtns = open(os.path.join(golden_dir, tag + ".wtns"), "rb").read()
     res = groth16.prove(zkey, wtns, r_mont=bytes.fromhex(g["r_mont"]), s_mont=bytes.fromhex(g["s_mont"]))
     assert res["proof"] == g["proof"]
     assert res["publicSignals"] == g["publicSignals"]
-    assert sha(groth16.proof_to_json(res["proof"]).encode()) == g["proof_sha256"] == "08797809c8de2c2053a925b1772af3e04c41f8c9b4c41f5b71ae5135435da44d"
+    assert sha(groth16.proof_to_json(res["proof"]).encode()) == g["proof_sha256"] == sha_proof
     with pytest.raises(ValueError):
         groth16.prove(zkey, wtns[:-32])
+
+
+def test_groth16_two_proofs_in_flight(zk):
+    """zkmi_groth16_submit_dev / _collect: two proofs in flight (different witnesses) in the two pipeline slots give exactly the serial
+    proofs, in any collect order, repeatedly; a slot cannot be submitted twice without a collect."""
+    import synth_zkey
+    from snarkjs_amd import groth16, binfile, zkmi
+    c = O.BN128
+    zkey, wtns = synth_zkey.make("bn128", 15, seed=0x91E, b_zero_every=0)
+    pk = groth16.ProvingKey(zkey)
+    w0 = binfile.read_wtns(wtns)["witness"].copy()
+    w1 = w0.copy()
+    w1[32 * 7:32 * 8] = synth.elems(5, 1)                  # a different witness for the second slot
+    r_m, s_m = O.fr_e(c, 21), O.fr_e(c, 34)
+    want0 = [bytes(x) for x in pk.prove_raw(w0, r_m, s_m)]
+    want1 = [bytes(x) for x in pk.prove_raw(w1, r_m, s_m)]
+    assert want0 != want1
+    d0, d1 = zkmi.DeviceBuffer.from_host(w0), zkmi.DeviceBuffer.from_host(w1)
+    for rnd in range(6):
+        pk.submit(d0.ptr, 0)
+        pk.submit(d1.ptr, 1)
+        with pytest.raises(Exception):
+            pk.submit(d0.ptr, 0)
+        order = (0, 1) if rnd % 2 == 0 else (1, 0)
+        got = {sl: [bytes(x) for x in pk.collect(sl, r_m, s_m)] for sl in order}
+        assert got[0] == want0 and got[1] == want1
+    # steady-state pipeline: submit i+1 before collecting i
+    seq = [d0, d1, d1, d0, d1, d0, d0]
+    wants = [want0, want1, want1, want0, want1, want0, want0]
+    outs = []
+    for i, d in enumerate(seq):
+        pk.submit(d.ptr, i & 1)
+        if i:
+            outs.append([bytes(x) for x in pk.collect((i - 1) & 1, r_m, s_m)])
+    outs.append([bytes(x) for x in pk.collect((len(seq) - 1) & 1, r_m, s_m)])
+    assert outs == wants
+    with pytest.raises(Exception):
+        pk.collect(0, r_m, s_m)                           # nothing in flight
+    assert [bytes(x) for x in pk.prove_raw(w0, r_m, s_m)] == want0
+    d0.free(); d1.free()
+    pk.release()
+
+
+def test_groth16_malformed_inputs_fail_cleanly(zk, golden_dir):
+    """Truncated sections / witness and key-number re-use must fail with an error, never read past the caller's buffers or prove
+    against another circuit's key (include/zkmi.h: zkmi_groth16_zkey *_len fields, zkmi_groth16_prove witness_len)."""
+    import ctypes as C
+    from snarkjs_amd import groth16, zkmi, binfile
+    L = zkmi.lib()
+    zkey = open(os.path.join(golden_dir, "groth16_bn128_n1024.zkey"), "rb").read()
+    wtns = open(os.path.join(golden_dir, "groth16_bn128_n1024.wtns"), "rb").read()
+    w = binfile.read_wtns(wtns)["witness"]
+    pk = groth16.ProvingKey(zkey)
+    r_m, s_m = O.fr_e(0, 3), O.fr_e(0, 5)
+    good = [bytes(x) for x in pk.prove_raw(w, r_m, s_m)]
+    out = [np.zeros(64, np.uint8), np.zeros(128, np.uint8), np.zeros(64, np.uint8)]
+    short = zkmi.u8(w[:-32])
+    rc = L.zkmi_groth16_prove(None, pk.key, zkmi.ptr(short), short.size, zkmi.ptr(r_m), zkmi.ptr(s_m), *(zkmi.ptr(o) for o in out))
+    assert rc != 0 and b"Invalid witness length" in L.zkmi_last_error()
+    # a descriptor of ANOTHER circuit next to the resident key number is refused (it used to prove against the resident key)
+    import synth_zkey
+    other, _ = synth_zkey.make("bn128", 8, seed=5)
+    pk2 = groth16.ProvingKey(other)
+    w8 = zkmi.u8(w)
+    rc = L.zkmi_groth16_prove(C.byref(pk2.desc), pk.key, zkmi.ptr(w8), w8.size, zkmi.ptr(r_m), zkmi.ptr(s_m), *(zkmi.ptr(o) for o in out))
+    assert rc != 0 and b"different circuit" in L.zkmi_last_error()
+    pk2.release()
+    # a section shorter than the header requires
+    d = pk.desc
+    bad = zkmi.Groth16Zkey.from_buffer_copy(bytes(d))
+    bad.bases_h_len = d.bases_h_len - 64
+    assert L.zkmi_groth16_load(C.byref(bad), 0x7777) != 0 and b"shorter" in L.zkmi_last_error()
+    assert [bytes(x) for x in pk.prove_raw(w, r_m, s_m)] == good          # the resident key is intact
+    pk.release()
 
 
 @pytest.mark.parametrize("name,lg", [("bn128", 12), ("bn128", 16), ("bls12381", 12)])
@@ -275,56 +404,64 @@ def test_msm_resident_tables(zk, name, group, lg):
     zkmi.check(L.zkmi_msm_table_release(h))
 
 
-@pytest.mark.parametrize("name,lg", [("bn128", 20), ("bls12381", 20)])
-def test_groth16_full_size_closed_form(zk, name, lg):
-    """BASELINE configs[1] at its full size (2^20 constraints), checked through a size-independent property: every base of the
-    synthetic key is a known multiple of the generator (7*11^i*G, tests/synth_zkey.py), so each proof point has a closed-form
-    discrete log — pi_a = a*G1, pi_b = b*G2, pi_c = c*G1 with a, b, c from O(n) field sums over the witness and the quotient
-    evaluations h (src/groth16_prove.js:103-128).  h comes from the CPU restatement's buildABC / NTT chain / joinABC; the five
-    2^20-term MSMs are never run on the CPU."""
+def _groth16_closed_form(c, name, zk_, w, lg, n_public, rr, ss, b_zero_every):
+    """Closed-form discrete logs (a, b, cc) of pi_a, pi_b, pi_c for a tests/synth_zkey.py key: every base is a known multiple of
+    the generator (T[i] = 7*11^i*G), so each MSM result is an O(n) field sum (oracle/zk_oracle.c: orc_fr_geom_dot) over the witness
+    and over h, the odd-coset evaluations of A*B - C from the CPU restatement's buildABC / NTT chain / joinABC (:62-83). The five
+    MSMs themselves are never run on the CPU."""
     import synth_zkey
-    from snarkjs_amd import groth16, binfile
-    c = O.CURVE_ID[name]
     r = synth_zkey.PRIMES[name][2]
-    n_public = 2
-    zkey, wtns = synth_zkey.make(name, lg, seed=0xBEEF + lg, n_public=n_public)
-    zk_ = binfile.read_groth16_zkey(zkey)
-    w = binfile.read_wtns(wtns)["witness"]
     n, m = zk_["domainSize"], zk_["nVars"]
-    r_m, s_m = O.fr_e(c, 0x1234567), O.fr_e(c, 0x7654321)
-    pk = groth16.ProvingKey(zkey)
-    pi_a, pi_b, pi_c = pk.prove_raw(w, r_m, s_m)
-    pk.release()
-    # h = odd-coset evaluations of (A*B - C) (:62-83)
     A, B, Cc = O.build_abc(c, zk_["coeffs"], w, m, n)
     one, inc = O.fr_one(c), O.fr_w(c, lg + 1)
     A, B, Cc = (O.ntt(c, O.apply_key(c, O.ntt(c, x, inverse=True), one, inc)) for x in (A, B, Cc))
-    h = np.frombuffer(O.join_abc(c, A, B, Cc), "<u8").reshape(n, 4)      # joinABC already leaves normal form (:362)
-    wv = np.frombuffer(w, "<u8").reshape(m, 4)
-    to_int = lambda row: int(row[0]) | int(row[1]) << 64 | int(row[2]) << 128 | int(row[3]) << 192
+    h = O.join_abc(c, A, B, Cc)                                # joinABC already leaves normal form (:362)
+    del A, B, Cc
+    d = lambda i: 7 * pow(11, i, r) % r                        # discrete log of T[i]
+    sa = O.geom_dot(c, w, m)                                   # A_i = T1[i]
+    sb = O.geom_dot(c, w, m, skip_mod=b_zero_every, skip_rem=1) if b_zero_every else sa     # B2_i = T2[i] (or infinity)
+    sc = O.geom_dot(c, w[(n_public + 1) * 32:], m - n_public - 1)                           # C_j = T1[2 + j]: shift applied below
+    sh = O.geom_dot(c, h, n)                                   # H_i = T1[3 + i]
+    a = (d(5) + sa + rr * d(7)) % r                            # alpha1 = T1[5], delta1 = T1[7]
+    b = (d(1) + sb + ss * d(2)) % r                            # beta2 = T2[1], delta2 = T2[2]
+    b1 = (d(6) + sb * 11 + ss * d(7)) % r                      # beta1 = T1[6], B1_i = T1[i + 1]
+    cc = (sc * pow(11, 2, r) + sh * pow(11, 3, r) + ss * a + rr * b1 - rr * ss % r * d(7)) % r
+    return a, b, cc
+
+
+@pytest.mark.parametrize("name,lg,b_zero_every", [("bn128", 20, 3), ("bn128", 20, 0), ("bls12381", 20, 3), ("bn128", 24, 0)])
+def test_groth16_full_size_closed_form(zk, name, lg, b_zero_every):
+    """BASELINE configs[1], [4] (2^20 constraints, sparse and dense B sections) and configs[2] (2^24 constraints, single device AND
+    8 key shards folded as the ranks would after the all_gather) at their full sizes, checked through a size-independent property:
+    every proof point has a closed-form discrete log (see _groth16_closed_form), bit-exact affine bytes."""
+    import synth_zkey
+    from snarkjs_amd import groth16, binfile
+    from snarkjs_amd import distributed as D
+    c = O.CURVE_ID[name]
+    n_public = 2
+    zkey, wtns = synth_zkey.make(name, lg, seed=0xBEEF + lg, n_public=n_public, b_zero_every=b_zero_every)
+    zk_ = binfile.read_groth16_zkey(zkey)
+    w = binfile.read_wtns(wtns)["witness"]
     rr, ss = 0x1234567, 0x7654321
-    d = lambda i: 7 * pow(11, i, r) % r                       # discrete log of T[i]
-    sa = sb = sc = sh = 0
-    g = 7                                                     # 7 * 11^i
-    for i in range(m):
-        wi = to_int(wv[i])
-        sa += wi * g
-        if i % 3 != 1:
-            sb += wi * g
-        if i > n_public:
-            sc += wi * g                                      # C_j = T1[2 + j], j = i - nPublic - 1: shift applied below
-        g = g * 11 % r
-    g = 7
-    for i in range(n):
-        sh += to_int(h[i]) * g
-        g = g * 11 % r
-    a = (d(5) + sa + rr * d(7)) % r                           # alpha1 = T1[5], A_i = T1[i], delta1 = T1[7]
-    b = (d(1) + sb + ss * d(2)) % r                           # beta2 = T2[1], B2_i = T2[i], delta2 = T2[2]
-    b1 = (d(6) + sb * 11 + ss * d(7)) % r                     # beta1 = T1[6], B1_i = T1[i + 1]
-    cc = (sc * pow(11, 2 - n_public - 1, r) + sh * pow(11, 3, r) + ss * a + rr * b1 - rr * ss % r * d(7)) % r
-    assert np.array_equal(pi_a, O.to_affine(c, 1, O.generator_mul(c, 1, a)))
-    assert np.array_equal(pi_b, O.to_affine(c, 2, O.generator_mul(c, 2, b)))
-    assert np.array_equal(pi_c, O.to_affine(c, 1, O.generator_mul(c, 1, cc)))
+    r_m, s_m = O.fr_e(c, rr), O.fr_e(c, ss)
+    pk = groth16.ProvingKey(zkey)
+    got = [pk.prove_raw(w, r_m, s_m)]
+    pk.release()
+    if lg >= 24:                                               # configs[2]: the same proof from 8 base-index-range shards
+        world, parts, last = 8, [], None
+        for rank in range(world):
+            sh = groth16.ProvingKey(zkey, shard=(rank, world))
+            parts.append(sh.sums_raw(w))
+            last = sh if rank == world - 1 else sh.release()
+        got.append(last.finish_raw(D.fold_groth16_sums(c, parts), r_m, s_m))
+        last.release()
+    del zkey
+    a, b, cc = _groth16_closed_form(c, name, zk_, w, lg, n_public, rr, ss, b_zero_every)
+    want = (O.to_affine(c, 1, O.generator_mul(c, 1, a)), O.to_affine(c, 2, O.generator_mul(c, 2, b)), O.to_affine(c, 1, O.generator_mul(c, 1, cc)))
+    for pi_a, pi_b, pi_c in got:
+        assert np.array_equal(pi_a, want[0])
+        assert np.array_equal(pi_b, want[1])
+        assert np.array_equal(pi_c, want[2])
 
 
 @pytest.mark.parametrize("dist", ["equal", "zero", "ones", "witness", "two_values", "max"])

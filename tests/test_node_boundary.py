@@ -44,6 +44,15 @@ def test_addon_against_golden_vectors_on_gpu():
 
 @pytest.mark.gpu
 @need_node
+def test_register_js_replay_with_real_addon_on_gpu():
+    """register.js + the REAL addon on the GPU, fed with the bulk calls the real snarkjs makes in its seeded groth16.prove (n = 1024)
+    and plonk.prove (n = 2048), recorded from the reference bundle (oracle/gen_replay.js -> tests/golden/replay_bn128.*)."""
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "register_replay.js")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@need_node
 def test_node_fused_plonk_prover_on_gpu():
     """snarkjs_amd/js/plonk_native.js (device-resident PLONK prover driven from Node) == the reference's seeded proofs"""
     r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "plonk_native_golden.js")], capture_output=True, text=True, timeout=600)

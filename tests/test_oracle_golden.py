@@ -184,3 +184,21 @@ def test_groth16_golden_proof(golden_dir):
     A, B, Cc = O.build_abc(c, zk["coeffs"], w["witness"], zk["nVars"], zk["domainSize"])
     calls = [x for x in g["calls"] if x["op"] == "Fr.ifft"]
     assert [sha(A), sha(B), sha(Cc)] == [x["in0"] for x in calls]
+
+
+def test_groth16_golden_proof_bls12381(golden_dir):
+    """BLS12-381 Groth16 proof generated (and verified) by the reference itself on the Multiplier(1000) r1cs written over the
+    BLS12-381 scalar field (oracle/gen_golden.js groth16GoldenBls, SURVEY.md 8d recipe): pins the 381-bit limb path of the C
+    restatement — the reference has no BLS12-381 test of its own."""
+    with open(os.path.join(golden_dir, "groth16_bls12381_n1024.json")) as f:
+        g = json.load(f)
+    zkey = open(os.path.join(golden_dir, "groth16_bls12381_n1024.zkey"), "rb").read()
+    wtns = open(os.path.join(golden_dir, "groth16_bls12381_n1024.wtns"), "rb").read()
+    assert sha(zkey) == g["zkey_sha256"] and sha(wtns) == g["wtns_sha256"] and g["verified"] is True
+    zk, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)
+    assert w["nWitness"] == zk["nVars"] == 1003 and zk["domainSize"] == 1024 and zk["n8q"] == 48
+    c = O.BLS12381
+    pa, pb, pc = O.groth16_prove(c, zk, w["witness"], bytes.fromhex(g["r_mont"]), bytes.fromhex(g["s_mont"]))
+    proof, js = binfile.proof_json("bls12381", 48, O.fq_from_mont(c, pa), O.fq_from_mont(c, pb), O.fq_from_mont(c, pc))
+    assert proof == g["proof"]
+    assert sha(js.encode()) == g["proof_sha256"] == "955b9f3652e544aac16a90fd1ce6b8660701a7eb20e71fa7681ced22f0acd5eb"

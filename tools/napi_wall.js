@@ -1,0 +1,69 @@
+// tools/napi_wall.js — wall time THROUGH the N-API boundary (SURVEY.md 8d timing protocol: "hipEvent device time and wall time
+// through the N-API call", bases resident and cold). Driven by bench.py on rank 0 (outside the timed region):
+//   node tools/napi_wall.js <zkey> <wtns> <reps>
+// Measures, with host buffers in and host results out (H2D of inputs and D2H of results inside the timed call):
+//   groth16  addon.groth16Prove: cold = first call (zkey sections H2D + window-table build + proof), warm = key resident, only the
+//            witness (32 B x nVars) crosses PCIe per proof
+//   msm      addon.msm on the A section (nVars points): cold (bases uploaded every call, cache not allowed) / resident (3rd+ call)
+//   ntt      addon.ntt of domainSize elements (32 B x n in, 32 B x n out)
+// Prints ONE JSON line.
+"use strict";
+const fs = require("fs"), path = require("path");
+const addon = require(path.join(__dirname, "..", "snarkjs_amd", "napi", "zkmi_napi.node"));
+const [zkeyPath, wtnsPath, repsArg] = process.argv.slice(2);
+const reps = parseInt(repsArg || "5");
+const now = () => Number(process.hrtime.bigint()) / 1e6;
+function sections(data) {
+    const dv = new DataView(data.buffer, data.byteOffset, data.byteLength), n = dv.getUint32(8, true), out = {};
+    let off = 12;
+    for (let i = 0; i < n; i++) { const t = dv.getUint32(off, true), len = Number(dv.getBigUint64(off + 4, true)); off += 12; out[t] = data.subarray(off, off + len); off += len; }
+    return out;
+}
+const med = (a) => { const s = a.slice().sort((x, y) => x - y); return s[s.length >> 1]; };
+addon.init(0);
+const zkey = new Uint8Array(fs.readFileSync(zkeyPath)), wtns = new Uint8Array(fs.readFileSync(wtnsPath));
+const zs = sections(zkey), ws = sections(wtns);
+const hv = new DataView(zs[2].buffer, zs[2].byteOffset, zs[2].byteLength);
+const n8q = hv.getUint32(0, true), n8r = hv.getUint32(4 + n8q, true);
+let o = 8 + n8q + n8r;
+const nVars = hv.getUint32(o, true), nPublic = hv.getUint32(o + 4, true), domainSize = hv.getUint32(o + 8, true);
+o += 12;
+const pt = (k) => { const v = zs[2].subarray(o, o + k * n8q); o += k * n8q; return v; };
+const alpha1 = pt(2), beta1 = pt(2), beta2 = pt(4); pt(4); const delta1 = pt(2), delta2 = pt(4);
+const cid = n8q == 32 ? 0 : 1;
+const desc = { curve: cid, nVars, nPublic, domainSize, coeffs: zs[4], A: zs[5], B1: zs[6], B2: zs[7], C: zs[8], H: zs[9], alpha1, beta1, beta2, delta1, delta2 };
+const r = new Uint8Array(32), s = new Uint8Array(32); r[0] = 3; s[0] = 5;
+const witness = ws[2];
+const out = { n_vars: nVars, domain: domainSize, reps };
+{
+    const key = 424242;
+    let t0 = now();
+    addon.groth16Prove(desc, key, witness, r, s);
+    out.groth16_cold_ms = +(now() - t0).toFixed(3);
+    const t = [];
+    for (let i = 0; i < reps; i++) { t0 = now(); addon.groth16Prove(cid, key, witness, r, s); t.push(now() - t0); }
+    out.groth16_warm_ms = +med(t).toFixed(3);
+    out.groth16_warm_h2d_bytes = witness.byteLength;
+    addon.groth16Release(key);
+}
+{
+    const bases = zs[5], scalars = witness;
+    const t = [], tr = [];
+    for (let i = 0; i < reps; i++) { const t0 = now(); addon.msm(cid, 1, bases, scalars, nVars, 32, 0); t.push(now() - t0); }
+    addon.msm(cid, 1, bases, scalars, nVars, 32, 1); addon.msm(cid, 1, bases, scalars, nVars, 32, 1);      // 1st sight, 2nd sight (table build)
+    for (let i = 0; i < reps; i++) { const t0 = now(); addon.msm(cid, 1, bases, scalars, nVars, 32, 1); tr.push(now() - t0); }
+    addon.releaseBases(0);
+    out.g1_msm_cold_ms = +med(t).toFixed(3);                 // bases + scalars H2D every call
+    out.g1_msm_resident_ms = +med(tr).toFixed(3);            // scalars H2D + content hash of the bases on the host
+    out.g1_msm_h2d_bytes_cold = bases.byteLength + scalars.byteLength;
+}
+{
+    const n = domainSize, lg = Math.round(Math.log2(n));
+    const x = new Uint8Array(n * 32), y = new Uint8Array(n * 32);
+    x.set(witness.subarray(0, Math.min(witness.byteLength, x.byteLength)));
+    const t = [];
+    for (let i = 0; i < reps + 1; i++) { const t0 = now(); addon.ntt(cid, x, y, lg, 0, null, null); t.push(now() - t0); }
+    out.ntt_ms = +med(t.slice(1)).toFixed(3);
+    out.ntt_bytes_over_pcie = 2 * n * 32;
+}
+console.log(JSON.stringify(out));
