@@ -316,7 +316,8 @@ def main():
                    "exchange": "all_gather of %d x %d-byte partial points + host fold" % (world, 3 * q8)}
         d_bs.free(); d_ss.free()
         # ---- ONE Groth16 proof stream over all ranks (BASELINE configs[2]: MSMs sharded by base-index range): every rank holds
-        # 1/world of the five base sections of the SAME key, the NTT chain is replicated, one all_gather of 7*3*n8q bytes per proof
+        # 1/world of the five base sections of the SAME key; the three NTT chains run on different ranks, slices of their outputs are
+        # exchanged point to point, one all_gather of 7*3*n8q bytes per proof (snarkjs_amd/distributed.py)
         if rank == 0:
             zkey0, wtns0 = zkey, wtns
         else:
@@ -336,7 +337,7 @@ def main():
         same = all(np.array_equal(a, b) for a, b in zip(sh_proof, proof_pts)) if rank == 0 else True
         sharded["groth16_one_proof_over_all_ranks"] = {"ms_per_proof": round(float(tsh.item()) / reps * 1e3, 3), "proofs_per_s": round(reps / float(tsh.item()), 3),
                                                          "log_n": lg, "scaling": "strong", "equals_single_device_proof": bool(same),
-                                                         "exchange": "all_gather of %d x %d-byte MSM sums + host fold" % (world, 21 * q8)}
+                                                         "exchange": "chain-parallel transforms (chain c on rank c %% world), point-to-point slices of the chain outputs (%d bytes leave each chain owner), all_gather of %d x %d-byte MSM sums + host fold" % ((1 << lg) * 32, world, 21 * q8)}
         pks.release(); d_w0.free()
 
     out = None

@@ -178,6 +178,14 @@ int zkmi_groth16_release(uint64_t zkey_cache_key);
  * blinding and toAffine (:103-132, host, O(1)). With the full key, sums + finish == zkmi_groth16_prove_dev. */
 int zkmi_groth16_load_shard(const zkmi_groth16_zkey* zkey, uint64_t zkey_cache_key, uint32_t var_lo, uint32_t var_hi, uint32_t h_lo, uint32_t h_hi);
 int zkmi_groth16_sums_dev(uint64_t zkey_cache_key, const void* d_witness, uint8_t* sums);
+/* Chain-parallel multi-GPU proof: the three iNTT -> coset -> NTT chains of src/groth16_prove.js:64-76 are independent until joinABC
+ * (:79), so each runs on a different rank. zkmi_groth16_chains_dev runs buildABC (cheap, every owning rank) and the chains selected by
+ * chain_mask (bit 0: A, 1: B, 2: C) on the full domain and writes their outputs (domain x 32 B, Montgomery) to d_a / d_b / d_c
+ * (NULL for unselected chains). The owner of a chain sends rank j the slice [h_lo_j, h_hi_j) of its output (point-to-point over
+ * xGMI, domain*32 bytes leave each owner in total); rank j joins its three slices (zkmi_groth16_join_abc_dev) into ITS H-MSM scalars and
+ * zkmi_groth16_sums_h_dev runs the five MSMs of its key shard with them — no rank repeats another rank's transforms. */
+int zkmi_groth16_chains_dev(uint64_t zkey_cache_key, const void* d_witness, unsigned chain_mask, void* d_a, void* d_b, void* d_c);
+int zkmi_groth16_sums_h_dev(uint64_t zkey_cache_key, const void* d_witness, const void* d_h_scalars, uint8_t* sums);
 int zkmi_groth16_finish(uint64_t zkey_cache_key, const uint8_t* sums, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 /* Device time (ms, HIP events) of the stages of the last proof, in order: buildABC, 6 NTTs, joinABC, sort(witness),
  * bucket accumulation of MSM B2, B1 (+ the second witness sort), A, C, sort(H scalars), accumulation of MSM H, batched G1 bucket reductions (the B2

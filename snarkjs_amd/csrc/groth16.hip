@@ -323,7 +323,7 @@ static void g16_finish(const G16Key& K, const uint8_t* jA, const uint8_t* jB1, c
 // partial sums over its base-index range, to be added across devices before g16_finish.
 // g16_enqueue puts the whole device part of a proof on the streams of the ACTIVE pipeline slot and returns without waiting;
 // g16_complete waits for that slot and folds the window sums on the host.
-template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness) {
+template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, const void* d_h_ext = nullptr) {
     Ctx& cx = ctx();
     ZK_TRY(g16_work_alloc(K, cx.pipe));
     G16Key::Work& Wk = K.wk[cx.pipe];
@@ -333,7 +333,9 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness) {
     const host::HField<4> Fr = host::HField<4>::from_cfg<FrC>();
     const uint32_t* w = (const uint32_t*)d_witness;
     const uint8_t* w_sh = (const uint8_t*)d_witness + (size_t)K.v_lo * 32;       // scalars of this shard's witness-side bases
-    const uint8_t* h_sh = (const uint8_t*)Wk.T + (size_t)K.h_lo * 32;
+    // d_h_ext: this shard's H-MSM scalars (h_cnt x 32 B, normal form) computed elsewhere (chain-parallel multi-GPU proof): the
+    // buildABC / NTT / joinABC stages are skipped
+    const uint8_t* h_sh = d_h_ext ? (const uint8_t*)d_h_ext : (const uint8_t*)Wk.T + (size_t)K.h_lo * 32;
     // The three digit sorts (witness without the B-infinity entries, witness, H scalars) are LDS/latency-bound; the NTT chain and
     // the bucket accumulations are ALU-bound. With ZKMI_OVERLAP (default) the sorts run on the auxiliary stream underneath them
     // and the main stream only waits on their events. ZKMI_OVERLAP=0 keeps everything on one stream.
@@ -361,19 +363,21 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness) {
         ZK_TRY(rc);
     }
     ZK_HIP(hipEventRecord(Wk.ev[ST_BUILD], st));
-    hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, w, n, Wk.A, Wk.B, Wk.C);
+    if (!d_h_ext) hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, w, n, Wk.A, Wk.B, Wk.C);
     ZK_HIP(hipEventRecord(Wk.ev[ST_NTT], st));
-    // inc = power == Fr.s ? Fr.shift : Fr.w[power+1] (:64); Fr.shift = nqr^2 — both come from the NTT module's root table
-    uint8_t one[32], inc[32];
-    memcpy(one, Fr.one, 32);
-    ZK_TRY(fr_coset_inc(K.curve, K.power, inc));
-    uint32_t* bufs[3] = {Wk.A, Wk.B, Wk.C};
-    for (int k = 0; k < 3; k++) {
-        ZK_TRY(ntt_dev_dispatch(K.curve, bufs[k], Wk.T, K.power, 1, nullptr, nullptr));
-        ZK_TRY(ntt_dev_dispatch(K.curve, Wk.T, bufs[k], K.power, 0, one, inc));
+    if (!d_h_ext) {
+        // inc = power == Fr.s ? Fr.shift : Fr.w[power+1] (:64); Fr.shift = nqr^2 — both come from the NTT module's root table
+        uint8_t one[32], inc[32];
+        memcpy(one, Fr.one, 32);
+        ZK_TRY(fr_coset_inc(K.curve, K.power, inc));
+        uint32_t* bufs[3] = {Wk.A, Wk.B, Wk.C};
+        for (int k = 0; k < 3; k++) {
+            ZK_TRY(ntt_dev_dispatch(K.curve, bufs[k], Wk.T, K.power, 1, nullptr, nullptr));
+            ZK_TRY(ntt_dev_dispatch(K.curve, Wk.T, bufs[k], K.power, 0, one, inc));
+        }
     }
     ZK_HIP(hipEventRecord(Wk.ev[ST_JOIN], st));
-    ZK_TRY(join_abc_dev_dispatch(K.curve, Wk.A, Wk.B, Wk.C, Wk.T, n));          // T = H-MSM scalars (normal form)
+    if (!d_h_ext) ZK_TRY(join_abc_dev_dispatch(K.curve, Wk.A, Wk.B, Wk.C, Wk.T, n));          // T = H-MSM scalars (normal form)
     ZK_HIP(hipEventRecord(Wk.ev[ST_SORT_W], st));
     if (ov) {
         ZK_HIP(hipEventRecord(cx.sort_ev[3], st));
@@ -458,6 +462,32 @@ template <class FrC> static int g16_prove_dev(G16Key& K, const void* d_witness, 
     return ZKMI_OK;
 }
 
+// buildABC + the selected iNTT -> coset -> NTT chains of one proof (bit 0: A, 1: B, 2: C), results copied out of the key's work
+// buffers: the chain-parallel part of a multi-GPU proof (each chain on a different rank)
+template <class FrC> static int g16_chains(G16Key& K, const void* d_witness, unsigned mask, void* d_a, void* d_b, void* d_c) {
+    Ctx& cx = ctx();
+    hipStream_t st = cx.stream;
+    ZK_TRY(g16_work_alloc(K, cx.pipe));
+    G16Key::Work& Wk = K.wk[cx.pipe];
+    if (Wk.in_flight) return fail(ZKMI_ERR_INVALID, "groth16_chains: a proof is in flight in this pipeline slot");
+    const host::HField<4> Fr = host::HField<4>::from_cfg<FrC>();
+    const uint32_t n = K.domain;
+    hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, (const uint32_t*)d_witness, n, Wk.A, Wk.B, Wk.C);
+    uint8_t one[32], inc[32];
+    memcpy(one, Fr.one, 32);
+    ZK_TRY(fr_coset_inc(K.curve, K.power, inc));
+    uint32_t* bufs[3] = {Wk.A, Wk.B, Wk.C};
+    void* outs[3] = {d_a, d_b, d_c};
+    for (int k = 0; k < 3; k++) {
+        if (!((mask >> k) & 1u)) continue;
+        if (!outs[k]) return fail(ZKMI_ERR_INVALID, "groth16_chains: null output for a selected chain");
+        ZK_TRY(ntt_dev_dispatch(K.curve, bufs[k], Wk.T, K.power, 1, nullptr, nullptr));
+        ZK_TRY(ntt_dev_dispatch(K.curve, Wk.T, outs[k], K.power, 0, one, inc));
+    }
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+}
 static G16Key* g16_find(uint64_t key) {
     auto it = ctx().groth16.find(key);
     return it == ctx().groth16.end() ? nullptr : (G16Key*)it->second;
@@ -515,6 +545,26 @@ int zkmi_groth16_prove_dev(uint64_t key, const void* d_witness, const uint8_t* r
     g_last_key = key;
     if (K->curve == ZKMI_CURVE_BN128) return g16_prove_dev<Bn254Fr>(*K, d_witness, r_mont, s_mont, pi_a, pi_b, pi_c);
     return g16_prove_dev<Bls12381Fr>(*K, d_witness, r_mont, s_mont, pi_a, pi_b, pi_c);
+}
+int zkmi_groth16_chains_dev(uint64_t key, const void* d_witness, unsigned chain_mask, void* d_a, void* d_b, void* d_c) {
+    ZK_TRY(require_ctx());
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_chains_dev: key not loaded");
+    if (!d_witness || chain_mask > 7u) return fail(ZKMI_ERR_INVALID, "groth16_chains_dev: bad argument");
+    if (K->curve == ZKMI_CURVE_BN128) return g16_chains<Bn254Fr>(*K, d_witness, chain_mask, d_a, d_b, d_c);
+    return g16_chains<Bls12381Fr>(*K, d_witness, chain_mask, d_a, d_b, d_c);
+}
+int zkmi_groth16_sums_h_dev(uint64_t key, const void* d_witness, const void* d_h_scalars, uint8_t* sums) {
+    ZK_TRY(require_ctx());
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_sums_h_dev: key not loaded");
+    if (!d_witness || !d_h_scalars || !sums) return fail(ZKMI_ERR_INVALID, "groth16_sums_h_dev: null argument");
+    g_last_key = key;
+    const size_t j1 = 3 * (size_t)n8q_of(K->curve);
+    uint8_t *jA = sums, *jB1 = sums + j1, *jB2 = sums + 2 * j1, *jC = sums + 4 * j1, *jH = sums + 5 * j1;
+    if (K->curve == ZKMI_CURVE_BN128) { ZK_TRY(g16_enqueue<Bn254Fr>(*K, d_witness, d_h_scalars)); return g16_complete<Bn254Fr>(*K, jA, jB1, jB2, jC, jH); }
+    ZK_TRY(g16_enqueue<Bls12381Fr>(*K, d_witness, d_h_scalars));
+    return g16_complete<Bls12381Fr>(*K, jA, jB1, jB2, jC, jH);
 }
 int zkmi_groth16_submit_dev(uint64_t key, const void* d_witness, int slot) {
     ZK_TRY(require_ctx());

@@ -66,11 +66,131 @@ def fold_groth16_sums(curve_id, all_sums):
     return out
 
 
-def groth16_prove_sharded(pk, witness, r_mont, s_mont, process_group=None, d_witness=None):
-    """One Groth16 proof with the five MSMs split by base-index range over the ranks of `process_group` (BASELINE configs[2]).
+def chain_owner(chain, world):
+    """Rank that runs chain 0 (A), 1 (B) or 2 (C) of the iNTT -> coset -> NTT step (src/groth16_prove.js:64-76)."""
+    return chain % world
 
-    pk: ProvingKey(zkey, shard=(rank, world)) on every rank; witness: the FULL witness on every rank (buildABC / NTT chain /
-    joinABC are replicated — they need no exchange); r_mont, s_mont: the same blinding draws on every rank. ONE all_gather of
-    the 7*3*n8q-byte partial sums, folded in rank order, so every rank returns the identical (pi_a, pi_b, pi_c)."""
-    part = pk.sums_raw(witness, d_witness=d_witness)
-    return pk.finish_raw(fold_groth16_sums(pk.curve_id, all_gather_bytes(part, process_group)), r_mont, s_mont)
+
+class DeviceShard:
+    """Backend of groth16_prove_sharded on the MI355X: a ProvingKey shard + torch CUDA tensors for the exchanged slices."""
+
+    def __init__(self, pk, witness=None, d_witness=None):
+        import torch
+        self.pk, self.torch = pk, torch
+        self.curve_id = pk.curve_id
+        self.n, self.m = pk.zk["domainSize"], pk.zk["nVars"]
+        self._wbuf = None
+        if d_witness is None:
+            self._wbuf = zkmi.DeviceBuffer.from_host(zkmi.u8(witness))
+            d_witness = self._wbuf.ptr
+        self.d_witness = d_witness
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+
+    def empty(self, nbytes):
+        return self.torch.empty(max(nbytes, 1), dtype=self.torch.uint8, device=self.dev)
+
+    def chains(self, owned):
+        """{chain: tensor of n*32 bytes} for the chains this rank owns (buildABC + iNTT + coset NTT on the full domain)."""
+        if not owned:
+            return {}
+        out = {c: self.empty(self.n * 32) for c in owned}
+        ptr = lambda c: out[c].data_ptr() if c in out else None
+        mask = sum(1 << c for c in owned)
+        zkmi.check(zkmi.lib().zkmi_groth16_chains_dev(self.pk.key, self.d_witness, mask, ptr(0), ptr(1), ptr(2)))      # synchronises the library stream
+        return out
+
+    def join(self, a, b, c, cnt):
+        """joinABC (:79, :320-374) on this rank's slice -> H-MSM scalars (normal form)"""
+        h = self.empty(cnt * 32)
+        self.torch.cuda.synchronize()                         # the exchanged slices were written on torch's stream
+        if cnt:
+            zkmi.check(zkmi.lib().zkmi_groth16_join_abc_dev(self.curve_id, a.data_ptr(), b.data_ptr(), c.data_ptr(), h.data_ptr(), cnt))
+        return h
+
+    def sums(self, h):
+        q = 32 if self.curve_id == 0 else 48
+        out = np.zeros(7 * 3 * q, np.uint8)
+        zkmi.check(zkmi.lib().zkmi_groth16_sums_h_dev(self.pk.key, self.d_witness, h.data_ptr(), zkmi.ptr(out)))
+        return out
+
+    def finish(self, sums, r_mont, s_mont):
+        return self.pk.finish_raw(sums, r_mont, s_mont)
+
+    def close(self):
+        if self._wbuf is not None:
+            self._wbuf.free()
+            self._wbuf = None
+
+
+def exchange_chain_slices(be, outs, rank, world, h_ranges, process_group=None):
+    """The reduce-scatter-shaped exchange of the chain-parallel proof: the owner of chain c sends rank j the byte slice
+    [32*h_lo_j, 32*h_hi_j) of its output; returns this rank's three slices [A', B', C']. Point-to-point (batch_isend_irecv: RCCL
+    send/recv over xGMI, or gloo on CPU); domain*32 bytes leave each owner in total, nothing is replicated."""
+    import torch.distributed as dist
+    lo, hi = h_ranges[rank]
+    mine = [None, None, None]
+    ops = []
+    for c in range(3):
+        o = chain_owner(c, world)
+        if o == rank:
+            mine[c] = outs[c][32 * lo:32 * hi].clone() if hi > lo else be.empty(0)
+            for j in range(world):
+                jl, jh = h_ranges[j]
+                if j != rank and jh > jl:
+                    ops.append(dist.P2POp(dist.isend, outs[c][32 * jl:32 * jh].contiguous(), j, group=process_group))
+        elif hi > lo:
+            mine[c] = be.empty(32 * (hi - lo))
+            ops.append(dist.P2POp(dist.irecv, mine[c], o, group=process_group))
+        else:
+            mine[c] = be.empty(0)
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return mine
+
+
+def groth16_prove_sharded(pk, witness, r_mont, s_mont, process_group=None, d_witness=None, backend=None):
+    """One Groth16 proof over the ranks of `process_group` (BASELINE configs[2]), nothing replicated but buildABC:
+
+      1. chain-parallel transforms: rank c % world runs buildABC + the iNTT -> coset -> NTT chain c (A, B, C are independent until
+         joinABC, src/groth16_prove.js:64-79);
+      2. every chain owner sends rank j the slice [h_lo_j, h_hi_j) of its output (point-to-point over xGMI);
+      3. rank j joins its slices into ITS H-MSM scalars and runs the five MSMs of its key shard (base-index ranges of A/B1/B2/C/H);
+      4. ONE all_gather of the 7*3*n8q-byte partial sums, folded in rank order: every rank returns the identical (pi_a, pi_b, pi_c).
+
+    pk: ProvingKey(zkey, shard=(rank, world)) on every rank; witness: the FULL witness on every rank; r_mont, s_mont: the same
+    blinding draws on every rank. backend: object with the DeviceShard interface (the gloo CPU test passes an oracle-backed one)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+    be = backend or DeviceShard(pk, witness, d_witness)
+    try:
+        h_ranges = [shard_range(be.n, j, world) for j in range(world)]
+        outs = be.chains([c for c in range(3) if chain_owner(c, world) == rank])
+        a, b, c = exchange_chain_slices(be, outs, rank, world, h_ranges, process_group)
+        lo, hi = h_ranges[rank]
+        part = be.sums(be.join(a, b, c, hi - lo))
+        return be.finish(fold_groth16_sums(be.curve_id, all_gather_bytes(part, process_group)), r_mont, s_mont)
+    finally:
+        if backend is None:
+            be.close()
+
+
+def groth16_prove_sharded_local(make_shard, world, r_mont, s_mont):
+    """The same proof with all `world` ranks simulated one after the other on ONE device (tests / single-GPU checks of the
+    multi-GPU path): make_shard(rank) -> backend (DeviceShard interface); the exchange is done in-process."""
+    bes = [make_shard(j) for j in range(world)]
+    try:
+        n = bes[0].n
+        h_ranges = [shard_range(n, j, world) for j in range(world)]
+        outs = {}
+        for j, be in enumerate(bes):
+            outs.update(be.chains([c for c in range(3) if chain_owner(c, world) == j]))
+        parts = []
+        for j, be in enumerate(bes):
+            lo, hi = h_ranges[j]
+            sl = [outs[c][32 * lo:32 * hi].clone() if hi > lo else be.empty(0) for c in range(3)]
+            parts.append(be.sums(be.join(sl[0], sl[1], sl[2], hi - lo)))
+        return bes[-1].finish(fold_groth16_sums(bes[0].curve_id, parts), r_mont, s_mont)
+    finally:
+        for be in bes:
+            be.close()

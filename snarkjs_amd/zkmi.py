@@ -24,7 +24,7 @@ SYMBOLS = [
     "zkmi_ntt", "zkmi_ntt_dev",
     "zkmi_fr_batch_apply_key", "zkmi_fr_batch_apply_key_dev", "zkmi_fr_batch", "zkmi_fr_batch_dev",
     "zkmi_groth16_join_abc", "zkmi_groth16_join_abc_dev",
-    "zkmi_base_cache_stats", "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_submit_dev", "zkmi_groth16_collect", "zkmi_groth16_release", "zkmi_groth16_load_shard", "zkmi_groth16_sums_dev", "zkmi_groth16_finish", "zkmi_groth16_stage_ms",
+    "zkmi_base_cache_stats", "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_submit_dev", "zkmi_groth16_collect", "zkmi_groth16_release", "zkmi_groth16_load_shard", "zkmi_groth16_sums_dev", "zkmi_groth16_chains_dev", "zkmi_groth16_sums_h_dev", "zkmi_groth16_finish", "zkmi_groth16_stage_ms",
     "zkmi_gen_geometric_bases_dev", "zkmi_to_affine", "zkmi_point_add", "zkmi_fr_root",
     "zkmi_plonk_gather_wires_dev", "zkmi_plonk_compute_z_dev", "zkmi_plonk_compute_t_dev", "zkmi_fflonk_t0_dev", "zkmi_fflonk_t1_dev",
     "zkmi_fflonk_t2_dev", "zkmi_poly_degree_dev", "zkmi_keccak256", "zkmi_poly_blind_dev", "zkmi_poly_add_scalar_dev", "zkmi_poly_axpy_dev", "zkmi_poly_scale_dev",
@@ -129,6 +129,8 @@ def lib():
     L.zkmi_groth16_collect.argtypes = [C.c_uint64, C.c_int, u8p, u8p, u8p, u8p, u8p]
     L.zkmi_groth16_load_shard.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.zkmi_groth16_sums_dev.argtypes = [C.c_uint64, vp, u8p]
+    L.zkmi_groth16_chains_dev.argtypes = [C.c_uint64, vp, C.c_uint, vp, vp, vp]
+    L.zkmi_groth16_sums_h_dev.argtypes = [C.c_uint64, vp, vp, u8p]
     L.zkmi_groth16_finish.argtypes = [C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p]
     L.zkmi_groth16_stage_ms.argtypes = [C.POINTER(C.c_double), C.c_int]
     _lib = L

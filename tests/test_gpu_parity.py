@@ -447,14 +447,15 @@ def test_groth16_full_size_closed_form(zk, name, lg, b_zero_every):
     pk = groth16.ProvingKey(zkey)
     got = [pk.prove_raw(w, r_m, s_m)]
     pk.release()
-    if lg >= 24:                                               # configs[2]: the same proof from 8 base-index-range shards
-        world, parts, last = 8, [], None
-        for rank in range(world):
-            sh = groth16.ProvingKey(zkey, shard=(rank, world))
-            parts.append(sh.sums_raw(w))
-            last = sh if rank == world - 1 else sh.release()
-        got.append(last.finish_raw(D.fold_groth16_sums(c, parts), r_m, s_m))
-        last.release()
+    if lg >= 24:                                               # configs[2]: the same proof from 8 base-index-range shards,
+        world, keys = 8, []                                    # chain-parallel transforms + slice exchange (distributed.py), ranks simulated here
+
+        def make(rank):
+            keys.append(groth16.ProvingKey(zkey, shard=(rank, world)))
+            return D.DeviceShard(keys[-1], w)
+        got.append(D.groth16_prove_sharded_local(make, world, r_m, s_m))
+        for k in keys:
+            k.release()
     del zkey
     a, b, cc = _groth16_closed_form(c, name, zk_, w, lg, n_public, rr, ss, b_zero_every)
     want = (O.to_affine(c, 1, O.generator_mul(c, 1, a)), O.to_affine(c, 2, O.generator_mul(c, 2, b)), O.to_affine(c, 1, O.generator_mul(c, 1, cc)))
@@ -596,6 +597,17 @@ def test_groth16_sharded_equals_single_device(zk, name, lg, world):
     got = [bytes(x) for x in last.finish_raw(D.fold_groth16_sums(c, parts), r_m, s_m)]
     last.release()
     assert got == want
+    # chain-parallel flow (what distributed.groth16_prove_sharded runs over RCCL): chain c on rank c % world, slices of the chain
+    # outputs exchanged, every rank joins ITS slice and runs its shard's MSMs with those H scalars — all ranks simulated on this GPU
+    keys = []
+
+    def make(rank):
+        keys.append(groth16.ProvingKey(zkey, shard=(rank, world)))
+        return D.DeviceShard(keys[-1], w)
+    got2 = [bytes(x) for x in D.groth16_prove_sharded_local(make, world, r_m, s_m)]
+    for k in keys:
+        k.release()
+    assert got2 == want
     if lg <= 12:
         ref = O.groth16_prove(c, binfile.read_groth16_zkey(zkey), w, r_m, s_m)
         assert got == [bytes(x) for x in ref]
