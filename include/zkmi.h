@@ -258,6 +258,10 @@ int zkmi_cpoly_interleave_dev(int curve, const void* const* d_polys, const size_
 /* Synthetic base table of SURVEY.md §8d: P_i = (f*g^i mod r)*G written to device memory as affine Montgomery points
  * (what G.batchApplyKey(G repeated n, Fr.e(f), Fr.e(g)) returns).  For benchmarks and tests. */
 int zkmi_gen_geometric_bases_dev(int curve, int group, size_t n, uint64_t f, uint64_t g, void* d_out);
+/* P_i = k_i * G for n caller-supplied scalars (device, 32-byte little-endian integers, normal form), affine Montgomery points out:
+ * the base sections of synthetic VALID proving keys built from a known trapdoor (src/zkey_new.js:182-201, :338-502
+ * compute the same points from a ptau file). For tests and benchmarks. */
+int zkmi_gen_bases_from_scalars_dev(int curve, int group, const void* d_scalars, size_t n, void* d_out);
 /* G.toAffine on host for one Jacobian point (tiny; used by bindings to normalise results). */
 int zkmi_to_affine(int curve, int group, const uint8_t* jacobian, uint8_t* affine);
 /* G.add on host for two Jacobian points (O(1)): folds the per-GPU partial results of a sharded MSM

@@ -309,8 +309,9 @@ int orc_fr_batch_from_mont(int curve, const uint8_t *in, uint8_t *out, size_t n)
 /* Fr.batchInverse (min.js:1@188677): element-wise inverse, 0 -> 0. (The reference uses Montgomery's trick per worker
  * slice with zeros skipped; the function computed is the element-wise inverse.) */
 int orc_fr_batch_inverse(int curve, const uint8_t *in, uint8_t *out, size_t n) {
-    curve_t *C = get_curve(curve); u64 x[MAXL], y[MAXL];
-    for (size_t i = 0; i < n; i++) { memcpy(x, in + 32 * i, 32); fe_inv(&C->Fr, y, x); memcpy(out + 32 * i, y, 32); }
+    curve_t *C = get_curve(curve);
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) { u64 x[MAXL], y[MAXL]; memcpy(x, in + 32 * i, 32); fe_inv(&C->Fr, y, x); memcpy(out + 32 * i, y, 32); }
     return 0;
 }
 /* Fr.batchApplyKey(buf, first, inc) (min.js:1@211529, kernel frm_batchApplyKey @128060): out[i] = in[i]·first·inc^i.
@@ -618,6 +619,42 @@ int orc_fr_geom_dot(int curve, const uint8_t *scalars, size_t n, int sb, u64 f, 
     for (size_t ci = 0; ci < nch; ci++) fe_add(F, acc, acc, part[ci]);
     free(part);
     fe_from_mont(F, acc, acc);
+    memcpy(out, acc, 32);
+    return 0;
+}
+/* element-wise Fr vector helpers for the valid-key synthesiser of the tests (tests/synth_valid_groth16.py): op 0 add, 1 sub, 2 mul;
+ * Montgomery in, Montgomery out */
+int orc_fr_vec_op(int curve, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) {
+    curve_t *C = get_curve(curve); const fld *F = &C->Fr;
+    if (op < 0 || op > 2) return -1;
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        u64 x[MAXL], y[MAXL], z[MAXL];
+        memcpy(x, a + 32 * i, 32); memcpy(y, b + 32 * i, 32);
+        if (op == 0) fe_add(F, z, x, y); else if (op == 1) fe_sub(F, z, x, y); else fe_mul(F, z, x, y);
+        memcpy(out + 32 * i, z, 32);
+    }
+    return 0;
+}
+/* sum_i a_i * w_i mod r with a_i in Montgomery form and w_i plain 32-byte integers (not reduced): result in normal form */
+int orc_fr_dot(int curve, const uint8_t *a_mont, const uint8_t *w_plain, size_t n, uint8_t *out) {
+    curve_t *C = get_curve(curve); const fld *F = &C->Fr;
+    const size_t CH = 8192, nch = (n + CH - 1) / CH;
+    u64 (*part)[4] = calloc(nch ? nch : 1, 32);
+    #pragma omp parallel for schedule(static)
+    for (size_t ci = 0; ci < nch; ci++) {
+        const size_t c0 = ci * CH, hi = c0 + CH < n ? c0 + CH : n;
+        u64 acc[MAXL] = {0}, x[MAXL], y[MAXL], z[MAXL];
+        for (size_t i = c0; i < hi; i++) {
+            memcpy(x, a_mont + 32 * i, 32); memcpy(y, w_plain + 32 * i, 32);
+            fe_mul(F, z, x, y);                        /* (a R)(w) R^-1 = a w, any w < 2^256 */
+            fe_add(F, acc, acc, z);
+        }
+        memcpy(part[ci], acc, 32);
+    }
+    u64 acc[MAXL] = {0};
+    for (size_t ci = 0; ci < nch; ci++) fe_add(F, acc, acc, part[ci]);
+    free(part);
     memcpy(out, acc, 32);
     return 0;
 }

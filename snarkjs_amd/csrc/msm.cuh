@@ -799,4 +799,26 @@ k_gen_geometric_bases(const uint32_t* __restrict__ gen_affine, uint32_t n, uint6
     f_store(out + (size_t)i * 2 * FW, r.x); f_store(out + (size_t)i * 2 * FW + FW, r.y);
 }
 
+// P_i = k_i * G for caller-supplied scalars k_i (32-byte little-endian integers, normal form): bases of synthetic VALID proving keys
+// (tests/synth_valid_groth16.py: A_i = u_i(tau) G, ...). One lane per point, double-and-add + one Fermat inversion; set-up only.
+template <class F> __global__ void __launch_bounds__(256)
+k_gen_scalar_bases(const uint32_t* __restrict__ gen_affine, const uint32_t* __restrict__ scalars, uint32_t n, uint32_t* __restrict__ out) {
+    constexpr int FW = FieldWords<F>::value;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) k[w] = scalars[(size_t)i * 8 + w];
+    Affine<F> G; pt_load(G, gen_affine);
+    XYZZ<F> acc; pt_set_inf(acc);
+    for (int b = 255; b >= 0; b--) {
+        acc = pt_dbl(acc);
+        if ((k[b >> 5] >> (b & 31)) & 1) pt_madd(acc, G);
+    }
+    Affine<F> r;
+    if (pt_is_inf(acc)) { f_set_zero(r.x); f_set_zero(r.y); }
+    else { r.x = f_mul(acc.X, f_inv(acc.ZZ)); r.y = f_mul(acc.Y, f_inv(acc.ZZZ)); }
+    f_store(out + (size_t)i * 2 * FW, r.x); f_store(out + (size_t)i * 2 * FW + FW, r.y);
+}
+
 }  // namespace zkmi

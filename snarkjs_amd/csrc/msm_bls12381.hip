@@ -61,6 +61,12 @@ int gen_bases_bls12381(int group, size_t n, uint64_t f, uint64_t g, void* d_out)
     if (group == 1) return gen_bases_run<Fp<Bls12381Fq>, Bls12381Fr>(gen, n, f, g, d_out);
     return gen_bases_run<Fp2<Bls12381Fq>, Bls12381Fr>(gen, n, f, g, d_out);
 }
+int gen_scalar_bases_bls12381(int group, const void* d_scalars, size_t n, void* d_out) {
+    uint8_t gen[192];
+    bls_generator(group, gen);
+    if (group == 1) return gen_scalar_bases_run<Fp<Bls12381Fq>>(gen, d_scalars, n, d_out);
+    return gen_scalar_bases_run<Fp2<Bls12381Fq>>(gen, d_scalars, n, d_out);
+}
 int point_add_bls12381(int group, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     if (group == 1) return point_add_host<Fp<Bls12381Fq>>(a, b, out);
     return point_add_host<Fp2<Bls12381Fq>>(a, b, out);

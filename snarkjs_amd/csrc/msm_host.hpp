@@ -448,4 +448,16 @@ template <class F, class FrC> int gen_bases_run(const uint8_t* gen_affine_host, 
     return ZKMI_OK;
 }
 
+template <class F> int gen_scalar_bases_run(const uint8_t* gen_affine_host, const void* d_scalars, size_t n, void* d_out) {
+    constexpr int FW = FieldWords<F>::value;
+    Ctx& cx = ctx();
+    uint32_t* d_gen;
+    ZK_TRY(ws_get("gen.generator", 2 * FW * 4, (void**)&d_gen));
+    ZK_HIP(hipMemcpyAsync(d_gen, gen_affine_host, 2 * FW * 4, hipMemcpyHostToDevice, cx.stream));
+    hipLaunchKernelGGL((k_gen_scalar_bases<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cx.stream, d_gen, (const uint32_t*)d_scalars, (uint32_t)n, (uint32_t*)d_out);
+    ZK_HIP(hipStreamSynchronize(cx.stream));
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+}
+
 }  // namespace zkmi

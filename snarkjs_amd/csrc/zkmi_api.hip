@@ -95,6 +95,8 @@ int msm_reduce_bls12381(int group, MsmJob* const*, int, bool);
 int msm_fold_bn254(int group, const MsmJob&, uint8_t*);
 int msm_fold_bls12381(int group, const MsmJob&, uint8_t*);
 int gen_bases_bn254(int group, size_t, uint64_t, uint64_t, void*);
+int gen_scalar_bases_bn254(int group, const void*, size_t, void*);
+int gen_scalar_bases_bls12381(int group, const void*, size_t, void*);
 int gen_bases_bls12381(int group, size_t, uint64_t, uint64_t, void*);
 int to_affine_bn254(int group, const uint8_t*, uint8_t*);
 int point_add_bn254(int group, const uint8_t*, const uint8_t*, uint8_t*);
@@ -256,6 +258,13 @@ int zkmi_memset_dev(void* d_dst, int value, size_t bytes) {
     ZK_TRY(require_ctx());
     if (bytes) ZK_HIP(hipMemsetAsync(d_dst, value, bytes, g_ctx.stream));
     return ZKMI_OK;
+}
+int zkmi_gen_bases_from_scalars_dev(int curve, int group, const void* d_scalars, size_t n, void* d_out) {
+    ZK_TRY(require_ctx());
+    ZK_TRY(check_cg(curve, group));
+    if (!d_scalars || !d_out) return fail(ZKMI_ERR_INVALID, "gen_bases_from_scalars: null argument");
+    if (!n) return ZKMI_OK;
+    return curve == ZKMI_CURVE_BN128 ? gen_scalar_bases_bn254(group, d_scalars, n, d_out) : gen_scalar_bases_bls12381(group, d_scalars, n, d_out);
 }
 int zkmi_msm_set_window_bits(int c) {
     if (c < 0 || c > 20) return fail(ZKMI_ERR_INVALID, "window bits must be 0 (auto) or 1..20");

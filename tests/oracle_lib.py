@@ -144,6 +144,22 @@ def geom_dot(curve, scalars, n, sb=32, f=7, g=11, skip_mod=0, skip_rem=0) -> int
     return int.from_bytes(out.tobytes(), "little")
 
 
+def vec_op(curve, op, a, b):
+    """element-wise Fr add / sub / mul (op = "add" | "sub" | "mul"), Montgomery in and out"""
+    a, b = _u8(a), _u8(b)
+    out = np.empty_like(a)
+    assert lib().orc_fr_vec_op(curve, {"add": 0, "sub": 1, "mul": 2}[op], _p(a), _p(b), _p(out), C.c_size_t(a.size // 32)) == 0
+    return out
+
+
+def dot(curve, a_mont, w_plain) -> int:
+    """sum a_i * w_i mod r (a Montgomery, w plain integers)"""
+    a, w = _u8(a_mont), _u8(w_plain)
+    out = np.zeros(32, np.uint8)
+    assert lib().orc_fr_dot(curve, _p(a), _p(w), C.c_size_t(a.size // 32), _p(out)) == 0
+    return int.from_bytes(out.tobytes(), "little")
+
+
 def threads():
     return lib().orc_threads()
 

@@ -202,3 +202,48 @@ def test_groth16_golden_proof_bls12381(golden_dir):
     proof, js = binfile.proof_json("bls12381", 48, O.fq_from_mont(c, pa), O.fq_from_mont(c, pb), O.fq_from_mont(c, pc))
     assert proof == g["proof"]
     assert sha(js.encode()) == g["proof_sha256"] == "955b9f3652e544aac16a90fd1ce6b8660701a7eb20e71fa7681ced22f0acd5eb"
+
+
+def _verify_mod():
+    import sys
+    od = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    if od not in sys.path:
+        sys.path.insert(0, od)
+    import groth16_verify_oracle as V
+    return V
+
+
+def test_groth16_verifier_restatement_pinned(golden_dir):
+    """oracle/groth16_verify_oracle.py (src/groth16_verify.js:26-87 + a plain-Python optimal ate pairing) against the reference's own
+    verdicts: the proofs its verifier accepted are accepted, tampered ones are rejected; bilinearity of the pairing."""
+    import copy
+    V = _verify_mod()
+    for tag in ("groth16_bn128_n1024", "groth16_valid_synth_n64"):
+        g = json.load(open(os.path.join(golden_dir, tag + ".json")))
+        assert g["verified"] is True
+        assert V.groth16_verify(g["vk"], g["publicSignals"], g["proof"]) is True
+        bad = copy.deepcopy(g["proof"])
+        bad["pi_c"] = g["proof"]["pi_a"]
+        assert V.groth16_verify(g["vk"], g["publicSignals"], bad) is False
+        pub = list(g["publicSignals"])
+        pub[-1] = str((int(pub[-1]) + 1) % V.R)
+        assert V.groth16_verify(g["vk"], pub, g["proof"]) is False
+        assert V.groth16_verify(g["vk"], [str(V.R)] + pub[1:], g["proof"]) is False          # public input not < r (:37-42)
+    g2 = V._g2(g["vk"]["vk_beta_2"])
+    e1 = V.final_exp(V.miller_loop(g2, V.g1_mul((1, 2), 7)))
+    assert e1 == V.f12_pow(V.final_exp(V.miller_loop(g2, (1, 2))), 7) and e1 != V.F12_ONE
+
+
+def test_valid_key_synthesiser_pinned(golden_dir):
+    """tests/synth_valid_groth16.py regenerates, byte for byte, the small valid key that the REFERENCE accepted (its exported vk, its
+    seeded proof and its verifier: oracle/gen_valid_fixture.py); the C restatement's proof on it equals the reference's."""
+    import synth_valid_groth16 as SV
+    g = json.load(open(os.path.join(golden_dir, "groth16_valid_synth_n64.json")))
+    zkey, wtns, info = SV.make("bn128", 6, use_device=False)
+    assert sha(zkey) == g["zkey_sha256"] == sha(open(os.path.join(golden_dir, "groth16_valid_synth_n64.zkey"), "rb").read())
+    assert sha(wtns) == g["wtns_sha256"]
+    assert info["vk"]["IC"] == g["vk"]["IC"] and all(info["vk"][k] == g["vk"][k] for k in ("vk_alpha_1", "vk_beta_2", "vk_gamma_2", "vk_delta_2"))
+    zk, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)
+    pa, pb, pc = O.groth16_prove(O.BN128, zk, w["witness"], bytes.fromhex(g["r_mont"]), bytes.fromhex(g["s_mont"]))
+    proof, js = binfile.proof_json("bn128", 32, O.fq_from_mont(O.BN128, pa), O.fq_from_mont(O.BN128, pb), O.fq_from_mont(O.BN128, pc))
+    assert proof == g["proof"] and sha(js.encode()) == g["proof_sha256"]
