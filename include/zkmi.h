@@ -254,6 +254,18 @@ int zkmi_poly_div_by_zerofier_dev(int curve, void* d_p, size_t len, uint32_t n, 
  * NULL), zero elsewhere; n <= 16 component polynomials; out_len elements are written. */
 int zkmi_cpoly_interleave_dev(int curve, const void* const* d_polys, const size_t* lens, int n, void* d_out, size_t out_len);
 
+/* ---- group-element FFTs and G.batchApplyKey (ceremony side) -------------------------------------------------
+ * curve.G1/G2.fft / .ifft (engine_fft for groups, min.js:1@215859: the Fr butterflies with "multiply by a twiddle" = G.timesFr) and, through
+ * it, G.lagrangeEvaluations for 2^k <= 2^Fr.s points (src/powersoftau_preparephase2.js:87). n = 2^log_n affine points in (2*group*n8q bytes
+ * each, Montgomery, all-zero = infinity), n affine points out, natural order; the inverse includes the factor 1/n. */
+int zkmi_group_fft(int curve, int group, zkmi_pages in, uint8_t* const* out_ptr, const size_t* out_len, int n_out_pages, unsigned log_n, int inverse);
+int zkmi_group_fft_dev(int curve, int group, const void* d_in, void* d_out, unsigned log_n, int inverse);
+/* curve.G1/G2.batchApplyKey(buff, first, inc) (engine_applykey, min.js:1@211529; src/mpc_applykey.js:44-70): out_i = (first * inc^i) * P_i,
+ * affine in and out; first / inc are Montgomery Fr elements (host pointers). */
+int zkmi_group_batch_apply_key(int curve, int group, zkmi_pages in, uint8_t* const* out_ptr, const size_t* out_len, int n_out_pages, size_t n,
+                               const uint8_t* first, const uint8_t* inc);
+int zkmi_group_batch_apply_key_dev(int curve, int group, const void* d_in, void* d_out, size_t n, const uint8_t* first, const uint8_t* inc);
+
 /* ---- utilities --------------------------------------------------------------------------------------------------- */
 /* Synthetic base table of SURVEY.md §8d: P_i = (f*g^i mod r)*G written to device memory as affine Montgomery points
  * (what G.batchApplyKey(G repeated n, Fr.e(f), Fr.e(g)) returns).  For benchmarks and tests. */

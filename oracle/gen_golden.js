@@ -214,6 +214,27 @@ async function groth16GoldenBls() {
     console.log('groth16 BLS12-381 golden done: zkey', z1.data.length, 'bytes, proof sha', sha(JSON.stringify(proof)), 'verify', ok);
 }
 
+// Group-element FFTs and G.batchApplyKey (SURVEY.md 8 f4, ceremony side): G.fft / G.ifft / G.lagrangeEvaluations over the first n points
+// of the geometric base table and G.batchApplyKey with non-trivial first / inc; raw outputs for the small sizes, hashes otherwise.
+async function groupVectors(name, tag) {
+    const curve = await snarkjs.curves.getCurveFromName(name);
+    const { Fr, G1, G2 } = curve, res = { curve: name };
+    for (const [gn, G, n] of [['g1', G1, 256], ['g2', G2, 64]]) {
+        const sG = G.F.n8 * 2, bases = (await geomBases(curve, G, n));
+        const f = await G.fft(bases, 'affine', 'affine'), fi = await G.ifft(bases, 'affine', 'affine'), le = await G.lagrangeEvaluations(bases, 'affine', 'affine');
+        const ak = await G.batchApplyKey(bases, Fr.e(3), Fr.e(5));
+        fs.writeFileSync(path.join(OUT, `${tag}_gfft_${gn}_n${n}_fft.bin`), f);
+        fs.writeFileSync(path.join(OUT, `${tag}_gfft_${gn}_n${n}_ifft.bin`), fi);
+        // with a point at infinity and a repeated point inside
+        const b2 = bases.slice(0, bases.byteLength); b2.fill(0, 5 * sG, 6 * sG); b2.set(bases.slice(0, sG), 9 * sG);
+        res[gn] = { n, bases_sha: sha(bases), fft: sha(f), ifft: sha(fi), lagrange: sha(le), lagrange_equals_ifft: sha(le) === sha(fi), applykey_3_5: sha(ak),
+                    fft_with_zero_and_repeat: sha(await G.fft(b2, 'affine', 'affine')) };
+        for (const lg of [0, 1, 2, 5]) { const k = 1 << lg; res[gn]['fft_n' + k] = sha(await G.fft(bases.slice(0, k * sG), 'affine', 'affine')); res[gn]['ifft_n' + k] = sha(await G.ifft(bases.slice(0, k * sG), 'affine', 'affine')); }
+    }
+    fs.writeFileSync(path.join(OUT, `${tag}_group_vectors.json`), JSON.stringify(res, null, 1));
+    console.log(tag, 'group vectors done');
+}
+
 // Seeded PLONK fixtures: plonk.setup on two circuits of the reference's test tree with the same seeded ptau, then a seeded
 // plonk.prove whose 11 blinding draws (src/plonk_prove.js:224-227) and Fiat-Shamir challenges are recorded.
 async function plonkGolden() {
@@ -312,6 +333,7 @@ async function fflonkGolden() {
     const what = process.argv[2] || 'all';
     if (what === 'all' || what === 'bn128') await kernelVectors('bn128', 'bn128');
     if (what === 'all' || what === 'bls12381') await kernelVectors('bls12381', 'bls12381');
+    if (what === 'all' || what === 'group') { await groupVectors('bn128', 'bn128'); await groupVectors('bls12381', 'bls12381'); }
     if (what === 'all' || what === 'groth16') await groth16Golden();
     if (what === 'all' || what === 'groth16bls') await groth16GoldenBls();
     if (what === 'all' || what === 'plonk') await plonkGolden();

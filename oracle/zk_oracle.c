@@ -589,6 +589,64 @@ int orc_fq_from_mont(int curve, const uint8_t *in, uint8_t *out, size_t n) {
     return 0;
 }
 
+static void pt_times_fr(const curve_t *C, const ext *E, u64 *R, const u64 *P, const u64 *k_mont);
+/* ---- group-element FFT and batchApplyKey -----------------------------------------------------------------
+ * G.fft / G.ifft (engine_fft for G1 / G2, min.js:1@215859 with g1m_/g2m_fftMix/_fftJoin/_fftFinal): X_k = sum_j w^(jk) P_j with
+ * w = Fr.w[log n], natural order, the inverse scaled by 1/n; "multiply by a twiddle" = G.timesFr. Restated as bit-reversal +
+ * radix-2 decimation in time. Affine (Montgomery, all-zero = infinity) in and out. */
+int orc_group_fft(int curve, int group, const uint8_t *in, uint8_t *out, unsigned log_n, int inverse) {
+    curve_t *C = get_curve(curve); const fld *Fr = &C->Fr; ext E = make_ext(C, group);
+    if ((int)log_n > C->s) return -1;
+    const size_t n = (size_t)1 << log_n, PB = (size_t)16 * E.L, JW = (size_t)3 * E.L;
+    u64 *a = malloc(n * JW * 8);
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        size_t r = 0; for (unsigned b = 0; b < log_n; b++) r |= ((i >> b) & 1) << (log_n - 1 - b);
+        u64 A[2 * MAXE]; memcpy(A, in + i * PB, PB); pt_from_affine(&E, a + r * JW, A);
+    }
+    for (unsigned st = 1; st <= log_n; st++) {
+        const size_t h = (size_t)1 << (st - 1);
+        const u64 *wst = inverse ? C->wi[st] : C->w[st];
+        #pragma omp parallel for schedule(dynamic, 16)
+        for (size_t idx = 0; idx < n / 2; idx++) {
+            const size_t j = idx & (h - 1), lo = ((idx >> (st - 1)) << st) + j;
+            u64 tw[MAXL], e[1] = {(u64)j}, T[3 * MAXE], U[3 * MAXE], N[3 * MAXE];
+            fe_pow(Fr, tw, wst, e, 1);
+            pt_times_fr(C, &E, T, a + (lo + h) * JW, tw);
+            memcpy(U, a + lo * JW, JW * 8);
+            pt_add(&E, a + lo * JW, U, T);
+            pt_neg(&E, N, T);
+            pt_add(&E, a + (lo + h) * JW, U, N);
+        }
+    }
+    u64 ni[MAXL] = {0};
+    if (inverse) { u64 nn[MAXL] = {(u64)n}; fe_to_mont(Fr, ni, nn); fe_inv(Fr, ni, ni); }
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (size_t i = 0; i < n; i++) {
+        u64 P[3 * MAXE], A[2 * MAXE];
+        if (inverse) pt_times_fr(C, &E, P, a + i * JW, ni); else memcpy(P, a + i * JW, JW * 8);
+        pt_to_affine(&E, A, P); memcpy(out + i * PB, A, PB);
+    }
+    free(a);
+    return 0;
+}
+/* G.batchApplyKey(buff, first, inc) (engine_applykey, min.js:1@211529; g1m_/g2m_batchApplyKey): out_i = (first * inc^i) * P_i, affine */
+int orc_group_apply_key(int curve, int group, const uint8_t *in, uint8_t *out, size_t n, const uint8_t *first, const uint8_t *inc) {
+    curve_t *C = get_curve(curve); const fld *Fr = &C->Fr; ext E = make_ext(C, group);
+    const size_t PB = (size_t)16 * E.L;
+    u64 f0[MAXL], k[MAXL];
+    memcpy(f0, first, 32); memcpy(k, inc, 32);
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (size_t i = 0; i < n; i++) {
+        u64 t[MAXL], e[1] = {(u64)i}, A[2 * MAXE], P[3 * MAXE], Q[3 * MAXE];
+        fe_pow(Fr, t, k, e, 1); fe_mul(Fr, t, t, f0);
+        memcpy(A, in + i * PB, PB); pt_from_affine(&E, P, A);
+        pt_times_fr(C, &E, Q, P, t);
+        pt_to_affine(&E, A, Q); memcpy(out + i * PB, A, PB);
+    }
+    return 0;
+}
+
 /* ---- helpers of the full-size closed-form checks (tests/test_gpu_parity.py) ------------------------------------------
  * sum_i s_i * f * g^i mod r over the entries with (i % skip_mod) != skip_rem (skip_mod = 0: all entries); s_i are plain
  * little-endian integers of sb <= 32 bytes (not reduced), result in normal form (32 bytes LE). These are the discrete logs

@@ -190,6 +190,17 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
     return ZKMI_OK;
 }
 
+// split power tables of root = Fr.w[L] (or its inverse): root^e = T_lo[e & (2^lb - 1)] * T_hi[e >> lb]; n_inv = (2^L)^-1 (Montgomery). Shared
+// with the group FFT (gfft.hip), whose twiddles are the same roots.
+int ntt_power_tables(int curve, unsigned L, int inverse, const uint32_t** T_lo, const uint32_t** T_hi, uint32_t* log_lb, const uint32_t** n_inv) {
+    NttPlan* P = nullptr;
+    if (curve == ZKMI_CURVE_BN128) { if ((int)L > fr_roots<Bn254Fr>().s) return fail(ZKMI_ERR_UNSUPPORTED, "fft: log2(n) exceeds the 2-adicity of Fr"); ZK_TRY((get_plan<Bn254Fr>(curve, L, inverse, &P))); }
+    else if (curve == ZKMI_CURVE_BLS12381) { if ((int)L > fr_roots<Bls12381Fr>().s) return fail(ZKMI_ERR_UNSUPPORTED, "fft: log2(n) exceeds the 2-adicity of Fr"); ZK_TRY((get_plan<Bls12381Fr>(curve, L, inverse, &P))); }
+    else return fail(ZKMI_ERR_INVALID, "unknown curve");
+    *T_lo = P->T_lo; *T_hi = P->T_hi; *log_lb = P->log_lb; *n_inv = P->n_inv;
+    return ZKMI_OK;
+}
+
 int ntt_dev_dispatch(int curve, const void* d_in, void* d_out, unsigned log_n, int inverse, const uint8_t* first, const uint8_t* inc) {
     if (curve == ZKMI_CURVE_BN128) return ntt_run<Bn254Fr>(curve, d_in, d_out, log_n, inverse, first, inc);
     if (curve == ZKMI_CURVE_BLS12381) return ntt_run<Bls12381Fr>(curve, d_in, d_out, log_n, inverse, first, inc);

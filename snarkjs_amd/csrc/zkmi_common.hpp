@@ -92,6 +92,7 @@ int to_affine_dispatch(int curve, int group, const uint8_t* jac, uint8_t* aff);
 // inc of the Groth16 coset step: Fr.shift when power == Fr.s, else Fr.w[power+1] (src/groth16_prove.js:64), Montgomery bytes
 int fr_coset_inc(int curve, unsigned power, uint8_t* out32);
 int fr_root(int curve, unsigned i, uint8_t* out32);      // Fr.w[i], Montgomery bytes
+int ntt_power_tables(int curve, unsigned L, int inverse, const uint32_t** T_lo, const uint32_t** T_hi, uint32_t* log_lb, const uint32_t** n_inv);
 
 inline int n8q_of(int curve) { return curve == ZKMI_CURVE_BN128 ? 32 : 48; }
 

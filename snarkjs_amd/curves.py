@@ -136,6 +136,45 @@ class _Group:
         zkmi.check(zkmi.lib().zkmi_msm(self._c, self._g, pb.pages, ps.pages, n, ns // n, cache_key, zkmi.ptr(out)))
         return out
 
+    def _gfft(self, buff, inverse):
+        nb = _byte_length(buff)
+        n = nb // self.point_bytes
+        if n == 0 or (n & (n - 1)) or n * self.point_bytes != nb:
+            raise ValueError("fft must be multiple of 2")                  # reference message, min.js:1@215859
+        pg = zkmi.pages_of(buff)
+        out = np.empty(nb, np.uint8)
+        op, ol = (C.c_void_p * 1)(out.ctypes.data), (C.c_size_t * 1)(nb)
+        zkmi.check(zkmi.lib().zkmi_group_fft(self._c, self._g, pg.pages, op, ol, 1, n.bit_length() - 1, int(inverse)))
+        return out
+
+    def fft(self, buff, inType="affine", outType="affine", logger=None, name=None):
+        """G.fft over affine points (ceremony side); only the affine -> affine form the reference's callers use"""
+        if inType != "affine" or outType != "affine":
+            raise ValueError("group fft: only affine in / affine out is implemented")
+        return self._gfft(buff, False)
+
+    def ifft(self, buff, inType="affine", outType="affine", logger=None, name=None):
+        if inType != "affine" or outType != "affine":
+            raise ValueError("group fft: only affine in / affine out is implemented")
+        return self._gfft(buff, True)
+
+    def lagrangeEvaluations(self, buff, inType="affine", outType="affine", logger=None, name=None):
+        """G.lagrangeEvaluations for 2^k <= 2^Fr.s points = G.ifft (min.js: lagrangeEvaluations -> ifft)"""
+        return self.ifft(buff, inType, outType)
+
+    def batchApplyKey(self, buff, first, inc, inType="affine", outType="affine"):
+        """out_i = (first * inc^i) * P_i; first / inc: Montgomery Fr elements (32 bytes)"""
+        if inType != "affine" or outType != "affine":
+            raise ValueError("group batchApplyKey: only affine in / affine out is implemented")
+        nb = _byte_length(buff)
+        n = nb // self.point_bytes
+        pg = zkmi.pages_of(buff)
+        out = np.empty(n * self.point_bytes, np.uint8)
+        f, g = zkmi.u8(first), zkmi.u8(inc)
+        op, ol = (C.c_void_p * 1)(out.ctypes.data), (C.c_size_t * 1)(out.size)
+        zkmi.check(zkmi.lib().zkmi_group_batch_apply_key(self._c, self._g, pg.pages, op, ol, 1, n, zkmi.ptr(f), zkmi.ptr(g)))
+        return out
+
     def toAffine(self, jac):
         j = zkmi.u8(jac)
         out = np.zeros(2 * self.F_n8, np.uint8)

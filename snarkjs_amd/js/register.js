@@ -77,6 +77,39 @@ function register(curve, options) {
         };
     }
 
+    // Ceremony side (SURVEY.md 8 f4): G.fft / G.ifft over affine points (src/powersoftau_preparephase2.js:87 reaches G.ifft through
+    // G.lagrangeEvaluations, which the reference implements on top of this very property for 2^k <= 2^Fr.s points) and
+    // G.batchApplyKey (src/mpc_applykey.js:44-70). Only the affine -> affine forms the reference's callers use are taken over; any other
+    // inType / outType combination, the array-of-elements form and sizes above 2^28 fall through to the WASM original.
+    // options.ceremony === false leaves these three methods alone.
+    if (options.ceremony !== false) {
+        for (const [gname, group] of [["G1", 1], ["G2", 2]]) {
+            const G = curve[gname], sG = G.F.n8 * 2;
+            Object.assign(orig[gname], { fft: G.fft, ifft: G.ifft, batchApplyKey: G.batchApplyKey });
+            const gfft = (inverse, origFn) => async function (buff, inType, outType, logger, loggerTxt) {
+                inType = inType || "affine"; outType = outType || "affine";
+                if (!isBuf(buff) || inType !== "affine" || outType !== "affine") return origFn.apply(G, arguments);
+                const n = buff.byteLength / sG, bits = log2(n);
+                if ((1 << bits) != n) throw new Error("fft must be multiple of 2");
+                if (bits > 28 || bits > Fr.s) return origFn.apply(G, arguments);
+                const out = allocLikeSliced(buff, buff.byteLength);
+                addon.groupFft(cid, group, pagesOf(buff), pagesOf(out), bits, inverse ? 1 : 0);
+                return out;
+            };
+            if (typeof G.fft === "function") { G.fft = gfft(false, orig[gname].fft); G.ifft = gfft(true, orig[gname].ifft); }
+            if (typeof G.batchApplyKey === "function") {
+                G.batchApplyKey = async function (buff, first, inc, inType, outType) {
+                    inType = inType || "affine"; outType = outType || "affine";
+                    if (!isBuf(buff) || inType !== "affine" || outType !== "affine") return orig[gname].batchApplyKey.apply(G, arguments);
+                    const n = Math.floor(buff.byteLength / sG);
+                    const out = allocLike(buff, n * sG);
+                    addon.groupApplyKey(cid, group, pagesOf(buff), pagesOf(out), n, Fr.e(first), Fr.e(inc));
+                    return out;
+                };
+            }
+        }
+    }
+
     orig.Fr = { fft: Fr.fft, ifft: Fr.ifft, batchApplyKey: Fr.batchApplyKey, batchToMontgomery: Fr.batchToMontgomery,
                 batchFromMontgomery: Fr.batchFromMontgomery, batchInverse: Fr.batchInverse };
 
@@ -120,8 +153,8 @@ function register(curve, options) {
 function unregister(curve) {
     if (!curve.__zkmi) return curve;
     const o = curve.__zkmi.orig;
-    curve.G1.multiExpAffine = o.G1.multiExpAffine;
-    curve.G2.multiExpAffine = o.G2.multiExpAffine;
+    Object.assign(curve.G1, o.G1);
+    Object.assign(curve.G2, o.G2);
     Object.assign(curve.Fr, o.Fr);
     delete curve.__zkmi;
     return curve;

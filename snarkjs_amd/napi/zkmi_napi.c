@@ -165,6 +165,29 @@ static napi_value js_apply_key(napi_env env, napi_callback_info info) {
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
+/* groupFft(curve, group, in, out, logN, inverse): G.fft / G.ifft over affine points, out preallocated by the caller */
+static napi_value js_group_fft(napi_env env, napi_callback_info info) {
+    ARGS(6);
+    int32_t curve, group, logn, inverse;
+    pages_t in, out;
+    if (get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &group) || get_pages(env, argv[2], &in) || get_pages(env, argv[3], &out) ||
+        get_i32(env, argv[4], &logn) || get_i32(env, argv[5], &inverse)) BAD_ARG();
+    int rc = zkmi_group_fft(curve, group, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (unsigned)logn, inverse);
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+/* groupApplyKey(curve, group, in, out, n, first, inc): G.batchApplyKey over affine points */
+static napi_value js_group_apply_key(napi_env env, napi_callback_info info) {
+    ARGS(7);
+    int32_t curve, group; double n;
+    pages_t in, out;
+    const uint8_t *first, *inc;
+    if (get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &group) || get_pages(env, argv[2], &in) || get_pages(env, argv[3], &out) || get_f64(env, argv[4], &n) ||
+        get_opt32(env, argv[5], &first) || get_opt32(env, argv[6], &inc) || !first || !inc) BAD_ARG();
+    int rc = zkmi_group_batch_apply_key(curve, group, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n, first, inc);
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
 /* joinABC(curve, a, b, c, out, n) */
 static napi_value js_join_abc(napi_env env, napi_callback_info info) {
     ARGS(6);
@@ -303,7 +326,7 @@ static napi_value js_call(napi_env env, napi_callback_info info) {
 static napi_value module_init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"init", js_init}, {"deviceCount", js_device_count}, {"version", js_version}, {"msm", js_msm}, {"releaseBases", js_release_bases},
-        {"ntt", js_ntt}, {"frBatch", js_fr_batch}, {"applyKey", js_apply_key}, {"joinABC", js_join_abc}, {"toAffine", js_to_affine},
+        {"ntt", js_ntt}, {"frBatch", js_fr_batch}, {"applyKey", js_apply_key}, {"joinABC", js_join_abc}, {"toAffine", js_to_affine}, {"groupFft", js_group_fft}, {"groupApplyKey", js_group_apply_key},
         {"groth16Prove", js_groth16_prove}, {"groth16Release", js_groth16_release}, {"call", js_call},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

@@ -47,6 +47,20 @@ for (const [tag, cid] of [["bn128", 0], ["bls12381", 1]]) {
         check(`${tag} G${g}.multiExpAffine (resident tables)`, eq(addon.toAffine(cid, g, j1), raw(tag, `g${g}_msm_affine`)) && eq(addon.toAffine(cid, g, j2), raw(tag, `g${g}_msm_affine`)));
         addon.releaseBases(key);
     }
+    // ceremony side (SURVEY.md 8 f4): group-element FFTs and G.batchApplyKey against the reference's vectors
+    {
+        const gv = JSON.parse(fs.readFileSync(path.join(GOLD, `${tag}_group_vectors.json`)));
+        for (const [gn, g, n] of [["g1", 1, 256], ["g2", 2, 64]]) {
+            const sG = 2 * g * n8q, bases = raw(tag, `g${g}_bases`).subarray(0, n * sG);
+            const lg = Math.round(Math.log2(n));
+            let o2 = new Uint8Array(n * sG); addon.groupFft(cid, g, bases, o2, lg, 0);
+            check(`${tag} G${g}.fft`, sha(o2) === gv[gn].fft && eq(o2, new Uint8Array(fs.readFileSync(path.join(GOLD, `${tag}_gfft_${gn}_n${n}_fft.bin`)))));
+            o2 = new Uint8Array(n * sG); addon.groupFft(cid, g, [bases.subarray(0, 10 * sG), bases.subarray(10 * sG)], o2, lg, 1);
+            check(`${tag} G${g}.ifft (paged input)`, sha(o2) === gv[gn].ifft);
+            o2 = new Uint8Array(n * sG); addon.groupApplyKey(cid, g, bases, o2, n, frE(r, 3), frE(r, 5));
+            check(`${tag} G${g}.batchApplyKey`, sha(o2) === gv[gn].applykey_3_5);
+        }
+    }
     let threw = false;
     try { addon.msm(cid, 1, raw(tag, "g1_bases"), x.subarray(0, 1024 * 32 - 1), 1024, 32, 0); } catch (e) { threw = /Scalar size does not match/.test(e.message); }
     check(`${tag} scalar size error`, threw);

@@ -20,6 +20,8 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
 (async () => {
     const curve = await snarkjs.curves.getCurveFromName("bn128");
     const saved = { g1: curve.G1.multiExpAffine.bind(curve.G1), g2: curve.G2.multiExpAffine.bind(curve.G2), fft: curve.Fr.fft.bind(curve.Fr), ifft: curve.Fr.ifft.bind(curve.Fr),
+                    gfft: { 1: [curve.G1.fft.bind(curve.G1), curve.G1.ifft.bind(curve.G1)], 2: [curve.G2.fft.bind(curve.G2), curve.G2.ifft.bind(curve.G2)] },
+                    gak: { 1: curve.G1.batchApplyKey.bind(curve.G1), 2: curve.G2.batchApplyKey.bind(curve.G2) },
                     ak: curve.Fr.batchApplyKey.bind(curve.Fr), tm: curve.Fr.batchToMontgomery.bind(curve.Fr), fm: curve.Fr.batchFromMontgomery.bind(curve.Fr), inv: curve.Fr.batchInverse.bind(curve.Fr) };
     const calls = {};
     const note = (k) => { calls[k] = (calls[k] || 0) + 1; };
@@ -31,12 +33,14 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
         init() { note("init"); },
         msm(cid, group, bases, scalars, n, sb, key) { note("msm" + group); const out = new Uint8Array(96 * group); out.__p = (group == 1 ? saved.g1 : saved.g2)(cat(bases), cat(scalars)).then((r) => out.set(r)); return out; },
         ntt(cid, inp, out, logn, inverse) { note(inverse ? "ifft" : "fft"); out.__p = (inverse ? saved.ifft : saved.fft)(cat(inp)).then((r) => spread(r, out)); },
+        groupFft(cid, group, inp, out, logn, inverse) { note("gfft" + group); out.__p = saved.gfft[group][inverse ? 1 : 0](cat(inp), "affine", "affine").then((r) => spread(r, out)); },
+        groupApplyKey(cid, group, inp, out, n, first, inc) { note("gak" + group); out.__p = saved.gak[group](cat(inp), first, inc).then((r) => spread(r, out)); },
         applyKey(cid, inp, out, n, first, inc) { note("applyKey"); out.__p = saved.ak(cat(inp), first, inc).then((r) => spread(r, out)); },
         frBatch(cid, op, inp, out, n) { note("batch" + op); out.__p = [saved.tm, saved.fm, saved.inv][op](cat(inp)).then((r) => spread(r, out)); },
     };
     register(curve, { addon: mock });
     // the mock fills its outputs asynchronously: wrap every patched method so that it awaits that work
-    for (const [obj, names] of [[curve.G1, ["multiExpAffine"]], [curve.G2, ["multiExpAffine"]], [curve.Fr, ["fft", "ifft", "batchApplyKey", "batchToMontgomery", "batchFromMontgomery", "batchInverse"]]]) {
+    for (const [obj, names] of [[curve.G1, ["multiExpAffine", "fft", "ifft", "batchApplyKey"]], [curve.G2, ["multiExpAffine", "fft", "ifft", "batchApplyKey"]], [curve.Fr, ["fft", "ifft", "batchApplyKey", "batchToMontgomery", "batchFromMontgomery", "batchInverse"]]]) {
         for (const nm of names) {
             const f = obj[nm];
             obj[nm] = async function () { const r = await f.apply(this, arguments); const c = (r instanceof Uint8Array) ? r : (r && r.buffers); if (c && c.__p) { await c.__p; delete c.__p; } return r; };
@@ -54,6 +58,20 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
     try { await curve.G1.multiExpAffine(new Uint8Array(128), new Uint8Array(63)); } catch (e) { threw = e.message === "Scalar size does not match"; }
     check("multiExpAffine error message", threw);
     check("multiExpAffine empty -> G1.zero", (await curve.G1.multiExpAffine(new Uint8Array(0), new Uint8Array(0))) === curve.G1.zero);
+
+    // 1b. ceremony-side group operations (SURVEY.md 8 f4): affine -> affine forms go to the addon, everything else to the WASM original
+    {
+        const gen = curve.G1.toAffine(curve.G1.g), pts = new Uint8Array(64 * 64);
+        for (let i = 0; i < 64; i++) pts.set(gen, i * 64);
+        const bases = await saved.gak[1](pts, curve.Fr.e(7), curve.Fr.e(11));
+        for (const k of Object.keys(calls)) delete calls[k];
+        check("G1.ifft affine -> affine through register.js", sha(await curve.G1.ifft(bases, "affine", "affine")) === sha(await saved.gfft[1][1](bases, "affine", "affine")) && calls.gfft1 === 1);
+        check("G1.lagrangeEvaluations reaches the patched G1.ifft", sha(await curve.G1.lagrangeEvaluations(bases, "affine", "affine")) === sha(await saved.gfft[1][1](bases, "affine", "affine")) && calls.gfft1 === 2);
+        check("G1.batchApplyKey through register.js", sha(await curve.G1.batchApplyKey(bases, curve.Fr.e(3), curve.Fr.e(5))) === sha(await saved.gak[1](bases, curve.Fr.e(3), curve.Fr.e(5))) && calls.gak1 === 1);
+        const before = calls.gfft1;
+        const jac = await curve.G1.fft(bases, "affine", "jacobian");
+        check("G1.fft affine -> jacobian falls through to the WASM original", jac.byteLength === 64 * 96 && calls.gfft1 === before);
+    }
 
     // 2. seeded Groth16 proof through the patched surface == SURVEY.md Appendix C.3 / golden fixture
     const g = JSON.parse(fs.readFileSync(path.join(GOLD, "groth16_bn128_n1024.json")));

@@ -144,6 +144,22 @@ def geom_dot(curve, scalars, n, sb=32, f=7, g=11, skip_mod=0, skip_rem=0) -> int
     return int.from_bytes(out.tobytes(), "little")
 
 
+def group_fft(curve, group, pts, inverse=False):
+    """G.fft / G.ifft over n affine points (oracle/zk_oracle.c: orc_group_fft)"""
+    pts = _u8(pts)
+    n = pts.size // (2 * group * n8q(curve))
+    out = np.empty_like(pts)
+    assert lib().orc_group_fft(curve, group, _p(pts), _p(out), C.c_uint(max(n, 1).bit_length() - 1), int(inverse)) == 0
+    return out
+
+
+def group_apply_key(curve, group, pts, first, inc):
+    pts, first, inc = _u8(pts), _u8(first), _u8(inc)
+    out = np.empty_like(pts)
+    assert lib().orc_group_apply_key(curve, group, _p(pts), _p(out), C.c_size_t(pts.size // (2 * group * n8q(curve))), _p(first), _p(inc)) == 0
+    return out
+
+
 def vec_op(curve, op, a, b):
     """element-wise Fr add / sub / mul (op = "add" | "sub" | "mul"), Montgomery in and out"""
     a, b = _u8(a), _u8(b)

@@ -356,6 +356,40 @@ def test_groth16_valid_key_proof_verifies(zk, golden_dir, lg):
     assert V.groth16_verify(info["vk"], res["publicSignals"], bad) is False
 
 
+@pytest.mark.parametrize("name", CURVES)
+def test_group_fft_and_apply_key(zk, golden_dir, name):
+    """SURVEY.md 8 f4 (ceremony side): G1/G2.fft / ifft / lagrangeEvaluations / batchApplyKey on the device vs the reference's golden vectors
+    (oracle/gen_golden.js groupVectors) bit for bit, vs the C restatement at 2^10, round trip at 2^14."""
+    c, cv = O.CURVE_ID[name], curve_of(zk, name)
+    g = json.load(open(os.path.join(golden_dir, f"{name}_group_vectors.json")))
+    q8 = O.n8q(c)
+    for gn, group, G in (("g1", 1, cv.G1), ("g2", 2, cv.G2)):
+        v, pb = g[gn], 2 * group * q8
+        n = v["n"]
+        bases = O.geom_bases(c, group, n)
+        assert sha(G.fft(bases)) == v["fft"] and sha(G.ifft(bases)) == v["ifft"] and sha(G.lagrangeEvaluations(bases)) == v["lagrange"]
+        assert sha(G.batchApplyKey(bases, O.fr_e(c, 3), O.fr_e(c, 5))) == v["applykey_3_5"]
+        b2 = bases.copy()
+        b2[5 * pb:6 * pb] = 0
+        b2[9 * pb:10 * pb] = bases[:pb]
+        assert sha(G.fft(b2)) == v["fft_with_zero_and_repeat"]
+        for k in (1, 2, 4, 32):
+            assert sha(G.fft(bases[:k * pb])) == v[f"fft_n{k}"] and sha(G.ifft(bases[:k * pb])) == v[f"ifft_n{k}"]
+        with pytest.raises(ValueError):
+            G.fft(bases[:3 * pb])
+        # paged ("BigBuffer") input
+        assert sha(G.fft([bases[:100 * pb // 2], bases[100 * pb // 2:]])) == v["fft"]
+    m = 1 << (10 if name == "bn128" else 8)
+    B = O.geom_bases(c, 1, m)
+    assert np.array_equal(cv.G1.fft(B), O.group_fft(c, 1, B)) and np.array_equal(cv.G1.ifft(B), O.group_fft(c, 1, B, inverse=True))
+    f, inc = synth.elems(0x61, 1), synth.elems(0x62, 1)
+    assert np.array_equal(cv.G1.batchApplyKey(B, O.to_mont(c, f), O.to_mont(c, inc)), O.group_apply_key(c, 1, B, O.to_mont(c, f), O.to_mont(c, inc)))
+    big = O.geom_bases(c, 1, 64)
+    big = np.tile(big, (1 << 14) // 64)
+    big = cv.G1.batchApplyKey(big, O.fr_e(c, 2), O.fr_e(c, 3))            # 2^14 distinct points
+    assert np.array_equal(cv.G1.ifft(cv.G1.fft(big)), big)
+
+
 def test_groth16_malformed_inputs_fail_cleanly(zk, golden_dir):
     """Truncated sections / witness and key-number re-use must fail with an error, never read past the caller's buffers or prove
     against another circuit's key (include/zkmi.h: zkmi_groth16_zkey *_len fields, zkmi_groth16_prove witness_len)."""

@@ -21,7 +21,7 @@ FLAGS = ["--harmony-optional-chaining", "--harmony-nullish"]
 @need_node
 def test_addon_exports_and_no_silent_fallback():
     js = ("const a=require(%r);const want=['init','deviceCount','version','msm','releaseBases','ntt','frBatch','applyKey','joinABC','toAffine',"
-          "'groth16Prove','groth16Release','call'];for(const k of want) if(typeof a[k]!=='function'){console.log('missing',k);process.exit(3)}"
+          "'groth16Prove','groth16Release','call','groupFft','groupApplyKey'];for(const k of want) if(typeof a[k]!=='function'){console.log('missing',k);process.exit(3)}"
           "if(a.deviceCount()==0){try{a.init(0);console.log('init did not throw');process.exit(4)}catch(e){if(!/no HIP device/.test(e.message)){console.log(e.message);process.exit(5)}}}"
           "console.log('ok')") % ADDON
     r = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=120)

@@ -247,3 +247,29 @@ def test_valid_key_synthesiser_pinned(golden_dir):
     pa, pb, pc = O.groth16_prove(O.BN128, zk, w["witness"], bytes.fromhex(g["r_mont"]), bytes.fromhex(g["s_mont"]))
     proof, js = binfile.proof_json("bn128", 32, O.fq_from_mont(O.BN128, pa), O.fq_from_mont(O.BN128, pb), O.fq_from_mont(O.BN128, pc))
     assert proof == g["proof"] and sha(js.encode()) == g["proof_sha256"]
+
+
+@pytest.mark.parametrize("name", ["bn128", "bls12381"])
+def test_group_fft_and_apply_key_golden(golden_dir, name):
+    """G.fft / G.ifft / G.lagrangeEvaluations / G.batchApplyKey of the reference (oracle/gen_golden.js groupVectors) vs the C
+    restatement, incl. a point at infinity and a repeated point inside the input, sizes 1 .. 256."""
+    c = O.CURVE_ID[name]
+    g = json.load(open(os.path.join(golden_dir, f"{name}_group_vectors.json")))
+    q8 = O.n8q(c)
+    for gn, group in (("g1", 1), ("g2", 2)):
+        v, pb = g[gn], 2 * group * q8
+        n = v["n"]
+        bases = O.geom_bases(c, group, n)
+        assert sha(bases) == v["bases_sha"]
+        f, fi = O.group_fft(c, group, bases), O.group_fft(c, group, bases, inverse=True)
+        assert sha(f) == v["fft"] and sha(fi) == v["ifft"] == v["lagrange"]
+        assert bytes(f) == open(os.path.join(golden_dir, f"{name}_gfft_{gn}_n{n}_fft.bin"), "rb").read()
+        assert bytes(fi) == open(os.path.join(golden_dir, f"{name}_gfft_{gn}_n{n}_ifft.bin"), "rb").read()
+        assert sha(O.group_apply_key(c, group, bases, O.fr_e(c, 3), O.fr_e(c, 5))) == v["applykey_3_5"]
+        b2 = bases.copy()
+        b2[5 * pb:6 * pb] = 0
+        b2[9 * pb:10 * pb] = bases[:pb]
+        assert sha(O.group_fft(c, group, b2)) == v["fft_with_zero_and_repeat"]
+        for k in (1, 2, 4, 32):
+            assert sha(O.group_fft(c, group, bases[:k * pb])) == v[f"fft_n{k}"]
+            assert sha(O.group_fft(c, group, bases[:k * pb], inverse=True)) == v[f"ifft_n{k}"]

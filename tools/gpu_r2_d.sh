@@ -1,0 +1,6 @@
+#!/bin/bash
+set -u
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r2d; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -14 $O/pytest.log
