@@ -15,6 +15,8 @@ min.js:1@183423); results come back as numpy uint8 arrays, or a list of them whe
 BigBuffer (see _alloc_like / _alloc_like_sliced).
 All work happens in the HIP library behind include/zkmi.h; nothing here computes.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import zkmi
