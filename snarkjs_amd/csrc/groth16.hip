@@ -117,6 +117,7 @@ struct G16Key {
         void** ptrs[] = {&bA, &bB1, &bB2, &bC, &bH, (void**)&row_cnt, (void**)&row_start, (void**)&sig, (void**)&val, (void**)&mask[0], (void**)&mask[1], (void**)&mask[2],
                          (void**)&mask[3], (void**)&mask[4], (void**)&drop_b, (void**)&wk[0].w, (void**)&wk[0].A, (void**)&wk[0].B, (void**)&wk[0].C, (void**)&wk[0].T,
                          (void**)&wk[1].w, (void**)&wk[1].A, (void**)&wk[1].B, (void**)&wk[1].C, (void**)&wk[1].T};
+        for (void* t : {bA, bB1, bB2, bC, bH}) if (t) msm_table_forget_r29(t);
         for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
         for (auto& wkk : wk) for (auto& e : wkk.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
@@ -196,6 +197,7 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
         }
         ZK_HIP(hipMalloc((void**)mask, (((size_t)Wd * tot + 31) / 32) * 4 + 16));
         ZK_TRY(msm_infmask_dispatch(zk->curve, group, *dst, (size_t)Wd * tot, *mask));
+        if (c) ZK_TRY(msm_table_to_r29(zk->curve, group, *dst, (size_t)Wd * tot, *mask));      // R'-form tables where the 29-bit path exists
         ZK_HIP(hipStreamSynchronize(st));
         return ZKMI_OK;                                    // ~DevTmp frees the plain copy when a table was built from it
     };

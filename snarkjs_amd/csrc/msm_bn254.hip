@@ -26,6 +26,13 @@ int msm_bn254(int group, const void* d_bases, const void* d_scalars, size_t n, s
     if (group == 1) return msm_run<Fp<Bn254Fq>>(d_bases, d_scalars, n, sb, out_jac);
     return msm_run<Fp2<Bn254Fq>>(d_bases, d_scalars, n, sb, out_jac);
 }
+int msm_table_to_r29_bn254(int group, void* d_table, size_t n_points) {
+    Ctx& cx = ctx();
+    const size_t elems = n_points * 2 * (size_t)group;         // base-field elements: 2 per G1 point, 4 per G2 point
+    hipLaunchKernelGGL((k_table_to_r29<Bn254Fq>), dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, cx.stream, (uint32_t*)d_table, elems);
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
+}
 int msm_accumulate_bn254(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask, MsmJob* into) {
     if (group == 1) return msm_accumulate<Fp<Bn254Fq>>(d_bases, pl, skip, job, d_infmask, into);
     return msm_accumulate<Fp2<Bn254Fq>>(d_bases, pl, skip, job, d_infmask, into);

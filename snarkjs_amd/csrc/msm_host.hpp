@@ -5,6 +5,8 @@
 #include <algorithm>
 #include "host_field.hpp"
 #include "msm.cuh"
+#include "msm29.cuh"
+#include <type_traits>
 #include "zkmi_common.hpp"
 
 namespace zkmi {
@@ -159,7 +161,31 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
     }
     if (job.acc0) ZK_HIP(hipEventRecord(job.acc0, st));
     bool launched = false;
-    if constexpr (!WIDE) if (into) {
+    if constexpr (std::is_same<F, Fp<Bn254Fq>>::value) {
+        // window tables registered in the R'-form of field29.cuh: the hot loop on unsaturated 29-bit limbs
+        auto r29 = cx.r29_tables.find(d_bases);
+        if (r29 != cx.r29_tables.end() && sh.precomp) {
+            launched = true;
+            const uint32_t* mask = d_infmask ? d_infmask : r29->second;
+            const dim3 grid((unsigned)((pl.lane_bound + 255) / 256));
+            if (into) hipLaunchKernelGGL((k_msm_accum29<Bn254Fq, true>), grid, dim3(256), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
+                                         pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);
+            else hipLaunchKernelGGL((k_msm_accum29<Bn254Fq, false>), grid, dim3(256), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
+                                    pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);
+        }
+    }
+    if constexpr (std::is_same<F, Fp2<Bn254Fq>>::value) {
+        auto r29 = cx.r29_tables.find(d_bases);
+        if (r29 != cx.r29_tables.end() && sh.precomp && !into) {
+            launched = true;
+            constexpr size_t lds29 = (size_t)256 * 72 * 4;                     // 4 coordinates x 18 limbs per lane
+            static bool a29 = false;
+            if (!a29) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum29_g2<Bn254Fq>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29)); a29 = true; }
+            hipLaunchKernelGGL((k_msm_accum29_g2<Bn254Fq>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), lds29, st, (const uint32_t*)d_bases,
+                               d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials);
+        }
+    }
+    if constexpr (!WIDE) if (into && !launched) {
         launched = true;
         hipLaunchKernelGGL((k_msm_accum<F, false, true>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_bases, d_infmask, sh, skip, pl.cap, pl.counts,
                            pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);

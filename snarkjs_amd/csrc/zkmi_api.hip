@@ -81,6 +81,7 @@ int download_pages(const void* d_src, size_t total_bytes, uint8_t* const* out_pt
 int msm_bn254(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_bls12381(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_accumulate_bn254(int group, const void*, const MsmPlan&, uint32_t, MsmJob&, const uint32_t*, MsmJob*);
+int msm_table_to_r29_bn254(int group, void* d_table, size_t n_points);
 int msm_accumulate_bls12381(int group, const void*, const MsmPlan&, uint32_t, MsmJob&, const uint32_t*, MsmJob*);
 int msm_infmask_bn254(int group, const void*, size_t, uint32_t*);
 int msm_infmask_bls12381(int group, const void*, size_t, uint32_t*);
@@ -124,6 +125,15 @@ int msm_precompute_dispatch(int curve, int group, const void* d_bases, size_t n,
     ZK_TRY(check_cg(curve, group));
     return curve == ZKMI_CURVE_BN128 ? msm_precompute_bn254(group, d_bases, n, c, Wd, d_table) : msm_precompute_bls12381(group, d_bases, n, c, Wd, d_table);
 }
+int msm_table_to_r29(int curve, int group, void* d_table, size_t n_points, const uint32_t* d_infmask) {
+    static const bool on = !(getenv("ZKMI_R29") && atoi(getenv("ZKMI_R29")) == 0);
+    static const int g2_on = getenv("ZKMI_R29_G2") ? atoi(getenv("ZKMI_R29_G2")) : 1;
+    if (!on || curve != ZKMI_CURVE_BN128 || (group != 1 && !(group == 2 && g2_on)) || !d_infmask) return ZKMI_OK;
+    ZK_TRY(msm_table_to_r29_bn254(group, d_table, n_points));
+    g_ctx.r29_tables[d_table] = d_infmask;
+    return ZKMI_OK;
+}
+void msm_table_forget_r29(const void* d_table) { g_ctx.r29_tables.erase(d_table); }
 int msm_table_dispatch(int curve, int group, const void* d_table, size_t stride, int c, const void* d_scalars, size_t k, size_t sb, uint8_t* out) {
     ZK_TRY(check_cg(curve, group));
     return curve == ZKMI_CURVE_BN128 ? msm_table_bn254(group, d_table, stride, c, d_scalars, k, sb, out) : msm_table_bls12381(group, d_table, stride, c, d_scalars, k, sb, out);
@@ -272,7 +282,7 @@ int zkmi_msm_set_window_bits(int c) {
     return ZKMI_OK;
 }
 // ---- resident base tables --------------------------------------------------------------------------------------------------
-struct MsmTable { void* p = nullptr; size_t n = 0; int c = 0, Wd = 0, curve = 0, group = 0; };
+struct MsmTable { void* p = nullptr; size_t n = 0; int c = 0, Wd = 0, curve = 0, group = 0; uint32_t* mask = nullptr; };
 static std::map<uint64_t, MsmTable> g_tables;
 static uint64_t g_next_table = 1;
 static int table_build(int curve, int group, const void* d_bases, size_t n, MsmTable& t) {
@@ -292,6 +302,11 @@ int zkmi_msm_table_build(int curve, int group, const void* d_bases, size_t n, ui
     if (!handle || !d_bases || !n) return fail(ZKMI_ERR_INVALID, "msm_table_build: bad argument");
     MsmTable t;
     ZK_TRY(table_build(curve, group, d_bases, n, t));
+    // handle tables are private to the library: keep them in the R'-form of field29.cuh where that path exists (needs the infinity bitmap)
+    ZK_HIP(hipMalloc((void**)&t.mask, (((size_t)t.Wd * n + 31) / 32) * 4 + 16));
+    ZK_TRY(msm_infmask_dispatch(curve, group, t.p, (size_t)t.Wd * n, t.mask));
+    ZK_TRY(msm_table_to_r29(curve, group, t.p, (size_t)t.Wd * n, t.mask));
+    ZK_HIP(hipStreamSynchronize(g_ctx.stream));
     *handle = g_next_table++;
     g_tables[*handle] = t;
     return ZKMI_OK;
@@ -321,7 +336,9 @@ int zkmi_msm_table_release(uint64_t handle) {
     auto it = g_tables.find(handle);
     if (it == g_tables.end()) return ZKMI_OK;
     if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+    msm_table_forget_r29(it->second.p);
     if (it->second.p) (void)hipFree(it->second.p);
+    if (it->second.mask) (void)hipFree(it->second.mask);
     g_tables.erase(it);
     return ZKMI_OK;
 }

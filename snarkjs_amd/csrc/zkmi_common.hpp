@@ -65,6 +65,8 @@ struct Ctx {
     std::map<size_t, std::vector<void*>> pool;              // freed zkmi_dev_alloc blocks by size
     size_t pool_bytes = 0, pool_limit = (size_t)96 << 30;
     std::map<uint64_t, void*> groth16;                      // zkmi_groth16 resident keys (groth16.hip)
+    // window tables kept in the R'-form of field29.cuh (base pointer -> infinity bitmap): msm_accumulate runs them through k_msm_accum29
+    std::map<const void*, const uint32_t*> r29_tables;
     hipStream_t aux_stream = nullptr;                       // second stream for latency-bound reductions (groth16.hip)
     hipEvent_t aux_ev[2] = {};
     hipEvent_t sort_ev[5] = {};                             // groth16.hip: digit sorts on the auxiliary stream (start, B, witness, join, H)
@@ -92,6 +94,10 @@ int to_affine_dispatch(int curve, int group, const uint8_t* jac, uint8_t* aff);
 // inc of the Groth16 coset step: Fr.shift when power == Fr.s, else Fr.w[power+1] (src/groth16_prove.js:64), Montgomery bytes
 int fr_coset_inc(int curve, unsigned power, uint8_t* out32);
 int fr_root(int curve, unsigned i, uint8_t* out32);      // Fr.w[i], Montgomery bytes
+// Convert a freshly built window table (n_points affine points, R-form) to the R'-form of field29.cuh in place and register it together
+// with its infinity bitmap; returns without doing anything for curves / groups that have no 29-bit path (or with ZKMI_R29=0).
+int msm_table_to_r29(int curve, int group, void* d_table, size_t n_points, const uint32_t* d_infmask);
+void msm_table_forget_r29(const void* d_table);
 int ntt_power_tables(int curve, unsigned L, int inverse, const uint32_t** T_lo, const uint32_t** T_hi, uint32_t* log_lb, const uint32_t** n_inv);
 
 inline int n8q_of(int curve) { return curve == ZKMI_CURVE_BN128 ? 32 : 48; }

@@ -20,6 +20,8 @@ sha = lambda b: hashlib.sha256(bytes(b)).hexdigest()
 
 @pytest.fixture(scope="module")
 def zk():
+    import torch
+    torch.cuda.init()                  # before the library takes device memory: the sharded tests exchange torch CUDA tensors
     import snarkjs_amd
     from snarkjs_amd import zkmi
     zkmi.init(0)
