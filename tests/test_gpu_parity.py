@@ -469,6 +469,53 @@ def test_msm_resident_tables(zk, name, group, lg):
     zkmi.check(L.zkmi_msm_table_release(h))
 
 
+@pytest.mark.parametrize("name,group", [("bn128", 1), ("bn128", 2), ("bls12381", 1)])
+def test_msm_resident_tables_special_cases(zk, name, group):
+    """Resident window tables (on BN254 the 29-bit-limb accumulation kernels of msm29.cuh) on inputs that force the special cases of the
+    mixed addition inside one bucket: the same base many times with the same small scalar (P + P doubling branch), a base next to its
+    negation (P - P -> infinity and back), points at infinity in the base array, zero scalars, scalars with every digit at the maximum."""
+    import ctypes as C
+    from snarkjs_amd import zkmi
+    c, L = O.CURVE_ID[name], zkmi.lib()
+    q8 = O.n8q(c)
+    pb = 2 * group * q8
+    q = int(json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"{name}_kernel_vectors.json")))["q"])
+    n = 4096
+    G = O.geom_bases(c, group, 16).reshape(16, pb)
+    bases = np.zeros((n, pb), np.uint8)
+    for i in range(n):
+        bases[i] = G[i % 5]                                   # heavy repetition: equal points meet in one bucket
+    neg = G[1].copy()                                          # -G[1]: negate y (Fq, or both Fq2 components)
+    for k in range(group):
+        y = int.from_bytes(bytes(G[1][(group + k) * q8:(group + k + 1) * q8]), "little")
+        neg[(group + k) * q8:(group + k + 1) * q8] = np.frombuffer(((q - y) % q).to_bytes(q8, "little"), np.uint8)
+    bases[7::11] = neg
+    bases[3::17] = 0                                           # points at infinity
+    bases = bases.reshape(-1)
+    cases = []
+    sc = np.zeros((n, 32), np.uint8); sc[:, 0] = 5                                   # one digit, same bucket for everything
+    cases.append(sc.copy())
+    sc = np.zeros((n, 32), np.uint8); sc[:, 0] = (np.arange(n) % 3).astype(np.uint8)   # zeros, ones, twos
+    cases.append(sc.copy())
+    sc = synth.elems(0xC0DE, n).reshape(n, 32).copy(); sc[::2] = sc[1::2]              # pairs of equal full-width scalars on (often) equal bases
+    cases.append(sc.copy())
+    sc = np.full((n, 32), 0xFF, np.uint8); sc[:, 31] = 0x1F                            # every signed digit at its extreme
+    cases.append(sc.copy())
+    d_b = zkmi.DeviceBuffer.from_host(bases)
+    h = C.c_uint64(0)
+    zkmi.check(L.zkmi_msm_table_build(c, group, d_b.ptr, n, C.byref(h)))
+    for idx, sc in enumerate(cases):
+        sc = sc.reshape(-1)
+        d_s = zkmi.DeviceBuffer.from_host(sc)
+        out = np.zeros(3 * group * q8, np.uint8)
+        zkmi.check(L.zkmi_msm_table_dev(h, d_s.ptr, n, 32, zkmi.ptr(out)))
+        want = O.to_affine(c, group, O.msm(c, group, bases, sc, n))
+        assert np.array_equal(O.to_affine(c, group, out), want), idx
+        d_s.free()
+    zkmi.check(L.zkmi_msm_table_release(h))
+    d_b.free()
+
+
 def _groth16_closed_form(c, name, zk_, w, lg, n_public, rr, ss, b_zero_every):
     """Closed-form discrete logs (a, b, cc) of pi_a, pi_b, pi_c for a tests/synth_zkey.py key: every base is a known multiple of
     the generator (T[i] = 7*11^i*G), so each MSM result is an O(n) field sum (oracle/zk_oracle.c: orc_fr_geom_dot) over the witness
