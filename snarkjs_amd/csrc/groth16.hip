@@ -115,8 +115,8 @@ struct G16Key {
     double stage_ms[ST_COUNT] = {};
     void release() {
         void** ptrs[] = {&bA, &bB1, &bB2, &bC, &bH, (void**)&row_cnt, (void**)&row_start, (void**)&sig, (void**)&val, (void**)&mask[0], (void**)&mask[1], (void**)&mask[2],
-                         (void**)&mask[3], (void**)&mask[4], (void**)&drop_b, (void**)&wk[0].w, (void**)&wk[0].A, (void**)&wk[0].B, (void**)&wk[0].C, (void**)&wk[0].T,
-                         (void**)&wk[1].w, (void**)&wk[1].A, (void**)&wk[1].B, (void**)&wk[1].C, (void**)&wk[1].T};
+                         (void**)&mask[3], (void**)&mask[4], (void**)&drop_b, (void**)&wk[0].w, (void**)&wk[0].A, (void**)&wk[0].T,
+                         (void**)&wk[1].w, (void**)&wk[1].A, (void**)&wk[1].T};        // B and C live inside the A allocation
         for (void* t : {bA, bB1, bB2, bC, bH}) if (t) msm_table_forget_r29(t);
         for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
         for (auto& wkk : wk) for (auto& e : wkk.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -136,7 +136,10 @@ static int g16_work_alloc(G16Key& K, int slot) {
     G16Key::Work& W = K.wk[slot];
     if (W.A) return ZKMI_OK;
     ZK_HIP(hipMalloc((void**)&W.w, (size_t)K.n_vars * 32));
-    for (uint32_t** p : {&W.A, &W.B, &W.C, &W.T}) ZK_HIP(hipMalloc((void**)p, (size_t)K.domain * 32));
+    // A | B | C contiguous and T three transforms long: the three chains run as batched NTT launches (ntt_dev_batch_dispatch)
+    ZK_HIP(hipMalloc((void**)&W.A, (size_t)K.domain * 32 * 3));
+    W.B = W.A + (size_t)K.domain * 8; W.C = W.B + (size_t)K.domain * 8;
+    ZK_HIP(hipMalloc((void**)&W.T, (size_t)K.domain * 32 * 3));
     for (auto& e : W.ev) ZK_HIP(hipEventCreate(&e));
     return ZKMI_OK;
 }
@@ -372,10 +375,16 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, co
         uint8_t one[32], inc[32];
         memcpy(one, Fr.one, 32);
         ZK_TRY(fr_coset_inc(K.curve, K.power, inc));
-        uint32_t* bufs[3] = {Wk.A, Wk.B, Wk.C};
-        for (int k = 0; k < 3; k++) {
-            ZK_TRY(ntt_dev_dispatch(K.curve, bufs[k], Wk.T, K.power, 1, nullptr, nullptr));
-            ZK_TRY(ntt_dev_dispatch(K.curve, Wk.T, bufs[k], K.power, 0, one, inc));
+        static const bool batch3 = !(getenv("ZKMI_NTT_BATCH") && atoi(getenv("ZKMI_NTT_BATCH")) == 0);
+        if (batch3 && K.power > 0) {
+            ZK_TRY(ntt_dev_batch_dispatch(K.curve, Wk.A, n, Wk.T, n, 3, K.power, 1, nullptr, nullptr));
+            ZK_TRY(ntt_dev_batch_dispatch(K.curve, Wk.T, n, Wk.A, n, 3, K.power, 0, one, inc));
+        } else {
+            uint32_t* bufs[3] = {Wk.A, Wk.B, Wk.C};
+            for (int k = 0; k < 3; k++) {
+                ZK_TRY(ntt_dev_dispatch(K.curve, bufs[k], Wk.T, K.power, 1, nullptr, nullptr));
+                ZK_TRY(ntt_dev_dispatch(K.curve, Wk.T, bufs[k], K.power, 0, one, inc));
+            }
         }
     }
     ZK_HIP(hipEventRecord(Wk.ev[ST_JOIN], st));

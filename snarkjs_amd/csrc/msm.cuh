@@ -605,8 +605,12 @@ k_msm_rowcol_wave(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, ui
     __shared__ uint32_t inf_s[T];
     const uint32_t C = 1u << cbits, R = 1u << rbits;
     const uint32_t t = threadIdx.x, sub = t & 63u;
-    const size_t gw = (size_t)blockIdx.x * (T / 64) + (t >> 6);            // sum index: ((job*W + w)*2 + kind)*C + i
     const size_t n_out = (size_t)rb.njobs * W * 2 * C;
+    // persistent blocks: a grid smaller than the number of sums strides over them. The Fq2 reduction runs on the auxiliary stream
+    // underneath the G1 accumulations and its blocks fill a CU's register file (256 VGPRs x 2 waves per SIMD): capped at a quarter of
+    // the chip it leaves the other CUs to the main stream instead of stalling it for the whole reduction
+    for (size_t blk = blockIdx.x; blk * (T / 64) < n_out; blk += gridDim.x) {
+    const size_t gw = blk * (T / 64) + (t >> 6);            // sum index: ((job*W + w)*2 + kind)*C + i
     const bool valid = gw < n_out;
     const uint32_t i = (uint32_t)(gw & (C - 1)), kind = (uint32_t)(gw >> cbits) & 1u;
     const size_t jw = gw >> (cbits + 1);
@@ -640,6 +644,8 @@ k_msm_rowcol_wave(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, ui
             __syncthreads();
         }
         if (valid && sub == 0) pt_store(out + gw * PW, acc);
+    }
+    __syncthreads();
     }
 }
 // k_msm_bitsums for Fq2 points with LDS-parked accumulators (see k_msm_rowcol_wave): one block per (array, k)

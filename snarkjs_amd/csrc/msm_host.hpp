@@ -258,7 +258,10 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
         const size_t lds_rc = (size_t)T * PW * 4;
         static bool rc_attr = false;
         if (!rc_attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rc)); rc_attr = true; }
-        hipLaunchKernelGGL((k_msm_rowcol_wave<F>), dim3((unsigned)((n_out + T / 64 - 1) / (T / 64))), dim3(T), lds_rc, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
+        size_t rc_blocks = (n_out + T / 64 - 1) / (T / 64);
+        static const int aux_cap = getenv("ZKMI_AUX_RC_BLOCKS") ? atoi(getenv("ZKMI_AUX_RC_BLOCKS")) : 128;
+        if (aux && aux_cap > 0) rc_blocks = std::min<size_t>(rc_blocks, (size_t)aux_cap);       // see k_msm_rowcol_wave: leave CUs to the main stream
+        hipLaunchKernelGGL((k_msm_rowcol_wave<F>), dim3((unsigned)rc_blocks), dim3(T), lds_rc, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
     } else {
     uint32_t *p0, *p1;
     ZK_TRY(ws_get("msm.rcpart0" + ax, n_out * L * PW * 4, (void**)&p0));

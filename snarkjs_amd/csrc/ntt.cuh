@@ -41,6 +41,7 @@ struct NttPassArgs {
     const uint32_t* LT;                   // local twiddles w_{Ni}^k, k < Ni/2
     const uint32_t* rowinc;               // per-pass pre-scale factors (Ni entries) or nullptr
     const uint32_t* scale;                // single constant applied on load (1/n for single-pass inverse) or nullptr
+    uint64_t in_bs, out_bs;               // batched launches (gridDim.y transforms of the same plan): words between the inputs / outputs of consecutive members
 };
 
 template <class C> ZK_DEV Fp<C> ntt_pow(const NttPassArgs& a, uint64_t e) {
@@ -107,6 +108,7 @@ template <class C, bool ROWMAJOR> ZK_DEV void ntt_tile_stages(uint4* p0, uint4* 
 template <class C> __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    in += (size_t)blockIdx.y * a.in_bs; out += (size_t)blockIdx.y * a.out_bs;
     const uint32_t l = a.l[a.pass], N = 1u << l, CH = 1u << a.log_ch, E = N << a.log_ch;
     uint4* p0 = lds4;                 // E
     uint4* p1 = p0 + E;               // E
@@ -153,6 +155,7 @@ k_ntt_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
 template <class C> __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass_last(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    in += (size_t)blockIdx.y * a.in_bs; out += (size_t)blockIdx.y * a.out_bs;
     const uint32_t l = a.l[a.pass], N = 1u << l, CH = 1u << a.log_ch, E = N << a.log_ch, PL = (N + 1) << a.log_ch;
     uint4* p0 = lds4;                 // (N+1)*CH
     uint4* p1 = p0 + PL;

@@ -89,13 +89,17 @@ template <class C> static int get_plan(int curve, unsigned L, int inverse, NttPl
     return ZKMI_OK;
 }
 
-template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, unsigned L, int inverse, const uint8_t* first, const uint8_t* inc) {
+// batch > 1: `batch` transforms of the same size in ONE launch per pass (gridDim.y): member k reads d_in + k*in_stride elements and writes
+// d_out + k*out_stride elements (Groth16's A, B, C chains: three times the blocks per launch, a third of the launches and launch tails)
+template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, unsigned L, int inverse, const uint8_t* first, const uint8_t* inc, unsigned batch = 1, size_t in_stride = 0,
+                                      size_t out_stride = 0) {
     Ctx& cx = ctx();
     const FrRoots& R = fr_roots<C>();
     if ((int)L > R.s) return fail(ZKMI_ERR_UNSUPPORTED, "fft: log2(n) exceeds the 2-adicity of Fr (the reference's n = 2^(s+1) coset case is not supported)");
     hipStream_t st = cx.stream;
     const size_t n = (size_t)1 << L;
     if ((first == nullptr) != (inc == nullptr)) return fail(ZKMI_ERR_INVALID, "fft: prescale needs both first and inc");
+    if (L == 0 && batch > 1) return fail(ZKMI_ERR_UNSUPPORTED, "fft: batched launches need n > 1");
     if (L == 0) {
         if (first) {
             HE x, f; std::vector<uint8_t> tmp(32);
@@ -148,7 +152,7 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
     }
     // work buffer for the in-place middle passes (the caller's input is never modified)
     uint32_t* work = nullptr;
-    if (p > 1) ZK_TRY(ws_get("ntt.work", n * 32, (void**)&work));
+    if (p > 1) ZK_TRY(ws_get("ntt.work", n * 32 * batch, (void**)&work));
     static bool attr = false;
     if (!attr) {
         ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_strided<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -169,7 +173,8 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
         const size_t lds = (2 * E + N + 2 * N) * 16;
         const unsigned tiles = (unsigned)(n >> (P->l[i] + a.log_ch));
         const uint32_t* src = (i == 0) ? (const uint32_t*)d_in : work;
-        hipLaunchKernelGGL((k_ntt_pass_strided<C>), dim3(tiles), dim3(NTT_THREADS), lds, st, src, work, a);
+        a.in_bs = (i == 0) ? (uint64_t)in_stride * 8 : (uint64_t)n * 8; a.out_bs = (uint64_t)n * 8;
+        hipLaunchKernelGGL((k_ntt_pass_strided<C>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, work, a);
     }
     {
         const int i = p - 1;
@@ -183,7 +188,8 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
         const uint32_t* src = (p == 1) ? (const uint32_t*)d_in : work;
         uint32_t* dst = (uint32_t*)d_out;
         if (p == 1 && d_in == d_out) { /* single tile: loads complete before stores */ }
-        hipLaunchKernelGGL((k_ntt_pass_last<C>), dim3(tiles), dim3(NTT_THREADS), lds, st, src, dst, a);
+        a.in_bs = (p == 1) ? (uint64_t)in_stride * 8 : (uint64_t)n * 8; a.out_bs = (uint64_t)out_stride * 8;
+        hipLaunchKernelGGL((k_ntt_pass_last<C>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, dst, a);
     }
     ZK_HIP(hipEventRecord(cx.ev1, st));
     ZK_HIP(hipGetLastError());
@@ -204,6 +210,13 @@ int ntt_power_tables(int curve, unsigned L, int inverse, const uint32_t** T_lo, 
 int ntt_dev_dispatch(int curve, const void* d_in, void* d_out, unsigned log_n, int inverse, const uint8_t* first, const uint8_t* inc) {
     if (curve == ZKMI_CURVE_BN128) return ntt_run<Bn254Fr>(curve, d_in, d_out, log_n, inverse, first, inc);
     if (curve == ZKMI_CURVE_BLS12381) return ntt_run<Bls12381Fr>(curve, d_in, d_out, log_n, inverse, first, inc);
+    return fail(ZKMI_ERR_INVALID, "unknown curve");
+}
+int ntt_dev_batch_dispatch(int curve, const void* d_in, size_t in_stride, void* d_out, size_t out_stride, unsigned batch, unsigned log_n, int inverse, const uint8_t* first,
+                           const uint8_t* inc) {
+    if (batch < 1 || batch > 16) return fail(ZKMI_ERR_INVALID, "fft: batch must be 1..16");
+    if (curve == ZKMI_CURVE_BN128) return ntt_run<Bn254Fr>(curve, d_in, d_out, log_n, inverse, first, inc, batch, in_stride, out_stride);
+    if (curve == ZKMI_CURVE_BLS12381) return ntt_run<Bls12381Fr>(curve, d_in, d_out, log_n, inverse, first, inc, batch, in_stride, out_stride);
     return fail(ZKMI_ERR_INVALID, "unknown curve");
 }
 

@@ -87,6 +87,9 @@ int download_pages(const void* d_src, size_t total_bytes, uint8_t* const* out_pt
 int msm_dev_dispatch(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t sb, uint8_t* out_jac);
 int gen_bases_dispatch(int curve, int group, size_t n, uint64_t f, uint64_t g, void* d_out);
 int ntt_dev_dispatch(int curve, const void* d_in, void* d_out, unsigned log_n, int inverse, const uint8_t* first, const uint8_t* inc);
+// `batch` transforms of one size per launch: member k at d_in + k*in_stride / d_out + k*out_stride ELEMENTS
+int ntt_dev_batch_dispatch(int curve, const void* d_in, size_t in_stride, void* d_out, size_t out_stride, unsigned batch, unsigned log_n, int inverse, const uint8_t* first,
+                           const uint8_t* inc);
 int apply_key_dev_dispatch(int curve, const void* d_in, void* d_out, size_t n, const uint8_t* first, const uint8_t* inc);
 int fr_batch_dev_dispatch(int curve, int op, const void* d_in, void* d_out, size_t n);
 int join_abc_dev_dispatch(int curve, const void* a, const void* b, const void* c, void* out, size_t n);

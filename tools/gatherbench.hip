@@ -17,6 +17,19 @@ template <int V> __global__ void k_gather(const uint4* __restrict__ tab, size_t 
     for (int i = 0; i < V; i++) { uint4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
     out[t] = acc;
 }
+// the same 64-byte gathers, but lane t only picks inside a window of `win_pts` points that slides with the lane index: what the MSM
+// would do if every bucket list were sorted by table row (all lanes in flight gather from the same ~64 MB row at the same time)
+__global__ void k_gather_window(const uint4* __restrict__ tab, size_t n_pts, size_t win_pts, uint32_t* __restrict__ out, uint32_t lanes) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    uint64_t h = (uint64_t)t * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    const size_t base = (size_t)((double)t / lanes * (double)(n_pts - win_pts));
+    const uint4* p = tab + (base + h % win_pts) * 4;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { uint4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    out[t] = acc;
+}
 __global__ void k_stream(const uint4* __restrict__ tab, uint32_t* __restrict__ out, size_t n_vec) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_vec) return;
@@ -36,6 +49,16 @@ int main() {
         hipEventElapsedTime(&ms, e0, e1); printf("k_gather<4>  %u lanes x 64 B  = %.1f MB  %.3f ms  %.1f GB/s\n", lanes, lanes * 64.0 / 1e6, ms, lanes * 64.0 / ms / 1e6);
         hipEventRecord(e0); k_gather<8><<<lanes / 256, 256>>>(tab, bytes / 128, out, lanes); hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1); printf("k_gather<8>  %u lanes x 128 B = %.1f MB  %.3f ms  %.1f GB/s\n", lanes, lanes * 128.0 / 1e6, ms, lanes * 128.0 / ms / 1e6);
+        for (size_t win_mb : {16, 64, 256}) {
+            const size_t n13 = ((size_t)832 << 20) / 64;      // a 2^20-point G1 window table: 13 rows x 64 MB
+            hipEventRecord(e0); k_gather_window<<<lanes / 256, 256>>>(tab, n13, (win_mb << 20) / 64, out, lanes); hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1); printf("k_gather_window %zu MB window over 832 MB: %.3f ms  %.1f GB/s\n", win_mb, ms, lanes * 64.0 / ms / 1e6);
+        }
+        {
+            const size_t n13 = ((size_t)832 << 20) / 64;
+            hipEventRecord(e0); k_gather<4><<<lanes / 256, 256>>>(tab, n13, out, lanes); hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1); printf("k_gather<4> random over 832 MB: %.3f ms  %.1f GB/s\n", ms, lanes * 64.0 / ms / 1e6);
+        }
         const size_t nv = ((size_t)1 << 30) / 16;
         hipEventRecord(e0); k_stream<<<(unsigned)(nv / 256), 256>>>(tab, out, nv); hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1); printf("k_stream     1 GiB coalesced   = %.1f MB  %.3f ms  %.1f GB/s\n", 1073.7, ms, 1073.7 / ms);
