@@ -23,9 +23,9 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# measured Montgomery-multiply ceilings of the chip (tools/fieldbench, profiles/r01_fieldbench.txt), Gmul/s: 256-bit (BN254 Fq)
-# and 384-bit (BLS12-381 Fq) moduli
-FIELD_MUL_PEAK_G = {"bn128": 126.0, "bls12381": 58.6}
+# measured Montgomery-multiply ceilings of the chip, Gmul/s, in the limb form the accumulation kernels of the curve use: BN254 Fq on
+# unsaturated 29-bit limbs (field29.cuh), BLS12-381 Fq on saturated 32-bit limbs (tools/fieldbench, profiles/r01_fieldbench.txt)
+FIELD_MUL_PEAK_G = {"bn128": 175.0, "bls12381": 58.6}      # bn128: 9 x 29-bit limbs (tools/fieldbench29, profiles/r02_fieldbench29.txt; 8 x 32-bit limbs: 130)
 
 
 def _oracle():
@@ -373,8 +373,9 @@ def main():
         acc = {k: float(np.mean(v)) for k, v in accum_ms.items()}
         fq = "Bn254Fq" if cid == 0 else "Bls12381Fq"
         b1, b2 = 2 * q8 + 32, 4 * q8 + 32                     # affine base + 32-byte scalar per term
-        names = {0: (f"k_msm_accum<Fp<{fq}>> (A)", b1), 1: (f"k_msm_accum<Fp<{fq}>> (B1)", b1), 2: (f"k_msm_accum<Fp2<{fq}>> (B2)", b2),
-                 3: (f"k_msm_accum<Fp<{fq}>> (C)", b1), 4: (f"k_msm_accum<Fp<{fq}>> (H)", b1)}
+        r29 = cid == 0 and os.environ.get("ZKMI_R29", "1") != "0"          # BN254: accumulation kernels on 29-bit limbs (msm29.cuh)
+        k1, k2 = (f"k_msm_accum29<{fq}>", f"k_msm_accum29_g2<{fq}>") if r29 else (f"k_msm_accum<Fp<{fq}>>", f"k_msm_accum<Fp2<{fq}>>")
+        names = {0: (f"{k1} (A)", b1), 1: (f"{k1} (B1)", b1), 2: (f"{k2} (B2)", b2), 3: (f"{k1} (C)", b1), 4: (f"{k1} (H)", b1)}
         dom = max(acc, key=lambda k: acc[k])
         units = {0: m, 1: m, 2: m, 3: m - zk["nPublic"] - 1, 4: zk["domainSize"]}[dom]
         alg_bytes = names[dom][1] * units                      # B/term (affine base + 32-B scalar) x terms
@@ -409,7 +410,7 @@ def main():
         fmuls = int(digits * units * density * (28 if dom == 2 else 10))    # 8M + 2S; in Fq2 a product is 3, a square 2 base-field products
         int_alu = {"unit": "Gmul/s", "field_muls": fmuls, "achieved": round(fmuls / (acc[dom] * 1e-3) / 1e9, 1), "peak": FIELD_MUL_PEAK_G[args.curve],
                    "frac": round(fmuls / (acc[dom] * 1e-3) / 1e9 / FIELD_MUL_PEAK_G[args.curve], 4),
-                   "note": "field multiplications of the mixed additions of this launch (digits x non-infinity terms x 10 in G1 / 28 in G2; the Fq2 kernel's ~70 additions per mixed addition are not counted) / launch time; peak = measured Montgomery-multiply ceiling of the chip for this curve's base field (tools/fieldbench, profiles/r01_fieldbench.txt: 256-bit 126, 384-bit 58.6 Gmul/s)"}
+                   "note": "field multiplications of the mixed additions of this launch (digits x non-infinity terms x 10 in G1 / 28 in G2; the Fq2 kernel's ~70 additions per mixed addition are not counted) / launch time; peak = measured Montgomery-multiply ceiling of the chip in the kernel's limb form (BN254: 9 x 29-bit limbs 175 Gmul/s, tools/fieldbench29; BLS12-381: 12 x 32-bit limbs 58.6 Gmul/s, tools/fieldbench); the G2 kernel computes an Fq2 product as two double products with one reduction each (4 multiplications + 2 reductions instead of Karatsuba's 3 + 3): it is counted at Karatsuba's 3"}
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),

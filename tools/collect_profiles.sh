@@ -14,9 +14,13 @@ timeout 600 python bench.py --workload plonk --log-n 20 --steps 8 --warmup 3 > $
 timeout 600 python bench.py --curve bls12381 --steps 8 --warmup 2 --no-cpu-baseline --no-napi-wall > $O/bench_bls12381_2p20.json 2>/dev/null
 timeout 300 python bench.py --workload fflonk --log-n 18 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_fflonk_2p18.json 2>/dev/null
 timeout 900 python bench.py --log-n 24 --steps 3 --warmup 1 --no-cpu-baseline --no-napi-wall > $O/bench_bn128_2p24.json 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-napi-wall > $O/bench_under_rocprof.json 2>/dev/null
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-napi-wall > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-napi-wall > /dev/null 2>&1
+# kernel durations are judged on the SERIAL command (--pipeline 1): with two proofs in flight kernels of different proofs share the chip and a
+# per-launch average would not be the kernel's own time (bench.py measures its live roofline time on serial proofs for the same reason)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python bench.py --steps 20 --warmup 3 --pipeline 1 --no-cpu-baseline --no-napi-wall > $O/bench_under_rocprof.json 2>/dev/null
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-napi-wall > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-napi-wall > /dev/null 2>&1
+tools/bin/fieldbench29 > $O/fieldbench29.txt 2>&1; tools/bin/maddbench29 >> $O/fieldbench29.txt 2>&1
+# second pass of the default line AFTER the PMC files exist is done by the caller (publish, then re-run bench.py so that roofline.traffic is filled)
 for f in bench bench_serial bench_sparse_b bench_plonk_2p20 bench_bls12381_2p20 bench_fflonk_2p18 bench_bn128_2p24; do python - "$O/$f.json" <<'PY'
 import json,sys
 try:

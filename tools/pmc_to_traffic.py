@@ -31,7 +31,7 @@ f, w = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
 # FETCH_SIZE tallies memory-side read requests at 64 B each (profiles/r02_gather_calibration.md): exact for the 64-byte gathers of
 # the G1 accumulation (one affine point per request), half the bytes for 128-byte requests (G2 gathers, coalesced wave reads)
 def fetch_factor(kernel):
-    return 1 if re.match(r"k_msm_accum<Fp<", kernel) else 2
+    return 1 if re.match(r"k_msm_accum(29<|<Fp<)", kernel) else 2
 out = {k: int(f[k] * 1024 * fetch_factor(k) + w.get(k, 0.0) * 1024) for k in f}
 if len(sys.argv) > 4:
     out["__workload__"] = sys.argv[4]

@@ -12,9 +12,11 @@ wl = json.loads(open(f"{src}/bench.json").read().strip().splitlines()[-1])["conf
 wl_tag = f"groth16:{wl['curve']}:2^{wl['log_n']}:b_zero_every={0 if wl['b_density'] == 1.0 else round(1 / (1 - wl['b_density']))}:{wl['witness']}"
 subprocess.check_call([sys.executable, "tools/pmc_to_traffic.py", f"{src}/pmc_fetch/f_counter_collection.csv", f"{src}/pmc_write/w_counter_collection.csv", f"{dst}/pmc_traffic.json", wl_tag])
 shutil.copy(f"{dst}/pmc_traffic.json", f"{dst}/{tag}_pmc_traffic.json")
+if os.path.exists(f"{src}/fieldbench29.txt"):
+    shutil.copy(f"{src}/fieldbench29.txt", f"{dst}/{tag}_fieldbench29.txt")
 rows = list(csv.DictReader(open(f"{src}/stats/bench_kernel_stats.csv")))
 with open(f"{dst}/{tag}_bench_kernel_stats_summary.md", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-napi-wall ({tag}, MI355X)\n\n"
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --pipeline 1 --no-cpu-baseline --no-napi-wall ({tag}, MI355X)\n\n"
             f"Full CSV: {tag}_bench_kernel_stats.csv. Includes the one-off set-up kernels (k_gen_geometric_bases, k_msm_precompute, k_coef_*, k_scan_u32) and the\n"
             "sub-metric runs (plain-base G1 MSM, NTT) after the timed region.\n\n| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n")
     for r in rows[:40]:
