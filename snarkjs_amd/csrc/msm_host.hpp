@@ -259,8 +259,10 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
         static bool rc_attr = false;
         if (!rc_attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rc)); rc_attr = true; }
         size_t rc_blocks = (n_out + T / 64 - 1) / (T / 64);
-        static const int aux_cap = getenv("ZKMI_AUX_RC_BLOCKS") ? atoi(getenv("ZKMI_AUX_RC_BLOCKS")) : 128;
-        if (aux && aux_cap > 0) rc_blocks = std::min<size_t>(rc_blocks, (size_t)aux_cap);       // see k_msm_rowcol_wave: leave CUs to the main stream
+        // see k_msm_rowcol_wave: on the auxiliary stream at most aux_cap sums (waves) are in flight, a quarter of the chip's CUs at two
+        // 256-lane blocks per CU; the rest of the CUs stay with the main stream
+        static const int aux_cap = getenv("ZKMI_AUX_RC_SUMS") ? atoi(getenv("ZKMI_AUX_RC_SUMS")) : 512;
+        if (aux && aux_cap > 0) rc_blocks = std::min<size_t>(rc_blocks, (size_t)aux_cap / (T / 64));
         hipLaunchKernelGGL((k_msm_rowcol_wave<F>), dim3((unsigned)rc_blocks), dim3(T), lds_rc, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
     } else {
     uint32_t *p0, *p1;
