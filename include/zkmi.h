@@ -266,6 +266,19 @@ int zkmi_group_batch_apply_key(int curve, int group, zkmi_pages in, uint8_t* con
                                const uint8_t* first, const uint8_t* inc);
 int zkmi_group_batch_apply_key_dev(int curve, int group, const void* d_in, void* d_out, size_t n, const uint8_t* first, const uint8_t* inc);
 
+/* curve.G1/G2.batchLEMtoU / batchUtoLEM / batchLEMtoC / batchCtoLEM (engine_batchconvert over wasmcurves' g1m_/g2m_batch*, min.js:1@128060;
+ * callers src/powersoftau_import.js:159,221, src/powersoftau_contribute.js:145,176, src/powersoftau_export_challenge.js:72,
+ * src/powersoftau_verify.js:358, src/mpc_applykey.js:64-70, src/zkey_export_bellman.js:36-83, src/zkey_new.js:103-115,373).
+ *   LEM = affine little-endian Montgomery (2*group*n8q bytes, all-zero = infinity), U = affine big-endian normal form (same size, Fq2 as
+ *   c1 || c0, all-zero = infinity), C = x alone big-endian (group*n8q bytes; first byte |= 0x80 when y > (p-1)/2, 0x40 = infinity).
+ * n points in, n points out. C_TO_LEM recovers y by a square root and returns ZKMI_ERR_INVALID when some x has no point on the curve. */
+#define ZKMI_CONV_LEM_TO_U 0
+#define ZKMI_CONV_U_TO_LEM 1
+#define ZKMI_CONV_LEM_TO_C 2
+#define ZKMI_CONV_C_TO_LEM 3
+int zkmi_group_convert(int curve, int group, int kind, zkmi_pages in, uint8_t* const* out_ptr, const size_t* out_len, int n_out_pages, size_t n);
+int zkmi_group_convert_dev(int curve, int group, int kind, const void* d_in, void* d_out, size_t n);
+
 /* ---- utilities --------------------------------------------------------------------------------------------------- */
 /* Synthetic base table of SURVEY.md §8d: P_i = (f*g^i mod r)*G written to device memory as affine Montgomery points
  * (what G.batchApplyKey(G repeated n, Fr.e(f), Fr.e(g)) returns).  For benchmarks and tests. */

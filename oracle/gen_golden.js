@@ -235,6 +235,26 @@ async function groupVectors(name, tag) {
     console.log(tag, 'group vectors done');
 }
 
+// Point-format conversions of the ceremony files (SURVEY 8 f4: G.batchLEMtoU / batchUtoLEM / batchLEMtoC / batchCtoLEM, callers
+// src/powersoftau_import.js:159, src/powersoftau_contribute.js:145,176, src/mpc_applykey.js:64-70, src/zkey_export_bellman.js:36-83):
+// bases P_i = 7*11^i*G with a point at infinity inside; the U and C byte strings the reference writes, and its round trips.
+async function convertVectors(name, tag) {
+    const curve = await snarkjs.curves.getCurveFromName(name), res = { curve: name };
+    for (const [gn, G, n] of [['g1', curve.G1, 96], ['g2', curve.G2, 48]]) {
+        const sG = G.F.n8 * 2, bases = await geomBases(curve, G, n);
+        bases.fill(0, 7 * sG, 8 * sG); bases.fill(0, (n - 1) * sG, n * sG);
+        const U = await G.batchLEMtoU(bases), C = await G.batchLEMtoC(bases);
+        const backU = await G.batchUtoLEM(U), backC = await G.batchCtoLEM(C);
+        fs.writeFileSync(path.join(OUT, `${tag}_conv_${gn}_n${n}_lem.bin`), bases);
+        fs.writeFileSync(path.join(OUT, `${tag}_conv_${gn}_n${n}_u.bin`), U);
+        fs.writeFileSync(path.join(OUT, `${tag}_conv_${gn}_n${n}_c.bin`), C);
+        res[gn] = { n, lem: sha(bases), u: sha(U), c: sha(C), u_roundtrip: sha(backU) === sha(bases), c_roundtrip: sha(backC) === sha(bases),
+                    u_bytes: U.byteLength, c_bytes: C.byteLength };
+    }
+    fs.writeFileSync(path.join(OUT, `${tag}_conv_vectors.json`), JSON.stringify(res, null, 1));
+    console.log(tag, 'conversion vectors done', JSON.stringify(res));
+}
+
 // Seeded PLONK fixtures: plonk.setup on two circuits of the reference's test tree with the same seeded ptau, then a seeded
 // plonk.prove whose 11 blinding draws (src/plonk_prove.js:224-227) and Fiat-Shamir challenges are recorded.
 async function plonkGolden() {
@@ -334,6 +354,7 @@ async function fflonkGolden() {
     if (what === 'all' || what === 'bn128') await kernelVectors('bn128', 'bn128');
     if (what === 'all' || what === 'bls12381') await kernelVectors('bls12381', 'bls12381');
     if (what === 'all' || what === 'group') { await groupVectors('bn128', 'bn128'); await groupVectors('bls12381', 'bls12381'); }
+    if (what === 'all' || what === 'conv') { await convertVectors('bn128', 'bn128'); await convertVectors('bls12381', 'bls12381'); }
     if (what === 'all' || what === 'groth16') await groth16Golden();
     if (what === 'all' || what === 'groth16bls') await groth16GoldenBls();
     if (what === 'all' || what === 'plonk') await plonkGolden();

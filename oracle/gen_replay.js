@@ -4,6 +4,7 @@
 // (G1/G2.multiExpAffine, Fr.fft/ifft/batchApplyKey/batchToMontgomery/batchFromMontgomery/batchInverse), while it runs
 //   * the seeded groth16.prove of tests/golden/groth16_bn128_n1024.{zkey,wtns}   (src/groth16_prove.js:64-101), and
 //   * the seeded plonk.prove   of tests/golden/plonk_bn128_n2048.{zkey,wtns}     (src/plonk_prove.js:247-313 and on),
+//   * a power-8 ceremony (powersOfTau new / contribute / preparePhase2) followed by plonk.setup and zKey.newZKey (setup-side callers),
 // with the reference's own WASM implementation doing the work. Per call: method, argument containers (Uint8Array or
 // ffjavascript BigBuffer) and bytes, result container and bytes (MSM results after toAffine: the Jacobian representative is
 // implementation-defined). tests/js/register_replay.js feeds the same calls through register() + the REAL N-API addon on the
@@ -45,6 +46,7 @@ async function record(tag, curve, files, run) {
             const rec = { m: `${oname}.${nm}`, args: [] };
             for (const x of a) {
                 if (x instanceof Uint8Array || isBig(x)) rec.args.push(Object.assign({ c: kind(x) }, refIn(flat(x))));
+                else if (typeof x === 'string' && (x === 'affine' || x === 'jacobian')) rec.args.push({ s: x });               // inType / outType of the group FFTs
                 else if (x === undefined || x === null || typeof x === 'string' || typeof x === 'object') rec.args.push(null);   // logger / log text
                 else rec.args.push({ v: String(x) });
             }
@@ -59,9 +61,11 @@ async function record(tag, curve, files, run) {
     };
     wrap(G1, 'G1', 'multiExpAffine', true); wrap(G2, 'G2', 'multiExpAffine', true);
     for (const nm of ['fft', 'ifft', 'batchApplyKey', 'batchToMontgomery', 'batchFromMontgomery', 'batchInverse']) wrap(Fr, 'Fr', nm, false);
+    // ceremony / setup side (SURVEY 8 f3, f4): group FFTs, G.batchApplyKey and the point-format conversions
+    for (const [G, gn] of [[G1, 'G1'], [G2, 'G2']]) for (const nm of ['fft', 'ifft', 'batchApplyKey', 'batchLEMtoU', 'batchUtoLEM', 'batchLEMtoC', 'batchCtoLEM']) wrap(G, gn, nm, false);
     const proof = await run();
     for (const [o, nm, f] of undo) o[nm] = f;
-    return { tag, calls, blobs, proof_sha256: sha(JSON.stringify(proof.proof)) };
+    return { tag, calls, blobs, proof_sha256: proof && proof.proof ? sha(JSON.stringify(proof.proof)) : null };
 }
 
 (async () => {
@@ -94,6 +98,23 @@ async function record(tag, curve, files, run) {
         for (const c of r.calls) for (const a of c.args) if (a && a.blob !== undefined) a.blob += base;
         for (const b of r.blobs) { allBlobs.push(b); base += b.length; }
         out.runs.push({ tag: r.tag, proof_sha256: r.proof_sha256, calls: r.calls });
+    }
+    {   // setup side: a power-8 ceremony (new -> contribute -> preparePhase2), then plonk.setup and groth16 zKey.newZKey of the reference's
+        // small PLONK test circuit over it (src/powersoftau_*.js, src/plonk_setup.js:323-403, src/zkey_new.js)
+        const mem = () => ({ type: 'mem' });
+        const r1cs = new Uint8Array(fs.readFileSync('/root/reference/test/plonk_circuit/circuit.r1cs'));
+        const r = await record('setup_bn128_p8', curve, {}, async () => {
+            const p0 = mem(), p1 = mem(), pf = mem(), zp = mem(), zg = mem();
+            await snarkjs.powersOfTau.newAccumulator(curve, 8, p0);
+            await snarkjs.powersOfTau.contribute(p0, p1, 'C1', 'Entropy1');
+            await snarkjs.powersOfTau.preparePhase2(p1, pf);
+            await snarkjs.plonk.setup(r1cs, pf, zp);
+            await snarkjs.zKey.newZKey(r1cs, pf, zg);
+            return null;
+        });
+        for (const c of r.calls) for (const a of c.args) if (a && a.blob !== undefined) a.blob += base;
+        for (const b of r.blobs) { allBlobs.push(b); base += b.length; }
+        out.runs.push({ tag: r.tag, proof_sha256: null, calls: r.calls });
     }
     const blob = Buffer.concat(allBlobs);
     out.blob_sha256 = sha(blob);

@@ -716,6 +716,111 @@ int orc_fr_dot(int curve, const uint8_t *a_mont, const uint8_t *w_plain, size_t 
     memcpy(out, acc, 32);
     return 0;
 }
+/* ---- point-format conversions of the ceremony files -------------------------------------------------------
+ * G.batchLEMtoU / batchUtoLEM / batchLEMtoC / batchCtoLEM (wasmcurves g1m_/g2m_batchLEMtoU ..., reached through ffjavascript's
+ * engine_batchconvert, min.js:1@128060; callers src/powersoftau_import.js:159,221, src/powersoftau_contribute.js:145,176,
+ * src/mpc_applykey.js:64-70, src/zkey_export_bellman.js:36-83, src/zkey_new.js:103-115). The byte formats are pinned by
+ * tests/golden/<curve>_conv_* (outputs of the reference, oracle/gen_golden.js convertVectors):
+ *   LEM  affine, little-endian, Montgomery; infinity = all zero
+ *   U    affine, BIG-endian, normal form, x || y; an Fq2 coordinate is written c1 || c0; infinity = all zero
+ *   C    x only, big-endian normal form (Fq2: c1 || c0); first byte |= 0x80 when y is "negative" (y > (p-1)/2; for Fq2 the
+ *        test is made on c1, on c0 when c1 = 0); infinity = 0x40 followed by zeros
+ * CtoLEM recovers y = sqrt(x^3 + b) (b = 3 / 4 on G1, 3/(9+u) / 4(1+u) on the twists) and picks the root whose sign matches the flag.
+ * kind: 0 LEMtoU, 1 UtoLEM, 2 LEMtoC, 3 CtoLEM. Returns -2 when a compressed x has no point on the curve. */
+static void be_store(uint8_t *out, const u64 *v, int n) { for (int i = 0; i < 8 * n; i++) out[i] = (uint8_t)(v[(8 * n - 1 - i) / 8] >> (8 * ((8 * n - 1 - i) % 8))); }
+static void be_load(u64 *v, const uint8_t *in, int n) { memset(v, 0, 8 * n); for (int i = 0; i < 8 * n; i++) v[(8 * n - 1 - i) / 8] |= (u64)in[i] << (8 * ((8 * n - 1 - i) % 8)); }
+static int fe_is_negative(const fld *F, const u64 *a_mont) {          /* normal form > (p-1)/2 */
+    u64 a[MAXL], half[MAXL];
+    fe_from_mont(F, a, a_mont);
+    for (int i = 0; i < F->n; i++) half[i] = (F->p[i] >> 1) | (i + 1 < F->n ? F->p[i + 1] << 63 : 0);
+    return bn_cmp(a, half, F->n) > 0;
+}
+static int e_is_negative(const ext *E, const u64 *a) {
+    const int n = E->F->n;
+    if (E->deg == 1) return fe_is_negative(E->F, a);
+    return bn_is_zero(a + n, n) ? fe_is_negative(E->F, a) : fe_is_negative(E->F, a + n);
+}
+static int fe_sqrt(const fld *F, u64 *r, const u64 *a) {              /* p = 3 mod 4 on both curves: a^((p+1)/4), checked */
+    u64 e[MAXL], one[MAXL] = {1}, t[MAXL];
+    bn_add(e, F->p, one, F->n);
+    for (int i = 0; i < F->n; i++) e[i] = (e[i] >> 2) | (i + 1 < F->n ? e[i + 1] << 62 : 0);
+    fe_pow(F, r, a, e, F->n);
+    fe_sqr(F, t, r);
+    return memcmp(t, a, 8 * F->n) == 0;
+}
+static int e_sqrt(const ext *E, u64 *r, const u64 *a) {
+    const fld *F = E->F; const int n = F->n;
+    if (E->deg == 1) return fe_sqrt(F, r, a);
+    /* norm method: (x0 + x1 u)^2 = a0 + a1 u  <=>  x0^2 = (a0 +- sqrt(a0^2 + a1^2)) / 2, x1 = a1 / (2 x0) */
+    u64 t0[MAXL], t1[MAXL], s[MAXL], d[MAXL], x0[MAXL], x1[MAXL], inv2[MAXL], two[MAXL], chk[MAXE];
+    if (bn_is_zero(a + n, n)) {
+        if (fe_sqrt(F, r, a)) { memset(r + n, 0, 8 * n); return 1; }
+        fe_neg(F, t0, a);
+        if (!fe_sqrt(F, r + n, t0)) return 0;
+        memset(r, 0, 8 * n); return 1;
+    }
+    fe_sqr(F, t0, a); fe_sqr(F, t1, a + n); fe_add(F, t0, t0, t1);
+    if (!fe_sqrt(F, s, t0)) return 0;
+    fe_add(F, two, F->one, F->one); fe_inv(F, inv2, two);
+    fe_add(F, d, a, s); fe_mul(F, d, d, inv2);
+    if (!fe_sqrt(F, x0, d)) { fe_sub(F, d, a, s); fe_mul(F, d, d, inv2); if (!fe_sqrt(F, x0, d)) return 0; }
+    fe_add(F, t0, x0, x0); fe_inv(F, t0, t0); fe_mul(F, x1, a + n, t0);
+    memcpy(r, x0, 8 * n); memcpy(r + n, x1, 8 * n);
+    e_sqr(E, chk, r);
+    return e_eq(E, chk, a);
+}
+static void curve_b(const curve_t *C, const ext *E, int curve, u64 *b) {   /* Montgomery form */
+    const fld *F = &C->Fq; const int n = F->n;
+    u64 k[MAXL] = {curve == 0 ? 3u : 4u}, km[MAXL];
+    fe_to_mont(F, km, k);
+    memset(b, 0, 8 * E->L);
+    if (E->deg == 1) { memcpy(b, km, 8 * n); return; }
+    if (curve == 0) {                                   /* 3 / (9 + u) */
+        u64 xi[MAXE], nine[MAXL] = {9}, inv[MAXE], three[MAXE];
+        fe_to_mont(F, xi, nine); memcpy(xi + n, F->one, 8 * n);
+        e_inv(E, inv, xi);
+        memset(three, 0, sizeof three); memcpy(three, km, 8 * n);
+        e_mul(E, b, three, inv);
+    } else { memcpy(b, km, 8 * n); memcpy(b + n, km, 8 * n); }          /* 4 (1 + u) */
+}
+int orc_group_convert(int curve, int group, int kind, const uint8_t *in, size_t n, uint8_t *out) {
+    curve_t *C = get_curve(curve); const ext E = make_ext(C, group); const fld *F = &C->Fq;
+    const int fn = F->n, nb = 8 * fn, sG = 2 * group * nb, sC = group * nb;
+    u64 b[MAXE];
+    curve_b(C, &E, curve, b);
+    int bad = 0;
+    #pragma omp parallel for schedule(static) reduction(|:bad)
+    for (size_t i = 0; i < n; i++) {
+        u64 P[2 * MAXE], t[MAXL];
+        if (kind == 0 || kind == 2) {
+            const uint8_t *src = in + i * sG; uint8_t *dst = out + i * (kind == 0 ? sG : sC);
+            memcpy(P, src, sG);
+            const int inf = bn_is_zero(P, 2 * E.L);
+            for (int c = 0; c < (kind == 0 ? 2 : 1); c++)
+                for (int k = 0; k < group; k++) { fe_from_mont(F, t, P + (c * group + k) * fn); be_store(dst + (c * group + (group - 1 - k)) * nb, t, fn); }
+            if (kind == 2) { if (inf) dst[0] |= 0x40; else if (e_is_negative(&E, P + E.L)) dst[0] |= 0x80; }
+        } else if (kind == 1) {
+            const uint8_t *src = in + i * sG;
+            for (int c = 0; c < 2; c++)
+                for (int k = 0; k < group; k++) { be_load(t, src + (c * group + (group - 1 - k)) * nb, fn); fe_to_mont(F, P + (c * group + k) * fn, t); }
+            memcpy(out + i * sG, P, sG);
+        } else {
+            uint8_t x[2 * 8 * MAXL];
+            memcpy(x, in + i * sC, sC);
+            const int flags = x[0] & 0xc0; x[0] &= 0x3f;
+            if (flags & 0x40) { memset(out + i * sG, 0, sG); continue; }
+            for (int k = 0; k < group; k++) { be_load(t, x + (group - 1 - k) * nb, fn); fe_to_mont(F, P + k * fn, t); }
+            u64 rhs[MAXE], y[MAXE];
+            e_sqr(&E, rhs, P); e_mul(&E, rhs, rhs, P); e_add(&E, rhs, rhs, b);
+            if (!e_sqrt(&E, y, rhs)) { bad |= 1; memset(out + i * sG, 0, sG); continue; }
+            if (e_is_negative(&E, y) != ((flags & 0x80) != 0)) e_neg(&E, y, y);
+            memcpy(P + E.L, y, 8 * E.L);
+            memcpy(out + i * sG, P, sG);
+        }
+    }
+    return bad ? -2 : 0;
+}
+
 #ifdef _OPENMP
 #include <omp.h>
 int orc_threads(void) { return omp_get_max_threads(); }

@@ -13,7 +13,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libzkmi.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
-UNITS = ["zkmi_api.hip", "ntt.hip", "msm_sort.hip", "msm_bn254.hip", "msm_bls12381.hip", "groth16.hip", "plonk.hip", "gfft.hip"]
+UNITS = ["zkmi_api.hip", "ntt.hip", "msm_sort.hip", "msm_bn254.hip", "msm_bls12381.hip", "groth16.hip", "plonk.hip", "gfft.hip", "gconv.hip"]
 
 
 def _stale(target, deps):
@@ -69,7 +69,7 @@ def build_addon(verbose=False):
     if not _stale(out, [src, LIB, os.path.join(os.path.dirname(HERE), "include", "zkmi.h")]):
         return out
     cmd = ["gcc", "-O2", "-shared", "-fPIC", "-Wall", "-DNODE_GYP_MODULE_NAME=zkmi_napi", "-I" + inc, src, "-o", out,
-           "-L" + HERE, "-lzkmi", "-ldl", "-Wl,-rpath,$ORIGIN/.."]
+           "-L" + HERE, "-lzkmi", "-ldl", "-lpthread", "-Wl,-rpath,$ORIGIN/.."]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -16,9 +16,13 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 static Ctx g_ctx;
 Ctx& ctx() { return g_ctx; }
 
+// Every entry point passes through here: a thread that has not called into the library before (e.g. a libuv pool thread of the
+// N-API addon's *Async functions) is bound to the context's device first — HIP's current device is per thread.
 int require_ctx() {
-    if (g_ctx.ready) return ZKMI_OK;
-    return zkmi_init(0);
+    static thread_local bool bound = false;
+    if (!g_ctx.ready) ZK_TRY(zkmi_init(0));
+    if (!bound) { ZK_HIP(hipSetDevice(g_ctx.device)); bound = true; }
+    return ZKMI_OK;
 }
 
 int select_pipe(int p) {

@@ -177,6 +177,32 @@ class _Group:
         zkmi.check(zkmi.lib().zkmi_group_batch_apply_key(self._c, self._g, pg.pages, op, ol, 1, n, zkmi.ptr(f), zkmi.ptr(g)))
         return out
 
+    def _convert(self, kind, buff):
+        """point-format conversions of the ceremony files (include/zkmi.h: zkmi_group_convert)"""
+        nb = _byte_length(buff)
+        in_sz = self.point_bytes // 2 if kind == zkmi.CONV_C_TO_LEM else self.point_bytes
+        out_sz = self.point_bytes // 2 if kind == zkmi.CONV_LEM_TO_C else self.point_bytes
+        if nb % in_sz:
+            raise ValueError("Invalid buffer size")
+        n = nb // in_sz
+        pg = zkmi.pages_of(buff)
+        out = np.empty(n * out_sz, np.uint8)
+        op, ol = (C.c_void_p * 1)(out.ctypes.data), (C.c_size_t * 1)(out.size)
+        zkmi.check(zkmi.lib().zkmi_group_convert(self._c, self._g, kind, pg.pages, op, ol, 1, n))
+        return out
+
+    def batchLEMtoU(self, buff):
+        return self._convert(zkmi.CONV_LEM_TO_U, buff)
+
+    def batchUtoLEM(self, buff):
+        return self._convert(zkmi.CONV_U_TO_LEM, buff)
+
+    def batchLEMtoC(self, buff):
+        return self._convert(zkmi.CONV_LEM_TO_C, buff)
+
+    def batchCtoLEM(self, buff):
+        return self._convert(zkmi.CONV_C_TO_LEM, buff)
+
     def toAffine(self, jac):
         j = zkmi.u8(jac)
         out = np.zeros(2 * self.F_n8, np.uint8)

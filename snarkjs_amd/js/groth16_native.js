@@ -61,7 +61,9 @@ function makeProver(snarkjs, options) {
                      alpha1, beta1, beta2, delta1, delta2 };
         }
         const r = curve.Fr.random(), s = curve.Fr.random();           // src/groth16_prove.js:103-104
-        const res = addon.groth16Prove(desc, key, witness, r, s);
+        // options.async !== false: the proof runs on a libuv pool thread (addon.groth16ProveAsync) and the event loop keeps turning
+        const res = (options.async !== false && typeof addon.groth16ProveAsync === "function") ? await addon.groth16ProveAsync(desc, key, witness, r, s)
+                                                                                               : addon.groth16Prove(desc, key, witness, r, s);
         if (fresh) resident.set(zkeyBytes, key);                      // only a key that actually loaded is remembered
         const proof = {
             pi_a: curve.G1.toObject(res.pi_a), pi_b: curve.G2.toObject(res.pi_b), pi_c: curve.G1.toObject(res.pi_c),

@@ -51,6 +51,9 @@ function register(curve, options) {
     const orig = {};
     const cacheBases = options.cacheBases !== false;      // keep base tables resident between calls (static zkey sections)
     const cacheMinPoints = options.cacheMinPoints === undefined ? 4096 : options.cacheMinPoints;
+    // options.async !== false: multiExpAffine / fft / ifft run on a libuv pool thread (addon.msmAsync / nttAsync, napi_create_async_work)
+    // and the Node event loop keeps turning meanwhile; `async: false` keeps the blocking calls.
+    const useAsync = options.async !== false && typeof addon.msmAsync === "function" && typeof addon.nttAsync === "function";
 
     for (const [gname, group] of [["G1", 1], ["G2", 2]]) {
         const G = curve[gname];
@@ -71,7 +74,8 @@ function register(curve, options) {
             if (sScalar * nPoints != buffScalars.byteLength) throw new Error("Scalar size does not match");
             if (logger) logger.debug(`Multiexp start: ${logText}: 0/${nPoints}`);
             const key = (cacheBases && nPoints >= cacheMinPoints) ? CACHE_ALLOWED : 0;
-            const res = addon.msm(cid, group, pagesOf(buffBases), pagesOf(buffScalars), nPoints, sScalar, key);
+            const res = useAsync ? await addon.msmAsync(cid, group, pagesOf(buffBases), pagesOf(buffScalars), nPoints, sScalar, key)
+                                 : addon.msm(cid, group, pagesOf(buffBases), pagesOf(buffScalars), nPoints, sScalar, key);
             if (logger) logger.debug(`Multiexp end: ${logText}: 0/${nPoints}`);
             return res;                                                  // Jacobian, Montgomery, 3*F.n8 bytes
         };
@@ -81,7 +85,8 @@ function register(curve, options) {
     // G.lagrangeEvaluations, which the reference implements on top of this very property for 2^k <= 2^Fr.s points) and
     // G.batchApplyKey (src/mpc_applykey.js:44-70). Only the affine -> affine forms the reference's callers use are taken over; any other
     // inType / outType combination, the array-of-elements form and sizes above 2^28 fall through to the WASM original.
-    // options.ceremony === false leaves these three methods alone.
+    // The point-format conversions G.batchLEMtoU / batchUtoLEM / batchLEMtoC / batchCtoLEM of the ceremony files are taken over as well.
+    // options.ceremony === false leaves all of these methods alone.
     if (options.ceremony !== false) {
         for (const [gname, group] of [["G1", 1], ["G2", 2]]) {
             const G = curve[gname], sG = G.F.n8 * 2;
@@ -97,6 +102,20 @@ function register(curve, options) {
                 return out;
             };
             if (typeof G.fft === "function") { G.fft = gfft(false, orig[gname].fft); G.ifft = gfft(true, orig[gname].ifft); }
+            // Point-format conversions of the ceremony files (helper `Ia`, min.js:1 before @185893: output has the input's own container
+            // type, "Invalid buffer size" when the length is not a whole number of points): LEM <-> U, LEM <-> C.
+            for (const [name, kind, sIn, sOut] of [["batchLEMtoU", 0, sG, sG], ["batchUtoLEM", 1, sG, sG], ["batchLEMtoC", 2, sG, sG / 2], ["batchCtoLEM", 3, sG / 2, sG]]) {
+                if (typeof G[name] !== "function") continue;
+                orig[gname][name] = G[name];
+                G[name] = async function (buff) {
+                    if (!isBuf(buff)) return orig[gname][name].apply(G, arguments);
+                    const n = Math.floor(buff.byteLength / sIn);
+                    if (n * sIn !== buff.byteLength) throw new Error("Invalid buffer size");
+                    const out = allocLike(buff, n * sOut);
+                    addon.groupConvert(cid, group, kind, pagesOf(buff), pagesOf(out), n);
+                    return out;
+                };
+            }
             if (typeof G.batchApplyKey === "function") {
                 G.batchApplyKey = async function (buff, first, inc, inType, outType) {
                     inType = inType || "affine"; outType = outType || "affine";
@@ -120,7 +139,8 @@ function register(curve, options) {
         const bits = log2(n);
         if ((1 << bits) != n) throw new Error("fft must be multiple of 2");
         const out = allocLikeSliced(buff, buff.byteLength);
-        addon.ntt(cid, pagesOf(buff), pagesOf(out), bits, inverse ? 1 : 0, null, null);
+        if (useAsync) await addon.nttAsync(cid, pagesOf(buff), pagesOf(out), bits, inverse ? 1 : 0, null, null);
+        else addon.ntt(cid, pagesOf(buff), pagesOf(out), bits, inverse ? 1 : 0, null, null);
         return out;
     }
     Fr.fft = function (buff, inType, outType, logger, loggerTxt) { return ntt(buff, false, orig.Fr.fft, arguments); };

@@ -10,6 +10,7 @@
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <node_api.h>
+#include <pthread.h>
 #include <stdbool.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -18,6 +19,11 @@
 #include "../../include/zkmi.h"
 
 #define MAX_PAGES 64
+
+/* The library serves one caller at a time (include/zkmi.h): every entry point is taken under this lock, on the main thread and on
+ * the libuv pool threads of the *Async functions alike. */
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+#define ZK_CALL(expr) ({ pthread_mutex_lock(&g_lock); int rc__ = (expr); pthread_mutex_unlock(&g_lock); rc__; })
 
 #define NAPI_OK(call)                                                              \
     do {                                                                           \
@@ -90,12 +96,84 @@ static napi_value new_u8(napi_env env, size_t n, uint8_t** data) {
     if (argc < N) { napi_throw_type_error(env, NULL, "zkmi: too few arguments"); return NULL; }
 #define BAD_ARG() do { napi_throw_type_error(env, NULL, "zkmi: bad argument"); return NULL; } while (0)
 
+/* ---- asynchronous calls (napi_create_async_work; SURVEY.md 8 b) -----------------------------------------------------------------
+ * msmAsync / nttAsync / groth16ProveAsync take the arguments of msm / ntt / groth16Prove and return a Promise: arguments are parsed
+ * on the main thread, the library call runs on a libuv pool thread (the Node event loop keeps turning), the promise is settled
+ * back on the main thread. Input and output buffers stay referenced until then; the caller must not write to them meanwhile. */
+typedef struct {
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref keep[8]; int n_keep;          /* arguments and result kept alive while the job runs */
+    napi_ref result;                       /* value the promise resolves to (NULL: undefined) */
+    int kind;                              /* 0 msm, 1 ntt, 2 groth16Prove */
+    int32_t curve, group, logn, inverse;
+    pages_t a, b;
+    double n, sb, key;
+    uint8_t first[32], inc[32]; bool has_first, has_inc;
+    zkmi_groth16_zkey zk; bool has_zk;
+    uint8_t *o0, *o1, *o2;
+    int rc; char err[400];
+} job_t;
+
+static int job_run(job_t* j) {
+    switch (j->kind) {
+    case 0: return zkmi_msm(j->curve, j->group, as_zk(&j->a), as_zk(&j->b), (size_t)j->n, (size_t)j->sb, (uint64_t)j->key, j->o0);
+    case 1: return zkmi_ntt(j->curve, as_zk(&j->a), (uint8_t* const*)j->b.ptr, j->b.len, j->b.n, (unsigned)j->logn, j->inverse, j->has_first ? j->first : NULL, j->has_inc ? j->inc : NULL);
+    default: return zkmi_groth16_prove(j->has_zk ? &j->zk : NULL, (uint64_t)j->key, j->a.ptr[0], j->a.len[0], j->first, j->inc, j->o0, j->o1, j->o2);
+    }
+}
+static void job_execute(napi_env env, void* data) {
+    (void)env;
+    job_t* j = (job_t*)data;
+    pthread_mutex_lock(&g_lock);
+    j->rc = job_run(j);
+    if (j->rc) { const char* e = zkmi_last_error(); snprintf(j->err, sizeof j->err, "zkmi error %d: %s", j->rc, e ? e : ""); }   /* thread-local: read it here */
+    pthread_mutex_unlock(&g_lock);
+}
+static void job_complete(napi_env env, napi_status status, void* data) {
+    job_t* j = (job_t*)data;
+    napi_value v = NULL, msg, err;
+    if (status == napi_ok && j->rc == 0) {
+        if (j->result) napi_get_reference_value(env, j->result, &v); else napi_get_undefined(env, &v);
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_create_string_utf8(env, status == napi_ok ? j->err : "zkmi: asynchronous call cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+    }
+    for (int i = 0; i < j->n_keep; i++) napi_delete_reference(env, j->keep[i]);
+    if (j->result) napi_delete_reference(env, j->result);
+    napi_delete_async_work(env, j->work);
+    free(j);
+}
+/* queue `j` (heap, filled by the caller); keeps argv[0..argc) and `result` alive; returns the promise */
+static napi_value job_queue(napi_env env, job_t* j, const char* name, napi_value* argv, size_t argc, napi_value result) {
+    napi_value promise, rname;
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) { free(j); napi_throw_error(env, NULL, "zkmi: cannot create a promise"); return NULL; }
+    for (size_t i = 0; i < argc && j->n_keep < 8; i++) {
+        napi_valuetype t;
+        if (napi_typeof(env, argv[i], &t) == napi_ok && t == napi_object && napi_create_reference(env, argv[i], 1, &j->keep[j->n_keep]) == napi_ok) j->n_keep++;
+    }
+    if (result) napi_create_reference(env, result, 1, &j->result);
+    napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &rname);
+    if (napi_create_async_work(env, NULL, rname, job_execute, job_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+        napi_value msg, err;
+        napi_create_string_utf8(env, "zkmi: cannot queue asynchronous work", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+        for (int i = 0; i < j->n_keep; i++) napi_delete_reference(env, j->keep[i]);
+        if (j->result) napi_delete_reference(env, j->result);
+        free(j);
+    }
+    return promise;
+}
+
 /* init(device) */
 static napi_value js_init(napi_env env, napi_callback_info info) {
     ARGS(1);
     int32_t dev;
     if (get_i32(env, argv[0], &dev)) BAD_ARG();
-    int rc = zkmi_init(dev);
+    int rc = ZK_CALL(zkmi_init(dev));
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
@@ -109,8 +187,8 @@ static napi_value js_version(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_create_string_utf8(env, zkmi_version(), NAPI_AUTO_LENGTH, &v));
     return v;
 }
-/* msm(curve, group, bases, scalars, n, scalarBytes, cacheKey) -> Uint8Array(3*group*n8q) */
-static napi_value js_msm(napi_env env, napi_callback_info info) {
+/* msm(curve, group, bases, scalars, n, scalarBytes, cacheKey) -> Uint8Array(3*group*n8q); msmAsync(...) -> Promise of the same */
+static napi_value msm_impl(napi_env env, napi_callback_info info, bool async) {
     ARGS(7);
     int32_t curve, group; double n, sb, key;
     pages_t b, s;
@@ -120,10 +198,18 @@ static napi_value js_msm(napi_env env, napi_callback_info info) {
     uint8_t* out;
     napi_value res = new_u8(env, (size_t)3 * group * (curve == ZKMI_CURVE_BN128 ? 32 : 48), &out);
     if (!res) BAD_ARG();
-    int rc = zkmi_msm(curve, group, as_zk(&b), as_zk(&s), (size_t)n, (size_t)sb, (uint64_t)key, out);
+    if (async) {
+        job_t* j = (job_t*)calloc(1, sizeof *j);
+        if (!j) BAD_ARG();
+        j->kind = 0; j->curve = curve; j->group = group; j->a = b; j->b = s; j->n = n; j->sb = sb; j->key = key; j->o0 = out;
+        return job_queue(env, j, "zkmi.msm", argv, 7, res);
+    }
+    int rc = ZK_CALL(zkmi_msm(curve, group, as_zk(&b), as_zk(&s), (size_t)n, (size_t)sb, (uint64_t)key, out));
     if (rc) return throw_zkmi(env, rc);
     return res;
 }
+static napi_value js_msm(napi_env env, napi_callback_info info) { return msm_impl(env, info, false); }
+static napi_value js_msm_async(napi_env env, napi_callback_info info) { return msm_impl(env, info, true); }
 static napi_value js_release_bases(napi_env env, napi_callback_info info) {
     ARGS(1);
     double key;
@@ -131,25 +217,36 @@ static napi_value js_release_bases(napi_env env, napi_callback_info info) {
     zkmi_release_bases((uint64_t)key);
     return NULL;
 }
-/* ntt(curve, in, out, logN, inverse, first|null, inc|null): out is preallocated by the caller (same container type) */
-static napi_value js_ntt(napi_env env, napi_callback_info info) {
+/* ntt(curve, in, out, logN, inverse, first|null, inc|null): out is preallocated by the caller (same container type);
+ * nttAsync(...) -> Promise<undefined>, `out` is filled when it resolves */
+static napi_value ntt_impl(napi_env env, napi_callback_info info, bool async) {
     ARGS(7);
     int32_t curve, logn, inverse;
     pages_t in, out;
     const uint8_t *first, *inc;
     if (get_i32(env, argv[0], &curve) || get_pages(env, argv[1], &in) || get_pages(env, argv[2], &out) || get_i32(env, argv[3], &logn) ||
         get_i32(env, argv[4], &inverse) || get_opt32(env, argv[5], &first) || get_opt32(env, argv[6], &inc)) BAD_ARG();
-    int rc = zkmi_ntt(curve, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (unsigned)logn, inverse, first, inc);
+    if (async) {
+        job_t* j = (job_t*)calloc(1, sizeof *j);
+        if (!j) BAD_ARG();
+        j->kind = 1; j->curve = curve; j->a = in; j->b = out; j->logn = logn; j->inverse = inverse;
+        if (first) { memcpy(j->first, first, 32); j->has_first = true; }
+        if (inc) { memcpy(j->inc, inc, 32); j->has_inc = true; }
+        return job_queue(env, j, "zkmi.ntt", argv, 7, NULL);
+    }
+    int rc = ZK_CALL(zkmi_ntt(curve, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (unsigned)logn, inverse, first, inc));
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
+static napi_value js_ntt(napi_env env, napi_callback_info info) { return ntt_impl(env, info, false); }
+static napi_value js_ntt_async(napi_env env, napi_callback_info info) { return ntt_impl(env, info, true); }
 /* frBatch(curve, op, in, out, n) */
 static napi_value js_fr_batch(napi_env env, napi_callback_info info) {
     ARGS(5);
     int32_t curve, op; double n;
     pages_t in, out;
     if (get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &op) || get_pages(env, argv[2], &in) || get_pages(env, argv[3], &out) || get_f64(env, argv[4], &n)) BAD_ARG();
-    int rc = zkmi_fr_batch(curve, op, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n);
+    int rc = ZK_CALL(zkmi_fr_batch(curve, op, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n));
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
@@ -161,7 +258,7 @@ static napi_value js_apply_key(napi_env env, napi_callback_info info) {
     const uint8_t *first, *inc;
     if (get_i32(env, argv[0], &curve) || get_pages(env, argv[1], &in) || get_pages(env, argv[2], &out) || get_f64(env, argv[3], &n) ||
         get_opt32(env, argv[4], &first) || get_opt32(env, argv[5], &inc) || !first || !inc) BAD_ARG();
-    int rc = zkmi_fr_batch_apply_key(curve, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n, first, inc);
+    int rc = ZK_CALL(zkmi_fr_batch_apply_key(curve, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n, first, inc));
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
@@ -172,7 +269,7 @@ static napi_value js_group_fft(napi_env env, napi_callback_info info) {
     pages_t in, out;
     if (get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &group) || get_pages(env, argv[2], &in) || get_pages(env, argv[3], &out) ||
         get_i32(env, argv[4], &logn) || get_i32(env, argv[5], &inverse)) BAD_ARG();
-    int rc = zkmi_group_fft(curve, group, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (unsigned)logn, inverse);
+    int rc = ZK_CALL(zkmi_group_fft(curve, group, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (unsigned)logn, inverse));
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
@@ -184,7 +281,18 @@ static napi_value js_group_apply_key(napi_env env, napi_callback_info info) {
     const uint8_t *first, *inc;
     if (get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &group) || get_pages(env, argv[2], &in) || get_pages(env, argv[3], &out) || get_f64(env, argv[4], &n) ||
         get_opt32(env, argv[5], &first) || get_opt32(env, argv[6], &inc) || !first || !inc) BAD_ARG();
-    int rc = zkmi_group_batch_apply_key(curve, group, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n, first, inc);
+    int rc = ZK_CALL(zkmi_group_batch_apply_key(curve, group, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n, first, inc));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+/* groupConvert(curve, group, kind, in, out, n): G.batchLEMtoU (0) / batchUtoLEM (1) / batchLEMtoC (2) / batchCtoLEM (3) */
+static napi_value js_group_convert(napi_env env, napi_callback_info info) {
+    ARGS(6);
+    int32_t curve, group, kind; double n;
+    pages_t in, out;
+    if (get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &group) || get_i32(env, argv[2], &kind) || get_pages(env, argv[3], &in) || get_pages(env, argv[4], &out) ||
+        get_f64(env, argv[5], &n)) BAD_ARG();
+    int rc = ZK_CALL(zkmi_group_convert(curve, group, kind, as_zk(&in), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n));
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
@@ -195,7 +303,7 @@ static napi_value js_join_abc(napi_env env, napi_callback_info info) {
     pages_t a, b, c, out;
     if (get_i32(env, argv[0], &curve) || get_pages(env, argv[1], &a) || get_pages(env, argv[2], &b) || get_pages(env, argv[3], &c) ||
         get_pages(env, argv[4], &out) || get_f64(env, argv[5], &n)) BAD_ARG();
-    int rc = zkmi_groth16_join_abc(curve, as_zk(&a), as_zk(&b), as_zk(&c), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n);
+    int rc = ZK_CALL(zkmi_groth16_join_abc(curve, as_zk(&a), as_zk(&b), as_zk(&c), (uint8_t* const*)out.ptr, out.len, out.n, (size_t)n));
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
@@ -210,7 +318,7 @@ static napi_value js_to_affine(napi_env env, napi_callback_info info) {
     uint8_t* out;
     napi_value res = new_u8(env, 2 * group * q, &out);
     if (!res) BAD_ARG();
-    int rc = zkmi_to_affine(curve, group, j.ptr[0], out);
+    int rc = ZK_CALL(zkmi_to_affine(curve, group, j.ptr[0], out));
     if (rc) return throw_zkmi(env, rc);
     return res;
 }
@@ -226,7 +334,7 @@ static int get_named_u32(napi_env env, napi_value obj, const char* name, uint32_
     napi_value v;
     return (napi_get_named_property(env, obj, name, &v) == napi_ok && napi_get_value_uint32(env, v, o) == napi_ok) ? 0 : -1;
 }
-static napi_value js_groth16_prove(napi_env env, napi_callback_info info) {
+static napi_value groth16_impl(napi_env env, napi_callback_info info, bool async) {
     ARGS(5);
     zkmi_groth16_zkey zk, *pzk = NULL;
     napi_valuetype t;
@@ -263,14 +371,24 @@ static napi_value js_groth16_prove(napi_env env, napi_callback_info info) {
         if (get_named_u8(env, argv[0], "alpha1", &d, &l1) || get_named_u8(env, argv[0], "beta1", &d, &l2) || get_named_u8(env, argv[0], "beta2", &d, &l3) ||
             get_named_u8(env, argv[0], "delta1", &d, &l4) || get_named_u8(env, argv[0], "delta2", &d, &l5) || l1 < 2 * q || l2 < 2 * q || l3 < 4 * q || l4 < 2 * q || l5 < 4 * q) BAD_ARG();
     }
-    int rc = zkmi_groth16_prove(pzk, (uint64_t)key, w.ptr[0], w.len[0], r, s, pa, pb, pc);
-    if (rc) return throw_zkmi(env, rc);
     NAPI_OK(napi_create_object(env, &res));
     NAPI_OK(napi_set_named_property(env, res, "pi_a", va));
     NAPI_OK(napi_set_named_property(env, res, "pi_b", vb));
     NAPI_OK(napi_set_named_property(env, res, "pi_c", vc));
+    if (async) {           /* the zkey sections are referenced through argv[0] (the descriptor object holds the typed arrays) */
+        job_t* j = (job_t*)calloc(1, sizeof *j);
+        if (!j) BAD_ARG();
+        j->kind = 2; j->key = key; j->a = w; j->o0 = pa; j->o1 = pb; j->o2 = pc;
+        memcpy(j->first, r, 32); memcpy(j->inc, s, 32);
+        if (pzk) { j->zk = zk; j->has_zk = true; }
+        return job_queue(env, j, "zkmi.groth16Prove", argv, 5, res);
+    }
+    int rc = ZK_CALL(zkmi_groth16_prove(pzk, (uint64_t)key, w.ptr[0], w.len[0], r, s, pa, pb, pc));
+    if (rc) return throw_zkmi(env, rc);
     return res;
 }
+static napi_value js_groth16_prove(napi_env env, napi_callback_info info) { return groth16_impl(env, info, false); }
+static napi_value js_groth16_prove_async(napi_env env, napi_callback_info info) { return groth16_impl(env, info, true); }
 static napi_value js_groth16_release(napi_env env, napi_callback_info info) {
     ARGS(1);
     double key;
@@ -316,7 +434,7 @@ static napi_value js_call(napi_env env, napi_callback_info info) {
             a[i - 1] = (uintptr_t)data;
         }
     }
-    int rc = fn(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
+    int rc = ZK_CALL(fn(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]));
     if (rc) return throw_zkmi(env, rc);
     napi_value z;
     NAPI_OK(napi_create_int32(env, 0, &z));
@@ -326,8 +444,8 @@ static napi_value js_call(napi_env env, napi_callback_info info) {
 static napi_value module_init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"init", js_init}, {"deviceCount", js_device_count}, {"version", js_version}, {"msm", js_msm}, {"releaseBases", js_release_bases},
-        {"ntt", js_ntt}, {"frBatch", js_fr_batch}, {"applyKey", js_apply_key}, {"joinABC", js_join_abc}, {"toAffine", js_to_affine}, {"groupFft", js_group_fft}, {"groupApplyKey", js_group_apply_key},
-        {"groth16Prove", js_groth16_prove}, {"groth16Release", js_groth16_release}, {"call", js_call},
+        {"ntt", js_ntt}, {"frBatch", js_fr_batch}, {"applyKey", js_apply_key}, {"joinABC", js_join_abc}, {"toAffine", js_to_affine}, {"groupFft", js_group_fft}, {"groupApplyKey", js_group_apply_key}, {"groupConvert", js_group_convert},
+        {"groth16Prove", js_groth16_prove}, {"groth16ProveAsync", js_groth16_prove_async}, {"msmAsync", js_msm_async}, {"nttAsync", js_ntt_async}, {"groth16Release", js_groth16_release}, {"call", js_call},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

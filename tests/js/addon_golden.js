@@ -61,12 +61,28 @@ for (const [tag, cid] of [["bn128", 0], ["bls12381", 1]]) {
             check(`${tag} G${g}.batchApplyKey`, sha(o2) === gv[gn].applykey_3_5);
         }
     }
+    // point-format conversions of the ceremony files against the reference's vectors (oracle/gen_golden.js convertVectors)
+    {
+        const cv = JSON.parse(fs.readFileSync(path.join(GOLD, `${tag}_conv_vectors.json`)));
+        for (const [gn, g] of [["g1", 1], ["g2", 2]]) {
+            const n = cv[gn].n, sG = 2 * g * n8q, rd = (k) => new Uint8Array(fs.readFileSync(path.join(GOLD, `${tag}_conv_${gn}_n${n}_${k}.bin`)));
+            const lem = rd("lem"), U = rd("u"), Cc = rd("c");
+            let o2 = new Uint8Array(n * sG); addon.groupConvert(cid, g, 0, lem, o2, n);
+            check(`${tag} G${g}.batchLEMtoU`, eq(o2, U));
+            o2 = new Uint8Array(n * sG); addon.groupConvert(cid, g, 1, [U.subarray(0, 3 * sG), U.subarray(3 * sG)], o2, n);
+            check(`${tag} G${g}.batchUtoLEM (paged input)`, eq(o2, lem));
+            o2 = new Uint8Array(n * sG / 2); addon.groupConvert(cid, g, 2, lem, o2, n);
+            check(`${tag} G${g}.batchLEMtoC`, eq(o2, Cc));
+            o2 = new Uint8Array(n * sG); addon.groupConvert(cid, g, 3, Cc, o2, n);
+            check(`${tag} G${g}.batchCtoLEM`, eq(o2, lem));
+        }
+    }
     let threw = false;
     try { addon.msm(cid, 1, raw(tag, "g1_bases"), x.subarray(0, 1024 * 32 - 1), 1024, 32, 0); } catch (e) { threw = /Scalar size does not match/.test(e.message); }
     check(`${tag} scalar size error`, threw);
 }
 // fused Groth16 prover against the reference's seeded proof (SURVEY.md Appendix C.3)
-{
+(async () => {
     const g = JSON.parse(fs.readFileSync(path.join(GOLD, "groth16_bn128_n1024.json")));
     const zkey = new Uint8Array(fs.readFileSync(path.join(GOLD, "groth16_bn128_n1024.zkey")));
     const wtns = new Uint8Array(fs.readFileSync(path.join(GOLD, "groth16_bn128_n1024.wtns")));
@@ -98,7 +114,29 @@ for (const [tag, cid] of [["bn128", 0], ["bls12381", 1]]) {
     check("groth16Prove == reference proof (sha256 of JSON)", sha(JSON.stringify(proof)) === g.proof_sha256);
     const again = addon.groth16Prove(0, 7, ws[2], hexb(g.r_mont), hexb(g.s_mont));       // resident key
     check("groth16Prove with resident key", eq(again.pi_a, res.pi_a) && eq(again.pi_b, res.pi_b) && eq(again.pi_c, res.pi_c));
+    // asynchronous variants (napi_create_async_work): same results, the event loop keeps turning while they run, errors reject
+    await (async () => {
+        let ticks = 0;
+        const timer = setInterval(() => { ticks++; }, 0);
+        const x = iota(1024), bases = raw("bn128", "g1_bases"), o1 = new Uint8Array(1024 * 32);
+        const pr = addon.groth16ProveAsync(0, 7, ws[2], hexb(g.r_mont), hexb(g.s_mont)), pm = addon.msmAsync(0, 1, bases, x, 1024, 32, 0),
+              pn = addon.nttAsync(0, x, o1, 10, 0, null, null);
+        check("async calls return promises", pr instanceof Promise && pm instanceof Promise && pn instanceof Promise);
+        const [ar, am] = await Promise.all([pr, pm, pn]);
+        check("groth16ProveAsync == groth16Prove", eq(ar.pi_a, res.pi_a) && eq(ar.pi_b, res.pi_b) && eq(ar.pi_c, res.pi_c));
+        check("msmAsync == reference", eq(addon.toAffine(0, 1, am), raw("bn128", "g1_msm_affine")));
+        check("nttAsync == reference", eq(o1, raw("bn128", "fft")));
+        const big = new Uint8Array(32 << 18), ob = new Uint8Array(32 << 18);
+        for (let i = 0; i < (1 << 18); i++) big[32 * i] = i & 255;
+        const t0 = ticks;
+        await Promise.all([0, 1, 2, 3].map(() => addon.nttAsync(0, big, ob, 18, 0, null, null)));
+        check(`event loop turned while async calls ran (${ticks - t0} timer ticks)`, ticks - t0 >= 1);
+        let rejected = false;
+        try { await addon.msmAsync(0, 1, bases, x.subarray(0, 1024 * 32 - 1), 1024, 32, 0); } catch (e) { rejected = /Scalar size does not match/.test(e.message); }
+        check("msmAsync rejects with the library's message", rejected);
+        clearInterval(timer);
+    })();
     addon.groth16Release(7);
-}
-console.log(fails ? `${fails} FAILED` : "ALL OK");
-process.exit(fails ? 1 : 0);
+    console.log(fails ? `${fails} FAILED` : "ALL OK");
+    process.exit(fails ? 1 : 0);
+})().catch((e) => { console.error(e); process.exit(1); });

@@ -22,6 +22,7 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
     const saved = { g1: curve.G1.multiExpAffine.bind(curve.G1), g2: curve.G2.multiExpAffine.bind(curve.G2), fft: curve.Fr.fft.bind(curve.Fr), ifft: curve.Fr.ifft.bind(curve.Fr),
                     gfft: { 1: [curve.G1.fft.bind(curve.G1), curve.G1.ifft.bind(curve.G1)], 2: [curve.G2.fft.bind(curve.G2), curve.G2.ifft.bind(curve.G2)] },
                     gak: { 1: curve.G1.batchApplyKey.bind(curve.G1), 2: curve.G2.batchApplyKey.bind(curve.G2) },
+                    conv: { 1: ["batchLEMtoU", "batchUtoLEM", "batchLEMtoC", "batchCtoLEM"].map((nm) => curve.G1[nm].bind(curve.G1)), 2: ["batchLEMtoU", "batchUtoLEM", "batchLEMtoC", "batchCtoLEM"].map((nm) => curve.G2[nm].bind(curve.G2)) },
                     ak: curve.Fr.batchApplyKey.bind(curve.Fr), tm: curve.Fr.batchToMontgomery.bind(curve.Fr), fm: curve.Fr.batchFromMontgomery.bind(curve.Fr), inv: curve.Fr.batchInverse.bind(curve.Fr) };
     const calls = {};
     const note = (k) => { calls[k] = (calls[k] || 0) + 1; };
@@ -35,12 +36,13 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
         ntt(cid, inp, out, logn, inverse) { note(inverse ? "ifft" : "fft"); out.__p = (inverse ? saved.ifft : saved.fft)(cat(inp)).then((r) => spread(r, out)); },
         groupFft(cid, group, inp, out, logn, inverse) { note("gfft" + group); out.__p = saved.gfft[group][inverse ? 1 : 0](cat(inp), "affine", "affine").then((r) => spread(r, out)); },
         groupApplyKey(cid, group, inp, out, n, first, inc) { note("gak" + group); out.__p = saved.gak[group](cat(inp), first, inc).then((r) => spread(r, out)); },
+        groupConvert(cid, group, kind, inp, out, n) { note("conv" + group + kind); out.__p = saved.conv[group][kind](cat(inp)).then((r) => spread(r, out)); },
         applyKey(cid, inp, out, n, first, inc) { note("applyKey"); out.__p = saved.ak(cat(inp), first, inc).then((r) => spread(r, out)); },
         frBatch(cid, op, inp, out, n) { note("batch" + op); out.__p = [saved.tm, saved.fm, saved.inv][op](cat(inp)).then((r) => spread(r, out)); },
     };
     register(curve, { addon: mock });
     // the mock fills its outputs asynchronously: wrap every patched method so that it awaits that work
-    for (const [obj, names] of [[curve.G1, ["multiExpAffine", "fft", "ifft", "batchApplyKey"]], [curve.G2, ["multiExpAffine", "fft", "ifft", "batchApplyKey"]], [curve.Fr, ["fft", "ifft", "batchApplyKey", "batchToMontgomery", "batchFromMontgomery", "batchInverse"]]]) {
+    for (const [obj, names] of [[curve.G1, ["multiExpAffine", "fft", "ifft", "batchApplyKey", "batchLEMtoU", "batchUtoLEM", "batchLEMtoC", "batchCtoLEM"]], [curve.G2, ["multiExpAffine", "fft", "ifft", "batchApplyKey", "batchLEMtoU", "batchUtoLEM", "batchLEMtoC", "batchCtoLEM"]], [curve.Fr, ["fft", "ifft", "batchApplyKey", "batchToMontgomery", "batchFromMontgomery", "batchInverse"]]]) {
         for (const nm of names) {
             const f = obj[nm];
             obj[nm] = async function () { const r = await f.apply(this, arguments); const c = (r instanceof Uint8Array) ? r : (r && r.buffers); if (c && c.__p) { await c.__p; delete c.__p; } return r; };
@@ -68,6 +70,12 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
         check("G1.ifft affine -> affine through register.js", sha(await curve.G1.ifft(bases, "affine", "affine")) === sha(await saved.gfft[1][1](bases, "affine", "affine")) && calls.gfft1 === 1);
         check("G1.lagrangeEvaluations reaches the patched G1.ifft", sha(await curve.G1.lagrangeEvaluations(bases, "affine", "affine")) === sha(await saved.gfft[1][1](bases, "affine", "affine")) && calls.gfft1 === 2);
         check("G1.batchApplyKey through register.js", sha(await curve.G1.batchApplyKey(bases, curve.Fr.e(3), curve.Fr.e(5))) === sha(await saved.gak[1](bases, curve.Fr.e(3), curve.Fr.e(5))) && calls.gak1 === 1);
+        const U = await curve.G1.batchLEMtoU(bases), Cc = await curve.G1.batchLEMtoC(bases);
+        check("G1.batchLEMtoU / batchLEMtoC through register.js", U instanceof Uint8Array && sha(U) === sha(await saved.conv[1][0](bases)) && Cc.byteLength === 64 * 32 && sha(Cc) === sha(await saved.conv[1][2](bases)) && calls.conv10 === 1 && calls.conv12 === 1);
+        check("G1.batchUtoLEM / batchCtoLEM through register.js", sha(await curve.G1.batchUtoLEM(U)) === sha(bases) && sha(await curve.G1.batchCtoLEM(Cc)) === sha(bases) && calls.conv11 === 1 && calls.conv13 === 1);
+        let bad = false;
+        try { await curve.G1.batchLEMtoU(new Uint8Array(65)); } catch (e) { bad = e.message === "Invalid buffer size"; }
+        check("batchLEMtoU error message", bad);
         const before = calls.gfft1;
         const jac = await curve.G1.fft(bases, "affine", "jacobian");
         check("G1.fft affine -> jacobian falls through to the WASM original", jac.byteLength === 64 * 96 && calls.gfft1 === before);

@@ -1,6 +1,8 @@
 // tests/js/register_replay.js — GPU test of the drop-in path in ONE piece short of the bundle itself: snarkjs_amd/js/register.js
 // applied to a curve object, driving the REAL N-API addon (zkmi_napi.node -> libzkmi.so), fed with exactly the bulk calls the real
-// snarkjs makes during its seeded groth16.prove (n = 1024) and plonk.prove (n = 2048): tests/golden/replay_bn128.{json,bin},
+// snarkjs makes during its seeded groth16.prove (n = 1024) and plonk.prove (n = 2048), and during a power-8 ceremony (powersOfTau new /
+// contribute / preparePhase2: G.batchApplyKey, G.ifft, batchLEMtoU / LEMtoC) followed by plonk.setup and zKey.newZKey (the setup-side
+// callers, src/plonk_setup.js:323-403): tests/golden/replay_bn128.{json,bin},
 // recorded from the reference bundle by oracle/gen_replay.js (the bundle cannot travel to the GPU box). Checked per call: result
 // container type (Uint8Array vs BigBuffer, the rule downstream snarkjs code depends on), byte-exact Fr results, MSM results as
 // affine points; chained inputs use OUR earlier outputs. A second pass allows the resident-base cache for every MSM, which sends
@@ -49,10 +51,14 @@ addon.init(0);
 
 function makeCurve() {           // the part of ffjavascript's curve object register.js touches
     const nope = (nm) => async function () { throw new Error(nm + ": the WASM original must not be reached in this test"); };
-    const Fr = { n8: 32, e: (x) => x };
+    const Fr = { n8: 32, s: 28, e: (x) => x };
     for (const nm of ["fft", "ifft", "batchApplyKey", "batchToMontgomery", "batchFromMontgomery", "batchInverse"]) Fr[nm] = nope("Fr." + nm);
-    return { name: "bn128", Fr, G1: { F: { n8: 32 }, zero: new Uint8Array(96), multiExpAffine: nope("G1.multiExpAffine") },
-             G2: { F: { n8: 64 }, zero: new Uint8Array(192), multiExpAffine: nope("G2.multiExpAffine") } };
+    const group = (gn, n8, zlen) => {
+        const G = { F: { n8 }, zero: new Uint8Array(zlen) };
+        for (const nm of ["multiExpAffine", "fft", "ifft", "batchApplyKey", "batchLEMtoU", "batchUtoLEM", "batchLEMtoC", "batchCtoLEM"]) G[nm] = nope(gn + "." + nm);
+        return G;
+    };
+    return { name: "bn128", Fr, G1: group("G1", 32, 96), G2: group("G2", 64, 192) };
 }
 
 async function replay(passName, options) {
@@ -74,6 +80,7 @@ async function replay(passName, options) {
             const args = c.args.map((a) => {
                 if (a === null) return undefined;
                 if (a.v !== undefined) return Number(a.v);
+                if (a.s !== undefined) return a.s;                       // inType / outType of the group FFTs
                 const b = bytesOf(a);
                 if (a.c === "big") { const bb = new BigBuffer(b.byteLength); bb.set(b, 0); return bb; }
                 return b;
@@ -100,7 +107,7 @@ async function replay(passName, options) {
 (async () => {
     await replay("plain", { cacheBases: false });
     addon.releaseBases(0);
-    await replay("resident-bases pass 1", { cacheMinPoints: 1 });          // first sight of every base buffer
+    await replay("resident-bases pass 1", { cacheMinPoints: 1, async: false });   // first sight of every base buffer; blocking addon calls (the other passes use msmAsync / nttAsync)
     await replay("resident-bases pass 2", { cacheMinPoints: 1 });          // tables get built, prefixes re-use them
     await replay("resident-bases pass 3", { cacheMinPoints: 1 });          // everything served from resident tables
     addon.releaseBases(0);

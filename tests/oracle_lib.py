@@ -160,6 +160,21 @@ def group_apply_key(curve, group, pts, first, inc):
     return out
 
 
+CONVERT_KINDS = {"LEMtoU": 0, "UtoLEM": 1, "LEMtoC": 2, "CtoLEM": 3}
+
+
+def group_convert(curve, group, kind, buf):
+    """G.batchLEMtoU / batchUtoLEM / batchLEMtoC / batchCtoLEM (oracle/zk_oracle.c: orc_group_convert)"""
+    buf = _u8(buf)
+    k, full, half = CONVERT_KINDS[kind], 2 * group * n8q(curve), group * n8q(curve)
+    n = buf.size // (half if k == 3 else full)
+    out = np.zeros(n * (half if k == 2 else full), np.uint8)
+    rc = lib().orc_group_convert(curve, group, k, _p(buf), C.c_size_t(n), _p(out))
+    if rc:
+        raise ValueError("compressed point is not on the curve")
+    return out
+
+
 def vec_op(curve, op, a, b):
     """element-wise Fr add / sub / mul (op = "add" | "sub" | "mul"), Montgomery in and out"""
     a, b = _u8(a), _u8(b)

@@ -392,6 +392,48 @@ def test_group_fft_and_apply_key(zk, golden_dir, name):
     assert np.array_equal(cv.G1.ifft(cv.G1.fft(big)), big)
 
 
+@pytest.mark.parametrize("name", CURVES)
+def test_point_format_conversions(zk, golden_dir, name):
+    """G.batchLEMtoU / batchUtoLEM / batchLEMtoC / batchCtoLEM on the device vs the reference's byte strings (oracle/gen_golden.js
+    convertVectors: points at infinity inside), vs the C restatement on 2^12 points, compress -> decompress round trip at 2^16 (G1) / 2^14 (G2), a
+    compressed x off the curve refused, "Invalid buffer size" on ragged input."""
+    from snarkjs_amd import zkmi
+    c, cv = O.CURVE_ID[name], curve_of(zk, name)
+    g = json.load(open(os.path.join(golden_dir, f"{name}_conv_vectors.json")))
+    q8 = O.n8q(c)
+    for gn, group, G in (("g1", 1, cv.G1), ("g2", 2, cv.G2)):
+        v, pb = g[gn], 2 * group * q8
+        rd = lambda k: np.frombuffer(open(os.path.join(golden_dir, f"{name}_conv_{gn}_n{v['n']}_{k}.bin"), "rb").read(), np.uint8)
+        lem, U, Cc = rd("lem"), rd("u"), rd("c")
+        assert bytes(G.batchLEMtoU(lem)) == bytes(U) and bytes(G.batchLEMtoC(lem)) == bytes(Cc)
+        assert bytes(G.batchUtoLEM(U)) == bytes(lem) and bytes(G.batchCtoLEM(Cc)) == bytes(lem)
+        assert bytes(G.batchLEMtoU([lem[:5 * pb], lem[5 * pb:]])) == bytes(U)            # paged ("BigBuffer") input
+        assert G.batchLEMtoU(lem[:0]).size == 0
+        with pytest.raises(ValueError):
+            G.batchLEMtoU(lem[:pb + 1])
+        m = 1 << 12
+        B = O.geom_bases(c, group, 64)
+        B = G.batchApplyKey(np.tile(B, m // 64), O.fr_e(c, 5), O.fr_e(c, 7))              # 2^12 distinct points
+        B[3 * pb:4 * pb] = 0
+        for kind, fn in (("LEMtoU", G.batchLEMtoU), ("LEMtoC", G.batchLEMtoC)):
+            assert np.array_equal(fn(B), O.group_convert(c, group, kind, B)), kind
+        assert np.array_equal(G.batchUtoLEM(O.group_convert(c, group, "LEMtoU", B)), B)
+        assert np.array_equal(G.batchCtoLEM(O.group_convert(c, group, "LEMtoC", B)), B)
+        big = 1 << (16 if group == 1 else 14)
+        P = G.batchApplyKey(np.tile(B[:64 * pb], big // 64), O.fr_e(c, 11), O.fr_e(c, 13))
+        comp = G.batchLEMtoC(P)
+        assert comp.size == P.size // 2 and np.array_equal(G.batchCtoLEM(comp), P) and np.array_equal(G.batchUtoLEM(G.batchLEMtoU(P)), P)
+        bad, refused = Cc.copy(), False
+        for delta in range(1, 40):
+            bad[group * q8 - 1] = (int(Cc[group * q8 - 1]) + delta) & 0xff
+            try:
+                G.batchCtoLEM(bad)
+            except zkmi.ZkmiError as e:
+                refused = "not on the curve" in str(e)
+                break
+        assert refused
+
+
 def test_groth16_malformed_inputs_fail_cleanly(zk, golden_dir):
     """Truncated sections / witness and key-number re-use must fail with an error, never read past the caller's buffers or prove
     against another circuit's key (include/zkmi.h: zkmi_groth16_zkey *_len fields, zkmi_groth16_prove witness_len)."""

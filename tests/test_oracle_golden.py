@@ -273,3 +273,29 @@ def test_group_fft_and_apply_key_golden(golden_dir, name):
         for k in (1, 2, 4, 32):
             assert sha(O.group_fft(c, group, bases[:k * pb])) == v[f"fft_n{k}"]
             assert sha(O.group_fft(c, group, bases[:k * pb], inverse=True)) == v[f"ifft_n{k}"]
+
+
+@pytest.mark.parametrize("name", ["bn128", "bls12381"])
+def test_point_format_conversions_golden(golden_dir, name):
+    """G.batchLEMtoU / batchUtoLEM / batchLEMtoC / batchCtoLEM of the reference (oracle/gen_golden.js convertVectors: 96 G1 /
+    48 G2 points with two points at infinity inside) vs the C restatement, both directions; a compressed x off the curve is refused."""
+    c = O.CURVE_ID[name]
+    g = json.load(open(os.path.join(golden_dir, f"{name}_conv_vectors.json")))
+    for gn, group in (("g1", 1), ("g2", 2)):
+        v = g[gn]
+        rd = lambda k: np.frombuffer(open(os.path.join(golden_dir, f"{name}_conv_{gn}_n{v['n']}_{k}.bin"), "rb").read(), np.uint8)
+        lem, U, Cc = rd("lem"), rd("u"), rd("c")
+        assert sha(lem) == v["lem"] and sha(U) == v["u"] and sha(Cc) == v["c"] and v["u_roundtrip"] and v["c_roundtrip"]
+        assert bytes(O.group_convert(c, group, "LEMtoU", lem)) == bytes(U)
+        assert bytes(O.group_convert(c, group, "LEMtoC", lem)) == bytes(Cc)
+        assert bytes(O.group_convert(c, group, "UtoLEM", U)) == bytes(lem)
+        assert bytes(O.group_convert(c, group, "CtoLEM", Cc)) == bytes(lem)
+        bad, found = Cc.copy(), False
+        for delta in range(1, 40):                       # about half of all x have no point: one of these must be refused
+            bad[group * O.n8q(c) - 1] = (int(Cc[group * O.n8q(c) - 1]) + delta) & 0xff
+            try:
+                O.group_convert(c, group, "CtoLEM", bad)
+            except ValueError:
+                found = True
+                break
+        assert found
