@@ -163,6 +163,12 @@ template <class C, int T> struct LdsAcc29 {
         for (int i = 0; i < 9; i++) { base[(coord * 18 + i) * T] = v.c0.l[i]; base[(coord * 18 + 9 + i) * T] = v.c1.l[i]; }
     }
 };
+// Scheduling fence between Fq2-level operations of madd29_lds: the machine scheduler otherwise interleaves independent Fq2 products up to
+// the register budget of the launch bounds (256 VGPRs + 25 spilled registers whose reloads wait on scratch); fenced, the kernel needs 208
+// VGPRs and no scratch. Inside one Fq2 product the two component chains still overlap. (Same speed on MI355X, r02 A/B: the kernel is bound
+// by integer issue, not by occupancy, spills or gather latency — a software-prefetched variant and a 120-VGPR G1 variant at 4 waves per SIMD
+// measured the same as well.)
+#define ZK_SFENCE() __builtin_amdgcn_sched_barrier(0)
 // acc += q over Fq2. Invariants (units of p, per component): X <= 8.4, Y <= 3.8, ZZ, ZZZ <= 1.1, all normalised. q.x canonical, q.y <= 2.
 template <class C, int T> ZK_DEV void madd29_lds(const LdsAcc29<C, T>& A, bool& inf, const F2x<C>& qx, const F2x<C>& qy) {
     F2x<C> t;
@@ -175,10 +181,12 @@ template <class C, int T> ZK_DEV void madd29_lds(const LdsAcc29<C, T>& A, bool& 
     }
     A.get(2, t);
     const F2x<C> U2 = f2mul(t, qx, neg29<C, 2>(qx.c1));                                // <= 1.1
+    ZK_SFENCE();
     A.get(0, t);
     F2x<C> P = f2sub<C, 9>(U2, t); f2norm(P);                                           // X <= 8.4 < 9;  P <= 10.1
     A.get(3, t);
     const F2x<C> S2 = f2mul(t, qy, neg29<C, 3>(qy.c1));                                // <= 1.1
+    ZK_SFENCE();
     A.get(1, t);
     F2x<C> R = f2sub<C, 4>(S2, t); f2norm(R);                                           // Y <= 3.8 < 4;  R <= 5.1
     if (f2zero(P)) {
@@ -199,18 +207,25 @@ template <class C, int T> ZK_DEV void madd29_lds(const LdsAcc29<C, T>& A, bool& 
         return;
     }
     const F2x<C> PP = f2sqr<C, 11>(P);                                                  // <= 3.5
+    ZK_SFENCE();
     const Fp29<C> nPP1 = neg29<C, 4>(PP.c1);
     const F2x<C> PPP = f2mul(P, PP, nPP1);                                              // <= 1.5
+    ZK_SFENCE();
     const Fp29<C> nPPP1 = neg29<C, 2>(PPP.c1);
     A.get(2, t); A.put(2, f2mul(t, PP, nPP1));                                          // ZZ3 = ZZ1 * PP  <= 1.1
+    ZK_SFENCE();
     A.get(3, t); A.put(3, f2mul(t, PPP, nPPP1));                                        // ZZZ3 = ZZZ1 * PPP
+    ZK_SFENCE();
     A.get(0, t);
     const F2x<C> Q = f2mul(t, PP, nPP1);                                                // <= 1.4
+    ZK_SFENCE();
     F2x<C> X3 = f2sub<C, 2>(f2sub<C, 2>(f2sub<C, 2>(f2sqr<C, 6>(R), PPP), Q), Q); f2norm(X3);      // <= 2.4 + 6 = 8.4
     A.put(0, X3);
+    ZK_SFENCE();
     F2x<C> Tq = f2sub<C, 9>(Q, X3); f2norm(Tq);                                         // <= 10.4
     A.get(1, t);
     const F2x<C> W = f2mul(t, PPP, nPPP1);                                              // Y1 * PPP  <= 1.1
+    ZK_SFENCE();
     F2x<C> Y3 = f2sub<C, 2>(f2mul(Tq, R, neg29<C, 6>(R.c1)), W); f2norm(Y3);            // <= 1.8 + 2 = 3.8
     A.put(1, Y3);
 }

@@ -448,10 +448,33 @@ template <class F> int msm_run_table_multi(const void* d_table, size_t stride, i
     MsmJob* jp[MSM_MAX_BATCH];
     int live = 0;
     ZK_HIP(hipEventRecord(cx.ev0, st));
+    // The digit sorts are memory-bound, the accumulations ALU-bound: with more than one MSM in the call the sorts go to the
+    // auxiliary stream, so that sort i+1 runs underneath accumulation i (ZKMI_MULTI_OVERLAP=0 keeps one stream).
+    static const bool ov_env = !(getenv("ZKMI_MULTI_OVERLAP") && atoi(getenv("ZKMI_MULTI_OVERLAP")) == 0);
+    int n_live = 0;
+    for (int i = 0; i < count; i++) n_live += ks[i] != 0;
+    const bool ov = ov_env && n_live > 1;
+    if (ov) {
+        ZK_TRY(ensure_aux_stream());
+        hipStream_t aux = cx.aux_stream;
+        if (!cx.sort_ev[0]) for (int i = 0; i < 5; i++) ZK_HIP(hipEventCreateWithFlags(&cx.sort_ev[i], hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(cx.sort_ev[0], st));                   // the scalars are ready on the main stream at this point
+        ZK_HIP(hipStreamWaitEvent(aux, cx.sort_ev[0], 0));
+        cx.stream = aux;
+        int rc = ZKMI_OK;
+        for (int i = 0; i < count && !rc; i++) {
+            if (ks[i] == 0) continue;
+            rc = msm_sort(d_scalars[i], ks[i], sb, pl[i], i, c, stride);
+            if (!rc && hipEventRecord(cx.sort_ev[1 + i], aux) != hipSuccess) rc = fail(ZKMI_ERR_HIP, "hipEventRecord");
+        }
+        cx.stream = st;
+        ZK_TRY(rc);
+    }
     for (int i = 0; i < count; i++) {
         if (ks[i] == 0) continue;
         ZK_TRY(msm_job_slot(i, job[i]));
-        ZK_TRY(msm_sort(d_scalars[i], ks[i], sb, pl[i], i, c, stride));
+        if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[1 + i], 0));
+        else ZK_TRY(msm_sort(d_scalars[i], ks[i], sb, pl[i], i, c, stride));
         ZK_TRY(msm_accumulate<F>(d_table, pl[i], 0, job[i]));
         jp[live++] = &job[i];
     }

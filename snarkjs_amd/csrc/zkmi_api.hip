@@ -142,17 +142,20 @@ int msm_table_dispatch(int curve, int group, const void* d_table, size_t stride,
     ZK_TRY(check_cg(curve, group));
     return curve == ZKMI_CURVE_BN128 ? msm_table_bn254(group, d_table, stride, c, d_scalars, k, sb, out) : msm_table_bls12381(group, d_table, stride, c, d_scalars, k, sb, out);
 }
+int ensure_aux_stream() {
+    if (g_ctx.aux_stream) return ZKMI_OK;
+    // highest priority: the auxiliary stream carries latency-bound work (few waves, long dependency chains) and memory-bound digit
+    // sorts that must not queue behind the main stream's throughput-bound kernels for wave slots
+    int prio_least = 0, prio_greatest = 0;
+    ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    ZK_HIP(hipStreamCreateWithPriority(&g_ctx.aux_stream, hipStreamNonBlocking, getenv("ZKMI_AUX_PRIO") ? atoi(getenv("ZKMI_AUX_PRIO")) : prio_greatest));
+    ZK_HIP(hipEventCreateWithFlags(&g_ctx.aux_ev[0], hipEventDisableTiming));
+    ZK_HIP(hipEventCreateWithFlags(&g_ctx.aux_ev[1], hipEventDisableTiming));
+    return ZKMI_OK;
+}
 int msm_reduce_dispatch(int curve, int group, MsmJob* const* jobs, int njobs, bool aux) {
     ZK_TRY(check_cg(curve, group));
-    if (aux && !g_ctx.aux_stream) {
-        // highest priority: the auxiliary stream carries latency-bound work (few waves, long dependency chains) that must not
-        // queue behind the main stream's throughput-bound kernels for wave slots
-        int prio_least = 0, prio_greatest = 0;
-        ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        ZK_HIP(hipStreamCreateWithPriority(&g_ctx.aux_stream, hipStreamNonBlocking, getenv("ZKMI_AUX_PRIO") ? atoi(getenv("ZKMI_AUX_PRIO")) : prio_greatest));
-        ZK_HIP(hipEventCreateWithFlags(&g_ctx.aux_ev[0], hipEventDisableTiming));
-        ZK_HIP(hipEventCreateWithFlags(&g_ctx.aux_ev[1], hipEventDisableTiming));
-    }
+    if (aux) ZK_TRY(ensure_aux_stream());
     if (njobs == 0) return ZKMI_OK;                               // only makes sure the auxiliary stream exists
     return curve == ZKMI_CURVE_BN128 ? msm_reduce_bn254(group, jobs, njobs, aux) : msm_reduce_bls12381(group, jobs, njobs, aux);
 }

@@ -223,7 +223,9 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     """plonk.prove(zkeyFileName, witnessFileName). blinding_mont: the 11 Fr.random() draws (:224-227) as Montgomery bytes,
     for bit-exact reproduction; default = fresh randomness."""
     def data(x):
-        if isinstance(x, (bytes, bytearray, memoryview, np.ndarray)):
+        if isinstance(x, (bytes, bytearray)):
+            return x                                                   # parsed in place: no copy of a 2^20-signal witness per proof
+        if isinstance(x, (memoryview, np.ndarray)):
             return bytes(x)
         with open(x, "rb") as fh:
             return fh.read()
@@ -244,9 +246,8 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
         raise ValueError("Curve of the witness does not match the curve of the proving key")
     if n_witness != key.nVars - key.nAdditions:
         raise ValueError(f"Invalid witness length. Circuit: {key.nVars}, witness: {n_witness}, {key.nAdditions}")
-    wit = np.frombuffer(wt, np.uint8, n_witness * 32, ws[2][0]).copy()
+    wit = np.frombuffer(wt, np.uint8, n_witness * 32, ws[2][0])                           # a view: the signal 0 slot is cleared on the device
     public = [int.from_bytes(bytes(wit[32 * i:32 * i + 32]), "little") for i in range(1, key.nPublic + 1)]
-    wit[:32] = 0                                                                          # :94-96
     if blinding_mont is None:
         b = [0] + [int.from_bytes(os.urandom(64), "little") % r for _ in range(11)]
     else:
@@ -258,7 +259,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
 
     def get_witness(idx):
         if idx < nW:
-            return int.from_bytes(bytes(wit[32 * idx:32 * idx + 32]), "little")
+            return int.from_bytes(bytes(wit[32 * idx:32 * idx + 32]), "little") if idx else 0    # signal 0 reads as 0 (:94-96)
         return internal[idx - nW] if idx < key.nVars else 0
     for i in range(key.nAdditions):
         o = 72 * i
@@ -266,6 +267,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
         f1, f2 = f.unmont(key.additions[o + 8:o + 40]), f.unmont(key.additions[o + 40:o + 72])
         internal.append((f1 * get_witness(s1) + f2 * get_witness(s2)) % r)
     d_wit = zkmi.DeviceBuffer.from_host(wit)
+    zkmi.check(L.zkmi_memset_dev(d_wit.ptr, 0, 32))                                       # :94-96
     d_int = zkmi.DeviceBuffer.from_host(np.frombuffer(b"".join(v.to_bytes(32, "little") for v in internal) or bytes(32), np.uint8))
 
     tr = _Transcript(f)
