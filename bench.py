@@ -25,6 +25,8 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # measured Montgomery-multiply ceilings of the chip, Gmul/s, in the limb form the accumulation kernels of the curve use: BN254 Fq on
 # unsaturated 29-bit limbs (field29.cuh), BLS12-381 Fq on saturated 32-bit limbs (tools/fieldbench, profiles/r01_fieldbench.txt)
+VALU_PER_ADD = {"g1": 2417, "g2": 6218}       # VALU instructions of one mixed addition, main path (tools/isa_counts.py, k_msm_accum29 / k_msm_accum29_g2)
+VALU_ISSUE_PEAK_G = 614.4                      # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave instruction
 FIELD_MUL_PEAK_G = {"bn128": 175.0, "bls12381": 58.6}      # bn128: 9 x 29-bit limbs (tools/fieldbench29, profiles/r02_fieldbench29.txt; 8 x 32-bit limbs: 130)
 
 
@@ -411,6 +413,14 @@ def main():
         int_alu = {"unit": "Gmul/s", "field_muls": fmuls, "achieved": round(fmuls / (acc[dom] * 1e-3) / 1e9, 1), "peak": FIELD_MUL_PEAK_G[args.curve],
                    "frac": round(fmuls / (acc[dom] * 1e-3) / 1e9 / FIELD_MUL_PEAK_G[args.curve], 4),
                    "note": "field multiplications of the mixed additions of this launch (digits x non-infinity terms x 10 in G1 / 28 in G2; the Fq2 kernel's ~70 additions per mixed addition are not counted) / launch time; peak = measured Montgomery-multiply ceiling of the chip in the kernel's limb form (BN254: 9 x 29-bit limbs 175 Gmul/s, tools/fieldbench29; BLS12-381: 12 x 32-bit limbs 58.6 Gmul/s, tools/fieldbench); the G2 kernel computes an Fq2 product as two double products with one reduction each (4 multiplications + 2 reductions instead of Karatsuba's 3 + 3): it is counted at Karatsuba's 3"}
+        # VALU issue: static instruction count of the kernel's main path (tools/isa_counts.py on the shipped code object, profiles/r02_isa_counts.md)
+        # x additions of the launch, against one wave instruction per SIMD every 4 cycles (1024 SIMDs x 2.4 GHz / 4)
+        if r29:
+            vpa = VALU_PER_ADD["g2" if dom == 2 else "g1"]
+            adds = digits * units * density
+            wrate = adds * vpa / 64 / (acc[dom] * 1e-3) / 1e9
+            int_alu["valu_issue"] = {"valu_instr_per_addition": vpa, "achieved": round(wrate, 1), "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instr/s", "frac": round(wrate / VALU_ISSUE_PEAK_G, 4),
+                                     "note": "the kernel holds 2 waves per SIMD (LDS-parked Fq2 accumulators + 208 VGPRs); a dependent v_mad_u64_u32 chain issues every ~5 cycles per wave: measured ceiling at 2 waves/SIMD = 0.82 of peak (tools/fieldbench29)"}
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
