@@ -96,6 +96,67 @@ template <class C> ZK_DEV Fp29<C> mul29_2(const Fp29<C>& a0, const Fp29<C>& b0, 
     }
     return r;
 }
+// (a0 b0 + a1 b1 + a2 b2 + a3 b3) / 2^261 mod p with ONE reduction: every operand normalised (limbs < 2^29), so that a column holds at most
+// 36 products of < 2^58 plus 9 reduction terms: < 2^63.5. Used where a formula ends in a difference of Fq2 products (Y3 = R T - Y1 PPP).
+template <class C> ZK_DEV Fp29<C> mul29_4(const Fp29<C>& a0, const Fp29<C>& b0, const Fp29<C>& a1, const Fp29<C>& b1, const Fp29<C>& a2, const Fp29<C>& b2, const Fp29<C>& a3,
+                                          const Fp29<C>& b3) {
+    using L = Lim29<C>;
+    Fp29<C> r;
+    uint32_t m[9];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) { mad29(acc, a0.l[i], b0.l[k - i]); mad29(acc, a1.l[i], b1.l[k - i]); mad29(acc, a2.l[i], b2.l[k - i]); mad29(acc, a3.l[i], b3.l[k - i]); }
+#pragma unroll
+        for (int i = 0; i < k; i++) mad29c(acc, m[i], L::p(k - i));
+        m[k] = ((uint32_t)acc * L::NP) & M29;
+        mad29c(acc, m[k], L::p(0));
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 18; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) { mad29(acc, a0.l[i], b0.l[k - i]); mad29(acc, a1.l[i], b1.l[k - i]); mad29(acc, a2.l[i], b2.l[k - i]); mad29(acc, a3.l[i], b3.l[k - i]); }
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) mad29c(acc, m[i], L::p(k - i));
+        r.l[k - 9] = (k == 17) ? (uint32_t)acc : ((uint32_t)acc & M29);
+        acc >>= 29;
+    }
+    return r;
+}
+// a^2 / 2^261 mod p for a normalised a: 45 products instead of 81 — every cross term once, against the doubled operand d = 2a (limbs < 2^30).
+// A column holds at most 4 cross terms of < 2^59, one square of < 2^58 and 9 reduction terms of < 2^58: < 2^62.4.
+template <class C> ZK_DEV Fp29<C> sqr29(const Fp29<C>& a) {
+    using L = Lim29<C>;
+    Fp29<C> r;
+    uint32_t m[9], d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) mad29(acc, d[i], a.l[k - i]);
+        if ((k & 1) == 0) mad29(acc, a.l[k / 2], a.l[k / 2]);
+#pragma unroll
+        for (int i = 0; i < k; i++) mad29c(acc, m[i], L::p(k - i));
+        m[k] = ((uint32_t)acc * L::NP) & M29;
+        mad29c(acc, m[k], L::p(0));
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 18; k++) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; i++) mad29(acc, d[i], a.l[k - i]);
+        if ((k & 1) == 0) mad29(acc, a.l[k / 2], a.l[k / 2]);
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) mad29c(acc, m[i], L::p(k - i));
+        r.l[k - 9] = (k == 17) ? (uint32_t)acc : ((uint32_t)acc & M29);
+        acc >>= 29;
+    }
+    return r;
+}
 // carry propagation: limbs 0..7 back below 2^29 (input limbs < 2^32 - 2^3, value unchanged)
 template <class C> ZK_DEV void norm29(Fp29<C>& a) {
 #pragma unroll

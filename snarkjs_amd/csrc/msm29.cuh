@@ -27,7 +27,8 @@ template <class C> ZK_DEV void dbl_affine29(XYZZ29<C>& r, const Aff29<C>& q) {
     Fp29<C> Y3 = sub29<C, 2>(mul29(M, T), mul29(W, q.y)); norm29(Y3);           // <= 3.2
     r.X = X3; r.Y = Y3; r.ZZ = V; r.ZZZ = W;
 }
-// acc += q (q affine, not the point at infinity, x canonical, y <= 2 normalised); inf = accumulator is the point at infinity
+// acc += q (q affine, not the point at infinity, x canonical, y <= 2 normalised); inf = accumulator is the point at infinity.
+// 8 products + 2 squarings (sqr29) with 9 reductions: the last two products share one (mul29_2).
 template <class C> ZK_DEV void madd29(XYZZ29<C>& acc, bool& inf, const Aff29<C>& q) {
     if (inf) { acc.X = q.x; acc.Y = q.y; acc.ZZ = one29<C>(); acc.ZZZ = one29<C>(); inf = false; return; }
     const Fp29<C> U2 = mul29(q.x, acc.ZZ), S2 = mul29(q.y, acc.ZZZ);           // <= 1.1
@@ -37,11 +38,12 @@ template <class C> ZK_DEV void madd29(XYZZ29<C>& acc, bool& inf, const Aff29<C>&
         if (is_zero29(R)) dbl_affine29(acc, q); else inf = true;
         return;
     }
-    const Fp29<C> PP = mul29(P, P);                                             // <= 1.49
+    const Fp29<C> PP = sqr29(P);                                                // <= 1.49
     const Fp29<C> PPP = mul29(P, PP), Q = mul29(acc.X, PP);                     // <= 1.08, 1.07
-    Fp29<C> X3 = sub29<C, 2>(sub29<C, 2>(sub29<C, 2>(mul29(R, R), PPP), Q), Q); norm29(X3);        // <= 1.16 + 6 = 7.16
-    const Fp29<C> T = sub29<C, 8>(Q, X3);                                       // <= 9.1, limbs < 2^31 (R is normalised)
-    Fp29<C> Y3 = sub29<C, 2>(mul29(R, T), mul29(acc.Y, PPP)); norm29(Y3);       // <= 1.27 + 2 = 3.27
+    Fp29<C> X3 = sub29<C, 2>(sub29<C, 2>(sub29<C, 2>(sqr29(R), PPP), Q), Q); norm29(X3);          // <= 1.16 + 6 = 7.16
+    Fp29<C> T = sub29<C, 8>(Q, X3); norm29(T);                                  // <= 9.1
+    // Y3 = R T - Y1 PPP as ONE double product with one reduction: (R T + (4p - Y1) PPP) / R' + p <= (46.4 + 4.4) / 169 + 1 = 1.3
+    const Fp29<C> Y3 = mul29_2(R, T, sub29<C, 4>(zero29<C>(), acc.Y), PPP);     // 4p - Y1: limbs < 2^30 (not normalised), as in f2mul
     acc.ZZ = mul29(acc.ZZ, PP); acc.ZZZ = mul29(acc.ZZZ, PPP);
     acc.X = X3; acc.Y = Y3;
 }
@@ -224,9 +226,13 @@ template <class C, int T> ZK_DEV void madd29_lds(const LdsAcc29<C, T>& A, bool& 
     ZK_SFENCE();
     F2x<C> Tq = f2sub<C, 9>(Q, X3); f2norm(Tq);                                         // <= 10.4
     A.get(1, t);
-    const F2x<C> W = f2mul(t, PPP, nPPP1);                                              // Y1 * PPP  <= 1.1
-    ZK_SFENCE();
-    F2x<C> Y3 = f2sub<C, 2>(f2mul(Tq, R, neg29<C, 6>(R.c1)), W); f2norm(Y3);            // <= 1.8 + 2 = 3.8
+    // Y3 = Tq R - Y1 PPP with ONE reduction per component (mul29_4, every operand normalised):
+    //   c0 = Tq0 R0 + Tq1 (6p - R1) + Y0 (2p - PPP0) + Y1 PPP1      <= (53 + 62.4 + 7.6 + 5.7) / 169 + 1 = 1.8
+    //   c1 = Tq0 R1 + Tq1 R0 + Y0 (2p - PPP1) + Y1 (2p - PPP0)      <= (53 + 53 + 7.6 + 7.6) / 169 + 1 = 1.8
+    const Fp29<C> nR1 = neg29<C, 6>(R.c1), nPPP0 = neg29<C, 2>(PPP.c0);
+    F2x<C> Y3;
+    Y3.c0 = mul29_4(Tq.c0, R.c0, Tq.c1, nR1, t.c0, nPPP0, t.c1, PPP.c1);
+    Y3.c1 = mul29_4(Tq.c0, R.c1, Tq.c1, R.c0, t.c0, nPPP1, t.c1, nPPP0);
     A.put(1, Y3);
 }
 template <class C, int T> ZK_DEV void store_xyzz29_lds(uint32_t* dst, const LdsAcc29<C, T>& A, bool inf) {
