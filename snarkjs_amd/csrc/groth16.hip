@@ -135,11 +135,11 @@ struct DevTmp {
 static int g16_work_alloc(G16Key& K, int slot) {
     G16Key::Work& W = K.wk[slot];
     if (W.A) return ZKMI_OK;
-    ZK_HIP(hipMalloc((void**)&W.w, (size_t)K.n_vars * 32));
+    ZK_TRY(dev_alloc_big((void**)&W.w, (size_t)K.n_vars * 32));
     // A | B | C contiguous and T three transforms long: the three chains run as batched NTT launches (ntt_dev_batch_dispatch)
-    ZK_HIP(hipMalloc((void**)&W.A, (size_t)K.domain * 32 * 3));
+    ZK_TRY(dev_alloc_big((void**)&W.A, (size_t)K.domain * 32 * 3));
     W.B = W.A + (size_t)K.domain * 8; W.C = W.B + (size_t)K.domain * 8;
-    ZK_HIP(hipMalloc((void**)&W.T, (size_t)K.domain * 32 * 3));
+    ZK_TRY(dev_alloc_big((void**)&W.T, (size_t)K.domain * 32 * 3));
     for (auto& e : W.ev) ZK_HIP(hipEventCreate(&e));
     return ZKMI_OK;
 }
@@ -188,14 +188,14 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
     auto put_table = [&](void** dst, uint32_t** mask, const uint8_t* src, size_t cnt, size_t pad_front, int group, int c) -> int {
         const size_t pb = group == 1 ? g1 : g2, tot = cnt + pad_front;
         DevTmp tmp;
-        ZK_HIP(hipMalloc(&tmp.p, tot * pb ? tot * pb : 16));
+        ZK_TRY(dev_alloc_big(&tmp.p, tot * pb ? tot * pb : 16));
         void* raw = tmp.p;
         if (pad_front) ZK_HIP(hipMemsetAsync(raw, 0, pad_front * pb, st));             // all-zero bytes = point at infinity
         if (cnt) ZK_HIP(hipMemcpyAsync((uint8_t*)raw + pad_front * pb, src, cnt * pb, hipMemcpyHostToDevice, st));
         const int Wd = c ? msm_digits(32, c) : 1;
         if (!c) { *dst = raw; tmp.p = nullptr; }
         else {
-            ZK_HIP(hipMalloc(dst, (size_t)Wd * tot * pb));
+            ZK_TRY(dev_alloc_big(dst, (size_t)Wd * tot * pb));
             ZK_TRY(msm_precompute_dispatch(zk->curve, group, raw, tot, c, Wd, *dst));
         }
         ZK_HIP(hipMalloc((void**)mask, (((size_t)Wd * tot + 31) / 32) * 4 + 16));
@@ -236,7 +236,7 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
     ZK_HIP(hipMalloc((void**)&K->row_cnt, rows * 4)); ZK_HIP(hipMalloc((void**)&K->row_start, rows * 4));
     ZK_HIP(hipMalloc(&cursor_t.p, rows * 4 + 16));
     uint32_t* cursor = (uint32_t*)cursor_t.p;
-    ZK_HIP(hipMalloc((void**)&K->sig, std::max<size_t>(K->n_coef, 1) * 4)); ZK_HIP(hipMalloc((void**)&K->val, std::max<size_t>(K->n_coef, 1) * 32));
+    ZK_TRY(dev_alloc_big((void**)&K->sig, std::max<size_t>(K->n_coef, 1) * 4)); ZK_TRY(dev_alloc_big((void**)&K->val, std::max<size_t>(K->n_coef, 1) * 32));
     ZK_HIP(hipMemsetAsync(K->row_cnt, 0, rows * 4, st)); ZK_HIP(hipMemsetAsync(cursor, 0, rows * 4 + 16, st));
     uint32_t* bad = cursor + rows;
     if (K->n_coef) {

@@ -168,8 +168,7 @@ template <class C, int T> struct LdsAcc29 {
 // Scheduling fence between Fq2-level operations of madd29_lds: the machine scheduler otherwise interleaves independent Fq2 products up to
 // the register budget of the launch bounds (256 VGPRs + 25 spilled registers whose reloads wait on scratch); fenced, the kernel needs 208
 // VGPRs and no scratch. Inside one Fq2 product the two component chains still overlap. (Same speed on MI355X, r02 A/B: the kernel is bound
-// by integer issue, not by occupancy, spills or gather latency — a software-prefetched variant and a 120-VGPR G1 variant at 4 waves per SIMD
-// measured the same as well.)
+// by integer issue, not by occupancy or spills — a 120-VGPR G1 variant at 4 waves per SIMD measured the same as well.)
 #define ZK_SFENCE() __builtin_amdgcn_sched_barrier(0)
 // acc += q over Fq2. Invariants (units of p, per component): X <= 8.4, Y <= 3.8, ZZ, ZZZ <= 1.1, all normalised. q.x canonical, q.y <= 2.
 template <class C, int T> ZK_DEV void madd29_lds(const LdsAcc29<C, T>& A, bool& inf, const F2x<C>& qx, const F2x<C>& qy) {
@@ -266,15 +265,35 @@ k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict_
     const LdsAcc29<C, 256> A{lds_acc29 + threadIdx.x};
     bool inf = true;
     auto unpack = [](const uint4& a, const uint4& b) { const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}; return unpack29<C>(w); };
-    for (uint32_t k = lo; k < hi; k++) {
-        const uint32_t e = list[k];
-        uint32_t idx = e & 0x7fffffffu;
-        if (idx < skip) continue;
-        idx -= skip;
-        if ((infmask[idx >> 5] >> (idx & 31)) & 1u) continue;
-        const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)idx * 32);
-        const uint4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3], r4 = p[4], r5 = p[5], r6 = p[6], r7 = p[7];
-        F2x<C> qx{unpack(r0, r1), unpack(r2, r3)}, qy{unpack(r4, r5), unpack(r6, r7)};
+    // Software pipeline as in the G1 kernel: the next point (packed, 8 x 16 bytes) is gathered while the current addition runs. On a box
+    // with fast address translation this measures the same as the plain loop (the kernel is issue-bound); on boxes where random 128-byte
+    // gathers over the 1.7 GB table are slow (r02: the same binary took 5.8 ms instead of 3.3 ms without it) two waves per SIMD cannot hide
+    // the gather latency by themselves.
+    uint32_t k = lo;
+    struct Raw { uint4 v[8]; };
+    auto fetch = [&](uint32_t& e_out, Raw& r_out) -> bool {
+        while (k < hi) {
+            const uint32_t e = list[k++];
+            uint32_t idx = e & 0x7fffffffu;
+            if (idx < skip) continue;
+            idx -= skip;
+            if ((infmask[idx >> 5] >> (idx & 31)) & 1u) continue;
+            const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)idx * 32);
+#pragma unroll
+            for (int i = 0; i < 8; i++) r_out.v[i] = p[i];
+            e_out = e;
+            return true;
+        }
+        return false;
+    };
+    uint32_t e_next = 0;
+    Raw r_next;
+    bool have = fetch(e_next, r_next);
+    while (have) {
+        const uint32_t e = e_next;
+        const Raw r = r_next;
+        have = fetch(e_next, r_next);                           // the next gather is in flight during this addition
+        F2x<C> qx{unpack(r.v[0], r.v[1]), unpack(r.v[2], r.v[3])}, qy{unpack(r.v[4], r.v[5]), unpack(r.v[6], r.v[7])};
         if (e >> 31) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }      // 2p - y
         madd29_lds<C, 256>(A, inf, qx, qy);
     }

@@ -44,12 +44,29 @@ int select_pipe(int p) {
     return ZKMI_OK;
 }
 
+// Allocation of the large device buffers (window tables, bucket arrays, NTT work arrays, the host's pooled buffers). ZKMI_CONTIG=1 asks for
+// PHYSICALLY CONTIGUOUS VRAM first (hipExtMallocWithFlags + hipDeviceMallocContiguous, falling back to hipMalloc) — an experiment against the
+// box-to-box spread of the gather- and stream-heavy kernels (r02: the same binary measured 3.3 ms and 5.8 ms for the G2 accumulation on two
+// boxes). Measured on a box in the fast state (tools/gpu_ab9.sh): contiguous ranges are SLOWER — buildABC 0.37 vs 0.14 ms, the NTT chain 1.29 vs
+// 1.11 ms, the G2 accumulation 3.5 vs 3.3 ms, 90.8 vs 99.8 proofs/s — presumably because a contiguous range interleaves over fewer HBM
+// channels than the driver's default placement. Default: off.
+int dev_alloc_big(void** p, size_t bytes) {
+    static const bool contig = getenv("ZKMI_CONTIG") && atoi(getenv("ZKMI_CONTIG")) == 1;
+    static const size_t min_bytes = getenv("ZKMI_CONTIG_MIN") ? (size_t)atoll(getenv("ZKMI_CONTIG_MIN")) : ((size_t)2 << 20);
+    if (contig && bytes >= min_bytes) {
+        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return ZKMI_OK;
+        (void)hipGetLastError();                                  // not available / no contiguous range: plain allocation
+    }
+    ZK_HIP(hipMalloc(p, bytes));
+    return ZKMI_OK;
+}
+
 int ws_get(const std::string& name, size_t bytes, void** out) {
     DevBuf& b = g_ctx.ws[g_ctx.pipe ? "P1:" + name : name];
     if (b.cap < bytes) {
         if (b.p) { ZK_HIP(hipStreamSynchronize(g_ctx.stream)); ZK_HIP(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
         size_t cap = bytes + bytes / 8 + 256;
-        ZK_HIP(hipMalloc(&b.p, cap));
+        ZK_TRY(dev_alloc_big(&b.p, cap));
         b.cap = cap;
     }
     *out = b.p;
@@ -236,7 +253,7 @@ int zkmi_dev_alloc(size_t bytes, void** d_ptr) {
         *d_ptr = it->second.back();
         it->second.pop_back();
         g_ctx.pool_bytes -= bytes;
-    } else ZK_HIP(hipMalloc(d_ptr, bytes));
+    } else ZK_TRY(dev_alloc_big(d_ptr, bytes));
     g_ctx.user_allocs[*d_ptr] = bytes;
     return ZKMI_OK;
 }
@@ -298,7 +315,7 @@ static int table_build(int curve, int group, const void* d_bases, size_t n, MsmT
     t.c = msm_precomp_c(n);
     t.Wd = msm_digits(32, t.c);
     if ((size_t)t.Wd * n >= (1ull << 31)) return fail(ZKMI_ERR_UNSUPPORTED, "msm table: too many points");
-    ZK_HIP(hipMalloc(&t.p, (size_t)t.Wd * n * pb));
+    ZK_TRY(dev_alloc_big(&t.p, (size_t)t.Wd * n * pb));
     ZK_TRY(msm_precompute_dispatch(curve, group, d_bases, n, t.c, t.Wd, t.p));
     ZK_HIP(hipStreamSynchronize(g_ctx.stream));
     return ZKMI_OK;

@@ -76,6 +76,7 @@ struct Ctx {
 Ctx& ctx();
 int require_ctx();
 int select_pipe(int p);
+int dev_alloc_big(void** p, size_t bytes);                // hipMalloc; ZKMI_CONTIG=1: physically contiguous VRAM first (zkmi_api.hip: measured slower)
 int ensure_aux_stream();                                  // creates Ctx::aux_stream (+ aux_ev) on first use                                     // make pipeline slot p (0 | 1) the active one
 // scratch buffer `name` with at least `bytes` capacity (contents undefined)
 int ws_get(const std::string& name, size_t bytes, void** out);
