@@ -25,7 +25,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # measured Montgomery-multiply ceilings of the chip, Gmul/s, in the limb form the accumulation kernels of the curve use: BN254 Fq on
 # unsaturated 29-bit limbs (field29.cuh), BLS12-381 Fq on saturated 32-bit limbs (tools/fieldbench, profiles/r01_fieldbench.txt)
-VALU_PER_ADD = {"g1": 2227, "g2": 5933}       # VALU instructions of one mixed addition, main path (tools/isa_counts.py, k_msm_accum29 / k_msm_accum29_g2)
+VALU_PER_ADD = {"g1": 2227, "g2": 5948}       # VALU instructions of one mixed addition, main path (tools/isa_counts.py, k_msm_accum29 / k_msm_accum29_g2)
 VALU_ISSUE_PEAK_G = 614.4                      # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave instruction
 FIELD_MUL_PEAK_G = {"bn128": 175.0, "bls12381": 58.6}      # bn128: 9 x 29-bit limbs (tools/fieldbench29, profiles/r02_fieldbench29.txt; 8 x 32-bit limbs: 130)
 
@@ -420,7 +420,7 @@ def main():
             adds = digits * units * density
             wrate = adds * vpa / 64 / (acc[dom] * 1e-3) / 1e9
             int_alu["valu_issue"] = {"valu_instr_per_addition": vpa, "achieved": round(wrate, 1), "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instr/s", "frac": round(wrate / VALU_ISSUE_PEAK_G, 4),
-                                     "note": "VALU instructions of the main path of one mixed addition (tools/isa_counts.py) x additions / 64 / launch time against one wave instruction per SIMD every 4 cycles; the G2 kernel holds 2 waves per SIMD (LDS-parked Fq2 accumulators + 207 VGPRs), where a dependent v_mad_u64_u32 chain reaches 0.82 of that peak (tools/fieldbench29)"}
+                                     "note": "VALU instructions of the main path of one mixed addition (tools/isa_counts.py) x additions / 64 / launch time against one wave instruction per SIMD every 4 cycles; the G2 kernel holds 2 waves per SIMD (LDS-parked Fq2 accumulators + 241 VGPRs), where a dependent v_mad_u64_u32 chain reaches 0.82 of that peak (tools/fieldbench29)"}
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
