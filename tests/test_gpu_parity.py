@@ -329,20 +329,20 @@ def test_groth16_two_proofs_in_flight(zk):
     pk.release()
 
 
-@pytest.mark.parametrize("lg", [6, 16, 20])
-def test_groth16_valid_key_proof_verifies(zk, golden_dir, lg):
-    """proofs on a synthetic VALID key (tests/synth_valid_groth16.py, known trapdoor; the small instance is the one the
-    reference itself exported / proved / verified) VERIFY under the pinned verifier restatement (oracle/groth16_verify_oracle.py), at
-    2^16 and at BASELINE configs[1]'s full size 2^20; a wrong public input or a swapped proof point is rejected. lg = 6: the device
-    proof equals the reference's seeded proof bit for bit."""
+@pytest.mark.parametrize("name,lg", [("bn128", 6), ("bn128", 16), ("bn128", 20), ("bls12381", 8), ("bls12381", 16)])
+def test_groth16_valid_key_proof_verifies(zk, golden_dir, name, lg):
+    """proofs on a synthetic VALID key (tests/synth_valid_groth16.py, known trapdoor; the small BN254 instance is the one the
+    reference itself exported / proved / verified) VERIFY under the pinned verifier restatement (oracle/groth16_verify_oracle.py: BN254 and
+    BLS12-381 pairings), at 2^16 on both curves and at BASELINE configs[1]'s full size 2^20; a wrong public input or a swapped proof point is
+    rejected. bn128 lg = 6: the device proof equals the reference's seeded proof bit for bit."""
     import copy
     import sys
     import synth_valid_groth16 as SV
     from snarkjs_amd import groth16
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import groth16_verify_oracle as V
-    zkey, wtns, info = SV.make("bn128", lg, use_device=True)
-    if lg == 6:
+    zkey, wtns, info = SV.make(name, lg, use_device=True)
+    if name == "bn128" and lg == 6:
         g = json.load(open(os.path.join(golden_dir, "groth16_valid_synth_n64.json")))
         assert sha(zkey) == g["zkey_sha256"]                   # device-generated points == the oracle's (and the reference accepted them)
         res = groth16.prove(zkey, wtns, r_mont=bytes.fromhex(g["r_mont"]), s_mont=bytes.fromhex(g["s_mont"]))

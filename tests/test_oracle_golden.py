@@ -214,24 +214,42 @@ def _verify_mod():
 
 
 def test_groth16_verifier_restatement_pinned(golden_dir):
-    """oracle/groth16_verify_oracle.py (src/groth16_verify.js:26-87 + a plain-Python optimal ate pairing) against the reference's own
-    verdicts: the proofs its verifier accepted are accepted, tampered ones are rejected; bilinearity of the pairing."""
+    """oracle/groth16_verify_oracle.py (src/groth16_verify.js:26-87 + plain-Python optimal ate pairings on BN254 and BLS12-381) against the
+    reference's own verdicts: the proofs its verifier accepted are accepted, tampered ones are rejected; bilinearity of the pairings."""
     import copy
     V = _verify_mod()
-    for tag in ("groth16_bn128_n1024", "groth16_valid_synth_n64"):
+    for tag in ("groth16_bn128_n1024", "groth16_valid_synth_n64", "groth16_bls12381_n1024"):
         g = json.load(open(os.path.join(golden_dir, tag + ".json")))
         assert g["verified"] is True
+        R = V.CURVES[g["vk"].get("curve", "bn128")].R
         assert V.groth16_verify(g["vk"], g["publicSignals"], g["proof"]) is True
         bad = copy.deepcopy(g["proof"])
         bad["pi_c"] = g["proof"]["pi_a"]
         assert V.groth16_verify(g["vk"], g["publicSignals"], bad) is False
         pub = list(g["publicSignals"])
-        pub[-1] = str((int(pub[-1]) + 1) % V.R)
+        pub[-1] = str((int(pub[-1]) + 1) % R)
         assert V.groth16_verify(g["vk"], pub, g["proof"]) is False
-        assert V.groth16_verify(g["vk"], [str(V.R)] + pub[1:], g["proof"]) is False          # public input not < r (:37-42)
-    g2 = V._g2(g["vk"]["vk_beta_2"])
-    e1 = V.final_exp(V.miller_loop(g2, V.g1_mul((1, 2), 7)))
-    assert e1 == V.f12_pow(V.final_exp(V.miller_loop(g2, (1, 2))), 7) and e1 != V.F12_ONE
+        assert V.groth16_verify(g["vk"], [str(R)] + pub[1:], g["proof"]) is False            # public input not < r (:37-42)
+        cv = V.CURVES[g["vk"].get("curve", "bn128")]                                          # bilinearity: e(7 P, Q) = e(P, Q)^7 != 1
+        g1, g2 = V._g1(g["vk"]["vk_alpha_1"]), V._g2(g["vk"]["vk_beta_2"])
+        e1 = cv.final_exp(cv.miller_loop(g2, cv.g1_mul(g1, 7)))
+        assert e1 == cv.f12_pow(cv.final_exp(cv.miller_loop(g2, g1)), 7) and e1 != cv.F12_ONE
+
+
+def test_valid_key_synthesiser_bls12381_verifies():
+    """tests/synth_valid_groth16.py on BLS12-381 (no reference-accepted instance of it is committed: the synthesiser is pinned on BN254 below,
+    the BLS12-381 verifier on the reference's own BLS proof above): the C restatement's proof on the synthetic key verifies, a wrong public
+    input does not."""
+    import synth_valid_groth16 as SV
+    V = _verify_mod()
+    c = O.CURVE_ID["bls12381"]
+    zkey, wtns, info = SV.make("bls12381", 6, use_device=False)
+    zk, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)
+    pa, pb, pc = O.groth16_prove(c, zk, w["witness"], bytes(O.fr_e(c, 3)), bytes(O.fr_e(c, 5)))
+    proof, _ = binfile.proof_json("bls12381", 48, O.fq_from_mont(c, pa), O.fq_from_mont(c, pb), O.fq_from_mont(c, pc))
+    pub = [str(int.from_bytes(bytes(w["witness"][32 * i:32 * i + 32]), "little")) for i in range(1, 3)]
+    assert V.groth16_verify(info["vk"], pub, proof) is True
+    assert V.groth16_verify(info["vk"], [pub[0], str(int(pub[1]) + 1)], proof) is False
 
 
 def test_valid_key_synthesiser_pinned(golden_dir):
