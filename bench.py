@@ -39,6 +39,20 @@ def _oracle():
     return O
 
 
+def drain_c_stdout_to_stderr():
+    """RCCL prints its version banner through C stdio; with stdout redirected to a pipe or file that text sits in libc's buffer until exit
+    and would land AFTER the JSON line. Flush it to stderr so that stdout carries the one JSON line and nothing else."""
+    import ctypes
+    sys.stdout.flush()
+    keep = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        ctypes.CDLL(None).fflush(None)
+    finally:
+        os.dup2(keep, 1)
+        os.close(keep)
+
+
 def relaunch_if_needed(args):
     """`python bench.py --gpus N` starts its own N ranks (one process per GPU over RCCL) when it was not already started by
     torch.distributed.run; a world size that does not match --gpus is refused rather than reported under a wrong n_gpus."""
@@ -184,10 +198,12 @@ def bench_plonk(args, rank, world, dist, torch):
             out["cpu_baseline"] = {"value": 1.0 / (dt * (1 << (lg - slg))), "unit": "proofs/s", "cores": 1, "kind": "port",
                                    "sample": f"one PLONK proof at 2^{slg} constraints by oracle/plonk_oracle.py (pure Python, 1 thread, {dt:.1f} s), scaled linearly x{1 << (lg - slg)}",
                                    "parity_on_sample": bool(got["proof"] == ref_proof)}
+        drain_c_stdout_to_stderr()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        drain_c_stdout_to_stderr()
 
 
 def main():
@@ -210,6 +226,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank != 0:
+        os.dup2(2, 1)                                       # only rank 0 owns stdout (the one JSON line)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
@@ -218,6 +236,9 @@ def main():
     if world > 1 or os.environ.get("ZKMI_FORCE_DIST"):      # ZKMI_FORCE_DIST: exercise the RCCL path with a single rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                      # ZKMI_FORCE_DIST without a launcher
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29517")):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from snarkjs_amd import groth16, zkmi, binfile
     from snarkjs_amd.workloads import synth, synth_zkey
@@ -456,8 +477,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    drain_c_stdout_to_stderr()                   # every rank: nothing but rank 0's JSON line may reach stdout
     if out is not None:
-        sys.stdout.flush()
         print(json.dumps(out), flush=True)       # the ONE JSON line, after everything else this process may write
 
 
