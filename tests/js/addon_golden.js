@@ -126,10 +126,10 @@ for (const [tag, cid] of [["bn128", 0], ["bls12381", 1]]) {
         check("groth16ProveAsync == groth16Prove", eq(ar.pi_a, res.pi_a) && eq(ar.pi_b, res.pi_b) && eq(ar.pi_c, res.pi_c));
         check("msmAsync == reference", eq(addon.toAffine(0, 1, am), raw("bn128", "g1_msm_affine")));
         check("nttAsync == reference", eq(o1, raw("bn128", "fft")));
-        const big = new Uint8Array(32 << 18), ob = new Uint8Array(32 << 18);
-        for (let i = 0; i < (1 << 18); i++) big[32 * i] = i & 255;
+        const big = new Uint8Array(32 << 20), ob = new Uint8Array(32 << 20);
+        for (let i = 0; i < (1 << 20); i++) big[32 * i] = i & 255;
         const t0 = ticks;
-        await Promise.all([0, 1, 2, 3].map(() => addon.nttAsync(0, big, ob, 18, 0, null, null)));
+        await Promise.all([0, 1, 2, 3].map(() => addon.nttAsync(0, big, ob, 20, 0, null, null)));    // >= 5 ms of library time in total
         check(`event loop turned while async calls ran (${ticks - t0} timer ticks)`, ticks - t0 >= 1);
         let rejected = false;
         try { await addon.msmAsync(0, 1, bases, x.subarray(0, 1024 * 32 - 1), 1024, 32, 0); } catch (e) { rejected = /Scalar size does not match/.test(e.message); }
