@@ -53,6 +53,17 @@ def drain_c_stdout_to_stderr():
         os.close(keep)
 
 
+def box_calibration(L):
+    """Two 20-ms probes of the device this run landed on (include/zkmi.h: zkmi_calibrate_box), AFTER the timed region: the boxes differ,
+    and a low line next to a `mul29_gmul_per_s` well under 150 or a gather rate well under 6 TB/s says so."""
+    import ctypes
+    a, b = ctypes.c_double(0), ctypes.c_double(0)
+    if L.zkmi_calibrate_box(ctypes.byref(a), ctypes.byref(b)) != 0:
+        return None
+    return {"mul29_gmul_per_s": round(a.value, 1), "gather128_gb_per_s": round(b.value, 1), "healthy": {"mul29_gmul_per_s": 150.0, "gather128_gb_per_s": 6000.0},
+            "note": "two dependent chains of Montgomery products on 29-bit limbs, 8 workgroups per CU; 16 dependent random 128-byte gathers per lane over a 2 GiB table; after the timed region; `healthy` = what this probe measures on a box that gives ~100 proofs/s"}
+
+
 def relaunch_if_needed(args):
     """`python bench.py --gpus N` starts its own N ranks (one process per GPU over RCCL) when it was not already started by
     torch.distributed.run; a world size that does not match --gpus is refused rather than reported under a wrong n_gpus."""
@@ -198,6 +209,7 @@ def bench_plonk(args, rank, world, dist, torch):
             out["cpu_baseline"] = {"value": 1.0 / (dt * (1 << (lg - slg))), "unit": "proofs/s", "cores": 1, "kind": "port",
                                    "sample": f"one PLONK proof at 2^{slg} constraints by oracle/plonk_oracle.py (pure Python, 1 thread, {dt:.1f} s), scaled linearly x{1 << (lg - slg)}",
                                    "parity_on_sample": bool(got["proof"] == ref_proof)}
+        out["box_calibration"] = box_calibration(zkmi.lib())
         drain_c_stdout_to_stderr()
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -474,6 +486,8 @@ def main():
             got = pk_s.prove_raw(binfile.read_wtns(wt_s)["witness"], rs, ss)
             out["cpu_baseline"]["parity_on_sample"] = bool(all(np.array_equal(a, b) for a, b in zip(got, ref)))
             pk_s.release()
+    if out is not None:
+        out["box_calibration"] = box_calibration(L)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -279,6 +279,11 @@ int zkmi_group_batch_apply_key_dev(int curve, int group, const void* d_in, void*
 int zkmi_group_convert(int curve, int group, int kind, zkmi_pages in, uint8_t* const* out_ptr, const size_t* out_len, int n_out_pages, size_t n);
 int zkmi_group_convert_dev(int curve, int group, int kind, const void* d_in, void* d_out, size_t n);
 
+/* Two short probes of the device a run landed on, for reading benchmark lines (no reference counterpart): Montgomery products per second on
+ * 29-bit limbs (two dependent chains per lane, 8 workgroups per CU: about 150 G products/s on a healthy MI355X) and 16 dependent random 128-byte
+ * gathers per lane over a 2 GiB table (about 6 TB/s on a healthy box). */
+int zkmi_calibrate_box(double* mul29_gmul_per_s, double* gather128_gb_per_s);
+
 /* ---- utilities --------------------------------------------------------------------------------------------------- */
 /* Synthetic base table of SURVEY.md §8d: P_i = (f*g^i mod r)*G written to device memory as affine Montgomery points
  * (what G.batchApplyKey(G repeated n, Fr.e(f), Fr.e(g)) returns).  For benchmarks and tests. */
