@@ -320,60 +320,67 @@ def main():
     # ---- one large G1 MSM sharded by base-index range over the ranks (north star: "G1 MSM shards across the GPUs ... final
     # RCCL reduce"): every rank runs the device Pippenger on its slice, one all_gather of the partial points, local fold.
     sharded = None
+    extras_failed = False
     if dist is not None:
-        from snarkjs_amd import distributed as D
-        n_tot = 1 << (lg + 2)
-        lo, hi = D.shard_range(n_tot, rank, world)
-        k = hi - lo
-        d_bs = zkmi.DeviceBuffer(max(k, 1) * 2 * q8)
-        zkmi.check(L.zkmi_gen_geometric_bases_dev(cid, 1, max(k, 1), 7 + rank, 11, d_bs.ptr))
-        d_ss = zkmi.DeviceBuffer.from_host(synth.elems(0xD157 + rank, max(k, 1)))
+        # The replica metric above is complete at this point; the two multi-rank extras below must never cost the line: any error in them is
+        # reported inside the line and the process then leaves without further collectives.
+        try:
+            from snarkjs_amd import distributed as D
+            n_tot = 1 << (lg + 2)
+            lo, hi = D.shard_range(n_tot, rank, world)
+            k = hi - lo
+            d_bs = zkmi.DeviceBuffer(max(k, 1) * 2 * q8)
+            zkmi.check(L.zkmi_gen_geometric_bases_dev(cid, 1, max(k, 1), 7 + rank, 11, d_bs.ptr))
+            d_ss = zkmi.DeviceBuffer.from_host(synth.elems(0xD157 + rank, max(k, 1)))
 
-        class _Cv:
-            id = cid
-            G1 = G2 = None
+            class _Cv:
+                id = cid
+                G1 = G2 = None
 
-        def shard_msm(_b, _s):
-            o = np.zeros(3 * q8, np.uint8)
-            if k:
-                zkmi.check(L.zkmi_msm_dev(cid, 1, d_bs.ptr, d_ss.ptr, k, 32, zkmi.ptr(o)))
-            return o
-        D.msm_sharded(_Cv, 1, None, None, compute=shard_msm)
-        barrier()
-        ts = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
+            def shard_msm(_b, _s):
+                o = np.zeros(3 * q8, np.uint8)
+                if k:
+                    zkmi.check(L.zkmi_msm_dev(cid, 1, d_bs.ptr, d_ss.ptr, k, 32, zkmi.ptr(o)))
+                return o
             D.msm_sharded(_Cv, 1, None, None, compute=shard_msm)
-        barrier()
-        tsh = torch.tensor([time.perf_counter() - ts], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
-        sharded = {"terms": n_tot, "ms": round(float(tsh.item()) / reps * 1e3, 3), "mscalar_per_s": round(n_tot * reps / float(tsh.item()) / 1e6, 2),
-                   "exchange": "all_gather of %d x %d-byte partial points + host fold" % (world, 3 * q8)}
-        d_bs.free(); d_ss.free()
-        # ---- ONE Groth16 proof stream over all ranks (BASELINE configs[2]: MSMs sharded by base-index range): every rank holds
-        # 1/world of the five base sections of the SAME key; the three NTT chains run on different ranks, slices of their outputs are
-        # exchanged point to point, one all_gather of 7*3*n8q bytes per proof (snarkjs_amd/distributed.py)
-        if rank == 0:
-            zkey0, wtns0 = zkey, wtns
-        else:
-            zkey0, wtns0 = synth_zkey.make(args.curve, lg, seed=0x5EED, witness=args.witness, b_zero_every=args.b_zero_every)
-        pks = groth16.ProvingKey(zkey0, shard=(rank, world))
-        d_w0 = zkmi.DeviceBuffer.from_host(binfile.read_wtns(wtns0)["witness"])
-        for _ in range(2):
-            sh_proof = D.groth16_prove_sharded(pks, None, r_m, s_m, d_witness=d_w0.ptr)
-        barrier()
-        ts = time.perf_counter()
-        reps = max(3, args.steps // 2)
-        for _ in range(reps):
-            sh_proof = D.groth16_prove_sharded(pks, None, r_m, s_m, d_witness=d_w0.ptr)
-        barrier()
-        tsh = torch.tensor([time.perf_counter() - ts], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
-        same = all(np.array_equal(a, b) for a, b in zip(sh_proof, proof_pts)) if rank == 0 else True
-        sharded["groth16_one_proof_over_all_ranks"] = {"ms_per_proof": round(float(tsh.item()) / reps * 1e3, 3), "proofs_per_s": round(reps / float(tsh.item()), 3),
-                                                         "log_n": lg, "scaling": "strong", "equals_single_device_proof": bool(same),
-                                                         "exchange": "chain-parallel transforms (chain c on rank c %% world), point-to-point slices of the chain outputs (%d bytes leave each chain owner), all_gather of %d x %d-byte MSM sums + host fold" % ((1 << lg) * 32, world, 21 * q8)}
-        pks.release(); d_w0.free()
+            barrier()
+            ts = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                D.msm_sharded(_Cv, 1, None, None, compute=shard_msm)
+            barrier()
+            tsh = torch.tensor([time.perf_counter() - ts], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
+            sharded = {"terms": n_tot, "ms": round(float(tsh.item()) / reps * 1e3, 3), "mscalar_per_s": round(n_tot * reps / float(tsh.item()) / 1e6, 2),
+                       "exchange": "all_gather of %d x %d-byte partial points + host fold" % (world, 3 * q8)}
+            d_bs.free(); d_ss.free()
+            # ---- ONE Groth16 proof stream over all ranks (BASELINE configs[2]: MSMs sharded by base-index range): every rank holds
+            # 1/world of the five base sections of the SAME key; the three NTT chains run on different ranks, slices of their outputs are
+            # exchanged point to point, one all_gather of 7*3*n8q bytes per proof (snarkjs_amd/distributed.py)
+            if rank == 0:
+                zkey0, wtns0 = zkey, wtns
+            else:
+                zkey0, wtns0 = synth_zkey.make(args.curve, lg, seed=0x5EED, witness=args.witness, b_zero_every=args.b_zero_every)
+            pks = groth16.ProvingKey(zkey0, shard=(rank, world))
+            d_w0 = zkmi.DeviceBuffer.from_host(binfile.read_wtns(wtns0)["witness"])
+            for _ in range(2):
+                sh_proof = D.groth16_prove_sharded(pks, None, r_m, s_m, d_witness=d_w0.ptr)
+            barrier()
+            ts = time.perf_counter()
+            reps = max(3, args.steps // 2)
+            for _ in range(reps):
+                sh_proof = D.groth16_prove_sharded(pks, None, r_m, s_m, d_witness=d_w0.ptr)
+            barrier()
+            tsh = torch.tensor([time.perf_counter() - ts], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
+            same = all(np.array_equal(a, b) for a, b in zip(sh_proof, proof_pts)) if rank == 0 else True
+            sharded["groth16_one_proof_over_all_ranks"] = {"ms_per_proof": round(float(tsh.item()) / reps * 1e3, 3), "proofs_per_s": round(reps / float(tsh.item()), 3),
+                                                             "log_n": lg, "scaling": "strong", "equals_single_device_proof": bool(same),
+                                                             "exchange": "chain-parallel transforms (chain c on rank c %% world), point-to-point slices of the chain outputs (%d bytes leave each chain owner), all_gather of %d x %d-byte MSM sums + host fold" % ((1 << lg) * 32, world, 21 * q8)}
+            pks.release(); d_w0.free()
+        except Exception as e:                               # noqa: BLE001 — report, do not die
+            extras_failed = True
+            sharded = dict(sharded or {}, error=repr(e)[:400])
 
     out = None
     if rank == 0:
@@ -488,12 +495,15 @@ def main():
             pk_s.release()
     if out is not None:
         out["box_calibration"] = box_calibration(L)
-    if dist is not None:
+    if dist is not None and not extras_failed:
         dist.barrier()
         dist.destroy_process_group()
     drain_c_stdout_to_stderr()                   # every rank: nothing but rank 0's JSON line may reach stdout
     if out is not None:
         print(json.dumps(out), flush=True)       # the ONE JSON line, after everything else this process may write
+    if extras_failed:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)                              # the communicator may be unusable: no teardown collectives
 
 
 if __name__ == "__main__":
