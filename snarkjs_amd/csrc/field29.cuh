@@ -228,12 +228,13 @@ template <class C> ZK_DEV Fp29<C> from_r256(const uint32_t* p) {
     for (int i = 0; i < 9; i++) k.l[i] = Lim29<C>::kin(i);
     return mul29(load29_packed<C>(p), k);
 }
-// R'-form limbs (any lazy value below 2^258) -> reference format: multiply by 2^256 mod p (result < 1.6 p), subtract p while >= p, pack
-template <class C> ZK_DEV void store_r256(uint32_t* dst, const Fp29<C>& a_in) {
+// R'-form limbs (any lazy value below 2^258) -> 8 canonical words: multiply by 2^256 mod p (the reference's R-form) or, KEEP29, by R' mod p
+// (the value stays in R'-form: a later load is unpack29 alone); the product is < 1.6 p: subtract p while >= p, pack
+template <class C, bool KEEP29 = false> ZK_DEV void store_r256(uint32_t* dst, const Fp29<C>& a_in) {
     Fp29<C> k, a = a_in;
     norm29(a);
 #pragma unroll
-    for (int i = 0; i < 9; i++) k.l[i] = Lim29<C>::kout(i);
+    for (int i = 0; i < 9; i++) k.l[i] = KEEP29 ? Lim29<C>::one(i) : Lim29<C>::kout(i);
     Fp29<C> t = mul29(a, k);
 #pragma unroll 1
     for (int rep = 0; rep < 2; rep++) {
@@ -257,5 +258,6 @@ template <class C> ZK_DEV void store_r256(uint32_t* dst, const Fp29<C>& a_in) {
     uint4* q = reinterpret_cast<uint4*>(dst);
     q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
+template <class C> ZK_DEV void store_r29(uint32_t* dst, const Fp29<C>& a) { store_r256<C, true>(dst, a); }
 
 }  // namespace zkmi

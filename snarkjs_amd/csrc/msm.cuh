@@ -325,6 +325,12 @@ ZK_DEV uint32_t msm_key(uint32_t cnt, uint32_t cap) {
 }
 ZK_DEV uint32_t msm_key_lanes_log(uint32_t key, uint32_t cap) { return key < 2 * cap ? 0u : key - (2 * cap - 1); }
 
+// every coordinate times 2^5: the same point with its coordinates moved from the reference's R-form (x 2^256) to the R'-form of field29.cuh
+// (x 2^261) — buckets whose row / column sums are formed on 29-bit limbs (msm29.cuh: k_msm_rowcol_wave29) are kept in that form
+template <class F> ZK_DEV void pt_scale32(XYZZ<F>& p) {
+#pragma unroll 1
+    for (int k = 0; k < 5; k++) { p.X = f_dbl(p.X); p.Y = f_dbl(p.Y); p.ZZ = f_dbl(p.ZZ); p.ZZZ = f_dbl(p.ZZZ); }
+}
 static __global__ void __launch_bounds__(256) k_msm_classify(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[MSM_NKEYS];
     for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) h[i] = 0;
@@ -454,7 +460,7 @@ static __global__ void k_msm_counts_add(const uint32_t* __restrict__ a, const ui
 // lanes; groups wider than a block leave one partial per block for k_msm_giant.
 template <class F, int TB> __global__ void __launch_bounds__(TB)
 k_msm_tree(const uint32_t* __restrict__ lane_partials, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ counts, uint32_t cap,
-           const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ block_partials) {
+           const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ block_partials, int bucket_x32) {
     constexpr int PW = 4 * FieldWords<F>::value;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t jmax_s;
@@ -483,14 +489,14 @@ k_msm_tree(const uint32_t* __restrict__ lane_partials, const uint32_t* __restric
             __syncthreads();
         }
         if (lane < multi) {
-            if (j <= LOG_TB) { if ((t & ((1u << j) - 1)) == 0) pt_store(buckets + (size_t)g * PW, acc); }
+            if (j <= LOG_TB) { if ((t & ((1u << j) - 1)) == 0) { if (bucket_x32) pt_scale32(acc); pt_store(buckets + (size_t)g * PW, acc); } }
             else if (t == 0) pt_store(block_partials + (size_t)blk * PW, acc);
         }
         __syncthreads();
     }
 }
 template <class F, int TB> __global__ void __launch_bounds__(TB)
-k_msm_giant(const uint32_t* __restrict__ giants, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ block_partials, uint32_t* __restrict__ buckets) {
+k_msm_giant(const uint32_t* __restrict__ giants, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ block_partials, uint32_t* __restrict__ buckets, int bucket_x32) {
     constexpr int PW = 4 * FieldWords<F>::value;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t t = threadIdx.x, ngiants = meta[2];
@@ -505,7 +511,7 @@ k_msm_giant(const uint32_t* __restrict__ giants, const uint32_t* __restrict__ me
             if (t < (uint32_t)d) { XYZZ<F> o; pt_load(o, lds + (t + d) * PW); acc = pt_add(acc, o); pt_store(lds + t * PW, acc); }
             __syncthreads();
         }
-        if (t == 0) pt_store(buckets + (size_t)g * PW, acc);
+        if (t == 0) { if (bucket_x32) pt_scale32(acc); pt_store(buckets + (size_t)g * PW, acc); }
         __syncthreads();
     }
 }

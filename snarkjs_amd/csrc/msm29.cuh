@@ -47,14 +47,55 @@ template <class C> ZK_DEV void madd29(XYZZ29<C>& acc, bool& inf, const Aff29<C>&
     acc.ZZ = mul29(acc.ZZ, PP); acc.ZZZ = mul29(acc.ZZZ, PPP);
     acc.X = X3; acc.Y = Y3;
 }
-template <class C> ZK_DEV void store_xyzz29(uint32_t* dst, const XYZZ29<C>& a, bool inf) {
+// KEEP29: canonical words in R'-form (buckets that the 29-bit row/column sums read back with shifts alone); else the reference's R-form
+template <class C, bool KEEP29 = false> ZK_DEV void store_xyzz29(uint32_t* dst, const XYZZ29<C>& a, bool inf) {
     if (inf) {
 #pragma unroll
         for (int i = 0; i < 8; i++) reinterpret_cast<uint4*>(dst)[i] = make_uint4(0, 0, 0, 0);
         return;
     }
-    store_r256(dst, a.X); store_r256(dst + 8, a.Y); store_r256(dst + 16, a.ZZ); store_r256(dst + 24, a.ZZZ);
+    store_r256<C, KEEP29>(dst, a.X); store_r256<C, KEEP29>(dst + 8, a.Y); store_r256<C, KEEP29>(dst + 16, a.ZZ); store_r256<C, KEEP29>(dst + 24, a.ZZZ);
 }
+// a point stored by store_xyzz29<C, true> (all-zero = infinity)
+template <class C> ZK_DEV bool load_xyzz29(XYZZ29<C>& a, const uint32_t* src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    const uint4 z0 = q[4], z1 = q[5];
+    if (!(z0.x | z0.y | z0.z | z0.w | z1.x | z1.y | z1.z | z1.w)) return false;
+    a.X = load29_packed<C>(src); a.Y = load29_packed<C>(src + 8); a.ZZ = load29_packed<C>(src + 16); a.ZZZ = load29_packed<C>(src + 24);
+    return true;
+}
+// acc = 2 acc for a general XYZZ accumulator (dbl-2008-s-1, a = 0): the rare equal-points branch of padd29. Same invariants as madd29.
+template <class C> ZK_DEV void dbl_xyzz29(XYZZ29<C>& r) {
+    Fp29<C> U = add29(r.Y, r.Y); norm29(U);                                     // <= 6.6
+    const Fp29<C> V = sqr29(U), W = mul29(U, V), S = mul29(r.X, V), xx = sqr29(r.X);            // <= 1.26, 1.05, 1.06, 1.32
+    Fp29<C> M = add29(add29(xx, xx), xx); norm29(M);                            // <= 3.96
+    Fp29<C> X3 = sub29<C, 2>(sub29<C, 2>(sqr29(M), S), S); norm29(X3);          // <= 1.1 + 4 = 5.1
+    Fp29<C> T = sub29<C, 6>(S, X3); norm29(T);                                  // <= 7.1
+    const Fp29<C> Y3 = mul29_2(M, T, sub29<C, 2>(zero29<C>(), W), r.Y);         // (M T + (2p - W) Y) / R' + p <= (28.1 + 6.6) / 169 + 1 = 1.21
+    r.ZZ = mul29(V, r.ZZ); r.ZZZ = mul29(W, r.ZZZ);
+    r.X = X3; r.Y = Y3;
+}
+// acc += p for two general XYZZ points (add-2008-s, 12M + 2S, the last two products share one reduction). Both operands within the
+// invariants of madd29 (X <= 7.3, Y <= 3.3, ZZ, ZZZ <= 1.1, normalised; a point just unpacked from memory is canonical); the result too.
+template <class C> ZK_DEV void padd29(XYZZ29<C>& acc, bool& inf, const XYZZ29<C>& p) {
+    if (inf) { acc = p; inf = false; return; }
+    const Fp29<C> U1 = mul29(acc.X, p.ZZ), U2 = mul29(p.X, acc.ZZ);             // <= 1.05
+    Fp29<C> P = sub29<C, 2>(U2, U1); norm29(P);                                 // <= 3.05
+    const Fp29<C> S1 = mul29(acc.Y, p.ZZZ), S2 = mul29(p.Y, acc.ZZZ);           // <= 1.03
+    Fp29<C> R = sub29<C, 2>(S2, S1); norm29(R);                                 // <= 3.03
+    if (is_zero29(P)) {
+        if (is_zero29(R)) dbl_xyzz29(acc); else inf = true;
+        return;
+    }
+    const Fp29<C> PP = sqr29(P);                                                // <= 1.06
+    const Fp29<C> PPP = mul29(P, PP), Q = mul29(U1, PP);                        // <= 1.02, 1.01
+    Fp29<C> X3 = sub29<C, 2>(sub29<C, 2>(sub29<C, 2>(sqr29(R), PPP), Q), Q); norm29(X3);          // <= 1.06 + 6 = 7.06
+    Fp29<C> T = sub29<C, 8>(Q, X3); norm29(T);                                  // <= 9.1
+    const Fp29<C> Y3 = mul29_2(R, T, sub29<C, 2>(zero29<C>(), S1), PPP);        // (R T + (2p - S1) PPP) / R' + p <= (27.6 + 2.1) / 169 + 1 = 1.18
+    acc.ZZ = mul29(mul29(acc.ZZ, p.ZZ), PP); acc.ZZZ = mul29(mul29(acc.ZZZ, p.ZZZ), PPP);
+    acc.X = X3; acc.Y = Y3;
+}
+
 
 // one base-field element of a window table: canonical R-form -> canonical R'-form (x * 2^5 mod p), in place; all-zero stays all-zero
 template <class C> __global__ void __launch_bounds__(256) k_table_to_r29(uint32_t* __restrict__ table, size_t n_elems) {
@@ -70,7 +111,7 @@ template <class C> __global__ void __launch_bounds__(256) k_table_to_r29(uint32_
 template <class C, bool MERGE> __global__ void __launch_bounds__(256, 2)
 k_msm_accum29(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ infmask, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts,
               const uint32_t* __restrict__ starts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub,
-              const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials, const uint32_t* __restrict__ prev_counts) {
+              const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials, const uint32_t* __restrict__ prev_counts, int bucket_r29) {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= meta[0]) return;
     const uint32_t g = lane_g[lane];
@@ -90,7 +131,9 @@ k_msm_accum29(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ i
             const uint32_t* b = buckets + (size_t)g * 32;
             const uint4 z0 = reinterpret_cast<const uint4*>(b + 16)[0], z1 = reinterpret_cast<const uint4*>(b + 16)[1];
             if (z0.x | z0.y | z0.z | z0.w | z1.x | z1.y | z1.z | z1.w) {
-                acc.X = from_r256<C>(b); acc.Y = from_r256<C>(b + 8); acc.ZZ = from_r256<C>(b + 16); acc.ZZZ = from_r256<C>(b + 24);
+                if (bucket_r29) {                                    // buckets kept in R'-form: shifts alone
+                    acc.X = load29_packed<C>(b); acc.Y = load29_packed<C>(b + 8); acc.ZZ = load29_packed<C>(b + 16); acc.ZZZ = load29_packed<C>(b + 24);
+                } else { acc.X = from_r256<C>(b); acc.Y = from_r256<C>(b + 8); acc.ZZ = from_r256<C>(b + 16); acc.ZZZ = from_r256<C>(b + 24); }
                 inf = false;
             }
         }
@@ -126,7 +169,60 @@ k_msm_accum29(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ i
         if (e >> 31) { q.y = sub29<C, 2>(zero29<C>(), q.y); norm29(q.y); }      // 2p - y
         madd29(acc, inf, q);
     }
-    store_xyzz29(j ? lane_partials + (size_t)lane * 32 : buckets + (size_t)g * 32, acc, inf);
+    // lane partials of multi-lane buckets go to k_msm_tree in the reference's R-form; finished buckets stay in R'-form for the 29-bit row /
+    // column sums (k_msm_rowcol_wave29) and for a later merge into the same buckets
+    if (j) store_xyzz29<C, false>(lane_partials + (size_t)lane * 32, acc, inf);
+    else if (bucket_r29) store_xyzz29<C, true>(buckets + (size_t)g * 32, acc, inf);
+    else store_xyzz29<C, false>(buckets + (size_t)g * 32, acc, inf);
+}
+
+// Row / column sums of the 2-D bucket reduction (msm.cuh: k_msm_rowcol_wave) over R'-form buckets on 29-bit limbs: one wave per sum, 64 lanes add
+// strided shares, then a 6-level tree through LDS in the same launch; the sums leave in the reference's R-form (k_msm_bitsums reads them).
+template <class C> __global__ void __launch_bounds__(256)
+k_msm_rowcol_wave29(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_t cbits, uint32_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                  // 256 lanes x 36 words
+    __shared__ uint32_t inf_s[256];
+    const uint32_t Cn = 1u << cbits, R = 1u << rbits;
+    const uint32_t t = threadIdx.x, sub = t & 63u;
+    const size_t n_out = (size_t)rb.njobs * W * 2 * Cn;
+    for (size_t blk = blockIdx.x; blk * 4 < n_out; blk += gridDim.x) {
+        const size_t gw = blk * 4 + (t >> 6);                    // sum index: ((job*W + w)*2 + kind)*C + i
+        const bool valid = gw < n_out;
+        const uint32_t i = (uint32_t)(gw & (Cn - 1)), kind = (uint32_t)(gw >> cbits) & 1u;
+        const size_t jw = gw >> (cbits + 1);
+        const uint32_t w = (uint32_t)(jw % W), job = (uint32_t)(jw / W);
+        XYZZ29<C> acc;
+        bool inf = true;
+        if (valid) {
+            const uint32_t* bk = rb.buckets[job];
+            const uint32_t* cn = rb.counts[job];
+            const uint32_t cnt = kind ? R : Cn;
+            if (!kind && i >= R) { /* row index beyond the row count: empty sum */ }
+            else for (uint32_t e = sub; e < cnt; e += 64) {
+                const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
+                XYZZ29<C> p;
+                if (cn[g] && load_xyzz29(p, bk + g * 32)) padd29(acc, inf, p);
+            }
+        }
+        uint32_t* mine = lds + t;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            inf_s[t] = inf ? 1u : 0u;
+            if (!inf) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) { mine[k * 256] = acc.X.l[k]; mine[(9 + k) * 256] = acc.Y.l[k]; mine[(18 + k) * 256] = acc.ZZ.l[k]; mine[(27 + k) * 256] = acc.ZZZ.l[k]; }
+            }
+            __syncthreads();
+            if ((t & (2 * d - 1)) == 0 && !inf_s[t + d]) {
+                XYZZ29<C> o;
+                const uint32_t* pn = lds + t + d;
+#pragma unroll
+                for (int k = 0; k < 9; k++) { o.X.l[k] = pn[k * 256]; o.Y.l[k] = pn[(9 + k) * 256]; o.ZZ.l[k] = pn[(18 + k) * 256]; o.ZZZ.l[k] = pn[(27 + k) * 256]; }
+                padd29(acc, inf, o);
+            }
+            __syncthreads();
+        }
+        if (valid && sub == 0) store_xyzz29<C, false>(out + gw * 32, acc, inf);
+    }
 }
 
 // ---- G2: Fq2 = Fq[u]/(u^2 + 1) over 29-bit limbs ------------------------------------------------------------------------------

@@ -110,6 +110,7 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& plan, int plan
 struct MsmJob {
     int W = 0, c = 0, cbits = 0, slot = 0;
     bool merged = false;                            // accumulated into another job's buckets (msm_accumulate `into`)
+    bool r29 = false;                               // the buckets hold R'-form words (msm29.cuh): reduced by k_msm_rowcol_wave29
     int bitsums = 0;                                // h_win holds per (array, k) plain sums (k_msm_bitsums) instead of weighted sums
     uint32_t nb = 0;
     uint32_t* h_win = nullptr;                      // pinned host: 2W weighted sums then 2W totals (XYZZ)
@@ -160,18 +161,21 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
         acc_attr = true;
     }
     if (job.acc0) ZK_HIP(hipEventRecord(job.acc0, st));
-    bool launched = false;
+    bool launched = false, r29_buckets = false;
     if constexpr (std::is_same<F, Fp<Bn254Fq>>::value) {
         // window tables registered in the R'-form of field29.cuh: the hot loop on unsaturated 29-bit limbs
         auto r29 = cx.r29_tables.find(d_bases);
         if (r29 != cx.r29_tables.end() && sh.precomp) {
+            // ZKMI_R29_REDUCE=0: buckets leave the kernel in the reference's R-form and the generic row / column sums reduce them
+            static const bool r29_reduce = !(getenv("ZKMI_R29_REDUCE") && atoi(getenv("ZKMI_R29_REDUCE")) == 0) && !(getenv("ZKMI_ROWCOL_WAVE") && atoi(getenv("ZKMI_ROWCOL_WAVE")) == 0);
             launched = true;
+            r29_buckets = into ? into->r29 : (r29_reduce && (sh.c - 1) / 2 >= 6);       // the wave row/column sums need >= 64 buckets per row and column
             const uint32_t* mask = d_infmask ? d_infmask : r29->second;
             const dim3 grid((unsigned)((pl.lane_bound + 255) / 256));
             if (into) hipLaunchKernelGGL((k_msm_accum29<Bn254Fq, true>), grid, dim3(256), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
-                                         pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);
+                                         pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts, (int)r29_buckets);
             else hipLaunchKernelGGL((k_msm_accum29<Bn254Fq, false>), grid, dim3(256), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
-                                    pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);
+                                    pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts, (int)r29_buckets);
         }
     }
     if constexpr (std::is_same<F, Fp2<Bn254Fq>>::value) {
@@ -185,6 +189,7 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
                                d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials);
         }
     }
+    if (into && !launched && into->r29) return fail(ZKMI_ERR_INVALID, "msm_accumulate: merge target holds R'-form buckets");
     if constexpr (!WIDE) if (into && !launched) {
         launched = true;
         hipLaunchKernelGGL((k_msm_accum<F, false, true>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_bases, d_infmask, sh, skip, pl.cap, pl.counts,
@@ -195,10 +200,11 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
                            pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);
     if (job.acc1) ZK_HIP(hipEventRecord(job.acc1, st));
     hipLaunchKernelGGL((k_msm_tree<F, MSM_TB>), dim3((unsigned)std::min<size_t>(tree_blocks, 512)), dim3(MSM_TB), tree_lds, st, lane_partials, pl.lane_g, pl.counts, pl.cap, pl.meta, buckets,
-                       block_partials);
-    hipLaunchKernelGGL((k_msm_giant<F, MSM_TB>), dim3((unsigned)std::min<size_t>(tree_blocks, 256)), dim3(MSM_TB), tree_lds, st, pl.giants, pl.meta, block_partials, buckets);
+                       block_partials, (int)r29_buckets);
+    hipLaunchKernelGGL((k_msm_giant<F, MSM_TB>), dim3((unsigned)std::min<size_t>(tree_blocks, 256)), dim3(MSM_TB), tree_lds, st, pl.giants, pl.meta, block_partials, buckets, (int)r29_buckets);
     job.W = sh.W; job.c = sh.c; job.nb = sh.nb; job.buckets = buckets; job.counts = pl.counts;
     job.merged = into != nullptr;
+    job.r29 = r29_buckets;
     if (into) {
         uint32_t* cmb;
         ZK_TRY(ws_get("msm.cmbcounts." + std::to_string(into->slot), total * 4, (void**)&cmb));
@@ -253,7 +259,21 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
     // ZKMI_ROWCOL_WAVE=0 keeps the staged k_msm_rowcol + k_msm_fold sequence
     static const bool wave_env = !(getenv("ZKMI_ROWCOL_WAVE") && atoi(getenv("ZKMI_ROWCOL_WAVE")) == 0);
     const bool wave_rc = wave_env && rbits >= 6 && cbits >= 6;
-    if (wave_rc) {
+    bool all_r29 = std::is_same<F, Fp<Bn254Fq>>::value;
+    for (int i = 0; i < njobs; i++) all_r29 = all_r29 && jobs[i]->r29;
+    for (int i = 0; i < njobs; i++) if (jobs[i]->r29 != jobs[0]->r29) return fail(ZKMI_ERR_INVALID, "msm_reduce: jobs with different bucket formats");
+    if (jobs[0]->r29 && !(all_r29 && wave_rc)) return fail(ZKMI_ERR_UNSUPPORTED, "msm_reduce: R'-form buckets need the wave row/column sums");
+    if (all_r29 && wave_rc) {
+        if constexpr (std::is_same<F, Fp<Bn254Fq>>::value) {
+            constexpr size_t lds29 = (size_t)256 * 36 * 4;
+            static bool rc29_attr = false;
+            if (!rc29_attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave29<Bn254Fq>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29)); rc29_attr = true; }
+            size_t rc_blocks = (n_out + 3) / 4;
+            static const int aux_cap29 = getenv("ZKMI_AUX_RC_SUMS") ? atoi(getenv("ZKMI_AUX_RC_SUMS")) : 512;
+            if (aux && aux_cap29 > 0) rc_blocks = std::min<size_t>(rc_blocks, (size_t)aux_cap29 / 4);
+            hipLaunchKernelGGL((k_msm_rowcol_wave29<Bn254Fq>), dim3((unsigned)rc_blocks), dim3(256), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
+        }
+    } else if (wave_rc) {
         constexpr int T = MsmRcBlock<F>::value;
         const size_t lds_rc = (size_t)T * PW * 4;
         static bool rc_attr = false;
