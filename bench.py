@@ -23,11 +23,15 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# measured Montgomery-multiply ceilings of the chip, Gmul/s, in the limb form the accumulation kernels of the curve use: BN254 Fq on
-# unsaturated 29-bit limbs (field29.cuh), BLS12-381 Fq on saturated 32-bit limbs (tools/fieldbench, profiles/r01_fieldbench.txt)
-VALU_PER_ADD = {"g1": 2227, "g2": 5948}       # VALU instructions of one mixed addition, main path (tools/isa_counts.py, k_msm_accum29 / k_msm_accum29_g2)
+# VALU instructions of one mixed addition, main path of the shipped code objects (tools/isa_counts.py -> profiles/r03_isa_counts.md):
+# k_msm_accum29 / k_msm_accum29_g2 per curve
+VALU_PER_ADD = {"bn128": {"g1": 2238, "g2": 5944}, "bls12381": {"g1": 5012, "g2": 13373}}
 VALU_ISSUE_PEAK_G = 614.4                      # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave instruction
-FIELD_MUL_PEAK_G = {"bn128": 175.0, "bls12381": 58.6}      # bn128: 9 x 29-bit limbs (tools/fieldbench29, profiles/r02_fieldbench29.txt; 8 x 32-bit limbs: 130)
+# measured Montgomery-multiply ceilings of the chip, Gmul/s at 8 waves per SIMD, in the limb form the accumulation kernels of the curve use
+# (tools/fieldbench29 on the library's own mul29): BN254 Fq 9 x 29-bit limbs, BLS12-381 Fq 14 x 28-bit limbs; the saturated 32-bit forms they
+# replaced measured 130 and 58.6 (tools/fieldbench, profiles/r01_fieldbench.txt). profiles/r03_fieldbench29.txt holds this round's run.
+FIELD_MUL_PEAK_G = {"bn128": 175.0, "bls12381": 80.0}
+FIELD_MUL_PEAK_32 = {"bn128": 130.0, "bls12381": 58.6}
 
 
 def _oracle():
@@ -177,7 +181,7 @@ def bench_plonk(args, rank, world, dist, torch):
         alg = 96 * n                                            # 64-byte affine base + 32-byte scalar per term
         roof = None
         if acc_ms and acc_ms > 0:
-            roof = {"bound": "hbm", "kernel": "k_msm_accum<Fp<Bn254Fq>> (last commitment, n terms)", "achieved": round(alg / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+            roof = {"bound": "hbm", "kernel": ("k_msm_accum29<Bn254Fq>" if os.environ.get("ZKMI_R29", "1") != "0" else "k_msm_accum<Fp<Bn254Fq>>") + " (last commitment, n terms)", "achieved": round(alg / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(alg / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms": round(acc_ms, 4), "algorithmic_bytes": alg,
                     "note": "integer-ALU-bound (256-bit Montgomery carry chains, no MFMA); traffic: no PMC pass for this workload"}
         out = {
@@ -311,6 +315,11 @@ def main():
         for k in range(5):
             accum_ms[k].append(L.zkmi_msm_accum_ms(k))
     assert all(np.array_equal(a, b) for a, b in zip(serial_pts, proof_pts)), "pipelined and serial proofs differ"
+    # mixed additions per accumulation launch, counted ON THE DEVICE from the digit lists of one more serial proof (zkmi_msm_stats)
+    zkmi.check(L.zkmi_msm_stats(1))
+    step()
+    additions = {k: L.zkmi_msm_accum_additions(k) for k in range(5)}
+    zkmi.check(L.zkmi_msm_stats(0))
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -415,7 +424,7 @@ def main():
         acc = {k: float(np.mean(v)) for k, v in accum_ms.items()}
         fq = "Bn254Fq" if cid == 0 else "Bls12381Fq"
         b1, b2 = 2 * q8 + 32, 4 * q8 + 32                     # affine base + 32-byte scalar per term
-        r29 = cid == 0 and os.environ.get("ZKMI_R29", "1") != "0"          # BN254: accumulation kernels on 29-bit limbs (msm29.cuh)
+        r29 = os.environ.get("ZKMI_R29", "1") != "0" and not (cid == 1 and os.environ.get("ZKMI_R29_BLS", "1") == "0")     # accumulation kernels on unsaturated limbs (msm29.cuh)
         k1, k2 = (f"k_msm_accum29<{fq}>", f"k_msm_accum29_g2<{fq}>") if r29 else (f"k_msm_accum<Fp<{fq}>>", f"k_msm_accum<Fp2<{fq}>>")
         names = {0: (f"{k1} (A)", b1), 1: (f"{k1} (B1)", b1), 2: (f"{k2} (B2)", b2), 3: (f"{k1} (C)", b1), 4: (f"{k1} (H)", b1)}
         dom = max(acc, key=lambda k: acc[k])
@@ -438,29 +447,23 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "kernel_ms": round(acc[dom], 4),
                 "algorithmic_bytes": alg_bytes,
                 "note": "integer-ALU-bound (256-bit Montgomery carry chains, no MFMA): see int_alu"}
-        # the resource that actually binds: field multiplications. Digits per scalar with the resident pre-computed tables
-        # (msm_host.hpp: msm_precomp_c); every digit is one mixed addition = 8M+2S, x3 base-field products per Fq2 product (G2).
-        lgv = max(1, units).bit_length() - 1
-        if units > (3 << lgv) // 2:
-            lgv += 1
-        cpre = max(8, min(21, lgv))
-        if lgv >= 14:
-            cpre = [15, 15, 16, 17, 17, 20, 20, 20][min(max(cpre, 14), 21) - 14]
-        digits = -(-254 // cpre) if cid == 0 else -(-255 // cpre)      # non-zero signed digits of a uniform < r scalar (top digits beyond the field size are zero)
-        bze = args.b_zero_every
-        density = (1.0 - 1.0 / bze) if (bze and dom in (1, 2)) else 1.0     # workloads/synth_zkey.py: every bze-th B1 / B2 base is the point at infinity (dropped before the sort)
-        fmuls = int(digits * units * density * (28 if dom == 2 else 10))    # 8M + 2S; in Fq2 a product is 3, a square 2 base-field products
-        int_alu = {"unit": "Gmul/s", "field_muls": fmuls, "achieved": round(fmuls / (acc[dom] * 1e-3) / 1e9, 1), "peak": FIELD_MUL_PEAK_G[args.curve],
-                   "frac": round(fmuls / (acc[dom] * 1e-3) / 1e9 / FIELD_MUL_PEAK_G[args.curve], 4),
-                   "note": "field multiplications of the mixed additions of this launch (digits x non-infinity terms x 10 in G1 / 28 in G2; the Fq2 kernel's ~70 additions per mixed addition are not counted) / launch time; peak = measured Montgomery-multiply ceiling of the chip in the kernel's limb form (BN254: 9 x 29-bit limbs 175 Gmul/s, tools/fieldbench29; BLS12-381: 12 x 32-bit limbs 58.6 Gmul/s, tools/fieldbench); the G2 kernel computes an Fq2 product as two double products with one reduction each (4 multiplications + 2 reductions instead of Karatsuba's 3 + 3): it is counted at Karatsuba's 3"}
-        # VALU issue: static instruction count of the kernel's main path (tools/isa_counts.py on the shipped code object, profiles/r02_isa_counts.md)
+        # the resource that actually binds: field multiplications. Every non-zero signed digit of a scalar whose base is not at infinity is one
+        # mixed addition (8M + 2S; x3 base-field products per Fq2 product in G2, Karatsuba's count); the additions of the launch are COUNTED ON
+        # THE DEVICE from the digit lists of a serial proof (zkmi_msm_accum_additions), not modelled from the scalar distribution.
+        adds = additions.get(dom, -1.0)
+        peak_mul = FIELD_MUL_PEAK_G[args.curve] if r29 else FIELD_MUL_PEAK_32[args.curve]
+        fmuls = int(adds * (28 if dom == 2 else 10))
+        limb_form = ("9 x 29-bit" if cid == 0 else "14 x 28-bit") + " unsaturated limbs" if r29 else ("8" if cid == 0 else "12") + " x 32-bit saturated limbs"
+        int_alu = {"unit": "Gmul/s", "mixed_additions": int(adds), "field_muls": fmuls, "achieved": round(fmuls / (acc[dom] * 1e-3) / 1e9, 1), "peak": peak_mul,
+                   "frac": round(fmuls / (acc[dom] * 1e-3) / 1e9 / peak_mul, 4), "limb_form": limb_form,
+                   "note": "mixed additions of this launch counted on the device (entries of the digit sort whose base is neither skipped nor at infinity) x 10 field multiplications in G1 / 28 in G2 (the Fq2 kernel's ~70 additions per mixed addition are not counted) / launch time; peak = measured Montgomery-multiply ceiling of the chip in the kernel's limb form at 8 waves per SIMD (tools/fieldbench29 / tools/fieldbench); the G2 kernel computes an Fq2 product as two double products with one reduction each (4 multiplications + 2 reductions instead of Karatsuba's 3 + 3): it is counted at Karatsuba's 3"}
+        # VALU issue: static instruction count of the kernel's main path (tools/isa_counts.py on the shipped code object, profiles/r03_isa_counts.md)
         # x additions of the launch, against one wave instruction per SIMD every 4 cycles (1024 SIMDs x 2.4 GHz / 4)
         if r29:
-            vpa = VALU_PER_ADD["g2" if dom == 2 else "g1"]
-            adds = digits * units * density
+            vpa = VALU_PER_ADD[args.curve]["g2" if dom == 2 else "g1"]
             wrate = adds * vpa / 64 / (acc[dom] * 1e-3) / 1e9
             int_alu["valu_issue"] = {"valu_instr_per_addition": vpa, "achieved": round(wrate, 1), "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instr/s", "frac": round(wrate / VALU_ISSUE_PEAK_G, 4),
-                                     "note": "VALU instructions of the main path of one mixed addition (tools/isa_counts.py) x additions / 64 / launch time against one wave instruction per SIMD every 4 cycles; the G2 kernel holds 2 waves per SIMD (LDS-parked Fq2 accumulators + 241 VGPRs), where a dependent v_mad_u64_u32 chain reaches 0.82 of that peak (tools/fieldbench29)"}
+                                     "note": "VALU instructions of the main path of one mixed addition (tools/isa_counts.py) x additions / 64 / launch time against one wave instruction per SIMD every 4 cycles; the BN254 G2 kernel holds 2 waves per SIMD (LDS-parked Fq2 accumulators + 241 VGPRs), the BLS12-381 G2 kernel 1.5 (three 128-lane blocks per CU), where a dependent v_mad_u64_u32 chain reaches 0.82 of that peak at 2 waves (tools/fieldbench29)"}
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -479,6 +482,7 @@ def main():
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "g1_msm_sharded": sharded,
             "accum_kernel_ms": {names[k][0]: round(v, 4) for k, v in acc.items()},
+            "accum_mixed_additions": {names[k][0]: int(v) for k, v in additions.items()},
             "roofline": roof,
             "int_alu": int_alu,
         }

@@ -90,6 +90,12 @@ int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalar
 /* Device time (ms, HIP events on the library stream) of the bucket-accumulation kernel of the last MSM that used job
  * slot `slot`: zkmi_msm / zkmi_msm_dev use slot 0; zkmi_groth16_prove uses 0..4 = A, B1, B2, C, H. -1 if never run. */
 double zkmi_msm_accum_ms(int slot);
+/* Diagnostics for the roofline accounting (bench.py int_alu): with zkmi_msm_stats(1) every bucket-accumulation launch is followed by a
+ * small kernel that counts the mixed additions the launch performed (list entries of the digit sort whose base is not skipped and not the
+ * point at infinity); zkmi_msm_accum_additions(slot) returns the count of the last MSM that used the job slot once the stream has been
+ * synchronised (-1: never counted). Off by default; costs one pass over the sorted lists (~20 us at 2^20 terms) per MSM. */
+int zkmi_msm_stats(int enable);
+double zkmi_msm_accum_additions(int slot);
 /* Resident bases with pre-computed window tables T[k][i] = 2^(c*k) * P_i (static per zkey / SRS: src/groth16_prove.js:84-100,
  * src/polynomial/polynomial.js:970-977 slices the same PTau for every commitment). Build once from n device-resident affine
  * points; each MSM then uses the first k <= n bases with k scalars of at most 32 bytes. */

@@ -11,7 +11,7 @@ namespace zkmi {
 template <class C> __global__ void __launch_bounds__(256) k_calib_mul29(uint32_t* out, int iters) {
     Fp29<C> a, b;
 #pragma unroll
-    for (int i = 0; i < 9; i++) { a.l[i] = (threadIdx.x * 2654435761u + i * 40503u) & M29; b.l[i] = (blockIdx.x * 2246822519u + i * 3266489917u) & M29; }
+    for (int i = 0; i < 9; i++) { a.l[i] = (threadIdx.x * 2654435761u + i * 40503u) & mask29<C>(); b.l[i] = (blockIdx.x * 2246822519u + i * 3266489917u) & mask29<C>(); }
     a.l[8] &= 0xffffu; b.l[8] &= 0xffffu;
     for (int it = 0; it < iters; it++) { a = mul29(a, b); b = mul29(b, a); }
     uint32_t acc = 0;

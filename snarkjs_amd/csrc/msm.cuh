@@ -17,6 +17,7 @@
 // windows on the host, @213360).  Signed digits halve the bucket count: 2^(c-1) buckets per window.
 #pragma once
 #include "curve.cuh"
+#include "field29.cuh"
 
 namespace zkmi {
 
@@ -325,11 +326,12 @@ ZK_DEV uint32_t msm_key(uint32_t cnt, uint32_t cap) {
 }
 ZK_DEV uint32_t msm_key_lanes_log(uint32_t key, uint32_t cap) { return key < 2 * cap ? 0u : key - (2 * cap - 1); }
 
-// every coordinate times 2^5: the same point with its coordinates moved from the reference's R-form (x 2^256) to the R'-form of field29.cuh
-// (x 2^261) — buckets whose row / column sums are formed on 29-bit limbs (msm29.cuh: k_msm_rowcol_wave29) are kept in that form
+// every coordinate times 2^5 (2^8 for BLS12-381): the same point with its coordinates moved from the reference's R-form (x 2^(32 N)) to the
+// R'-form of field29.cuh (x 2^(B NL)) — buckets whose row / column sums are formed on unsaturated limbs (msm29.cuh: k_msm_rowcol_wave29) are
+// kept in that form
 template <class F> ZK_DEV void pt_scale32(XYZZ<F>& p) {
 #pragma unroll 1
-    for (int k = 0; k < 5; k++) { p.X = f_dbl(p.X); p.Y = f_dbl(p.Y); p.ZZ = f_dbl(p.ZZ); p.ZZZ = f_dbl(p.ZZZ); }
+    for (int k = 0; k < r29_shift<typename F::Cfg>(); k++) { p.X = f_dbl(p.X); p.Y = f_dbl(p.Y); p.ZZ = f_dbl(p.ZZ); p.ZZZ = f_dbl(p.ZZZ); }
 }
 static __global__ void __launch_bounds__(256) k_msm_classify(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[MSM_NKEYS];
@@ -451,6 +453,23 @@ k_msm_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ inf
     }
     if (j) pt_store(lane_partials + (size_t)lane * (4 * FW), acc);
     else pt_store(buckets + (size_t)g * (4 * FW), acc);
+}
+// Diagnostics (zkmi_msm_stats): the number of mixed additions an accumulation launch performs = list entries whose base index is >= skip and
+// not flagged in the infinity bitmap. bench.py's int_alu figures use this count instead of a model of the scalar distribution.
+static __global__ void __launch_bounds__(256)
+k_msm_count_adds(const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts, uint32_t total, uint32_t skip,
+                 const uint32_t* __restrict__ infmask, unsigned long long* __restrict__ out) {
+    const uint32_t E = starts[total - 1] + counts[total - 1];
+    uint32_t c = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x) {
+        uint32_t idx = sorted[i] & 0x7fffffffu;
+        if (idx < skip) continue;
+        idx -= skip;
+        if (infmask && ((infmask[idx >> 5] >> (idx & 31)) & 1u)) continue;
+        c++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
 static __global__ void k_msm_counts_add(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t total, uint32_t* __restrict__ out) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;

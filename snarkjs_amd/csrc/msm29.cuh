@@ -1,13 +1,15 @@
-// snarkjs_amd/csrc/msm29.cuh — bucket accumulation over resident window tables on unsaturated 29-bit limbs (field29.cuh).
+// snarkjs_amd/csrc/msm29.cuh — bucket accumulation over resident window tables on unsaturated limbs (field29.cuh): 9 x 29 bits for BN254,
+// 14 x 28 bits for BLS12-381.
 //
 // Same job as k_msm_accum (msm.cuh: one lane per bucket or bucket share, XYZZ mixed additions over the sorted digit lists), but the
-// field arithmetic of the hot loop runs on 9 x 29-bit limbs with lazy additions: 10 products of ~207 instructions instead of ~290 per
-// mixed addition. Boundaries keep the library's formats: window tables are canonical 8-word values in R'-form (k_table_to_r29 converts a
-// table once, when it is built), buckets and lane partials are written in the reference's R-form (store_r256), so the lane-partial
-// trees and the bucket reduction are unchanged.
+// field arithmetic of the hot loop runs on unsaturated limbs with lazy additions: BN254 10 products of ~207 instructions instead of ~290
+// per mixed addition, BLS12-381 ~450 instead of ~620. Boundaries keep the library's formats: window tables are canonical N-word values in
+// R'-form (k_table_to_r29 converts a table once, when it is built), lane partials are written in the reference's R-form (store_r256), so
+// the lane-partial trees are unchanged; finished G1 buckets stay in R'-form for the row / column sums on the same limbs.
 //
-// Value bounds (units of p; R'/p = 170): a product of a and b comes back below a*b/170 + 1. Offsets K of the lazy subtractions are
-// chosen from the bounds noted on each line of madd29.
+// Value bounds (units of p): a product of a and b comes back below a*b/(R'/p) + 1 with R'/p = 169 (BN254) or 2520 (BLS12-381). The bounds
+// noted on each line are those of BN254, the tighter case; offsets K of the lazy subtractions are chosen from them. The point functions are
+// __host__ __device__ like field29.cuh (tools/field29_hosttest.hip runs them on the CPU against Python big integers).
 #pragma once
 #include "field29.cuh"
 #include "msm.cuh"
@@ -18,18 +20,18 @@ template <class C> struct Aff29 { Fp29<C> x, y; };
 template <class C> struct XYZZ29 { Fp29<C> X, Y, ZZ, ZZZ; };          // invariants: X <= 7.3, Y <= 3.3, ZZ, ZZZ <= 1.1; all normalised
 
 // doubling of an affine point (mdbl-2008-s-1, a = 0): the rare equal-points branch of madd29
-template <class C> ZK_DEV void dbl_affine29(XYZZ29<C>& r, const Aff29<C>& q) {
+template <class C> ZK_HD void dbl_affine29(XYZZ29<C>& r, const Aff29<C>& q) {
     Fp29<C> U = add29(q.y, q.y); norm29(U);                                     // <= 4
     const Fp29<C> V = mul29(U, U), W = mul29(U, V), S = mul29(q.x, V), xx = mul29(q.x, q.x);       // <= 1.1
     Fp29<C> M = add29(add29(xx, xx), xx); norm29(M);                            // <= 3.3
     Fp29<C> X3 = sub29<C, 2>(sub29<C, 2>(mul29(M, M), S), S); norm29(X3);       // <= 5.1
-    const Fp29<C> T = sub29<C, 6>(S, X3);                                       // <= 7.1, limbs < 2^31
+    const Fp29<C> T = sub29<C, 6>(S, X3);                                       // <= 7.1, limbs < 2^(B+2)
     Fp29<C> Y3 = sub29<C, 2>(mul29(M, T), mul29(W, q.y)); norm29(Y3);           // <= 3.2
     r.X = X3; r.Y = Y3; r.ZZ = V; r.ZZZ = W;
 }
 // acc += q (q affine, not the point at infinity, x canonical, y <= 2 normalised); inf = accumulator is the point at infinity.
 // 8 products + 2 squarings (sqr29) with 9 reductions: the last two products share one (mul29_2).
-template <class C> ZK_DEV void madd29(XYZZ29<C>& acc, bool& inf, const Aff29<C>& q) {
+template <class C> ZK_HD void madd29(XYZZ29<C>& acc, bool& inf, const Aff29<C>& q) {
     if (inf) { acc.X = q.x; acc.Y = q.y; acc.ZZ = one29<C>(); acc.ZZZ = one29<C>(); inf = false; return; }
     const Fp29<C> U2 = mul29(q.x, acc.ZZ), S2 = mul29(q.y, acc.ZZZ);           // <= 1.1
     Fp29<C> P = sub29<C, 8>(U2, acc.X); norm29(P);                              // X <= 7.3 < 8;  P <= 9.1
@@ -43,29 +45,33 @@ template <class C> ZK_DEV void madd29(XYZZ29<C>& acc, bool& inf, const Aff29<C>&
     Fp29<C> X3 = sub29<C, 2>(sub29<C, 2>(sub29<C, 2>(sqr29(R), PPP), Q), Q); norm29(X3);          // <= 1.16 + 6 = 7.16
     Fp29<C> T = sub29<C, 8>(Q, X3); norm29(T);                                  // <= 9.1
     // Y3 = R T - Y1 PPP as ONE double product with one reduction: (R T + (4p - Y1) PPP) / R' + p <= (46.4 + 4.4) / 169 + 1 = 1.3
-    const Fp29<C> Y3 = mul29_2(R, T, sub29<C, 4>(zero29<C>(), acc.Y), PPP);     // 4p - Y1: limbs < 2^30 (not normalised), as in f2mul
+    const Fp29<C> Y3 = mul29_2(R, T, sub29<C, 4>(zero29<C>(), acc.Y), PPP);     // 4p - Y1: limbs < 2^(B+1) (not normalised), as in f2mul
     acc.ZZ = mul29(acc.ZZ, PP); acc.ZZZ = mul29(acc.ZZZ, PPP);
     acc.X = X3; acc.Y = Y3;
 }
-// KEEP29: canonical words in R'-form (buckets that the 29-bit row/column sums read back with shifts alone); else the reference's R-form
-template <class C, bool KEEP29 = false> ZK_DEV void store_xyzz29(uint32_t* dst, const XYZZ29<C>& a, bool inf) {
+// KEEP29: canonical words in R'-form (buckets that the row/column sums on the same limbs read back with shifts alone); else the reference's R-form
+template <class C, bool KEEP29 = false> ZK_HD void store_xyzz29(uint32_t* dst, const XYZZ29<C>& a, bool inf) {
+    constexpr int N = C::N;
     if (inf) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) reinterpret_cast<uint4*>(dst)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < N; i++) reinterpret_cast<uint4*>(dst)[i] = make_uint4(0, 0, 0, 0);
         return;
     }
-    store_r256<C, KEEP29>(dst, a.X); store_r256<C, KEEP29>(dst + 8, a.Y); store_r256<C, KEEP29>(dst + 16, a.ZZ); store_r256<C, KEEP29>(dst + 24, a.ZZZ);
+    store_r256<C, KEEP29>(dst, a.X); store_r256<C, KEEP29>(dst + N, a.Y); store_r256<C, KEEP29>(dst + 2 * N, a.ZZ); store_r256<C, KEEP29>(dst + 3 * N, a.ZZZ);
 }
 // a point stored by store_xyzz29<C, true> (all-zero = infinity)
-template <class C> ZK_DEV bool load_xyzz29(XYZZ29<C>& a, const uint32_t* src) {
-    const uint4* q = reinterpret_cast<const uint4*>(src);
-    const uint4 z0 = q[4], z1 = q[5];
-    if (!(z0.x | z0.y | z0.z | z0.w | z1.x | z1.y | z1.z | z1.w)) return false;
-    a.X = load29_packed<C>(src); a.Y = load29_packed<C>(src + 8); a.ZZ = load29_packed<C>(src + 16); a.ZZZ = load29_packed<C>(src + 24);
+template <class C> ZK_HD bool load_xyzz29(XYZZ29<C>& a, const uint32_t* src) {
+    constexpr int N = C::N;
+    const uint4* q = reinterpret_cast<const uint4*>(src + 2 * N);
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < N / 4; i++) { const uint4 z = q[i]; nz |= z.x | z.y | z.z | z.w; }
+    if (!nz) return false;
+    a.X = load29_packed<C>(src); a.Y = load29_packed<C>(src + N); a.ZZ = load29_packed<C>(src + 2 * N); a.ZZZ = load29_packed<C>(src + 3 * N);
     return true;
 }
 // acc = 2 acc for a general XYZZ accumulator (dbl-2008-s-1, a = 0): the rare equal-points branch of padd29. Same invariants as madd29.
-template <class C> ZK_DEV void dbl_xyzz29(XYZZ29<C>& r) {
+template <class C> ZK_HD void dbl_xyzz29(XYZZ29<C>& r) {
     Fp29<C> U = add29(r.Y, r.Y); norm29(U);                                     // <= 6.6
     const Fp29<C> V = sqr29(U), W = mul29(U, V), S = mul29(r.X, V), xx = sqr29(r.X);            // <= 1.26, 1.05, 1.06, 1.32
     Fp29<C> M = add29(add29(xx, xx), xx); norm29(M);                            // <= 3.96
@@ -77,7 +83,7 @@ template <class C> ZK_DEV void dbl_xyzz29(XYZZ29<C>& r) {
 }
 // acc += p for two general XYZZ points (add-2008-s, 12M + 2S, the last two products share one reduction). Both operands within the
 // invariants of madd29 (X <= 7.3, Y <= 3.3, ZZ, ZZZ <= 1.1, normalised; a point just unpacked from memory is canonical); the result too.
-template <class C> ZK_DEV void padd29(XYZZ29<C>& acc, bool& inf, const XYZZ29<C>& p) {
+template <class C> ZK_HD void padd29(XYZZ29<C>& acc, bool& inf, const XYZZ29<C>& p) {
     if (inf) { acc = p; inf = false; return; }
     const Fp29<C> U1 = mul29(acc.X, p.ZZ), U2 = mul29(p.X, acc.ZZ);             // <= 1.05
     Fp29<C> P = sub29<C, 2>(U2, U1); norm29(P);                                 // <= 3.05
@@ -97,14 +103,40 @@ template <class C> ZK_DEV void padd29(XYZZ29<C>& acc, bool& inf, const XYZZ29<C>
 }
 
 
-// one base-field element of a window table: canonical R-form -> canonical R'-form (x * 2^5 mod p), in place; all-zero stays all-zero
+// one base-field element of a window table: canonical R-form -> canonical R'-form (x * 2^5 mod p, 2^8 for BLS12-381), in place; all-zero
+// stays all-zero
 template <class C> __global__ void __launch_bounds__(256) k_table_to_r29(uint32_t* __restrict__ table, size_t n_elems) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_elems) return;
     Fp<C> v = fp_load<C>(table + i * C::N);
 #pragma unroll
-    for (int k = 0; k < 5; k++) v = fp_dbl(v);
+    for (int k = 0; k < r29_shift<C>(); k++) v = fp_dbl(v);
     fp_store<C>(table + i * C::N, v);
+}
+
+// Sorted digit lists are read FOUR entries (16 bytes) at a time: a lane comes back for its next entry only after a whole mixed addition
+// (2 200 .. 13 000 instructions), by which time the streaming gathers have evicted the line — a 4-byte read per entry cost a whole 64-byte
+// sector each (r02: 54 MB of lists became 0.87 GB of HBM reads per 2^20 MSM, half of the accumulation's traffic). The group of four is
+// aligned in the flat `sorted` array, so the first and last group of a list may hold neighbours' entries, which are never selected.
+struct ListReader {
+    const uint4* sorted4;
+    uint32_t a, a_end, at = 0xffffffffu;
+    uint4 buf;
+    ZK_DEV ListReader(const uint32_t* sorted, uint32_t first, uint32_t last) : sorted4(reinterpret_cast<const uint4*>(sorted)), a(first), a_end(last), buf(make_uint4(0, 0, 0, 0)) {}
+    ZK_DEV bool more() const { return a < a_end; }
+    ZK_DEV uint32_t next() {
+        const uint32_t grp = a >> 2, sel = a & 3u;
+        if (grp != at) { buf = sorted4[grp]; at = grp; }
+        a++;
+        return sel == 0 ? buf.x : (sel == 1 ? buf.y : (sel == 2 ? buf.z : buf.w));
+    }
+};
+// an affine coordinate (C::N words = C::N / 4 vectors) of a gathered table entry -> limbs
+template <class C> ZK_DEV Fp29<C> unpack29_v(const uint4* v) {
+    uint32_t w[C::N];
+#pragma unroll
+    for (int i = 0; i < C::N / 4; i++) { w[4 * i] = v[i].x; w[4 * i + 1] = v[i].y; w[4 * i + 2] = v[i].z; w[4 * i + 3] = v[i].w; }
+    return unpack29<C>(w);
 }
 
 // G1 accumulation over an R'-form window table (bases = table, infmask required)
@@ -112,6 +144,7 @@ template <class C, bool MERGE> __global__ void __launch_bounds__(256, 2)
 k_msm_accum29(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ infmask, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts,
               const uint32_t* __restrict__ starts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub,
               const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials, const uint32_t* __restrict__ prev_counts, int bucket_r29) {
+    constexpr int N = C::N, PW = 4 * N, AV = N / 2;                 // words per XYZZ point; 16-byte vectors per affine table entry
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= meta[0]) return;
     const uint32_t g = lane_g[lane];
@@ -123,40 +156,40 @@ k_msm_accum29(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ i
         lo = min(cnt, lane_sub[lane] * chunk);
         hi = min(cnt, lo + chunk);
     }
-    const uint32_t* list = sorted + starts[g];
     XYZZ29<C> acc;
     bool inf = true;
     if (MERGE) {
         if (prev_counts[g] && (!j || lane_sub[lane] == 0)) {
-            const uint32_t* b = buckets + (size_t)g * 32;
-            const uint4 z0 = reinterpret_cast<const uint4*>(b + 16)[0], z1 = reinterpret_cast<const uint4*>(b + 16)[1];
-            if (z0.x | z0.y | z0.z | z0.w | z1.x | z1.y | z1.z | z1.w) {
-                if (bucket_r29) {                                    // buckets kept in R'-form: shifts alone
-                    acc.X = load29_packed<C>(b); acc.Y = load29_packed<C>(b + 8); acc.ZZ = load29_packed<C>(b + 16); acc.ZZZ = load29_packed<C>(b + 24);
-                } else { acc.X = from_r256<C>(b); acc.Y = from_r256<C>(b + 8); acc.ZZ = from_r256<C>(b + 16); acc.ZZZ = from_r256<C>(b + 24); }
-                inf = false;
+            const uint32_t* b = buckets + (size_t)g * PW;
+            if (bucket_r29) inf = !load_xyzz29(acc, b);              // buckets kept in R'-form: shifts alone
+            else {
+                uint32_t nz = 0;
+#pragma unroll
+                for (int i = 0; i < N / 4; i++) { const uint4 z = reinterpret_cast<const uint4*>(b + 2 * N)[i]; nz |= z.x | z.y | z.z | z.w; }
+                if (nz) { acc.X = from_r256<C>(b); acc.Y = from_r256<C>(b + N); acc.ZZ = from_r256<C>(b + 2 * N); acc.ZZZ = from_r256<C>(b + 3 * N); inf = false; }
             }
         }
     }
-    uint32_t k = lo;
-    // The gathered point stays in its packed form (4 x 16 bytes) until the iteration that consumes it: unpacking inside fetch would
+    const uint32_t s0 = starts[g];
+    ListReader list(sorted, s0 + lo, s0 + hi);
+    // The gathered point stays in its packed form (AV x 16 bytes) until the iteration that consumes it: unpacking inside fetch would
     // wait for the loads at once and expose the gather latency that the software pipeline is there to hide.
-    struct Raw { uint4 v[4]; };
+    struct Raw { uint4 v[AV]; };
     auto fetch = [&](uint32_t& e_out, Raw& r_out) -> bool {
-        while (k < hi) {
-            const uint32_t e = list[k++];
+        while (list.more()) {
+            const uint32_t e = list.next();
             uint32_t idx = e & 0x7fffffffu;
             if (idx < skip) continue;
             idx -= skip;
             if ((infmask[idx >> 5] >> (idx & 31)) & 1u) continue;
-            const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)idx * 16);
-            r_out.v[0] = p[0]; r_out.v[1] = p[1]; r_out.v[2] = p[2]; r_out.v[3] = p[3];
+            const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)idx * (2 * N));
+#pragma unroll
+            for (int i = 0; i < AV; i++) r_out.v[i] = p[i];
             e_out = e;
             return true;
         }
         return false;
     };
-    auto unpack = [](const uint4& a, const uint4& b) { const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}; return unpack29<C>(w); };
     uint32_t e_next = 0;
     Raw r_next;
     bool have = fetch(e_next, r_next);
@@ -165,22 +198,23 @@ k_msm_accum29(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ i
         const Raw r = r_next;
         have = fetch(e_next, r_next);                       // the next gather is in flight during this addition
         Aff29<C> q;
-        q.x = unpack(r.v[0], r.v[1]); q.y = unpack(r.v[2], r.v[3]);
+        q.x = unpack29_v<C>(r.v); q.y = unpack29_v<C>(r.v + AV / 2);
         if (e >> 31) { q.y = sub29<C, 2>(zero29<C>(), q.y); norm29(q.y); }      // 2p - y
         madd29(acc, inf, q);
     }
-    // lane partials of multi-lane buckets go to k_msm_tree in the reference's R-form; finished buckets stay in R'-form for the 29-bit row /
-    // column sums (k_msm_rowcol_wave29) and for a later merge into the same buckets
-    if (j) store_xyzz29<C, false>(lane_partials + (size_t)lane * 32, acc, inf);
-    else if (bucket_r29) store_xyzz29<C, true>(buckets + (size_t)g * 32, acc, inf);
-    else store_xyzz29<C, false>(buckets + (size_t)g * 32, acc, inf);
+    // lane partials of multi-lane buckets go to k_msm_tree in the reference's R-form; finished buckets stay in R'-form for the row /
+    // column sums on the same limbs (k_msm_rowcol_wave29) and for a later merge into the same buckets
+    if (j) store_xyzz29<C, false>(lane_partials + (size_t)lane * PW, acc, inf);
+    else if (bucket_r29) store_xyzz29<C, true>(buckets + (size_t)g * PW, acc, inf);
+    else store_xyzz29<C, false>(buckets + (size_t)g * PW, acc, inf);
 }
 
-// Row / column sums of the 2-D bucket reduction (msm.cuh: k_msm_rowcol_wave) over R'-form buckets on 29-bit limbs: one wave per sum, 64 lanes add
-// strided shares, then a 6-level tree through LDS in the same launch; the sums leave in the reference's R-form (k_msm_bitsums reads them).
+// Row / column sums of the 2-D bucket reduction (msm.cuh: k_msm_rowcol_wave) over R'-form buckets on unsaturated limbs: one wave per sum, 64
+// lanes add strided shares, then a 6-level tree through LDS in the same launch; the sums leave in the reference's R-form (k_msm_bitsums reads them).
 template <class C> __global__ void __launch_bounds__(256)
 k_msm_rowcol_wave29(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_t cbits, uint32_t* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                  // 256 lanes x 36 words
+    constexpr int NL = Lim29<C>::NL, PW = 4 * C::N;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                  // 256 lanes x 4 NL words
     __shared__ uint32_t inf_s[256];
     const uint32_t Cn = 1u << cbits, R = 1u << rbits;
     const uint32_t t = threadIdx.x, sub = t & 63u;
@@ -201,7 +235,7 @@ k_msm_rowcol_wave29(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, 
             else for (uint32_t e = sub; e < cnt; e += 64) {
                 const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
                 XYZZ29<C> p;
-                if (cn[g] && load_xyzz29(p, bk + g * 32)) padd29(acc, inf, p);
+                if (cn[g] && load_xyzz29(p, bk + g * PW)) padd29(acc, inf, p);
             }
         }
         uint32_t* mine = lds + t;
@@ -209,65 +243,95 @@ k_msm_rowcol_wave29(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, 
             inf_s[t] = inf ? 1u : 0u;
             if (!inf) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) { mine[k * 256] = acc.X.l[k]; mine[(9 + k) * 256] = acc.Y.l[k]; mine[(18 + k) * 256] = acc.ZZ.l[k]; mine[(27 + k) * 256] = acc.ZZZ.l[k]; }
+                for (int k = 0; k < NL; k++) { mine[k * 256] = acc.X.l[k]; mine[(NL + k) * 256] = acc.Y.l[k]; mine[(2 * NL + k) * 256] = acc.ZZ.l[k]; mine[(3 * NL + k) * 256] = acc.ZZZ.l[k]; }
             }
             __syncthreads();
             if ((t & (2 * d - 1)) == 0 && !inf_s[t + d]) {
                 XYZZ29<C> o;
                 const uint32_t* pn = lds + t + d;
 #pragma unroll
-                for (int k = 0; k < 9; k++) { o.X.l[k] = pn[k * 256]; o.Y.l[k] = pn[(9 + k) * 256]; o.ZZ.l[k] = pn[(18 + k) * 256]; o.ZZZ.l[k] = pn[(27 + k) * 256]; }
+                for (int k = 0; k < NL; k++) { o.X.l[k] = pn[k * 256]; o.Y.l[k] = pn[(NL + k) * 256]; o.ZZ.l[k] = pn[(2 * NL + k) * 256]; o.ZZZ.l[k] = pn[(3 * NL + k) * 256]; }
                 padd29(acc, inf, o);
             }
             __syncthreads();
         }
-        if (valid && sub == 0) store_xyzz29<C, false>(out + gw * 32, acc, inf);
+        if (valid && sub == 0) store_xyzz29<C, false>(out + gw * PW, acc, inf);
     }
 }
 
-// ---- G2: Fq2 = Fq[u]/(u^2 + 1) over 29-bit limbs ------------------------------------------------------------------------------
+// ---- G2: Fq2 = Fq[u]/(u^2 + 1) over unsaturated limbs --------------------------------------------------------------------------
 // A product (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u is computed as TWO double products with one Montgomery reduction
-// each (mul29_2; the minus sign is carried by a negated operand K p - b1): 2 x (162 + 81) MACs instead of Karatsuba's 3 x 171 plus its
+// each (mul29_2; the minus sign is carried by a negated operand K p - b1): BN254 2 x (162 + 81) MACs instead of Karatsuba's 3 x 171 plus its
 // five additions / subtractions with their normalisations, and the outputs are plain products again (no offsets to track).
 // A square is (a0 + a1)(a0 - a1) + 2 a0 a1 u.  All operands of mul29_2 must be normalised.
 template <class C> struct F2x { Fp29<C> c0, c1; };
-template <class C, int K> ZK_DEV Fp29<C> neg29(const Fp29<C>& a) { Fp29<C> r = sub29<C, K>(zero29<C>(), a); norm29(r); return r; }     // K p - a
+template <class C, int K> ZK_HD Fp29<C> neg29(const Fp29<C>& a) { Fp29<C> r = sub29<C, K>(zero29<C>(), a); norm29(r); return r; }     // K p - a
 // a * b, nb1 = K p - b.c1 supplied by the caller (often shared by several products)
-template <class C> ZK_DEV F2x<C> f2mul(const F2x<C>& a, const F2x<C>& b, const Fp29<C>& nb1) {
+template <class C> ZK_HD F2x<C> f2mul(const F2x<C>& a, const F2x<C>& b, const Fp29<C>& nb1) {
     return F2x<C>{mul29_2(a.c0, b.c0, a.c1, nb1), mul29_2(a.c0, b.c1, a.c1, b.c0)};
 }
 // a^2 for components <= KB (the offset of the difference)
-template <class C, int KB> ZK_DEV F2x<C> f2sqr(const F2x<C>& a) {
+template <class C, int KB> ZK_HD F2x<C> f2sqr(const F2x<C>& a) {
     Fp29<C> s = add29(a.c0, a.c1), d = sub29<C, KB>(a.c0, a.c1);
-    norm29(d);                                                     // s: limbs < 2^30, d normalised
+    norm29(d);                                                     // s: limbs < 2^(B+1), d normalised
     Fp29<C> t = mul29(a.c0, a.c1);
     Fp29<C> c1 = add29(t, t);
     norm29(c1);
     return F2x<C>{mul29(s, d), c1};
 }
-template <class C, int K> ZK_DEV F2x<C> f2sub(const F2x<C>& a, const F2x<C>& b) { return F2x<C>{sub29<C, K>(a.c0, b.c0), sub29<C, K>(a.c1, b.c1)}; }   // not normalised
-template <class C> ZK_DEV void f2norm(F2x<C>& a) { norm29(a.c0); norm29(a.c1); }
-template <class C> ZK_DEV bool f2zero(const F2x<C>& a) { return is_zero29(a.c0) && is_zero29(a.c1); }
+template <class C, int K> ZK_HD F2x<C> f2sub(const F2x<C>& a, const F2x<C>& b) { return F2x<C>{sub29<C, K>(a.c0, b.c0), sub29<C, K>(a.c1, b.c1)}; }   // not normalised
+template <class C> ZK_HD void f2norm(F2x<C>& a) { norm29(a.c0); norm29(a.c1); }
+template <class C> ZK_HD bool f2zero(const F2x<C>& a) { return is_zero29(a.c0) && is_zero29(a.c1); }
 
-// XYZZ accumulator of a lane parked in LDS: word i of coordinate `coord` of lane t at ((coord * 18 + i) * T + t) (conflict-free)
-template <class C, int T> struct LdsAcc29 {
+// XYZZ accumulator of a lane parked in LDS: word i of component `comp` of coordinate `coord` of lane t at (((2 coord + comp) EW + i) T + t)
+// (conflict-free). PACK = false: EW = NL limbs as they are (BN254: 288 bytes per lane, two 256-lane blocks per CU). PACK = true: EW = N packed
+// words (BLS12-381: 384 instead of 448 bytes per lane — three 128-lane blocks per CU instead of two; every parked value is normalised and
+// below 2^384 = 9.7 p, the shifts cost ~5 % of the addition's instructions and buy half a wave per SIMD).
+template <class C, int T, bool PACK> struct LdsAcc29 {
+    static constexpr int NL = Lim29<C>::NL, EW = PACK ? C::N : NL;
     uint32_t* base;                                                // &lds[threadIdx.x]
-    ZK_DEV void get(int coord, F2x<C>& v) const {
+    ZK_HD void get1(int slot, Fp29<C>& v) const {
+        if constexpr (PACK) {
+            uint32_t w[C::N];
 #pragma unroll
-        for (int i = 0; i < 9; i++) { v.c0.l[i] = base[(coord * 18 + i) * T]; v.c1.l[i] = base[(coord * 18 + 9 + i) * T]; }
-    }
-    ZK_DEV void put(int coord, const F2x<C>& v) const {
+            for (int i = 0; i < C::N; i++) w[i] = base[(slot * EW + i) * T];
+            v = unpack29<C>(w);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 9; i++) { base[(coord * 18 + i) * T] = v.c0.l[i]; base[(coord * 18 + 9 + i) * T] = v.c1.l[i]; }
+            for (int i = 0; i < NL; i++) v.l[i] = base[(slot * EW + i) * T];
+        }
     }
+    ZK_HD void put1(int slot, const Fp29<C>& v) const {
+        if constexpr (PACK) {
+            uint32_t w[C::N];
+            pack29<C>(w, v);
+#pragma unroll
+            for (int i = 0; i < C::N; i++) base[(slot * EW + i) * T] = w[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; i++) base[(slot * EW + i) * T] = v.l[i];
+        }
+    }
+    ZK_HD void get(int coord, F2x<C>& v) const { get1(2 * coord, v.c0); get1(2 * coord + 1, v.c1); }
+    ZK_HD void put(int coord, const F2x<C>& v) const { put1(2 * coord, v.c0); put1(2 * coord + 1, v.c1); }
 };
 // Scheduling fence between Fq2-level operations of madd29_lds: the machine scheduler otherwise interleaves independent Fq2 products up to
 // the register budget of the launch bounds (256 VGPRs + 25 spilled registers whose reloads wait on scratch); fenced, the kernel needs 208
 // VGPRs and no scratch. Inside one Fq2 product the two component chains still overlap. (Same speed on MI355X, r02 A/B: the kernel is bound
 // by integer issue, not by occupancy or spills — a 120-VGPR G1 variant at 4 waves per SIMD measured the same as well.)
+#ifndef ZK_Y3_SPLIT
+#define ZK_Y3_SPLIT(C) (Lim29<C>::NL > 9)
+#endif
+#ifndef ZK_G2_PREFETCH
+#define ZK_G2_PREFETCH(C) true
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
 #define ZK_SFENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ZK_SFENCE() ((void)0)
+#endif
 // acc += q over Fq2. Invariants (units of p, per component): X <= 8.4, Y <= 3.8, ZZ, ZZZ <= 1.1, all normalised. q.x canonical, q.y <= 2.
-template <class C, int T> ZK_DEV void madd29_lds(const LdsAcc29<C, T>& A, bool& inf, const F2x<C>& qx, const F2x<C>& qy) {
+template <class C, class Acc> ZK_HD void madd29_lds(const Acc& A, bool& inf, const F2x<C>& qx, const F2x<C>& qy) {
     F2x<C> t;
     if (inf) {
         A.put(0, qx); A.put(1, qy);
@@ -320,31 +384,54 @@ template <class C, int T> ZK_DEV void madd29_lds(const LdsAcc29<C, T>& A, bool& 
     A.put(0, X3);
     ZK_SFENCE();
     F2x<C> Tq = f2sub<C, 9>(Q, X3); f2norm(Tq);                                         // <= 10.4
-    A.get(1, t);
     // Y3 = Tq R - Y1 PPP with ONE reduction per component (mul29_4, every operand normalised):
     //   c0 = Tq0 R0 + Tq1 (6p - R1) + Y0 (2p - PPP0) + Y1 PPP1      <= (53 + 62.4 + 7.6 + 5.7) / 169 + 1 = 1.8
     //   c1 = Tq0 R1 + Tq1 R0 + Y0 (2p - PPP1) + Y1 (2p - PPP0)      <= (53 + 53 + 7.6 + 7.6) / 169 + 1 = 1.8
-    const Fp29<C> nR1 = neg29<C, 6>(R.c1), nPPP0 = neg29<C, 2>(PPP.c0);
+    // Y3_SPLIT (14-limb moduli, where Tq, R, Y1, PPP and the three negations together exceed the register file next to the prefetched point):
+    // the same sum as two 2-product sums per component — Tq R first, then Y1 and PPP — with two reductions: +392 MACs, half the live operands
+    const Fp29<C> nR1 = neg29<C, 6>(R.c1);
     F2x<C> Y3;
-    Y3.c0 = mul29_4(Tq.c0, R.c0, Tq.c1, nR1, t.c0, nPPP0, t.c1, PPP.c1);
-    Y3.c1 = mul29_4(Tq.c0, R.c1, Tq.c1, R.c0, t.c0, nPPP1, t.c1, nPPP0);
+    if constexpr (ZK_Y3_SPLIT(C)) {
+        const F2x<C> TR{mul29_2(Tq.c0, R.c0, Tq.c1, nR1), mul29_2(Tq.c0, R.c1, Tq.c1, R.c0)};     // <= (53 + 62.4) / 169 + 1 = 1.7
+        ZK_SFENCE();
+        const Fp29<C> nPPP0 = neg29<C, 2>(PPP.c0);
+        A.get(1, t);
+        Y3.c0 = add29(TR.c0, mul29_2(t.c0, nPPP0, t.c1, PPP.c1));                       // <= 1.7 + 1.1
+        Y3.c1 = add29(TR.c1, mul29_2(t.c0, nPPP1, t.c1, nPPP0));
+        f2norm(Y3);
+    } else {
+        const Fp29<C> nPPP0 = neg29<C, 2>(PPP.c0);
+        A.get(1, t);
+        Y3.c0 = mul29_4(Tq.c0, R.c0, Tq.c1, nR1, t.c0, nPPP0, t.c1, PPP.c1);
+        Y3.c1 = mul29_4(Tq.c0, R.c1, Tq.c1, R.c0, t.c0, nPPP1, t.c1, nPPP0);
+    }
     A.put(1, Y3);
 }
-template <class C, int T> ZK_DEV void store_xyzz29_lds(uint32_t* dst, const LdsAcc29<C, T>& A, bool inf) {
+template <class C, class Acc> ZK_HD void store_xyzz29_lds(uint32_t* dst, const Acc& A, bool inf) {
+    constexpr int N = C::N;
     if (inf) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) reinterpret_cast<uint4*>(dst)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < 2 * N; i++) reinterpret_cast<uint4*>(dst)[i] = make_uint4(0, 0, 0, 0);
         return;
     }
     F2x<C> v;
 #pragma unroll 1
-    for (int cdn = 0; cdn < 4; cdn++) { A.get(cdn, v); store_r256(dst + cdn * 16, v.c0); store_r256(dst + cdn * 16 + 8, v.c1); }
+    for (int cdn = 0; cdn < 4; cdn++) { A.get(cdn, v); store_r256(dst + cdn * 2 * N, v.c0); store_r256(dst + cdn * 2 * N + N, v.c1); }
 }
-// G2 accumulation over an R'-form window table: 256 lanes per block, accumulators in LDS (288 bytes per lane: two blocks per CU)
-template <class C> __global__ void __launch_bounds__(256, 2)
+// G2 accumulation over an R'-form window table, accumulators in LDS: BN254 256 lanes per block (288 bytes per lane: two blocks per CU),
+// BLS12-381 128 lanes per block with packed accumulators (384 bytes per lane: three blocks per CU)
+template <class C> struct Accum29G2 {
+    static constexpr int T = MsmAccumBlock<Fp2<C>>::value;
+    static constexpr bool PACK = C::N > 8;
+    typedef LdsAcc29<C, T, PACK> Acc;
+    static constexpr size_t lds_bytes = (size_t)T * 8 * Acc::EW * 4;
+};
+template <class C> __global__ void __launch_bounds__(Accum29G2<C>::T, 2)
 k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ infmask, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts,
                  const uint32_t* __restrict__ starts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub,
                  const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials) {
+    constexpr int N = C::N, AV = N;                                 // 16-byte vectors per affine G2 table entry (4 N words)
+    typedef typename Accum29G2<C>::Acc Acc;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_acc29[];
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= meta[0]) return;
@@ -357,43 +444,52 @@ k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict_
         lo = min(cnt, lane_sub[lane] * chunk);
         hi = min(cnt, lo + chunk);
     }
-    const uint32_t* list = sorted + starts[g];
-    const LdsAcc29<C, 256> A{lds_acc29 + threadIdx.x};
+    const Acc A{lds_acc29 + threadIdx.x};
     bool inf = true;
-    auto unpack = [](const uint4& a, const uint4& b) { const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}; return unpack29<C>(w); };
-    // Software pipeline as in the G1 kernel: the next point (packed, 8 x 16 bytes) is gathered while the current addition runs. On a box
+    // Software pipeline as in the G1 kernel: the next point (packed, AV x 16 bytes) is gathered while the current addition runs. On a box
     // with fast address translation this measures the same as the plain loop (the kernel is issue-bound); on boxes where random 128-byte
     // gathers over the 1.7 GB table are slow (r02: the same binary took 5.8 ms instead of 3.3 ms without it) two waves per SIMD cannot hide
     // the gather latency by themselves.
-    uint32_t k = lo;
-    struct Raw { uint4 v[8]; };
+    const uint32_t s0 = starts[g];
+    ListReader list(sorted, s0 + lo, s0 + hi);
+    struct Raw { uint4 v[AV]; };
     auto fetch = [&](uint32_t& e_out, Raw& r_out) -> bool {
-        while (k < hi) {
-            const uint32_t e = list[k++];
+        while (list.more()) {
+            const uint32_t e = list.next();
             uint32_t idx = e & 0x7fffffffu;
             if (idx < skip) continue;
             idx -= skip;
             if ((infmask[idx >> 5] >> (idx & 31)) & 1u) continue;
-            const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)idx * 32);
+            const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)idx * (4 * N));
 #pragma unroll
-            for (int i = 0; i < 8; i++) r_out.v[i] = p[i];
+            for (int i = 0; i < AV; i++) r_out.v[i] = p[i];
             e_out = e;
             return true;
         }
         return false;
     };
-    uint32_t e_next = 0;
-    Raw r_next;
-    bool have = fetch(e_next, r_next);
-    while (have) {
-        const uint32_t e = e_next;
-        const Raw r = r_next;
-        have = fetch(e_next, r_next);                           // the next gather is in flight during this addition
-        F2x<C> qx{unpack(r.v[0], r.v[1]), unpack(r.v[2], r.v[3])}, qy{unpack(r.v[4], r.v[5]), unpack(r.v[6], r.v[7])};
-        if (e >> 31) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }      // 2p - y
-        madd29_lds<C, 256>(A, inf, qx, qy);
+    if constexpr (ZK_G2_PREFETCH(C)) {
+        uint32_t e_next = 0;
+        Raw r_next;
+        bool have = fetch(e_next, r_next);
+        while (have) {
+            const uint32_t e = e_next;
+            const Raw r = r_next;
+            have = fetch(e_next, r_next);                           // the next gather is in flight during this addition
+            F2x<C> qx{unpack29_v<C>(r.v), unpack29_v<C>(r.v + AV / 4)}, qy{unpack29_v<C>(r.v + AV / 2), unpack29_v<C>(r.v + 3 * AV / 4)};
+            if (e >> 31) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }      // 2p - y
+            madd29_lds<C>(A, inf, qx, qy);
+        }
+    } else {
+        uint32_t e;
+        Raw r;
+        while (fetch(e, r)) {
+            F2x<C> qx{unpack29_v<C>(r.v), unpack29_v<C>(r.v + AV / 4)}, qy{unpack29_v<C>(r.v + AV / 2), unpack29_v<C>(r.v + 3 * AV / 4)};
+            if (e >> 31) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }
+            madd29_lds<C>(A, inf, qx, qy);
+        }
     }
-    store_xyzz29_lds<C, 256>(j ? lane_partials + (size_t)lane * 64 : buckets + (size_t)g * 64, A, inf);
+    store_xyzz29_lds<C>(j ? lane_partials + (size_t)lane * (8 * N) : buckets + (size_t)g * (8 * N), A, inf);
 }
 
 }  // namespace zkmi

@@ -1,4 +1,4 @@
-// snarkjs_amd/csrc/msm_bls12381.hip — BLS12-381 instantiations of the MSM pipeline (12-limb Fq, G1 and G2).
+// snarkjs_amd/csrc/msm_bls12381.hip — BLS12-381 instantiations of the MSM pipeline (12-word Fq; 14 x 28-bit limbs in the accumulation kernels; G1 and G2).
 #include "msm_host.hpp"
 
 namespace zkmi {
@@ -26,6 +26,13 @@ static void bls_generator(int group, uint8_t* out) {
 int msm_bls12381(int group, const void* d_bases, const void* d_scalars, size_t n, size_t sb, uint8_t* out_jac) {
     if (group == 1) return msm_run<Fp<Bls12381Fq>>(d_bases, d_scalars, n, sb, out_jac);
     return msm_run<Fp2<Bls12381Fq>>(d_bases, d_scalars, n, sb, out_jac);
+}
+int msm_table_to_r29_bls12381(int group, void* d_table, size_t n_points) {
+    Ctx& cx = ctx();
+    const size_t elems = n_points * 2 * (size_t)group;         // base-field elements: 2 per G1 point, 4 per G2 point
+    hipLaunchKernelGGL((k_table_to_r29<Bls12381Fq>), dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, cx.stream, (uint32_t*)d_table, elems);
+    ZK_HIP(hipGetLastError());
+    return ZKMI_OK;
 }
 int msm_accumulate_bls12381(int group, const void* d_bases, const MsmPlan& pl, uint32_t skip, MsmJob& job, const uint32_t* d_infmask, MsmJob* into) {
     if (group == 1) return msm_accumulate<Fp<Bls12381Fq>>(d_bases, pl, skip, job, d_infmask, into);

@@ -162,30 +162,33 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
     }
     if (job.acc0) ZK_HIP(hipEventRecord(job.acc0, st));
     bool launched = false, r29_buckets = false;
-    if constexpr (std::is_same<F, Fp<Bn254Fq>>::value) {
-        // window tables registered in the R'-form of field29.cuh: the hot loop on unsaturated 29-bit limbs
-        auto r29 = cx.r29_tables.find(d_bases);
-        if (r29 != cx.r29_tables.end() && sh.precomp) {
+    typedef typename F::Cfg C;
+    // base arrays registered in the R'-form of field29.cuh (window tables of resident bases; the library's own upload of a plain zkmi_msm
+    // call): the hot loop on unsaturated limbs (9 x 29 bits BN254, 14 x 28 bits BLS12-381)
+    auto r29 = cx.r29_tables.find(d_bases);
+    const bool table29 = r29 != cx.r29_tables.end();
+    if constexpr (!WIDE) {
+        if (table29) {
             // ZKMI_R29_REDUCE=0: buckets leave the kernel in the reference's R-form and the generic row / column sums reduce them
             static const bool r29_reduce = !(getenv("ZKMI_R29_REDUCE") && atoi(getenv("ZKMI_R29_REDUCE")) == 0) && !(getenv("ZKMI_ROWCOL_WAVE") && atoi(getenv("ZKMI_ROWCOL_WAVE")) == 0);
             launched = true;
             r29_buckets = into ? into->r29 : (r29_reduce && (sh.c - 1) / 2 >= 6);       // the wave row/column sums need >= 64 buckets per row and column
             const uint32_t* mask = d_infmask ? d_infmask : r29->second;
             const dim3 grid((unsigned)((pl.lane_bound + 255) / 256));
-            if (into) hipLaunchKernelGGL((k_msm_accum29<Bn254Fq, true>), grid, dim3(256), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
+            if (into) hipLaunchKernelGGL((k_msm_accum29<C, true>), grid, dim3(256), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
                                          pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts, (int)r29_buckets);
-            else hipLaunchKernelGGL((k_msm_accum29<Bn254Fq, false>), grid, dim3(256), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
+            else hipLaunchKernelGGL((k_msm_accum29<C, false>), grid, dim3(256), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
                                     pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts, (int)r29_buckets);
         }
-    }
-    if constexpr (std::is_same<F, Fp2<Bn254Fq>>::value) {
-        auto r29 = cx.r29_tables.find(d_bases);
-        if (r29 != cx.r29_tables.end() && sh.precomp && !into) {
+    } else {
+        if (table29 && into) return fail(ZKMI_ERR_UNSUPPORTED, "msm_accumulate: no merge mode over an R'-form G2 table");
+        if (table29) {
             launched = true;
-            constexpr size_t lds29 = (size_t)256 * 72 * 4;                     // 4 coordinates x 18 limbs per lane
+            constexpr unsigned T29 = Accum29G2<C>::T;
+            constexpr size_t lds29 = Accum29G2<C>::lds_bytes;              // 4 coordinates x 2 components per lane
             static bool a29 = false;
-            if (!a29) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum29_g2<Bn254Fq>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29)); a29 = true; }
-            hipLaunchKernelGGL((k_msm_accum29_g2<Bn254Fq>), dim3((unsigned)((pl.lane_bound + 255) / 256)), dim3(256), lds29, st, (const uint32_t*)d_bases,
+            if (!a29) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum29_g2<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29)); a29 = true; }
+            hipLaunchKernelGGL((k_msm_accum29_g2<C>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
                                d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials);
         }
     }
@@ -199,6 +202,13 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
         hipLaunchKernelGGL((k_msm_accum<F, WIDE, false>), dim3((unsigned)((pl.lane_bound + AT - 1) / AT)), dim3(AT), acc_lds, st, (const uint32_t*)d_bases, d_infmask, sh, skip, pl.cap, pl.counts,
                            pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts);
     if (job.acc1) ZK_HIP(hipEventRecord(job.acc1, st));
+    if (cx.msm_stats && cx.d_addcount && job.slot < MSM_JOB_SLOTS) {           // outside the bracketed launch
+        const int ci = cx.pipe * MSM_JOB_SLOTS + job.slot;
+        const uint32_t* mask = d_infmask ? d_infmask : (table29 ? r29->second : nullptr);
+        ZK_HIP(hipMemsetAsync(cx.d_addcount + ci, 0, 8, st));
+        hipLaunchKernelGGL(k_msm_count_adds, dim3(1024), dim3(256), 0, st, pl.sorted, pl.counts, pl.starts, (uint32_t)total, skip, mask, cx.d_addcount + ci);
+        ZK_HIP(hipMemcpyAsync(cx.h_addcount + ci, cx.d_addcount + ci, 8, hipMemcpyDeviceToHost, st));
+    }
     hipLaunchKernelGGL((k_msm_tree<F, MSM_TB>), dim3((unsigned)std::min<size_t>(tree_blocks, 512)), dim3(MSM_TB), tree_lds, st, lane_partials, pl.lane_g, pl.counts, pl.cap, pl.meta, buckets,
                        block_partials, (int)r29_buckets);
     hipLaunchKernelGGL((k_msm_giant<F, MSM_TB>), dim3((unsigned)std::min<size_t>(tree_blocks, 256)), dim3(MSM_TB), tree_lds, st, pl.giants, pl.meta, block_partials, buckets, (int)r29_buckets);
@@ -259,19 +269,20 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
     // ZKMI_ROWCOL_WAVE=0 keeps the staged k_msm_rowcol + k_msm_fold sequence
     static const bool wave_env = !(getenv("ZKMI_ROWCOL_WAVE") && atoi(getenv("ZKMI_ROWCOL_WAVE")) == 0);
     const bool wave_rc = wave_env && rbits >= 6 && cbits >= 6;
-    bool all_r29 = std::is_same<F, Fp<Bn254Fq>>::value;
+    bool all_r29 = FW <= 12;                                 // G1 (Fq points): R'-form buckets and the row / column sums on the same limbs
     for (int i = 0; i < njobs; i++) all_r29 = all_r29 && jobs[i]->r29;
     for (int i = 0; i < njobs; i++) if (jobs[i]->r29 != jobs[0]->r29) return fail(ZKMI_ERR_INVALID, "msm_reduce: jobs with different bucket formats");
     if (jobs[0]->r29 && !(all_r29 && wave_rc)) return fail(ZKMI_ERR_UNSUPPORTED, "msm_reduce: R'-form buckets need the wave row/column sums");
     if (all_r29 && wave_rc) {
-        if constexpr (std::is_same<F, Fp<Bn254Fq>>::value) {
-            constexpr size_t lds29 = (size_t)256 * 36 * 4;
+        if constexpr (FW <= 12) {
+            typedef typename F::Cfg C;
+            constexpr size_t lds29 = (size_t)256 * 4 * Lim29<C>::NL * 4;
             static bool rc29_attr = false;
-            if (!rc29_attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave29<Bn254Fq>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29)); rc29_attr = true; }
+            if (!rc29_attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave29<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29)); rc29_attr = true; }
             size_t rc_blocks = (n_out + 3) / 4;
             static const int aux_cap29 = getenv("ZKMI_AUX_RC_SUMS") ? atoi(getenv("ZKMI_AUX_RC_SUMS")) : 512;
             if (aux && aux_cap29 > 0) rc_blocks = std::min<size_t>(rc_blocks, (size_t)aux_cap29 / 4);
-            hipLaunchKernelGGL((k_msm_rowcol_wave29<Bn254Fq>), dim3((unsigned)rc_blocks), dim3(256), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
+            hipLaunchKernelGGL((k_msm_rowcol_wave29<C>), dim3((unsigned)rc_blocks), dim3(256), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
         }
     } else if (wave_rc) {
         constexpr int T = MsmRcBlock<F>::value;

@@ -103,6 +103,7 @@ int msm_bn254(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_bls12381(int group, const void*, const void*, size_t, size_t, uint8_t*);
 int msm_accumulate_bn254(int group, const void*, const MsmPlan&, uint32_t, MsmJob&, const uint32_t*, MsmJob*);
 int msm_table_to_r29_bn254(int group, void* d_table, size_t n_points);
+int msm_table_to_r29_bls12381(int group, void* d_table, size_t n_points);
 int msm_accumulate_bls12381(int group, const void*, const MsmPlan&, uint32_t, MsmJob&, const uint32_t*, MsmJob*);
 int msm_infmask_bn254(int group, const void*, size_t, uint32_t*);
 int msm_infmask_bls12381(int group, const void*, size_t, uint32_t*);
@@ -147,10 +148,14 @@ int msm_precompute_dispatch(int curve, int group, const void* d_bases, size_t n,
     return curve == ZKMI_CURVE_BN128 ? msm_precompute_bn254(group, d_bases, n, c, Wd, d_table) : msm_precompute_bls12381(group, d_bases, n, c, Wd, d_table);
 }
 int msm_table_to_r29(int curve, int group, void* d_table, size_t n_points, const uint32_t* d_infmask) {
+    // ZKMI_R29=0: every curve on saturated 32-bit limbs; ZKMI_R29_BLS=0: BLS12-381 only; ZKMI_R29_G2=0: G2 tables only (A/B switches)
     static const bool on = !(getenv("ZKMI_R29") && atoi(getenv("ZKMI_R29")) == 0);
+    static const bool bls_on = !(getenv("ZKMI_R29_BLS") && atoi(getenv("ZKMI_R29_BLS")) == 0);
     static const int g2_on = getenv("ZKMI_R29_G2") ? atoi(getenv("ZKMI_R29_G2")) : 1;
-    if (!on || curve != ZKMI_CURVE_BN128 || (group != 1 && !(group == 2 && g2_on)) || !d_infmask) return ZKMI_OK;
-    ZK_TRY(msm_table_to_r29_bn254(group, d_table, n_points));
+    if (!on || (group != 1 && !(group == 2 && g2_on)) || !d_infmask) return ZKMI_OK;
+    if (curve == ZKMI_CURVE_BN128) ZK_TRY(msm_table_to_r29_bn254(group, d_table, n_points));
+    else if (curve == ZKMI_CURVE_BLS12381 && bls_on) ZK_TRY(msm_table_to_r29_bls12381(group, d_table, n_points));
+    else return ZKMI_OK;
     g_ctx.r29_tables[d_table] = d_infmask;
     return ZKMI_OK;
 }
@@ -243,6 +248,20 @@ double zkmi_msm_accum_ms(int slot) {
     if (hipEventElapsedTime(&ms, g_ctx.job_ev[2 * slot], g_ctx.job_ev[2 * slot + 1]) != hipSuccess) return -1.0;
     return ms;
 }
+int zkmi_msm_stats(int enable) {
+    ZK_TRY(require_ctx());
+    if (enable && !g_ctx.d_addcount) {
+        ZK_HIP(hipMalloc((void**)&g_ctx.d_addcount, 2 * MSM_JOB_SLOTS * 8));
+        ZK_HIP(hipHostMalloc((void**)&g_ctx.h_addcount, 2 * MSM_JOB_SLOTS * 8, hipHostMallocDefault));
+        memset(g_ctx.h_addcount, 0, 2 * MSM_JOB_SLOTS * 8);
+    }
+    g_ctx.msm_stats = enable != 0;
+    return ZKMI_OK;
+}
+double zkmi_msm_accum_additions(int slot) {
+    if (!g_ctx.ready || !g_ctx.h_addcount || slot < 0 || slot >= MSM_JOB_SLOTS) return -1.0;
+    return (double)g_ctx.h_addcount[g_ctx.pipe * MSM_JOB_SLOTS + slot];
+}
 // Device buffers handed to the host are pooled by size: a prover allocates and drops the same few sizes every proof, and
 // hipMalloc / hipFree are synchronous and slow (and the first touch of fresh VRAM costs milliseconds of page-table set-up).
 int zkmi_dev_alloc(size_t bytes, void** d_ptr) {
@@ -320,17 +339,28 @@ static int table_build(int curve, int group, const void* d_bases, size_t n, MsmT
     ZK_HIP(hipStreamSynchronize(g_ctx.stream));
     return ZKMI_OK;
 }
+static void table_free(MsmTable& t) {
+    if (t.p) { msm_table_forget_r29(t.p); (void)hipFree(t.p); }
+    if (t.mask) (void)hipFree(t.mask);
+    t = MsmTable();
+}
+// library-private tables (handles, the content-addressed cache behind zkmi_msm): kept in the R'-form of field29.cuh where that path exists
+// (needs the infinity bitmap); on any failure nothing stays registered or allocated
+static int table_build_r29(int curve, int group, const void* d_bases, size_t n, MsmTable& t) {
+    int rc = table_build(curve, group, d_bases, n, t);
+    if (!rc && hipMalloc((void**)&t.mask, (((size_t)t.Wd * n + 31) / 32) * 4 + 16) != hipSuccess) rc = fail(ZKMI_ERR_HIP, "hipMalloc: infinity bitmap of a window table");
+    if (!rc) rc = msm_infmask_dispatch(curve, group, t.p, (size_t)t.Wd * n, t.mask);
+    if (!rc) rc = msm_table_to_r29(curve, group, t.p, (size_t)t.Wd * n, t.mask);
+    if (!rc && hipStreamSynchronize(g_ctx.stream) != hipSuccess) rc = fail(ZKMI_ERR_HIP, "hipStreamSynchronize: window table");
+    if (rc) table_free(t);
+    return rc;
+}
 int zkmi_msm_table_build(int curve, int group, const void* d_bases, size_t n, uint64_t* handle) {
     ZK_TRY(require_ctx());
     ZK_TRY(check_cg(curve, group));
     if (!handle || !d_bases || !n) return fail(ZKMI_ERR_INVALID, "msm_table_build: bad argument");
     MsmTable t;
-    ZK_TRY(table_build(curve, group, d_bases, n, t));
-    // handle tables are private to the library: keep them in the R'-form of field29.cuh where that path exists (needs the infinity bitmap)
-    ZK_HIP(hipMalloc((void**)&t.mask, (((size_t)t.Wd * n + 31) / 32) * 4 + 16));
-    ZK_TRY(msm_infmask_dispatch(curve, group, t.p, (size_t)t.Wd * n, t.mask));
-    ZK_TRY(msm_table_to_r29(curve, group, t.p, (size_t)t.Wd * n, t.mask));
-    ZK_HIP(hipStreamSynchronize(g_ctx.stream));
+    ZK_TRY(table_build_r29(curve, group, d_bases, n, t));
     *handle = g_next_table++;
     g_tables[*handle] = t;
     return ZKMI_OK;
@@ -360,9 +390,7 @@ int zkmi_msm_table_release(uint64_t handle) {
     auto it = g_tables.find(handle);
     if (it == g_tables.end()) return ZKMI_OK;
     if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
-    msm_table_forget_r29(it->second.p);
-    if (it->second.p) (void)hipFree(it->second.p);
-    if (it->second.mask) (void)hipFree(it->second.mask);
+    table_free(it->second);
     g_tables.erase(it);
     return ZKMI_OK;
 }
@@ -445,9 +473,20 @@ static size_t bc_budget() {
     static const size_t v = [] { const char* e = getenv("ZKMI_BASE_CACHE_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)64 << 30); }();
     return v;
 }
+// In-place x -> x * 2^SH mod p (SH = r29_shift: 5 for BN254, 8 for BLS12-381) on `len` bytes of whole base-field elements
+static void bc_elems_to_r29(int curve, uint8_t* bytes, size_t len) {
+    const size_t es = (size_t)n8q_of(curve);
+    if (curve == ZKMI_CURVE_BN128) {
+        const auto F = host::HField<4>::from_cfg<Bn254Fq>();
+        for (size_t o = 0; o + es <= len; o += es) { host::HFp<4> v; memcpy(v.v, bytes + o, es); for (int k = 0; k < r29_shift<Bn254Fq>(); k++) v = F.dbl(v); memcpy(bytes + o, v.v, es); }
+    } else {
+        const auto F = host::HField<6>::from_cfg<Bls12381Fq>();
+        for (size_t o = 0; o + es <= len; o += es) { host::HFp<6> v; memcpy(v.v, bytes + o, es); for (int k = 0; k < r29_shift<Bls12381Fq>(); k++) v = F.dbl(v); memcpy(bytes + o, v.v, es); }
+    }
+}
 static size_t bc_resident_bytes() { size_t t = 0; for (auto& e : g_bc) t += e.bytes(); return t; }
 static void bc_free(BcEntry& e) {
-    if (e.table.p) { if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream); (void)hipFree(e.table.p); e.table = MsmTable(); }
+    if (e.table.p) { if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream); table_free(e.table); }
 }
 // does the resident entry e hold, as a prefix, exactly the `total` bytes whose chunk hashes are `q`? Whole chunks are compared by
 // hash; a trailing partial chunk of the query is compared byte for byte against row 0 of the table (the plain bases).
@@ -461,18 +500,24 @@ static int bc_prefix_match(const BcEntry& e, const zkmi_pages& pg, size_t total,
         if (total == ebytes) { if (q[full] != e.chunks[full]) return ZKMI_OK; }
         else {
             if (!e.table.p) return ZKMI_OK;                  // nothing to compare the partial chunk with
-            std::vector<uint8_t> dev(tail), host(tail);
-            ZK_HIP(hipMemcpy(dev.data(), (const uint8_t*)e.table.p + full * BC_CHUNK, tail, hipMemcpyDeviceToHost));
-            size_t off = full * BC_CHUNK, done = 0, base = 0;
-            for (int i = 0; i < pg.n_pages && done < tail; i++) {
+            // compared from the first byte of the field element that holds the chunk boundary (BLS12-381's 48-byte elements straddle 64 KiB
+            // boundaries): the range is whole elements on both ends
+            const size_t es = (size_t)n8q_of(e.curve);
+            const size_t off = full * BC_CHUNK - (full * BC_CHUNK) % es, len = total - off;
+            std::vector<uint8_t> dev(len), host(len);
+            ZK_HIP(hipMemcpy(dev.data(), (const uint8_t*)e.table.p + off, len, hipMemcpyDeviceToHost));
+            size_t done = 0, base = 0;
+            for (int i = 0; i < pg.n_pages && done < len; i++) {
                 if (off + done < base + pg.len[i]) {
-                    const size_t o = off + done - base, k = std::min(tail - done, pg.len[i] - o);
+                    const size_t o = off + done - base, k = std::min(len - done, pg.len[i] - o);
                     memcpy(host.data() + done, pg.ptr[i] + o, k);
                     done += k;
                 }
                 base += pg.len[i];
             }
-            if (memcmp(dev.data(), host.data(), tail)) return ZKMI_OK;
+            // row 0 of an R'-form table holds x 2^SH for every coordinate x of the plain bases: bring the caller's bytes to the same form
+            if (g_ctx.r29_tables.count(e.table.p)) bc_elems_to_r29(e.curve, host.data(), len);
+            if (memcmp(dev.data(), host.data(), len)) return ZKMI_OK;
         }
     }
     *match = true;
@@ -517,7 +562,7 @@ int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t 
                 void* raw = nullptr;
                 ZK_HIP(hipMalloc(&raw, n * pb));
                 int rc = upload_pages(bases, n * pb, raw);
-                if (!rc) rc = table_build(curve, group, raw, n, t);
+                if (!rc) rc = table_build_r29(curve, group, raw, n, t);
                 (void)hipFree(raw);
                 if (rc == ZKMI_OK) {
                     seen->table = t;
@@ -530,7 +575,7 @@ int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t 
                             for (size_t k = 0; pre && k < full; k++) pre = e.chunks[k] == q[k];
                             if (pre && (e.n * pb) % BC_CHUNK == 0) bc_free(e);
                         }
-                } else if (t.p) (void)hipFree(t.p);
+                }
                 // a failed build (out of device memory) falls through to the plain path
             }
         }
@@ -551,7 +596,15 @@ int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t 
     }
     ZK_TRY(ws_get("api.bases", n * pb, &d_b));
     ZK_TRY(upload_pages(bases, n * pb, d_b));
-    return msm_dev_dispatch(curve, group, d_b, d_s, n, scalar_bytes, out);
+    // the upload is the library's own copy: moved to R'-form in place (one pass of 5 / 8 doublings per coordinate), so that plain-base MSMs
+    // run the unsaturated-limb accumulation too; the registration lives for this call only
+    uint32_t* d_mask = nullptr;
+    ZK_TRY(ws_get("api.basemask", ((n + 31) / 32) * 4 + 16, (void**)&d_mask));
+    ZK_TRY(msm_infmask_dispatch(curve, group, d_b, n, d_mask));
+    ZK_TRY(msm_table_to_r29(curve, group, d_b, n, d_mask));
+    const int rc = msm_dev_dispatch(curve, group, d_b, d_s, n, scalar_bytes, out);
+    msm_table_forget_r29(d_b);
+    return rc;
 }
 // key != 0 / 0: both drop every cached base table (the cache is content-addressed; per-key release has no meaning any more)
 int zkmi_release_bases(uint64_t key) {

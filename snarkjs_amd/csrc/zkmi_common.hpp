@@ -72,6 +72,8 @@ struct Ctx {
     hipEvent_t sort_ev[5] = {};                             // groth16.hip: digit sorts on the auxiliary stream (start, B, witness, join, H)
     hipEvent_t job_ev[16] = {};                             // per MSM job slot: events around k_msm_accum
     uint8_t* pinned = nullptr;                              // pinned host slots for MSM window sums
+    bool msm_stats = false;                                 // zkmi_msm_stats: count the mixed additions of every accumulation launch
+    unsigned long long *d_addcount = nullptr, *h_addcount = nullptr;      // per (pipeline slot, job slot): device counters, pinned host copies
 };
 Ctx& ctx();
 int require_ctx();

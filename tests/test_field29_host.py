@@ -1,0 +1,371 @@
+"""The unsaturated-limb field / point arithmetic of csrc/field29.cuh + msm29.cuh, executed ON THE CPU (tools/field29_hosttest.hip compiles
+the same __host__ __device__ code for the host) and checked against Python big integers: Montgomery products with shared reductions, the
+squaring, lazy subtractions (no limb may wrap), the zero test, packing, the R-form / R'-form conversions, G1 mixed / general additions and
+the LDS-parked G2 mixed addition incl. the doubling and cancellation branches — for 9 x 29-bit limbs (BN254 Fq) and 14 x 28-bit limbs
+(BLS12-381 Fq). The column sums of the product scanning are re-computed here for the worst legal operands: they must stay below 2^64."""
+import os
+import random
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tools", "bin", "field29_hosttest")
+SRC = os.path.join(ROOT, "tools", "field29_hosttest.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+P = {
+    "bn254fq": 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47,
+    "bls12381fq": 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+}
+FORM = {"bn254fq": (8, 9, 29), "bls12381fq": (12, 14, 28)}       # words, limbs, bits per limb
+CURVES = list(P)
+
+
+def _deps():
+    d = [SRC]
+    for f in ("field.cuh", "field29.cuh", "msm29.cuh", "msm.cuh", "curve.cuh"):
+        d.append(os.path.join(ROOT, "snarkjs_amd", "csrc", f))
+    return d
+
+
+@pytest.fixture(scope="module")
+def tool():
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    if not os.path.exists(TOOL) or any(os.path.getmtime(d) > os.path.getmtime(TOOL) for d in _deps()):
+        os.makedirs(os.path.dirname(TOOL), exist_ok=True)
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "snarkjs_amd", "csrc"), SRC, "-o", TOOL])
+    p = subprocess.Popen([TOOL], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+
+    def call(op, curve, words):
+        p.stdin.write(op + " " + curve + " " + " ".join("%x" % w for w in words) + "\n")
+        p.stdin.flush()
+        line = p.stdout.readline().strip()
+        assert not line.startswith("ERR"), (op, curve, line)
+        return [int(t, 16) for t in line.split()]
+    yield call
+    p.stdin.close()
+    p.wait(timeout=10)
+
+
+class Form:
+    def __init__(self, curve):
+        self.curve = curve
+        self.p = P[curve]
+        self.N, self.NL, self.B = FORM[curve]
+        self.M = (1 << self.B) - 1
+        self.Rp = 1 << (self.B * self.NL)
+        self.Rinv = pow(self.Rp, -1, self.p)
+        self.NP = (-pow(self.p, -1, 1 << self.B)) % (1 << self.B)
+
+    def limbs(self, v):                    # normalised limbs of v (top limb takes the excess)
+        out = []
+        for i in range(self.NL):
+            out.append(v & self.M if i < self.NL - 1 else v)
+            v >>= self.B
+        assert out[-1] < (1 << 32)
+        return out
+
+    def value(self, l):
+        return sum(x << (self.B * i) for i, x in enumerate(l))
+
+    def normalised(self, l):
+        return all(x <= self.M for x in l[:-1]) and l[-1] < (1 << 32)
+
+    def rand_norm(self, rng, bound=None):
+        bound = bound or (1 << (self.B * self.NL - 3))
+        return self.limbs(rng.randrange(bound))
+
+    def lazy(self, rng, terms):            # limb-wise sum of `terms` normalised elements whose values add up below 2^(B NL - 3)
+        ls = [self.limbs(rng.randrange((1 << (self.B * self.NL - 3)) // terms)) for _ in range(terms)]
+        return [sum(c) for c in zip(*ls)]
+
+    def to29(self, x):                      # canonical R'-form limbs of the field element x
+        return self.limbs(x * self.Rp % self.p)
+
+    def words(self, v):
+        return [(v >> (32 * i)) & 0xffffffff for i in range(self.N)]
+
+    # product scanning exactly as ZK_MS29_BODY: returns result limbs; asserts that no column overflows 64 bits
+    def model_mont(self, pairs):
+        NL, B, M = self.NL, self.B, self.M
+        pl = self.limbs(self.p)
+        m, r, acc = [0] * NL, [0] * NL, 0
+        for k in range(NL):
+            for i in range(k + 1):
+                for a, b in pairs:
+                    acc += a[i] * b[k - i]
+            for i in range(k):
+                acc += m[i] * pl[k - i]
+            m[k] = ((acc & 0xffffffff) * self.NP) & M
+            acc += m[k] * pl[0]
+            assert acc < (1 << 64), "column overflow"
+            acc >>= B
+        for k in range(NL, 2 * NL):
+            for i in range(k - NL + 1, NL):
+                for a, b in pairs:
+                    acc += a[i] * b[k - i]
+            for i in range(k - NL + 1, NL):
+                acc += m[i] * pl[k - i]
+            assert acc < (1 << 64), "column overflow"
+            r[k - NL] = (acc & 0xffffffff) if k == 2 * NL - 1 else (acc & M)
+            acc >>= B
+        return r
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_constants(tool, curve):
+    F = Form(curve)
+    c = tool("consts", curve, [])
+    NL = F.NL
+    assert c[:3] == [F.NL, F.B, F.N]
+    assert c[3] == F.NP and c[4] == pow(F.p, -1, 1 << F.B)
+    assert c[5:5 + NL] == F.limbs(F.p)
+    assert c[5 + NL:5 + 2 * NL] == F.limbs(F.Rp % F.p)
+    assert c[5 + 2 * NL:5 + 3 * NL] == F.limbs(pow(2, 2 * F.B * NL - 32 * F.N, F.p))
+    assert c[5 + 3 * NL:5 + 4 * NL] == F.limbs(pow(2, 32 * F.N, F.p))
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_products(tool, curve):
+    F = Form(curve)
+    rng = random.Random(0x29 + F.NL)
+    p, NL = F.p, F.NL
+
+    def check(op, ops, res):
+        pairs = list(zip(ops[0::2], ops[1::2]))
+        assert res == F.model_mont(pairs), op                                      # limb for limb what the model of the algorithm gives
+        val = sum(F.value(a) * F.value(b) for a, b in pairs)
+        assert F.value(res) % p == val * F.Rinv % p
+        assert F.normalised(res) and F.value(res) <= val // F.Rp + p
+
+    for _ in range(200):
+        a, b = F.rand_norm(rng), F.rand_norm(rng)
+        check("mul", [a, b], tool("mul", curve, a + b))
+        a, b = F.lazy(rng, 2), F.lazy(rng, 2)                                      # both operands with limbs < 2^(B+1)
+        check("mul lazy2", [a, b], tool("mul", curve, a + b))
+        a, b = F.lazy(rng, 4), F.rand_norm(rng, p)                                 # one operand with limbs < 2^(B+2)
+        check("mul lazy4", [a, b], tool("mul", curve, a + b))
+        ops = [F.rand_norm(rng, 16 * p) for _ in range(4)]
+        ops[rng.randrange(4)] = F.lazy(rng, 2)
+        check("mul2", ops, tool("mul2", curve, sum(ops, [])))
+        ops = [F.rand_norm(rng, 16 * p) for _ in range(8)]
+        check("mul4", ops, tool("mul4", curve, sum(ops, [])))
+        a = F.rand_norm(rng)
+        r = tool("sqr", curve, a)
+        assert F.value(r) % p == F.value(a) ** 2 * F.Rinv % p and F.normalised(r) and F.value(r) <= F.value(a) ** 2 // F.Rp + p
+    # worst legal operands: every limb at its bound — the 64-bit column accumulator must hold (model_mont asserts it) and the tool must agree
+    top = (1 << (F.B - 3)) - 1
+    mx = [F.M] * (NL - 1) + [top]
+    mx2 = [2 * F.M] * (NL - 1) + [2 * top]
+    mx4 = [4 * F.M] * (NL - 1) + [4 * top]
+    check("mul max", [mx, mx], tool("mul", curve, mx + mx))
+    check("mul max lazy2", [mx2, mx2], tool("mul", curve, mx2 + mx2))
+    check("mul max lazy4", [mx4, mx], tool("mul", curve, mx4 + mx))
+    check("mul2 max", [mx, mx, mx, mx2], tool("mul2", curve, mx + mx + mx + mx2))
+    check("mul4 max", [mx] * 8, tool("mul4", curve, mx * 8))
+    r = tool("sqr", curve, mx)
+    assert F.value(r) % p == F.value(mx) ** 2 * F.Rinv % p
+    # the squaring's own column bound: NL/2 cross terms of < 2^(2B+1), one square, NL reduction terms
+    assert (NL // 2) * (2 * F.M) * F.M + F.M * F.M + NL * F.M * F.M < (1 << 64)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_lazy_sub_norm_zero_pack(tool, curve):
+    F = Form(curve)
+    rng = random.Random(0x51 + F.NL)
+    p, NL, B = F.p, F.NL, F.B
+    for K in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 15):
+        kp = F.limbs(K * p)
+        off = [kp[0] + (1 << B)] + [x + (1 << B) - 1 for x in kp[1:-1]] + [kp[-1] - 1]
+        assert F.value(off) == K * p
+        for _ in range(40):
+            b = F.rand_norm(rng, K * p - (1 << (B * (NL - 1))))                   # any normalised subtrahend below K p - 2^(B (NL-1))
+            t = F.lazy(rng, rng.choice((1, 2)))
+            r = tool("sub", curve, [K] + t + b)
+            assert r == [t[i] + off[i] - b[i] for i in range(NL)]                 # no limb wrapped below zero or above 2^32
+            assert all(0 <= x < (1 << 32) for x in r) and F.value(r) == F.value(t) + K * p - F.value(b)
+            n = tool("norm", curve, r)
+            assert F.normalised(n) and F.value(n) == F.value(r)
+        bmax = F.limbs(K * p - (1 << (B * (NL - 1))) - 1)                          # the largest admissible subtrahend
+        r = tool("sub", curve, [K] + [0] * NL + bmax)
+        assert all(0 <= x < (1 << 32) for x in r) and F.value(r) == K * p - F.value(bmax)
+    for k in range(0, 20):
+        assert tool("iszero", curve, F.limbs(k * p)) == [1]
+        v = k * p + rng.randrange(1, p)
+        assert tool("iszero", curve, F.limbs(v)) == [0]
+        assert tool("iszero", curve, F.limbs(k * p + (1 << B) * rng.randrange(1, 1 << 40))) == [0]      # same low limb as k p
+    for _ in range(50):
+        v = rng.randrange(1 << (32 * F.N))
+        l = tool("unpack", curve, F.words(v))
+        assert l == F.limbs(v)
+        assert tool("pack", curve, l) == F.words(v)
+        x = rng.randrange(p)
+        for top in (0, 1, 2):
+            c = tool("canon", curve, F.limbs(x + top * p))
+            assert c == F.limbs(x)
+        # store: any lazy value -> canonical words in R-form (x 2^(32 N)) or R'-form; fromr: R-form words -> R'-form limbs
+        a = F.lazy(rng, rng.choice((1, 2, 3)))
+        xa = F.value(a) * F.Rinv % p                                               # the field element a stands for
+        assert tool("store", curve, a) == F.words(xa * (1 << (32 * F.N)) % p)
+        assert tool("store29", curve, a) == F.words(xa * F.Rp % p)
+        r = tool("fromr", curve, F.words(x * (1 << (32 * F.N)) % p))
+        assert F.value(r) % p == x * F.Rp % p and F.normalised(r) and F.value(r) < 2 * p
+
+
+# ---- points: affine chord / tangent rule over Fp and Fp2 = Fp[u]/(u^2 + 1) (a = 0; the formulas never use b) -------------------
+class Fp2:
+    def __init__(s, p):
+        s.p = p
+
+    def add(s, a, b): return ((a[0] + b[0]) % s.p, (a[1] + b[1]) % s.p)
+    def sub(s, a, b): return ((a[0] - b[0]) % s.p, (a[1] - b[1]) % s.p)
+    def mul(s, a, b): return ((a[0] * b[0] - a[1] * b[1]) % s.p, (a[0] * b[1] + a[1] * b[0]) % s.p)
+
+    def inv(s, a):
+        d = pow(a[0] * a[0] + a[1] * a[1], -1, s.p)
+        return (a[0] * d % s.p, -a[1] * d % s.p)
+    zero, one = (0, 0), (1, 0)
+
+
+class Fp1:
+    def __init__(s, p):
+        s.p = p
+
+    def add(s, a, b): return (a + b) % s.p
+    def sub(s, a, b): return (a - b) % s.p
+    def mul(s, a, b): return a * b % s.p
+    def inv(s, a): return pow(a, -1, s.p)
+    zero, one = 0, 1
+
+
+def aff_add(K, P1, P2):
+    if P1 is None:
+        return P2
+    if P2 is None:
+        return P1
+    (x1, y1), (x2, y2) = P1, P2
+    if x1 == x2:
+        if K.add(y1, y2) == K.zero:
+            return None
+        lam = K.mul(K.mul(K.add(K.add(x1, x1), x1), x1), K.inv(K.add(y1, y1)))      # 3 x^2 / 2 y
+    else:
+        lam = K.mul(K.sub(y2, y1), K.inv(K.sub(x2, x1)))
+    x3 = K.sub(K.sub(K.mul(lam, lam), x1), x2)
+    return (x3, K.sub(K.mul(lam, K.sub(x1, x3)), y1))
+
+
+def aff_neg(K, Pt):
+    return None if Pt is None else (Pt[0], K.sub(K.zero, Pt[1]))
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_g1_additions(tool, curve):
+    F = Form(curve)
+    K = Fp1(F.p)
+    rng = random.Random(0x61 + F.NL)
+    p, NL = F.p, F.NL
+
+    def xyzz_value(st):
+        inf, l = st[0], st[1:]
+        if inf:
+            return None
+        X, Y, ZZ, ZZZ = (F.value(l[i * NL:(i + 1) * NL]) * F.Rinv % p for i in range(4))
+        assert ZZ and (ZZ ** 3 - ZZZ ** 2) % p == 0
+        return (X * pow(ZZ, -1, p) % p, Y * pow(ZZZ, -1, p) % p)
+
+    def check_inv(st):                       # the invariants madd29 / padd29 promise for their results (units of p)
+        if st[0]:
+            return
+        l = st[1:]
+        vals = [F.value(l[i * NL:(i + 1) * NL]) for i in range(4)]
+        assert all(F.normalised(l[i * NL:(i + 1) * NL]) for i in range(4))
+        assert vals[0] <= 7.3 * p and vals[1] <= 3.3 * p and vals[2] <= 1.1 * p and vals[3] <= 1.1 * p
+
+    for trial in range(6):
+        pts = [(rng.randrange(p), rng.randrange(1, p)) for _ in range(12)]
+        seq = list(pts)
+        seq.insert(1, pts[0])                          # acc == q: the doubling branch
+        seq.insert(5, None)                            # placeholder: add the negative of the running sum (-> infinity), then go on
+        st = [1] + [0] * (4 * NL)
+        want = None
+        for q in seq:
+            if q is None:
+                q = aff_neg(K, want)
+            neg = rng.random() < 0.5
+            qq = aff_neg(K, q) if neg else q
+            # the kernel negates y as 2p - y (normalised): feed that representation
+            ylim = F.to29(q[1])
+            if neg:
+                ylim = tool("norm", curve, tool("sub", curve, [2] + [0] * NL + ylim))
+            st = tool("madd", curve, st + F.to29(q[0]) + ylim)
+            want = aff_add(K, want, qq)
+            assert xyzz_value(st) == want
+            check_inv(st)
+        # general additions: fold two accumulators, an accumulator with itself (doubling), with its negative (infinity)
+        st2 = [1] + [0] * (4 * NL)
+        w2 = None
+        for q in pts[:5]:
+            st2 = tool("madd", curve, st2 + F.to29(q[0]) + F.to29(q[1]))
+            w2 = aff_add(K, w2, q)
+        s3 = tool("padd", curve, st + st2[1:])
+        assert xyzz_value(s3) == aff_add(K, want, w2)
+        check_inv(s3)
+        d = tool("padd", curve, st2 + st2[1:])
+        assert xyzz_value(d) == aff_add(K, w2, w2)
+        check_inv(d)
+        # the same point with another representative (scale ZZ by l^2, ZZZ by l^3): P + P must still take the doubling branch
+        lam = rng.randrange(2, p)
+        X, Y, ZZ, ZZZ = (F.value(st2[1 + i * NL:1 + (i + 1) * NL]) * F.Rinv % p for i in range(4))
+        alt = [0] + F.to29(X * lam * lam % p) + F.to29(Y * lam ** 3 % p) + F.to29(ZZ * lam * lam % p) + F.to29(ZZZ * lam ** 3 % p)
+        assert xyzz_value(tool("padd", curve, st2 + alt[1:])) == aff_add(K, w2, w2)
+        negalt = [0] + alt[1:1 + NL] + F.to29(-Y * lam ** 3 % p) + alt[1 + 2 * NL:]
+        assert tool("padd", curve, st2 + negalt[1:])[0] == 1
+        assert xyzz_value(tool("padd", curve, [1] + [0] * (4 * NL) + st2[1:])) == w2
+        # bucket formats: R-form words, R'-form words and the way back
+        w = tool("storept", curve, st2)
+        Rw = 1 << (32 * F.N)
+        got = [sum(w[i * F.N + k] << (32 * k) for k in range(F.N)) for i in range(4)]
+        assert got == [X * Rw % p, Y * Rw % p, ZZ * Rw % p, ZZZ * Rw % p]
+        w = tool("storept29", curve, st2)
+        got = [sum(w[i * F.N + k] << (32 * k) for k in range(F.N)) for i in range(4)]
+        assert got == [X * F.Rp % p, Y * F.Rp % p, ZZ * F.Rp % p, ZZZ * F.Rp % p]
+        assert w[4 * F.N] == 1 and xyzz_value([0] + w[4 * F.N + 1:]) == w2
+        assert tool("storept29", curve, [1] + [0] * (4 * NL))[:4 * F.N + 1] == [0] * (4 * F.N + 1)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_g2_lds_parked_additions(tool, curve):
+    F = Form(curve)
+    K = Fp2(F.p)
+    rng = random.Random(0x71 + F.NL)
+    p, N = F.p, F.N
+    Rw = 1 << (32 * N)
+    for trial in range(6):
+        pts = [((rng.randrange(p), rng.randrange(p)), (rng.randrange(p), rng.randrange(1, p))) for _ in range(10)]
+        seq = [(q, rng.random() < 0.5) for q in pts]
+        seq.insert(1, seq[0])                          # the same signed point twice: doubling branch
+        cut = 6
+        want = None
+        for q, neg in seq[:cut]:
+            want = aff_add(K, want, aff_neg(K, q) if neg else q)
+        seq.insert(cut, (aff_neg(K, want), False))     # cancels the running sum: infinity, then the sequence goes on from there
+        for upto in (1, 2, cut, cut + 1, len(seq)):
+            want = None
+            req = [upto]
+            for q, neg in seq[:upto]:
+                want = aff_add(K, want, aff_neg(K, q) if neg else q)
+                req += [1 if neg else 0] + F.to29(q[0][0]) + F.to29(q[0][1]) + F.to29(q[1][0]) + F.to29(q[1][1])
+            out = tool("madd2seq", curve, req)
+            inf, w = out[0], out[1:]
+            if want is None:
+                assert inf == 1 and not any(w)
+                continue
+            assert inf == 0
+            v = [sum(w[i * N + k] << (32 * k) for k in range(N)) for i in range(8)]
+            assert all(x < p for x in v)                                            # canonical words
+            Rwi = pow(Rw, -1, p)
+            X, Y, ZZ, ZZZ = ((v[2 * i] * Rwi % p, v[2 * i + 1] * Rwi % p) for i in range(4))
+            assert K.mul(K.mul(ZZ, ZZ), ZZ) == K.mul(ZZZ, ZZZ)
+            assert (K.mul(X, K.inv(ZZ)), K.mul(Y, K.inv(ZZZ))) == want

@@ -488,7 +488,7 @@ def test_groth16_synthetic_vs_oracle(zk, name, lg):
     pk.release()
 
 
-@pytest.mark.parametrize("name,group,lg", [("bn128", 1, 14), ("bn128", 2, 12), ("bls12381", 1, 12)])
+@pytest.mark.parametrize("name,group,lg", [("bn128", 1, 14), ("bn128", 2, 12), ("bls12381", 1, 12), ("bls12381", 2, 11)])
 def test_msm_resident_tables(zk, name, group, lg):
     """zkmi_msm_table_*: pre-computed window tables; MSMs over a PREFIX of the resident bases (PLONK commits with PTau[0:k])."""
     import ctypes as C
@@ -511,9 +511,9 @@ def test_msm_resident_tables(zk, name, group, lg):
     zkmi.check(L.zkmi_msm_table_release(h))
 
 
-@pytest.mark.parametrize("name,group", [("bn128", 1), ("bn128", 2), ("bls12381", 1)])
+@pytest.mark.parametrize("name,group", [("bn128", 1), ("bn128", 2), ("bls12381", 1), ("bls12381", 2)])
 def test_msm_resident_tables_special_cases(zk, name, group):
-    """Resident window tables (on BN254 the 29-bit-limb accumulation kernels of msm29.cuh) on inputs that force the special cases of the
+    """Resident window tables (the unsaturated-limb accumulation kernels of msm29.cuh: 9 x 29 bits on BN254, 14 x 28 bits on BLS12-381) on inputs that force the special cases of the
     mixed addition inside one bucket: the same base many times with the same small scalar (P + P doubling branch), a base next to its
     negation (P - P -> infinity and back), points at infinity in the base array, zero scalars, scalars with every digit at the maximum."""
     import ctypes as C
@@ -583,7 +583,7 @@ def _groth16_closed_form(c, name, zk_, w, lg, n_public, rr, ss, b_zero_every):
     return a, b, cc
 
 
-@pytest.mark.parametrize("name,lg,b_zero_every", [("bn128", 20, 3), ("bn128", 20, 0), ("bls12381", 20, 3), ("bn128", 24, 0)])
+@pytest.mark.parametrize("name,lg,b_zero_every", [("bn128", 20, 3), ("bn128", 20, 0), ("bls12381", 20, 3), ("bls12381", 20, 0), ("bn128", 24, 0)])
 def test_groth16_full_size_closed_form(zk, name, lg, b_zero_every):
     """BASELINE configs[1], [4] (2^20 constraints, sparse and dense B sections) and configs[2] (2^24 constraints, single device AND
     8 key shards folded as the ranks would after the all_gather) at their full sizes, checked through a size-independent property:
@@ -723,8 +723,8 @@ def test_soak_many_proofs_same_key(zk):
     assert free_bytes() >= free0 - (64 << 20)
 
 
-@pytest.mark.parametrize("name,lg,world", [("bn128", 12, 3), ("bn128", 16, 8), ("bls12381", 12, 2), ("bn128", 10, 1)])
-def test_groth16_sharded_equals_single_device(zk, name, lg, world):
+@pytest.mark.parametrize("name,lg,world,bze", [("bn128", 12, 3, 3), ("bn128", 16, 8, 3), ("bls12381", 12, 2, 3), ("bn128", 10, 1, 3), ("bn128", 16, 4, 0), ("bls12381", 14, 3, 0)])
+def test_groth16_sharded_equals_single_device(zk, name, lg, world, bze):
     """BASELINE configs[2] (MSMs sharded across the GPUs of a node by base-index range): the `world` key shards are loaded one after
     the other on this one GPU, their partial MSM sums are folded as the ranks would after the all_gather, and the finished proof
     must equal the single-device proof bit for bit (and the CPU oracle's at the small sizes)."""
@@ -732,7 +732,7 @@ def test_groth16_sharded_equals_single_device(zk, name, lg, world):
     from snarkjs_amd import groth16, binfile
     from snarkjs_amd import distributed as D
     c = O.CURVE_ID[name]
-    zkey, wtns = synth_zkey.make(name, lg, seed=0x5A4D + lg, n_public=3)
+    zkey, wtns = synth_zkey.make(name, lg, seed=0x5A4D + lg, n_public=3, b_zero_every=bze)      # bze = 0: dense B1 / B2 sections
     w = binfile.read_wtns(wtns)["witness"]
     r_m, s_m = O.fr_e(c, 0xAAA1), O.fr_e(c, 0xBBB2)
     full = groth16.ProvingKey(zkey)

@@ -1,0 +1,135 @@
+// tools/field29_hosttest.hip — runs the __host__ __device__ arithmetic of csrc/field29.cuh and the point formulas of csrc/msm29.cuh ON THE CPU,
+// driven over stdin/stdout by tests/test_field29_host.py, which checks every result against Python big integers. The build container has no
+// GPU: this is how the unsaturated-limb code (9 x 29 bits, 14 x 28 bits) is verified before it is sent to one. Only the MAC differs between
+// the two compilations (inline v_mad_u64_u32 on the device, a 64-bit multiply-add here); limb bounds, offsets, carries and formulas are shared.
+//
+// build: hipcc --offload-arch=gfx950 -O1 -std=c++17 -Isnarkjs_amd/csrc tools/field29_hosttest.hip -o tools/bin/field29_hosttest
+// protocol: one request per line "<op> <curve> <hex words...>", one reply line of hex words (or "ERR ...").
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <sstream>
+#include <iostream>
+#include "msm29.cuh"
+
+using namespace zkmi;
+
+template <class C> static Fp29<C> rd(const std::vector<uint32_t>& v, size_t& at) {
+    Fp29<C> r;
+    for (int i = 0; i < Lim29<C>::NL; i++) r.l[i] = v.at(at++);
+    return r;
+}
+template <class C> static void wr(std::vector<uint32_t>& o, const Fp29<C>& a) { for (int i = 0; i < Lim29<C>::NL; i++) o.push_back(a.l[i]); }
+
+template <class C, int K> static Fp29<C> sub_k(const Fp29<C>& t, const Fp29<C>& b) { return sub29<C, K>(t, b); }
+template <class C> static bool sub_any(int K, const Fp29<C>& t, const Fp29<C>& b, Fp29<C>& r) {
+    switch (K) {
+#define ZK_CASE(k) case k: r = sub_k<C, k>(t, b); return true;
+        ZK_CASE(1) ZK_CASE(2) ZK_CASE(3) ZK_CASE(4) ZK_CASE(5) ZK_CASE(6) ZK_CASE(7) ZK_CASE(8) ZK_CASE(9) ZK_CASE(11) ZK_CASE(15) ZK_CASE(16) ZK_CASE(32) ZK_CASE(64)
+#undef ZK_CASE
+    }
+    return false;
+}
+
+template <class C> static std::string run(const std::string& op, const std::vector<uint32_t>& v) {
+    constexpr int N = C::N, NL = Lim29<C>::NL;
+    std::vector<uint32_t> o;
+    size_t at = 0;
+    if (op == "mul") { auto a = rd<C>(v, at), b = rd<C>(v, at); wr(o, mul29(a, b)); }
+    else if (op == "mul2") { auto a0 = rd<C>(v, at), b0 = rd<C>(v, at), a1 = rd<C>(v, at), b1 = rd<C>(v, at); wr(o, mul29_2(a0, b0, a1, b1)); }
+    else if (op == "mul4") {
+        Fp29<C> x[8];
+        for (auto& e : x) e = rd<C>(v, at);
+        wr(o, mul29_4(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]));
+    }
+    else if (op == "sqr") { auto a = rd<C>(v, at); wr(o, sqr29(a)); }
+    else if (op == "norm") { auto a = rd<C>(v, at); norm29(a); wr(o, a); }
+    else if (op == "sub") { int K = (int)v.at(at++); auto t = rd<C>(v, at), b = rd<C>(v, at); Fp29<C> r; if (!sub_any<C>(K, t, b, r)) return "ERR K"; wr(o, r); }
+    else if (op == "iszero") { auto a = rd<C>(v, at); o.push_back(is_zero29(a) ? 1u : 0u); }
+    else if (op == "canon") { auto a = rd<C>(v, at); canon29(a); wr(o, a); }
+    else if (op == "unpack") { uint32_t w[N]; for (int i = 0; i < N; i++) w[i] = v.at(at++); wr(o, unpack29<C>(w)); }
+    else if (op == "pack") { auto a = rd<C>(v, at); uint32_t w[N]; pack29<C>(w, a); for (int i = 0; i < N; i++) o.push_back(w[i]); }
+    else if (op == "store" || op == "store29") {
+        auto a = rd<C>(v, at);
+        alignas(16) uint32_t w[N];
+        if (op == "store") store_r256<C, false>(w, a); else store_r256<C, true>(w, a);
+        for (int i = 0; i < N; i++) o.push_back(w[i]);
+    }
+    else if (op == "fromr") { alignas(16) uint32_t w[N]; for (int i = 0; i < N; i++) w[i] = v.at(at++); wr(o, from_r256<C>(w)); }
+    else if (op == "madd" || op == "padd") {
+        // in: inf, X, Y, ZZ, ZZZ, then the operand (x, y | X, Y, ZZ, ZZZ); out: inf, X, Y, ZZ, ZZZ
+        bool inf = v.at(at++) != 0;
+        XYZZ29<C> acc;
+        acc.X = rd<C>(v, at); acc.Y = rd<C>(v, at); acc.ZZ = rd<C>(v, at); acc.ZZZ = rd<C>(v, at);
+        if (op == "madd") { Aff29<C> q; q.x = rd<C>(v, at); q.y = rd<C>(v, at); madd29(acc, inf, q); }
+        else { XYZZ29<C> p; p.X = rd<C>(v, at); p.Y = rd<C>(v, at); p.ZZ = rd<C>(v, at); p.ZZZ = rd<C>(v, at); padd29(acc, inf, p); }
+        o.push_back(inf ? 1u : 0u);
+        wr(o, acc.X); wr(o, acc.Y); wr(o, acc.ZZ); wr(o, acc.ZZZ);
+    }
+    else if (op == "storept" || op == "storept29") {
+        XYZZ29<C> a;
+        bool inf = v.at(at++) != 0;
+        a.X = rd<C>(v, at); a.Y = rd<C>(v, at); a.ZZ = rd<C>(v, at); a.ZZZ = rd<C>(v, at);
+        alignas(16) uint32_t w[4 * N];
+        if (op == "storept") store_xyzz29<C, false>(w, a, inf); else store_xyzz29<C, true>(w, a, inf);
+        for (int i = 0; i < 4 * N; i++) o.push_back(w[i]);
+        if (op == "storept29") {                 // and back through load_xyzz29
+            XYZZ29<C> b;
+            const bool ok = load_xyzz29(b, w);
+            o.push_back(ok ? 1u : 0u);
+            if (ok) { wr(o, b.X); wr(o, b.Y); wr(o, b.ZZ); wr(o, b.ZZZ); }
+        }
+    }
+    else if (op == "madd2seq") {
+        // G2: a sequence of mixed additions into one LDS-parked accumulator (T = 1: the "LDS" is a host array), packed or not as the kernel
+        // has it for this curve. in: count, then count x (neg, x.c0, x.c1, y.c0, y.c1) canonical R'-form limbs; out: inf + 8 N words (store_xyzz29_lds)
+        typedef LdsAcc29<C, 1, Accum29G2<C>::PACK> Acc;
+        std::vector<uint32_t> lds(8 * Acc::EW, 0xdeadbeefu);
+        const Acc A{lds.data()};
+        bool inf = true;
+        const uint32_t cnt = v.at(at++);
+        for (uint32_t k = 0; k < cnt; k++) {
+            const bool neg = v.at(at++) != 0;
+            F2x<C> qx, qy;
+            qx.c0 = rd<C>(v, at); qx.c1 = rd<C>(v, at); qy.c0 = rd<C>(v, at); qy.c1 = rd<C>(v, at);
+            if (neg) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }
+            madd29_lds<C>(A, inf, qx, qy);
+        }
+        alignas(16) uint32_t w[8 * N];
+        store_xyzz29_lds<C>(w, A, inf);
+        o.push_back(inf ? 1u : 0u);
+        for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
+    }
+    else if (op == "consts") {
+        o.push_back(NL); o.push_back(Lim29<C>::B); o.push_back(N); o.push_back(Lim29<C>::NP); o.push_back(Lim29<C>::PINV);
+        for (int i = 0; i < NL; i++) o.push_back(Lim29<C>::p(i));
+        for (int i = 0; i < NL; i++) o.push_back(Lim29<C>::one(i));
+        for (int i = 0; i < NL; i++) o.push_back(Lim29<C>::kin(i));
+        for (int i = 0; i < NL; i++) o.push_back(Lim29<C>::kout(i));
+    }
+    else return "ERR op";
+    if (at != v.size()) return "ERR trailing input";
+    std::ostringstream ss;
+    for (size_t i = 0; i < o.size(); i++) { if (i) ss << ' '; ss << std::hex << o[i]; }
+    return ss.str();
+}
+
+int main() {
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        std::istringstream is(line);
+        std::string op, curve, tok;
+        is >> op >> curve;
+        std::vector<uint32_t> v;
+        while (is >> tok) v.push_back((uint32_t)strtoul(tok.c_str(), nullptr, 16));
+        std::string out;
+        try {
+            if (curve == "bn254fq") out = run<Bn254Fq>(op, v);
+            else if (curve == "bls12381fq") out = run<Bls12381Fq>(op, v);
+            else out = "ERR curve";
+        } catch (const std::exception& e) { out = std::string("ERR ") + e.what(); }
+        std::cout << out << "\n" << std::flush;
+    }
+    return 0;
+}
