@@ -173,6 +173,10 @@ int zkmi_groth16_prove_dev(uint64_t zkey_cache_key, const void* d_witness, const
  * copies; host folds) the throughput-bound front of proof k+1 (buildABC, NTTs, accumulations) already runs. Each slot owns its
  * streams, scratch and work buffers; d_witness must stay valid until the slot is collected. prove_dev == submit(0) + collect(0). */
 int zkmi_groth16_submit_dev(uint64_t zkey_cache_key, const void* d_witness, int slot);
+/* The same for a witness in HOST memory (wtns section 2, witness_len = n_vars x 32): it crosses PCIe on the slot's own stream into the
+ * slot's own buffer, i.e. underneath the kernels of the proof in the other slot — the throughput mode of a host that keeps witnesses in
+ * host memory (js/groth16_native.js: proveMany). `witness` may be re-used as soon as the call returns. */
+int zkmi_groth16_submit(uint64_t zkey_cache_key, const uint8_t* witness, size_t witness_len, int slot);
 int zkmi_groth16_collect(uint64_t zkey_cache_key, int slot, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 int zkmi_groth16_release(uint64_t zkey_cache_key);
 /* Multi-GPU proof (BASELINE configs[2]: MSMs sharded across the GPUs of a node). Every rank loads the shard of the
@@ -191,6 +195,11 @@ int zkmi_groth16_sums_dev(uint64_t zkey_cache_key, const void* d_witness, uint8_
  * xGMI, domain*32 bytes leave each owner in total); rank j joins its three slices (zkmi_groth16_join_abc_dev) into ITS H-MSM scalars and
  * zkmi_groth16_sums_h_dev runs the five MSMs of its key shard with them — no rank repeats another rank's transforms. */
 int zkmi_groth16_chains_dev(uint64_t zkey_cache_key, const void* d_witness, unsigned chain_mask, void* d_a, void* d_b, void* d_c);
+/* The shard's MSMs in two halves, so that no rank idles while transforms run elsewhere and slices travel: zkmi_groth16_sums_w_dev enqueues
+ * the witness-side half (digit sorts of the witness, bucket accumulations B2, B1, A, C, the G2 bucket reduction — they need the witness
+ * only) and returns at once; zkmi_groth16_sums_h_dev then enqueues the H half (digit sort of d_h_scalars, accumulation H, the batched G1
+ * bucket reductions), waits and returns the sums. Without a preceding _sums_w_dev, _sums_h_dev runs both halves (r02 behaviour). */
+int zkmi_groth16_sums_w_dev(uint64_t zkey_cache_key, const void* d_witness);
 int zkmi_groth16_sums_h_dev(uint64_t zkey_cache_key, const void* d_witness, const void* d_h_scalars, uint8_t* sums);
 int zkmi_groth16_finish(uint64_t zkey_cache_key, const uint8_t* sums, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 /* Device time (ms, HIP events) of the stages of the last proof, in order: buildABC, 6 NTTs, joinABC, sort(witness),
@@ -298,6 +307,10 @@ int zkmi_gen_geometric_bases_dev(int curve, int group, size_t n, uint64_t f, uin
  * the base sections of synthetic VALID proving keys built from a known trapdoor (src/zkey_new.js:182-201, :338-502
  * compute the same points from a ptau file). For tests and benchmarks. */
 int zkmi_gen_bases_from_scalars_dev(int curve, int group, const void* d_scalars, size_t n, void* d_out);
+/* Page-lock caller-owned host memory for device transfers (hipHostRegister): shared-memory regions through which the processes of a
+ * multi-GPU proof exchange chain outputs (js/groth16_shards.js). Optional: transfers from unregistered memory work, slower. */
+int zkmi_host_register(void* host_ptr, size_t bytes);
+int zkmi_host_unregister(void* host_ptr);
 /* G.toAffine on host for one Jacobian point (tiny; used by bindings to normalise results). */
 int zkmi_to_affine(int curve, int group, const uint8_t* jacobian, uint8_t* affine);
 /* G.add on host for two Jacobian points (O(1)): folds the per-GPU partial results of a sharded MSM

@@ -109,6 +109,11 @@ struct G16Key {
         hipEvent_t ev[ST_COUNT + 1] = {};
         MsmJob job[5];
         bool in_flight = false, ov = false;
+        // the witness-side half of a proof has been enqueued (zkmi_groth16_sums_w_dev) and waits for its H half: bucket shape of the
+        // witness plan (the H accumulation merges into C's buckets when the shapes agree)
+        bool w_enqueued = false;
+        int pl_W = 0;
+        uint32_t pl_nb = 0;
     } wk[2];
     std::vector<uint8_t> vk_alpha_1, vk_beta_1, vk_beta_2, vk_delta_1, vk_delta_2;
     mutable std::vector<uint8_t> fb_delta1, fb_delta2;   // host fixed-base tables of delta (g16_finish), built on first use
@@ -328,11 +333,20 @@ static void g16_finish(const G16Key& K, const uint8_t* jA, const uint8_t* jB1, c
 // partial sums over its base-index range, to be added across devices before g16_finish.
 // g16_enqueue puts the whole device part of a proof on the streams of the ACTIVE pipeline slot and returns without waiting;
 // g16_complete waits for that slot and folds the window sums on the host.
-template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, const void* d_h_ext = nullptr) {
+// phase G16_ALL: the whole device part. The multi-GPU proof splits it so that no rank idles while the chain outputs travel:
+// G16_W = the witness-side half (digit sorts of the witness, accumulations B2, B1, A, C, the G2 bucket reduction) — needs the witness only;
+// G16_H = the H half (digit sort of this shard's H scalars, accumulation H, the batched G1 bucket reductions) — needs d_h_ext, computed
+// elsewhere and received over xGMI. G16_W followed by G16_H in the same pipeline slot enqueues the same kernels as G16_ALL with d_h_ext.
+enum { G16_ALL = 0, G16_W = 1, G16_H = 2 };
+template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, const void* d_h_ext = nullptr, int phase = G16_ALL) {
     Ctx& cx = ctx();
     ZK_TRY(g16_work_alloc(K, cx.pipe));
     G16Key::Work& Wk = K.wk[cx.pipe];
     if (Wk.in_flight) return fail(ZKMI_ERR_INVALID, "groth16: this pipeline slot already holds a proof in flight (collect it first)");
+    if (phase == G16_H && !Wk.w_enqueued) return fail(ZKMI_ERR_INVALID, "groth16: the witness-side half of this proof has not been enqueued");
+    if (phase != G16_H && Wk.w_enqueued) return fail(ZKMI_ERR_INVALID, "groth16: a witness-side half is waiting for its H half in this pipeline slot");
+    if (phase == G16_H && !d_h_ext) return fail(ZKMI_ERR_INVALID, "groth16: the H half needs its scalars");
+    const bool do_w = phase != G16_H, do_h = phase != G16_W, transforms = phase == G16_ALL && !d_h_ext;
     hipStream_t st = cx.stream;
     const uint32_t n = K.domain;
     const host::HField<4> Fr = host::HField<4>::from_cfg<FrC>();
@@ -347,7 +361,7 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, co
     static const bool ov = !(getenv("ZKMI_OVERLAP") && atoi(getenv("ZKMI_OVERLAP")) == 0);
     MsmPlan pl, plh, plb;
     MsmJob* job = Wk.job;
-    for (int i = 0; i < 5; i++) { job[i] = MsmJob(); ZK_TRY(msm_job_slot(i, job[i])); }
+    if (do_w) for (int i = 0; i < 5; i++) { job[i] = MsmJob(); ZK_TRY(msm_job_slot(i, job[i])); }
     // Two digit sorts of the witness: one without the entries whose B bases are at infinity (feeds B2 and B1), one complete
     // (feeds A and C). The second sort pays for itself once ~10 % of the B bases are at infinity.
     const bool split_b = K.b_density < 0.9;
@@ -357,6 +371,8 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, co
         ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 0, true));        // njobs = 0: only creates the auxiliary stream
         aux = cx.aux_stream;
         if (!cx.sort_ev[0]) for (int i = 0; i < 5; i++) ZK_HIP(hipEventCreateWithFlags(&cx.sort_ev[i], hipEventDisableTiming));
+    }
+    if (ov && do_w) {
         ZK_HIP(hipEventRecord(cx.sort_ev[0], st));                   // the witness upload (if any) is ordered before this point
         ZK_HIP(hipStreamWaitEvent(aux, cx.sort_ev[0], 0));
         cx.stream = aux;
@@ -367,10 +383,10 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, co
         cx.stream = st;
         ZK_TRY(rc);
     }
-    ZK_HIP(hipEventRecord(Wk.ev[ST_BUILD], st));
-    if (!d_h_ext) hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, w, n, Wk.A, Wk.B, Wk.C);
-    ZK_HIP(hipEventRecord(Wk.ev[ST_NTT], st));
-    if (!d_h_ext) {
+    if (do_w) ZK_HIP(hipEventRecord(Wk.ev[ST_BUILD], st));
+    if (transforms) hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, w, n, Wk.A, Wk.B, Wk.C);
+    if (do_w) ZK_HIP(hipEventRecord(Wk.ev[ST_NTT], st));
+    if (transforms) {
         // inc = power == Fr.s ? Fr.shift : Fr.w[power+1] (:64); Fr.shift = nqr^2 — both come from the NTT module's root table
         uint8_t one[32], inc[32];
         memcpy(one, Fr.one, 32);
@@ -387,19 +403,23 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, co
             }
         }
     }
-    ZK_HIP(hipEventRecord(Wk.ev[ST_JOIN], st));
-    if (!d_h_ext) ZK_TRY(join_abc_dev_dispatch(K.curve, Wk.A, Wk.B, Wk.C, Wk.T, n));          // T = H-MSM scalars (normal form)
-    ZK_HIP(hipEventRecord(Wk.ev[ST_SORT_W], st));
-    if (ov) {
+    if (do_w) ZK_HIP(hipEventRecord(Wk.ev[ST_JOIN], st));
+    if (transforms) ZK_TRY(join_abc_dev_dispatch(K.curve, Wk.A, Wk.B, Wk.C, Wk.T, n));          // T = H-MSM scalars (normal form)
+    if (do_w) ZK_HIP(hipEventRecord(Wk.ev[ST_SORT_W], st));
+    // the digit sort of the H scalars: as soon as they exist (after joinABC here; at once when they come from outside)
+    auto sort_h_aux = [&]() -> int {
         ZK_HIP(hipEventRecord(cx.sort_ev[3], st));
         ZK_HIP(hipStreamWaitEvent(aux, cx.sort_ev[3], 0));
         cx.stream = aux;
         int rc = msm_sort(h_sh, K.h_cnt, 32, plh, 1, K.ch);
         if (!rc) rc = hipEventRecord(cx.sort_ev[4], aux) == hipSuccess ? 0 : fail(ZKMI_ERR_HIP, "hipEventRecord");
         cx.stream = st;
-        ZK_TRY(rc);
-        ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[1], 0));
-    } else ZK_TRY(msm_sort(w_sh, K.v_cnt, 32, split_b ? plb : pl, split_b ? 2 : 0, K.cw, 0, split_b ? K.drop_b : nullptr));
+        return rc;
+    };
+    if (ov && do_h && do_w) ZK_TRY(sort_h_aux());
+    if (do_w) {
+    if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[1], 0));
+    else ZK_TRY(msm_sort(w_sh, K.v_cnt, 32, split_b ? plb : pl, split_b ? 2 : 0, K.cw, 0, split_b ? K.drop_b : nullptr));
     const MsmPlan& pB = split_b ? plb : pl;
     // The G2 MSM goes first: its bucket reduction is pure latency (~50 us per Fq2 point addition, little parallel work), so it
     // also runs on the auxiliary stream, underneath the G1 accumulations.
@@ -420,13 +440,21 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, co
     ZK_HIP(hipEventRecord(Wk.ev[ST_MSM_C], st));
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bC, pl, K.c_skip, job[3], K.mask[3]));
     ZK_HIP(hipEventRecord(Wk.ev[ST_SORT_H], st));
+    Wk.pl_W = pl.sh.W; Wk.pl_nb = pl.sh.nb;
+    }
+    if (!do_h) {                                               // witness-side half only: the H half follows in this slot
+        ZK_HIP(hipGetLastError());
+        Wk.w_enqueued = true; Wk.ov = ov;
+        return ZKMI_OK;
+    }
+    if (ov && !do_w) ZK_TRY(sort_h_aux());
     if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[4], 0));
     else ZK_TRY(msm_sort(h_sh, K.h_cnt, 32, plh, 1, K.ch));
     ZK_HIP(hipEventRecord(Wk.ev[ST_MSM_H], st));
     // pi_c only needs C + H (:115): when both MSMs have the same bucket shape, H is accumulated into C's buckets and the two share
     // one bucket reduction (ZKMI_MERGE_CH=0 keeps them apart)
     static const bool merge_env = !(getenv("ZKMI_MERGE_CH") && atoi(getenv("ZKMI_MERGE_CH")) == 0);
-    const bool merge_ch = merge_env && K.ch == K.cw && plh.sh.W == pl.sh.W && plh.sh.nb == pl.sh.nb;
+    const bool merge_ch = merge_env && K.ch == K.cw && plh.sh.W == Wk.pl_W && plh.sh.nb == Wk.pl_nb;
     ZK_TRY(msm_accumulate_dispatch(K.curve, 1, K.bH, plh, 0, job[4], K.mask[4], merge_ch ? &job[3] : nullptr));
     ZK_HIP(hipEventRecord(Wk.ev[ST_REDUCE], st));
     // bucket reductions are latency-bound: all G1 jobs of one shape go through ONE set of launches
@@ -437,7 +465,7 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, co
     if (!ov) ZK_TRY(msm_reduce_dispatch(K.curve, 2, g2, 1));
     ZK_HIP(hipEventRecord(Wk.ev[ST_COUNT], st));
     ZK_HIP(hipGetLastError());
-    Wk.in_flight = true; Wk.ov = ov;
+    Wk.in_flight = true; Wk.ov = ov; Wk.w_enqueued = false;
     return ZKMI_OK;
 }
 template <class FrC> static int g16_complete(G16Key& K, uint8_t* jA, uint8_t* jB1, uint8_t* jB2, uint8_t* jC, uint8_t* jH) {
@@ -565,6 +593,14 @@ int zkmi_groth16_chains_dev(uint64_t key, const void* d_witness, unsigned chain_
     if (K->curve == ZKMI_CURVE_BN128) return g16_chains<Bn254Fr>(*K, d_witness, chain_mask, d_a, d_b, d_c);
     return g16_chains<Bls12381Fr>(*K, d_witness, chain_mask, d_a, d_b, d_c);
 }
+int zkmi_groth16_sums_w_dev(uint64_t key, const void* d_witness) {
+    ZK_TRY(require_ctx());
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_sums_w_dev: key not loaded");
+    if (!d_witness) return fail(ZKMI_ERR_INVALID, "groth16_sums_w_dev: null witness");
+    g_last_key = key;
+    return K->curve == ZKMI_CURVE_BN128 ? g16_enqueue<Bn254Fr>(*K, d_witness, nullptr, G16_W) : g16_enqueue<Bls12381Fr>(*K, d_witness, nullptr, G16_W);
+}
 int zkmi_groth16_sums_h_dev(uint64_t key, const void* d_witness, const void* d_h_scalars, uint8_t* sums) {
     ZK_TRY(require_ctx());
     G16Key* K = g16_find(key);
@@ -573,9 +609,31 @@ int zkmi_groth16_sums_h_dev(uint64_t key, const void* d_witness, const void* d_h
     g_last_key = key;
     const size_t j1 = 3 * (size_t)n8q_of(K->curve);
     uint8_t *jA = sums, *jB1 = sums + j1, *jB2 = sums + 2 * j1, *jC = sums + 4 * j1, *jH = sums + 5 * j1;
-    if (K->curve == ZKMI_CURVE_BN128) { ZK_TRY(g16_enqueue<Bn254Fr>(*K, d_witness, d_h_scalars)); return g16_complete<Bn254Fr>(*K, jA, jB1, jB2, jC, jH); }
-    ZK_TRY(g16_enqueue<Bls12381Fr>(*K, d_witness, d_h_scalars));
+    // after zkmi_groth16_sums_w_dev only the H half is left to enqueue; without it the call runs both halves
+    const int phase = K->wk[ctx().pipe].w_enqueued ? G16_H : G16_ALL;
+    if (K->curve == ZKMI_CURVE_BN128) { ZK_TRY(g16_enqueue<Bn254Fr>(*K, d_witness, d_h_scalars, phase)); return g16_complete<Bn254Fr>(*K, jA, jB1, jB2, jC, jH); }
+    ZK_TRY(g16_enqueue<Bls12381Fr>(*K, d_witness, d_h_scalars, phase));
     return g16_complete<Bls12381Fr>(*K, jA, jB1, jB2, jC, jH);
+}
+/* Host-witness variant of zkmi_groth16_submit_dev: the witness crosses PCIe on the SLOT's stream into the slot's own buffer, so the upload of
+ * proof k+1 runs underneath the kernels of proof k in the other slot (throughput mode of a host that holds witnesses in host memory: the
+ * Node addon). `witness` must stay valid until the call returns (pageable memory is staged by the runtime before it does). */
+int zkmi_groth16_submit(uint64_t key, const uint8_t* witness, size_t witness_len, int slot) {
+    ZK_TRY(require_ctx());
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_submit: key not loaded");
+    if (!K->full()) return fail(ZKMI_ERR_INVALID, "groth16_submit: the key is a shard");
+    if (!witness) return fail(ZKMI_ERR_INVALID, "groth16_submit: null witness");
+    if (witness_len != (size_t)K->n_vars * 32)
+        return fail(ZKMI_ERR_INVALID, "Invalid witness length. Circuit: " + std::to_string(K->n_vars) + ", witness: " + std::to_string(witness_len / 32));
+    ZK_TRY(select_pipe(slot));
+    g_last_key = key;
+    int rc = g16_work_alloc(*K, slot);
+    if (!rc && K->wk[slot].in_flight) rc = fail(ZKMI_ERR_INVALID, "groth16: this pipeline slot already holds a proof in flight (collect it first)");
+    if (!rc && hipMemcpyAsync(K->wk[slot].w, witness, witness_len, hipMemcpyHostToDevice, ctx().stream) != hipSuccess) rc = fail(ZKMI_ERR_HIP, "groth16_submit: witness upload");
+    if (!rc) rc = K->curve == ZKMI_CURVE_BN128 ? g16_enqueue<Bn254Fr>(*K, K->wk[slot].w) : g16_enqueue<Bls12381Fr>(*K, K->wk[slot].w);
+    int rc2 = select_pipe(0);
+    return rc ? rc : rc2;
 }
 int zkmi_groth16_submit_dev(uint64_t key, const void* d_witness, int slot) {
     ZK_TRY(require_ctx());

@@ -302,6 +302,18 @@ int zkmi_memcpy_d2h(void* h, const void* d, size_t bytes) {
     return ZKMI_OK;
 }
 
+int zkmi_host_register(void* host_ptr, size_t bytes) {
+    ZK_TRY(require_ctx());
+    if (!host_ptr || !bytes) return fail(ZKMI_ERR_INVALID, "host_register: null or empty range");
+    ZK_HIP(hipHostRegister(host_ptr, bytes, hipHostRegisterPortable));
+    return ZKMI_OK;
+}
+int zkmi_host_unregister(void* host_ptr) {
+    ZK_TRY(require_ctx());
+    if (!host_ptr) return ZKMI_OK;
+    ZK_HIP(hipHostUnregister(host_ptr));
+    return ZKMI_OK;
+}
 int zkmi_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes) {
     ZK_TRY(require_ctx());
     if (bytes) ZK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, g_ctx.stream));

@@ -99,10 +99,17 @@ class DeviceShard:
         zkmi.check(zkmi.lib().zkmi_groth16_chains_dev(self.pk.key, self.d_witness, mask, ptr(0), ptr(1), ptr(2)))      # synchronises the library stream
         return out
 
+    def sums_w(self):
+        """Enqueue the witness-side half of this shard's MSMs (digit sorts of the witness, accumulations B2, B1, A, C, the G2 bucket
+        reduction): needs the witness only, returns at once — the kernels run while the chain slices travel (zkmi_groth16_sums_w_dev)."""
+        zkmi.check(zkmi.lib().zkmi_groth16_sums_w_dev(self.pk.key, self.d_witness))
+
     def join(self, a, b, c, cnt):
         """joinABC (:79, :320-374) on this rank's slice -> H-MSM scalars (normal form)"""
         h = self.empty(cnt * 32)
-        self.torch.cuda.synchronize()                         # the exchanged slices were written on torch's stream
+        # the exchanged slices were written on torch's streams: wait for THOSE (a device-wide synchronize would also wait for the
+        # witness-side accumulations already running on the library's stream)
+        self.torch.cuda.current_stream().synchronize()
         if cnt:
             zkmi.check(zkmi.lib().zkmi_groth16_join_abc_dev(self.curve_id, a.data_ptr(), b.data_ptr(), c.data_ptr(), h.data_ptr(), cnt))
         return h
@@ -122,10 +129,11 @@ class DeviceShard:
             self._wbuf = None
 
 
-def exchange_chain_slices(be, outs, rank, world, h_ranges, process_group=None):
-    """The reduce-scatter-shaped exchange of the chain-parallel proof: the owner of chain c sends rank j the byte slice
-    [32*h_lo_j, 32*h_hi_j) of its output; returns this rank's three slices [A', B', C']. Point-to-point (batch_isend_irecv: RCCL
-    send/recv over xGMI, or gloo on CPU); domain*32 bytes leave each owner in total, nothing is replicated."""
+def start_chain_exchange(be, outs, rank, world, h_ranges, process_group=None):
+    """Starts the reduce-scatter-shaped exchange of the chain-parallel proof: the owner of chain c sends rank j the byte slice
+    [32*h_lo_j, 32*h_hi_j) of its output. Returns (this rank's three slice buffers [A', B', C'], pending requests): the buffers are
+    complete after wait_chain_exchange. Point-to-point (batch_isend_irecv: RCCL send/recv over xGMI, or gloo on CPU); domain*32 bytes
+    leave each owner in total, nothing is replicated."""
     import torch.distributed as dist
     lo, hi = h_ranges[rank]
     mine = [None, None, None]
@@ -143,9 +151,18 @@ def exchange_chain_slices(be, outs, rank, world, h_ranges, process_group=None):
             ops.append(dist.P2POp(dist.irecv, mine[c], o, group=process_group))
         else:
             mine[c] = be.empty(0)
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    return mine, (dist.batch_isend_irecv(ops) if ops else [])
+
+
+def wait_chain_exchange(reqs):
+    for req in reqs:
+        req.wait()
+
+
+def exchange_chain_slices(be, outs, rank, world, h_ranges, process_group=None):
+    """start_chain_exchange + wait_chain_exchange in one call."""
+    mine, reqs = start_chain_exchange(be, outs, rank, world, h_ranges, process_group)
+    wait_chain_exchange(reqs)
     return mine
 
 
@@ -154,9 +171,11 @@ def groth16_prove_sharded(pk, witness, r_mont, s_mont, process_group=None, d_wit
 
       1. chain-parallel transforms: rank c % world runs buildABC + the iNTT -> coset -> NTT chain c (A, B, C are independent until
          joinABC, src/groth16_prove.js:64-79);
-      2. every chain owner sends rank j the slice [h_lo_j, h_hi_j) of its output (point-to-point over xGMI);
-      3. rank j joins its slices into ITS H-MSM scalars and runs the five MSMs of its key shard (base-index ranges of A/B1/B2/C/H);
-      4. ONE all_gather of the 7*3*n8q-byte partial sums, folded in rank order: every rank returns the identical (pi_a, pi_b, pi_c).
+      2. every chain owner starts sending rank j the slice [h_lo_j, h_hi_j) of its output (point-to-point over xGMI);
+      3. WHILE the slices travel every rank runs the witness-side half of its shard's MSMs (A, B1, B2, C depend on the witness only:
+         ranks without a chain start here at time 0, nobody idles through the transforms and the exchange);
+      4. rank j joins its slices into ITS H-MSM scalars and runs the H half (digit sort, accumulation H, G1 bucket reductions);
+      5. ONE all_gather of the 7*3*n8q-byte partial sums, folded in rank order: every rank returns the identical (pi_a, pi_b, pi_c).
 
     pk: ProvingKey(zkey, shard=(rank, world)) on every rank; witness: the FULL witness on every rank; r_mont, s_mont: the same
     blinding draws on every rank. backend: object with the DeviceShard interface (the gloo CPU test passes an oracle-backed one)."""
@@ -166,7 +185,9 @@ def groth16_prove_sharded(pk, witness, r_mont, s_mont, process_group=None, d_wit
     try:
         h_ranges = [shard_range(be.n, j, world) for j in range(world)]
         outs = be.chains([c for c in range(3) if chain_owner(c, world) == rank])
-        a, b, c = exchange_chain_slices(be, outs, rank, world, h_ranges, process_group)
+        (a, b, c), reqs = start_chain_exchange(be, outs, rank, world, h_ranges, process_group)
+        be.sums_w()                                            # witness-side MSMs underneath the exchange
+        wait_chain_exchange(reqs)
         lo, hi = h_ranges[rank]
         part = be.sums(be.join(a, b, c, hi - lo))
         return be.finish(fold_groth16_sums(be.curve_id, all_gather_bytes(part, process_group)), r_mont, s_mont)
@@ -189,6 +210,7 @@ def groth16_prove_sharded_local(make_shard, world, r_mont, s_mont):
         for j, be in enumerate(bes):
             lo, hi = h_ranges[j]
             sl = [outs[c][32 * lo:32 * hi].clone() if hi > lo else be.empty(0) for c in range(3)]
+            be.sums_w()                                        # the same split order as the ranks run it: witness-side half, join, H half
             parts.append(be.sums(be.join(sl[0], sl[1], sl[2], hi - lo)))
         return bes[-1].finish(fold_groth16_sums(bes[0].curve_id, parts), r_mont, s_mont)
     finally:

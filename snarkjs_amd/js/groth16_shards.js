@@ -1,0 +1,185 @@
+// snarkjs_amd/js/groth16_shards.js — ONE Groth16 proof over several GPUs from Node.js (BASELINE configs[2]; north star: "host side stays
+// Node.js"). The Node twin of snarkjs_amd/distributed.py: one worker PROCESS per GPU (child_process.fork — the library binds one device per
+// process), the same split of the work, the exchange through page-locked shared host memory instead of RCCL.
+//
+// What the reference does with its workers (ffjavascript engine_multiexp, build/snarkjs.min.js:1@214651): cut a multiExp into contiguous index
+// chunks, one per worker, add the chunk results on the host. Here a chunk is the base-index range of a GPU's key shard, and the transforms are
+// split too:
+//   1. every worker uploads the witness; the owner of chain c (rank c % world) runs buildABC + iNTT -> coset -> NTT of chain c
+//      (src/groth16_prove.js:64-76: A, B, C are independent until joinABC) and copies its output into the shared region of that chain;
+//   2. meanwhile every worker runs the witness-side half of its shard's MSMs (A, B1, B2, C need the witness only: zkmi_groth16_sums_w_dev);
+//   3. when the three regions are complete each worker uploads ITS slice [h_lo, h_hi) of them, joins it into its H-MSM scalars
+//      (zkmi_groth16_join_abc_dev) and runs the H half (zkmi_groth16_sums_h_dev): 7 x 3 x n8q bytes of partial sums per worker;
+//   4. worker 0 adds the sums of all workers point by point in rank order (zkmi_point_add) and applies blinding + toAffine
+//      (zkmi_groth16_finish, src/groth16_prove.js:103-132).
+// Control messages travel over the fork IPC channel (a few hundred bytes each); the bulk data (domain x 32 bytes per chain) only through
+// the shared regions: owner GPU -> pinned host pages -> the other GPUs over PCIe.
+//
+//   const { ShardedProver } = require("snarkjs_amd/js/groth16_shards.js");
+//   const sp = new ShardedProver({ world: 8, zkeyPath });          // forks the workers, every worker loads its key shard
+//   await sp.ready();
+//   const { proof, publicSignals } = await sp.prove(wtnsBytes, { r, s });      // r, s: Montgomery Fr bytes (default: fresh random draws)
+//   await sp.close();
+"use strict";
+const path = require("path"), fs = require("fs"), crypto = require("crypto");
+const { fork } = require("child_process");
+const { parseZkey, parseWtns } = require("./groth16_native.js");
+
+const R = { 0: 21888242871839275222246405745257275088548364400416034343698204186575808495617n, 1: 52435875175126190479447740508185965837690552500527637822603658699938581184513n };
+const Q = { 0: 21888242871839275222246405745257275088696311157297823662689037894645226208583n,
+            1: 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaabn };
+const fromLE = (b) => { let v = 0n; for (let i = b.length - 1; i >= 0; i--) v = (v << 8n) | BigInt(b[i]); return v; };
+const toLE = (v, n) => { const o = new Uint8Array(n); for (let i = 0; i < n; i++) { o[i] = Number(v & 0xffn); v >>= 8n; } return o; };
+function modinv(a, m) { let [r0, r1, s0, s1] = [((a % m) + m) % m, m, 1n, 0n]; while (r1 !== 0n) { const q = r0 / r1; [r0, r1] = [r1, r0 - q * r1]; [s0, s1] = [s1, s0 - q * s1]; } return ((s0 % m) + m) % m; }
+// contiguous slice [lo, hi) of n terms owned by `rank` (ceil split, like the reference's chunking; = distributed.py: shard_range)
+function shardRange(n, rank, world) { const per = Math.ceil(n / world), lo = Math.min(n, rank * per); return [lo, Math.min(n, lo + per)]; }
+const chainOwner = (c, world) => c % world;
+// affine Montgomery bytes -> the decimal strings of G1.toObject / G2.toObject (projective [x, y, "1"])
+function pointToObject(cid, group, bytes) {
+    const q = Q[cid], n8q = cid === 0 ? 32 : 48, ri = modinv((1n << BigInt(8 * n8q)) % q, q);
+    const el = (k) => (fromLE(bytes.subarray(k * n8q, (k + 1) * n8q)) * ri % q).toString();
+    const zero = bytes.every((x) => x === 0);
+    if (group === 1) return zero ? ["0", "1", "0"] : [el(0), el(1), "1"];
+    return zero ? [["0", "0"], ["1", "0"], ["0", "0"]] : [[el(0), el(1)], [el(2), el(3)], ["1", "0"]];
+}
+// a uniform Fr element in Montgomery form (the reference draws with its ChaCha: curve.Fr.random(), src/groth16_prove.js:103-104)
+function randomFrMont(cid) { const r = R[cid]; return toLE((fromLE(crypto.randomBytes(64)) % r) * ((1n << 256n) % r) % r, 32); }
+
+// ---- worker process -----------------------------------------------------------------------------------------------------------------------
+async function workerMain() {
+    const cfg = JSON.parse(process.env.ZKMI_SHARD_CFG);
+    const addon = require(cfg.addonPath);
+    const { rank, world } = cfg;
+    await addon.init(cfg.devices ? cfg.devices[rank] : rank);
+    const zkeyBytes = new Uint8Array(fs.readFileSync(cfg.zkeyPath));
+    const zk = parseZkey(zkeyBytes);
+    const n = zk.domainSize, m = zk.nVars, cid = zk.curveId, key = 1;
+    const [vLo, vHi] = shardRange(m, rank, world), [hLo, hHi] = shardRange(n, rank, world);
+    await addon.groth16LoadShard(zk.desc, key, vLo, vHi, hLo, hHi);
+    const owned = [0, 1, 2].filter((c) => chainOwner(c, world) === rank);
+    const shm = [0, 1, 2].map((c) => addon.shmMap(`${cfg.shmPrefix}_c${c}`, n * 32, false));
+    const dW = await addon.devAlloc(m * 32);
+    const dChain = {};
+    for (const c of owned) dChain[c] = await addon.devAlloc(n * 32);
+    const cnt = hHi - hLo;
+    const dSl = [], dH = await addon.devAlloc(Math.max(cnt, 1) * 32);
+    for (let c = 0; c < 3; c++) dSl.push(await addon.devAlloc(Math.max(cnt, 1) * 32));
+    process.send({ ev: "ready", rank });
+    process.on("message", async (msg) => {
+        try {
+            if (msg.cmd === "prove") {
+                const witness = new Uint8Array(fs.readFileSync(msg.wtnsPath));
+                await addon.memcpyH2D(dW, parseWtns(witness, zk));
+                if (owned.length) {                         // transforms first: their output leaves early
+                    const ptr = (c) => (dChain[c] === undefined ? 0 : dChain[c]);
+                    await addon.groth16ChainsDev(key, dW, owned.reduce((a, c) => a | (1 << c), 0), ptr(0), ptr(1), ptr(2));
+                    for (const c of owned) { await addon.memcpyD2H(shm[c], dChain[c]); process.send({ ev: "chain", id: msg.id, chain: c }); }
+                }
+                await addon.groth16SumsWDev(key, dW);       // witness-side MSMs: enqueued, run while the other chains finish and travel
+                process.send({ ev: "w", id: msg.id, rank });
+            } else if (msg.cmd === "slices") {
+                if (cnt) {
+                    for (let c = 0; c < 3; c++) await addon.memcpyH2D(dSl[c], shm[c].subarray(32 * hLo, 32 * hHi));
+                    await addon.joinABCDev(cid, dSl[0], dSl[1], dSl[2], dH, cnt);
+                }
+                const sums = await addon.groth16SumsHDev(cid, key, dW, dH);
+                process.send({ ev: "sums", id: msg.id, rank, sums: Buffer.from(sums).toString("base64") });
+            } else if (msg.cmd === "finish") {             // worker 0: fold in rank order + blinding + toAffine
+                const q = cid === 0 ? 32 : 48, j1 = 3 * q;
+                const parts = msg.sums.map((b) => new Uint8Array(Buffer.from(b, "base64")));
+                const total = new Uint8Array(7 * j1);
+                for (const [a, b, grp] of [[0, j1, 1], [j1, 2 * j1, 1], [2 * j1, 4 * j1, 2], [4 * j1, 5 * j1, 1], [5 * j1, 6 * j1, 1]]) {
+                    let acc = new Uint8Array(b - a);
+                    for (const p of parts) acc = await addon.pointAdd(cid, grp, acc, p.subarray(a, b));
+                    total.set(acc, a);
+                }
+                const res = await addon.groth16Finish(cid, key, total, new Uint8Array(Buffer.from(msg.r, "base64")), new Uint8Array(Buffer.from(msg.s, "base64")));
+                process.send({ ev: "proof", id: msg.id, pi_a: Buffer.from(res.pi_a).toString("base64"), pi_b: Buffer.from(res.pi_b).toString("base64"), pi_c: Buffer.from(res.pi_c).toString("base64") });
+            } else if (msg.cmd === "exit") {
+                try { addon.groth16Release(key); } catch (e) { /* going away anyway */ }
+                process.exit(0);
+            }
+        } catch (e) { process.send({ ev: "error", id: msg.id, rank, message: String(e && e.message || e) }); }
+    });
+}
+
+// ---- parent ---------------------------------------------------------------------------------------------------------------------------------
+class ShardedProver {
+    constructor(opts) {
+        this.world = opts.world;
+        this.zkeyPath = opts.zkeyPath;
+        this.addonPath = opts.addonPath || path.join(__dirname, "..", "napi", "zkmi_napi.node");
+        const addon = this.addon = require(this.addonPath);
+        const zk = this.zk = parseZkey(new Uint8Array(fs.readFileSync(this.zkeyPath)));
+        this.shmPrefix = `/zkmi_${process.pid}_${crypto.randomBytes(4).toString("hex")}`;
+        // the three chain-output regions: created here, mapped by every worker; unlinked at close()
+        this.regions = [0, 1, 2].map((c) => addon.shmMap(`${this.shmPrefix}_c${c}`, zk.domainSize * 32, true));
+        this.waiters = new Map();
+        this.nextId = 1;
+        this.workers = [];
+        this._ready = new Promise((resolve, reject) => {
+            let up = 0;
+            for (let rank = 0; rank < this.world; rank++) {
+                const cfg = { rank, world: this.world, zkeyPath: this.zkeyPath, addonPath: this.addonPath, shmPrefix: this.shmPrefix, devices: opts.devices || null };
+                const w = fork(__filename, ["--zkmi-shard-worker"], { env: Object.assign({}, process.env, { ZKMI_SHARD_CFG: JSON.stringify(cfg) }), execArgv: opts.execArgv || process.execArgv });
+                w.on("message", (msg) => {
+                    if (msg.ev === "ready") { if (++up === this.world) resolve(); return; }
+                    if (msg.ev === "error" && !msg.id) { reject(new Error(`shard worker ${msg.rank}: ${msg.message}`)); return; }
+                    const wt = this.waiters.get(msg.id);
+                    if (wt) wt(msg);
+                });
+                w.on("exit", (code) => { if (code && up < this.world) reject(new Error(`shard worker ${rank} exited with code ${code}`)); });
+                this.workers.push(w);
+            }
+        });
+    }
+    ready() { return this._ready; }
+    // wtns: Uint8Array (written to a temporary file the workers read) or a path
+    async prove(wtns, opts) {
+        opts = opts || {};
+        await this._ready;
+        const zk = this.zk, cid = zk.curveId, id = this.nextId++;
+        let wtnsPath = wtns, tmp = null;
+        if (typeof wtns !== "string") { tmp = path.join(require("os").tmpdir(), `zkmi_${process.pid}_${id}.wtns`); fs.writeFileSync(tmp, wtns); wtnsPath = tmp; }
+        const witness = parseWtns(new Uint8Array(fs.readFileSync(wtnsPath)), zk);
+        const r = opts.r || randomFrMont(cid), s = opts.s || randomFrMont(cid);
+        try {
+            const res = await new Promise((resolve, reject) => {
+                let chains = 0, ws = 0;
+                const sums = new Array(this.world).fill(null);
+                const order = [];
+                this.waiters.set(id, (msg) => {
+                    if (msg.ev === "error") { reject(new Error(`shard worker ${msg.rank}: ${msg.message}`)); return; }
+                    order.push(msg.ev);
+                    if (msg.ev === "chain") chains++;
+                    if (msg.ev === "w") ws++;
+                    // every region complete and every witness-side half enqueued: the slices may be read
+                    if ((msg.ev === "chain" || msg.ev === "w") && chains === 3 && ws === this.world) for (const w of this.workers) w.send({ cmd: "slices", id });
+                    if (msg.ev === "sums") {
+                        sums[msg.rank] = msg.sums;
+                        if (sums.every((x) => x !== null)) this.workers[0].send({ cmd: "finish", id, sums, r: Buffer.from(r).toString("base64"), s: Buffer.from(s).toString("base64") });
+                    }
+                    if (msg.ev === "proof") resolve({ msg, order });
+                });
+                for (const w of this.workers) w.send({ cmd: "prove", id, wtnsPath });
+            });
+            const b = (x) => new Uint8Array(Buffer.from(x, "base64"));
+            const publicSignals = [];
+            for (let i = 1; i <= zk.nPublic; i++) publicSignals.push(fromLE(witness.subarray(i * zk.n8r, (i + 1) * zk.n8r)).toString());
+            return { proof: { pi_a: pointToObject(cid, 1, b(res.msg.pi_a)), pi_b: pointToObject(cid, 2, b(res.msg.pi_b)), pi_c: pointToObject(cid, 1, b(res.msg.pi_c)), protocol: "groth16", curve: zk.curveName },
+                     publicSignals, events: res.order };
+        } finally {
+            this.waiters.delete(id);
+            if (tmp) fs.unlinkSync(tmp);
+        }
+    }
+    async close() {
+        for (const w of this.workers) { try { w.send({ cmd: "exit" }); } catch (e) { /* already gone */ } }
+        await Promise.all(this.workers.map((w) => new Promise((res) => { if (w.exitCode !== null) res(); else w.on("exit", res); })));
+        for (let c = 0; c < 3; c++) this.addon.shmUnlink(`${this.shmPrefix}_c${c}`);
+        this.regions = [];
+    }
+}
+
+if (process.argv.includes("--zkmi-shard-worker")) workerMain().catch((e) => { try { process.send({ ev: "error", rank: -1, message: String(e && e.message || e) }); } catch (e2) { /* no channel */ } process.exit(1); });
+else module.exports = { ShardedProver, shardRange, chainOwner, pointToObject, randomFrMont };

@@ -105,7 +105,8 @@ typedef struct {
     napi_deferred deferred;
     napi_ref keep[8]; int n_keep;          /* arguments and result kept alive while the job runs */
     napi_ref result;                       /* value the promise resolves to (NULL: undefined) */
-    int kind;                              /* 0 msm, 1 ntt, 2 groth16Prove */
+    int kind;                              /* 0 msm, 1 ntt, 2 groth16Prove, 3 groth16Submit, 4 groth16Collect, 5 groth16Load */
+    int32_t slot;
     int32_t curve, group, logn, inverse;
     pages_t a, b;
     double n, sb, key;
@@ -119,7 +120,10 @@ static int job_run(job_t* j) {
     switch (j->kind) {
     case 0: return zkmi_msm(j->curve, j->group, as_zk(&j->a), as_zk(&j->b), (size_t)j->n, (size_t)j->sb, (uint64_t)j->key, j->o0);
     case 1: return zkmi_ntt(j->curve, as_zk(&j->a), (uint8_t* const*)j->b.ptr, j->b.len, j->b.n, (unsigned)j->logn, j->inverse, j->has_first ? j->first : NULL, j->has_inc ? j->inc : NULL);
-    default: return zkmi_groth16_prove(j->has_zk ? &j->zk : NULL, (uint64_t)j->key, j->a.ptr[0], j->a.len[0], j->first, j->inc, j->o0, j->o1, j->o2);
+    case 2: return zkmi_groth16_prove(j->has_zk ? &j->zk : NULL, (uint64_t)j->key, j->a.ptr[0], j->a.len[0], j->first, j->inc, j->o0, j->o1, j->o2);
+    case 3: return zkmi_groth16_submit((uint64_t)j->key, j->a.ptr[0], j->a.len[0], j->slot);
+    case 4: return zkmi_groth16_collect((uint64_t)j->key, j->slot, j->first, j->inc, j->o0, j->o1, j->o2);
+    default: return zkmi_groth16_load(&j->zk, (uint64_t)j->key);
     }
 }
 static void job_execute(napi_env env, void* data) {
@@ -214,7 +218,7 @@ static napi_value js_release_bases(napi_env env, napi_callback_info info) {
     ARGS(1);
     double key;
     if (get_f64(env, argv[0], &key)) BAD_ARG();
-    zkmi_release_bases((uint64_t)key);
+    (void)ZK_CALL(zkmi_release_bases((uint64_t)key));          /* under the lock: an asynchronous job may be running on a pool thread */
     return NULL;
 }
 /* ntt(curve, in, out, logN, inverse, first|null, inc|null): out is preallocated by the caller (same container type);
@@ -334,6 +338,32 @@ static int get_named_u32(napi_env env, napi_value obj, const char* name, uint32_
     napi_value v;
     return (napi_get_named_property(env, obj, name, &v) == napi_ok && napi_get_value_uint32(env, v, o) == napi_ok) ? 0 : -1;
 }
+/* {curve,nVars,nPublic,domainSize,coeffs,A,B1,B2,C,H,alpha1,beta1,beta2,delta1,delta2} -> zkmi_groth16_zkey (pointers into the typed arrays) */
+static int get_zkey_desc(napi_env env, napi_value obj, zkmi_groth16_zkey* zk) {
+    uint32_t c;
+    memset(zk, 0, sizeof *zk);
+    if (get_named_u32(env, obj, "curve", &c) || get_named_u32(env, obj, "nVars", &zk->n_vars) || get_named_u32(env, obj, "nPublic", &zk->n_public) ||
+        get_named_u32(env, obj, "domainSize", &zk->domain_size) || get_named_u8(env, obj, "coeffs", &zk->coeffs, &zk->coeffs_len) ||
+        get_named_u8(env, obj, "A", &zk->bases_a, &zk->bases_a_len) || get_named_u8(env, obj, "B1", &zk->bases_b1, &zk->bases_b1_len) ||
+        get_named_u8(env, obj, "B2", &zk->bases_b2, &zk->bases_b2_len) || get_named_u8(env, obj, "C", &zk->bases_c, &zk->bases_c_len) ||
+        get_named_u8(env, obj, "H", &zk->bases_h, &zk->bases_h_len)) return -1;
+    if (c != ZKMI_CURVE_BN128 && c != ZKMI_CURVE_BLS12381) return -1;
+    zk->curve = (int)c;
+    /* header points: 2*n8q (G1) / 4*n8q (G2) bytes each */
+    const size_t q = c == ZKMI_CURVE_BN128 ? 32 : 48;
+    size_t l1, l2, l3, l4, l5;
+    if (get_named_u8(env, obj, "alpha1", &zk->vk_alpha_1, &l1) || get_named_u8(env, obj, "beta1", &zk->vk_beta_1, &l2) || get_named_u8(env, obj, "beta2", &zk->vk_beta_2, &l3) ||
+        get_named_u8(env, obj, "delta1", &zk->vk_delta_1, &l4) || get_named_u8(env, obj, "delta2", &zk->vk_delta_2, &l5) || l1 < 2 * q || l2 < 2 * q || l3 < 4 * q || l4 < 2 * q || l5 < 4 * q) return -1;
+    return 0;
+}
+/* {pi_a, pi_b, pi_c} with fresh Uint8Arrays of 2 / 4 / 2 x n8q bytes */
+static napi_value new_proof_obj(napi_env env, int curve, uint8_t** pa, uint8_t** pb, uint8_t** pc) {
+    const size_t q = curve == ZKMI_CURVE_BN128 ? 32 : 48;
+    napi_value va = new_u8(env, 2 * q, pa), vb = new_u8(env, 4 * q, pb), vc = new_u8(env, 2 * q, pc), res;
+    if (!va || !vb || !vc || napi_create_object(env, &res) != napi_ok) return NULL;
+    if (napi_set_named_property(env, res, "pi_a", va) != napi_ok || napi_set_named_property(env, res, "pi_b", vb) != napi_ok || napi_set_named_property(env, res, "pi_c", vc) != napi_ok) return NULL;
+    return res;
+}
 static napi_value groth16_impl(napi_env env, napi_callback_info info, bool async) {
     ARGS(5);
     zkmi_groth16_zkey zk, *pzk = NULL;
@@ -344,17 +374,8 @@ static napi_value groth16_impl(napi_env env, napi_callback_info info, bool async
     const uint8_t *r, *s;
     int curve = 0;
     if (t == napi_object) {
-        uint32_t c;
-        memset(&zk, 0, sizeof zk);
-        if (get_named_u32(env, argv[0], "curve", &c) || get_named_u32(env, argv[0], "nVars", &zk.n_vars) || get_named_u32(env, argv[0], "nPublic", &zk.n_public) ||
-            get_named_u32(env, argv[0], "domainSize", &zk.domain_size) || get_named_u8(env, argv[0], "coeffs", &zk.coeffs, &zk.coeffs_len) ||
-            get_named_u8(env, argv[0], "A", &zk.bases_a, &zk.bases_a_len) || get_named_u8(env, argv[0], "B1", &zk.bases_b1, &zk.bases_b1_len) ||
-            get_named_u8(env, argv[0], "B2", &zk.bases_b2, &zk.bases_b2_len) || get_named_u8(env, argv[0], "C", &zk.bases_c, &zk.bases_c_len) ||
-            get_named_u8(env, argv[0], "H", &zk.bases_h, &zk.bases_h_len) ||
-            get_named_u8(env, argv[0], "alpha1", &zk.vk_alpha_1, NULL) || get_named_u8(env, argv[0], "beta1", &zk.vk_beta_1, NULL) ||
-            get_named_u8(env, argv[0], "beta2", &zk.vk_beta_2, NULL) || get_named_u8(env, argv[0], "delta1", &zk.vk_delta_1, NULL) ||
-            get_named_u8(env, argv[0], "delta2", &zk.vk_delta_2, NULL)) BAD_ARG();
-        zk.curve = (int)c; curve = zk.curve; pzk = &zk;
+        if (get_zkey_desc(env, argv[0], &zk)) BAD_ARG();
+        curve = zk.curve; pzk = &zk;
     }
     if (get_f64(env, argv[1], &key) || get_pages(env, argv[2], &w) || w.n != 1 || get_opt32(env, argv[3], &r) || get_opt32(env, argv[4], &s) || !r || !s) BAD_ARG();
     if (!pzk) {            /* key already resident: the caller passes the curve id in place of the zkey object */
@@ -362,19 +383,9 @@ static napi_value groth16_impl(napi_env env, napi_callback_info info, bool async
         if (get_i32(env, argv[0], &c)) BAD_ARG();
         curve = c;
     }
-    const size_t q = curve == ZKMI_CURVE_BN128 ? 32 : 48;
     uint8_t *pa, *pb, *pc;
-    napi_value va = new_u8(env, 2 * q, &pa), vb = new_u8(env, 4 * q, &pb), vc = new_u8(env, 2 * q, &pc), res;
-    if (!va || !vb || !vc) BAD_ARG();
-    if (pzk) {             /* header points: 2*n8q (G1) / 4*n8q (G2) bytes each */
-        size_t l1, l2, l3, l4, l5; const uint8_t* d;
-        if (get_named_u8(env, argv[0], "alpha1", &d, &l1) || get_named_u8(env, argv[0], "beta1", &d, &l2) || get_named_u8(env, argv[0], "beta2", &d, &l3) ||
-            get_named_u8(env, argv[0], "delta1", &d, &l4) || get_named_u8(env, argv[0], "delta2", &d, &l5) || l1 < 2 * q || l2 < 2 * q || l3 < 4 * q || l4 < 2 * q || l5 < 4 * q) BAD_ARG();
-    }
-    NAPI_OK(napi_create_object(env, &res));
-    NAPI_OK(napi_set_named_property(env, res, "pi_a", va));
-    NAPI_OK(napi_set_named_property(env, res, "pi_b", vb));
-    NAPI_OK(napi_set_named_property(env, res, "pi_c", vc));
+    napi_value res = new_proof_obj(env, curve, &pa, &pb, &pc);
+    if (!res) BAD_ARG();
     if (async) {           /* the zkey sections are referenced through argv[0] (the descriptor object holds the typed arrays) */
         job_t* j = (job_t*)calloc(1, sizeof *j);
         if (!j) BAD_ARG();
@@ -393,16 +404,215 @@ static napi_value js_groth16_release(napi_env env, napi_callback_info info) {
     ARGS(1);
     double key;
     if (get_f64(env, argv[0], &key)) BAD_ARG();
-    zkmi_groth16_release((uint64_t)key);
+    (void)ZK_CALL(zkmi_groth16_release((uint64_t)key));        /* waits for the lock: never frees a key under a running job */
     return NULL;
 }
 
-/* call(name, ...args) -> 0 — generic binding of any `int zkmi_*(...)` entry point of include/zkmi.h whose parameters are all
- * integers or pointers (every *_dev function is): numbers pass as 64-bit integers (device pointers fit a double's 53 bits),
- * typed arrays as their data pointer, null/undefined as NULL. Used by js/plonk_native.js, which drives the device-resident
- * PLONK prover from Node the way snarkjs_amd/plonk.py does from Python. Throws Error(zkmi_last_error()) on a non-zero return. */
+/* ---- resident keys, the two-slot pipeline and the multi-GPU shard API: one typed wrapper per C entry point --------------------------------
+ * groth16Load(desc, key) / groth16LoadAsync(desc, key) -> undefined | Promise; groth16LoadShard(desc, key, varLo, varHi, hLo, hHi) */
+static napi_value load_impl(napi_env env, napi_callback_info info, bool async) {
+    ARGS(2);
+    double key;
+    zkmi_groth16_zkey zk;
+    if (get_zkey_desc(env, argv[0], &zk) || get_f64(env, argv[1], &key) || key < 1) BAD_ARG();
+    if (async) {
+        job_t* j = (job_t*)calloc(1, sizeof *j);
+        if (!j) BAD_ARG();
+        j->kind = 5; j->key = key; j->zk = zk; j->has_zk = true;
+        return job_queue(env, j, "zkmi.groth16Load", argv, 2, NULL);
+    }
+    int rc = ZK_CALL(zkmi_groth16_load(&zk, (uint64_t)key));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_groth16_load(napi_env env, napi_callback_info info) { return load_impl(env, info, false); }
+static napi_value js_groth16_load_async(napi_env env, napi_callback_info info) { return load_impl(env, info, true); }
+static napi_value js_groth16_load_shard(napi_env env, napi_callback_info info) {
+    ARGS(6);
+    double key, a, b, c, d;
+    zkmi_groth16_zkey zk;
+    if (get_zkey_desc(env, argv[0], &zk) || get_f64(env, argv[1], &key) || key < 1 || get_f64(env, argv[2], &a) || get_f64(env, argv[3], &b) || get_f64(env, argv[4], &c) ||
+        get_f64(env, argv[5], &d) || a < 0 || b < a || c < 0 || d < c || b > 4294967295.0 || d > 4294967295.0) BAD_ARG();
+    int rc = ZK_CALL(zkmi_groth16_load_shard(&zk, (uint64_t)key, (uint32_t)a, (uint32_t)b, (uint32_t)c, (uint32_t)d));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+/* groth16Submit(key, witness, slot) / groth16SubmitAsync: the witness crosses PCIe on the slot's stream and the device part of the proof is
+ * enqueued (zkmi_groth16_submit); groth16Collect(curve, key, slot, r, s) / groth16CollectAsync -> {pi_a, pi_b, pi_c} waits for the slot. */
+static napi_value submit_impl(napi_env env, napi_callback_info info, bool async) {
+    ARGS(3);
+    double key; int32_t slot; pages_t w;
+    if (get_f64(env, argv[0], &key) || get_pages(env, argv[1], &w) || w.n != 1 || get_i32(env, argv[2], &slot) || (slot != 0 && slot != 1)) BAD_ARG();
+    if (async) {
+        job_t* j = (job_t*)calloc(1, sizeof *j);
+        if (!j) BAD_ARG();
+        j->kind = 3; j->key = key; j->a = w; j->slot = slot;
+        return job_queue(env, j, "zkmi.groth16Submit", argv, 3, NULL);
+    }
+    int rc = ZK_CALL(zkmi_groth16_submit((uint64_t)key, w.ptr[0], w.len[0], slot));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_groth16_submit(napi_env env, napi_callback_info info) { return submit_impl(env, info, false); }
+static napi_value js_groth16_submit_async(napi_env env, napi_callback_info info) { return submit_impl(env, info, true); }
+static napi_value collect_impl(napi_env env, napi_callback_info info, bool async) {
+    ARGS(5);
+    int32_t curve, slot; double key;
+    const uint8_t *r, *s;
+    if (get_i32(env, argv[0], &curve) || get_f64(env, argv[1], &key) || get_i32(env, argv[2], &slot) || (slot != 0 && slot != 1) || get_opt32(env, argv[3], &r) ||
+        get_opt32(env, argv[4], &s) || !r || !s || (curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381)) BAD_ARG();
+    uint8_t *pa, *pb, *pc;
+    napi_value res = new_proof_obj(env, curve, &pa, &pb, &pc);
+    if (!res) BAD_ARG();
+    if (async) {
+        job_t* j = (job_t*)calloc(1, sizeof *j);
+        if (!j) BAD_ARG();
+        j->kind = 4; j->key = key; j->slot = slot; j->o0 = pa; j->o1 = pb; j->o2 = pc;
+        memcpy(j->first, r, 32); memcpy(j->inc, s, 32);
+        return job_queue(env, j, "zkmi.groth16Collect", argv, 5, res);
+    }
+    int rc = ZK_CALL(zkmi_groth16_collect((uint64_t)key, slot, r, s, pa, pb, pc));
+    if (rc) return throw_zkmi(env, rc);
+    return res;
+}
+static napi_value js_groth16_collect(napi_env env, napi_callback_info info) { return collect_impl(env, info, false); }
+static napi_value js_groth16_collect_async(napi_env env, napi_callback_info info) { return collect_impl(env, info, true); }
+
+/* device memory for the shard driver: devAlloc(bytes) -> pointer (a Number: device addresses fit 53 bits), devFree(ptr),
+ * memcpyH2D(ptr, Uint8Array), memcpyD2H(Uint8Array, ptr) */
+static int get_dptr(napi_env env, napi_value v, void** o) {
+    double d;
+    if (napi_get_value_double(env, v, &d) != napi_ok || d < 0 || d > 9007199254740992.0) return -1;
+    *o = (void*)(uintptr_t)d;
+    return 0;
+}
+static napi_value js_dev_alloc(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    double bytes; void* p = NULL; napi_value v;
+    if (get_f64(env, argv[0], &bytes) || bytes < 0) BAD_ARG();
+    int rc = ZK_CALL(zkmi_dev_alloc((size_t)bytes, &p));
+    if (rc) return throw_zkmi(env, rc);
+    NAPI_OK(napi_create_double(env, (double)(uintptr_t)p, &v));
+    return v;
+}
+static napi_value js_dev_free(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    void* p;
+    if (get_dptr(env, argv[0], &p)) BAD_ARG();
+    int rc = ZK_CALL(zkmi_dev_free(p));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_memcpy_h2d(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    void* p; pages_t h;
+    if (get_dptr(env, argv[0], &p) || get_pages(env, argv[1], &h) || h.n != 1) BAD_ARG();
+    int rc = h.len[0] ? ZK_CALL(zkmi_memcpy_h2d(p, h.ptr[0], h.len[0])) : 0;
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_memcpy_d2h(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    void* p; pages_t h;
+    if (get_pages(env, argv[0], &h) || h.n != 1 || get_dptr(env, argv[1], &p)) BAD_ARG();
+    int rc = h.len[0] ? ZK_CALL(zkmi_memcpy_d2h((void*)h.ptr[0], p, h.len[0])) : 0;
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+/* groth16ChainsDev(key, dWitness, chainMask, dA|0, dB|0, dC|0); groth16SumsWDev(key, dWitness);
+ * groth16SumsHDev(curve, key, dWitness, dH) / groth16SumsDev(curve, key, dWitness) -> Uint8Array(7*3*n8q) partial sums;
+ * groth16Finish(curve, key, sums, r, s) -> {pi_a, pi_b, pi_c}; joinABCDev(curve, dA, dB, dC, dOut, n); pointAdd(curve, group, a, b) -> Uint8Array */
+static napi_value js_groth16_chains_dev(napi_env env, napi_callback_info info) {
+    ARGS(6);
+    double key; int32_t mask; void *w, *a, *b, *c;
+    if (get_f64(env, argv[0], &key) || get_dptr(env, argv[1], &w) || get_i32(env, argv[2], &mask) || mask < 0 || mask > 7 || get_dptr(env, argv[3], &a) || get_dptr(env, argv[4], &b) ||
+        get_dptr(env, argv[5], &c)) BAD_ARG();
+    int rc = ZK_CALL(zkmi_groth16_chains_dev((uint64_t)key, w, (unsigned)mask, a, b, c));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_groth16_sums_w_dev(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    double key; void* w;
+    if (get_f64(env, argv[0], &key) || get_dptr(env, argv[1], &w)) BAD_ARG();
+    int rc = ZK_CALL(zkmi_groth16_sums_w_dev((uint64_t)key, w));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value sums_impl(napi_env env, napi_callback_info info, bool with_h) {
+    size_t argc = 4; napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < (with_h ? 4u : 3u)) { napi_throw_type_error(env, NULL, "zkmi: too few arguments"); return NULL; }
+    int32_t curve; double key; void *w, *h = NULL;
+    if (get_i32(env, argv[0], &curve) || (curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381) || get_f64(env, argv[1], &key) || get_dptr(env, argv[2], &w) ||
+        (with_h && get_dptr(env, argv[3], &h))) BAD_ARG();
+    uint8_t* out;
+    napi_value res = new_u8(env, (size_t)21 * (curve == ZKMI_CURVE_BN128 ? 32 : 48), &out);
+    if (!res) BAD_ARG();
+    int rc = with_h ? ZK_CALL(zkmi_groth16_sums_h_dev((uint64_t)key, w, h, out)) : ZK_CALL(zkmi_groth16_sums_dev((uint64_t)key, w, out));
+    if (rc) return throw_zkmi(env, rc);
+    return res;
+}
+static napi_value js_groth16_sums_h_dev(napi_env env, napi_callback_info info) { return sums_impl(env, info, true); }
+static napi_value js_groth16_sums_dev(napi_env env, napi_callback_info info) { return sums_impl(env, info, false); }
+static napi_value js_groth16_finish(napi_env env, napi_callback_info info) {
+    ARGS(5);
+    int32_t curve; double key; pages_t sm; const uint8_t *r, *s;
+    if (get_i32(env, argv[0], &curve) || (curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381) || get_f64(env, argv[1], &key) || get_pages(env, argv[2], &sm) || sm.n != 1 ||
+        sm.len[0] != (size_t)21 * (curve == ZKMI_CURVE_BN128 ? 32 : 48) || get_opt32(env, argv[3], &r) || get_opt32(env, argv[4], &s) || !r || !s) BAD_ARG();
+    uint8_t *pa, *pb, *pc;
+    napi_value res = new_proof_obj(env, curve, &pa, &pb, &pc);
+    if (!res) BAD_ARG();
+    int rc = ZK_CALL(zkmi_groth16_finish((uint64_t)key, sm.ptr[0], r, s, pa, pb, pc));
+    if (rc) return throw_zkmi(env, rc);
+    return res;
+}
+static napi_value js_join_abc_dev(napi_env env, napi_callback_info info) {
+    ARGS(6);
+    int32_t curve; double n; void *a, *b, *c, *o;
+    if (get_i32(env, argv[0], &curve) || get_dptr(env, argv[1], &a) || get_dptr(env, argv[2], &b) || get_dptr(env, argv[3], &c) || get_dptr(env, argv[4], &o) || get_f64(env, argv[5], &n) || n < 0) BAD_ARG();
+    int rc = ZK_CALL(zkmi_groth16_join_abc_dev(curve, a, b, c, o, (size_t)n));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_point_add(napi_env env, napi_callback_info info) {
+    ARGS(4);
+    int32_t curve, group; pages_t a, b;
+    if (get_i32(env, argv[0], &curve) || (curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381) || get_i32(env, argv[1], &group) || (group != 1 && group != 2) ||
+        get_pages(env, argv[2], &a) || get_pages(env, argv[3], &b) || a.n != 1 || b.n != 1) BAD_ARG();
+    const size_t len = (size_t)3 * group * (curve == ZKMI_CURVE_BN128 ? 32 : 48);
+    if (a.len[0] != len || b.len[0] != len) BAD_ARG();
+    uint8_t* out;
+    napi_value res = new_u8(env, len, &out);
+    if (!res) BAD_ARG();
+    int rc = zkmi_point_add(curve, group, a.ptr[0], b.ptr[0], out);        /* host only, no library state */
+    if (rc) return throw_zkmi(env, rc);
+    return res;
+}
+
+/* call(name, ...args) -> 0 — table-driven binding of the device-resident PLONK / FFLONK entry points of include/zkmi.h (every parameter an
+ * integer, a device pointer or a host buffer). Only the entry points listed below can be reached, and every argument is checked against the
+ * kind the C prototype expects before the call is made:
+ *   i  integer (a JS number)                       d  device pointer (a JS number; null / 0 where the prototype allows NULL)
+ *   bN host buffer (typed array) of at least N bytes; b@K: at least as many bytes as the integer argument K; BN / B@K: the same, or null
+ * Used by js/plonk_native.js and js/fflonk_native.js, which drive the device-resident provers from Node the way snarkjs_amd/plonk.py does
+ * from Python. Throws Error(zkmi_last_error()) on a non-zero return. */
 typedef int (*zk_fn16)(uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t,
                        uintptr_t, uintptr_t, uintptr_t, uintptr_t);
+static const struct { const char* name; const char* sig; } g_call_table[] = {
+    {"zkmi_fr_root", "i i b32"},
+    {"zkmi_dev_alloc", "i b8"}, {"zkmi_dev_free", "d"}, {"zkmi_memcpy_h2d", "d b@2 i"}, {"zkmi_memcpy_d2h", "b@2 d i"}, {"zkmi_memcpy_d2d", "d d i"}, {"zkmi_memset_dev", "d i i"},
+    {"zkmi_fr_batch_dev", "i i d d i"}, {"zkmi_ntt_dev", "i d d i i B32 B32"},
+    {"zkmi_msm_table_build", "i i d i b8"}, {"zkmi_msm_table_dev", "i d i i b96"}, {"zkmi_msm_table_multi_dev", "i b8 b8 i i b96"}, {"zkmi_msm_table_release", "i"},
+    {"zkmi_plonk_gather_wires_dev", "i d i d i d d d i i d d d"},
+    {"zkmi_plonk_compute_z_dev", "i d d d d d d i b32 b32 b32 b32 b32 d"},
+    {"zkmi_plonk_compute_t_dev", "i b112 i i b352 b32 b32 b32 b32 b32 b32 b32 b32 d d"},
+    {"zkmi_fflonk_t0_dev", "i b112 i i d"}, {"zkmi_fflonk_t1_dev", "i d d i b96 b32 d d"}, {"zkmi_fflonk_t2_dev", "i b112 i b96 b32 b32 b32 b32 b32 b32 d d"},
+    {"zkmi_poly_degree_dev", "i d i b8"}, {"zkmi_keccak256", "B@1 i b32"},
+    {"zkmi_poly_axpy_dev", "i d d i B32 i"}, {"zkmi_poly_scale_dev", "i d i b32"}, {"zkmi_poly_blind_dev", "i d i b32 i"}, {"zkmi_poly_add_scalar_dev", "i d b32"},
+    {"zkmi_poly_evaluate_dev", "i d i b32 b32"}, {"zkmi_poly_is_zero_dev", "i d i b4"}, {"zkmi_poly_div_zh_dev", "i d i i i"}, {"zkmi_poly_div_by_zerofier_dev", "i d i i b32"},
+    {"zkmi_cpoly_interleave_dev", "i b8 b8 i d i"}, {"zkmi_to_affine", "i i b96 b64"},
+};
 static void* zk_lib_handle(void) {
     static void* h = NULL;
     if (!h) {
@@ -416,24 +626,49 @@ static napi_value js_call(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     if (argc < 1) { napi_throw_type_error(env, NULL, "zkmi.call: function name expected"); return NULL; }
     char name[96]; size_t nl = 0;
-    if (napi_get_value_string_utf8(env, argv[0], name, sizeof name, &nl) != napi_ok || strncmp(name, "zkmi_", 5)) BAD_ARG();
+    if (napi_get_value_string_utf8(env, argv[0], name, sizeof name, &nl) != napi_ok) BAD_ARG();
+    const char* sig = NULL;
+    for (size_t i = 0; i < sizeof g_call_table / sizeof g_call_table[0]; i++) if (!strcmp(name, g_call_table[i].name)) sig = g_call_table[i].sig;
+    if (!sig) { napi_throw_error(env, NULL, "zkmi.call: not an entry point of the checked binding table"); return NULL; }
     void* h = zk_lib_handle();
     zk_fn16 fn = h ? (zk_fn16)dlsym(h, name) : NULL;
     if (!fn) { napi_throw_error(env, NULL, "zkmi.call: no such entry point"); return NULL; }
     uintptr_t a[16] = {0};
-    for (size_t i = 1; i < argc && i <= 16; i++) {
+    size_t blen[16] = {0};
+    struct { int arg; int ref; } at_checks[16];
+    int n_at = 0;
+    size_t k = 0;
+    for (const char* c = sig; *c; k++) {
+        const char kind = *c++;
+        size_t min_len = 0; int ref = -1;
+        if (*c == '@') { c++; ref = (int)strtol(c, (char**)&c, 10); } else if (*c >= '0' && *c <= '9') min_len = (size_t)strtol(c, (char**)&c, 10);
+        while (*c == ' ') c++;
+        if (k + 1 >= argc || k >= 16) { napi_throw_type_error(env, NULL, "zkmi.call: too few arguments for this entry point"); return NULL; }
         napi_valuetype t;
-        NAPI_OK(napi_typeof(env, argv[i], &t));
-        if (t == napi_number) { double d; NAPI_OK(napi_get_value_double(env, argv[i], &d)); a[i - 1] = (uintptr_t)(int64_t)d; }
-        else if (t == napi_null || t == napi_undefined) a[i - 1] = 0;
-        else {
+        NAPI_OK(napi_typeof(env, argv[k + 1], &t));
+        const bool is_null = t == napi_null || t == napi_undefined;
+        if (kind == 'i' || kind == 'd') {
+            if (is_null && kind == 'd') { a[k] = 0; continue; }
+            double d;
+            if (t != napi_number || napi_get_value_double(env, argv[k + 1], &d) != napi_ok || (kind == 'd' && (d < 0 || d > 9007199254740992.0))) BAD_ARG();
+            a[k] = (uintptr_t)(int64_t)d;
+        } else {                                            /* b / B */
+            if (is_null) { if (kind != 'B') BAD_ARG(); a[k] = 0; blen[k] = 0; if (ref >= 0) { at_checks[n_at].arg = (int)k; at_checks[n_at++].ref = ref; } continue; }
             bool is_ta = false;
-            if (napi_is_typedarray(env, argv[i], &is_ta) != napi_ok || !is_ta) BAD_ARG();
+            if (napi_is_typedarray(env, argv[k + 1], &is_ta) != napi_ok || !is_ta) BAD_ARG();
             napi_typedarray_type tt; size_t len; void* data; napi_value ab; size_t off;
-            NAPI_OK(napi_get_typedarray_info(env, argv[i], &tt, &len, &data, &ab, &off));
-            a[i - 1] = (uintptr_t)data;
+            NAPI_OK(napi_get_typedarray_info(env, argv[k + 1], &tt, &len, &data, &ab, &off));
+            const size_t esz = (tt == napi_uint8_array || tt == napi_int8_array || tt == napi_uint8_clamped_array) ? 1 : (tt == napi_uint16_array || tt == napi_int16_array) ? 2 :
+                               (tt == napi_uint32_array || tt == napi_int32_array || tt == napi_float32_array) ? 4 : 8;
+            blen[k] = len * esz;
+            if (blen[k] < min_len) { napi_throw_type_error(env, NULL, "zkmi.call: a host buffer is shorter than the entry point requires"); return NULL; }
+            if (ref >= 0) { at_checks[n_at].arg = (int)k; at_checks[n_at++].ref = ref; }
+            a[k] = (uintptr_t)data;
         }
     }
+    if (k + 1 != argc) { napi_throw_type_error(env, NULL, "zkmi.call: too many arguments for this entry point"); return NULL; }
+    for (int i = 0; i < n_at; i++)
+        if ((uint64_t)blen[at_checks[i].arg] < (uint64_t)a[at_checks[i].ref]) { napi_throw_type_error(env, NULL, "zkmi.call: a host buffer is shorter than its length argument"); return NULL; }
     int rc = ZK_CALL(fn(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]));
     if (rc) return throw_zkmi(env, rc);
     napi_value z;
@@ -441,11 +676,63 @@ static napi_value js_call(napi_env env, napi_callback_info info) {
     return z;
 }
 
+/* ---- shared host memory between the processes of a multi-GPU proof (js/groth16_shards.js): shmMap(name, bytes, create) -> Uint8Array over
+ * a POSIX shared-memory object (the chain outputs travel owner GPU -> shared pages -> the other GPUs; north star: host side stays Node.js);
+ * shmUnlink(name). The mapping is page-locked for the device (zkmi_host_register) when a device is bound; it lives until the array is
+ * collected. */
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+typedef struct { void* p; size_t len; int registered; } shm_t;
+static void shm_finalize(napi_env env, void* data, void* hint) {
+    (void)env; (void)data;
+    shm_t* m = (shm_t*)hint;
+    if (m->registered) (void)ZK_CALL(zkmi_host_unregister(m->p));
+    munmap(m->p, m->len);
+    free(m);
+}
+static napi_value js_shm_map(napi_env env, napi_callback_info info) {
+    ARGS(3);
+    char name[128]; size_t nl = 0; double bytes; bool create = false;
+    if (napi_get_value_string_utf8(env, argv[0], name, sizeof name, &nl) != napi_ok || name[0] != '/' || get_f64(env, argv[1], &bytes) || bytes < 1 ||
+        napi_get_value_bool(env, argv[2], &create) != napi_ok) BAD_ARG();
+    int fd = shm_open(name, create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) { napi_throw_error(env, NULL, "zkmi.shmMap: shm_open failed"); return NULL; }
+    if (create && ftruncate(fd, (off_t)bytes) != 0) { close(fd); napi_throw_error(env, NULL, "zkmi.shmMap: ftruncate failed"); return NULL; }
+    void* p = mmap(NULL, (size_t)bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { napi_throw_error(env, NULL, "zkmi.shmMap: mmap failed"); return NULL; }
+    shm_t* m = (shm_t*)calloc(1, sizeof *m);
+    if (!m) { munmap(p, (size_t)bytes); BAD_ARG(); }
+    m->p = p; m->len = (size_t)bytes;
+    m->registered = ZK_CALL(zkmi_host_register(p, (size_t)bytes)) == 0;      /* without a device the pages simply stay pageable */
+    napi_value ab, ta;
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, shm_finalize, m, &ab) != napi_ok || napi_create_typedarray(env, napi_uint8_array, (size_t)bytes, ab, 0, &ta) != napi_ok) {
+        shm_finalize(env, p, m);
+        napi_throw_error(env, NULL, "zkmi.shmMap: cannot wrap the mapping");
+        return NULL;
+    }
+    return ta;
+}
+static napi_value js_shm_unlink(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    char name[128]; size_t nl = 0;
+    if (napi_get_value_string_utf8(env, argv[0], name, sizeof name, &nl) != napi_ok || name[0] != '/') BAD_ARG();
+    shm_unlink(name);
+    return NULL;
+}
+
 static napi_value module_init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"init", js_init}, {"deviceCount", js_device_count}, {"version", js_version}, {"msm", js_msm}, {"releaseBases", js_release_bases},
         {"ntt", js_ntt}, {"frBatch", js_fr_batch}, {"applyKey", js_apply_key}, {"joinABC", js_join_abc}, {"toAffine", js_to_affine}, {"groupFft", js_group_fft}, {"groupApplyKey", js_group_apply_key}, {"groupConvert", js_group_convert},
         {"groth16Prove", js_groth16_prove}, {"groth16ProveAsync", js_groth16_prove_async}, {"msmAsync", js_msm_async}, {"nttAsync", js_ntt_async}, {"groth16Release", js_groth16_release}, {"call", js_call},
+        {"groth16Load", js_groth16_load}, {"groth16LoadAsync", js_groth16_load_async}, {"groth16LoadShard", js_groth16_load_shard}, {"groth16Submit", js_groth16_submit},
+        {"groth16SubmitAsync", js_groth16_submit_async}, {"groth16Collect", js_groth16_collect}, {"groth16CollectAsync", js_groth16_collect_async},
+        {"devAlloc", js_dev_alloc}, {"devFree", js_dev_free}, {"memcpyH2D", js_memcpy_h2d}, {"memcpyD2H", js_memcpy_d2h},
+        {"groth16ChainsDev", js_groth16_chains_dev}, {"groth16SumsWDev", js_groth16_sums_w_dev}, {"groth16SumsHDev", js_groth16_sums_h_dev}, {"groth16SumsDev", js_groth16_sums_dev},
+        {"groth16Finish", js_groth16_finish}, {"joinABCDev", js_join_abc_dev}, {"pointAdd", js_point_add}, {"shmMap", js_shm_map}, {"shmUnlink", js_shm_unlink},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

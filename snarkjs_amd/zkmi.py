@@ -24,8 +24,8 @@ SYMBOLS = [
     "zkmi_ntt", "zkmi_ntt_dev",
     "zkmi_fr_batch_apply_key", "zkmi_fr_batch_apply_key_dev", "zkmi_fr_batch", "zkmi_fr_batch_dev",
     "zkmi_groth16_join_abc", "zkmi_groth16_join_abc_dev",
-    "zkmi_base_cache_stats", "zkmi_gen_bases_from_scalars_dev", "zkmi_group_fft", "zkmi_group_fft_dev", "zkmi_group_batch_apply_key", "zkmi_group_batch_apply_key_dev", "zkmi_group_convert", "zkmi_group_convert_dev", "zkmi_calibrate_box", "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_submit_dev", "zkmi_groth16_collect", "zkmi_groth16_release", "zkmi_groth16_load_shard", "zkmi_groth16_sums_dev", "zkmi_groth16_chains_dev", "zkmi_groth16_sums_h_dev", "zkmi_groth16_finish", "zkmi_groth16_stage_ms",
-    "zkmi_gen_geometric_bases_dev", "zkmi_to_affine", "zkmi_point_add", "zkmi_fr_root",
+    "zkmi_base_cache_stats", "zkmi_gen_bases_from_scalars_dev", "zkmi_group_fft", "zkmi_group_fft_dev", "zkmi_group_batch_apply_key", "zkmi_group_batch_apply_key_dev", "zkmi_group_convert", "zkmi_group_convert_dev", "zkmi_calibrate_box", "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_submit_dev", "zkmi_groth16_submit", "zkmi_groth16_sums_w_dev", "zkmi_groth16_collect", "zkmi_groth16_release", "zkmi_groth16_load_shard", "zkmi_groth16_sums_dev", "zkmi_groth16_chains_dev", "zkmi_groth16_sums_h_dev", "zkmi_groth16_finish", "zkmi_groth16_stage_ms",
+    "zkmi_gen_geometric_bases_dev", "zkmi_host_register", "zkmi_host_unregister", "zkmi_to_affine", "zkmi_point_add", "zkmi_fr_root",
     "zkmi_plonk_gather_wires_dev", "zkmi_plonk_compute_z_dev", "zkmi_plonk_compute_t_dev", "zkmi_fflonk_t0_dev", "zkmi_fflonk_t1_dev",
     "zkmi_fflonk_t2_dev", "zkmi_poly_degree_dev", "zkmi_keccak256", "zkmi_poly_blind_dev", "zkmi_poly_add_scalar_dev", "zkmi_poly_axpy_dev", "zkmi_poly_scale_dev",
     "zkmi_poly_evaluate_dev", "zkmi_poly_is_zero_dev", "zkmi_poly_div_zh_dev", "zkmi_cpoly_interleave_dev", "zkmi_poly_div_by_zerofier_dev", "zkmi_last_kernel_ms",
@@ -140,6 +140,8 @@ def lib():
     L.zkmi_groth16_prove_dev.argtypes = [C.c_uint64, vp, u8p, u8p, u8p, u8p, u8p]
     L.zkmi_groth16_release.argtypes = [C.c_uint64]
     L.zkmi_groth16_submit_dev.argtypes = [C.c_uint64, vp, C.c_int]
+    L.zkmi_groth16_submit.argtypes = [C.c_uint64, u8p, sz, C.c_int]
+    L.zkmi_groth16_sums_w_dev.argtypes = [C.c_uint64, vp]
     L.zkmi_groth16_collect.argtypes = [C.c_uint64, C.c_int, u8p, u8p, u8p, u8p, u8p]
     L.zkmi_groth16_load_shard.argtypes = [C.POINTER(Groth16Zkey), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.zkmi_groth16_sums_dev.argtypes = [C.c_uint64, vp, u8p]

@@ -1,0 +1,54 @@
+// tests/js/native_gpu.js — snarkjs_amd/js/groth16_native.js (makeProver: prove, throughput mode) and snarkjs_amd/js/groth16_shards.js (one
+// proof over several worker processes) with the REAL addon on a GPU. The reference bundle cannot travel to the GPU box, so `snarkjs` is a
+// stub that provides exactly what makeProver takes from it (curves.getCurveFromName -> {name, Fr.random, G1/G2.toObject}); the blinding draws
+// are the recorded ones of the reference's seeded proof, and sha256(JSON.stringify(proof)) must equal the reference's (tests/golden).
+"use strict";
+const fs = require("fs"), path = require("path"), crypto = require("crypto");
+const { makeProver } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "groth16_native.js"));
+const { ShardedProver, pointToObject } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "groth16_shards.js"));
+const sha = (b) => crypto.createHash("sha256").update(b).digest("hex");
+const GOLD = path.join(__dirname, "..", "golden");
+let fails = 0;
+const check = (name, ok) => { if (!ok) { fails++; console.log("FAIL", name); } else console.log("ok  ", name); };
+const hexb = (s) => new Uint8Array(Buffer.from(s, "hex"));
+
+function stubSnarkjs(cid, name, draws) {
+    const curve = { name, Fr: { random: () => draws.shift() }, G1: { toObject: (b) => pointToObject(cid, 1, b) }, G2: { toObject: (b) => pointToObject(cid, 2, b) } };
+    return { curves: { getCurveFromName: async () => curve } };
+}
+
+(async () => {
+    for (const [tag, cid, name] of [["groth16_bn128_n1024", 0, "bn128"], ["groth16_bls12381_n1024", 1, "bls12381"]]) {
+        const g = JSON.parse(fs.readFileSync(path.join(GOLD, tag + ".json")));
+        const zkey = new Uint8Array(fs.readFileSync(path.join(GOLD, tag + ".zkey"))), wtns = new Uint8Array(fs.readFileSync(path.join(GOLD, tag + ".wtns")));
+        const draws = [];
+        const seed = (k) => { for (let i = 0; i < k; i++) draws.push(hexb(g.r_mont), hexb(g.s_mont)); };
+        const prover = makeProver(stubSnarkjs(cid, name, draws));
+        seed(1);
+        const res = await prover.prove(zkey, wtns);
+        check(`${name}: makeProver.prove (real addon) == reference proof`, sha(JSON.stringify(res.proof)) === g.proof_sha256 && JSON.stringify(res.publicSignals) === JSON.stringify(g.publicSignals));
+        seed(2);
+        const both = await Promise.all([prover.prove(zkey, wtns), prover.prove(zkey, wtns)]);
+        check(`${name}: two overlapping proofs`, both.every((x) => sha(JSON.stringify(x.proof)) === g.proof_sha256));
+        seed(7);
+        const many = await prover.proveMany(zkey, [wtns, wtns, wtns, wtns, wtns, wtns, wtns]);
+        check(`${name}: proveMany, two proofs in flight, seven proofs`, many.length === 7 && many.every((x) => sha(JSON.stringify(x.proof)) === g.proof_sha256));
+        let threw = false;
+        try { await prover.proveMany(zkey, [wtns, zkey]); } catch (e) { threw = /Invalid File format/.test(e.message); }
+        seed(1);
+        const after = await prover.proveMany(zkey, [wtns]);
+        check(`${name}: an error inside proveMany leaves no proof in flight`, threw && sha(JSON.stringify(after[0].proof)) === g.proof_sha256);
+        await prover.release();
+        // the same proof from key shards held by separate worker processes (all on device 0 here: the protocol, not the scaling)
+        for (const world of [2, 3]) {
+            const sp = new ShardedProver({ world, zkeyPath: path.join(GOLD, tag + ".zkey"), devices: new Array(world).fill(0) });
+            await sp.ready();
+            const r1 = await sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) });
+            const r2 = await sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) });
+            check(`${name}: ${world} shard processes == reference proof (twice)`, sha(JSON.stringify(r1.proof)) === g.proof_sha256 && sha(JSON.stringify(r2.proof)) === g.proof_sha256);
+            await sp.close();
+        }
+    }
+    console.log(fails ? `${fails} FAILED` : "ALL OK");
+    process.exit(fails ? 1 : 0);
+})().catch((e) => { console.log("ERROR", e); process.exit(2); });

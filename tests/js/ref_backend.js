@@ -1,0 +1,133 @@
+// tests/js/ref_backend.js — a stand-in for the N-API addon whose Groth16 entry points are computed by the REFERENCE's own curve object
+// (oracle/ref_shim.js evaluates /root/reference/build/snarkjs.min.js: build container only). Test infrastructure for the CPU checks of
+// snarkjs_amd/js/groth16_native.js (makeProver) and snarkjs_amd/js/groth16_shards.js (the multi-process shard driver): what those tests cover
+// is the JavaScript around the addon — parsing, key life cycle, the two-slot pipeline order, the shard protocol, ownership and slicing — with
+// real arithmetic behind it, so that a finished proof can be compared with the reference's own. Every function may return a promise (the
+// drivers await every addon call; the real addon returns plain values).
+//   shared-memory mapping and the host-only point addition are the REAL addon's (they need no device).
+"use strict";
+const path = require("path");
+process.env.SINGLE = "1";
+const snarkjs = require(path.join(__dirname, "..", "..", "oracle", "ref_shim.js"));
+const real = require(path.join(__dirname, "..", "..", "snarkjs_amd", "napi", "zkmi_napi.node"));
+
+const calls = [];                                           // every entry-point name in call order (tests read this)
+let curveP = null;
+const getCurve = (cid) => (curveP = curveP || snarkjs.curves.getCurveFromName(cid === 0 ? "bn128" : "bls12381"));
+const mem = new Map();
+let nextPtr = 4096;
+const keys = new Map();
+const slots = {};
+let failNextLoad = false;
+
+function loadKey(desc, key, vLo, vHi, hLo, hHi) {
+    if (failNextLoad) { failNextLoad = false; throw new Error("zkmi error 2: injected load failure"); }
+    keys.set(key, { desc, vLo, vHi, hLo, hHi });
+}
+async function buildABC(curve, K, w) {                       // src/groth16_prove.js:147-187 with the reference's own field operations
+    const Fr = curve.Fr, n = K.desc.domainSize, d = K.desc.coeffs;
+    const dv = new DataView(d.buffer, d.byteOffset, d.byteLength), nCoef = dv.getUint32(0, true);
+    const A = new Uint8Array(n * 32), B = new Uint8Array(n * 32), C = new Uint8Array(n * 32);
+    for (let i = 0; i < nCoef; i++) {
+        const o = 4 + i * 44, mtx = dv.getUint32(o, true), c = dv.getUint32(o + 4, true), s = dv.getUint32(o + 8, true);
+        const t = mtx === 0 ? A : B;
+        t.set(Fr.add(t.subarray(c * 32, c * 32 + 32), Fr.mul(d.subarray(o + 12, o + 44), w.subarray(s * 32, s * 32 + 32))), c * 32);
+    }
+    for (let c = 0; c < n; c++) C.set(Fr.mul(A.subarray(c * 32, c * 32 + 32), B.subarray(c * 32, c * 32 + 32)), c * 32);
+    return [A, B, C];
+}
+async function chain(curve, x, n) {                          // :64-76: ifft -> coset scale -> fft
+    const Fr = curve.Fr, power = Math.log2(n), inc = power == Fr.s ? Fr.shift : Fr.w[power + 1];
+    return Fr.fft(await Fr.batchApplyKey(await Fr.ifft(x), Fr.e(1), inc));
+}
+async function msm(curve, group, bases, pb, scalars, lo, hi, baseLo) {
+    const G = group === 1 ? curve.G1 : curve.G2, n8q = curve.F1.n8;
+    if (hi <= lo) return new Uint8Array(3 * group * n8q);
+    const r = await G.multiExpAffine(bases.slice((lo - baseLo) * pb, (hi - baseLo) * pb), scalars.slice(lo * 32, hi * 32));
+    return r === G.zero || G.isZero(r) ? new Uint8Array(3 * group * n8q) : new Uint8Array(r);
+}
+async function sumsW(K, w) {
+    const curve = await getCurve(K.desc.curve), q = curve.F1.n8, m = K.desc.nVars, first = K.desc.nPublic + 1;
+    const cLo = Math.max(K.vLo, first), cHi = Math.max(K.vHi, first);
+    return { jA: await msm(curve, 1, K.desc.A, 2 * q, w, K.vLo, K.vHi, 0), jB1: await msm(curve, 1, K.desc.B1, 2 * q, w, K.vLo, K.vHi, 0),
+             jB2: await msm(curve, 2, K.desc.B2, 4 * q, w, K.vLo, K.vHi, 0), jC: await msm(curve, 1, K.desc.C, 2 * q, w, cLo, cHi, first) };
+}
+async function sumsH(K, hSlice) {                             // hSlice: this shard's H scalars, (hHi - hLo) x 32 bytes
+    const curve = await getCurve(K.desc.curve), q = curve.F1.n8, cnt = K.hHi - K.hLo;
+    if (!cnt) return new Uint8Array(3 * q);
+    const G = curve.G1, r = await G.multiExpAffine(K.desc.H.slice(K.hLo * 2 * q, K.hHi * 2 * q), hSlice.slice(0, cnt * 32));
+    return G.isZero(r) ? new Uint8Array(3 * q) : new Uint8Array(r);
+}
+function pack(q, W, jH) { const o = new Uint8Array(21 * q); o.set(W.jA, 0); o.set(W.jB1, 3 * q); o.set(W.jB2, 6 * q); o.set(W.jC, 12 * q); o.set(jH, 15 * q); return o; }
+async function joinABC(curve, a, b, c, cnt) {
+    const Fr = curve.Fr, t = new Uint8Array(cnt * 32);
+    for (let i = 0; i < cnt; i++) t.set(Fr.sub(Fr.mul(a.subarray(i * 32, i * 32 + 32), b.subarray(i * 32, i * 32 + 32)), c.subarray(i * 32, i * 32 + 32)), i * 32);
+    return Fr.batchFromMontgomery(t);
+}
+async function finish(K, sums, r, s) {                        // :103-132
+    const curve = await getCurve(K.desc.curve), q = curve.F1.n8, G1 = curve.G1, G2 = curve.G2, Fr = curve.Fr, d = K.desc;
+    const j = (a, b) => sums.slice(a * q, b * q);
+    const pt1 = (x) => (x.every((v) => v === 0) ? G1.zero : x), pt2 = (x) => (x.every((v) => v === 0) ? G2.zero : x);
+    let pa = G1.add(G1.add(pt1(j(0, 3)), d.alpha1.slice()), G1.timesFr(d.delta1.slice(), r));
+    let pb = G2.add(G2.add(pt2(j(6, 12)), d.beta2.slice()), G2.timesFr(d.delta2.slice(), s));
+    let pb1 = G1.add(G1.add(pt1(j(3, 6)), d.beta1.slice()), G1.timesFr(d.delta1.slice(), s));
+    let pc = G1.add(pt1(j(12, 15)), pt1(j(15, 18)));
+    pc = G1.add(pc, G1.timesFr(pa, s));
+    pc = G1.add(pc, G1.timesFr(pb1, r));
+    pc = G1.add(pc, G1.timesFr(d.delta1.slice(), Fr.neg(Fr.mul(r, s))));
+    return { pi_a: new Uint8Array(G1.toAffine(pa)), pi_b: new Uint8Array(G2.toAffine(pb)), pi_c: new Uint8Array(G1.toAffine(pc)) };
+}
+async function proveFull(K, witness, r, s) {
+    const curve = await getCurve(K.desc.curve), n = K.desc.domainSize;
+    const [A, B, C] = await buildABC(curve, K, witness);
+    const h = await joinABC(curve, await chain(curve, A, n), await chain(curve, B, n), await chain(curve, C, n), n);
+    return finish(K, pack(curve.F1.n8, await sumsW(K, witness), await sumsH(K, h.slice(K.hLo * 32, K.hHi * 32))), r, s);
+}
+const note = (name) => calls.push(name);
+
+const backend = {
+    calls, snarkjs,
+    failNextLoad() { failNextLoad = true; },
+    init() { note("init"); },
+    groth16Load(desc, key) { note("groth16Load"); loadKey(desc, key, 0, desc.nVars, 0, desc.domainSize); },
+    async groth16LoadAsync(desc, key) { note("groth16LoadAsync"); await new Promise((r) => setTimeout(r, 20)); loadKey(desc, key, 0, desc.nVars, 0, desc.domainSize); },
+    groth16LoadShard(desc, key, a, b, c, d) { note("groth16LoadShard"); loadKey(desc, key, a, b, c, d); },
+    groth16Release(key) { note("groth16Release"); keys.delete(key); },
+    async groth16Prove(cid, key, witness, r, s) { note("groth16Prove"); return proveFull(keys.get(key), witness, r, s); },
+    async groth16ProveAsync(cid, key, witness, r, s) { note("groth16ProveAsync"); return proveFull(keys.get(key), witness, r, s); },
+    async groth16SubmitAsync(key, witness, slot) {
+        note("submit" + slot);
+        if (slots[slot]) throw new Error("zkmi error 2: groth16: this pipeline slot already holds a proof in flight (collect it first)");
+        slots[slot] = { key, witness: witness.slice() };
+    },
+    async groth16CollectAsync(cid, key, slot, r, s) {
+        note("collect" + slot);
+        const j = slots[slot];
+        if (!j) throw new Error("zkmi error 2: groth16: no proof in flight in this pipeline slot");
+        delete slots[slot];
+        return proveFull(keys.get(key), j.witness, r, s);
+    },
+    devAlloc(bytes) { const p = nextPtr; nextPtr += Math.max(bytes, 1) + 4096; mem.set(p, new Uint8Array(Math.max(bytes, 1))); return p; },
+    devFree(p) { mem.delete(p); },
+    memcpyH2D(p, h) { mem.get(p).set(h); },
+    memcpyD2H(h, p) { h.set(mem.get(p).subarray(0, h.length)); },
+    async groth16ChainsDev(key, dW, mask, pa, pb, pc) {
+        note("chains" + mask);
+        const K = keys.get(key), curve = await getCurve(K.desc.curve), n = K.desc.domainSize;
+        const abc = await buildABC(curve, K, mem.get(dW));
+        const out = [pa, pb, pc];
+        for (let c = 0; c < 3; c++) if ((mask >> c) & 1) mem.get(out[c]).set(await chain(curve, abc[c], n));
+    },
+    async groth16SumsWDev(key, dW) { note("sumsW"); const K = keys.get(key); K.W = await sumsW(K, mem.get(dW)); },
+    async groth16SumsHDev(cid, key, dW, dH) {
+        note("sumsH");
+        const K = keys.get(key), curve = await getCurve(K.desc.curve);
+        const W = K.W || await sumsW(K, mem.get(dW));
+        K.W = null;
+        return pack(curve.F1.n8, W, await sumsH(K, mem.get(dH)));
+    },
+    async joinABCDev(cid, dA, dB, dC, dOut, cnt) { note("join"); const curve = await getCurve(cid); mem.get(dOut).set(await joinABC(curve, mem.get(dA), mem.get(dB), mem.get(dC), cnt)); },
+    async groth16Finish(cid, key, sums, r, s) { note("finish"); return finish(keys.get(key), sums, r, s); },
+    pointAdd: real.pointAdd, shmMap: real.shmMap, shmUnlink: real.shmUnlink,
+};
+module.exports = backend;

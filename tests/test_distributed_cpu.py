@@ -76,6 +76,8 @@ def _worker(rank, world, port, n, out_dir):
     # what is covered is the ownership map, the slicing, the send/recv pairing and that both ranks end with the oracle's full proof.
     import torch
 
+    order = []
+
     class OracleShard:
         curve_id = O.BN128
         n = dom
@@ -83,17 +85,23 @@ def _worker(rank, world, port, n, out_dir):
         def empty(self, nbytes):
             return torch.empty(max(nbytes, 1), dtype=torch.uint8)
 
+        def sums_w(self):
+            order.append("sums_w")                     # the witness-side half: enqueued while the slices travel (device: zkmi_groth16_sums_w_dev)
+
         def chains(self, owned):
+            order.append("chains")
             a, b, cc = O.build_abc(O.BN128, zk["coeffs"], w, m, dom)
             src = {0: a, 1: b, 2: cc}
             return {c: torch.from_numpy(O.ntt(O.BN128, O.apply_key(O.BN128, O.ntt(O.BN128, src[c], inverse=True), one, inc)).copy()) for c in owned}
 
         def join(self, a, b, c, cnt):
+            order.append("join")
             if not cnt:
                 return self.empty(0)
             return torch.from_numpy(O.join_abc(O.BN128, a.numpy()[:cnt * 32], b.numpy()[:cnt * 32], c.numpy()[:cnt * 32]).copy())
 
         def sums(self, hh):
+            order.append("sums")
             (vl, vh), (hl, hh_) = D.shard_range(m, rank, world), D.shard_range(dom, rank, world)
             full_h = np.zeros(dom * 32, np.uint8)
             full_h[hl * 32:hh_ * 32] = hh.numpy()[:(hh_ - hl) * 32]
@@ -110,6 +118,8 @@ def _worker(rank, world, port, n, out_dir):
         def close(self):
             pass
     got = D.groth16_prove_sharded(None, w, None, None, backend=OracleShard())
+    # transforms first (their slices leave early), the witness-side MSMs underneath the exchange, only the H half after the join
+    assert order == ["chains", "sums_w", "join", "sums"], order
     for (a, b, grp) in ((0, 96, 1), (96, 192, 1), (192, 384, 2), (384, 480, 1), (480, 576, 1)):
         assert np.array_equal(O.to_affine(O.BN128, grp, got[a:b]), O.to_affine(O.BN128, grp, want[a:b])), ("chain-parallel", a, b)
     np.save(os.path.join(out_dir, f"r{rank}_g17.npy"), got)

@@ -35,6 +35,59 @@ def test_register_glue_against_reference_bundle():
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@need_node
+@pytest.mark.skipif(not os.path.exists("/root/reference/build/snarkjs.min.js"), reason="reference bundle not present (GPU box)")
+def test_make_prover_against_reference_bundle():
+    """js/groth16_native.js (makeProver: parsing, key life cycle, throughput-mode order) with the real bundle as `snarkjs` and a
+    reference-backed stand-in for the addon (tests/js/ref_backend.js)"""
+    r = subprocess.run([NODE] + FLAGS + [os.path.join(ROOT, "tests", "js", "native_glue.js")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@need_node
+@pytest.mark.skipif(not os.path.exists("/root/reference/build/snarkjs.min.js"), reason="reference bundle not present (GPU box)")
+def test_node_shard_driver_processes_on_cpu():
+    """js/groth16_shards.js: 2 and 3 worker PROCESSES, the exchange through POSIX shared memory mapped by the real addon, the arithmetic by the
+    reference's own curve: the sharded proof equals the reference's proof and the protocol runs in the overlapped order"""
+    r = subprocess.run([NODE] + FLAGS + [os.path.join(ROOT, "tests", "js", "shards_mock.js")], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@need_node
+def test_addon_checked_call_table():
+    """addon.call reaches only the entry points of its binding table and checks every argument's kind and minimum length before the call;
+    zkmi_keccak256 / zkmi_fr_root need no device"""
+    js = ("const a=require(%r);const eq=(x,y)=>Buffer.from(x).toString('hex')===y;"
+          "const o=new Uint8Array(32);a.call('zkmi_keccak256',new Uint8Array(0),0,o);"
+          "if(!eq(o,'c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470')){console.log('keccak',Buffer.from(o).toString('hex'));process.exit(3)}"
+          "const w=new Uint8Array(32);a.call('zkmi_fr_root',0,1,w);"
+          "const bad=(f,re)=>{try{f();return false}catch(e){return re.test(e.message)}};"
+          "if(!bad(()=>a.call('zkmi_init',0),/binding table/))process.exit(4);"
+          "if(!bad(()=>a.call('system',0),/binding table/))process.exit(5);"
+          "if(!bad(()=>a.call('zkmi_fr_root',0,1,new Uint8Array(31)),/shorter/))process.exit(6);"
+          "if(!bad(()=>a.call('zkmi_fr_root',0,1),/too few/))process.exit(7);"
+          "if(!bad(()=>a.call('zkmi_fr_root',0,1,w,1),/too many/))process.exit(8);"
+          "if(!bad(()=>a.call('zkmi_keccak256',new Uint8Array(4),5,o),/length argument/))process.exit(9);"
+          "if(!bad(()=>a.call('zkmi_fr_root','x',1,w),/bad argument/))process.exit(10);"
+          "const want=['groth16Load','groth16LoadAsync','groth16LoadShard','groth16Submit','groth16SubmitAsync','groth16Collect','groth16CollectAsync','devAlloc','devFree','memcpyH2D','memcpyD2H',"
+          "'groth16ChainsDev','groth16SumsWDev','groth16SumsHDev','groth16SumsDev','groth16Finish','joinABCDev','pointAdd','shmMap','shmUnlink'];"
+          "for(const k of want) if(typeof a[k]!=='function'){console.log('missing',k);process.exit(11)}"
+          "const z=new Uint8Array(96);if(a.pointAdd(0,1,z,z).length!==96)process.exit(12);"
+          "const m=a.shmMap('/zkmi_test_'+process.pid,4096,true);m[5]=7;const m2=a.shmMap('/zkmi_test_'+process.pid,4096,false);if(m2[5]!==7)process.exit(13);a.shmUnlink('/zkmi_test_'+process.pid);"
+          "console.log('ok')") % ADDON
+    r = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@need_node
+def test_node_make_prover_and_shard_processes_on_gpu():
+    """js/groth16_native.js (prove, proveMany: two proofs in flight) and js/groth16_shards.js (2 and 3 worker processes, shared-memory exchange)
+    with the REAL addon: the reference's seeded proofs on both curves"""
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "native_gpu.js")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 @need_node
 def test_addon_against_golden_vectors_on_gpu():

@@ -4,6 +4,7 @@
 // Measures, with host buffers in and host results out (H2D of inputs and D2H of results inside the timed call):
 //   groth16  addon.groth16Prove: cold = first call (zkey sections H2D + window-table build + proof), warm = key resident, only the
 //            witness (32 B x nVars) crosses PCIe per proof
+//            pipelined = two proofs in flight (addon.groth16Submit / groth16Collect), the witness upload of proof k+1 under proof k
 //   msm      addon.msm on the A section (nVars points): cold (bases uploaded every call, cache not allowed) / resident (3rd+ call)
 //   ntt      addon.ntt of domainSize elements (32 B x n in, 32 B x n out)
 // Prints ONE JSON line.
@@ -44,6 +45,20 @@ const out = { n_vars: nVars, domain: domainSize, reps };
     for (let i = 0; i < reps; i++) { t0 = now(); addon.groth16Prove(cid, key, witness, r, s); t.push(now() - t0); }
     out.groth16_warm_ms = +med(t).toFixed(3);
     out.groth16_warm_h2d_bytes = witness.byteLength;
+    // throughput mode through Node (js/groth16_native.js: proveMany): two proofs in flight, the witness of proof k+1 crosses PCIe on its slot's
+    // stream while proof k computes (zkmi_groth16_submit / _collect); per-proof wall time over `reps * 4` proofs
+    {
+        const N = Math.max(8, reps * 4);
+        t0 = now();
+        for (let i = 0; i < N; i++) {
+            addon.groth16Submit(key, witness, i & 1);
+            if (i) addon.groth16Collect(cid, key, (i - 1) & 1, r, s);
+        }
+        const last = addon.groth16Collect(cid, key, (N - 1) & 1, r, s);
+        out.groth16_pipelined_ms = +((now() - t0) / N).toFixed(3);
+        const ref = addon.groth16Prove(cid, key, witness, r, s);
+        out.groth16_pipelined_equals_serial = Buffer.from(last.pi_a).equals(Buffer.from(ref.pi_a)) && Buffer.from(last.pi_b).equals(Buffer.from(ref.pi_b)) && Buffer.from(last.pi_c).equals(Buffer.from(ref.pi_c));
+    }
     addon.groth16Release(key);
 }
 {
