@@ -295,6 +295,36 @@ async function plonkGolden() {
     }
 }
 
+// The reference proves PLONK on whatever curve the zkey names (src/plonk_prove.js:66-75, src/curves.js:36-53) but ships no BLS12-381 fixture:
+// plonk.setup over a seeded BLS12-381 ptau on the Multiplier(n) r1cs of the recipe above (SURVEY.md 8d), a seeded plonk.prove with its 11
+// blinding draws recorded, the reference's own verifier as the judge.
+async function plonkGoldenBls() {
+    const curve = await snarkjs.curves.getCurveFromName('bls12381');
+    const r = curve.Fr.p, n = 40;
+    const mem = () => ({ type: 'mem' });
+    const p0 = mem(), p1 = mem(), pf = mem(), z = mem();
+    await snarkjs.powersOfTau.newAccumulator(curve, 8, p0);
+    await snarkjs.powersOfTau.contribute(p0, p1, 'C1', 'Entropy1');
+    await snarkjs.powersOfTau.preparePhase2(p1, pf);
+    await snarkjs.plonk.setup(multiplierR1cs(r, n), pf, z);
+    const w = { data: multiplierWtns(r, n, 11n, 2n) };
+    const rnd = [], Fr = curve.Fr;
+    const origRandom = Fr.random.bind(Fr); Fr.random = () => { const v = origRandom(); rnd.push(hex(v)); return v; };
+    const { proof, publicSignals } = await snarkjs.plonk.prove(z.data, w.data);
+    Fr.random = origRandom;
+    const vk = await snarkjs.zKey.exportVerificationKey(z.data);
+    const verify_trace = [];
+    const vlog = { debug: (m) => verify_trace.push(m), info() {}, warn() {}, error() {} };
+    const ok = await snarkjs.plonk.verify(vk, publicSignals, proof, vlog);
+    if (!ok) throw new Error('golden BLS12-381 plonk proof does not verify');
+    const tag = 'plonk_bls12381_small';
+    fs.writeFileSync(path.join(OUT, `${tag}.zkey`), z.data);
+    fs.writeFileSync(path.join(OUT, `${tag}.wtns`), w.data);
+    fs.writeFileSync(path.join(OUT, `${tag}.json`), JSON.stringify({
+        zkey_sha256: sha(z.data), wtns_sha256: sha(w.data), proof_sha256: sha(JSON.stringify(proof)), blinding_mont: rnd, proof, publicSignals, verified: ok, vk, verify_trace }, null, 1));
+    console.log(tag, 'plonk golden done: zkey', z.data.length, 'bytes, proof sha', sha(JSON.stringify(proof)), 'verify', ok);
+}
+
 // Seeded FFLONK fixtures: fflonk.setup on two circuits of the reference's test tree with a seeded ptau (only tauG1/tauG2 are read,
 // src/fflonk_setup.js:430-438), then a seeded fflonk.prove whose 9 blinding draws (src/fflonk_prove.js:321-324) are recorded.
 async function fflonkGolden() {
@@ -358,6 +388,7 @@ async function fflonkGolden() {
     if (what === 'all' || what === 'groth16') await groth16Golden();
     if (what === 'all' || what === 'groth16bls') await groth16GoldenBls();
     if (what === 'all' || what === 'plonk') await plonkGolden();
+    if (what === 'all' || what === 'plonkbls') await plonkGoldenBls();
     if (what === 'all' || what === 'fflonk') await fflonkGolden();
     process.exit(0);
 })().catch(e => { console.error(e); process.exit(1); });

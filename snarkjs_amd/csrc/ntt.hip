@@ -3,6 +3,7 @@
 #include <algorithm>
 #include "host_field.hpp"
 #include "ntt.cuh"
+#include "ntt29.cuh"
 #include "zkmi_common.hpp"
 
 namespace zkmi {
@@ -76,6 +77,10 @@ template <class C> static int get_plan(int curve, unsigned L, int inverse, NttPl
     ZK_TRY(upload_table(tlo, &P.T_lo)); ZK_TRY(upload_table(thi, &P.T_hi)); ZK_TRY(upload_table(thil, &P.T_hi_last));
     std::vector<HE> one(1, ninv);
     ZK_TRY(upload_table(one, &P.n_inv));
+    // R'-form copies for ntt29.cuh: t 2^256 (the host's Montgomery form) times 2^5
+    auto to29 = [&](std::vector<HE> v) { for (auto& x : v) for (int k = 0; k < 5; k++) x = F.dbl(x); return v; };
+    ZK_TRY(upload_table(to29(tlo), &P.T_lo29)); ZK_TRY(upload_table(to29(thi), &P.T_hi29)); ZK_TRY(upload_table(to29(thil), &P.T_hi_last29));
+    ZK_TRY(upload_table(to29(one), &P.n_inv29));
     for (int i = 0; i < P.n_pass; i++) {
         const unsigned li = P.l[i];
         const HE* wt = inverse ? R.wi : R.w;
@@ -83,6 +88,10 @@ template <class C> static int get_plan(int curve, unsigned L, int inverse, NttPl
         lt[0] = F.One();
         for (size_t k = 1; k < lt.size(); k++) lt[k] = F.mul(lt[k - 1], wt[li]);      // w_{Ni} = Fr.w[li]
         ZK_TRY(upload_table(lt, &P.LT[i]));
+        // ntt29.cuh: U[m] = w_{Ni}^(bit reversal of m over li - 1 bits)
+        std::vector<HE> u(lt.size());
+        for (size_t mI = 0; mI < lt.size(); mI++) { size_t rv = 0; for (unsigned b = 0; b + 1 < li; b++) if ((mI >> b) & 1) rv |= (size_t)1 << (li - 2 - b); u[mI] = lt[rv]; }
+        ZK_TRY(upload_table(to29(u), &P.LT29[i]));
     }
     cx.plans[key] = P;
     *out = &cx.plans[key];
@@ -113,6 +122,8 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
     ZK_TRY((get_plan<C>(curve, L, inverse, &P)));
     const int p = P->n_pass;
     // pre-scale row tables: rowinc_i[j] = (i == 0 ? first : 1) * inc^(j*S_i)
+    // ZKMI_NTT29=0: the r02 passes on saturated 32-bit limbs (ntt.cuh) instead of the 9 x 29-bit ones (ntt29.cuh); A/B switch
+    static const bool use29 = !(getenv("ZKMI_NTT29") && atoi(getenv("ZKMI_NTT29")) == 0);
     uint32_t* d_rowinc = nullptr;
     size_t rowoff[4] = {0, 0, 0, 0};
     if (first) {
@@ -120,7 +131,7 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
         for (int i = 0; i < p; i++) { rowoff[i] = tot; tot += (size_t)1 << P->l[i]; }
         std::string ck((const char*)first, 32);
         ck.append((const char*)inc, 32);
-        ck.push_back((char)curve); ck.push_back((char)L);
+        ck.push_back((char)curve); ck.push_back((char)L); ck.push_back(use29 ? '9' : '2');
         DevBuf& cb = cx.ntt_prescale[ck];
         if (!cb.p) {                                  // tables are O(sum 2^l_i) elements: built once per (size, first, inc)
             if (cx.ntt_prescale.size() > 64) {         // bound the cache: drop everything but the new entry
@@ -142,6 +153,7 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
                 HE cur = (i == 0) ? f : F.One();
                 for (size_t j = 0; j < ((size_t)1 << P->l[i]); j++) { tab[rowoff[i] + j] = cur; cur = F.mul(cur, b); }
             }
+            if (use29) for (auto& x : tab) for (int k = 0; k < 5; k++) x = F.dbl(x);       // R'-form factors for ntt29.cuh
             DevBuf& nb = cx.ntt_prescale[ck];
             ZK_HIP(hipMalloc(&nb.p, tot * 32));
             nb.cap = tot * 32;
@@ -150,46 +162,55 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
             d_rowinc = (uint32_t*)nb.p;
         } else d_rowinc = (uint32_t*)cb.p;
     }
-    // work buffer for the in-place middle passes (the caller's input is never modified)
+    // work buffer for the in-place middle passes (the caller's input is never modified); ntt29: 36-byte lazy records
     uint32_t* work = nullptr;
-    if (p > 1) ZK_TRY(ws_get("ntt.work", n * 32 * batch, (void**)&work));
+    const size_t rec = use29 ? NTT29_REC : 8;                       // words per work-array element
+    if (p > 1) ZK_TRY(ws_get(use29 ? "ntt.work29" : "ntt.work", n * rec * 4 * batch, (void**)&work));
     static bool attr = false;
     if (!attr) {
         ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_strided<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_pass_last<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt29_pass_strided<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt29_pass_strided<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt29_pass_last<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt29_pass_last<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr = true;
     }
     ZK_HIP(hipEventRecord(cx.ev0, st));
     NttPassArgs a;
-    a.log_n = L; a.n_pass = (uint32_t)p; a.log_lb = P->log_lb; a.T_lo = P->T_lo;
+    a.log_n = L; a.n_pass = (uint32_t)p; a.log_lb = P->log_lb; a.T_lo = use29 ? P->T_lo29 : P->T_lo;
     for (int i = 0; i < 4; i++) a.l[i] = P->l[i];
     unsigned logS = L;
     for (int i = 0; i < p - 1; i++) {
         logS -= P->l[i];
-        a.pass = (uint32_t)i; a.T_hi = P->T_hi; a.LT = P->LT[i]; a.scale = nullptr;
+        a.pass = (uint32_t)i; a.T_hi = use29 ? P->T_hi29 : P->T_hi; a.LT = use29 ? P->LT29[i] : P->LT[i]; a.scale = nullptr;
         a.rowinc = d_rowinc ? d_rowinc + rowoff[i] * 8 : nullptr;
         a.log_ch = std::min<unsigned>(NTT_TILE_LOG - P->l[i], logS);
         const size_t N = (size_t)1 << P->l[i], E = N << a.log_ch;
-        const size_t lds = (2 * E + N + 2 * N) * 16;
+        const size_t lds = use29 ? (size_t)9 * (E + N / 2 + N) * 4 : (2 * E + N + 2 * N) * 16;
         const unsigned tiles = (unsigned)(n >> (P->l[i] + a.log_ch));
         const uint32_t* src = (i == 0) ? (const uint32_t*)d_in : work;
-        a.in_bs = (i == 0) ? (uint64_t)in_stride * 8 : (uint64_t)n * 8; a.out_bs = (uint64_t)n * 8;
-        hipLaunchKernelGGL((k_ntt_pass_strided<C>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, work, a);
+        a.in_bs = (i == 0) ? (uint64_t)in_stride * 8 : (uint64_t)n * rec; a.out_bs = (uint64_t)n * rec;
+        if (!use29) hipLaunchKernelGGL((k_ntt_pass_strided<C>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, work, a);
+        else if (i == 0) hipLaunchKernelGGL((k_ntt29_pass_strided<C, false>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, work, a);
+        else hipLaunchKernelGGL((k_ntt29_pass_strided<C, true>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, work, a);
     }
     {
         const int i = p - 1;
-        a.pass = (uint32_t)i; a.T_hi = P->T_hi_last; a.LT = P->LT[i];
+        a.pass = (uint32_t)i; a.T_hi = use29 ? P->T_hi_last29 : P->T_hi_last; a.LT = use29 ? P->LT29[i] : P->LT[i];
         a.rowinc = d_rowinc ? d_rowinc + rowoff[i] * 8 : nullptr;
-        a.scale = (p == 1 && inverse) ? P->n_inv : nullptr;
+        a.scale = (p == 1 && inverse) ? (use29 ? P->n_inv29 : P->n_inv) : nullptr;
         a.log_ch = (p == 1) ? 0 : std::min<unsigned>(NTT_TILE_LOG - P->l[i], P->l[0]);
         const size_t N = (size_t)1 << P->l[i];
-        const size_t lds = (2 * ((N + 1) << a.log_ch) + N) * 16;
+        const size_t lds = use29 ? (size_t)9 * (((N + 1) << a.log_ch) + std::max<size_t>(N / 2, 1)) * 4 : (2 * ((N + 1) << a.log_ch) + N) * 16;
         const unsigned tiles = (unsigned)(n >> (P->l[i] + a.log_ch));
         const uint32_t* src = (p == 1) ? (const uint32_t*)d_in : work;
         uint32_t* dst = (uint32_t*)d_out;
         if (p == 1 && d_in == d_out) { /* single tile: loads complete before stores */ }
-        a.in_bs = (p == 1) ? (uint64_t)in_stride * 8 : (uint64_t)n * 8; a.out_bs = (uint64_t)out_stride * 8;
-        hipLaunchKernelGGL((k_ntt_pass_last<C>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, dst, a);
+        a.in_bs = (p == 1) ? (uint64_t)in_stride * 8 : (uint64_t)n * rec; a.out_bs = (uint64_t)out_stride * 8;
+        if (!use29) hipLaunchKernelGGL((k_ntt_pass_last<C>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, dst, a);
+        else if (p == 1) hipLaunchKernelGGL((k_ntt29_pass_last<C, false>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, dst, a);
+        else hipLaunchKernelGGL((k_ntt29_pass_last<C, true>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, dst, a);
     }
     ZK_HIP(hipEventRecord(cx.ev1, st));
     ZK_HIP(hipGetLastError());

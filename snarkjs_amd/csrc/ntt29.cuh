@@ -1,0 +1,211 @@
+// snarkjs_amd/csrc/ntt29.cuh — the Fr NTT passes of ntt.cuh on unsaturated 9 x 29-bit limbs (field29.cuh), gfx950.
+//
+// Same passes, tiles, index algebra and launch geometry as ntt.cuh (read its header first); what changes is the arithmetic inside a tile:
+//   * the data keeps the reference's Montgomery factor: an element x is carried as the VALUE v = x 2^256 (what the caller's bytes hold), as 9
+//     lazy limbs. Twiddles, row factors, pre-scale factors and 1/n are stored in R'-form (t 2^261 mod r, packed canonical words), so that
+//     mul29(v, t') = v t 2^261 / 2^261 = (x t) 2^256: the product is again a value in the caller's form — no conversion anywhere;
+//   * butterflies are decimation-in-TIME: (x, y) -> (x + w y, x - w y + 2r). The multiplication comes first, so a lazy sum never meets
+//     another lazy sum multiplicatively: values grow by at most 2r per stage (< 1.3r + 2r l <= 19.3r < 2^258 after l <= 9 stages, r02's
+//     decimation-in-frequency form would double them per stage). A product is 207 instructions against ~290 on saturated limbs, and the
+//     addition / subtraction are 9 limb operations + one carry pass each instead of two carry chains with conditional corrections;
+//   * the DIT form used here takes its input in NATURAL order and leaves the output bit-reversed, exactly like the DIF stages of ntt.cuh, so
+//     the loads, the transposed stores and the digit reversal of the last pass are unchanged; stage s (span h = 2^s, from l-1 down to 0)
+//     multiplies the upper half of block `blk` by w_N^(bitrev(blk) 2^s) = U[blk] with U the local twiddle table in bit-reversed order:
+//     lanes read consecutive or identical entries (no bank conflicts, like the jl << (l-1-s) indexing of the DIF form);
+//   * between passes the work array holds the lazy values as 9-word records (36 bytes per element, internal); only the last pass brings
+//     every value to the canonical range (reduce29_small: quotient estimate from the top limb, one multiply-subtract pass, <= 3 conditional
+//     subtractions) and writes the reference's 32 bytes.
+// Tile storage in LDS: limb k of element e at plane k (E words per plane): consecutive lanes -> consecutive words, conflict-free.
+#pragma once
+#include "field29.cuh"
+#include "ntt.cuh"
+
+namespace zkmi {
+
+constexpr int NTT29_REC = 9;                  // words per element of the work array between passes
+
+// v (normalised, < 32 r) -> v mod r, canonical limbs
+template <class C> ZK_HD void reduce29_small(Fp29<C>& v) {
+    using L = Lim29<C>;
+    constexpr int NL = L::NL, B = L::B;
+    static_assert(NL == 9 && B == 29, "Fr form");
+    // q' <= floor(v / r) <= q' + 2: floor(top limb / (top limb of r + 1)) by a 40-bit reciprocal
+    constexpr uint64_t MAGIC = (1ull << 40) / ((uint64_t)L::p(NL - 1) + 1);
+    const uint32_t q = (uint32_t)(((uint64_t)v.l[NL - 1] * MAGIC) >> 40);
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int64_t t = (int64_t)v.l[i] - (int64_t)((uint64_t)q * L::p(i)) + c;
+        if (i < NL - 1) { v.l[i] = (uint32_t)t & mask29<C>(); c = t >> B; } else v.l[i] = (uint32_t)t;
+    }
+    // < 3 r left: subtract r while >= r
+#pragma unroll 1
+    for (int rep = 0; rep < 3; rep++) {
+        int32_t d[NL], cc = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) { int32_t t = (int32_t)v.l[i] - (int32_t)L::p(i) + cc; if (i < NL - 1) { cc = t >> B; d[i] = t & (int32_t)mask29<C>(); } else d[i] = t; }
+        const bool ge = d[NL - 1] >= 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) v.l[i] = ge ? (uint32_t)d[i] : v.l[i];
+    }
+}
+// one DIT butterfly: (x, y) -> (x + t, x - t + 2r), t = w y (or y itself in the first stage, where w = 1); x lazy (< 2^258, normalised),
+// t normalised and < 2r - 2^232; both results normalised
+template <class C> ZK_HD void ntt29_bfly(Fp29<C>& x, Fp29<C>& y, const Fp29<C>& t) {
+    const Fp29<C> s = add29(x, t);
+    y = sub29<C, 2>(x, t);
+    x = s;
+    norm29(x); norm29(y);
+}
+
+// tile planes in LDS: limb k of element e at p[k * stride + e]
+template <class C> ZK_DEV Fp29<C> lds29_get(const uint32_t* p, uint32_t stride, uint32_t e) {
+    Fp29<C> r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = p[k * stride + e];
+    return r;
+}
+template <class C> ZK_DEV void lds29_put(uint32_t* p, uint32_t stride, uint32_t e, const Fp29<C>& v) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) p[k * stride + e] = v.l[k];
+}
+// element `i` of an array of 36-byte records (the work array between passes)
+template <class C> ZK_DEV Fp29<C> rec29_load(const uint32_t* base, uint64_t i) {
+    Fp29<C> r;
+    const uint32_t* p = base + i * NTT29_REC;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = p[k];
+    return r;
+}
+template <class C> ZK_DEV void rec29_store(uint32_t* base, uint64_t i, const Fp29<C>& v) {
+    uint32_t* p = base + i * NTT29_REC;
+#pragma unroll
+    for (int k = 0; k < 9; k++) p[k] = v.l[k];
+}
+// w^e from the split power tables (R'-form packed words): one product, normalised, < 1.1 r
+template <class C> ZK_DEV Fp29<C> ntt29_pow(const NttPassArgs& a, uint64_t e) {
+    return mul29(load29_packed<C>(a.T_lo + (size_t)(e & ((1ull << a.log_lb) - 1)) * C::N), load29_packed<C>(a.T_hi + (size_t)(e >> a.log_lb) * C::N));
+}
+
+// radix-2 DIT stages on an LDS tile, natural order in, bit-reversed order out. ROWMAJOR: element (row j, col c) at j*CH + c (strided
+// passes); otherwise at c*(N+1) + j (last pass; +1 pad keeps the transposed store conflict-free). U: local twiddles in bit-reversed order.
+template <class C, bool ROWMAJOR> ZK_DEV void ntt29_tile_stages(uint32_t* p, uint32_t stride, const uint32_t* U, uint32_t l, uint32_t log_ch) {
+    const uint32_t half_elems = 1u << (l + log_ch - 1);
+    const uint32_t N = 1u << l, HN = N >> 1;
+    for (int s = (int)l - 1; s >= 0; s--) {
+        const uint32_t h = 1u << s;
+        for (uint32_t b = threadIdx.x; b < half_elems; b += NTT_THREADS) {
+            uint32_t c, pr;
+            if (ROWMAJOR) { c = b & ((1u << log_ch) - 1); pr = b >> log_ch; }
+            else { pr = b & (HN - 1); c = b >> (l - 1); }
+            const uint32_t jl = pr & (h - 1), blk = pr >> s;
+            const uint32_t j = (blk << (s + 1)) | jl;
+            const uint32_t e0 = ROWMAJOR ? (j << log_ch) + c : c * (N + 1) + j;
+            const uint32_t e1 = ROWMAJOR ? ((j + h) << log_ch) + c : c * (N + 1) + j + h;
+            Fp29<C> x = lds29_get<C>(p, stride, e0), y = lds29_get<C>(p, stride, e1);
+            if (s < (int)l - 1) y = mul29(y, lds29_get<C>(U, HN, blk));        // first stage: one block, w = 1, the operand is a fresh product or canonical
+            ntt29_bfly(x, y, Fp29<C>(y));
+            lds29_put<C>(p, stride, e0, x);
+            lds29_put<C>(p, stride, e1, y);
+        }
+        __syncthreads();
+    }
+}
+
+// IN_REC / OUT_REC: the input / output array holds 36-byte lazy records (work array) instead of the caller's canonical 32-byte elements
+// ---- passes 1 .. p-1 (in place over the FFT digit, columns contiguous in memory) ------------------------------------
+template <class C, bool IN_REC> __global__ void __launch_bounds__(NTT_THREADS)
+k_ntt29_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds29[];
+    in += (size_t)blockIdx.y * a.in_bs; out += (size_t)blockIdx.y * a.out_bs;
+    const uint32_t l = a.l[a.pass], N = 1u << l, CH = 1u << a.log_ch, E = N << a.log_ch, HN = N >> 1;
+    uint32_t* p = lds29;                   // 9 planes of E words
+    uint32_t* U = p + 9 * E;               // 9 planes of N/2 words: local twiddles (bit-reversed order)
+    uint32_t* rf = U + 9 * HN;             // 9 planes of N words: row factors
+    uint32_t log_S = 0;
+    for (uint32_t m = a.pass + 1; m < a.n_pass; m++) log_S += a.l[m];
+    const uint64_t tiles_per_u = (1ull << log_S) >> a.log_ch;
+    const uint64_t u = blockIdx.x / tiles_per_u, q0 = (blockIdx.x % tiles_per_u) << a.log_ch;
+    const uint64_t base = (u << (l + log_S)) + q0;
+    const bool has_fac = (a.pass > 0) || (a.rowinc != nullptr);
+    if (has_fac) {
+        const uint64_t K = a.pass > 0 ? ntt_digit_reverse(a, u, 0, a.pass) : 0;
+        for (uint32_t j = threadIdx.x; j < N; j += NTT_THREADS) {
+            Fp29<C> f;
+            if (a.pass > 0) {
+                const uint64_t e = (((uint64_t)j * K) << log_S) & ((1ull << a.log_n) - 1);
+                f = ntt29_pow<C>(a, e);
+                if (a.rowinc) f = mul29(f, load29_packed<C>(a.rowinc + (size_t)j * C::N));
+            } else f = load29_packed<C>(a.rowinc + (size_t)j * C::N);
+            lds29_put<C>(rf, N, j, f);
+        }
+    }
+    for (uint32_t k = threadIdx.x; k < HN; k += NTT_THREADS) lds29_put<C>(U, HN, k, load29_packed<C>(a.LT + (size_t)k * C::N));
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+        const uint32_t c = idx & (CH - 1), j = idx >> a.log_ch;
+        const uint64_t src = base + ((uint64_t)j << log_S) + c;
+        Fp29<C> x = IN_REC ? rec29_load<C>(in, src) : load29_packed<C>(in + src * C::N);
+        if (has_fac) x = mul29(x, lds29_get<C>(rf, N, j));
+        lds29_put<C>(p, E, idx, x);
+    }
+    __syncthreads();
+    ntt29_tile_stages<C, true>(p, E, U, l, a.log_ch);
+    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+        const uint32_t c = idx & (CH - 1), k = idx >> a.log_ch;
+        const uint32_t j = __brev(k) >> (32 - l);
+        rec29_store<C>(out, base + ((uint64_t)k << log_S) + c, lds29_get<C>(p, E, (j << a.log_ch) + c));
+    }
+}
+
+// ---- last pass: contiguous j_p runs in, natural order out, canonical bytes ------------------------------------------------
+template <class C, bool IN_REC> __global__ void __launch_bounds__(NTT_THREADS)
+k_ntt29_pass_last(const uint32_t* in, uint32_t* out, NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds29[];
+    in += (size_t)blockIdx.y * a.in_bs; out += (size_t)blockIdx.y * a.out_bs;
+    const uint32_t l = a.l[a.pass], N = 1u << l, CH = 1u << a.log_ch, E = N << a.log_ch, PL = (N + 1) << a.log_ch, HN = N >> 1;
+    uint32_t* p = lds29;                   // 9 planes of (N+1)*CH words
+    uint32_t* U = p + 9 * PL;
+    const bool multi = a.n_pass > 1;
+    const uint32_t l1 = a.l[0];
+    uint64_t r = 0, c0 = 0, Krest = 0;
+    uint32_t log_S1 = 0;
+    if (multi) {
+        const uint64_t tiles_per_r = (1ull << l1) >> a.log_ch;
+        r = blockIdx.x / tiles_per_r;
+        c0 = (blockIdx.x % tiles_per_r) << a.log_ch;
+        Krest = ntt_digit_reverse(a, r, 1, a.n_pass - 2);
+        log_S1 = a.log_n - l1;
+    }
+    for (uint32_t k = threadIdx.x; k < HN; k += NTT_THREADS) lds29_put<C>(U, HN > 0 ? HN : 1, k, load29_packed<C>(a.LT + (size_t)k * C::N));
+    Fp29<C> sc;
+    if (a.scale) sc = load29_packed<C>(a.scale);
+    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+        const uint32_t j = idx & (N - 1), c = idx >> l;
+        const uint64_t addr = multi ? (((c0 + c) << log_S1) + (r << l) + j) : j;
+        Fp29<C> x = IN_REC ? rec29_load<C>(in, addr) : load29_packed<C>(in + addr * C::N);
+        if (multi) {
+            const uint64_t K = (c0 + c) + (Krest << l1);
+            x = mul29(x, ntt29_pow<C>(a, (uint64_t)j * K));
+        }
+        if (a.rowinc) x = mul29(x, load29_packed<C>(a.rowinc + (size_t)j * C::N));
+        if (a.scale) x = mul29(x, sc);
+        lds29_put<C>(p, PL, c * (N + 1) + j, x);
+    }
+    __syncthreads();
+    ntt29_tile_stages<C, false>(p, PL, U, l, a.log_ch);
+    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+        const uint32_t c = idx & (CH - 1), k = idx >> a.log_ch;
+        const uint32_t j = l ? (__brev(k) >> (32 - l)) : 0u;
+        const uint64_t K = (c0 + c) + (Krest << l1);
+        const uint64_t addr = multi ? (K + ((uint64_t)k << (a.log_n - l))) : k;
+        Fp29<C> v = lds29_get<C>(p, PL, c * (N + 1) + j);
+        reduce29_small(v);
+        uint32_t w[C::N];
+        pack29<C>(w, v);
+        uint4* q = reinterpret_cast<uint4*>(out + addr * C::N);
+        q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+
+}  // namespace zkmi

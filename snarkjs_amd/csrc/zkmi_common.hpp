@@ -36,6 +36,9 @@ struct NttPlan {
     uint32_t log_lb = 0;
     uint32_t *T_lo = nullptr, *T_hi = nullptr, *T_hi_last = nullptr, *n_inv = nullptr;
     uint32_t* LT[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the same tables in the R'-form of field29.cuh (t 2^261 mod r, packed canonical words) for the passes of ntt29.cuh; LT29 in bit-reversed order
+    uint32_t *T_lo29 = nullptr, *T_hi29 = nullptr, *T_hi_last29 = nullptr, *n_inv29 = nullptr;
+    uint32_t* LT29[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 // Per-pipeline-slot resources. Two Groth16 proofs can be in flight (zkmi_groth16_submit_dev / _collect): the latency-bound tail of

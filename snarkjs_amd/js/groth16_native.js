@@ -133,8 +133,9 @@ function makeProver(snarkjs, options) {
             }
             while (pending.length) { const p = pending.shift(); out[p.i] = finishProof(zk, p.witness, await collect(zk.curveId, zk.key, p.i & 1, p.r, p.s)); }
         } catch (e) {
-            // leave no proof in flight behind an error: drain the slots (their results are discarded)
-            for (const p of pending) { try { await collect(zk.curveId, zk.key, p.i & 1, p.r, p.s); } catch (e2) { /* already failed */ } }
+            // leave no proof in flight behind an error: drain the slots (their results are discarded: any blinding values will do)
+            const z = new Uint8Array(32);
+            for (const p of pending) { try { await collect(zk.curveId, zk.key, p.i & 1, z, z); } catch (e2) { /* already failed */ } }
             throw e;
         }
         return out;

@@ -34,8 +34,9 @@ function stubSnarkjs(cid, name, draws) {
         const many = await prover.proveMany(zkey, [wtns, wtns, wtns, wtns, wtns, wtns, wtns]);
         check(`${name}: proveMany, two proofs in flight, seven proofs`, many.length === 7 && many.every((x) => sha(JSON.stringify(x.proof)) === g.proof_sha256));
         let threw = false;
-        try { await prover.proveMany(zkey, [wtns, zkey]); } catch (e) { threw = /Invalid File format/.test(e.message); }
         seed(1);
+        try { await prover.proveMany(zkey, [wtns, zkey]); } catch (e) { threw = /Invalid File format/.test(e.message); }
+        draws.length = 0; seed(1);
         const after = await prover.proveMany(zkey, [wtns]);
         check(`${name}: an error inside proveMany leaves no proof in flight`, threw && sha(JSON.stringify(after[0].proof)) === g.proof_sha256);
         await prover.release();

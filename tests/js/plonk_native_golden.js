@@ -10,7 +10,7 @@ let fails = 0;
 function check(name, ok) { if (!ok) { fails++; console.log("FAIL", name); } else console.log("ok  ", name); }
 const hexb = (s) => new Uint8Array(Buffer.from(s, "hex"));
 
-for (const tag of ["plonk_bn128_small", "plonk_bn128_n2048"]) {
+for (const tag of ["plonk_bn128_small", "plonk_bn128_n2048", "plonk_bls12381_small"]) {
     const g = JSON.parse(fs.readFileSync(path.join(GOLD, tag + ".json")));
     const zkey = new Uint8Array(fs.readFileSync(path.join(GOLD, tag + ".zkey"))), wtns = new Uint8Array(fs.readFileSync(path.join(GOLD, tag + ".wtns")));
     const res = prove(zkey, wtns, g.blinding_mont.map(hexb));

@@ -18,13 +18,16 @@ P = {
     "bn254fq": 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47,
     "bls12381fq": 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
 }
-FORM = {"bn254fq": (8, 9, 29), "bls12381fq": (12, 14, 28)}       # words, limbs, bits per limb
-CURVES = list(P)
+P["bn254fr"] = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+P["bls12381fr"] = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+FORM = {"bn254fq": (8, 9, 29), "bls12381fq": (12, 14, 28), "bn254fr": (8, 9, 29), "bls12381fr": (8, 9, 29)}       # words, limbs, bits per limb
+CURVES = ["bn254fq", "bls12381fq"]          # base fields: MSM accumulation
+FR_CURVES = ["bn254fr", "bls12381fr"]       # scalar fields: NTT
 
 
 def _deps():
     d = [SRC]
-    for f in ("field.cuh", "field29.cuh", "msm29.cuh", "msm.cuh", "curve.cuh"):
+    for f in ("field.cuh", "field29.cuh", "msm29.cuh", "msm.cuh", "curve.cuh", "ntt29.cuh", "ntt.cuh"):
         d.append(os.path.join(ROOT, "snarkjs_amd", "csrc", f))
     return d
 
@@ -114,7 +117,7 @@ class Form:
         return r
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", CURVES + FR_CURVES)
 def test_constants(tool, curve):
     F = Form(curve)
     c = tool("consts", curve, [])
@@ -127,7 +130,7 @@ def test_constants(tool, curve):
     assert c[5 + 3 * NL:5 + 4 * NL] == F.limbs(pow(2, 32 * F.N, F.p))
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", CURVES + FR_CURVES)
 def test_products(tool, curve):
     F = Form(curve)
     rng = random.Random(0x29 + F.NL)
@@ -369,3 +372,35 @@ def test_g2_lds_parked_additions(tool, curve):
             X, Y, ZZ, ZZZ = ((v[2 * i] * Rwi % p, v[2 * i + 1] * Rwi % p) for i in range(4))
             assert K.mul(K.mul(ZZ, ZZ), ZZ) == K.mul(ZZZ, ZZZ)
             assert (K.mul(X, K.inv(ZZ)), K.mul(Y, K.inv(ZZZ))) == want
+
+
+@pytest.mark.parametrize("curve", FR_CURVES)
+def test_ntt_butterfly_and_final_reduction(tool, curve):
+    """ntt29.cuh: the decimation-in-time butterfly on lazy values (x + w y, x - w y + 2r) through as many stages as the largest tile has, with the
+    worst admissible growth, and the final reduction of a lazy value to the canonical range (quotient estimate from the top limb)."""
+    F = Form(curve)
+    rng = random.Random(0x91 + F.p % 97)
+    r, NL = F.p, F.NL
+    # final reduction: every value below 32 r, incl. multiples of r and their neighbours
+    vals = [0, 1, r - 1, r, r + 1, 31 * r, 32 * r - 1] + [k * r + d for k in range(32) for d in (-1, 0, 1) if 0 <= k * r + d < 32 * r]
+    vals += [rng.randrange(32 * r) for _ in range(300)]
+    for v in vals:
+        assert tool("reduce", curve, F.limbs(v)) == F.limbs(v % r), hex(v)
+    # butterflies: 9 stages (the largest tile), twiddles in R'-form, data values in the caller's form (any residue)
+    for trial in range(20):
+        x, y = F.limbs(rng.randrange(r)), F.limbs(rng.randrange(r))
+        for stage in range(9):
+            w = rng.randrange(r)
+            out = tool("bfly", curve, x + y + F.to29(w) + [1 if stage else 0])
+            x2, y2 = out[:NL], out[NL:]
+            t = F.value(y) * w % r if stage else F.value(y) % r
+            assert F.value(x2) % r == (F.value(x) + t) % r and F.value(y2) % r == (F.value(x) - t) % r
+            assert F.normalised(x2) and F.normalised(y2)
+            assert F.value(x2) < 1.4 * r + 2 * r * (stage + 1) and F.value(y2) < 1.4 * r + 2 * r * (stage + 1)      # grows by at most 2r per stage
+            x, y = (x2, y2) if rng.random() < 0.5 else (y2, x2)                                                       # either output may be multiplied next
+        assert tool("reduce", curve, x) == F.limbs(F.value(x) % r)
+    # worst case: the largest lazy value the last stage can see (19.3 r) as BOTH operands
+    big = F.limbs(int(19.3 * r))
+    out = tool("bfly", curve, big + big + F.to29(r - 1) + [1])
+    assert F.value(out[:NL]) % r == (F.value(big) + F.value(big) * (r - 1)) % r and F.value(out[:NL]) < 32 * r and F.value(out[NL:]) < 32 * r
+    assert tool("reduce", curve, out[:NL]) == F.limbs(F.value(out[:NL]) % r)

@@ -108,9 +108,10 @@ def test_div_zh_vs_oracle(env, dom):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["plonk_bn128_small", "plonk_bn128_n2048"])
+@pytest.mark.parametrize("tag", ["plonk_bn128_small", "plonk_bn128_n2048", "plonk_bls12381_small"])
 def test_plonk_stages_and_golden_proof(env, golden_dir, tag):
-    """Device prover == the reference's seeded proof (sha256 of the proof JSON)."""
+    """Device prover == the reference's seeded proof (sha256 of the proof JSON); plonk_bls12381_small: the PLONK kernels with curve = 1
+    (the reference proves PLONK on the curve of the zkey, src/plonk_prove.js:66-75; fixture: oracle/gen_golden.js plonkbls)."""
     zkmi, plonk, f, cx = env
     with open(os.path.join(golden_dir, f"{tag}.json")) as fh:
         g = json.load(fh)

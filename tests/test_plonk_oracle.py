@@ -25,7 +25,7 @@ def test_keccak256_known_answers():
     assert len({P.keccak256(b"x" * k) for k in (135, 136, 137)}) == 3
 
 
-@pytest.mark.parametrize("tag", ["plonk_bn128_small", "plonk_bn128_n2048"])
+@pytest.mark.parametrize("tag", ["plonk_bn128_small", "plonk_bn128_n2048", "plonk_bls12381_small"])
 def test_plonk_golden_proof(golden_dir, tag):
     g, zkey, wtns = load(golden_dir, tag)
     proof, public = P.plonk_prove(zkey, wtns, [bytes.fromhex(x) for x in g["blinding_mont"]])

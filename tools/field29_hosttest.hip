@@ -12,6 +12,7 @@
 #include <sstream>
 #include <iostream>
 #include "msm29.cuh"
+#include "ntt29.cuh"
 
 using namespace zkmi;
 
@@ -101,6 +102,18 @@ template <class C> static std::string run(const std::string& op, const std::vect
         o.push_back(inf ? 1u : 0u);
         for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
     }
+    else if (op == "reduce") {
+        if constexpr (Lim29<C>::NL == 9) { auto a = rd<C>(v, at); reduce29_small(a); wr(o, a); } else return "ERR form";
+    }
+    else if (op == "bfly") {                 // in: x, y, w, has_w; out: x', y' (ntt29.cuh: one DIT butterfly as the tile stages run it)
+        if constexpr (Lim29<C>::NL == 9) {
+            auto x = rd<C>(v, at), y = rd<C>(v, at), w = rd<C>(v, at);
+            const bool has_w = v.at(at++) != 0;
+            if (has_w) y = mul29(y, w);
+            ntt29_bfly(x, y, Fp29<C>(y));
+            wr(o, x); wr(o, y);
+        } else return "ERR form";
+    }
     else if (op == "consts") {
         o.push_back(NL); o.push_back(Lim29<C>::B); o.push_back(N); o.push_back(Lim29<C>::NP); o.push_back(Lim29<C>::PINV);
         for (int i = 0; i < NL; i++) o.push_back(Lim29<C>::p(i));
@@ -127,6 +140,8 @@ int main() {
         try {
             if (curve == "bn254fq") out = run<Bn254Fq>(op, v);
             else if (curve == "bls12381fq") out = run<Bls12381Fq>(op, v);
+            else if (curve == "bn254fr") out = run<Bn254Fr>(op, v);
+            else if (curve == "bls12381fr") out = run<Bls12381Fr>(op, v);
             else out = "ERR curve";
         } catch (const std::exception& e) { out = std::string("ERR ") + e.what(); }
         std::cout << out << "\n" << std::flush;
