@@ -20,7 +20,17 @@ def _stale(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
+
+
+def _depfile(obj):
+    """headers a translation unit actually includes, from the compiler's own -MD output of its last build (None: not built yet)"""
+    d = obj[:-2] + ".d"
+    if not os.path.exists(d):
+        return None
+    txt = open(d).read().replace("\\\n", " ")
+    deps = txt.split(":", 1)[1].split() if ":" in txt else []
+    return [x for x in deps if x.startswith(os.path.dirname(HERE)) or x.startswith(CSRC)]
 
 
 def build(verbose=False, force=False):
@@ -31,12 +41,13 @@ def build(verbose=False, force=False):
     jobs = []
     for u in units:
         src, obj = os.path.join(CSRC, u), os.path.join(OBJ, u.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + headers):
+        deps = _depfile(obj)                               # per-unit dependencies once known; every header before the first build
+        if force or _stale(obj, [src] + (deps if deps is not None else headers)):
             jobs.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + ["-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -83,11 +83,14 @@ template <class C> ZK_HD void dbl_xyzz29(XYZZ29<C>& r) {
 }
 // acc += p for two general XYZZ points (add-2008-s, 12M + 2S, the last two products share one reduction). Both operands within the
 // invariants of madd29 (X <= 7.3, Y <= 3.3, ZZ, ZZZ <= 1.1, normalised; a point just unpacked from memory is canonical); the result too.
-template <class C> ZK_HD void padd29(XYZZ29<C>& acc, bool& inf, const XYZZ29<C>& p) {
-    if (inf) { acc = p; inf = false; return; }
-    const Fp29<C> U1 = mul29(acc.X, p.ZZ), U2 = mul29(p.X, acc.ZZ);             // <= 1.05
+// The coordinates of p are fetched on demand through ld(k), k = 0..3 = X, Y, ZZ, ZZZ (ZZ and ZZZ twice): p never sits in registers as a
+// whole — with 14-limb coordinates the two points, the intermediate values and a product's scratch do not fit 256 VGPRs together (the first
+// BLS12-381 version took 306 registers, one wave per SIMD).
+template <class C, class Ld> ZK_HD void padd29_ld(XYZZ29<C>& acc, bool& inf, Ld ld) {
+    if (inf) { acc.X = ld(0); acc.Y = ld(1); acc.ZZ = ld(2); acc.ZZZ = ld(3); inf = false; return; }
+    const Fp29<C> U1 = mul29(acc.X, ld(2)), U2 = mul29(ld(0), acc.ZZ);          // <= 1.05
     Fp29<C> P = sub29<C, 2>(U2, U1); norm29(P);                                 // <= 3.05
-    const Fp29<C> S1 = mul29(acc.Y, p.ZZZ), S2 = mul29(p.Y, acc.ZZZ);           // <= 1.03
+    const Fp29<C> S1 = mul29(acc.Y, ld(3)), S2 = mul29(ld(1), acc.ZZZ);         // <= 1.03
     Fp29<C> R = sub29<C, 2>(S2, S1); norm29(R);                                 // <= 3.03
     if (is_zero29(P)) {
         if (is_zero29(R)) dbl_xyzz29(acc); else inf = true;
@@ -98,8 +101,19 @@ template <class C> ZK_HD void padd29(XYZZ29<C>& acc, bool& inf, const XYZZ29<C>&
     Fp29<C> X3 = sub29<C, 2>(sub29<C, 2>(sub29<C, 2>(sqr29(R), PPP), Q), Q); norm29(X3);          // <= 1.06 + 6 = 7.06
     Fp29<C> T = sub29<C, 8>(Q, X3); norm29(T);                                  // <= 9.1
     const Fp29<C> Y3 = mul29_2(R, T, sub29<C, 2>(zero29<C>(), S1), PPP);        // (R T + (2p - S1) PPP) / R' + p <= (27.6 + 2.1) / 169 + 1 = 1.18
-    acc.ZZ = mul29(mul29(acc.ZZ, p.ZZ), PP); acc.ZZZ = mul29(mul29(acc.ZZZ, p.ZZZ), PPP);
+    acc.ZZ = mul29(mul29(acc.ZZ, ld(2)), PP); acc.ZZZ = mul29(mul29(acc.ZZZ, ld(3)), PPP);
     acc.X = X3; acc.Y = Y3;
+}
+template <class C> ZK_HD void padd29(XYZZ29<C>& acc, bool& inf, const XYZZ29<C>& p) {
+    padd29_ld(acc, inf, [&](int k) -> Fp29<C> { return k == 0 ? p.X : (k == 1 ? p.Y : (k == 2 ? p.ZZ : p.ZZZ)); });
+}
+// all-zero ZZ words = the point at infinity (store_xyzz29<C, true>)
+template <class C> ZK_HD bool xyzz29_words_inf(const uint32_t* src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src + 2 * C::N);
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < C::N / 4; i++) { const uint4 z = q[i]; nz |= z.x | z.y | z.z | z.w; }
+    return nz == 0;
 }
 
 
@@ -211,7 +225,8 @@ k_msm_accum29(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ i
 
 // Row / column sums of the 2-D bucket reduction (msm.cuh: k_msm_rowcol_wave) over R'-form buckets on unsaturated limbs: one wave per sum, 64
 // lanes add strided shares, then a 6-level tree through LDS in the same launch; the sums leave in the reference's R-form (k_msm_bitsums reads them).
-template <class C> __global__ void __launch_bounds__(256)
+// waves per SIMD the register budget is held to: 3 with 9-limb coordinates (168 VGPRs), 2 with 14-limb ones (256)
+template <class C> __global__ void __launch_bounds__(256, Lim29<C>::NL <= 9 ? 3 : 2)
 k_msm_rowcol_wave29(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_t cbits, uint32_t* __restrict__ out) {
     constexpr int NL = Lim29<C>::NL, PW = 4 * C::N;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                  // 256 lanes x 4 NL words
@@ -234,8 +249,8 @@ k_msm_rowcol_wave29(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, 
             if (!kind && i >= R) { /* row index beyond the row count: empty sum */ }
             else for (uint32_t e = sub; e < cnt; e += 64) {
                 const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
-                XYZZ29<C> p;
-                if (cn[g] && load_xyzz29(p, bk + g * PW)) padd29(acc, inf, p);
+                const uint32_t* src = bk + g * PW;
+                if (cn[g] && !xyzz29_words_inf<C>(src)) padd29_ld(acc, inf, [&](int k) { return load29_packed<C>(src + k * C::N); });
             }
         }
         uint32_t* mine = lds + t;
@@ -247,11 +262,11 @@ k_msm_rowcol_wave29(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, 
             }
             __syncthreads();
             if ((t & (2 * d - 1)) == 0 && !inf_s[t + d]) {
-                XYZZ29<C> o;
                 const uint32_t* pn = lds + t + d;
+                padd29_ld(acc, inf, [&](int k) { Fp29<C> v;
 #pragma unroll
-                for (int k = 0; k < NL; k++) { o.X.l[k] = pn[k * 256]; o.Y.l[k] = pn[(NL + k) * 256]; o.ZZ.l[k] = pn[(2 * NL + k) * 256]; o.ZZZ.l[k] = pn[(3 * NL + k) * 256]; }
-                padd29(acc, inf, o);
+                    for (int i = 0; i < NL; i++) v.l[i] = pn[(k * NL + i) * 256];
+                    return v; });
             }
             __syncthreads();
         }

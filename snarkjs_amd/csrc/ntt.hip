@@ -162,7 +162,7 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
             d_rowinc = (uint32_t*)nb.p;
         } else d_rowinc = (uint32_t*)cb.p;
     }
-    // work buffer for the in-place middle passes (the caller's input is never modified); ntt29: 36-byte lazy records
+    // work buffer for the in-place middle passes (the caller's input is never modified); ntt29: 48-byte lazy records
     uint32_t* work = nullptr;
     const size_t rec = use29 ? NTT29_REC : 8;                       // words per work-array element
     if (p > 1) ZK_TRY(ws_get(use29 ? "ntt.work29" : "ntt.work", n * rec * 4 * batch, (void**)&work));

@@ -12,7 +12,9 @@
 //     the loads, the transposed stores and the digit reversal of the last pass are unchanged; stage s (span h = 2^s, from l-1 down to 0)
 //     multiplies the upper half of block `blk` by w_N^(bitrev(blk) 2^s) = U[blk] with U the local twiddle table in bit-reversed order:
 //     lanes read consecutive or identical entries (no bank conflicts, like the jl << (l-1-s) indexing of the DIF form);
-//   * between passes the work array holds the lazy values as 9-word records (36 bytes per element, internal); only the last pass brings
+//   * between passes the work array holds the lazy values as 12-word records (9 limbs + padding: 48 bytes per element, three 16-byte
+//     vector accesses per lane and whole 64-byte sectors per group of four columns — 36-byte records cost nine scattered dword accesses per
+//     lane and ran the middle passes 8x slower); only the last pass brings
 //     every value to the canonical range (reduce29_small: quotient estimate from the top limb, one multiply-subtract pass, <= 3 conditional
 //     subtractions) and writes the reference's 32 bytes.
 // Tile storage in LDS: limb k of element e at plane k (E words per plane): consecutive lanes -> consecutive words, conflict-free.
@@ -22,7 +24,7 @@
 
 namespace zkmi {
 
-constexpr int NTT29_REC = 9;                  // words per element of the work array between passes
+constexpr int NTT29_REC = 12;                 // words per element of the work array between passes (9 limbs + 3 words of padding)
 
 // v (normalised, < 32 r) -> v mod r, canonical limbs
 template <class C> ZK_HD void reduce29_small(Fp29<C>& v) {
@@ -69,18 +71,17 @@ template <class C> ZK_DEV void lds29_put(uint32_t* p, uint32_t stride, uint32_t 
 #pragma unroll
     for (int k = 0; k < 9; k++) p[k * stride + e] = v.l[k];
 }
-// element `i` of an array of 36-byte records (the work array between passes)
+// element `i` of an array of 48-byte records (the work array between passes)
 template <class C> ZK_DEV Fp29<C> rec29_load(const uint32_t* base, uint64_t i) {
+    const uint4* p = reinterpret_cast<const uint4*>(base + i * NTT29_REC);
+    const uint4 a = p[0], b = p[1], c = p[2];
     Fp29<C> r;
-    const uint32_t* p = base + i * NTT29_REC;
-#pragma unroll
-    for (int k = 0; k < 9; k++) r.l[k] = p[k];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = c.x;
     return r;
 }
 template <class C> ZK_DEV void rec29_store(uint32_t* base, uint64_t i, const Fp29<C>& v) {
-    uint32_t* p = base + i * NTT29_REC;
-#pragma unroll
-    for (int k = 0; k < 9; k++) p[k] = v.l[k];
+    uint4* p = reinterpret_cast<uint4*>(base + i * NTT29_REC);
+    p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]); p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]); p[2] = make_uint4(v.l[8], 0u, 0u, 0u);
 }
 // w^e from the split power tables (R'-form packed words): one product, normalised, < 1.1 r
 template <class C> ZK_DEV Fp29<C> ntt29_pow(const NttPassArgs& a, uint64_t e) {
@@ -112,7 +113,7 @@ template <class C, bool ROWMAJOR> ZK_DEV void ntt29_tile_stages(uint32_t* p, uin
     }
 }
 
-// IN_REC / OUT_REC: the input / output array holds 36-byte lazy records (work array) instead of the caller's canonical 32-byte elements
+// IN_REC: the input array holds 48-byte lazy records (the work array; strided passes always write it) instead of the caller's canonical 32-byte elements
 // ---- passes 1 .. p-1 (in place over the FFT digit, columns contiguous in memory) ------------------------------------
 template <class C, bool IN_REC> __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt29_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
