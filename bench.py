@@ -97,7 +97,28 @@ def reference_wasm_baseline():
         return None
     d = json.load(open(f))
     return {"where": f"build container, {d['host']['cpus']} cpus ({d['host']['model']}), Node {d['runs'][0]['node']}; NOT this box",
-            "runs": [{k: r[k] for k in ("log_n", "threads", "ms_per_proof", "proofs_per_s")} for r in d["runs"]], "source": "profiles/r02_ref_wasm_baseline.json"}
+            "runs": [{k: r[k] for k in ("log_n", "threads", "ms_per_proof", "proofs_per_s")} for r in d["runs"]], "source": "profiles/r02_ref_wasm_baseline.json",
+            "note": "measured at 2^14 .. 2^18 only; any 2^20 figure derived from these runs (README / DESIGN: ~0.016 proofs/s on 8 threads) is an extrapolation of n log n + Pippenger work, not a measurement"}
+
+
+def reference_wasm_baseline_plonk(proto, lg):
+    """The reference's own plonk.prove / fflonk.prove (WASM + worker threads), measured in the BUILD container at 2^8 .. 2^12 by
+    tools/ref_wasm_baseline_plonk.js and committed under profiles/; the figure for the bench size is a LINEAR EXTRAPOLATION from the largest
+    measured size and is labelled as such."""
+    f = os.path.join(ROOT, "profiles", "r03_ref_wasm_baseline_plonk.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    runs = [r for r in d["runs"] if r["proto"] == proto]
+    if not runs:
+        return None
+    best = max(runs, key=lambda r: (r["log_n"], r["threads"]))
+    scale = 1 << (lg - best["log_n"])
+    return {"where": f"build container, {d['host']['cpus']} cpus ({d['host']['model']}), Node {best['node']}; NOT this box",
+            "measured": [{k: r[k] for k in ("log_n", "threads", "ms_per_proof")} for r in runs],
+            "extrapolated_proofs_per_s": round(1e3 / (best["ms_per_proof"] * scale), 6),
+            "extrapolation": f"linear x{scale} from the measured 2^{best['log_n']} proof ({best['threads']} threads, {best['ms_per_proof']} ms) - not a measurement at 2^{lg}",
+            "source": "profiles/r03_ref_wasm_baseline_plonk.json"}
 
 
 def cpu_baseline(args, zkey, wtns, log_n_full):
@@ -192,6 +213,9 @@ def bench_plonk(args, rank, world, dist, torch):
                        "curve": "bn128", "log_n": lg, "parallelism": f"replica x{world}"},
             "roofline": roof,
             "public_signal": res["publicSignals"][0][:24] + "..."}
+        if world == 1 and not args.no_cpu_baseline and proto == "fflonk":
+            out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "reference", "sample": "no live CPU leg for FFLONK: see reference_wasm",
+                                   "reference_wasm": reference_wasm_baseline_plonk(proto, lg)}
         if world == 1 and not args.no_cpu_baseline and proto == "plonk":
             # CPU port: the Python restatement of src/plonk_prove.js (oracle/plonk_oracle.py, pure-Python field loops, 1 thread) on a
             # small valid key, scaled linearly — the reference's own PLONK prover spends most of its time in single-threaded JS loops too
@@ -212,7 +236,7 @@ def bench_plonk(args, rank, world, dist, torch):
             key_s.release()
             out["cpu_baseline"] = {"value": 1.0 / (dt * (1 << (lg - slg))), "unit": "proofs/s", "cores": 1, "kind": "port",
                                    "sample": f"one PLONK proof at 2^{slg} constraints by oracle/plonk_oracle.py (pure Python, 1 thread, {dt:.1f} s), scaled linearly x{1 << (lg - slg)}",
-                                   "parity_on_sample": bool(got["proof"] == ref_proof)}
+                                   "parity_on_sample": bool(got["proof"] == ref_proof), "reference_wasm": reference_wasm_baseline_plonk(proto, lg)}
         out["box_calibration"] = box_calibration(zkmi.lib())
         drain_c_stdout_to_stderr()
         print(json.dumps(out), flush=True)
