@@ -433,13 +433,116 @@ template <class C, class Acc> ZK_HD void store_xyzz29_lds(uint32_t* dst, const A
 #pragma unroll 1
     for (int cdn = 0; cdn < 4; cdn++) { A.get(cdn, v); store_r256(dst + cdn * 2 * N, v.c0); store_r256(dst + cdn * 2 * N + N, v.c1); }
 }
-// G2 accumulation over an R'-form window table, accumulators in LDS: BN254 256 lanes per block (288 bytes per lane: two blocks per CU),
-// BLS12-381 128 lanes per block with packed accumulators (384 bytes per lane: three blocks per CU)
+
+// ---- the same accumulation with a JACOBIAN accumulator (X, Y, Z: x = X / Z^2, y = Y / Z^3) for 14-limb moduli --------------------------
+// The XYZZ accumulator of an Fq2 point is 4 x 2 x 12 packed words = 384 bytes per lane: three 128-lane blocks per CU, 1.5 waves per SIMD.
+// Three coordinates are 288 bytes: FOUR blocks, two waves per SIMD on every SIMD — where a dependent chain of 14-limb products runs at
+// 73 G/s instead of the 59 G/s average of a 2 + 1 split (tools/fieldbench29, profiles/r03_fieldbench29.txt). The price is one squaring:
+// 8M + 3S (Z^2 first) instead of 8M + 2S, +7 % multiply-accumulates. Coordinates in LDS slots 0 = X, 1 = Y, 2 = Z.
+//   ZZ = Z1^2, ZZZ = Z1 ZZ, U2 = x2 ZZ, S2 = y2 ZZZ, H = U2 - X1, R = S2 - Y1, HH = H^2, HHH = H HH, V = X1 HH,
+//   X3 = R^2 - HHH - 2 V, Y3 = R (V - X3) - Y1 HHH, Z3 = Z1 H
+// Invariants (units of p, per component): X <= 8.4, Y <= 3.8, Z <= 1.1, all normalised. q.x canonical, q.y <= 2. Offsets as in madd29_lds.
+// requery(qx, qy): fetches q again for the rare doubling branch — q is dead after S2 on the main path, which frees 56 registers at the
+// point where the live set peaks (H, R, the prefetched next point, a product's scratch)
+template <class C, class Acc, class Rq> ZK_HD void madd29_jac_lds(const Acc& A, bool& inf, const F2x<C>& qx_in, const F2x<C>& qy_in, Rq requery) {
+    F2x<C> t;
+    const F2x<C>&qx = qx_in, &qy = qy_in;
+    if (inf) {
+        A.put(0, qx); A.put(1, qy);
+        t.c0 = one29<C>(); t.c1 = zero29<C>();
+        A.put(2, t);
+        inf = false;
+        return;
+    }
+    A.get(2, t);
+    const F2x<C> ZZ = f2sqr<C, 2>(t);                                                   // <= 2.1 (second component: 2 a0 a1)
+    ZK_SFENCE();
+    const Fp29<C> nZZ1 = neg29<C, 3>(ZZ.c1);
+    const F2x<C> ZZZ = f2mul(t, ZZ, nZZ1);                                              // <= 1.1
+    ZK_SFENCE();
+    const F2x<C> U2 = f2mul(qx, ZZ, nZZ1);                                              // <= 1.1
+    ZK_SFENCE();
+    A.get(0, t);
+    F2x<C> H = f2sub<C, 9>(U2, t); f2norm(H);                                           // X <= 8.4 < 9;  H <= 10.1
+    const F2x<C> S2 = f2mul(qy, ZZZ, neg29<C, 2>(ZZZ.c1));                              // <= 1.1
+    ZK_SFENCE();
+    A.get(1, t);
+    F2x<C> R = f2sub<C, 4>(S2, t); f2norm(R);                                           // Y <= 3.8 < 4;  R <= 5.1
+    if (f2zero(H)) {
+        if (f2zero(R)) {
+            // acc = 2 q (mdbl-2008-s-1, a = 0): XYZZ (X3, Y3, U^2, U^3) is the Jacobian point (X3, Y3, Z = U), U = 2 y
+            F2x<C> qx, qy;
+            requery(qx, qy);
+            F2x<C> U{add29(qy.c0, qy.c0), add29(qy.c1, qy.c1)}; f2norm(U);             // <= 4
+            const F2x<C> V = f2sqr<C, 5>(U);                                            // <= 2.2
+            const Fp29<C> nV1 = neg29<C, 3>(V.c1);
+            const F2x<C> W = f2mul(U, V, nV1), S = f2mul(qx, V, nV1);                   // <= 1.2
+            const F2x<C> xx = f2sqr<C, 2>(qx);                                          // <= 2.1
+            F2x<C> M{add29(add29(xx.c0, xx.c0), xx.c0), add29(add29(xx.c1, xx.c1), xx.c1)}; f2norm(M);      // <= 6.1
+            F2x<C> X3 = f2sub<C, 2>(f2sub<C, 2>(f2sqr<C, 7>(M), S), S); f2norm(X3);    // <= 2.5 + 4 = 6.5
+            F2x<C> Tt = f2sub<C, 7>(S, X3); f2norm(Tt);                                 // <= 8.2
+            const F2x<C> MT = f2mul(M, Tt, neg29<C, 9>(Tt.c1)), Wy = f2mul(W, qy, neg29<C, 3>(qy.c1));       // <= 1.7, 1.1
+            F2x<C> Y3 = f2sub<C, 2>(MT, Wy); f2norm(Y3);                                // <= 3.7
+            A.put(0, X3); A.put(1, Y3); A.put(2, U);
+        } else inf = true;
+        return;
+    }
+    const F2x<C> HH = f2sqr<C, 11>(H);                                                  // <= 3.5
+    ZK_SFENCE();
+    const Fp29<C> nHH1 = neg29<C, 4>(HH.c1);
+    const F2x<C> HHH = f2mul(H, HH, nHH1);                                              // <= 1.5
+    ZK_SFENCE();
+    A.get(2, t); A.put(2, f2mul(t, H, neg29<C, 11>(H.c1)));                             // Z3 = Z1 H  <= 1.1
+    ZK_SFENCE();
+    A.get(0, t);
+    const F2x<C> V = f2mul(t, HH, nHH1);                                                // <= 1.4
+    ZK_SFENCE();
+    F2x<C> X3 = f2sub<C, 2>(f2sub<C, 2>(f2sub<C, 2>(f2sqr<C, 6>(R), HHH), V), V); f2norm(X3);     // <= 2.4 + 6 = 8.4
+    A.put(0, X3);
+    ZK_SFENCE();
+    F2x<C> Tq = f2sub<C, 9>(V, X3); f2norm(Tq);                                         // <= 10.4
+    // Y3 = Tq R - Y1 HHH as two 2-product sums per component (see madd29_lds: the split form, half the live operands)
+    const Fp29<C> nR1 = neg29<C, 6>(R.c1);
+    const F2x<C> TR{mul29_2(Tq.c0, R.c0, Tq.c1, nR1), mul29_2(Tq.c0, R.c1, Tq.c1, R.c0)};         // <= (53 + 62.4) / 169 + 1 = 1.7
+    ZK_SFENCE();
+    const Fp29<C> nHHH0 = neg29<C, 2>(HHH.c0), nHHH1 = neg29<C, 2>(HHH.c1);
+    A.get(1, t);
+    F2x<C> Y3;
+    Y3.c0 = add29(TR.c0, mul29_2(t.c0, nHHH0, t.c1, HHH.c1));                           // <= 1.7 + 1.1
+    Y3.c1 = add29(TR.c1, mul29_2(t.c0, nHHH1, t.c1, nHHH0));
+    f2norm(Y3);
+    A.put(1, Y3);
+}
+// Jacobian (X, Y, Z) parked in LDS -> the XYZZ words of the bucket arrays: ZZ = Z^2, ZZZ = Z ZZ (once per lane)
+template <class C, class Acc> ZK_HD void store_jac29_lds(uint32_t* dst, const Acc& A, bool inf) {
+    constexpr int N = C::N;
+    if (inf) {
+#pragma unroll
+        for (int i = 0; i < 2 * N; i++) reinterpret_cast<uint4*>(dst)[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    F2x<C> v;
+    A.get(0, v); store_r256(dst, v.c0); store_r256(dst + N, v.c1);
+    A.get(1, v); store_r256(dst + 2 * N, v.c0); store_r256(dst + 3 * N, v.c1);
+    A.get(2, v);
+    const F2x<C> ZZ = f2sqr<C, 2>(v);
+    const F2x<C> ZZZ = f2mul(v, ZZ, neg29<C, 3>(ZZ.c1));
+    store_r256(dst + 4 * N, ZZ.c0); store_r256(dst + 5 * N, ZZ.c1);
+    store_r256(dst + 6 * N, ZZZ.c0); store_r256(dst + 7 * N, ZZZ.c1);
+}
+// G2 accumulation over an R'-form window table, accumulators in LDS: BN254 256 lanes per block, XYZZ accumulators as they are (288 bytes per
+// lane: two blocks per CU); BLS12-381 128 lanes per block, packed JACOBIAN accumulators (288 bytes per lane: four blocks per CU)
 template <class C> struct Accum29G2 {
     static constexpr int T = MsmAccumBlock<Fp2<C>>::value;
-    static constexpr bool PACK = C::N > 8;
+    static constexpr bool PACK = C::N > 8, JAC = PACK;
     typedef LdsAcc29<C, T, PACK> Acc;
-    static constexpr size_t lds_bytes = (size_t)T * 8 * Acc::EW * 4;
+    static constexpr size_t lds_bytes = (size_t)T * (JAC ? 6 : 8) * Acc::EW * 4;
+    template <class A, class Rq> ZK_HD static void madd(const A& acc, bool& inf, const F2x<C>& qx, const F2x<C>& qy, Rq requery) {
+        if constexpr (JAC) madd29_jac_lds<C>(acc, inf, qx, qy, requery); else madd29_lds<C>(acc, inf, qx, qy);
+    }
+    template <class A> ZK_HD static void store(uint32_t* dst, const A& acc, bool inf) {
+        if constexpr (JAC) store_jac29_lds<C>(dst, acc, inf); else store_xyzz29_lds<C>(dst, acc, inf);
+    }
 };
 template <class C> __global__ void __launch_bounds__(Accum29G2<C>::T, 2)
 k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ infmask, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts,
@@ -483,6 +586,15 @@ k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict_
         }
         return false;
     };
+    // the current point again, from the table (the rare doubling branch of the Jacobian form asks for it instead of keeping it live)
+    auto regather = [&](uint32_t e, F2x<C>& qx, F2x<C>& qy) {
+        const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)((e & 0x7fffffffu) - skip) * (4 * N));
+        uint4 v[AV];
+#pragma unroll
+        for (int i = 0; i < AV; i++) v[i] = p[i];
+        qx.c0 = unpack29_v<C>(v); qx.c1 = unpack29_v<C>(v + AV / 4); qy.c0 = unpack29_v<C>(v + AV / 2); qy.c1 = unpack29_v<C>(v + 3 * AV / 4);
+        if (e >> 31) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }
+    };
     if constexpr (ZK_G2_PREFETCH(C)) {
         uint32_t e_next = 0;
         Raw r_next;
@@ -493,7 +605,7 @@ k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict_
             have = fetch(e_next, r_next);                           // the next gather is in flight during this addition
             F2x<C> qx{unpack29_v<C>(r.v), unpack29_v<C>(r.v + AV / 4)}, qy{unpack29_v<C>(r.v + AV / 2), unpack29_v<C>(r.v + 3 * AV / 4)};
             if (e >> 31) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }      // 2p - y
-            madd29_lds<C>(A, inf, qx, qy);
+            Accum29G2<C>::madd(A, inf, qx, qy, [&](F2x<C>& x2, F2x<C>& y2) { regather(e, x2, y2); });
         }
     } else {
         uint32_t e;
@@ -501,10 +613,10 @@ k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict_
         while (fetch(e, r)) {
             F2x<C> qx{unpack29_v<C>(r.v), unpack29_v<C>(r.v + AV / 4)}, qy{unpack29_v<C>(r.v + AV / 2), unpack29_v<C>(r.v + 3 * AV / 4)};
             if (e >> 31) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }
-            madd29_lds<C>(A, inf, qx, qy);
+            Accum29G2<C>::madd(A, inf, qx, qy, [&](F2x<C>& x2, F2x<C>& y2) { regather(e, x2, y2); });
         }
     }
-    store_xyzz29_lds<C>(j ? lane_partials + (size_t)lane * (8 * N) : buckets + (size_t)g * (8 * N), A, inf);
+    Accum29G2<C>::store(j ? lane_partials + (size_t)lane * (8 * N) : buckets + (size_t)g * (8 * N), A, inf);
 }
 
 }  // namespace zkmi

@@ -122,8 +122,12 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
     ZK_TRY((get_plan<C>(curve, L, inverse, &P)));
     const int p = P->n_pass;
     // pre-scale row tables: rowinc_i[j] = (i == 0 ? first : 1) * inc^(j*S_i)
-    // ZKMI_NTT29=0: the r02 passes on saturated 32-bit limbs (ntt.cuh) instead of the 9 x 29-bit ones (ntt29.cuh); A/B switch
-    static const bool use29 = !(getenv("ZKMI_NTT29") && atoi(getenv("ZKMI_NTT29")) == 0);
+    // ZKMI_NTT29=1: the passes on 9 x 29-bit limbs (ntt29.cuh) instead of the saturated 32-bit ones (ntt.cuh). Built and measured in r03
+    // (profiles/NOTES.md): bit-identical, and NOT faster — 2^20 0.147 vs 0.149 ms, in-proof chain 1.07-1.25 vs 1.07-1.18 ms on the same box,
+    // 2^24 chain 22.2 vs 20.9 ms: a pass is bound by instruction issue INCLUDING its LDS traffic, and nine 4-byte limb planes cost 45 LDS
+    // instructions per butterfly where two 16-byte planes cost 10, which eats what the cheaper product (207 vs ~290 instructions) saves.
+    // The 32-bit passes stay the default; the 29-bit ones are kept behind this switch with their own parity test.
+    static const bool use29 = getenv("ZKMI_NTT29") && atoi(getenv("ZKMI_NTT29")) == 1;
     uint32_t* d_rowinc = nullptr;
     size_t rowoff[4] = {0, 0, 0, 0};
     if (first) {

@@ -14,6 +14,7 @@ import synth
 from test_oracle_golden import load, raw, msm_inputs, _Q
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CURVES = ["bn128", "bls12381"]
 sha = lambda b: hashlib.sha256(bytes(b)).hexdigest()
 
@@ -58,6 +59,31 @@ def test_ntt_all_sizes_vs_oracle(zk, name):
         x = synth.elems(0x1000 + lg, 1 << lg)
         assert np.array_equal(cv.Fr.fft(x), O.ntt(c, x)), f"fft 2^{lg}"
         assert np.array_equal(cv.Fr.ifft(x), O.ntt(c, x, True)), f"ifft 2^{lg}"
+
+
+def test_ntt29_passes_opt_in_parity():
+    """The NTT passes on 9 x 29-bit limbs (csrc/ntt29.cuh; opt-in, ZKMI_NTT29=1 — measured no faster than the 32-bit passes in r03): the same
+    bytes as the oracle for every size, both curves, forward / inverse / fused pre-scale, in a process of its own (the switch is read once)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path[:0] = [%r, %r]\n"
+        "import oracle_lib as O, synth, snarkjs_amd\n"
+        "for name in ('bn128', 'bls12381'):\n"
+        "    c, cv = O.CURVE_ID[name], snarkjs_amd.get_curve_from_name(name)\n"
+        "    for lg in list(range(0, 19)) + [20]:\n"
+        "        x = synth.elems(0x2900 + lg, 1 << lg)\n"
+        "        if lg <= 18:\n"
+        "            assert np.array_equal(cv.Fr.fft(x), O.ntt(c, x)), ('fft', name, lg)\n"
+        "            assert np.array_equal(cv.Fr.ifft(x), O.ntt(c, x, True)), ('ifft', name, lg)\n"
+        "        else:\n"
+        "            assert np.array_equal(cv.Fr.ifft(cv.Fr.fft(x)), x), ('roundtrip', name, lg)\n"
+        "    x = synth.elems(0x2999, 1 << 13)\n"
+        "    first, inc = O.fr_e(c, 7), O.fr_e(c, 11)\n"
+        "    assert np.array_equal(cv.Fr.fft(cv.Fr.batchApplyKey(x, first, inc)), O.ntt(c, O.apply_key(c, x, first, inc)))\n"
+        "print('ntt29 ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, ZKMI_NTT29="1"))
+    assert r.returncode == 0 and "ntt29 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("name", CURVES)

@@ -86,7 +86,7 @@ template <class C> static std::string run(const std::string& op, const std::vect
         // G2: a sequence of mixed additions into one LDS-parked accumulator (T = 1: the "LDS" is a host array), packed or not as the kernel
         // has it for this curve. in: count, then count x (neg, x.c0, x.c1, y.c0, y.c1) canonical R'-form limbs; out: inf + 8 N words (store_xyzz29_lds)
         typedef LdsAcc29<C, 1, Accum29G2<C>::PACK> Acc;
-        std::vector<uint32_t> lds(8 * Acc::EW, 0xdeadbeefu);
+        std::vector<uint32_t> lds(Accum29G2<C>::lds_bytes / 4 / Accum29G2<C>::T, 0xdeadbeefu);      // exactly what the kernel gives a lane
         const Acc A{lds.data()};
         bool inf = true;
         const uint32_t cnt = v.at(at++);
@@ -95,10 +95,10 @@ template <class C> static std::string run(const std::string& op, const std::vect
             F2x<C> qx, qy;
             qx.c0 = rd<C>(v, at); qx.c1 = rd<C>(v, at); qy.c0 = rd<C>(v, at); qy.c1 = rd<C>(v, at);
             if (neg) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }
-            madd29_lds<C>(A, inf, qx, qy);
+            Accum29G2<C>::madd(A, inf, qx, qy, [&](F2x<C>& x2, F2x<C>& y2) { x2 = qx; y2 = qy; });
         }
         alignas(16) uint32_t w[8 * N];
-        store_xyzz29_lds<C>(w, A, inf);
+        Accum29G2<C>::store(w, A, inf);
         o.push_back(inf ? 1u : 0u);
         for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
     }
