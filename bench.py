@@ -25,7 +25,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU instructions of one mixed addition, main path of the shipped code objects (tools/isa_counts.py -> profiles/r03_isa_counts.md):
 # k_msm_accum29 / k_msm_accum29_g2 per curve
-VALU_PER_ADD = {"bn128": {"g1": 2238, "g2": 5944}, "bls12381": {"g1": 5012, "g2": 13373}}
+VALU_PER_ADD = {"bn128": {"g1": 2238, "g2": 5944}, "bls12381": {"g1": 5012, "g2": 14902}}
 VALU_ISSUE_PEAK_G = 614.4                      # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave instruction
 # measured Montgomery-multiply ceilings of the chip, Gmul/s at 8 waves per SIMD, in the limb form the accumulation kernels of the curve use
 # (tools/fieldbench29 on the library's own mul29): BN254 Fq 9 x 29-bit limbs, BLS12-381 Fq 14 x 28-bit limbs; the saturated 32-bit forms they
@@ -455,7 +455,7 @@ def main():
         units = {0: m, 1: m, 2: m, 3: m - zk["nPublic"] - 1, 4: zk["domainSize"]}[dom]
         alg_bytes = names[dom][1] * units                      # B/term (affine base + 32-B scalar) x terms
         achieved = alg_bytes / (acc[dom] * 1e-3) / 1e9
-        # HBM bytes of that launch from separate rocprofv3 --pmc passes of THIS workload (tools/pmc_to_traffic.py tags the file);
+        # HBM bytes of that launch from separate rocprofv3 --pmc passes of THIS workload (tools/publish_profiles.py tags the file);
         # a file collected on another workload (size / curve / B density) is not used: traffic stays null
         traffic = None
         wl_tag = f"groth16:{args.curve}:2^{lg}:b_zero_every={args.b_zero_every}:{args.witness}"

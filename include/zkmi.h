@@ -74,7 +74,8 @@ int zkmi_memset_dev(void* d_dst, int value, size_t bytes);
  * g1m_/g2m_multiexpAffine_chunk @75966).  group = 1 | 2.  n bases of 2*group*n8q bytes, n scalars of scalar_bytes.
  * base_cache_key != 0 ALLOWS the library to keep these bases resident (zkey sections / SRS slices are static per circuit,
  * src/groth16_prove.js:84-100); its value carries no identity. The cache is content-addressed: the library hashes the whole base
- * buffer on every call (128 bits per 64 KiB chunk), so a buffer that differs anywhere never re-uses another buffer's table. The
+ * buffer on every call (128 bits per 64 KiB chunk, a fast NON-cryptographic mix: accidental changes — another zkey, an edited section —
+ * are told apart, deliberately constructed colliding buffers are not; callers that take bases from an untrusted party pass key 0). The
  * pre-computed window table of a buffer is built on its SECOND sight, an MSM over a prefix of a resident buffer re-uses its
  * table, tables that cannot fit are never built (plain bases instead), and least-recently-used tables are evicted under a
  * byte budget (env ZKMI_BASE_CACHE_BYTES, default 64 GiB). zkmi_release_bases drops every cached table.

@@ -675,6 +675,13 @@ int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_
         if (R->curve != zkey->curve || R->n_vars != zkey->n_vars || R->n_public != zkey->n_public || R->domain != zkey->domain_size ||
             zkey->coeffs_len < 4 || (size_t)R->n_coef != (zkey->coeffs_len - 4) / 44)
             return fail(ZKMI_ERR_INVALID, "groth16_prove: the resident key under this cache key belongs to a different circuit (release it first)");
+        // same shape is not the same key: another phase-2 contribution of the same circuit has other delta / bases. The header points are cheap
+        // to compare and change with every contribution
+        const size_t g1b = 2 * (size_t)n8q_of(R->curve), g2b = 2 * g1b;
+        if (!zkey->vk_alpha_1 || !zkey->vk_beta_1 || !zkey->vk_beta_2 || !zkey->vk_delta_1 || !zkey->vk_delta_2 || memcmp(R->vk_alpha_1.data(), zkey->vk_alpha_1, g1b) ||
+            memcmp(R->vk_beta_1.data(), zkey->vk_beta_1, g1b) || memcmp(R->vk_beta_2.data(), zkey->vk_beta_2, g2b) || memcmp(R->vk_delta_1.data(), zkey->vk_delta_1, g1b) ||
+            memcmp(R->vk_delta_2.data(), zkey->vk_delta_2, g2b))
+            return fail(ZKMI_ERR_INVALID, "groth16_prove: the resident key under this cache key is another key of the same circuit shape (different alpha / beta / delta: release it first)");
     }
     G16Key* K = g16_find(k);
     if (witness_len != (size_t)K->n_vars * 32) {

@@ -117,6 +117,15 @@ template <class C> ZK_HD bool xyzz29_words_inf(const uint32_t* src) {
 }
 
 
+// the same for an Fq2 point (ZZ = words 4N .. 6N of 8N)
+template <class C> ZK_HD bool xyzz29_words_inf_g2(const uint32_t* src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src + 4 * C::N);
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < C::N / 2; i++) { const uint4 z = q[i]; nz |= z.x | z.y | z.z | z.w; }
+    return nz == 0;
+}
+
 // one base-field element of a window table: canonical R-form -> canonical R'-form (x * 2^5 mod p, 2^8 for BLS12-381), in place; all-zero
 // stays all-zero
 template <class C> __global__ void __launch_bounds__(256) k_table_to_r29(uint32_t* __restrict__ table, size_t n_elems) {
@@ -422,7 +431,7 @@ template <class C, class Acc> ZK_HD void madd29_lds(const Acc& A, bool& inf, con
     }
     A.put(1, Y3);
 }
-template <class C, class Acc> ZK_HD void store_xyzz29_lds(uint32_t* dst, const Acc& A, bool inf) {
+template <class C, class Acc, bool KEEP29 = false> ZK_HD void store_xyzz29_lds(uint32_t* dst, const Acc& A, bool inf) {
     constexpr int N = C::N;
     if (inf) {
 #pragma unroll
@@ -431,7 +440,7 @@ template <class C, class Acc> ZK_HD void store_xyzz29_lds(uint32_t* dst, const A
     }
     F2x<C> v;
 #pragma unroll 1
-    for (int cdn = 0; cdn < 4; cdn++) { A.get(cdn, v); store_r256(dst + cdn * 2 * N, v.c0); store_r256(dst + cdn * 2 * N + N, v.c1); }
+    for (int cdn = 0; cdn < 4; cdn++) { A.get(cdn, v); store_r256<C, KEEP29>(dst + cdn * 2 * N, v.c0); store_r256<C, KEEP29>(dst + cdn * 2 * N + N, v.c1); }
 }
 
 // ---- the same accumulation with a JACOBIAN accumulator (X, Y, Z: x = X / Z^2, y = Y / Z^3) for 14-limb moduli --------------------------
@@ -514,7 +523,7 @@ template <class C, class Acc, class Rq> ZK_HD void madd29_jac_lds(const Acc& A, 
     A.put(1, Y3);
 }
 // Jacobian (X, Y, Z) parked in LDS -> the XYZZ words of the bucket arrays: ZZ = Z^2, ZZZ = Z ZZ (once per lane)
-template <class C, class Acc> ZK_HD void store_jac29_lds(uint32_t* dst, const Acc& A, bool inf) {
+template <class C, class Acc, bool KEEP29 = false> ZK_HD void store_jac29_lds(uint32_t* dst, const Acc& A, bool inf) {
     constexpr int N = C::N;
     if (inf) {
 #pragma unroll
@@ -522,13 +531,13 @@ template <class C, class Acc> ZK_HD void store_jac29_lds(uint32_t* dst, const Ac
         return;
     }
     F2x<C> v;
-    A.get(0, v); store_r256(dst, v.c0); store_r256(dst + N, v.c1);
-    A.get(1, v); store_r256(dst + 2 * N, v.c0); store_r256(dst + 3 * N, v.c1);
+    A.get(0, v); store_r256<C, KEEP29>(dst, v.c0); store_r256<C, KEEP29>(dst + N, v.c1);
+    A.get(1, v); store_r256<C, KEEP29>(dst + 2 * N, v.c0); store_r256<C, KEEP29>(dst + 3 * N, v.c1);
     A.get(2, v);
     const F2x<C> ZZ = f2sqr<C, 2>(v);
     const F2x<C> ZZZ = f2mul(v, ZZ, neg29<C, 3>(ZZ.c1));
-    store_r256(dst + 4 * N, ZZ.c0); store_r256(dst + 5 * N, ZZ.c1);
-    store_r256(dst + 6 * N, ZZZ.c0); store_r256(dst + 7 * N, ZZZ.c1);
+    store_r256<C, KEEP29>(dst + 4 * N, ZZ.c0); store_r256<C, KEEP29>(dst + 5 * N, ZZ.c1);
+    store_r256<C, KEEP29>(dst + 6 * N, ZZZ.c0); store_r256<C, KEEP29>(dst + 7 * N, ZZZ.c1);
 }
 // G2 accumulation over an R'-form window table, accumulators in LDS: BN254 256 lanes per block, XYZZ accumulators as they are (288 bytes per
 // lane: two blocks per CU); BLS12-381 128 lanes per block, packed JACOBIAN accumulators (288 bytes per lane: four blocks per CU)
@@ -540,14 +549,14 @@ template <class C> struct Accum29G2 {
     template <class A, class Rq> ZK_HD static void madd(const A& acc, bool& inf, const F2x<C>& qx, const F2x<C>& qy, Rq requery) {
         if constexpr (JAC) madd29_jac_lds<C>(acc, inf, qx, qy, requery); else madd29_lds<C>(acc, inf, qx, qy);
     }
-    template <class A> ZK_HD static void store(uint32_t* dst, const A& acc, bool inf) {
-        if constexpr (JAC) store_jac29_lds<C>(dst, acc, inf); else store_xyzz29_lds<C>(dst, acc, inf);
+    template <bool KEEP29, class A> ZK_HD static void store(uint32_t* dst, const A& acc, bool inf) {
+        if constexpr (JAC) store_jac29_lds<C, A, KEEP29>(dst, acc, inf); else store_xyzz29_lds<C, A, KEEP29>(dst, acc, inf);
     }
 };
 template <class C> __global__ void __launch_bounds__(Accum29G2<C>::T, 2)
 k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ infmask, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts,
                  const uint32_t* __restrict__ starts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub,
-                 const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials) {
+                 const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials, int bucket_r29) {
     constexpr int N = C::N, AV = N;                                 // 16-byte vectors per affine G2 table entry (4 N words)
     typedef typename Accum29G2<C>::Acc Acc;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_acc29[];
@@ -616,7 +625,146 @@ k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict_
             Accum29G2<C>::madd(A, inf, qx, qy, [&](F2x<C>& x2, F2x<C>& y2) { regather(e, x2, y2); });
         }
     }
-    Accum29G2<C>::store(j ? lane_partials + (size_t)lane * (8 * N) : buckets + (size_t)g * (8 * N), A, inf);
+    // lane partials go to the trees in the reference's R-form; finished buckets stay in R'-form when the row / column sums run on the same limbs
+    if (j) Accum29G2<C>::template store<false>(lane_partials + (size_t)lane * (8 * N), A, inf);
+    else if (bucket_r29) Accum29G2<C>::template store<true>(buckets + (size_t)g * (8 * N), A, inf);
+    else Accum29G2<C>::template store<false>(buckets + (size_t)g * (8 * N), A, inf);
+}
+
+// ---- row / column sums of the Fq2 bucket reduction on unsaturated limbs ------------------------------------------------------------------
+// acc (XYZZ over Fq2, parked in LDS) = 2 acc (dbl-2008-s-1, a = 0): the rare equal-points branch of padd29_lds
+template <class C, class Acc> ZK_HD void dbl29_lds(const Acc& A) {
+    F2x<C> t;
+    A.get(1, t);
+    F2x<C> U{add29(t.c0, t.c0), add29(t.c1, t.c1)}; f2norm(U);                          // Y <= 3.8: U <= 7.6
+    const F2x<C> V = f2sqr<C, 8>(U);                                                    // <= 2.5
+    const Fp29<C> nV1 = neg29<C, 3>(V.c1);
+    const F2x<C> W = f2mul(U, V, nV1);                                                  // <= 1.3
+    const Fp29<C> nY0 = neg29<C, 4>(t.c0), nY1 = neg29<C, 4>(t.c1);
+    const F2x<C> nWY{mul29_2(W.c0, nY0, W.c1, t.c1), mul29_2(W.c0, nY1, W.c1, nY0)};    // - W Y1 <= 1.1
+    A.get(0, t);
+    const F2x<C> S = f2mul(t, V, nV1);                                                  // X1 V <= 1.3
+    const F2x<C> xx = f2sqr<C, 9>(t);                                                   // <= 2.9
+    F2x<C> M{add29(add29(xx.c0, xx.c0), xx.c0), add29(add29(xx.c1, xx.c1), xx.c1)}; f2norm(M);      // <= 8.6
+    F2x<C> X3 = f2sub<C, 2>(f2sub<C, 2>(f2sqr<C, 9>(M), S), S); f2norm(X3);             // <= 2.9 + 4 = 6.9
+    A.put(0, X3);
+    F2x<C> Tt = f2sub<C, 8>(S, X3); f2norm(Tt);                                         // <= 9.3
+    const F2x<C> MT = f2mul(M, Tt, neg29<C, 10>(Tt.c1));                                // <= 2
+    F2x<C> Y3{add29(MT.c0, nWY.c0), add29(MT.c1, nWY.c1)}; f2norm(Y3);                  // <= 3.1
+    A.put(1, Y3);
+    A.get(2, t); A.put(2, f2mul(t, V, nV1));
+    A.get(3, t); A.put(3, f2mul(t, W, neg29<C, 2>(W.c1)));
+}
+// acc (XYZZ over Fq2, parked in LDS) += p for a general XYZZ point whose coordinates are fetched on demand: ld(k, F2x&), k = 0..3 = X, Y, ZZ,
+// ZZZ (add-2008-s, 12M + 2S in Fq2). Invariants of madd29_lds for the accumulator (X <= 8.4, Y <= 3.8, ZZ, ZZZ <= 1.1, normalised); p within
+// the same bounds (a point just unpacked from R'-form words is canonical).
+template <class C, class Acc, class Ld> ZK_HD void padd29_lds(const Acc& A, bool& inf, Ld ld) {
+    F2x<C> t, u;
+    if (inf) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) { ld(k, u); A.put(k, u); }
+        inf = false;
+        return;
+    }
+    // Ordered for few live values (the 14-limb instance holds 28 registers per Fq2 element): S1 = Y1 ZZZ2 is formed twice — once for R, once
+    // for Y3 at the very end, while Y1 still sits in its slot — instead of being carried across the whole addition (one Fq2 product of 15).
+    ld(2, u); A.get(0, t);
+    const F2x<C> U1 = f2mul(t, u, neg29<C, 2>(u.c1));                                   // X1 ZZ2 <= 1.2
+    ZK_SFENCE();
+    ld(0, u); A.get(2, t);
+    F2x<C> P = f2sub<C, 2>(f2mul(u, t, neg29<C, 2>(t.c1)), U1); f2norm(P);              // X2 ZZ1 - U1 <= 3.2
+    ZK_SFENCE();
+    ld(3, u); A.get(1, t);
+    F2x<C> R = f2mul(t, u, neg29<C, 2>(u.c1));                                          // S1 = Y1 ZZZ2 <= 1.1
+    ZK_SFENCE();
+    ld(1, u); A.get(3, t);
+    R = f2sub<C, 2>(f2mul(u, t, neg29<C, 2>(t.c1)), R); f2norm(R);                      // Y2 ZZZ1 - S1 <= 3.2
+    ZK_SFENCE();
+    if (f2zero(P)) {
+        if (f2zero(R)) dbl29_lds<C>(A); else inf = true;
+        return;
+    }
+    const F2x<C> PP = f2sqr<C, 4>(P);                                                   // <= 1.2
+    ZK_SFENCE();
+    const Fp29<C> nPP1 = neg29<C, 2>(PP.c1);
+    const F2x<C> Q = f2mul(U1, PP, nPP1);                                               // <= 1.1
+    ZK_SFENCE();
+    const F2x<C> PPP = f2mul(P, PP, nPP1);                                              // <= 1.1
+    ZK_SFENCE();
+    ld(2, u); A.get(2, t);
+    t = f2mul(t, u, neg29<C, 2>(u.c1));
+    ZK_SFENCE();
+    A.put(2, f2mul(t, PP, nPP1));                                                       // ZZ3 = ZZ1 ZZ2 PP
+    ZK_SFENCE();
+    const Fp29<C> nPPP1 = neg29<C, 2>(PPP.c1);
+    ld(3, u); A.get(3, t);
+    t = f2mul(t, u, neg29<C, 2>(u.c1));
+    ZK_SFENCE();
+    A.put(3, f2mul(t, PPP, nPPP1));                                                     // ZZZ3 = ZZZ1 ZZZ2 PPP
+    ZK_SFENCE();
+    F2x<C> Tq = f2sub<C, 2>(f2sub<C, 2>(f2sub<C, 2>(f2sqr<C, 4>(R), PPP), Q), Q); f2norm(Tq);     // X3 <= 1.2 + 6 = 7.2
+    A.put(0, Tq);
+    ZK_SFENCE();
+    Tq = f2sub<C, 8>(Q, Tq); f2norm(Tq);                                                // Q - X3 <= 9.1
+    const Fp29<C> nR1 = neg29<C, 4>(R.c1);
+    const F2x<C> TR{mul29_2(Tq.c0, R.c0, Tq.c1, nR1), mul29_2(Tq.c0, R.c1, Tq.c1, R.c0)};         // <= (29 + 36) / 169 + 1 = 1.4
+    ZK_SFENCE();
+    ld(3, u); A.get(1, t);
+    const F2x<C> S1 = f2mul(t, u, neg29<C, 2>(u.c1));                                   // again: Y1 ZZZ2 (ld(3) is the OPERAND's ZZZ, untouched)
+    ZK_SFENCE();
+    const Fp29<C> nPPP0 = neg29<C, 2>(PPP.c0);
+    F2x<C> Y3;
+    Y3.c0 = add29(TR.c0, mul29_2(S1.c0, nPPP0, S1.c1, PPP.c1));                         // - S1 PPP: <= 1.4 + 1.1
+    Y3.c1 = add29(TR.c1, mul29_2(S1.c0, nPPP1, S1.c1, nPPP0));
+    f2norm(Y3);
+    A.put(1, Y3);
+}
+// XYZZ accumulators for the reduction kernels: the accumulation's lane layout, four coordinates
+template <class C> struct Reduce29G2 {
+    static constexpr int T = MsmAccumBlock<Fp2<C>>::value;
+    static constexpr bool PACK = C::N > 8;
+    typedef LdsAcc29<C, T, PACK> Acc;
+    static constexpr size_t lds_bytes = (size_t)T * 8 * Acc::EW * 4;
+};
+// one wave per row / column sum over R'-form Fq2 buckets (see k_msm_rowcol_wave29); the sums leave in the reference's R-form
+template <class C> __global__ void __launch_bounds__(Reduce29G2<C>::T, 2)
+k_msm_rowcol_wave29_g2(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, uint32_t cbits, uint32_t* __restrict__ out) {
+    constexpr int N = C::N, PW = 8 * N, T = Reduce29G2<C>::T;
+    typedef typename Reduce29G2<C>::Acc Acc;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ uint32_t inf_s[T];
+    const uint32_t Cn = 1u << cbits, R = 1u << rbits;
+    const uint32_t t = threadIdx.x, sub = t & 63u;
+    const size_t n_out = (size_t)rb.njobs * W * 2 * Cn;
+    const Acc A{lds + t};
+    for (size_t blk = blockIdx.x; blk * (T / 64) < n_out; blk += gridDim.x) {
+        const size_t gw = blk * (T / 64) + (t >> 6);             // sum index: ((job*W + w)*2 + kind)*C + i
+        const bool valid = gw < n_out;
+        const uint32_t i = (uint32_t)(gw & (Cn - 1)), kind = (uint32_t)(gw >> cbits) & 1u;
+        const size_t jw = gw >> (cbits + 1);
+        const uint32_t w = (uint32_t)(jw % W), job = valid ? (uint32_t)(jw / W) : 0u;
+        const uint32_t* bk = rb.buckets[job];
+        const uint32_t* cn = rb.counts[job];
+        const uint32_t cnt = !valid ? 0u : (kind ? R : ((i < R) ? Cn : 0u));
+        bool inf = true;
+        for (uint32_t e = sub; e < cnt; e += 64) {
+            const size_t g = (size_t)w * nb + (kind ? ((size_t)e << cbits) + i : ((size_t)i << cbits) + e);
+            const uint32_t* src = bk + g * PW;
+            if (cn[g] && !xyzz29_words_inf_g2<C>(src))
+                padd29_lds<C>(A, inf, [&](int k, F2x<C>& v) { v.c0 = load29_packed<C>(src + k * 2 * N); v.c1 = load29_packed<C>(src + k * 2 * N + N); });
+        }
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            inf_s[t] = inf ? 1u : 0u;
+            __syncthreads();
+            if ((t & (2 * d - 1)) == 0 && !inf_s[t + d]) {
+                const Acc Pn{A.base + d};
+                padd29_lds<C>(A, inf, [&](int k, F2x<C>& v) { Pn.get(k, v); });
+            }
+            __syncthreads();
+        }
+        if (valid && sub == 0) store_xyzz29_lds<C, Acc, false>(out + gw * PW, A, inf);
+        __syncthreads();
+    }
 }
 
 }  // namespace zkmi

@@ -174,10 +174,16 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
             launched = true;
             r29_buckets = into ? into->r29 : (r29_reduce && (sh.c - 1) / 2 >= 6);       // the wave row/column sums need >= 64 buckets per row and column
             const uint32_t* mask = d_infmask ? d_infmask : r29->second;
-            const dim3 grid((unsigned)((pl.lane_bound + 255) / 256));
-            if (into) hipLaunchKernelGGL((k_msm_accum29<C, true>), grid, dim3(256), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
+            // Threads per block. A workgroup is placed only when EVERY one of its waves finds registers: a 256-thread block needs a free slot
+            // on all four SIMDs of a CU. While the Fq2 bucket reduction runs beside it on the auxiliary stream (256-register waves on two of the
+            // four SIMDs), a second 14-limb accumulation block (224 registers per wave) no longer fits and the CU drops from eight to four
+            // accumulation waves (r03 trace: B1 4.5 ms against 2.1 ms for the same work alone); 128-thread blocks still fill the other two SIMDs.
+            static const unsigned acc_t_env = getenv("ZKMI_ACC29_BLOCK") ? (unsigned)atoi(getenv("ZKMI_ACC29_BLOCK")) : 0u;
+            const unsigned AT29 = (acc_t_env == 64 || acc_t_env == 128 || acc_t_env == 256) ? acc_t_env : (Lim29<C>::NL > 9 ? 128u : 256u);
+            const dim3 grid((unsigned)((pl.lane_bound + AT29 - 1) / AT29));
+            if (into) hipLaunchKernelGGL((k_msm_accum29<C, true>), grid, dim3(AT29), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
                                          pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts, (int)r29_buckets);
-            else hipLaunchKernelGGL((k_msm_accum29<C, false>), grid, dim3(256), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
+            else hipLaunchKernelGGL((k_msm_accum29<C, false>), grid, dim3(AT29), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted,
                                     pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts, (int)r29_buckets);
         }
     } else {
@@ -188,8 +194,14 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
             constexpr size_t lds29 = Accum29G2<C>::lds_bytes;              // 4 coordinates x 2 components per lane
             static bool a29 = false;
             if (!a29) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum29_g2<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29)); a29 = true; }
+            // ZKMI_R29_REDUCE_G2 = 1 / 0: the Fq2 buckets stay in R'-form and k_msm_rowcol_wave29_g2 forms the row / column sums on the same limbs
+            // (default: the 14-limb curve, where the 32-bit CIOS Fq2 products of the generic kernel are the slower side by the wider margin)
+            static const int g2r_env = getenv("ZKMI_R29_REDUCE_G2") ? atoi(getenv("ZKMI_R29_REDUCE_G2")) : -1;
+            static const bool wave_ok = !(getenv("ZKMI_ROWCOL_WAVE") && atoi(getenv("ZKMI_ROWCOL_WAVE")) == 0);
+            r29_buckets = wave_ok && (g2r_env < 0 ? Lim29<C>::NL > 9 : g2r_env != 0) && (sh.c - 1) / 2 >= 6;
             hipLaunchKernelGGL((k_msm_accum29_g2<C>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
-                               d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials);
+                               d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials,
+                               (int)r29_buckets);
         }
     }
     if (into && !launched && into->r29) return fail(ZKMI_ERR_INVALID, "msm_accumulate: merge target holds R'-form buckets");
@@ -269,7 +281,7 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
     // ZKMI_ROWCOL_WAVE=0 keeps the staged k_msm_rowcol + k_msm_fold sequence
     static const bool wave_env = !(getenv("ZKMI_ROWCOL_WAVE") && atoi(getenv("ZKMI_ROWCOL_WAVE")) == 0);
     const bool wave_rc = wave_env && rbits >= 6 && cbits >= 6;
-    bool all_r29 = FW <= 12;                                 // G1 (Fq points): R'-form buckets and the row / column sums on the same limbs
+    bool all_r29 = true;                                     // R'-form buckets and the row / column sums on the same limbs
     for (int i = 0; i < njobs; i++) all_r29 = all_r29 && jobs[i]->r29;
     for (int i = 0; i < njobs; i++) if (jobs[i]->r29 != jobs[0]->r29) return fail(ZKMI_ERR_INVALID, "msm_reduce: jobs with different bucket formats");
     if (jobs[0]->r29 && !(all_r29 && wave_rc)) return fail(ZKMI_ERR_UNSUPPORTED, "msm_reduce: R'-form buckets need the wave row/column sums");
@@ -283,6 +295,16 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
             static const int aux_cap29 = getenv("ZKMI_AUX_RC_SUMS") ? atoi(getenv("ZKMI_AUX_RC_SUMS")) : 512;
             if (aux && aux_cap29 > 0) rc_blocks = std::min<size_t>(rc_blocks, (size_t)aux_cap29 / 4);
             hipLaunchKernelGGL((k_msm_rowcol_wave29<C>), dim3((unsigned)rc_blocks), dim3(256), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
+        } else {
+            typedef typename F::Cfg C;
+            constexpr int T = Reduce29G2<C>::T;
+            constexpr size_t lds29 = Reduce29G2<C>::lds_bytes;
+            static bool rc29_attr = false;
+            if (!rc29_attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave29_g2<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29)); rc29_attr = true; }
+            size_t rc_blocks = (n_out + T / 64 - 1) / (T / 64);
+            static const int aux_cap29 = getenv("ZKMI_AUX_RC_SUMS") ? atoi(getenv("ZKMI_AUX_RC_SUMS")) : 512;
+            if (aux && aux_cap29 > 0) rc_blocks = std::min<size_t>(rc_blocks, (size_t)aux_cap29 / (T / 64));
+            hipLaunchKernelGGL((k_msm_rowcol_wave29_g2<C>), dim3((unsigned)rc_blocks), dim3(T), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
         }
     } else if (wave_rc) {
         constexpr int T = MsmRcBlock<F>::value;

@@ -374,6 +374,56 @@ def test_g2_lds_parked_additions(tool, curve):
             assert (K.mul(X, K.inv(ZZ)), K.mul(Y, K.inv(ZZZ))) == want
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_g2_bucket_reduction_additions(tool, curve):
+    """padd29_lds (general XYZZ additions of the Fq2 row / column sums): buckets built by the accumulation path and stored as R'-form words are
+    folded from the words; the sum is then added to itself through the accumulator-to-accumulator form (the tree step; doubling branch)."""
+    F = Form(curve)
+    K = Fp2(F.p)
+    rng = random.Random(0x93 + F.NL)
+    p, N = F.p, F.N
+    Rwi = pow(1 << (32 * N), -1, p)
+
+    def decode(out):
+        inf, w = out[0], out[1:1 + 8 * N]
+        if inf:
+            assert not any(w)
+            return None, out[1 + 8 * N:]
+        v = [sum(w[i * N + k] << (32 * k) for k in range(N)) for i in range(8)]
+        assert all(x < p for x in v)
+        X, Y, ZZ, ZZZ = ((v[2 * i] * Rwi % p, v[2 * i + 1] * Rwi % p) for i in range(4))
+        assert K.mul(K.mul(ZZ, ZZ), ZZ) == K.mul(ZZZ, ZZZ)
+        return (K.mul(X, K.inv(ZZ)), K.mul(Y, K.inv(ZZZ))), out[1 + 8 * N:]
+
+    for trial in range(5):
+        groups = []
+        for g in range(7):
+            groups.append([(((rng.randrange(p), rng.randrange(p)), (rng.randrange(p), rng.randrange(1, p))), rng.random() < 0.5) for _ in range(rng.randrange(1, 5))])
+        groups.insert(2, list(groups[1]))              # the same bucket twice: equal points from different representatives? same build: doubling
+        groups.insert(4, [groups[0][0], (groups[0][0][0], not groups[0][0][1])])      # a bucket that cancels to infinity: skipped
+        for upto in (1, 3, len(groups), len(groups) + 1):
+            gs = list(groups[:upto])
+            want = None                                # the points are random pairs, not points of one curve: the chord / tangent formulas are
+            for grp in gs:                             # still well defined but not associative, so the expectation associates like the kernel does
+                b = None
+                for q, neg in grp:
+                    b = aff_add(K, b, aff_neg(K, q) if neg else q)
+                want = aff_add(K, want, b)
+            if upto == len(groups) + 1:                # one more bucket: the negative of everything so far -> the sum is infinity
+                gs.append([(aff_neg(K, want), False)])
+                want = None
+            req = [len(gs)]
+            for grp in gs:
+                req.append(len(grp))
+                for q, neg in grp:
+                    req += [1 if neg else 0] + F.to29(q[0][0]) + F.to29(q[0][1]) + F.to29(q[1][0]) + F.to29(q[1][1])
+            out = tool("padd2", curve, req)
+            got, rest = decode(out)
+            assert got == want
+            got2, rest = decode(rest)
+            assert got2 == (aff_add(K, want, want) if want is not None else None) and not rest
+
+
 @pytest.mark.parametrize("curve", FR_CURVES)
 def test_ntt_butterfly_and_final_reduction(tool, curve):
     """ntt29.cuh: the decimation-in-time butterfly on lazy values (x + w y, x - w y + 2r) through as many stages as the largest tile has, with the

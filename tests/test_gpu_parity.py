@@ -86,6 +86,21 @@ def test_ntt29_passes_opt_in_parity():
     assert r.returncode == 0 and "ntt29 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+@pytest.mark.skipif(os.environ.get("ZKMI_TEST_NESTED") == "1", reason="already the nested run")
+@pytest.mark.parametrize("env", [{"ZKMI_R29_REDUCE_G2": "1"}, {"ZKMI_R29_REDUCE_G2": "0", "ZKMI_R29_REDUCE": "0"}, {"ZKMI_ACC29_BLOCK": "64"}],
+                         ids=["g2-rowcol29-both-curves", "generic-rowcol-both-groups", "accum-64-thread-blocks"])
+def test_non_default_kernel_variants_parity(env):
+    """The A/B switches select kernels that the default configuration does not run on one curve or the other (Fq2 row / column sums on
+    unsaturated limbs are the default on BLS12-381 only; the generic 32-bit sums are no default any more where a table is resident): the proof
+    and MSM parity tests that reach those kernels are run again in a process with the switch flipped (the switches are read once per process)."""
+    import subprocess
+    import sys
+    sel = "synthetic_vs_oracle or valid_key_proof_verifies or msm_resident_tables or two_proofs_in_flight"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, ZKMI_TEST_NESTED="1", **env))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("name", CURVES)
 def test_ntt_golden_hashes(zk, golden_dir, name):
     d, cv = load(golden_dir, name), curve_of(zk, name)

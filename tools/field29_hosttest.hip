@@ -98,8 +98,45 @@ template <class C> static std::string run(const std::string& op, const std::vect
             Accum29G2<C>::madd(A, inf, qx, qy, [&](F2x<C>& x2, F2x<C>& y2) { x2 = qx; y2 = qy; });
         }
         alignas(16) uint32_t w[8 * N];
-        Accum29G2<C>::store(w, A, inf);
+        Accum29G2<C>::template store<false>(w, A, inf);
         o.push_back(inf ? 1u : 0u);
+        for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
+    }
+    else if (op == "padd2") {
+        // G2 bucket reduction: groups of signed affine points are accumulated into buckets the way the accumulation kernel does and stored as
+        // R'-form words; a reduction accumulator (XYZZ, LDS-parked, the reduction kernel's packing) then folds the buckets from the words
+        // (padd29_lds), and a second one takes the first one twice through the accumulator-to-accumulator form (doubling branch).
+        // in: groups, per group: count, count x (neg, x.c0, x.c1, y.c0, y.c1); out: inf + 8 N R-form words of the sum, the same of its double
+        typedef LdsAcc29<C, 1, Accum29G2<C>::PACK> AccA;
+        typedef LdsAcc29<C, 1, Reduce29G2<C>::PACK> AccR;
+        std::vector<uint32_t> ldsA(Accum29G2<C>::lds_bytes / 4 / Accum29G2<C>::T), ldsR(Reduce29G2<C>::lds_bytes / 4 / Reduce29G2<C>::T, 0xdeadbeefu), ldsD(ldsR.size(), 0xdeadbeefu);
+        const AccR Rr{ldsR.data()}, Dd{ldsD.data()};
+        bool rinf = true, dinf = true;
+        const uint32_t groups = v.at(at++);
+        for (uint32_t gi = 0; gi < groups; gi++) {
+            const AccA A{ldsA.data()};
+            bool inf = true;
+            const uint32_t cnt = v.at(at++);
+            for (uint32_t k = 0; k < cnt; k++) {
+                const bool neg = v.at(at++) != 0;
+                F2x<C> qx, qy;
+                qx.c0 = rd<C>(v, at); qx.c1 = rd<C>(v, at); qy.c0 = rd<C>(v, at); qy.c1 = rd<C>(v, at);
+                if (neg) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }
+                Accum29G2<C>::madd(A, inf, qx, qy, [&](F2x<C>& x2, F2x<C>& y2) { x2 = qx; y2 = qy; });
+            }
+            alignas(16) uint32_t w[8 * N];
+            Accum29G2<C>::template store<true>(w, A, inf);
+            if (!xyzz29_words_inf_g2<C>(w) != !inf) return "ERR infinity encoding";
+            if (!inf) padd29_lds<C>(Rr, rinf, [&](int k, F2x<C>& x) { x.c0 = load29_packed<C>(w + k * 2 * N); x.c1 = load29_packed<C>(w + k * 2 * N + N); });
+        }
+        for (int rep = 0; rep < 2; rep++)
+            if (!rinf) padd29_lds<C>(Dd, dinf, [&](int k, F2x<C>& x) { Rr.get(k, x); });
+        alignas(16) uint32_t w[8 * N];
+        store_xyzz29_lds<C, AccR, false>(w, Rr, rinf);
+        o.push_back(rinf ? 1u : 0u);
+        for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
+        store_xyzz29_lds<C, AccR, false>(w, Dd, dinf);
+        o.push_back(dinf ? 1u : 0u);
         for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
     }
     else if (op == "reduce") {

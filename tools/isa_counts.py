@@ -57,11 +57,23 @@ def main():
         dn = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void zkmi::", "")
         macs = [k for k, (_, t) in enumerate(ins) if "v_mad_u64" in t]
         back = [(i, j) for i, j in branches(ins) if j < i and i - j > 2000 and any("v_mad_u64" in t for _, t in ins[j:i])]
+        fwd = [j for i, j in branches(ins) if j > i and j - i > 2000]
         if back:
             lo, hi = min(j for _, j in back), max(i for i, _ in back)
-        else:                                     # back-edge out of the 16-bit branch range (s_setpc): from the loads before the first product
+        elif fwd and sum(1 for _, t in ins if t.startswith("s_setpc")) <= 4:      # back-edge out of the 16-bit branch range (s_setpc): from the loads before the first product
             lo = max(k for k, (_, t) in enumerate(ins[:macs[0]]) if t.startswith("global_load_dwordx4")) - 12
-            hi = max(j for i, j in branches(ins) if j > i and j - i > 2000)
+            hi = max(fwd)
+        else:
+            # every long jump is an s_setpc (14-limb Fq2 kernel: > 128 KiB of code): split at them. Reading for k_msm_accum29_g2<Bls12381Fq>:
+            # segment 1 = gather, unpack, ZZ, ZZZ, U2, S2 (every addition); the next big segment = the rare doubling; the one after = the main path;
+            # the last = the once-per-lane store (Jacobian -> XYZZ words)
+            cuts = [0] + [k for k, (_, t) in enumerate(ins) if t.startswith("s_setpc")] + [len(ins)]
+            for a, b in zip(cuts, cuts[1:]):
+                if b - a < 1500:
+                    continue
+                m = mix(ins[a:b])
+                print(f"| `{dn}` | s_setpc-delimited segment [{a}, {b}) | " + " | ".join(str(m[k]) for k in ("instructions", "VALU", "v_mad_u64_u32", "s_nop", "LDS", "global/scratch loads", "scratch stores")) + " |")
+            continue
         # big forward-skipped regions inside the loop, outermost first, non-overlapping
         regs = []
         for i, j in sorted((x for x in branches(ins) if lo <= x[0] < x[1] <= hi + 1 and x[1] - x[0] > 600), key=lambda x: (x[0], -x[1])):

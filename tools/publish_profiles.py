@@ -1,24 +1,109 @@
-"""Copy the judged summaries of one gpurun_out/<tag>/ collection (tools/collect_profiles.sh) into profiles/ (tracked)."""
-import csv, json, os, shutil, subprocess, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+"""Copy the judged summaries of one gpurun_out/<tag>/ collection (tools/collect_profiles.sh) into profiles/ (tracked):
+bench lines, rocprofv3 kernel-stats summaries (BN254 and BLS12-381, serial command), the PLONK per-proof timeline, HBM traffic of the
+accumulation kernels from the two PMC passes WITH the per-access-class correction, the mul ceilings, the static instruction counts.
+usage: python tools/publish_profiles.py r03"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
-for f, t in (("bench.json", f"{tag}_bench.json"), ("bench_serial.json", f"{tag}_bench_serial.json"), ("bench_sparse_b.json", f"{tag}_bench_sparse_b.json"), ("bench_plonk_2p20.json", f"{tag}_bench_plonk_2p20.json"), ("bench_bls12381_2p20.json", f"{tag}_bench_bls12381_2p20.json"),
-             ("bench_bn128_2p24.json", f"{tag}_bench_bn128_2p24.json"), ("bench_fflonk_2p18.json", f"{tag}_bench_fflonk_2p18.json"), ("stats/bench_kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"),
-             ("stats_plonk/plonk_kernel_stats.csv", f"{tag}_plonk_kernel_stats.csv")):
-    if os.path.exists(os.path.join(src, f)):
-        shutil.copy(os.path.join(src, f), os.path.join(dst, t))
-wl = json.loads(open(f"{src}/bench.json").read().strip().splitlines()[-1])["config"]
-wl_tag = f"groth16:{wl['curve']}:2^{wl['log_n']}:b_zero_every={0 if wl['b_density'] == 1.0 else round(1 / (1 - wl['b_density']))}:{wl['witness']}"
-subprocess.check_call([sys.executable, "tools/pmc_to_traffic.py", f"{src}/pmc_fetch/f_counter_collection.csv", f"{src}/pmc_write/w_counter_collection.csv", f"{dst}/pmc_traffic.json", wl_tag])
-shutil.copy(f"{dst}/pmc_traffic.json", f"{dst}/{tag}_pmc_traffic.json")
+for f in ("bench", "bench_serial", "bench_sparse_b", "bench_mixed_witness", "bench_plonk_2p20", "bench_bls12381_2p20", "bench_bn128_2p24", "bench_fflonk_2p18"):
+    if os.path.exists(f"{src}/{f}.json"):
+        shutil.copy(f"{src}/{f}.json", f"{dst}/{tag}_{f}.json")
+line = lambda f: json.loads(open(f).read().strip().splitlines()[-1])
+bench = line(f"{src}/bench.json")
+
+
+def stats_md(csv_path, out, cmd):
+    rows = list(csv.DictReader(open(csv_path)))
+    shutil.copy(csv_path, out.replace("_summary.md", ".csv"))
+    with open(out, "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- {cmd} ({tag}, MI355X)\n\n"
+                f"Full CSV: {os.path.basename(out).replace('_summary.md', '.csv')}. Includes the one-off set-up kernels (k_gen_geometric_bases, k_msm_precompute, k_coef_*, k_scan_u32) and the\n"
+                "sub-metric runs (plain-base G1 MSM, NTT) after the timed region.\n\n| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n")
+        for r in rows[:40]:
+            f.write(f"| `{r['Name'].split('(')[0].replace('void ', '')[:90]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['Percentage']):.2f} |\n")
+
+
+for sub, name, cmd in (("stats", "bench_kernel_stats", "python bench.py --steps 20 --warmup 3 --pipeline 1 --no-cpu-baseline --no-napi-wall"),
+                       ("stats_bls", "bench_bls12381_kernel_stats", "python bench.py --curve bls12381 --steps 6 --warmup 2 --pipeline 1 --no-cpu-baseline --no-napi-wall")):
+    c = glob.glob(f"{src}/{sub}/**/*kernel_stats.csv", recursive=True)
+    if c:
+        stats_md(c[0], f"{dst}/{tag}_{name}_summary.md", cmd)
+
+# ---- PLONK per-proof timeline
+pt = glob.glob(f"{src}/stats_plonk/**/*kernel_trace.csv", recursive=True)
+if pt:
+    md = subprocess.run([sys.executable, "tools/plonk_trace_summary.py", pt[0]], capture_output=True, text=True).stdout
+    extra = ""
+    if os.path.exists(f"{src}/bench_plonk_under_rocprof.json"):
+        b = line(f"{src}/bench_plonk_under_rocprof.json")
+        extra = f"\nBench line of the profiled run itself: {b['value']} proofs/s, {b['ms_per_step']} ms per proof.\n"
+    open(f"{dst}/{tag}_plonk_kernel_summary.md", "w").write(md + extra)
+
+# ---- HBM traffic per launch of the accumulation kernels, corrected per access class
+# FETCH_SIZE tallies memory-side read requests at 64 B each (profiles/r02_gather_calibration.md): exact for 64-byte requests (a G1 table entry,
+# the sector behind a 16-byte list read), HALF the bytes of a 128-byte request (a G2 table entry). So: G1 bytes = raw; G2 bytes = raw + 64 B x
+# (number of 128-byte gathers) = raw + 64 B x mixed additions of the launch (counted on the device: bench line, accum_mixed_additions).
+def agg(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("zkmi::", "")].append(float(r["Counter_Value"]) * 1024)
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+fc, wc = glob.glob(f"{src}/pmc_fetch/**/*counter_collection.csv", recursive=True), glob.glob(f"{src}/pmc_write/**/*counter_collection.csv", recursive=True)
+if fc and wc:
+    F, W = agg(fc[0], "FETCH_SIZE"), agg(wc[0], "WRITE_SIZE")
+    adds = bench.get("accum_mixed_additions", {})
+    g1_adds = next((v for k, v in adds.items() if "(A)" in k), 0)
+    g2_adds = next((v for k, v in adds.items() if "(B2)" in k), 0)
+    out = {"__workload__": f"groth16:{bench['config']['curve']}:2^{bench['config']['log_n']}:b_zero_every={0 if bench['config']['b_density'] == 1.0 else round(1 / (1 - bench['config']['b_density']))}:{bench['config']['witness']}"}
+    rows = []
+    for k in sorted(F):
+        raw, wr = F[k], W.get(k, 0.0)
+        is_g2 = k.startswith("k_msm_accum29_g2") or k.startswith("k_msm_accum<Fp2")
+        corr = raw + (64.0 * g2_adds if is_g2 else 0.0)
+        if not (k.startswith("k_msm_accum") or k.startswith("k_ntt") or k.startswith("k_msm_rowcol") or k.startswith("k_build_abc")):
+            corr = 2 * raw                                       # coalesced streaming kernels: 128-byte requests tallied at 64 B (MI355X_MICROARCH.md)
+        key = k
+        while key.endswith(">") and any(key.endswith(s) for s in (", true>", ", false>")):
+            key = key[:key.rfind(",")] + ">"
+        out[key] = int(corr + wr)
+        rows.append((k, raw, wr, corr + wr))
+    json.dump(out, open(f"{dst}/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+    shutil.copy(f"{dst}/pmc_traffic.json", f"{dst}/{tag}_pmc_traffic.json")
+    with open(f"{dst}/{tag}_pmc_traffic.md", "w") as f:
+        f.write(f"# HBM traffic per launch, accumulation kernels ({tag}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, `bench.py --steps 2 --warmup 1 --pipeline 1`)\n\n"
+                "FETCH_SIZE tallies memory-side read requests at 64 B each (`r02_gather_calibration.md`): exact for the 64-byte gathers of a G1 table entry and for the sector\n"
+                "behind a 16-byte list read, half the bytes of a 128-byte G2 gather. Correction per access class: G1 bytes = raw; G2 bytes = raw + 64 B x gathers (= mixed\n"
+                f"additions counted on the device: {g2_adds}).\n\n| kernel | FETCH raw MB | WRITE MB | corrected total MB |\n|---|---|---|---|\n")
+        for k, raw, wr, tot in rows:
+            if "accum" in k:
+                f.write(f"| `{k}` | {raw/1e6:.0f} | {wr/1e6:.0f} | {tot/1e6:.0f} |\n")
+        m1 = g1_adds * 64 + g1_adds / 4 * 64 + (1 << 19) * 128
+        m2 = g2_adds * 128 + g2_adds / 4 * 64 + (1 << 19) * 256
+        f.write(f"\nModel per 2^20 launch (c = 20: 13 table rows, 2^19 buckets): G1 = gathers {g1_adds * 64 / 1e6:.0f} + list sectors (one 64-byte sector per 4 entries) {g1_adds / 4 * 64 / 1e6:.0f} + bucket stores "
+                f"{(1 << 19) * 128 / 1e6:.0f} = {m1 / 1e6:.0f} MB; G2 = {g2_adds * 128 / 1e6:.0f} + {g2_adds / 4 * 64 / 1e6:.0f} + {(1 << 19) * 256 / 1e6:.0f} = {m2 / 1e6:.0f} MB.\n"
+                "r02 (4-byte list reads, one sector per ENTRY): G1 1 937 MB, G2 3 558 MB under r02's x2-everything correction = 2 870 MB under this one.\n"
+                "The residual over the model (G1 ~15-20 %, G2 ~25 %) is not list traffic any more: page-table walks of 0.9 / 1.7 GB of random gathers are\n"
+                "tallied by the same counter, and the G2 kernel's WRITE_SIZE includes its scratch stores.\n")
+
 if os.path.exists(f"{src}/fieldbench29.txt"):
     shutil.copy(f"{src}/fieldbench29.txt", f"{dst}/{tag}_fieldbench29.txt")
-rows = list(csv.DictReader(open(f"{src}/stats/bench_kernel_stats.csv")))
-with open(f"{dst}/{tag}_bench_kernel_stats_summary.md", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --pipeline 1 --no-cpu-baseline --no-napi-wall ({tag}, MI355X)\n\n"
-            f"Full CSV: {tag}_bench_kernel_stats.csv. Includes the one-off set-up kernels (k_gen_geometric_bases, k_msm_precompute, k_coef_*, k_scan_u32) and the\n"
-            "sub-metric runs (plain-base G1 MSM, NTT) after the timed region.\n\n| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n")
-    for r in rows[:40]:
-        f.write(f"| `{r['Name'].split('(')[0].replace('void ', '')[:90]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['Percentage']):.2f} |\n")
-print(open(f"{dst}/{tag}_bench.json").read()[:3000])
+with open(f"{dst}/{tag}_isa_counts.md", "w") as f:
+    for obj in ("snarkjs_amd/build/msm_bn254.o", "snarkjs_amd/build/msm_bls12381.o"):
+        f.write(subprocess.run([sys.executable, "tools/isa_counts.py", obj], capture_output=True, text=True).stdout + "\n")
+    f.write("Reading: a mixed addition = the straight-line parts (and, for the G2 kernels, the region that is skipped only when no lane of the wave takes it);\n"
+            "the other conditionally skipped region is the rare equal-points doubling. BN254 G1 679 + 1 559 = 2 238 VALU (1 467 MACs); BN254 G2 1 500 + 4 444 =\n"
+            "5 944 (4 374); BLS12-381 G1 1 321 + 3 691 = 5 012 (3 570); BLS12-381 G2 (Jacobian accumulator, 8M + 3S): segment 1 + segment 3 =\n"
+            "5 438 + 9 464 = 14 902 VALU (11 760 MACs = 8 x 1 176 + 3 x 784), segment 2 = the doubling, segment 4 = the once-per-lane store.\n")
+print(json.dumps({k: bench[k] for k in ("value", "ms_per_step", "roofline", "int_alu") if k in bench}, indent=1)[:2500])
