@@ -174,6 +174,12 @@ int zkmi_groth16_prove_dev(uint64_t zkey_cache_key, const void* d_witness, const
  * copies; host folds) the throughput-bound front of proof k+1 (buildABC, NTTs, accumulations) already runs. Each slot owns its
  * streams, scratch and work buffers; d_witness must stay valid until the slot is collected. prove_dev == submit(0) + collect(0). */
 int zkmi_groth16_submit_dev(uint64_t zkey_cache_key, const void* d_witness, int slot);
+/* Host-orchestrated provers (plonk.prove, fflonk.prove: the rounds are driven by the host between transcript hashes) with two proofs in flight
+ * from ONE host thread: every library call works on the ACTIVE pipeline slot (0 | 1) — its own stream and events, scratch buffers, pool of
+ * zkmi_dev_alloc blocks and ring of per-call constants — so the host alternates between two proofs, switching slots at its blocking calls, and
+ * the GPU always holds the queued work of the other proof (snarkjs_amd/plonk.py: prove_many). Resident keys and window tables are shared. */
+int zkmi_pipeline_select(int slot);
+int zkmi_pipeline_active(void);
 /* The same for a witness in HOST memory (wtns section 2, witness_len = n_vars x 32): it crosses PCIe on the slot's own stream into the
  * slot's own buffer, i.e. underneath the kernels of the proof in the other slot — the throughput mode of a host that keeps witnesses in
  * host memory (js/groth16_native.js: proveMany). `witness` may be re-used as soon as the call returns. */
@@ -226,6 +232,11 @@ int zkmi_plonk_gather_wires_dev(int curve, const void* d_witness, uint32_t n_wit
 int zkmi_plonk_compute_z_dev(int curve, const void* d_a, const void* d_b, const void* d_c, const void* d_s1e, const void* d_s2e,
                              const void* d_s3e, uint32_t domain, const uint8_t* beta, const uint8_t* gamma, const uint8_t* k1,
                              const uint8_t* k2, const uint8_t* w_n, void* d_z);
+/* The same without the wait and without the Z[0] check: the caller compares Z[0] with one at its next synchronisation point and raises the
+ * reference's "Copy constraints does not match" there (two proofs in flight from one host thread: the host must not block per kernel). */
+int zkmi_plonk_compute_z_enqueue(int curve, const void* d_a, const void* d_b, const void* d_c, const void* d_s1e, const void* d_s2e,
+                                 const void* d_s3e, uint32_t domain, const uint8_t* beta, const uint8_t* gamma, const uint8_t* k1,
+                                 const uint8_t* k2, const uint8_t* w_n, void* d_z);
 /* computeT (plonk_prove.js:516-628 with MulZ.mul2/mul4, mul_z.js:49-148): T and Tz over the 4n extended evaluation points.
  * lagrange = zkey section 13 on the device (per public input: n coefficients then 4n evaluations); pub_a = buffers.A. */
 typedef struct zkmi_plonk_evals {

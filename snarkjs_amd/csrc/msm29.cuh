@@ -492,7 +492,9 @@ template <class C, class Acc, class Rq> ZK_HD void madd29_jac_lds(const Acc& A, 
             F2x<C> Tt = f2sub<C, 7>(S, X3); f2norm(Tt);                                 // <= 8.2
             const F2x<C> MT = f2mul(M, Tt, neg29<C, 9>(Tt.c1)), Wy = f2mul(W, qy, neg29<C, 3>(qy.c1));       // <= 1.7, 1.1
             F2x<C> Y3 = f2sub<C, 2>(MT, Wy); f2norm(Y3);                                // <= 3.7
-            A.put(0, X3); A.put(1, Y3); A.put(2, U);
+            // Z3 = U = 2 y is up to 4 p: one product by one brings it back under the invariant (Z <= 1.1) the next addition's offsets assume
+            F2x<C> one; one.c0 = one29<C>(); one.c1 = zero29<C>();
+            A.put(0, X3); A.put(1, Y3); A.put(2, f2mul(U, one, zero29<C>()));
         } else inf = true;
         return;
     }
@@ -684,9 +686,9 @@ template <class C, class Acc, class Ld> ZK_HD void padd29_lds(const Acc& A, bool
         if (f2zero(R)) dbl29_lds<C>(A); else inf = true;
         return;
     }
-    const F2x<C> PP = f2sqr<C, 4>(P);                                                   // <= 1.2
+    const F2x<C> PP = f2sqr<C, 4>(P);                                                   // c0 <= 1.3, c1 = 2 a0 a1 <= 2.2
     ZK_SFENCE();
-    const Fp29<C> nPP1 = neg29<C, 2>(PP.c1);
+    const Fp29<C> nPP1 = neg29<C, 3>(PP.c1);
     const F2x<C> Q = f2mul(U1, PP, nPP1);                                               // <= 1.1
     ZK_SFENCE();
     const F2x<C> PPP = f2mul(P, PP, nPP1);                                              // <= 1.1
@@ -702,12 +704,12 @@ template <class C, class Acc, class Ld> ZK_HD void padd29_lds(const Acc& A, bool
     ZK_SFENCE();
     A.put(3, f2mul(t, PPP, nPPP1));                                                     // ZZZ3 = ZZZ1 ZZZ2 PPP
     ZK_SFENCE();
-    F2x<C> Tq = f2sub<C, 2>(f2sub<C, 2>(f2sub<C, 2>(f2sqr<C, 4>(R), PPP), Q), Q); f2norm(Tq);     // X3 <= 1.2 + 6 = 7.2
+    F2x<C> Tq = f2sub<C, 2>(f2sub<C, 2>(f2sub<C, 2>(f2sqr<C, 4>(R), PPP), Q), Q); f2norm(Tq);     // X3 <= 2.2 + 6 = 8.2 (the square's c1 is a doubled product)
     A.put(0, Tq);
     ZK_SFENCE();
-    Tq = f2sub<C, 8>(Q, Tq); f2norm(Tq);                                                // Q - X3 <= 9.1
+    Tq = f2sub<C, 9>(Q, Tq); f2norm(Tq);                                                // Q - X3 <= 10.1
     const Fp29<C> nR1 = neg29<C, 4>(R.c1);
-    const F2x<C> TR{mul29_2(Tq.c0, R.c0, Tq.c1, nR1), mul29_2(Tq.c0, R.c1, Tq.c1, R.c0)};         // <= (29 + 36) / 169 + 1 = 1.4
+    const F2x<C> TR{mul29_2(Tq.c0, R.c0, Tq.c1, nR1), mul29_2(Tq.c0, R.c1, Tq.c1, R.c0)};         // <= (32 + 40) / 169 + 1 = 1.5
     ZK_SFENCE();
     ld(3, u); A.get(1, t);
     const F2x<C> S1 = f2mul(t, u, neg29<C, 2>(u.c1));                                   // again: Y1 ZZZ2 (ld(3) is the OPERAND's ZZZ, untouched)

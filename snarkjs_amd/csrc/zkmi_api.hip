@@ -267,13 +267,14 @@ double zkmi_msm_accum_additions(int slot) {
 int zkmi_dev_alloc(size_t bytes, void** d_ptr) {
     ZK_TRY(require_ctx());
     if (!bytes) bytes = 1;
-    auto it = g_ctx.pool.find(bytes);
-    if (it != g_ctx.pool.end() && !it->second.empty()) {
+    auto& pool = g_ctx.pool[g_ctx.pipe];
+    auto it = pool.find(bytes);
+    if (it != pool.end() && !it->second.empty()) {
         *d_ptr = it->second.back();
         it->second.pop_back();
         g_ctx.pool_bytes -= bytes;
     } else ZK_TRY(dev_alloc_big(d_ptr, bytes));
-    g_ctx.user_allocs[*d_ptr] = bytes;
+    g_ctx.user_allocs[*d_ptr] = std::make_pair(bytes, g_ctx.pipe);
     return ZKMI_OK;
 }
 int zkmi_dev_free(void* d_ptr) {
@@ -281,14 +282,27 @@ int zkmi_dev_free(void* d_ptr) {
     if (!d_ptr) return ZKMI_OK;
     auto it = g_ctx.user_allocs.find(d_ptr);
     if (it == g_ctx.user_allocs.end()) return fail(ZKMI_ERR_INVALID, "zkmi_dev_free: not a zkmi_dev_alloc pointer");
-    const size_t bytes = it->second;
+    const size_t bytes = it->second.first;
+    const int slot = it->second.second;
     g_ctx.user_allocs.erase(it);
-    if (g_ctx.pool_bytes + bytes <= g_ctx.pool_limit) {          // stream-ordered reuse: all library work runs on one stream
-        g_ctx.pool[bytes].push_back(d_ptr);
+    // Stream-ordered reuse: a freed block may still be read by kernels queued on its slot's stream, so it goes back to the pool of the slot
+    // that allocated it (whichever slot is active when the host drops it) and is only ever handed out to work queued behind those kernels.
+    if (g_ctx.pool_bytes + bytes <= g_ctx.pool_limit) {
+        g_ctx.pool[slot][bytes].push_back(d_ptr);
         g_ctx.pool_bytes += bytes;
-    } else ZK_HIP(hipFree(d_ptr));
+    } else {
+        if (g_ctx.saved[slot].init && slot != g_ctx.pipe) (void)hipStreamSynchronize(g_ctx.saved[slot].stream);
+        ZK_HIP(hipFree(d_ptr));
+    }
     return ZKMI_OK;
 }
+// Host-orchestrated provers (PLONK, FFLONK) with two proofs in flight from ONE host thread: every library call works on the active pipeline
+// slot — its stream and events, its scratch buffers (ws_get prefixes the names), its pool of zkmi_dev_alloc blocks, its ring of constants.
+int zkmi_pipeline_select(int slot) {
+    ZK_TRY(require_ctx());
+    return select_pipe(slot);
+}
+int zkmi_pipeline_active(void) { return g_ctx.ready ? g_ctx.pipe : 0; }
 int zkmi_memcpy_h2d(void* d, const void* h, size_t bytes) {
     ZK_TRY(require_ctx());
     ZK_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, g_ctx.stream));

@@ -64,8 +64,8 @@ struct Ctx {
     std::map<std::string, DevBuf> ws;                       // named scratch buffers (grow-only)
     std::map<std::tuple<int, unsigned, int>, NttPlan> plans;  // (curve, log_n, inverse)
     std::map<std::string, DevBuf> ntt_prescale;             // cached row-factor tables of fused NTT pre-scales
-    std::map<void*, size_t> user_allocs;
-    std::map<size_t, std::vector<void*>> pool;              // freed zkmi_dev_alloc blocks by size
+    std::map<void*, std::pair<size_t, int>> user_allocs;    // zkmi_dev_alloc blocks: (bytes, pipeline slot that allocated it)
+    std::map<size_t, std::vector<void*>> pool[2];           // freed zkmi_dev_alloc blocks by size, per pipeline slot (reuse is stream-ordered within a slot)
     size_t pool_bytes = 0, pool_limit = (size_t)96 << 30;
     std::map<uint64_t, void*> groth16;                      // zkmi_groth16 resident keys (groth16.hip)
     // window tables kept in the R'-form of field29.cuh (base pointer -> infinity bitmap): msm_accumulate runs them through k_msm_accum29

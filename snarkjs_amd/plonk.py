@@ -222,6 +222,58 @@ def _commit(key, *polys):
 def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     """plonk.prove(zkeyFileName, witnessFileName). blinding_mont: the 11 Fr.random() draws (:224-227) as Montgomery bytes,
     for bit-exact reproduction; default = fresh randomness."""
+    steps = _prove_steps(zkey, witness_file, logger, options, blinding_mont)
+    try:
+        while True:
+            next(steps)
+    except StopIteration as done:
+        return done.value
+
+
+def prove_many(zkey, witness_files, blinding_monts=None, in_flight=2):
+    """Throughput mode: one proof per witness against the same key, TWO in flight from this one host thread. A PLONK proof is a chain of
+    rounds separated by transcript hashes, so one proof alone leaves the GPU idle while the host hashes, folds window sums and launches, and
+    runs its memory- and latency-bound phases (digit sorts, bucket reductions, small scans) with nothing beside them. Here every proof is a
+    coroutine (_prove_steps) that yields right before each of its long blocking calls; the driver switches the library's pipeline slot
+    (zkmi_pipeline_select: own stream, scratch, allocation pool) and lets the other proof enqueue up to ITS next blocking call first, so the
+    GPU always holds queued work of the other proof while the host waits. Results come back in input order and are the proofs plonk.prove
+    would return for the same blinding values."""
+    key = zkey if isinstance(zkey, PlonkKey) else PlonkKey(zkey if isinstance(zkey, (bytes, bytearray)) else open(zkey, "rb").read())
+    L = zkmi.lib()
+    n = len(witness_files)
+    out = [None] * n
+    live, free, nxt = [], list(range(max(1, min(2, in_flight)))), 0
+    try:
+        while nxt < n or live:
+            while free and nxt < n:
+                live.append((free.pop(0), nxt, _prove_steps(key, witness_files[nxt], None, None, None if blinding_monts is None else blinding_monts[nxt])))
+                nxt += 1
+            for ent in list(live):
+                slot, idx, steps = ent
+                zkmi.check(L.zkmi_pipeline_select(slot))
+                try:
+                    next(steps)
+                except StopIteration as done:
+                    out[idx] = done.value
+                    live.remove(ent)
+                    free.append(slot)
+    finally:
+        for slot, _, steps in live:                    # an error in one proof: drop the other one too, leave no queued work behind
+            try:
+                L.zkmi_pipeline_select(slot)
+                steps.close()
+                L.zkmi_synchronize()
+            except Exception:
+                pass
+        L.zkmi_pipeline_select(0)
+        if not isinstance(zkey, PlonkKey):
+            key.release()
+    return out
+
+
+def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=None):
+    """plonk.prove as a coroutine: `yield` stands right before every long blocking call (the four commitment rounds, the divisibility check behind
+    the T pipeline, the round-4 evaluations); the value of the generator is the proof. Everything between two yields only enqueues work."""
     def data(x):
         if isinstance(x, (bytes, bytearray)):
             return x                                                   # parsed in place: no copy of a 2^20-signal witness per proof
@@ -284,6 +336,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     pA, pB, pC = A.ntt(True), B.ntt(True), Cw.ntt(True)
     eA, eB, eC = pA.extended_evals(4), pB.extended_evals(4), pC.extended_evals(4)
     pA, pB, pC = pA.blinded([b[2], b[1]]), pB.blinded([b[4], b[3]]), pC.blinded([b[6], b[5]])
+    yield
     pts["A"], pts["B"], pts["C"] = _commit(key, pA, pB, pC)
 
     # ---- ROUND 2 (:315-455)
@@ -298,11 +351,14 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     tr.reset(); tr.scalar(beta)
     gamma = tr.challenge()
     Zb = _Poly(f, n, False)
-    zkmi.check(L.zkmi_plonk_compute_z_dev(f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), n, zkmi.ptr(mont(beta)),
-                                          zkmi.ptr(mont(gamma)), zkmi.ptr(mont(key.k1)), zkmi.ptr(mont(key.k2)), zkmi.ptr(w_n), Zb.ptr))
+    zkmi.check(L.zkmi_plonk_compute_z_enqueue(f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), n, zkmi.ptr(mont(beta)),
+                                              zkmi.ptr(mont(gamma)), zkmi.ptr(mont(key.k1)), zkmi.ptr(mont(key.k2)), zkmi.ptr(w_n), Zb.ptr))
     pZ = Zb.ntt(True)
     eZ = pZ.extended_evals(4)
     pZ = pZ.blinded([b[9], b[8], b[7]])
+    yield
+    if Zb.get(0) != 1:                                                                   # the first wait after computeZ: its check (:437-439)
+        raise ValueError("Copy constraints does not match")
     pts["Z"], = _commit(key, pZ)
 
     # ---- ROUND 3 (:457-684)
@@ -318,6 +374,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     zkmi.check(L.zkmi_poly_div_zh_dev(f.cid, pT.ptr, 4 * n, n, 4))
     pTz = Tz.ntt(True, out=Tz)
     pT.axpy(pTz)
+    yield
     if not pT.tail_is_zero(3 * n + 6):
         raise ValueError("T Polynomial is not well calculated")                          # :645-647
     T1 = _Poly(f, n + 1).copy_from(pT.at(0), n)
@@ -326,6 +383,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     T1.set(n, b[10])
     T2.set(0, (T2.get(0) - b[10]) % r); T2.set(n, b[11])
     T3.set(0, (T3.get(0) - b[11]) % r)
+    yield
     pts["T1"], pts["T2"], pts["T3"] = _commit(key, T1, T2, T3)
 
     # ---- ROUND 4 (:686-708)
@@ -337,6 +395,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     S1c = _Poly(f, n, False).copy_from(key.sec(12, 0), n)
     S2c = _Poly(f, n, False).copy_from(key.sec(12, 5 * n), n)
     S3c = _Poly(f, n, False).copy_from(key.sec(12, 10 * n), n)
+    yield
     evs["eval_a"], evs["eval_b"], evs["eval_c"] = pA.evaluate(xi), pB.evaluate(xi), pC.evaluate(xi)
     evs["eval_s1"], evs["eval_s2"], evs["eval_zw"] = S1c.evaluate(xi), S2c.evaluate(xi), pZ.evaluate(xiw)
 
@@ -388,6 +447,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     Wxiw = _Poly(f, pZ.n, False).copy_from(pZ.ptr, pZ.n)
     Wxiw.add_scalar(-ezw % r)
     zkmi.check(L.zkmi_poly_div_by_zerofier_dev(f.cid, Wxiw.ptr, Wxiw.n, 1, zkmi.ptr(mont(xiw))))
+    yield
     pts["Wxi"], pts["Wxiw"] = _commit(key, Wxi, Wxiw)
 
     proof = {}

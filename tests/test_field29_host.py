@@ -38,7 +38,7 @@ def tool():
         pytest.skip("hipcc not available")
     if not os.path.exists(TOOL) or any(os.path.getmtime(d) > os.path.getmtime(TOOL) for d in _deps()):
         os.makedirs(os.path.dirname(TOOL), exist_ok=True)
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "snarkjs_amd", "csrc"), SRC, "-o", TOOL])
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-DZK29_CHECK", "-I" + os.path.join(ROOT, "snarkjs_amd", "csrc"), SRC, "-o", TOOL])
     p = subprocess.Popen([TOOL], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
 
     def call(op, curve, words):
@@ -422,6 +422,50 @@ def test_g2_bucket_reduction_additions(tool, curve):
             assert got == want
             got2, rest = decode(rest)
             assert got2 == (aff_add(K, want, want) if want is not None else None) and not rest
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_g2_row_sum_wave_flow(tool, curve):
+    """k_msm_rowcol_wave29_g2's flow for one wave, emulated on the host with the kernel's own accumulator layout (stride 64): every lane
+    places one R'-form bucket, six tree levels of accumulator-to-accumulator additions; empty buckets in between."""
+    F = Form(curve)
+    K = Fp2(F.p)
+    rng = random.Random(0xA7 + F.NL)
+    p, N = F.p, F.N
+    Rwi = pow(1 << (32 * N), -1, p)
+    words = lambda v: [(v >> (32 * k)) & 0xffffffff for k in range(N)]
+    for trial in range(3):
+        lanes, req = [], []
+        for l in range(64):
+            if trial and rng.random() < 0.3:
+                lanes.append(None)
+                req += [0] * (8 * N)
+                continue
+            q = ((rng.randrange(p), rng.randrange(p)), (rng.randrange(p), rng.randrange(1, p)))
+            lam = (rng.randrange(1, p), rng.randrange(p))                    # a non-trivial representative: ZZ = lam^2, ZZZ = lam^3
+            zz = K.mul(lam, lam)
+            zzz = K.mul(zz, lam)
+            coords = (K.mul(q[0], zz), K.mul(q[1], zzz), zz, zzz)
+            lanes.append(q)
+            for cdn in coords:
+                for comp in cdn:
+                    req += words(comp * F.Rp % p)
+        # the tree associates pairwise: (l, l + 1), then (l, l + 2), ...
+        cur = list(lanes)
+        d = 1
+        while d < 64:
+            for l in range(0, 64, 2 * d):
+                cur[l] = aff_add(K, cur[l], cur[l + d])
+            d *= 2
+        out = tool("rowsum", curve, req)
+        inf, w = out[0], out[1:]
+        if cur[0] is None:
+            assert inf == 1
+            continue
+        assert inf == 0
+        v = [sum(w[i * N + k] << (32 * k) for k in range(N)) for i in range(8)]
+        X, Y, ZZ, ZZZ = ((v[2 * i] * Rwi % p, v[2 * i + 1] * Rwi % p) for i in range(4))
+        assert (K.mul(X, K.inv(ZZ)), K.mul(Y, K.inv(ZZZ))) == cur[0]
 
 
 @pytest.mark.parametrize("curve", FR_CURVES)

@@ -354,6 +354,48 @@ def test_fflonk_large_proof_verifies(env, lg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag,lg", [("plonk_bn128_n2048", None), ("plonk_bls12381_small", None), (None, 13), (None, 16)])
+def test_plonk_two_proofs_in_flight_equal_serial(env, golden_dir, tag, lg):
+    """plonk.prove_many (two coroutine proofs on the library's two pipeline slots, one host thread): the same proofs, bit for bit, as one
+    plonk.prove after the other with the same blinding values — golden fixture first in the list; an odd number of proofs; a corrupted witness
+    in the middle fails the whole call with the reference's message and leaves the library ready for the next proof."""
+    import synth_plonk
+    zkmi, plonk, f, cx = env
+    if tag:
+        with open(os.path.join(golden_dir, f"{tag}.json")) as fh:
+            g = json.load(fh)
+        zkey = open(os.path.join(golden_dir, f"{tag}.zkey"), "rb").read()
+        wtns = open(os.path.join(golden_dir, f"{tag}.wtns"), "rb").read()
+        blinds = [[bytes.fromhex(x) for x in g["blinding_mont"]]]
+        fld = plonk.PlonkKey(zkey)
+        f2 = fld.f
+        fld.release()
+    else:
+        zkey, wtns = synth_plonk.make("bn128", lg, seed=40 + lg)
+        blinds, f2, g = [], f, None
+    for k in range(len(blinds), 5):
+        blinds.append([bytes(f2.mont(7000 + 131 * k + 17 * i)) for i in range(11)])
+    key = plonk.PlonkKey(zkey)
+    serial = [plonk.prove(key, wtns, blinding_mont=b) for b in blinds]
+    many = plonk.prove_many(key, [wtns] * len(blinds), blinding_monts=blinds)
+    assert [m["proof"] for m in many] == [s_["proof"] for s_ in serial]
+    assert all(m["publicSignals"] == serial[0]["publicSignals"] for m in many)
+    if g:
+        assert many[0]["proof"] == g["proof"]
+    assert zkmi.lib().zkmi_pipeline_active() == 0
+    bad = bytearray(wtns)
+    bad[-32] ^= 1
+    with pytest.raises(Exception) as ei:
+        plonk.prove_many(key, [wtns, bytes(bad), wtns, wtns], blinding_monts=blinds[:4])
+    assert "Copy constraints does not match" in str(ei.value) or "not divisible" in str(ei.value) or "not well calculated" in str(ei.value)
+    assert zkmi.lib().zkmi_pipeline_active() == 0
+    again = plonk.prove_many(key, [wtns] * 3, blinding_monts=blinds[:3])
+    assert [m["proof"] for m in again] == [s_["proof"] for s_ in serial[:3]]
+    assert plonk.prove(key, wtns, blinding_mont=blinds[1])["proof"] == serial[1]["proof"]
+    key.release()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lg", [12, 20])
 def test_plonk_full_size_proof_verifies(env, lg):
     """BASELINE configs[3] at its full size (2^20 constraints): the device proof VERIFIES.  The verifier is the restatement of

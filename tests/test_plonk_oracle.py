@@ -90,3 +90,59 @@ def test_fflonk_verifier_trace(golden_dir, tag):
     vk = V.vk_from_zkey(zkey)
     for k, v in vk.items():
         assert str(g["vk"][k]) == str(v) or g["vk"][k] == v, k
+
+
+def test_prove_many_schedules_two_coroutines_over_the_pipeline_slots(monkeypatch):
+    """plonk.prove_many (host logic, no GPU): proofs are coroutines that yield before their blocking calls; the driver keeps at most two alive,
+    selects the proof's pipeline slot before every step, returns results in input order, and on an error closes the other proof and goes back to
+    slot 0."""
+    from snarkjs_amd import plonk, zkmi
+
+    class FakeLib:
+        def __init__(self):
+            self.active, self.log = 0, []
+
+        def zkmi_pipeline_select(self, slot):
+            self.active = slot
+            return 0
+
+        def zkmi_synchronize(self):
+            self.log.append(("sync", self.active))
+            return 0
+
+    fake = FakeLib()
+    monkeypatch.setattr(zkmi, "lib", lambda: fake)
+    alive, peak, trace = set(), [0], []
+
+    def steps(key, wt, logger, options, blind):
+        alive.add(wt["id"])
+        peak[0] = max(peak[0], len(alive))
+        try:
+            for k in range(wt["n"]):
+                trace.append((wt["id"], fake.active))
+                if wt.get("fail_at") == k:
+                    raise ValueError("Copy constraints does not match")
+                yield
+            return {"proof": wt["id"], "blind": blind}
+        finally:
+            alive.discard(wt["id"])
+
+    monkeypatch.setattr(plonk, "_prove_steps", steps)
+    key = object.__new__(plonk.PlonkKey)
+    wts = [{"id": i, "n": n} for i, n in enumerate([3, 7, 2, 5, 4])]
+    out = plonk.prove_many(key, wts, blinding_monts=[10, 11, 12, 13, 14])
+    assert [o["proof"] for o in out] == [0, 1, 2, 3, 4] and [o["blind"] for o in out] == [10, 11, 12, 13, 14]
+    assert peak[0] == 2 and not alive and fake.active == 0
+    slot_of = {}
+    for pid, slot in trace:                                # every step of a proof runs on the slot it started on
+        assert slot_of.setdefault(pid, slot) == slot
+    assert sorted(set(slot_of.values())) == [0, 1]
+    # the two live proofs alternate step by step
+    first_two = [pid for pid, _ in trace if pid in (0, 1)][:6]
+    assert first_two == [0, 1, 0, 1, 0, 1]
+    # one proof fails: the other is closed, the slot goes back to 0, later calls work
+    trace.clear()
+    with pytest.raises(ValueError, match="Copy constraints"):
+        plonk.prove_many(key, [{"id": 0, "n": 6}, {"id": 1, "n": 6, "fail_at": 2}, {"id": 2, "n": 3}])
+    assert not alive and fake.active == 0 and 2 not in [pid for pid, _ in trace]
+    assert [o["proof"] for o in plonk.prove_many(key, [{"id": 7, "n": 1}], in_flight=1)] == [7]

@@ -6,6 +6,7 @@
 // build: hipcc --offload-arch=gfx950 -O1 -std=c++17 -Isnarkjs_amd/csrc tools/field29_hosttest.hip -o tools/bin/field29_hosttest
 // protocol: one request per line "<op> <curve> <hex words...>", one reply line of hex words (or "ERR ...").
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -137,6 +138,34 @@ template <class C> static std::string run(const std::string& op, const std::vect
         for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
         store_xyzz29_lds<C, AccR, false>(w, Dd, dinf);
         o.push_back(dinf ? 1u : 0u);
+        for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
+    }
+    else if (op == "rowsum") {
+        // the reduction kernel's flow for one wave on the host: 64 lanes with accumulators at stride T = 64 in one "LDS" array; lane l places
+        // bucket l (R'-form words; all-zero words = empty), then the six tree levels. in: 64 x 8 N words; out: inf + 8 N R-form words
+        constexpr int T = 64;
+        typedef LdsAcc29<C, T, Reduce29G2<C>::PACK> Acc;
+        std::vector<uint32_t> lds((size_t)T * 8 * Acc::EW, 0xdeadbeefu);
+        std::vector<uint32_t> words(v.begin() + at, v.begin() + at + 64 * 8 * N);
+        at += 64 * 8 * N;
+        bool inf[T];
+        for (int l = 0; l < T; l++) {
+            const Acc A{lds.data() + l};
+            inf[l] = true;
+            alignas(16) uint32_t w[8 * N];
+            for (int i = 0; i < 8 * N; i++) w[i] = words[(size_t)l * 8 * N + i];
+            if (!xyzz29_words_inf_g2<C>(w)) padd29_lds<C>(A, inf[l], [&](int k, F2x<C>& x) { x.c0 = load29_packed<C>(w + k * 2 * N); x.c1 = load29_packed<C>(w + k * 2 * N + N); });
+        }
+        for (int d = 1; d < 64; d <<= 1)
+            for (int l = 0; l < T; l++)
+                if ((l & (2 * d - 1)) == 0 && !inf[l + d]) {
+                    const Acc A{lds.data() + l}, Pn{lds.data() + l + d};
+                    padd29_lds<C>(A, inf[l], [&](int k, F2x<C>& x) { Pn.get(k, x); });
+                }
+        alignas(16) uint32_t w[8 * N];
+        const Acc A0{lds.data()};
+        store_xyzz29_lds<C, Acc, false>(w, A0, inf[0]);
+        o.push_back(inf[0] ? 1u : 0u);
         for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
     }
     else if (op == "reduce") {
