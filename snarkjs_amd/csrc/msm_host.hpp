@@ -194,11 +194,12 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
             constexpr size_t lds29 = Accum29G2<C>::lds_bytes;              // 4 coordinates x 2 components per lane
             static bool a29 = false;
             if (!a29) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum29_g2<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29)); a29 = true; }
-            // ZKMI_R29_REDUCE_G2 = 1 / 0: the Fq2 buckets stay in R'-form and k_msm_rowcol_wave29_g2 forms the row / column sums on the same limbs
-            // (default: the 14-limb curve, where the 32-bit CIOS Fq2 products of the generic kernel are the slower side by the wider margin)
-            static const int g2r_env = getenv("ZKMI_R29_REDUCE_G2") ? atoi(getenv("ZKMI_R29_REDUCE_G2")) : -1;
+            // The Fq2 buckets stay in R'-form and k_msm_rowcol_wave29_g2 forms the row / column sums on the same limbs (r03 A/B, same box:
+            // BLS12-381 51.1 / 50.2 against 50.3 / 50.0 proofs/s, BN254 105.9 against 105.5); ZKMI_R29_REDUCE_G2=0: R-form buckets and the
+            // generic 32-bit kernel
+            static const bool g2r = !(getenv("ZKMI_R29_REDUCE_G2") && atoi(getenv("ZKMI_R29_REDUCE_G2")) == 0);
             static const bool wave_ok = !(getenv("ZKMI_ROWCOL_WAVE") && atoi(getenv("ZKMI_ROWCOL_WAVE")) == 0);
-            r29_buckets = wave_ok && (g2r_env < 0 ? Lim29<C>::NL > 9 : g2r_env != 0) && (sh.c - 1) / 2 >= 6;
+            r29_buckets = wave_ok && g2r && (sh.c - 1) / 2 >= 6;
             hipLaunchKernelGGL((k_msm_accum29_g2<C>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
                                d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials,
                                (int)r29_buckets);

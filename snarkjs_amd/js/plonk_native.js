@@ -157,14 +157,51 @@ function prove(zkey, wtns, blindingMont = null) {
     const P = (n, zero = true) => { const p = new Poly(key.f, n, zero); polys.push(p); return p; };
     const track = (p) => { polys.push(p); return p; };
     try {
-        return proveWith(key, wtns instanceof Uint8Array ? wtns : new Uint8Array(wtns), blindingMont, P, track);
+        const steps = proveSteps(key, wtns instanceof Uint8Array ? wtns : new Uint8Array(wtns), blindingMont, P, track);
+        for (;;) { const s = steps.next(); if (s.done) return s.value; }
     } finally {
         polys.forEach((p) => p.free());
         if (!(zkey instanceof PlonkKey)) key.release();
     }
 }
 
-function proveWith(key, wt, blindingMont, P, track) {
+// Throughput mode: one proof per witness against one key, TWO in flight from this one thread. Every proof is a generator (proveSteps) that
+// yields right before each of its long blocking calls (the commitment rounds, the divisibility check behind the T pipeline, the round-4
+// evaluations); the driver switches the library's pipeline slot (zkmi_pipeline_select: own stream, scratch buffers, allocation pool) and lets
+// the other proof enqueue up to ITS next blocking call first, so the GPU holds queued work of one proof while the host waits for the other.
+// Results come back in input order and equal what prove() returns for the same blinding values.
+function proveMany(zkey, wtnsList, blindingMonts = null) {
+    const key = zkey instanceof PlonkKey ? zkey : new PlonkKey(zkey);
+    const out = new Array(wtnsList.length), live = [], free = [0, 1];
+    let nxt = 0;
+    const finish = (ent) => { ent.polys.forEach((p) => p.free()); live.splice(live.indexOf(ent), 1); free.push(ent.slot); };
+    try {
+        while (nxt < wtnsList.length || live.length) {
+            while (free.length && nxt < wtnsList.length) {
+                const polys = [], w = wtnsList[nxt];
+                const P = (n, zero = true) => { const p = new Poly(key.f, n, zero); polys.push(p); return p; };
+                const track = (p) => { polys.push(p); return p; };
+                live.push({ slot: free.shift(), idx: nxt, polys, steps: proveSteps(key, w instanceof Uint8Array ? w : new Uint8Array(w), blindingMonts ? blindingMonts[nxt] : null, P, track) });
+                nxt++;
+            }
+            for (const ent of live.slice()) {
+                call("zkmi_pipeline_select", ent.slot);
+                const s = ent.steps.next();
+                if (s.done) { out[ent.idx] = s.value; finish(ent); }
+            }
+        }
+    } finally {
+        for (const ent of live.slice()) {                  // an error in one proof: drop the other one too, leave no queued work behind
+            try { call("zkmi_pipeline_select", ent.slot); ent.steps.return(); call("zkmi_synchronize"); ent.polys.forEach((p) => p.free()); } catch (e) { /* already failing */ }
+        }
+        call("zkmi_pipeline_select", 0);
+        if (!(zkey instanceof PlonkKey)) key.release();
+    }
+    return out;
+}
+
+// plonk.prove as a generator: `yield` stands right before every long blocking call; everything between two yields only enqueues work
+function* proveSteps(key, wt, blindingMont, P, track) {
     const f = key.f, r = f.r, n = key.n, power = key.power;
     const { dv, s: ws } = readSections(wt);
     const n8 = dv.getUint32(ws[1][0], true), wq = fromLE(wt.subarray(ws[1][0] + 4, ws[1][0] + 4 + n8)), nWitness = dv.getUint32(ws[1][0] + 4 + n8, true);
@@ -201,6 +238,7 @@ function proveWith(key, wt, blindingMont, P, track) {
         let pA = track(A.ntt(true)), pB = track(B.ntt(true)), pC = track(Cw.ntt(true));
         const eA = track(pA.extendedEvals(4)), eB = track(pB.extendedEvals(4)), eC = track(pC.extendedEvals(4));
         pA = track(pA.blinded([b[2], b[1]])); pB = track(pB.blinded([b[4], b[3]])); pC = track(pC.blinded([b[6], b[5]]));
+        yield;
         [pts.A, pts.B, pts.C] = commit(key, [pA, pB, pC]);
 
         // ---- ROUND 2 (:315-455)
@@ -212,10 +250,12 @@ function proveWith(key, wt, blindingMont, P, track) {
         tr.reset(); tr.scalar(beta);
         const gamma = tr.challenge();
         const Zb = P(n, false);
-        call("zkmi_plonk_compute_z_dev", f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), n, mont(beta), mont(gamma), mont(key.k1), mont(key.k2), wN, Zb.ptr);
+        call("zkmi_plonk_compute_z_enqueue", f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), n, mont(beta), mont(gamma), mont(key.k1), mont(key.k2), wN, Zb.ptr);
         let pZ = track(Zb.ntt(true));
         const eZ = track(pZ.extendedEvals(4));
         pZ = track(pZ.blinded([b[9], b[8], b[7]]));
+        yield;
+        if (Zb.get(0) !== 1n) throw new Error("Copy constraints does not match");                        // the first wait after computeZ: its check (:437-439)
         [pts.Z] = commit(key, [pZ]);
 
         // ---- ROUND 3 (:457-684)
@@ -230,11 +270,13 @@ function proveWith(key, wt, blindingMont, P, track) {
         call("zkmi_poly_div_zh_dev", f.cid, pT.ptr, 4 * n, n, 4);
         const pTz = Tz.ntt(true, Tz);
         pT.axpy(pTz);
+        yield;
         if (!pT.tailIsZero(3 * n + 6)) throw new Error("T Polynomial is not well calculated");            // :645-647
         const T1 = P(n + 1).copyFrom(pT.at(0), n), T2 = P(n + 1).copyFrom(pT.at(n), n), T3 = P(n + 6).copyFrom(pT.at(2 * n), n + 6);
         T1.set(n, b[10]);
         T2.set(0, mod(T2.get(0) - b[10], r)); T2.set(n, b[11]);
         T3.set(0, mod(T3.get(0) - b[11], r));
+        yield;
         [pts.T1, pts.T2, pts.T3] = commit(key, [T1, T2, T3]);
 
         // ---- ROUND 4 (:686-708)
@@ -242,6 +284,7 @@ function proveWith(key, wt, blindingMont, P, track) {
         for (const nm of ["T1", "T2", "T3"]) tr.point(pts[nm]);
         const xi = tr.challenge(), wv = f.unmont(wN), xiw = xi * wv % r;
         const S1c = P(n, false).copyFrom(key.sec(12, 0), n), S2c = P(n, false).copyFrom(key.sec(12, 5 * n), n), S3c = P(n, false).copyFrom(key.sec(12, 10 * n), n);
+        yield;
         evs.eval_a = pA.evaluate(xi); evs.eval_b = pB.evaluate(xi); evs.eval_c = pC.evaluate(xi);
         evs.eval_s1 = S1c.evaluate(xi); evs.eval_s2 = S2c.evaluate(xi); evs.eval_zw = pZ.evaluate(xiw);
 
@@ -282,6 +325,7 @@ function proveWith(key, wt, blindingMont, P, track) {
         const Wxiw = P(pZ.n, false).copyFrom(pZ.ptr, pZ.n);
         Wxiw.addScalar(mod(-ezw, r));
         call("zkmi_poly_div_by_zerofier_dev", f.cid, Wxiw.ptr, Wxiw.n, 1, mont(xiw));
+        yield;
         [pts.Wxi, pts.Wxiw] = commit(key, [Wxi, Wxiw]);
 
         const proof = {};
@@ -295,5 +339,5 @@ function proveWith(key, wt, blindingMont, P, track) {
     }
 }
 
-module.exports = { prove, PlonkKey,
+module.exports = { prove, proveMany, PlonkKey,
                    _internals: { addon, call, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN } };

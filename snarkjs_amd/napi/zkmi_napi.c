@@ -605,7 +605,8 @@ static const struct { const char* name; const char* sig; } g_call_table[] = {
     {"zkmi_fr_batch_dev", "i i d d i"}, {"zkmi_ntt_dev", "i d d i i B32 B32"},
     {"zkmi_msm_table_build", "i i d i b8"}, {"zkmi_msm_table_dev", "i d i i b96"}, {"zkmi_msm_table_multi_dev", "i b8 b8 i i b96"}, {"zkmi_msm_table_release", "i"},
     {"zkmi_plonk_gather_wires_dev", "i d i d i d d d i i d d d"},
-    {"zkmi_plonk_compute_z_dev", "i d d d d d d i b32 b32 b32 b32 b32 d"},
+    {"zkmi_plonk_compute_z_dev", "i d d d d d d i b32 b32 b32 b32 b32 d"}, {"zkmi_plonk_compute_z_enqueue", "i d d d d d d i b32 b32 b32 b32 b32 d"},
+    {"zkmi_pipeline_select", "i"}, {"zkmi_synchronize", ""},
     {"zkmi_plonk_compute_t_dev", "i b112 i i b352 b32 b32 b32 b32 b32 b32 b32 b32 d d"},
     {"zkmi_fflonk_t0_dev", "i b112 i i d"}, {"zkmi_fflonk_t1_dev", "i d d i b96 b32 d d"}, {"zkmi_fflonk_t2_dev", "i b112 i b96 b32 b32 b32 b32 b32 b32 d d"},
     {"zkmi_poly_degree_dev", "i d i b8"}, {"zkmi_keccak256", "B@1 i b32"},

@@ -3,7 +3,7 @@
 // Run:  node tests/js/plonk_native_golden.js
 "use strict";
 const fs = require("fs"), path = require("path"), crypto = require("crypto");
-const { prove, PlonkKey } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "plonk_native.js"));
+const { prove, proveMany, PlonkKey, _internals } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "plonk_native.js"));
 const GOLD = path.join(__dirname, "..", "golden");
 const sha = (b) => crypto.createHash("sha256").update(b).digest("hex");
 let fails = 0;
@@ -24,6 +24,25 @@ for (const tag of ["plonk_bn128_small", "plonk_bn128_n2048", "plonk_bls12381_sma
     let threw = false;
     try { prove(zkey, wtns.subarray(0, wtns.length - 32)); } catch (e) { threw = /Invalid witness length/.test(e.message); }
     check(tag + ": truncated witness is rejected", threw);
+}
+// throughput mode (two generator proofs on the library's two pipeline slots): the same proofs as prove(), golden first; an error in the middle
+// fails the call, leaves slot 0 active and the library usable
+for (const tag of ["plonk_bn128_n2048", "plonk_bls12381_small"]) {
+    const g = JSON.parse(fs.readFileSync(path.join(GOLD, tag + ".json")));
+    const zkey = new Uint8Array(fs.readFileSync(path.join(GOLD, tag + ".zkey"))), wtns = new Uint8Array(fs.readFileSync(path.join(GOLD, tag + ".wtns")));
+    const key = new PlonkKey(zkey);
+    const blinds = [g.blinding_mont.map(hexb)];
+    for (let k = 1; k < 5; k++) { const b = []; for (let i = 0; i < 11; i++) b.push(key.f.mont(BigInt(7000 + 131 * k + 17 * i))); blinds.push(b); }
+    const serial = blinds.map((b) => prove(key, wtns, b));
+    const many = proveMany(key, blinds.map(() => wtns), blinds);
+    check(tag + ": proveMany == prove, proof by proof (5 proofs, two in flight)", JSON.stringify(many) === JSON.stringify(serial) && sha(JSON.stringify(many[0].proof)) === g.proof_sha256);
+    const bad = wtns.slice(); bad[bad.length - 32] ^= 1;
+    let msg = "";
+    try { proveMany(key, [wtns, bad, wtns, wtns], blinds.slice(0, 4)); } catch (e) { msg = e.message; }
+    check(tag + ": a bad witness in the middle fails the call with the reference's message", /Copy constraints does not match|not divisible|not well calculated/.test(msg));
+    check(tag + ": the library is usable afterwards", JSON.stringify(proveMany(key, [wtns, wtns, wtns], blinds.slice(0, 3))) === JSON.stringify(serial.slice(0, 3)) &&
+          JSON.stringify(prove(key, wtns, blinds[1])) === JSON.stringify(serial[1]));
+    key.release();
 }
 let threw = false;
 try { prove(new Uint8Array(fs.readFileSync(path.join(GOLD, "groth16_bn128_n1024.zkey"))), new Uint8Array(64)); } catch (e) { threw = e.message === "zkey file is not plonk"; }

@@ -87,12 +87,12 @@ def test_ntt29_passes_opt_in_parity():
 
 
 @pytest.mark.skipif(os.environ.get("ZKMI_TEST_NESTED") == "1", reason="already the nested run")
-@pytest.mark.parametrize("env", [{"ZKMI_R29_REDUCE_G2": "1"}, {"ZKMI_R29_REDUCE_G2": "0", "ZKMI_R29_REDUCE": "0"}, {"ZKMI_ACC29_BLOCK": "64"}],
-                         ids=["g2-rowcol29-both-curves", "generic-rowcol-both-groups", "accum-64-thread-blocks"])
+@pytest.mark.parametrize("env", [{"ZKMI_R29_REDUCE_G2": "0", "ZKMI_R29_REDUCE": "0"}, {"ZKMI_ACC29_BLOCK": "64"}, {"ZKMI_R29_G2": "0"}],
+                         ids=["generic-rowcol-both-groups", "accum-64-thread-blocks", "generic-g2-accumulation"])
 def test_non_default_kernel_variants_parity(env):
-    """The A/B switches select kernels that the default configuration does not run on one curve or the other (Fq2 row / column sums on
-    unsaturated limbs are the default on BLS12-381 only; the generic 32-bit sums are no default any more where a table is resident): the proof
-    and MSM parity tests that reach those kernels are run again in a process with the switch flipped (the switches are read once per process)."""
+    """The A/B switches select kernels that the default configuration no longer runs where a window table is resident (the generic 32-bit row /
+    column sums of both groups, the generic Fq2 accumulation, other block shapes): the proof and MSM parity tests that reach those kernels are run
+    again in a process with the switch flipped (the switches are read once per process)."""
     import subprocess
     import sys
     sel = "synthetic_vs_oracle or valid_key_proof_verifies or msm_resident_tables or two_proofs_in_flight"

@@ -11,7 +11,8 @@ timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench.json 2> $O
 timeout 300 python bench.py --steps 20 --warmup 3 --pipeline 1 --no-cpu-baseline --no-napi-wall > $O/bench_serial.json 2>/dev/null
 timeout 300 python bench.py --steps 20 --warmup 3 --b-zero-every 3 --no-cpu-baseline --no-napi-wall > $O/bench_sparse_b.json 2>/dev/null
 timeout 300 python bench.py --steps 20 --warmup 3 --witness mixed --no-cpu-baseline --no-napi-wall > $O/bench_mixed_witness.json 2>/dev/null
-timeout 600 python bench.py --workload plonk --log-n 20 --steps 8 --warmup 3 > $O/bench_plonk_2p20.json 2>/dev/null
+timeout 600 python bench.py --workload plonk --log-n 20 --steps 12 --warmup 4 > $O/bench_plonk_2p20.json 2>/dev/null
+timeout 600 python bench.py --workload plonk --log-n 20 --steps 12 --warmup 4 --pipeline 1 --no-cpu-baseline > $O/bench_plonk_2p20_serial.json 2>/dev/null
 timeout 600 python bench.py --curve bls12381 --steps 8 --warmup 2 --no-cpu-baseline --no-napi-wall > $O/bench_bls12381_2p20.json 2>/dev/null
 timeout 300 python bench.py --workload fflonk --log-n 18 --steps 5 --warmup 1 > $O/bench_fflonk_2p18.json 2>/dev/null
 timeout 900 python bench.py --log-n 24 --steps 3 --warmup 1 --no-cpu-baseline --no-napi-wall > $O/bench_bn128_2p24.json 2>/dev/null
@@ -19,13 +20,13 @@ timeout 900 python bench.py --log-n 24 --steps 3 --warmup 1 --no-cpu-baseline --
 # per-launch average would not be the kernel's own time (bench.py measures its live roofline time on serial proofs for the same reason)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python bench.py --steps 20 --warmup 3 --pipeline 1 --no-cpu-baseline --no-napi-wall > $O/bench_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bls -o bls -- python bench.py --curve bls12381 --steps 6 --warmup 2 --pipeline 1 --no-cpu-baseline --no-napi-wall > $O/bench_bls_under_rocprof.json 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/stats_plonk -o plonk -- python bench.py --workload plonk --log-n 20 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_plonk_under_rocprof.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/stats_plonk -o plonk -- python bench.py --workload plonk --log-n 20 --steps 4 --warmup 3 --pipeline 1 --no-cpu-baseline > $O/bench_plonk_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-napi-wall > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-napi-wall > /dev/null 2>&1
 tools/bin/fieldbench29 > $O/fieldbench29.txt 2>&1; tools/bin/maddbench29 >> $O/fieldbench29.txt 2>&1
 # keep the merge under the gpurun limit: the per-dispatch traces are large, the stats files are what gets published
 rm -f $O/stats/*kernel_trace.csv $O/stats_bls/*kernel_trace.csv $O/pmc_fetch/*kernel_trace.csv $O/pmc_write/*kernel_trace.csv
-for f in bench bench_serial bench_sparse_b bench_mixed_witness bench_plonk_2p20 bench_bls12381_2p20 bench_fflonk_2p18 bench_bn128_2p24; do python - "$O/$f.json" <<'PY'
+for f in bench bench_serial bench_sparse_b bench_mixed_witness bench_plonk_2p20 bench_plonk_2p20_serial bench_bls12381_2p20 bench_fflonk_2p18 bench_bn128_2p24; do python - "$O/$f.json" <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], d["value"], d["unit"], d["ms_per_step"], "ms")

@@ -14,7 +14,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
-for f in ("bench", "bench_serial", "bench_sparse_b", "bench_mixed_witness", "bench_plonk_2p20", "bench_bls12381_2p20", "bench_bn128_2p24", "bench_fflonk_2p18"):
+for f in ("bench", "bench_serial", "bench_sparse_b", "bench_mixed_witness", "bench_plonk_2p20", "bench_plonk_2p20_serial", "bench_bls12381_2p20", "bench_bn128_2p24", "bench_fflonk_2p18"):
     if os.path.exists(f"{src}/{f}.json"):
         shutil.copy(f"{src}/{f}.json", f"{dst}/{tag}_{f}.json")
 line = lambda f: json.loads(open(f).read().strip().splitlines()[-1])
