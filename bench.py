@@ -197,7 +197,7 @@ def bench_plonk(args, rank, world, dist, torch):
     barrier()
     elapsed = time.perf_counter() - t0
     lat = []
-    for _ in range(3 if two else 0):                                    # single-proof latency beside the throughput figure
+    for _ in range(6 if two else 0):                                    # single-proof latency beside the throughput figure
         tl = time.perf_counter()
         plonk.prove(key, wtns)
         lat.append(time.perf_counter() - tl)
@@ -223,7 +223,7 @@ def bench_plonk(args, rank, world, dist, torch):
             "config": {"workload": f"BN254 {proto.upper()} prove, 2^{lg} constraints, synthetic valid key" + (" (BASELINE configs[3])" if proto == "plonk" else "") + "; key resident, witness uploaded per proof",
                        "curve": "bn128", "log_n": lg, "parallelism": f"replica x{world}"},
             "roofline": roof,
-            "proofs_in_flight": 2 if two else 1, "latency_ms_single_proof": round(min(lat) * 1e3, 3) if lat else None,
+            "proofs_in_flight": 2 if two else 1, "latency_ms_single_proof": round(min(lat) * 1e3, 3) if lat else None, "latency_ms_serial_proofs": [round(x * 1e3, 2) for x in lat],
             "public_signal": res["publicSignals"][0][:24] + "..."}
         if world == 1 and not args.no_cpu_baseline and proto == "fflonk":
             out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "reference", "sample": "no live CPU leg for FFLONK: see reference_wasm",

@@ -255,8 +255,8 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         const eZ = track(pZ.extendedEvals(4));
         pZ = track(pZ.blinded([b[9], b[8], b[7]]));
         yield;
-        if (Zb.get(0) !== 1n) throw new Error("Copy constraints does not match");                        // the first wait after computeZ: its check (:437-439)
         [pts.Z] = commit(key, [pZ]);
+        if (Zb.get(0) !== 1n) throw new Error("Copy constraints does not match");                        // computeZ's check (:437-439), read behind the commitment's own wait
 
         // ---- ROUND 3 (:457-684)
         tr.reset(); tr.scalar(beta); tr.scalar(gamma); tr.point(pts.Z);

@@ -357,9 +357,9 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     eZ = pZ.extended_evals(4)
     pZ = pZ.blinded([b[9], b[8], b[7]])
     yield
-    if Zb.get(0) != 1:                                                                   # the first wait after computeZ: its check (:437-439)
-        raise ValueError("Copy constraints does not match")
     pts["Z"], = _commit(key, pZ)
+    if Zb.get(0) != 1:                                                                   # computeZ's check (:437-439), read behind the commitment's
+        raise ValueError("Copy constraints does not match")                              # own wait: no extra bubble between the transforms and the MSM
 
     # ---- ROUND 3 (:457-684)
     tr.reset(); tr.scalar(beta); tr.scalar(gamma); tr.point(pts["Z"])
