@@ -157,7 +157,7 @@ function prove(zkey, wtns, blindingMont = null) {
     const P = (n, zero = true) => { const p = new Poly(key.f, n, zero); polys.push(p); return p; };
     const track = (p) => { polys.push(p); return p; };
     try {
-        const steps = proveSteps(key, wtns instanceof Uint8Array ? wtns : new Uint8Array(wtns), blindingMont, P, track);
+        const steps = proveSteps(key, (wtns instanceof Uint8Array || wtns instanceof PlonkWitness) ? wtns : new Uint8Array(wtns), blindingMont, P, track);
         for (;;) { const s = steps.next(); if (s.done) return s.value; }
     } finally {
         polys.forEach((p) => p.free());
@@ -181,7 +181,7 @@ function proveMany(zkey, wtnsList, blindingMonts = null) {
                 const polys = [], w = wtnsList[nxt];
                 const P = (n, zero = true) => { const p = new Poly(key.f, n, zero); polys.push(p); return p; };
                 const track = (p) => { polys.push(p); return p; };
-                live.push({ slot: free.shift(), idx: nxt, polys, steps: proveSteps(key, w instanceof Uint8Array ? w : new Uint8Array(w), blindingMonts ? blindingMonts[nxt] : null, P, track) });
+                live.push({ slot: free.shift(), idx: nxt, polys, steps: proveSteps(key, (w instanceof Uint8Array || w instanceof PlonkWitness) ? w : new Uint8Array(w), blindingMonts ? blindingMonts[nxt] : null, P, track) });
                 nxt++;
             }
             for (const ent of live.slice()) {
@@ -203,30 +203,11 @@ function proveMany(zkey, wtnsList, blindingMonts = null) {
 // plonk.prove as a generator: `yield` stands right before every long blocking call; everything between two yields only enqueues work
 function* proveSteps(key, wt, blindingMont, P, track) {
     const f = key.f, r = f.r, n = key.n, power = key.power;
-    const { dv, s: ws } = readSections(wt);
-    const n8 = dv.getUint32(ws[1][0], true), wq = fromLE(wt.subarray(ws[1][0] + 4, ws[1][0] + 4 + n8)), nWitness = dv.getUint32(ws[1][0] + 4 + n8, true);
-    if (key.r !== wq) throw new Error("Curve of the witness does not match the curve of the proving key");
-    if (nWitness !== key.nVars - key.nAdditions) throw new Error(`Invalid witness length. Circuit: ${key.nVars}, witness: ${nWitness}, ${key.nAdditions}`);
-    if (ws[2][1] < nWitness * 32 || ws[2][0] + nWitness * 32 > wt.length) throw new Error("Invalid witness length: the wtns data section is shorter than its header says");
-    const wit = wt.slice(ws[2][0], ws[2][0] + nWitness * 32);
-    const pub = [];
-    for (let i = 1; i <= key.nPublic; i++) pub.push(fromLE(wit.subarray(32 * i, 32 * i + 32)));
-    wit.fill(0, 0, 32);                                                                                     // :94-96
+    const own = !(wt instanceof PlonkWitness);
+    const wres = own ? new PlonkWitness(key, wt) : wt;
+    const { pub, dWit, dInt, nW } = wres;
     const b = [0n];
     for (let i = 0; i < 11; i++) b.push(blindingMont ? f.unmont(blindingMont[i]) : fromLE(crypto.randomBytes(64)) % r);
-
-    // calculateAdditions (:174-204): sequential, on the host
-    const internal = [], nW = key.nVars - key.nAdditions;
-    const getWitness = (idx) => idx < nW ? fromLE(wit.subarray(32 * idx, 32 * idx + 32)) : (idx < key.nVars ? internal[idx - nW] : 0n);
-    const adv = new DataView(key.additions.buffer, key.additions.byteOffset, key.additions.byteLength);
-    for (let i = 0; i < key.nAdditions; i++) {
-        const o = 72 * i, s1 = adv.getUint32(o, true), s2 = adv.getUint32(o + 4, true);
-        const f1 = f.unmont(key.additions.subarray(o + 8, o + 40)), f2 = f.unmont(key.additions.subarray(o + 40, o + 72));
-        internal.push((f1 * getWitness(s1) + f2 * getWitness(s2)) % r);
-    }
-    const dWit = devFrom(wit), intBytes = new Uint8Array(Math.max(32, 32 * internal.length));
-    internal.forEach((v, i) => intBytes.set(toLE(v, 32), 32 * i));
-    const dInt = devFrom(intBytes);
     try {
         const tr = new Transcript(f), pts = {}, evs = {};
         const wN = f.root(power), w4N = f.root(power + 2), w2 = f.root(2), mont = (v) => f.mont(v);
@@ -335,9 +316,42 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         proof.curve = key.curveName;
         return { proof, publicSignals: pub.map((p) => p.toString()) };
     } finally {
-        devFree(dWit); devFree(dInt);
+        if (own) wres.release();
     }
 }
 
-module.exports = { prove, proveMany, PlonkKey,
+// A witness resident on the device for any number of proofs against `key` (the reference reads the .wtns file once per proof,
+// src/plonk_prove.js:83-97): header checks, public signals, calculateAdditions (:174-204, sequential on the host), signals and internal signals
+// uploaded once; read-only afterwards, so proofs on both pipeline slots share it.
+class PlonkWitness {
+    constructor(key, wtIn) {
+        const wt = wtIn instanceof Uint8Array ? wtIn : new Uint8Array(wtIn);
+        const f = key.f, r = f.r;
+        const { dv, s: ws } = readSections(wt);
+        const n8 = dv.getUint32(ws[1][0], true), wq = fromLE(wt.subarray(ws[1][0] + 4, ws[1][0] + 4 + n8)), nWitness = dv.getUint32(ws[1][0] + 4 + n8, true);
+        if (key.r !== wq) throw new Error("Curve of the witness does not match the curve of the proving key");
+        if (nWitness !== key.nVars - key.nAdditions) throw new Error(`Invalid witness length. Circuit: ${key.nVars}, witness: ${nWitness}, ${key.nAdditions}`);
+        if (ws[2][1] < nWitness * 32 || ws[2][0] + nWitness * 32 > wt.length) throw new Error("Invalid witness length: the wtns data section is shorter than its header says");
+        const wit = wt.slice(ws[2][0], ws[2][0] + nWitness * 32);
+        this.pub = [];
+        for (let i = 1; i <= key.nPublic; i++) this.pub.push(fromLE(wit.subarray(32 * i, 32 * i + 32)));
+        wit.fill(0, 0, 32);                                                                                 // :94-96
+        const internal = [], nW = key.nVars - key.nAdditions;
+        const getWitness = (idx) => idx < nW ? fromLE(wit.subarray(32 * idx, 32 * idx + 32)) : (idx < key.nVars ? internal[idx - nW] : 0n);
+        const adv = new DataView(key.additions.buffer, key.additions.byteOffset, key.additions.byteLength);
+        for (let i = 0; i < key.nAdditions; i++) {
+            const o = 72 * i, s1 = adv.getUint32(o, true), s2 = adv.getUint32(o + 4, true);
+            const f1 = f.unmont(key.additions.subarray(o + 8, o + 40)), f2 = f.unmont(key.additions.subarray(o + 40, o + 72));
+            internal.push((f1 * getWitness(s1) + f2 * getWitness(s2)) % r);
+        }
+        const intBytes = new Uint8Array(Math.max(32, 32 * internal.length));
+        internal.forEach((v, i) => intBytes.set(toLE(v, 32), 32 * i));
+        this.nW = nW;
+        this.dWit = devFrom(wit);
+        this.dInt = devFrom(intBytes);
+    }
+    release() { if (this.dWit) { devFree(this.dWit); devFree(this.dInt); this.dWit = this.dInt = 0; } }
+}
+
+module.exports = { prove, proveMany, PlonkKey, PlonkWitness,
                    _internals: { addon, call, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN } };

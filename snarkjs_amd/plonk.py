@@ -179,6 +179,50 @@ class PlonkKey:
             self.ptau_table = C.c_uint64(0)
 
 
+class PlonkWitness:
+    """A witness resident on the device for any number of proofs against `key` (the reference reads the .wtns file once per proof,
+    src/plonk_prove.js:83-97): header checks, the public signals, calculateAdditions (:174-204, sequential on the host: each internal signal may
+    depend on earlier ones), the signals and the internal signals uploaded once. Read-only afterwards: proofs on both pipeline slots share it."""
+
+    def __init__(self, key, wt):
+        f, r = key.f, key.f.r
+        ws = {}
+        off = 12
+        for _ in range(struct.unpack_from("<I", wt, 8)[0]):
+            t, ln = struct.unpack_from("<IQ", wt, off)
+            ws[t] = (off + 12, ln)
+            off += 12 + ln
+        n8 = struct.unpack_from("<I", wt, ws[1][0])[0]
+        wq = int.from_bytes(wt[ws[1][0] + 4:ws[1][0] + 4 + n8], "little")
+        n_witness = struct.unpack_from("<I", wt, ws[1][0] + 4 + n8)[0]
+        if key.r != wq:
+            raise ValueError("Curve of the witness does not match the curve of the proving key")
+        if n_witness != key.nVars - key.nAdditions:
+            raise ValueError(f"Invalid witness length. Circuit: {key.nVars}, witness: {n_witness}, {key.nAdditions}")
+        wit = np.frombuffer(wt, np.uint8, n_witness * 32, ws[2][0])                       # a view: the signal 0 slot is cleared on the device
+        self.public = [int.from_bytes(bytes(wit[32 * i:32 * i + 32]), "little") for i in range(1, key.nPublic + 1)]
+        internal = []
+        self.nW = nW = key.nVars - key.nAdditions
+
+        def get_witness(idx):
+            if idx < nW:
+                return int.from_bytes(bytes(wit[32 * idx:32 * idx + 32]), "little") if idx else 0    # signal 0 reads as 0 (:94-96)
+            return internal[idx - nW] if idx < key.nVars else 0
+        for i in range(key.nAdditions):
+            o = 72 * i
+            s1, s2 = struct.unpack_from("<II", key.additions, o)
+            f1, f2 = f.unmont(key.additions[o + 8:o + 40]), f.unmont(key.additions[o + 40:o + 72])
+            internal.append((f1 * get_witness(s1) + f2 * get_witness(s2)) % r)
+        self.d_wit = zkmi.DeviceBuffer.from_host(wit)
+        zkmi.check(zkmi.lib().zkmi_memset_dev(self.d_wit.ptr, 0, 32))                     # :94-96
+        self.d_int = zkmi.DeviceBuffer.from_host(np.frombuffer(b"".join(v.to_bytes(32, "little") for v in internal) or bytes(32), np.uint8))
+        zkmi.check(zkmi.lib().zkmi_synchronize())
+
+    def release(self):
+        self.d_wit.free()
+        self.d_int.free()
+
+
 class _Transcript:
     def __init__(self, f):
         self.f, self.parts = f, []
@@ -284,43 +328,12 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
 
     key = zkey if isinstance(zkey, PlonkKey) else PlonkKey(data(zkey))
     f, L, r, n, power = key.f, zkmi.lib(), key.f.r, key.n, key.power
-    wt = data(witness_file)
-    ws = {}
-    off = 12
-    for _ in range(struct.unpack_from("<I", wt, 8)[0]):
-        t, ln = struct.unpack_from("<IQ", wt, off)
-        ws[t] = (off + 12, ln)
-        off += 12 + ln
-    n8 = struct.unpack_from("<I", wt, ws[1][0])[0]
-    wq = int.from_bytes(wt[ws[1][0] + 4:ws[1][0] + 4 + n8], "little")
-    n_witness = struct.unpack_from("<I", wt, ws[1][0] + 4 + n8)[0]
-    if key.r != wq:
-        raise ValueError("Curve of the witness does not match the curve of the proving key")
-    if n_witness != key.nVars - key.nAdditions:
-        raise ValueError(f"Invalid witness length. Circuit: {key.nVars}, witness: {n_witness}, {key.nAdditions}")
-    wit = np.frombuffer(wt, np.uint8, n_witness * 32, ws[2][0])                           # a view: the signal 0 slot is cleared on the device
-    public = [int.from_bytes(bytes(wit[32 * i:32 * i + 32]), "little") for i in range(1, key.nPublic + 1)]
+    wres = witness_file if isinstance(witness_file, PlonkWitness) else PlonkWitness(key, data(witness_file))
+    public, d_wit, d_int, nW = wres.public, wres.d_wit, wres.d_int, wres.nW
     if blinding_mont is None:
         b = [0] + [int.from_bytes(os.urandom(64), "little") % r for _ in range(11)]
     else:
         b = [0] + [f.unmont(x) for x in blinding_mont]
-
-    # calculateAdditions (:174-204): each internal signal may depend on earlier ones — sequential, on the host
-    internal = []
-    nW = key.nVars - key.nAdditions
-
-    def get_witness(idx):
-        if idx < nW:
-            return int.from_bytes(bytes(wit[32 * idx:32 * idx + 32]), "little") if idx else 0    # signal 0 reads as 0 (:94-96)
-        return internal[idx - nW] if idx < key.nVars else 0
-    for i in range(key.nAdditions):
-        o = 72 * i
-        s1, s2 = struct.unpack_from("<II", key.additions, o)
-        f1, f2 = f.unmont(key.additions[o + 8:o + 40]), f.unmont(key.additions[o + 40:o + 72])
-        internal.append((f1 * get_witness(s1) + f2 * get_witness(s2)) % r)
-    d_wit = zkmi.DeviceBuffer.from_host(wit)
-    zkmi.check(L.zkmi_memset_dev(d_wit.ptr, 0, 32))                                       # :94-96
-    d_int = zkmi.DeviceBuffer.from_host(np.frombuffer(b"".join(v.to_bytes(32, "little") for v in internal) or bytes(32), np.uint8))
 
     tr = _Transcript(f)
     pts, evs = {}, {}

@@ -3,7 +3,7 @@
 // Run:  node tests/js/plonk_native_golden.js
 "use strict";
 const fs = require("fs"), path = require("path"), crypto = require("crypto");
-const { prove, proveMany, PlonkKey, _internals } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "plonk_native.js"));
+const { prove, proveMany, PlonkKey, PlonkWitness } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "plonk_native.js"));
 const GOLD = path.join(__dirname, "..", "golden");
 const sha = (b) => crypto.createHash("sha256").update(b).digest("hex");
 let fails = 0;
@@ -36,6 +36,10 @@ for (const tag of ["plonk_bn128_n2048", "plonk_bls12381_small"]) {
     const serial = blinds.map((b) => prove(key, wtns, b));
     const many = proveMany(key, blinds.map(() => wtns), blinds);
     check(tag + ": proveMany == prove, proof by proof (5 proofs, two in flight)", JSON.stringify(many) === JSON.stringify(serial) && sha(JSON.stringify(many[0].proof)) === g.proof_sha256);
+    const wres = new PlonkWitness(key, wtns);               // resident witness shared by the proofs of both slots
+    check(tag + ": proveMany over a resident witness", JSON.stringify(proveMany(key, blinds.map(() => wres), blinds)) === JSON.stringify(serial) &&
+          JSON.stringify(prove(key, wres, blinds[2])) === JSON.stringify(serial[2]));
+    wres.release();
     const bad = wtns.slice(); bad[bad.length - 32] ^= 1;
     let msg = "";
     try { proveMany(key, [wtns, bad, wtns, wtns], blinds.slice(0, 4)); } catch (e) { msg = e.message; }

@@ -379,6 +379,10 @@ def test_plonk_two_proofs_in_flight_equal_serial(env, golden_dir, tag, lg):
     serial = [plonk.prove(key, wtns, blinding_mont=b) for b in blinds]
     many = plonk.prove_many(key, [wtns] * len(blinds), blinding_monts=blinds)
     assert [m["proof"] for m in many] == [s_["proof"] for s_ in serial]
+    wres = plonk.PlonkWitness(key, wtns)                       # the witness resident on the device, shared by the proofs of both slots
+    assert [m["proof"] for m in plonk.prove_many(key, [wres] * len(blinds), blinding_monts=blinds)] == [s_["proof"] for s_ in serial]
+    assert plonk.prove(key, wres, blinding_mont=blinds[2])["proof"] == serial[2]["proof"]
+    wres.release()
     assert all(m["publicSignals"] == serial[0]["publicSignals"] for m in many)
     if g:
         assert many[0]["proof"] == g["proof"]
