@@ -58,14 +58,29 @@ def drain_c_stdout_to_stderr():
 
 
 def box_calibration(L):
-    """Two 20-ms probes of the device this run landed on (include/zkmi.h: zkmi_calibrate_box), AFTER the timed region: the boxes differ,
-    and a low line next to a `mul29_gmul_per_s` well under 150 or a gather rate well under 6 TB/s says so."""
+    """Probes of the device this run landed on (include/zkmi.h: zkmi_calibrate_box, zkmi_calibrate_code_fetch), AFTER the timed region: the
+    boxes differ, and a low line next to a `mul29_gmul_per_s` well under 150, a gather rate well under 6 TB/s or a code-fetch ratio well under
+    one says so; rocm-smi's clocks / power state of the card go beside them."""
     import ctypes
     a, b = ctypes.c_double(0), ctypes.c_double(0)
     if L.zkmi_calibrate_box(ctypes.byref(a), ctypes.byref(b)) != 0:
         return None
-    return {"mul29_gmul_per_s": round(a.value, 1), "gather128_gb_per_s": round(b.value, 1), "healthy": {"mul29_gmul_per_s": 150.0, "gather128_gb_per_s": 6000.0},
-            "note": "two dependent chains of Montgomery products on 29-bit limbs, 8 workgroups per CU; 16 dependent random 128-byte gathers per lane over a 2 GiB table; after the timed region; `healthy` = what this probe measures on a box that gives ~100 proofs/s"}
+    out = {"mul29_gmul_per_s": round(a.value, 1), "gather128_gb_per_s": round(b.value, 1), "healthy": {"mul29_gmul_per_s": 150.0, "gather128_gb_per_s": 6000.0},
+           "note": "two dependent chains of Montgomery products on 29-bit limbs, 8 workgroups per CU; 16 dependent random 128-byte gathers per lane over a 2 GiB table; after the timed region; `healthy` = what this probe measures on a box that gives ~100 proofs/s"}
+    c, d = ctypes.c_double(0), ctypes.c_double(0)
+    if hasattr(L, "zkmi_calibrate_code_fetch") and L.zkmi_calibrate_code_fetch(ctypes.byref(c), ctypes.byref(d)) == 0 and c.value > 0:
+        out["code_fetch"] = {"loop_17KB_gmul_per_s": round(c.value, 1), "loop_210KB_gmul_per_s": round(d.value, 1), "big_over_small": round(d.value / c.value, 3),
+                             "note": "the same product chain as straight-line loops of ~17 KB and ~210 KB of code at 2 waves per SIMD: the cost of instruction fetch beyond the 64 KB instruction cache on this box"}
+    try:
+        import subprocess
+        smi = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showperflevel", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
+        if smi.returncode == 0 and smi.stdout.strip():
+            card = next(iter(json.loads(smi.stdout).values()))
+            keep = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "power", "performance level", "temperature (sensor junction)", "temperature (sensor edge)"))}
+            out["rocm_smi"] = dict(list(keep.items())[:12])
+    except Exception:
+        pass
+    return out
 
 
 def relaunch_if_needed(args):

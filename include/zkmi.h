@@ -310,6 +310,9 @@ int zkmi_group_convert_dev(int curve, int group, int kind, const void* d_in, voi
  * 29-bit limbs (two dependent chains per lane, 8 workgroups per CU: about 150 G products/s on a healthy MI355X) and 16 dependent random 128-byte
  * gathers per lane over a 2 GiB table (about 6 TB/s on a healthy box). */
 int zkmi_calibrate_box(double* mul29_gmul_per_s, double* gather128_gb_per_s);
+/* Third probe: the same product chain as straight-line loops of ~17 KB and ~210 KB of code at two waves per SIMD; big / small < 1 is the cost of
+ * instruction fetch beyond the 64 KB instruction cache on this box (the accumulation loops of the 14-limb curve are that large). */
+int zkmi_calibrate_code_fetch(double* small_loop_gmul_per_s, double* big_loop_gmul_per_s);
 
 /* ---- utilities --------------------------------------------------------------------------------------------------- */
 /* Synthetic base table of SURVEY.md §8d: P_i = (f*g^i mod r)*G written to device memory as affine Montgomery points
