@@ -71,6 +71,8 @@ def box_calibration(L):
     if hasattr(L, "zkmi_calibrate_code_fetch") and L.zkmi_calibrate_code_fetch(ctypes.byref(c), ctypes.byref(d)) == 0 and c.value > 0:
         out["code_fetch"] = {"loop_17KB_gmul_per_s": round(c.value, 1), "loop_210KB_gmul_per_s": round(d.value, 1), "big_over_small": round(d.value / c.value, 3),
                              "note": "the same product chain as straight-line loops of ~17 KB and ~210 KB of code at 2 waves per SIMD: the cost of instruction fetch beyond the 64 KB instruction cache on this box"}
+    if hasattr(L, "zkmi_compact_code"):
+        out["compact_code_mask"] = int(L.zkmi_compact_code())     # which MSM kernels ran with called products on this box (include/zkmi.h)
     try:
         import subprocess
         smi = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showperflevel", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
@@ -206,15 +208,22 @@ def bench_plonk(args, rank, world, dist, torch):
     two = args.pipeline == 2 and hasattr(plonk, "prove_many")          # throughput mode: two proofs in flight from this one host thread
     if two:
         plonk.prove_many(key, [wtns, wtns])                             # size the second slot's buffers outside the timed region
+    per_proof = []
+    import gc
+    gc.collect()
+    gc.disable()                                                        # a cyclic collection of the Python host (~45 ms) is not part of a proof
     barrier()
     t0 = time.perf_counter()
     if two:
         res = plonk.prove_many(key, [wtns] * args.steps)[-1]            # EXACTLY args.steps whole proofs
     else:
         for _ in range(args.steps):
+            tp = time.perf_counter()
             res = plonk.prove(key, wtns)
+            per_proof.append(time.perf_counter() - tp)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     lat = []
     for _ in range(6 if two else 0):                                    # single-proof latency beside the throughput figure
         tl = time.perf_counter()
@@ -247,7 +256,7 @@ def bench_plonk(args, rank, world, dist, torch):
             "config": {"workload": f"BN254 {proto.upper()} prove, 2^{lg} constraints, synthetic valid key" + (" (BASELINE configs[3])" if proto == "plonk" else "") + "; key " + ("and witness resident" if wtns is not wtns_host else "resident, witness uploaded per proof"),
                        "curve": "bn128", "log_n": lg, "parallelism": f"replica x{world}"},
             "roofline": roof,
-            "proofs_in_flight": 2 if two else 1, "latency_ms_single_proof": round(min(lat) * 1e3, 3) if lat else None, "latency_ms_serial_proofs": [round(x * 1e3, 2) for x in lat],
+            "proofs_in_flight": 2 if two else 1, "host_gc": "Python's cyclic collector is off inside the timed region (timeit's convention)", "latency_ms_single_proof": round(min(lat) * 1e3, 3) if lat else None, "latency_ms_serial_proofs": [round(x * 1e3, 2) for x in lat], "timed_region_ms_per_proof": [round(x * 1e3, 2) for x in per_proof],
             "latency_ms_with_witness_upload": [round(x * 1e3, 2) for x in lat_up],
             "public_signal": res["publicSignals"][0][:24] + "..."}
         if world == 1 and not args.no_cpu_baseline and proto == "fflonk":

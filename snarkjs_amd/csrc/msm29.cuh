@@ -290,18 +290,35 @@ k_msm_rowcol_wave29(MsmReduceBatch rb, uint32_t W, uint32_t nb, uint32_t rbits, 
 // A square is (a0 + a1)(a0 - a1) + 2 a0 a1 u.  All operands of mul29_2 must be normalised.
 template <class C> struct F2x { Fp29<C> c0, c1; };
 template <class C, int K> ZK_HD Fp29<C> neg29(const Fp29<C>& a) { Fp29<C> r = sub29<C, K>(zero29<C>(), a); norm29(r); return r; }     // K p - a
+// Compact<C> (field29.cuh): the Fq2 product and square are CALLED — one copy of each in the code object instead of one per site (~15 per
+// addition); operands and result travel in registers by the AMDGPU calling convention, the excess over 32 argument registers through the stack
+#define ZK_F2_CALLS(C) (IsCompact<C>::value)
+template <class C> __host__ __device__ ZK_NOINLINE_DEV F2x<C> f2mul_call(F2x<C> a, F2x<C> b, Fp29<C> nb1) {
+    return F2x<C>{mul29_2_inl(a.c0, b.c0, a.c1, nb1), mul29_2_inl(a.c0, b.c1, a.c1, b.c0)};
+}
+// s = a0 + a1 (limbs < 2^(B+1)), d = a0 - a1 + KB p (normalised) prepared by the caller: the offset is a template constant there
+template <class C> __host__ __device__ ZK_NOINLINE_DEV F2x<C> f2sqr_call(Fp29<C> a0, Fp29<C> a1, Fp29<C> s, Fp29<C> d) {
+    Fp29<C> t = mul29_inl(a0, a1);
+    Fp29<C> c1 = add29(t, t);
+    norm29(c1);
+    return F2x<C>{mul29_inl(s, d), c1};
+}
 // a * b, nb1 = K p - b.c1 supplied by the caller (often shared by several products)
 template <class C> ZK_HD F2x<C> f2mul(const F2x<C>& a, const F2x<C>& b, const Fp29<C>& nb1) {
-    return F2x<C>{mul29_2(a.c0, b.c0, a.c1, nb1), mul29_2(a.c0, b.c1, a.c1, b.c0)};
+    if constexpr (ZK_F2_CALLS(C)) return f2mul_call<C>(a, b, nb1);
+    else return F2x<C>{mul29_2(a.c0, b.c0, a.c1, nb1), mul29_2(a.c0, b.c1, a.c1, b.c0)};
 }
 // a^2 for components <= KB (the offset of the difference)
 template <class C, int KB> ZK_HD F2x<C> f2sqr(const F2x<C>& a) {
     Fp29<C> s = add29(a.c0, a.c1), d = sub29<C, KB>(a.c0, a.c1);
     norm29(d);                                                     // s: limbs < 2^(B+1), d normalised
-    Fp29<C> t = mul29(a.c0, a.c1);
-    Fp29<C> c1 = add29(t, t);
-    norm29(c1);
-    return F2x<C>{mul29(s, d), c1};
+    if constexpr (ZK_F2_CALLS(C)) return f2sqr_call<C>(a.c0, a.c1, s, d);
+    else {
+        Fp29<C> t = mul29(a.c0, a.c1);
+        Fp29<C> c1 = add29(t, t);
+        norm29(c1);
+        return F2x<C>{mul29(s, d), c1};
+    }
 }
 template <class C, int K> ZK_HD F2x<C> f2sub(const F2x<C>& a, const F2x<C>& b) { return F2x<C>{sub29<C, K>(a.c0, b.c0), sub29<C, K>(a.c1, b.c1)}; }   // not normalised
 template <class C> ZK_HD void f2norm(F2x<C>& a) { norm29(a.c0); norm29(a.c1); }
@@ -344,7 +361,7 @@ template <class C, int T, bool PACK> struct LdsAcc29 {
 // VGPRs and no scratch. Inside one Fq2 product the two component chains still overlap. (Same speed on MI355X, r02 A/B: the kernel is bound
 // by integer issue, not by occupancy or spills — a 120-VGPR G1 variant at 4 waves per SIMD measured the same as well.)
 #ifndef ZK_Y3_SPLIT
-#define ZK_Y3_SPLIT(C) (Lim29<C>::NL > 9)
+#define ZK_Y3_SPLIT(C) (Lim29<C>::NL > 9 || IsCompact<C>::value)
 #endif
 #ifndef ZK_G2_PREFETCH
 #define ZK_G2_PREFETCH(C) true

@@ -50,6 +50,16 @@ int select_pipe(int p) {
 // boxes). Measured on a box in the fast state (tools/gpu_ab9.sh): contiguous ranges are SLOWER — buildABC 0.37 vs 0.14 ms, the NTT chain 1.29 vs
 // 1.11 ms, the G2 accumulation 3.5 vs 3.3 ms, 90.8 vs 99.8 proofs/s — presumably because a contiguous range interleaves over fewer HBM
 // channels than the driver's default placement. Default: off.
+extern "C" int zkmi_calibrate_code_fetch(double* small_loop_gmul_per_s, double* big_loop_gmul_per_s);
+static int g_compact_code = -1;
+int compact_code() {
+    if (g_compact_code >= 0) return g_compact_code;
+    if (getenv("ZKMI_COMPACT_CODE")) return g_compact_code = atoi(getenv("ZKMI_COMPACT_CODE")) & 15;
+    double small = 0, big = 0;
+    if (zkmi_calibrate_code_fetch(&small, &big) != ZKMI_OK || small <= 0) return g_compact_code = 0;
+    return g_compact_code = (big / small < 0.85) ? 15 : 0;
+}
+extern "C" int zkmi_compact_code(void) { return g_ctx.ready ? compact_code() : -1; }
 int dev_alloc_big(void** p, size_t bytes) {
     static const bool contig = getenv("ZKMI_CONTIG") && atoi(getenv("ZKMI_CONTIG")) == 1;
     static const size_t min_bytes = getenv("ZKMI_CONTIG_MIN") ? (size_t)atoll(getenv("ZKMI_CONTIG_MIN")) : ((size_t)2 << 20);

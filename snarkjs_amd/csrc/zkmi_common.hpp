@@ -81,6 +81,10 @@ struct Ctx {
 Ctx& ctx();
 int require_ctx();
 int select_pipe(int p);
+// Which kernels run their Compact instantiation (field29.cuh) on this box — bit 0: G1 accumulation of the 14-limb curve, 1: G2 accumulation,
+// 2: G1 row/column sums, 3: G2 row/column sums. ZKMI_COMPACT_CODE=<mask> fixes it; otherwise the box is probed once
+// (zkmi_calibrate_code_fetch: a 210 KB loop against a 17 KB loop of the same products) and every bit is set when the big loop runs below 0.85.
+int compact_code();
 int dev_alloc_big(void** p, size_t bytes);                // hipMalloc; ZKMI_CONTIG=1: physically contiguous VRAM first (zkmi_api.hip: measured slower)
 int ensure_aux_stream();                                  // creates Ctx::aux_stream (+ aux_ev) on first use                                     // make pipeline slot p (0 | 1) the active one
 // scratch buffer `name` with at least `bytes` capacity (contents undefined)

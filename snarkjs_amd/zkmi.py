@@ -24,7 +24,7 @@ SYMBOLS = [
     "zkmi_ntt", "zkmi_ntt_dev",
     "zkmi_fr_batch_apply_key", "zkmi_fr_batch_apply_key_dev", "zkmi_fr_batch", "zkmi_fr_batch_dev",
     "zkmi_groth16_join_abc", "zkmi_groth16_join_abc_dev",
-    "zkmi_base_cache_stats", "zkmi_gen_bases_from_scalars_dev", "zkmi_group_fft", "zkmi_group_fft_dev", "zkmi_group_batch_apply_key", "zkmi_group_batch_apply_key_dev", "zkmi_group_convert", "zkmi_group_convert_dev", "zkmi_calibrate_box", "zkmi_calibrate_code_fetch", "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_submit_dev", "zkmi_groth16_submit", "zkmi_groth16_sums_w_dev", "zkmi_groth16_collect", "zkmi_groth16_release", "zkmi_groth16_load_shard", "zkmi_groth16_sums_dev", "zkmi_groth16_chains_dev", "zkmi_groth16_sums_h_dev", "zkmi_groth16_finish", "zkmi_groth16_stage_ms",
+    "zkmi_base_cache_stats", "zkmi_gen_bases_from_scalars_dev", "zkmi_group_fft", "zkmi_group_fft_dev", "zkmi_group_batch_apply_key", "zkmi_group_batch_apply_key_dev", "zkmi_group_convert", "zkmi_group_convert_dev", "zkmi_calibrate_box", "zkmi_calibrate_code_fetch", "zkmi_compact_code", "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_submit_dev", "zkmi_groth16_submit", "zkmi_groth16_sums_w_dev", "zkmi_groth16_collect", "zkmi_groth16_release", "zkmi_groth16_load_shard", "zkmi_groth16_sums_dev", "zkmi_groth16_chains_dev", "zkmi_groth16_sums_h_dev", "zkmi_groth16_finish", "zkmi_groth16_stage_ms",
     "zkmi_gen_geometric_bases_dev", "zkmi_host_register", "zkmi_host_unregister", "zkmi_to_affine", "zkmi_point_add", "zkmi_fr_root",
     "zkmi_plonk_gather_wires_dev", "zkmi_plonk_compute_z_dev", "zkmi_plonk_compute_z_enqueue", "zkmi_pipeline_select", "zkmi_pipeline_active", "zkmi_plonk_compute_t_dev", "zkmi_fflonk_t0_dev", "zkmi_fflonk_t1_dev",
     "zkmi_fflonk_t2_dev", "zkmi_poly_degree_dev", "zkmi_keccak256", "zkmi_poly_blind_dev", "zkmi_poly_add_scalar_dev", "zkmi_poly_axpy_dev", "zkmi_poly_scale_dev",

@@ -87,12 +87,14 @@ def test_ntt29_passes_opt_in_parity():
 
 
 @pytest.mark.skipif(os.environ.get("ZKMI_TEST_NESTED") == "1", reason="already the nested run")
-@pytest.mark.parametrize("env", [{"ZKMI_R29_REDUCE_G2": "0", "ZKMI_R29_REDUCE": "0"}, {"ZKMI_ACC29_BLOCK": "64"}, {"ZKMI_R29_G2": "0"}],
-                         ids=["generic-rowcol-both-groups", "accum-64-thread-blocks", "generic-g2-accumulation"])
+@pytest.mark.parametrize("env", [{"ZKMI_R29_REDUCE_G2": "0", "ZKMI_R29_REDUCE": "0"}, {"ZKMI_ACC29_BLOCK": "64"}, {"ZKMI_R29_G2": "0"}, {"ZKMI_COMPACT_CODE": "15"},
+                                 {"ZKMI_COMPACT_CODE": "0"}],
+                         ids=["generic-rowcol-both-groups", "accum-64-thread-blocks", "generic-g2-accumulation", "compact-code-kernels", "inlined-kernels"])
 def test_non_default_kernel_variants_parity(env):
     """The A/B switches select kernels that the default configuration no longer runs where a window table is resident (the generic 32-bit row /
-    column sums of both groups, the generic Fq2 accumulation, other block shapes): the proof and MSM parity tests that reach those kernels are run
-    again in a process with the switch flipped (the switches are read once per process)."""
+    column sums of both groups, the generic Fq2 accumulation, other block shapes) or picks per box (the Compact instantiations with called
+    products against the inlined ones: decided by a probe of the box unless ZKMI_COMPACT_CODE fixes it): the proof and MSM parity tests that
+    reach those kernels are run again in a process with the switch flipped (the switches are read once per process)."""
     import subprocess
     import sys
     sel = "synthetic_vs_oracle or valid_key_proof_verifies or msm_resident_tables or two_proofs_in_flight"
