@@ -533,7 +533,7 @@ def main():
             vpa = VALU_PER_ADD[args.curve]["g2" if dom == 2 else "g1"]
             wrate = adds * vpa / 64 / (acc[dom] * 1e-3) / 1e9
             int_alu["valu_issue"] = {"valu_instr_per_addition": vpa, "achieved": round(wrate, 1), "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instr/s", "frac": round(wrate / VALU_ISSUE_PEAK_G, 4),
-                                     "note": "VALU instructions of the main path of one mixed addition (tools/isa_counts.py) x additions / 64 / launch time against one wave instruction per SIMD every 4 cycles; the BN254 G2 kernel holds 2 waves per SIMD (LDS-parked Fq2 accumulators + 241 VGPRs), the BLS12-381 G2 kernel 1.5 (three 128-lane blocks per CU), where a dependent v_mad_u64_u32 chain reaches 0.82 of that peak at 2 waves (tools/fieldbench29)"}
+                                     "note": "VALU instructions of the main path of one mixed addition (tools/isa_counts.py) x additions / 64 / launch time against one wave instruction per SIMD every 4 cycles; the G2 kernels hold 2 waves per SIMD (LDS-parked Fq2 accumulators: BN254 XYZZ in two 256-lane blocks per CU, BLS12-381 packed Jacobian in four 128-lane blocks), where a dependent v_mad_u64_u32 chain reaches 0.82 - 0.9 of that peak (tools/fieldbench29: wps=2)"}
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),

@@ -186,8 +186,9 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
             const bool cc = Lim29<C>::NL > 9 && (compact_code() & 1);
 #define ZK_LAUNCH_ACC29(CC, MG) hipLaunchKernelGGL((k_msm_accum29<CC, MG>), grid, dim3(AT29), 0, st, (const uint32_t*)d_bases, mask, sh, skip, pl.cap, pl.counts, pl.starts, \
                                                    pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials, prev_counts, (int)r29_buckets)
-            if (into) { if (cc) ZK_LAUNCH_ACC29(Compact<C>, true); else ZK_LAUNCH_ACC29(C, true); }
-            else { if (cc) ZK_LAUNCH_ACC29(Compact<C>, false); else ZK_LAUNCH_ACC29(C, false); }
+            bool done = false;
+            if constexpr (Lim29<C>::NL > 9) if (cc) { if (into) ZK_LAUNCH_ACC29(Compact<C>, true); else ZK_LAUNCH_ACC29(Compact<C>, false); done = true; }
+            if (!done) { if (into) ZK_LAUNCH_ACC29(C, true); else ZK_LAUNCH_ACC29(C, false); }
 #undef ZK_LAUNCH_ACC29
         }
     } else {
@@ -199,20 +200,27 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
             static bool a29 = false;
             if (!a29) {
                 ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum29_g2<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29));
-                ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum29_g2<Compact<C>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29));
+                if constexpr (Lim29<C>::NL > 9) ZK_HIP(hipFuncSetAttribute((const void*)k_msm_accum29_g2<Compact<C>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29));
                 a29 = true;
             }
-            const bool cc = (compact_code() & 2) != 0;
+            // BN254's 72 KB loop loses more to the calls (3.5 -> 7.8 ms on a healthy box) than a slow-fetch box costs it (+8 %): 14-limb curve only
+            const bool cc = Lim29<C>::NL > 9 && (compact_code() & 2) != 0;
             // The Fq2 buckets stay in R'-form and k_msm_rowcol_wave29_g2 forms the row / column sums on the same limbs (r03 A/B, same box:
             // BLS12-381 51.1 / 50.2 against 50.3 / 50.0 proofs/s, BN254 105.9 against 105.5); ZKMI_R29_REDUCE_G2=0: R-form buckets and the
             // generic 32-bit kernel
             static const bool g2r = !(getenv("ZKMI_R29_REDUCE_G2") && atoi(getenv("ZKMI_R29_REDUCE_G2")) == 0);
             static const bool wave_ok = !(getenv("ZKMI_ROWCOL_WAVE") && atoi(getenv("ZKMI_ROWCOL_WAVE")) == 0);
-            r29_buckets = wave_ok && g2r && (sh.c - 1) / 2 >= 6;
-            if (cc) hipLaunchKernelGGL((k_msm_accum29_g2<Compact<C>>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
-                                       d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets,
-                                       lane_partials, (int)r29_buckets);
-            else hipLaunchKernelGGL((k_msm_accum29_g2<C>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
+            // on a slow-fetch box (compact_code() bit 3) the Fq2 row / column sums go back to the generic 32-bit kernel, whose 55 - 84 KB of code
+            // was not affected there, instead of the 320 - 750 KB of k_msm_rowcol_wave29_g2 (7.1 instead of 2.1 ms on such a box)
+            r29_buckets = wave_ok && g2r && !(compact_code() & 8) && (sh.c - 1) / 2 >= 6;
+            bool done = false;
+            if constexpr (Lim29<C>::NL > 9) if (cc) {
+                hipLaunchKernelGGL((k_msm_accum29_g2<Compact<C>>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
+                                   d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets,
+                                   lane_partials, (int)r29_buckets);
+                done = true;
+            }
+            if (!done) hipLaunchKernelGGL((k_msm_accum29_g2<C>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
                                     d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials,
                                     (int)r29_buckets);
         }
@@ -305,29 +313,29 @@ template <class F> int msm_reduce(MsmJob* const* jobs, int njobs, bool aux = fal
             static bool rc29_attr = false;
             if (!rc29_attr) {
                 ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave29<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29));
-                ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave29<Compact<C>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29));
+                if constexpr (Lim29<C>::NL > 9) ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave29<Compact<C>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29));
                 rc29_attr = true;
             }
             size_t rc_blocks = (n_out + 3) / 4;
             static const int aux_cap29 = getenv("ZKMI_AUX_RC_SUMS") ? atoi(getenv("ZKMI_AUX_RC_SUMS")) : 512;
             if (aux && aux_cap29 > 0) rc_blocks = std::min<size_t>(rc_blocks, (size_t)aux_cap29 / 4);
-            if (compact_code() & 4) hipLaunchKernelGGL((k_msm_rowcol_wave29<Compact<C>>), dim3((unsigned)rc_blocks), dim3(256), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
-            else hipLaunchKernelGGL((k_msm_rowcol_wave29<C>), dim3((unsigned)rc_blocks), dim3(256), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
+            // slow-fetch box, 14-limb curve (254 KB inlined): 5.9 -> 3.0 ms there; BN254's 114 KB kernel gains nothing from the calls (measured)
+            bool done = false;
+            if constexpr (Lim29<C>::NL > 9) if (compact_code() & 4) {
+                hipLaunchKernelGGL((k_msm_rowcol_wave29<Compact<C>>), dim3((unsigned)rc_blocks), dim3(256), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
+                done = true;
+            }
+            if (!done) hipLaunchKernelGGL((k_msm_rowcol_wave29<C>), dim3((unsigned)rc_blocks), dim3(256), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
         } else {
             typedef typename F::Cfg C;
             constexpr int T = Reduce29G2<C>::T;
             constexpr size_t lds29 = Reduce29G2<C>::lds_bytes;
             static bool rc29_attr = false;
-            if (!rc29_attr) {
-                ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave29_g2<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29));
-                ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave29_g2<Compact<C>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29));
-                rc29_attr = true;
-            }
+            if (!rc29_attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_rowcol_wave29_g2<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds29)); rc29_attr = true; }
             size_t rc_blocks = (n_out + T / 64 - 1) / (T / 64);
             static const int aux_cap29 = getenv("ZKMI_AUX_RC_SUMS") ? atoi(getenv("ZKMI_AUX_RC_SUMS")) : 512;
             if (aux && aux_cap29 > 0) rc_blocks = std::min<size_t>(rc_blocks, (size_t)aux_cap29 / (T / 64));
-            if (compact_code() & 8) hipLaunchKernelGGL((k_msm_rowcol_wave29_g2<Compact<C>>), dim3((unsigned)rc_blocks), dim3(T), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
-            else hipLaunchKernelGGL((k_msm_rowcol_wave29_g2<C>), dim3((unsigned)rc_blocks), dim3(T), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
+            hipLaunchKernelGGL((k_msm_rowcol_wave29_g2<C>), dim3((unsigned)rc_blocks), dim3(T), lds29, st, rb, (uint32_t)W, nb, rbits, cbits, rc);
         }
     } else if (wave_rc) {
         constexpr int T = MsmRcBlock<F>::value;

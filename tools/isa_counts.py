@@ -48,47 +48,34 @@ def mix(seg):
 
 
 def main():
+    """One row per straight-line SEGMENT of every inlined accumulation kernel: the kernel is cut at every long jump (s_setpc) and at the source and
+    target of every 16-bit branch that spans more than 600 instructions; segments under 400 instructions are folded into a count. The main
+    path of one mixed addition = the segments executed on every iteration of the lane loop (see the reading under the table)."""
     text = disasm(sys.argv[1] if len(sys.argv) > 1 else OBJ)
-    print("# Static instruction mix of the accumulation hot loops (llvm-objdump of the gfx950 code object; tools/isa_counts.py)\n")
-    print("| kernel | part | instructions | VALU | v_mad_u64_u32 | s_nop | LDS | global/scratch loads | scratch stores |\n|---|---|---|---|---|---|---|---|---|")
+    print("# Static instruction mix of the accumulation kernels, segment by segment (llvm-objdump of the gfx950 code object; tools/isa_counts.py)\n")
+    print("| kernel | segment [first, last) | instructions | VALU | v_mad_u64_u32 | s_nop | LDS | global/scratch loads | scratch stores | entered by |\n|---|---|---|---|---|---|---|---|---|---|")
     for name, ins in kernels(text):
-        if "accum29" not in name:
+        if "accum29" not in name or "Compact" in name:
             continue
         dn = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void zkmi::", "")
-        macs = [k for k, (_, t) in enumerate(ins) if "v_mad_u64" in t]
-        back = [(i, j) for i, j in branches(ins) if j < i and i - j > 2000 and any("v_mad_u64" in t for _, t in ins[j:i])]
-        fwd = [j for i, j in branches(ins) if j > i and j - i > 2000]
-        if back:
-            lo, hi = min(j for _, j in back), max(i for i, _ in back)
-        elif fwd and sum(1 for _, t in ins if t.startswith("s_setpc")) <= 4:      # back-edge out of the 16-bit branch range (s_setpc): from the loads before the first product
-            lo = max(k for k, (_, t) in enumerate(ins[:macs[0]]) if t.startswith("global_load_dwordx4")) - 12
-            hi = max(fwd)
-        else:
-            # every long jump is an s_setpc (14-limb Fq2 kernel: > 128 KiB of code): split at them. Reading for k_msm_accum29_g2<Bls12381Fq>:
-            # segment 1 = gather, unpack, ZZ, ZZZ, U2, S2 (every addition); the next big segment = the rare doubling; the one after = the main path;
-            # the last = the once-per-lane store (Jacobian -> XYZZ words)
-            cuts = [0] + [k for k, (_, t) in enumerate(ins) if t.startswith("s_setpc")] + [len(ins)]
-            for a, b in zip(cuts, cuts[1:]):
-                if b - a < 1500:
-                    continue
-                m = mix(ins[a:b])
-                print(f"| `{dn}` | s_setpc-delimited segment [{a}, {b}) | " + " | ".join(str(m[k]) for k in ("instructions", "VALU", "v_mad_u64_u32", "s_nop", "LDS", "global/scratch loads", "scratch stores")) + " |")
-            continue
-        # big forward-skipped regions inside the loop, outermost first, non-overlapping
-        regs = []
-        for i, j in sorted((x for x in branches(ins) if lo <= x[0] < x[1] <= hi + 1 and x[1] - x[0] > 600), key=lambda x: (x[0], -x[1])):
-            if j - i > 0.9 * (hi - lo):
-                continue                           # the whole body (loop guard)
-            if regs and i < regs[-1][1]:
+        cuts, why = {0: "kernel entry", len(ins): ""}, {}
+        for k, (_, t) in enumerate(ins):
+            if t.startswith("s_setpc"):
+                cuts[k + 1] = "after s_setpc"
+        for i, j in branches(ins):
+            if abs(j - i) > 600:
+                cuts.setdefault(i + 1, f"fall-through of the branch at {i} (-> {j})")
+                cuts[j] = (cuts.get(j, "") + f" target of the branch at {i}").strip()
+        ks = sorted(cuts)
+        small = 0
+        for a, b in zip(ks, ks[1:]):
+            if b - a < 400:
+                small += b - a
                 continue
-            regs.append((i, j))
-        cuts = [lo] + [x for r in regs for x in r] + [hi + 1]
-        segs = [("straight-line part %d" % (k // 2 + 1) if k % 2 == 0 else "conditionally skipped region %d" % (k // 2 + 1), ins[cuts[k]:cuts[k + 1]]) for k in range(len(cuts) - 1)]
-        for part, seg in segs:
-            if not seg:
-                continue
-            m = mix(seg)
-            print(f"| `{dn}` | {part} | " + " | ".join(str(m[k]) for k in ("instructions", "VALU", "v_mad_u64_u32", "s_nop", "LDS", "global/scratch loads", "scratch stores")) + " |")
+            m = mix(ins[a:b])
+            print(f"| `{dn}` | [{a}, {b}) | " + " | ".join(str(m[k]) for k in ("instructions", "VALU", "v_mad_u64_u32", "s_nop", "LDS", "global/scratch loads", "scratch stores")) + f" | {cuts[a]} |")
+        print(f"| `{dn}` | segments under 400 instructions | {small} | | | | | | | |")
+
 
 if __name__ == "__main__":
     main()

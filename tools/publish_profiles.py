@@ -102,8 +102,11 @@ if os.path.exists(f"{src}/fieldbench29.txt"):
 with open(f"{dst}/{tag}_isa_counts.md", "w") as f:
     for obj in ("snarkjs_amd/build/msm_bn254.o", "snarkjs_amd/build/msm_bls12381.o"):
         f.write(subprocess.run([sys.executable, "tools/isa_counts.py", obj], capture_output=True, text=True).stdout + "\n")
-    f.write("Reading: a mixed addition = the straight-line parts (and, for the G2 kernels, the region that is skipped only when no lane of the wave takes it);\n"
-            "the other conditionally skipped region is the rare equal-points doubling. BN254 G1 679 + 1 559 = 2 238 VALU (1 467 MACs); BN254 G2 1 500 + 4 444 =\n"
-            "5 944 (4 374); BLS12-381 G1 1 321 + 3 691 = 5 012 (3 570); BLS12-381 G2 (Jacobian accumulator, 8M + 3S): segment 1 + segment 3 =\n"
-            "5 438 + 9 464 = 14 902 VALU (11 760 MACs = 8 x 1 176 + 3 x 784), segment 2 = the doubling, segment 4 = the once-per-lane store.\n")
+    f.write("Reading (r03 build). Each kernel is: gather + unpack + the head of the addition (first big segment), the rare equal-points doubling (the\n"
+            "segment skipped by a forward branch right after it), the body of the addition (the segment that ends in the backward jump), then three\n"
+            "copies of the once-per-lane store (lane partial in R-form, bucket in R-form, bucket in R'-form). Main path of ONE mixed addition = head +\n"
+            "body (+ the small gather / loop-control segments): BN254 G1 616 + 1 559 (+ ~60) = 2 238 VALU (1 467 MACs); BN254 G2 1 354 + 4 446 (+ ~140) =\n"
+            "5 944 (4 374 MACs); BLS12-381 G1 1 224 + 3 414 (+ ~370) = 5 012 (3 543 + MACs of the small segments); BLS12-381 G2 (packed Jacobian accumulator,\n"
+            "8M + 3S) 5 438 + 9 464 = 14 902 VALU (11 760 MACs = 8 x 1 176 + 3 x 784). Code size of the main path at ~8 bytes per instruction: 28 KB, 81 KB,\n"
+            "64 KB and 209 KB against a 64 KB instruction cache shared by two CUs (see `box_calibration.code_fetch` in the bench lines and DESIGN.md 5).\n")
 print(json.dumps({k: bench[k] for k in ("value", "ms_per_step", "roofline", "int_alu") if k in bench}, indent=1)[:2500])
