@@ -16,5 +16,12 @@ echo -n "bls auto: "; run --curve bls12381 --steps 8 --warmup 2; cp gpurun_out/r
 echo -n "bls inlined: "; ZKMI_COMPACT_CODE=0 run --curve bls12381 --steps 8 --warmup 2
 echo -n "plonk auto: "; run --workload plonk --log-n 20 --steps 12 --warmup 4; cp gpurun_out/r03p/last.json gpurun_out/r03p/bench_plonk_slow_fetch_box_auto.json
 echo -n "bn auto again: "; run --steps 20 --warmup 3
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03p/stp -o p -- python bench.py --workload plonk --log-n 20 --steps 4 --warmup 3 --pipeline 1 --no-cpu-baseline > /dev/null 2>&1
+rm -f gpurun_out/r03p/stp/*kernel_trace.csv
+python - gpurun_out/r03p/stp/p_kernel_stats.csv <<'PY'
+import csv,sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:16]:
+    print("  ", r["Name"].split("(")[0][-60:], r["Calls"], round(float(r["AverageNs"])/1e3,1))
+PY
 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "valid_key_proof_verifies or synthetic_vs_oracle or resident_tables" 2>&1 | tail -2
 fi
