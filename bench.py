@@ -30,7 +30,7 @@ VALU_ISSUE_PEAK_G = 614.4                      # 256 CUs x 4 SIMDs x 2.4 GHz / 4
 # measured Montgomery-multiply ceilings of the chip, Gmul/s at 8 waves per SIMD, in the limb form the accumulation kernels of the curve use
 # (tools/fieldbench29 on the library's own mul29): BN254 Fq 9 x 29-bit limbs, BLS12-381 Fq 14 x 28-bit limbs; the saturated 32-bit forms they
 # replaced measured 130 and 58.6 (tools/fieldbench, profiles/r01_fieldbench.txt). profiles/r03_fieldbench29.txt holds this round's run.
-FIELD_MUL_PEAK_G = {"bn128": 175.0, "bls12381": 80.0}
+FIELD_MUL_PEAK_G = {"bn128": 175.0, "bls12381": 78.3}
 FIELD_MUL_PEAK_32 = {"bn128": 130.0, "bls12381": 58.6}
 
 
