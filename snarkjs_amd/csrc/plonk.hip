@@ -200,34 +200,49 @@ struct PlonkTArgs {
     uint32_t domain, n_public;
     uint32_t *t, *tz;
 };
-template <class C> struct MulZ {
+// CALLS: the field product as a CALL (16 argument registers, no stack traffic): k_plonk_t is 63 - 82 KB of straight-line code per part against
+// a 64 KB instruction cache, 2.8 x slower on a slow-fetch box (field29.cuh: Compact; r03: 2.8 / 3.0 ms per part there against 1.0 ms)
+template <class C> __device__ __attribute__((noinline)) Fp<C> fp_mul_call(Fp<C> a, Fp<C> b) { return fp_mul(a, b); }
+template <class C, bool CALLS> ZK_DEV Fp<C> fp_mulx(const Fp<C>& a, const Fp<C>& b) {
+    if constexpr (CALLS) return fp_mul_call<C>(a, b); else return fp_mul(a, b);
+}
+template <class C, bool CALLS = false> struct MulZ {
     Fp<C> Z1, Z2, Z3;
     bool p;
     // mul_z.js:49-71
     ZK_DEV void mul2(const Fp<C>& a, const Fp<C>& b, const Fp<C>& ap, const Fp<C>& bp, Fp<C>& r, Fp<C>& rz) const {
-        r = fp_mul(a, b);
-        rz = fp_add(fp_mul(a, bp), fp_mul(ap, b));
-        if (p) rz = fp_add(rz, fp_mul(Z1, fp_mul(ap, bp)));
+        r = fp_mulx<C, CALLS>(a, b);
+        rz = fp_add(fp_mulx<C, CALLS>(a, bp), fp_mulx<C, CALLS>(ap, b));
+        if (p) rz = fp_add(rz, fp_mulx<C, CALLS>(Z1, fp_mulx<C, CALLS>(ap, bp)));
     }
-    // mul_z.js:103-148
+    // mul_z.js:103-148: the product (a + ap Z)(b + bp Z)(c + cp Z)(d + dp Z) reduced by the blinding terms. The reference expands it into 8
+    // pair products and 15 triple / quadruple sums (27 field multiplications). The same field elements follow from two quadratics
+    // (A0 + A1 Z + A2 Z^2)(B0 + B1 Z + B2 Z^2), A = (a b, a bp + ap b, ap bp), B likewise: Karatsuba on the pairs (3 + 3) and on the
+    // quadratics (6) + the three weights = 15 multiplications where all coefficients are needed (3 of 4 points), 9 where only Z^1 is.
+    // Field arithmetic is exact: the results are the reference's, bit for bit (tests: stages against the oracle's literal expansion).
     ZK_DEV void mul4(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d, const Fp<C>& ap, const Fp<C>& bp, const Fp<C>& cp, const Fp<C>& dp, Fp<C>& r, Fp<C>& rz) const {
-        const Fp<C> a_b = fp_mul(a, b), a_bp = fp_mul(a, bp), ap_b = fp_mul(ap, b), ap_bp = fp_mul(ap, bp);
-        const Fp<C> c_d = fp_mul(c, d), c_dp = fp_mul(c, dp), cp_d = fp_mul(cp, d), cp_dp = fp_mul(cp, dp);
-        r = fp_mul(a_b, c_d);
-        Fp<C> a0 = fp_add(fp_add(fp_mul(ap_b, c_d), fp_mul(a_bp, c_d)), fp_add(fp_mul(a_b, cp_d), fp_mul(a_b, c_dp)));
-        rz = a0;
-        if (p) {
-            Fp<C> a1 = fp_add(fp_add(fp_add(fp_mul(ap_bp, c_d), fp_mul(ap_b, cp_d)), fp_add(fp_mul(ap_b, c_dp), fp_mul(a_bp, cp_d))), fp_add(fp_mul(a_bp, c_dp), fp_mul(a_b, cp_dp)));
-            Fp<C> a2 = fp_add(fp_add(fp_mul(a_bp, cp_dp), fp_mul(ap_b, cp_dp)), fp_add(fp_mul(ap_bp, c_dp), fp_mul(ap_bp, cp_d)));
-            Fp<C> a3 = fp_mul(ap_bp, cp_dp);
-            rz = fp_add(fp_add(rz, fp_mul(Z1, a1)), fp_add(fp_mul(Z2, a2), fp_mul(Z3, a3)));
+        const Fp<C> A0 = fp_mulx<C, CALLS>(a, b), B0 = fp_mulx<C, CALLS>(c, d);
+        r = fp_mulx<C, CALLS>(A0, B0);
+        if (!p) {
+            const Fp<C> u = fp_add(fp_mulx<C, CALLS>(a, bp), fp_mulx<C, CALLS>(ap, b)), v = fp_add(fp_mulx<C, CALLS>(c, dp), fp_mulx<C, CALLS>(cp, d));
+            rz = fp_add(fp_mulx<C, CALLS>(u, B0), fp_mulx<C, CALLS>(A0, v));                                          // Z^1 only
+            return;
         }
+        const Fp<C> A2 = fp_mulx<C, CALLS>(ap, bp), B2 = fp_mulx<C, CALLS>(cp, dp);
+        const Fp<C> A1 = fp_sub(fp_sub(fp_mulx<C, CALLS>(fp_add(a, ap), fp_add(b, bp)), A0), A2);          // a bp + ap b
+        const Fp<C> B1 = fp_sub(fp_sub(fp_mulx<C, CALLS>(fp_add(c, cp), fp_add(d, dp)), B0), B2);          // c dp + cp d
+        const Fp<C> P1 = fp_mulx<C, CALLS>(A1, B1), P2 = fp_mulx<C, CALLS>(A2, B2);
+        const Fp<C> P01 = fp_mulx<C, CALLS>(fp_add(A0, A1), fp_add(B0, B1)), P02 = fp_mulx<C, CALLS>(fp_add(A0, A2), fp_add(B0, B2)), P12 = fp_mulx<C, CALLS>(fp_add(A1, A2), fp_add(B1, B2));
+        const Fp<C> z1 = fp_sub(fp_sub(P01, r), P1);                                            // Z^1: A0 B1 + A1 B0
+        const Fp<C> z2 = fp_add(fp_sub(fp_sub(P02, r), P2), P1);                                // Z^2: A0 B2 + A1 B1 + A2 B0
+        const Fp<C> z3 = fp_sub(fp_sub(P12, P1), P2);                                           // Z^3: A1 B2 + A2 B1
+        rz = fp_add(fp_add(z1, fp_mulx<C, CALLS>(Z1, z2)), fp_add(fp_mulx<C, CALLS>(Z2, z3), fp_mulx<C, CALLS>(Z3, P2)));         // Z^4: A2 B2
     }
 };
 // One lane per extended evaluation point. The numerator is a sum of four terms with little in common besides the wire values, and
 // the live set of all four together exceeds 256 VGPRs (1 wave per SIMD: 5.5 ms at 2^20, or 3.7 ms with scratch at 3 waves), so it is
 // evaluated in three launches that accumulate into t / tz:  PART 0: e1 + e4 (store),  PART 1: += e2,  PART 2: -= e3.
-template <class C, int PART> __global__ void __launch_bounds__(256, 2) k_plonk_t(PlonkTArgs g, PowTab w4) {
+template <class C, int PART, bool CALLS = false> __global__ void __launch_bounds__(256, 2) k_plonk_t(PlonkTArgs g, PowTab w4) {
     const uint32_t n4 = 4 * g.domain;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
@@ -236,8 +251,8 @@ template <class C, int PART> __global__ void __launch_bounds__(256, 2) k_plonk_t
     const Fp<C> w = pow_tab<C>(w4, i);                                     // w = Fr.w[power+2]^i
     auto bl = [&](int j) { return kc<C>(k, PK_B1 + j - 1); };              // challenges.b[j]
     const Fp<C> a = ld(g.a, i), b = ld(g.b, i), c = ld(g.c, i);
-    const Fp<C> ap = fp_add(bl(2), fp_mul(bl(1), w)), bp = fp_add(bl(4), fp_mul(bl(3), w)), cp = fp_add(bl(6), fp_mul(bl(5), w));
-    MulZ<C> mz;
+    const Fp<C> ap = fp_add(bl(2), fp_mulx<C, CALLS>(bl(1), w)), bp = fp_add(bl(4), fp_mulx<C, CALLS>(bl(3), w)), cp = fp_add(bl(6), fp_mulx<C, CALLS>(bl(5), w));
+    MulZ<C, CALLS> mz;
     mz.p = (i & 3) != 0;
     mz.Z1 = kc<C>(k, PK_Z1 + (i & 3)); mz.Z2 = kc<C>(k, PK_Z2 + (i & 3)); mz.Z3 = kc<C>(k, PK_Z3 + (i & 3));
     uint32_t* pt = g.t + (size_t)i * 8;
@@ -246,39 +261,60 @@ template <class C, int PART> __global__ void __launch_bounds__(256, 2) k_plonk_t
         // e1 := a b qM + a qL + b qR + c qO + PI + qC ;  e4 := alpha^2 (z - 1) L1
         Fp<C> pi = fp_zero<C>();
         for (uint32_t j = 0; j < g.n_public; j++)
-            pi = fp_sub(pi, fp_mul(ld(g.lagrange, (size_t)j * 5 * g.domain + g.domain + i), ld(g.pub_a, j)));
+            pi = fp_sub(pi, fp_mulx<C, CALLS>(ld(g.lagrange, (size_t)j * 5 * g.domain + g.domain + i), ld(g.pub_a, j)));
         Fp<C> e1, e1z;
         mz.mul2(a, b, ap, bp, e1, e1z);
         const Fp<C> qm = ld(g.qm, i), ql = ld(g.ql, i), qr = ld(g.qr, i), qo = ld(g.qo, i);
-        e1 = fp_mul(e1, qm); e1z = fp_mul(e1z, qm);
-        e1 = fp_add(e1, fp_mul(a, ql)); e1z = fp_add(e1z, fp_mul(ap, ql));
-        e1 = fp_add(e1, fp_mul(b, qr)); e1z = fp_add(e1z, fp_mul(bp, qr));
-        e1 = fp_add(e1, fp_mul(c, qo)); e1z = fp_add(e1z, fp_mul(cp, qo));
+        e1 = fp_mulx<C, CALLS>(e1, qm); e1z = fp_mulx<C, CALLS>(e1z, qm);
+        e1 = fp_add(e1, fp_mulx<C, CALLS>(a, ql)); e1z = fp_add(e1z, fp_mulx<C, CALLS>(ap, ql));
+        e1 = fp_add(e1, fp_mulx<C, CALLS>(b, qr)); e1z = fp_add(e1z, fp_mulx<C, CALLS>(bp, qr));
+        e1 = fp_add(e1, fp_mulx<C, CALLS>(c, qo)); e1z = fp_add(e1z, fp_mulx<C, CALLS>(cp, qo));
         e1 = fp_add(fp_add(e1, pi), ld(g.qc, i));
         const Fp<C> z = ld(g.z, i), alpha2 = kc<C>(k, PK_ALPHA2);
-        const Fp<C> zp = fp_add(fp_add(fp_mul(bl(7), fp_sqr(w)), fp_mul(bl(8), w)), bl(9));
+        const Fp<C> zp = fp_add(fp_mulx<C, CALLS>(fp_add(fp_mulx<C, CALLS>(bl(7), w), bl(8)), w), bl(9));
         const Fp<C> l1 = ld(g.lagrange, (size_t)g.domain + i);
-        fp_store<C>(pt, fp_add(e1, fp_mul(fp_mul(fp_sub(z, kc<C>(k, PK_ONE)), l1), alpha2)));
-        fp_store<C>(ptz, fp_add(e1z, fp_mul(fp_mul(zp, l1), alpha2)));
+        fp_store<C>(pt, fp_add(e1, fp_mulx<C, CALLS>(fp_mulx<C, CALLS>(fp_sub(z, kc<C>(k, PK_ONE)), l1), alpha2)));
+        fp_store<C>(ptz, fp_add(e1z, fp_mulx<C, CALLS>(fp_mulx<C, CALLS>(zp, l1), alpha2)));
+    } else if constexpr (PART == 3) {
+        // PART 1 and PART 2 in one pass (the factored mul4 leaves room for both): t += alpha (e2 - e3), the wire values, w, the blinding
+        // evaluations and t / tz touched once
+        const Fp<C> beta = kc<C>(k, PK_BETA), gamma = kc<C>(k, PK_GAMMA), alpha = kc<C>(k, PK_ALPHA);
+        Fp<C> e, ez;
+        {
+            const Fp<C> zp = fp_add(fp_mulx<C, CALLS>(fp_add(fp_mulx<C, CALLS>(bl(7), w), bl(8)), w), bl(9));
+            const Fp<C> betaw = fp_mulx<C, CALLS>(beta, w);
+            mz.mul4(fp_add(fp_add(a, betaw), gamma), fp_add(fp_add(b, fp_mulx<C, CALLS>(betaw, kc<C>(k, PK_K1))), gamma), fp_add(fp_add(c, fp_mulx<C, CALLS>(betaw, kc<C>(k, PK_K2))), gamma), ld(g.z, i), ap, bp,
+                    cp, zp, e, ez);
+        }
+        {
+            Fp<C> e3, e3z;
+            const Fp<C> wW = fp_mulx<C, CALLS>(w, kc<C>(k, PK_WN));
+            const Fp<C> zWp = fp_add(fp_mulx<C, CALLS>(fp_add(fp_mulx<C, CALLS>(bl(7), wW), bl(8)), wW), bl(9));
+            mz.mul4(fp_add(fp_add(a, fp_mulx<C, CALLS>(beta, ld(g.s1, i))), gamma), fp_add(fp_add(b, fp_mulx<C, CALLS>(beta, ld(g.s2, i))), gamma), fp_add(fp_add(c, fp_mulx<C, CALLS>(beta, ld(g.s3, i))), gamma),
+                    ld(g.z, (n4 + 4 + i) % n4), ap, bp, cp, zWp, e3, e3z);
+            e = fp_sub(e, e3); ez = fp_sub(ez, e3z);
+        }
+        fp_store<C>(pt, fp_add(fp_load<C>(pt), fp_mulx<C, CALLS>(e, alpha)));
+        fp_store<C>(ptz, fp_add(fp_load<C>(ptz), fp_mulx<C, CALLS>(ez, alpha)));
     } else {
         const Fp<C> beta = kc<C>(k, PK_BETA), gamma = kc<C>(k, PK_GAMMA), alpha = kc<C>(k, PK_ALPHA);
         Fp<C> e, ez;
         if constexpr (PART == 1) {
             // e2 := alpha (a + beta X + gamma)(b + beta k1 X + gamma)(c + beta k2 X + gamma) z
-            const Fp<C> zp = fp_add(fp_add(fp_mul(bl(7), fp_sqr(w)), fp_mul(bl(8), w)), bl(9));
-            const Fp<C> betaw = fp_mul(beta, w);
-            mz.mul4(fp_add(fp_add(a, betaw), gamma), fp_add(fp_add(b, fp_mul(betaw, kc<C>(k, PK_K1))), gamma), fp_add(fp_add(c, fp_mul(betaw, kc<C>(k, PK_K2))), gamma), ld(g.z, i), ap, bp,
+            const Fp<C> zp = fp_add(fp_mulx<C, CALLS>(fp_add(fp_mulx<C, CALLS>(bl(7), w), bl(8)), w), bl(9));
+            const Fp<C> betaw = fp_mulx<C, CALLS>(beta, w);
+            mz.mul4(fp_add(fp_add(a, betaw), gamma), fp_add(fp_add(b, fp_mulx<C, CALLS>(betaw, kc<C>(k, PK_K1))), gamma), fp_add(fp_add(c, fp_mulx<C, CALLS>(betaw, kc<C>(k, PK_K2))), gamma), ld(g.z, i), ap, bp,
                     cp, zp, e, ez);
-            fp_store<C>(pt, fp_add(fp_load<C>(pt), fp_mul(e, alpha)));
-            fp_store<C>(ptz, fp_add(fp_load<C>(ptz), fp_mul(ez, alpha)));
+            fp_store<C>(pt, fp_add(fp_load<C>(pt), fp_mulx<C, CALLS>(e, alpha)));
+            fp_store<C>(ptz, fp_add(fp_load<C>(ptz), fp_mulx<C, CALLS>(ez, alpha)));
         } else {
             // e3 := alpha (a + beta s1 + gamma)(b + beta s2 + gamma)(c + beta s3 + gamma) z(Xw)
-            const Fp<C> wW = fp_mul(w, kc<C>(k, PK_WN));
-            const Fp<C> zWp = fp_add(fp_add(fp_mul(bl(7), fp_sqr(wW)), fp_mul(bl(8), wW)), bl(9));
-            mz.mul4(fp_add(fp_add(a, fp_mul(beta, ld(g.s1, i))), gamma), fp_add(fp_add(b, fp_mul(beta, ld(g.s2, i))), gamma), fp_add(fp_add(c, fp_mul(beta, ld(g.s3, i))), gamma),
+            const Fp<C> wW = fp_mulx<C, CALLS>(w, kc<C>(k, PK_WN));
+            const Fp<C> zWp = fp_add(fp_mulx<C, CALLS>(fp_add(fp_mulx<C, CALLS>(bl(7), wW), bl(8)), wW), bl(9));
+            mz.mul4(fp_add(fp_add(a, fp_mulx<C, CALLS>(beta, ld(g.s1, i))), gamma), fp_add(fp_add(b, fp_mulx<C, CALLS>(beta, ld(g.s2, i))), gamma), fp_add(fp_add(c, fp_mulx<C, CALLS>(beta, ld(g.s3, i))), gamma),
                     ld(g.z, (n4 + 4 + i) % n4), ap, bp, cp, zWp, e, ez);
-            fp_store<C>(pt, fp_sub(fp_load<C>(pt), fp_mul(e, alpha)));
-            fp_store<C>(ptz, fp_sub(fp_load<C>(ptz), fp_mul(ez, alpha)));
+            fp_store<C>(pt, fp_sub(fp_load<C>(pt), fp_mulx<C, CALLS>(e, alpha)));
+            fp_store<C>(ptz, fp_sub(fp_load<C>(ptz), fp_mulx<C, CALLS>(ez, alpha)));
         }
     }
 }
@@ -536,9 +572,21 @@ template <class C> struct PlonkOps {
         g.s1 = (const uint32_t*)ev->s1; g.s2 = (const uint32_t*)ev->s2; g.s3 = (const uint32_t*)ev->s3;
         g.lagrange = (const uint32_t*)ev->lagrange; g.pub_a = (const uint32_t*)ev->pub_a; g.k = dk;
         g.domain = dom; g.n_public = n_public; g.t = (uint32_t*)T; g.tz = (uint32_t*)Tz;
-        hipLaunchKernelGGL((k_plonk_t<C, 0>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
-        hipLaunchKernelGGL((k_plonk_t<C, 1>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
-        hipLaunchKernelGGL((k_plonk_t<C, 2>), dim3((4 * dom + 255) / 256), dim3(256), 0, cx.stream, g, w4);
+        const dim3 grid((4 * dom + 255) / 256);
+        // default: three launches (the merged e2 + e3 kernel measured the same on a healthy box and is twice the code); ZKMI_PLONK_T_PARTS=2 merges
+        static const bool three = !(getenv("ZKMI_PLONK_T_PARTS") && atoi(getenv("ZKMI_PLONK_T_PARTS")) == 2);
+        if (compact_code() & 16) {                                  // slow-fetch box: products called, ~10 KB per part
+            hipLaunchKernelGGL((k_plonk_t<C, 0, true>), grid, dim3(256), 0, cx.stream, g, w4);
+            hipLaunchKernelGGL((k_plonk_t<C, 1, true>), grid, dim3(256), 0, cx.stream, g, w4);
+            hipLaunchKernelGGL((k_plonk_t<C, 2, true>), grid, dim3(256), 0, cx.stream, g, w4);
+        } else if (three) {
+            hipLaunchKernelGGL((k_plonk_t<C, 0>), grid, dim3(256), 0, cx.stream, g, w4);
+            hipLaunchKernelGGL((k_plonk_t<C, 1>), grid, dim3(256), 0, cx.stream, g, w4);
+            hipLaunchKernelGGL((k_plonk_t<C, 2>), grid, dim3(256), 0, cx.stream, g, w4);
+        } else {
+            hipLaunchKernelGGL((k_plonk_t<C, 0>), grid, dim3(256), 0, cx.stream, g, w4);
+            hipLaunchKernelGGL((k_plonk_t<C, 3>), grid, dim3(256), 0, cx.stream, g, w4);
+        }
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }

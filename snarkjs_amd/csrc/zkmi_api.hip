@@ -54,10 +54,10 @@ extern "C" int zkmi_calibrate_code_fetch(double* small_loop_gmul_per_s, double* 
 static int g_compact_code = -1;
 int compact_code() {
     if (g_compact_code >= 0) return g_compact_code;
-    if (getenv("ZKMI_COMPACT_CODE")) return g_compact_code = atoi(getenv("ZKMI_COMPACT_CODE")) & 15;
+    if (getenv("ZKMI_COMPACT_CODE")) return g_compact_code = atoi(getenv("ZKMI_COMPACT_CODE")) & 31;
     double small = 0, big = 0;
     if (zkmi_calibrate_code_fetch(&small, &big) != ZKMI_OK || small <= 0) return g_compact_code = 0;
-    return g_compact_code = (big / small < 0.85) ? 15 : 0;
+    return g_compact_code = (big / small < 0.85) ? 31 : 0;
 }
 extern "C" int zkmi_compact_code(void) { return g_ctx.ready ? compact_code() : -1; }
 int dev_alloc_big(void** p, size_t bytes) {
