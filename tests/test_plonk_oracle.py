@@ -146,3 +146,34 @@ def test_prove_many_schedules_two_coroutines_over_the_pipeline_slots(monkeypatch
         plonk.prove_many(key, [{"id": 0, "n": 6}, {"id": 1, "n": 6, "fail_at": 2}, {"id": 2, "n": 3}])
     assert not alive and fake.active == 0 and 2 not in [pid for pid, _ in trace]
     assert [o["proof"] for o in plonk.prove_many(key, [{"id": 7, "n": 1}], in_flight=1)] == [7]
+
+
+def test_mul4_karatsuba_form_equals_the_reference_expansion():
+    """csrc/plonk.hip MulZ::mul4 computes (a + a'Z)(b + b'Z)(c + c'Z)(d + d'Z) as the product of two quadratics with Karatsuba on the pairs and on
+    the quadratics (15 field multiplications); the oracle keeps the reference's literal expansion (mul_z.js:103-148, 27 multiplications). The two
+    are the same field elements for every input — checked here on random values and on the degenerate ones, for the four residues of the point
+    index, both scalar fields. (The kernel itself is held to the oracle on the GPU by test_compute_z_and_t_stages_vs_oracle and the golden proofs.)"""
+    import random
+    for r in (P.Ctx().r, P.Ctx(48).r if hasattr(P.Ctx(48), "r") else P.Ctx().r):
+        rng = random.Random(r & 0xFFFF)
+        Z = [[rng.randrange(r) for _ in range(4)] for _ in range(3)]
+
+        def kernel_form(a, b, c, d, ap, bp, cp, dp, p):
+            A0, B0 = a * b % r, c * d % r
+            rr = A0 * B0 % r
+            if not p:
+                u, v = (a * bp + ap * b) % r, (c * dp + cp * d) % r
+                return rr, (u * B0 + A0 * v) % r
+            A2, B2 = ap * bp % r, cp * dp % r
+            A1 = ((a + ap) * (b + bp) - A0 - A2) % r
+            B1 = ((c + cp) * (d + dp) - B0 - B2) % r
+            P1, P2 = A1 * B1 % r, A2 * B2 % r
+            P01, P02, P12 = (A0 + A1) * (B0 + B1) % r, (A0 + A2) * (B0 + B2) % r, (A1 + A2) * (B1 + B2) % r
+            z1, z2, z3 = (P01 - rr - P1) % r, (P02 - rr - P2 + P1) % r, (P12 - P1 - P2) % r
+            return rr, (z1 + Z[0][p] * z2 + Z[1][p] * z3 + Z[2][p] * P2) % r
+
+        cases = [[rng.randrange(r) for _ in range(8)] for _ in range(200)]
+        cases += [[0] * 8, [r - 1] * 8, [1, 0, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, r - 1, 1, r - 1, 1], [rng.randrange(r)] * 8]
+        for vals in cases:
+            for p in range(4):
+                assert kernel_form(*vals, p) == P.mul4(*vals, p, Z, r)
