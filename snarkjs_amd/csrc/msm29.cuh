@@ -293,32 +293,28 @@ template <class C, int K> ZK_HD Fp29<C> neg29(const Fp29<C>& a) { Fp29<C> r = su
 // Compact<C> (field29.cuh): the Fq2 product and square are CALLED — one copy of each in the code object instead of one per site (~15 per
 // addition); operands and result travel in registers by the AMDGPU calling convention, the excess over 32 argument registers through the stack
 #define ZK_F2_CALLS(C) (IsCompact<C>::value)
-template <class C> __host__ __device__ ZK_NOINLINE_DEV F2x<C> f2mul_call(F2x<C> a, F2x<C> b, Fp29<C> nb1) {
+// The negated component is formed INSIDE the call with one generous offset (16 p - b.c1: every site's b.c1 is far below that, and with
+// R' / p = 2^11 on the 14-limb curve the larger operand costs nothing in the bounds of the double product): 4 NL argument words instead of 5 NL
+template <class C> __host__ __device__ ZK_NOINLINE_DEV F2x<C> f2mul_call(F2x<C> a, F2x<C> b) {
+    static_assert(Lim29<C>::NL > 9, "called Fq2 product: 14-limb curve only (offset 16 p needs its headroom)");
+    const Fp29<C> nb1 = neg29<C, 16>(b.c1);
     return F2x<C>{mul29_2_inl(a.c0, b.c0, a.c1, nb1), mul29_2_inl(a.c0, b.c1, a.c1, b.c0)};
-}
-// s = a0 + a1 (limbs < 2^(B+1)), d = a0 - a1 + KB p (normalised) prepared by the caller: the offset is a template constant there
-template <class C> __host__ __device__ ZK_NOINLINE_DEV F2x<C> f2sqr_call(Fp29<C> a0, Fp29<C> a1, Fp29<C> s, Fp29<C> d) {
-    Fp29<C> t = mul29_inl(a0, a1);
-    Fp29<C> c1 = add29(t, t);
-    norm29(c1);
-    return F2x<C>{mul29_inl(s, d), c1};
 }
 // a * b, nb1 = K p - b.c1 supplied by the caller (often shared by several products)
 template <class C> ZK_HD F2x<C> f2mul(const F2x<C>& a, const F2x<C>& b, const Fp29<C>& nb1) {
-    if constexpr (ZK_F2_CALLS(C)) return f2mul_call<C>(a, b, nb1);
+    if constexpr (ZK_F2_CALLS(C)) return f2mul_call<C>(a, b);
     else return F2x<C>{mul29_2(a.c0, b.c0, a.c1, nb1), mul29_2(a.c0, b.c1, a.c1, b.c0)};
 }
 // a^2 for components <= KB (the offset of the difference)
 template <class C, int KB> ZK_HD F2x<C> f2sqr(const F2x<C>& a) {
     Fp29<C> s = add29(a.c0, a.c1), d = sub29<C, KB>(a.c0, a.c1);
     norm29(d);                                                     // s: limbs < 2^(B+1), d normalised
-    if constexpr (ZK_F2_CALLS(C)) return f2sqr_call<C>(a.c0, a.c1, s, d);
-    else {
-        Fp29<C> t = mul29(a.c0, a.c1);
-        Fp29<C> c1 = add29(t, t);
-        norm29(c1);
-        return F2x<C>{mul29(s, d), c1};
-    }
+    // Compact<C>: two mul29 CALLS, each with its 2 NL argument words in registers (one call for the whole square would push half of its four
+    // operands through the stack)
+    Fp29<C> t = mul29(a.c0, a.c1);
+    Fp29<C> c1 = add29(t, t);
+    norm29(c1);
+    return F2x<C>{mul29(s, d), c1};
 }
 template <class C, int K> ZK_HD F2x<C> f2sub(const F2x<C>& a, const F2x<C>& b) { return F2x<C>{sub29<C, K>(a.c0, b.c0), sub29<C, K>(a.c1, b.c1)}; }   // not normalised
 template <class C> ZK_HD void f2norm(F2x<C>& a) { norm29(a.c0); norm29(a.c1); }
