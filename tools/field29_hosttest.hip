@@ -206,6 +206,7 @@ int main() {
         try {
             if (curve == "bn254fq") out = run<Bn254Fq>(op, v);
             else if (curve == "bls12381fq") out = run<Bls12381Fq>(op, v);
+            else if (curve == "bls12381fq_compact") out = run<Compact<Bls12381Fq>>(op, v);
             else if (curve == "bn254fr") out = run<Bn254Fr>(op, v);
             else if (curve == "bls12381fr") out = run<Bls12381Fr>(op, v);
             else out = "ERR curve";
