@@ -575,7 +575,11 @@ template <class C> struct PlonkOps {
         const dim3 grid((4 * dom + 255) / 256);
         // default: three launches (the merged e2 + e3 kernel measured the same on a healthy box and is twice the code); ZKMI_PLONK_T_PARTS=2 merges
         static const bool three = !(getenv("ZKMI_PLONK_T_PARTS") && atoi(getenv("ZKMI_PLONK_T_PARTS")) == 2);
-        if (compact_code() & 16) {                                  // slow-fetch box: products called, ~10 KB per part
+        // Products CALLED (8 - 12 KB per part instead of 60 - 85 KB): the default on every box — same speed as the inlined kernels where
+        // instruction fetch is healthy (38.4 / 37.9 against 38.0 / 38.3 proofs/s, same box), 2.6 x faster where it is not; an explicit
+        // ZKMI_COMPACT_CODE mask without bit 4 selects the inlined kernels
+        static const bool calls = getenv("ZKMI_COMPACT_CODE") ? (compact_code() & 16) != 0 : true;
+        if (calls) {
             hipLaunchKernelGGL((k_plonk_t<C, 0, true>), grid, dim3(256), 0, cx.stream, g, w4);
             hipLaunchKernelGGL((k_plonk_t<C, 1, true>), grid, dim3(256), 0, cx.stream, g, w4);
             hipLaunchKernelGGL((k_plonk_t<C, 2, true>), grid, dim3(256), 0, cx.stream, g, w4);
