@@ -107,6 +107,9 @@ int zkmi_msm_table_dev(uint64_t handle, const void* d_scalars, size_t k, size_t 
 int zkmi_msm_table_multi_dev(uint64_t handle, const void* const* d_scalars, const size_t* ks, int count, size_t scalar_bytes,
                              uint8_t* out_jacobians);
 int zkmi_msm_table_release(uint64_t handle);
+/* Curve, group and number of resident points of a table (any pointer may be NULL): a binding sizes the result buffers of the two calls above
+ * — 3*group*n8q bytes per MSM — from the TABLE instead of trusting its caller. */
+int zkmi_msm_table_info(uint64_t handle, int* curve, int* group, size_t* n);
 /* Window width used for n terms (tuning knob; 0 restores the built-in table). */
 int zkmi_msm_set_window_bits(int c);
 
@@ -330,6 +333,33 @@ int zkmi_gen_bases_from_scalars_dev(int curve, int group, const void* d_scalars,
  * multi-GPU proof exchange chain outputs (js/groth16_shards.js). Optional: transfers from unregistered memory work, slower. */
 int zkmi_host_register(void* host_ptr, size_t bytes);
 int zkmi_host_unregister(void* host_ptr);
+/* ---- GPU-to-GPU exchange between the processes of a multi-GPU proof (snarkjs_amd/csrc/peer.hip) --------------------------------------
+ * The reference spreads one multiExp / one proof over its workers by handing them chunk buffers and folding the results on the host
+ * (ffjavascript engine_multiexp, min.js:1@214651; worker dispatch @207729). Here a worker is a process that owns one GPU; the bulk data of a
+ * sharded Groth16 proof (the three chain outputs, domain x 32 bytes each) moves device to device: the owner of a chain exports the buffer
+ * that holds its output, every other process opens the handle once and pulls ITS slice per proof — over xGMI between two GPUs, inside HBM
+ * when two processes share a device. Control (who is ready, the 7 x 3 x n8q-byte partial sums) stays on the host's own channel.
+ *   zkmi_ipc_export: handle (ZKMI_IPC_HANDLE_BYTES, plain bytes: send them over any channel) for a device pointer of this process
+ *                    (zkmi_dev_alloc or any hipMalloc'ed range; interior pointers allowed).
+ *   zkmi_ipc_open:   device pointer in THIS process for a handle (peer access is enabled on first use); *bytes_visible (optional) = bytes
+ *                    from the pointer to the end of the exported allocation. A handle exported by the calling process resolves to the
+ *                    original pointer. zkmi_ipc_close drops the mapping (the exporter keeps the memory).
+ *   zkmi_peer_copy:  d_dst <- d_src for `bytes` bytes on the library stream, complete on return; zkmi_peer_copy_async: queued only
+ *                    (zkmi_synchronize). The exporter must have finished writing (its zkmi_groth16_chains_dev returned) before a peer
+ *                    reads, and must not overwrite the buffer until every peer has reported its copy complete: the host orders this
+ *                    (js/groth16_shards.js: "chain" / "pulled" messages). */
+#define ZKMI_IPC_HANDLE_BYTES 96
+int zkmi_ipc_export(const void* d_ptr, uint8_t* handle);
+int zkmi_ipc_open(const uint8_t* handle, void** d_ptr, size_t* bytes_visible);
+int zkmi_ipc_close(void* d_ptr);
+int zkmi_peer_copy(void* d_dst, const void* d_src, size_t bytes);
+int zkmi_peer_copy_async(void* d_dst, const void* d_src, size_t bytes);
+/* Curve of a resident Groth16 key (ZKMI_CURVE_*), -1 when the key is not loaded: bindings size their output buffers from the KEY, not from
+ * a caller-supplied curve id. */
+int zkmi_groth16_key_curve(uint64_t key);
+/* Error recovery for the split proof (zkmi_groth16_sums_w_dev / _sums_h_dev, _submit / _collect): waits for the device, then forgets any
+ * half-enqueued or in-flight proof of this key in both pipeline slots, so that the next proof starts clean after a failed exchange. */
+int zkmi_groth16_reset(uint64_t key);
 /* G.toAffine on host for one Jacobian point (tiny; used by bindings to normalise results). */
 int zkmi_to_affine(int curve, int group, const uint8_t* jacobian, uint8_t* affine);
 /* G.add on host for two Jacobian points (O(1)): folds the per-GPU partial results of a sharded MSM

@@ -378,6 +378,37 @@ async function fflonkGolden() {
     }
 }
 
+// FFLONK on BLS12-381 — a NEGATIVE probe. The reference's prover takes the curve from the zkey (src/fflonk_prove.js:51-110), but its setup
+// hard-codes BN254 constants: computeW3 raises the BN254 generator 31624 to BN254's (r - 1) / 3, getOmegaCubicRoot starts from a literal cube root
+// of BN254's Fr.w[28] (src/fflonk_setup.js:533-556). On BLS12-381 fflonk.setup therefore writes a key whose w3 / wr are not roots of unity there,
+// and fflonk.prove on it throws "Polynomial is not divisible" for a satisfied circuit: the reference has no FFLONK on BLS12-381, so there is
+// nothing to be bit-identical to. This records the reference's own verdict (tests/golden/fflonk_bls12381_unsupported.json); the device path
+// refuses such keys up front ("Curve not supported", snarkjs_amd/fflonk.py, js/fflonk_native.js).
+async function fflonkBlsProbe() {
+    const curve = await snarkjs.curves.getCurveFromName('bls12381');
+    const r = curve.Fr.p, n = 40;
+    const mem = () => ({ type: 'mem' });
+    const p0 = mem(), p1 = mem(), pf = mem(), z = mem();
+    await snarkjs.powersOfTau.newAccumulator(curve, 10, p0);
+    await snarkjs.powersOfTau.contribute(p0, p1, 'C1', 'Entropy1');
+    await snarkjs.powersOfTau.preparePhase2(p1, pf);
+    await snarkjs.fflonk.setup(multiplierR1cs(r, n), pf, z);
+    const w = { data: multiplierWtns(r, n, 11n, 2n) };
+    let error = null;
+    try { await snarkjs.fflonk.prove(z.data, w.data); } catch (e) { error = String(e && e.message || e); }
+    // the constants the setup wrote (zkey section 2 tail is parsed by the reference's own reader)
+    const zk = await snarkjs.zKey.exportVerificationKey(z.data);
+    const Fr = curve.Fr, cube = (x) => Fr.mul(Fr.mul(x, x), x);
+    const hdr = { protocol: zk.protocol, curve: zk.curve, power: zk.power, w3: zk.w3 || null, w3_cubed_is_one: zk.w3 ? Fr.eq(cube(Fr.e(zk.w3)), Fr.one) : null,
+                  wr: zk.wr || null, wr_cubed_is_w_power: zk.wr ? Fr.eq(cube(Fr.e(zk.wr)), Fr.w[zk.power]) : null };
+    if (error === null) throw new Error('the reference proved FFLONK on BLS12-381: the probe\'s premise no longer holds, generate a positive fixture instead');
+    fs.writeFileSync(path.join(OUT, 'fflonk_bls12381_unsupported.json'), JSON.stringify({
+        what: 'fflonk.setup + fflonk.prove of the reference bundle on the Multiplier(40) r1cs over a seeded BLS12-381 ptau (oracle/gen_golden.js: fflonkBlsProbe)',
+        reference_prove_error: error, zkey_sha256: sha(z.data), header: hdr,
+        why: 'src/fflonk_setup.js:533-556 hard-codes BN254 constants (generator 31624 and exponent (r_bn254 - 1) / 3 in computeW3; a literal cube root of BN254 Fr.w[28] in getOmegaCubicRoot)' }, null, 1));
+    console.log('fflonk on bls12381: the reference fails with', JSON.stringify(error));
+}
+
 (async () => {
     fs.mkdirSync(OUT, { recursive: true });
     const what = process.argv[2] || 'all';
@@ -390,5 +421,6 @@ async function fflonkGolden() {
     if (what === 'all' || what === 'plonk') await plonkGolden();
     if (what === 'all' || what === 'plonkbls') await plonkGoldenBls();
     if (what === 'all' || what === 'fflonk') await fflonkGolden();
+    if (what === 'all' || what === 'fflonkbls') await fflonkBlsProbe();
     process.exit(0);
 })().catch(e => { console.error(e); process.exit(1); });

@@ -25,32 +25,43 @@ class G1:
         self.cx = cx
 
     def enc(self, p):
+        n8 = self.cx.n8
         if p is None:
-            return bytes(64)
-        q, Rq = self.cx.q, pow(2, 256, self.cx.q)
-        return (p[0] * Rq % q).to_bytes(32, "little") + (p[1] * Rq % q).to_bytes(32, "little")
+            return bytes(2 * n8)
+        q, Rq = self.cx.q, pow(2, 8 * n8, self.cx.q)
+        return (p[0] * Rq % q).to_bytes(n8, "little") + (p[1] * Rq % q).to_bytes(n8, "little")
 
     def lincomb(self, terms):
         """sum k_i * P_i for [(k_i, P_i)]"""
         r = self.cx.r
         bases = np.frombuffer(b"".join(self.enc(p) for _, p in terms), np.uint8)
         sc = np.frombuffer(b"".join((k % r).to_bytes(32, "little") for k, _ in terms), np.uint8)
-        aff = O.to_affine(0, 1, O.msm(0, 1, bases, sc, len(terms)))
+        cid, n8 = self.cx.cid, self.cx.n8
+        aff = O.to_affine(cid, 1, O.msm(cid, 1, bases, sc, len(terms)))
         if not aff.any():
             return None
-        return (int.from_bytes(bytes(aff[:32]), "little") * self.cx.Rqi % self.cx.q, int.from_bytes(bytes(aff[32:]), "little") * self.cx.Rqi % self.cx.q)
+        return (int.from_bytes(bytes(aff[:n8]), "little") * self.cx.Rqi % self.cx.q, int.from_bytes(bytes(aff[n8:]), "little") * self.cx.Rqi % self.cx.q)
 
     def generator(self):
-        return (1, 2)
+        """G1.g of the curve (ffjavascript: bn128 (1, 2); bls12381 the standard generator)"""
+        if self.cx.n8 == 32:
+            return (1, 2)
+        return (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
+                0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
 
 
 def _pt(obj):
     return None if (int(obj[0]), int(obj[1])) == (0, 1) and int(obj[2]) == 0 else (int(obj[0]), int(obj[1]))
 
 
+def _cx_of(vk):
+    """the curve context a verification key belongs to (the reference: getCurveFromName(vk.curve), src/plonk_verify.js:38)"""
+    return Ctx(48 if str(vk.get("curve", "bn128")) == "bls12381" else 32)
+
+
 def verifier_values(vk, public_signals, proof):
     """Everything the verifier computes before the pairing: dict with the challenges, L, pi, r0 and the points D, F, E, A1, B1."""
-    cx = Ctx()
+    cx = _cx_of(vk)
     r, g = cx.r, G1(cx)
     P = {k: _pt(proof[k]) for k in ("A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw")}
     ev = {k: int(proof["eval_" + k]) % r for k in ("a", "b", "c", "s1", "s2", "zw")}
@@ -117,17 +128,19 @@ def verifier_values(vk, public_signals, proof):
 
 def verify_known_tau(vk, public_signals, proof, tau):
     """plonk.verify with e(-A1, [tau]_2) e(B1, [1]_2) == 1 evaluated as B1 == tau * A1 (valid only for a key whose SRS is [tau^i] G)"""
-    cx = Ctx()
+    cx = _cx_of(vk)
     val = verifier_values(vk, public_signals, proof)
     return val["B1"] == G1(cx).lincomb([(tau, val["A1"])])
 
 
 def vk_from_zkey(zkey_bytes):
     """zKey.exportVerificationKey for a PLONK key (src/zkey_export_verificationkey.js:66-104): the fields the verifier reads"""
-    from plonk_oracle import read_plonk_zkey
-    cx = Ctx()
+    import struct
+    from plonk_oracle import read_plonk_zkey, read_sections
+    n8q = struct.unpack_from("<I", zkey_bytes, read_sections(zkey_bytes)[2][0])[0]        # the curve comes from the key's prime (src/curves.js:36-53)
+    cx = Ctx(n8q)
     zk = read_plonk_zkey(zkey_bytes, cx)
-    vk = {"nPublic": zk["nPublic"], "power": zk["power"], "k1": str(zk["k1"]), "k2": str(zk["k2"])}
+    vk = {"nPublic": zk["nPublic"], "power": zk["power"], "k1": str(zk["k1"]), "k2": str(zk["k2"]), "curve": cx.name}
     for k in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):
         vk[k] = ["0", "1", "0"] if zk[k] == (0, 0) else [str(zk[k][0]), str(zk[k][1]), "1"]     # G1.toObject of the point at infinity
     return vk

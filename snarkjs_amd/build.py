@@ -13,7 +13,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libzkmi.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
-UNITS = ["zkmi_api.hip", "ntt.hip", "msm_sort.hip", "msm_bn254.hip", "msm_bls12381.hip", "groth16.hip", "plonk.hip", "gfft.hip", "gconv.hip", "calib.hip"]
+UNITS = ["zkmi_api.hip", "ntt.hip", "msm_sort.hip", "msm_bn254.hip", "msm_bls12381.hip", "groth16.hip", "plonk.hip", "gfft.hip", "gconv.hip", "calib.hip", "peer.hip"]
 
 
 def _stale(target, deps):

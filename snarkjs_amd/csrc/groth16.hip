@@ -407,12 +407,25 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, co
     if (transforms) ZK_TRY(join_abc_dev_dispatch(K.curve, Wk.A, Wk.B, Wk.C, Wk.T, n));          // T = H-MSM scalars (normal form)
     if (do_w) ZK_HIP(hipEventRecord(Wk.ev[ST_SORT_W], st));
     // the digit sort of the H scalars: as soon as they exist (after joinABC here; at once when they come from outside)
+    // In the split proof (G16_H after G16_W) the auxiliary stream still holds the G2 bucket reduction of the witness-side half (~2 ms of pure
+    // latency): queued behind it the H sort — and with it the whole H half — would start that much later than in G16_ALL, where the sort was
+    // enqueued BEFORE that reduction. The H sort of a split proof therefore gets a stream of its own (one per pipeline slot, highest priority).
     auto sort_h_aux = [&]() -> int {
+        hipStream_t hs = aux;
+        if (!do_w) {
+            static hipStream_t h_sort_stream[2] = {nullptr, nullptr};
+            if (!h_sort_stream[cx.pipe]) {
+                int lo = 0, hi = 0;
+                ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                ZK_HIP(hipStreamCreateWithPriority(&h_sort_stream[cx.pipe], hipStreamNonBlocking, hi));
+            }
+            hs = h_sort_stream[cx.pipe];
+        }
         ZK_HIP(hipEventRecord(cx.sort_ev[3], st));
-        ZK_HIP(hipStreamWaitEvent(aux, cx.sort_ev[3], 0));
-        cx.stream = aux;
+        ZK_HIP(hipStreamWaitEvent(hs, cx.sort_ev[3], 0));
+        cx.stream = hs;
         int rc = msm_sort(h_sh, K.h_cnt, 32, plh, 1, K.ch);
-        if (!rc) rc = hipEventRecord(cx.sort_ev[4], aux) == hipSuccess ? 0 : fail(ZKMI_ERR_HIP, "hipEventRecord");
+        if (!rc) rc = hipEventRecord(cx.sort_ev[4], hs) == hipSuccess ? 0 : fail(ZKMI_ERR_HIP, "hipEventRecord");
         cx.stream = st;
         return rc;
     };
@@ -694,6 +707,17 @@ int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_
     int rc = zkmi_groth16_prove_dev(k, K->wk[0].w, r_mont, s_mont, pi_a, pi_b, pi_c);
     if (!key) zkmi_groth16_release(k);
     return rc;
+}
+int zkmi_groth16_key_curve(uint64_t key) {
+    const G16Key* K = g16_find(key);
+    return K ? K->curve : -1;
+}
+int zkmi_groth16_reset(uint64_t key) {
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_reset: key not loaded");
+    if (ctx().ready) ZK_HIP(hipDeviceSynchronize());            // both pipeline slots, main and auxiliary streams
+    for (auto& w : K->wk) { w.in_flight = false; w.w_enqueued = false; }
+    return ZKMI_OK;
 }
 int zkmi_groth16_stage_ms(double* out, int n) {
     G16Key* K = g16_find(g_last_key);

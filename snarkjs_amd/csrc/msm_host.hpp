@@ -447,7 +447,7 @@ template <class F> int msm_run(const void* d_bases, const void* d_scalars, size_
     MsmPlan pl;
     MsmJob job;
     ZK_TRY(msm_job_slot(0, job));
-    ZK_HIP(hipEventRecord(cx.ev0, st));
+    if (!cx.ev0_held) ZK_HIP(hipEventRecord(cx.ev0, st));
     ZK_TRY(msm_sort(d_scalars, n, sb, pl));
     ZK_TRY(msm_accumulate<F>(d_bases, pl, 0, job));
     MsmJob* jp = &job;

@@ -1,0 +1,99 @@
+// snarkjs_amd/csrc/peer.hip — GPU-to-GPU exchange between the PROCESSES of a multi-GPU proof, at the C-ABI (include/zkmi.h: zkmi_ipc_*,
+// zkmi_peer_copy). One process per GPU (zkmi_init binds one device); a chain owner exports the device buffer that holds its chain output,
+// every other process maps it and pulls ITS slice device to device — over xGMI when the two GPUs differ, inside HBM when the processes share
+// a device — instead of owner GPU -> pinned host pages -> the other GPUs over PCIe. The reference's analogue is ffjavascript handing chunk
+// buffers to its workers and folding the results on the host (build/snarkjs.min.js:1@214651, @207729); what travels here is the same data.
+//
+// Handle layout (ZKMI_IPC_HANDLE_BYTES = 96): bytes 0..63 hipIpcMemHandle_t of the ALLOCATION that holds the pointer, 64..71 byte offset of
+// the pointer inside it, 72..79 the exporter's pointer value, 80..83 exporter pid, 84..87 exporter device, 88..95 bytes visible from the
+// pointer to the end of the allocation. A handle opened by the process that exported it resolves to the original pointer (HIP refuses to
+// open its own handles), so a single-process test and a world of one need no special case in the caller.
+#include <string.h>
+#include <unistd.h>
+#include <map>
+#include "zkmi_common.hpp"
+
+namespace zkmi {
+
+struct IpcMapping { void* base = nullptr; int refs = 0; };
+static std::map<std::string, IpcMapping> g_ipc_open;           // by the 64 handle bytes: one mapping per exported allocation
+static std::map<void*, std::string> g_ipc_ptr;                 // pointer handed to the caller -> handle bytes
+
+}  // namespace zkmi
+
+using namespace zkmi;
+
+extern "C" {
+
+int zkmi_ipc_export(const void* d_ptr, uint8_t* handle) {
+    ZK_TRY(require_ctx());
+    if (!d_ptr || !handle) return fail(ZKMI_ERR_INVALID, "ipc_export: null argument");
+    void* base = nullptr;
+    size_t size = 0;
+    ZK_HIP(hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)d_ptr));
+    hipIpcMemHandle_t h;
+    ZK_HIP(hipIpcGetMemHandle(&h, base));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    memset(handle, 0, ZKMI_IPC_HANDLE_BYTES);
+    memcpy(handle, &h, 64);
+    const uint64_t off = (uint64_t)((const uint8_t*)d_ptr - (const uint8_t*)base), ptr = (uint64_t)(uintptr_t)d_ptr, avail = (uint64_t)size - off;
+    const uint32_t pid = (uint32_t)getpid(), dev = (uint32_t)ctx().device;
+    memcpy(handle + 64, &off, 8); memcpy(handle + 72, &ptr, 8); memcpy(handle + 80, &pid, 4); memcpy(handle + 84, &dev, 4); memcpy(handle + 88, &avail, 8);
+    return ZKMI_OK;
+}
+
+int zkmi_ipc_open(const uint8_t* handle, void** d_ptr, size_t* bytes_visible) {
+    ZK_TRY(require_ctx());
+    if (!handle || !d_ptr) return fail(ZKMI_ERR_INVALID, "ipc_open: null argument");
+    uint64_t off, ptr, avail;
+    uint32_t pid;
+    memcpy(&off, handle + 64, 8); memcpy(&ptr, handle + 72, 8); memcpy(&pid, handle + 80, 4); memcpy(&avail, handle + 88, 8);
+    if (bytes_visible) *bytes_visible = (size_t)avail;
+    if (pid == (uint32_t)getpid()) { *d_ptr = (void*)(uintptr_t)ptr; return ZKMI_OK; }      // our own export
+    const std::string key((const char*)handle, 64);
+    IpcMapping& m = g_ipc_open[key];
+    if (!m.base) {
+        hipIpcMemHandle_t h;
+        memcpy(&h, handle, 64);
+        const hipError_t e = hipIpcOpenMemHandle(&m.base, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { g_ipc_open.erase(key); return fail(ZKMI_ERR_HIP, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e)); }
+    }
+    m.refs++;
+    *d_ptr = (uint8_t*)m.base + off;
+    g_ipc_ptr[*d_ptr] = key;
+    return ZKMI_OK;
+}
+
+int zkmi_ipc_close(void* d_ptr) {
+    auto it = g_ipc_ptr.find(d_ptr);
+    if (it == g_ipc_ptr.end()) return ZKMI_OK;                   // our own export, or closed already
+    auto mt = g_ipc_open.find(it->second);
+    if (mt != g_ipc_open.end() && --mt->second.refs <= 0) {
+        if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+        (void)hipIpcCloseMemHandle(mt->second.base);
+        g_ipc_open.erase(mt);
+    }
+    g_ipc_ptr.erase(it);
+    return ZKMI_OK;
+}
+
+// d_dst (this process's device) <- d_src (a pointer from zkmi_ipc_open, or any device pointer of this process), stream-ordered on the
+// library stream and complete on return: the caller tells the exporter afterwards that its buffer may be overwritten.
+int zkmi_peer_copy(void* d_dst, const void* d_src, size_t bytes) {
+    ZK_TRY(require_ctx());
+    if (!bytes) return ZKMI_OK;
+    if (!d_dst || !d_src) return fail(ZKMI_ERR_INVALID, "peer_copy: null argument");
+    ZK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+    ZK_HIP(hipStreamSynchronize(ctx().stream));
+    return ZKMI_OK;
+}
+// the same without the wait: several slices queued back to back (the caller synchronises once, zkmi_synchronize)
+int zkmi_peer_copy_async(void* d_dst, const void* d_src, size_t bytes) {
+    ZK_TRY(require_ctx());
+    if (!bytes) return ZKMI_OK;
+    if (!d_dst || !d_src) return fail(ZKMI_ERR_INVALID, "peer_copy_async: null argument");
+    ZK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+    return ZKMI_OK;
+}
+
+}  // extern "C"

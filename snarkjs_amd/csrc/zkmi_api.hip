@@ -298,6 +298,18 @@ int zkmi_dev_free(void* d_ptr) {
     // Stream-ordered reuse: a freed block may still be read by kernels queued on its slot's stream, so it goes back to the pool of the slot
     // that allocated it (whichever slot is active when the host drops it) and is only ever handed out to work queued behind those kernels.
     if (g_ctx.pool_bytes + bytes <= g_ctx.pool_limit) {
+        // Buffers shared by both slots (a witness or key-side array allocated in slot 0 and read by kernels queued in slot 1) may still be in use
+        // on the OTHER slot's streams: the allocating slot's stream — the only one that will ever see the block again — is made to wait for what
+        // the other slot has queued so far (events, no host synchronisation).
+        const int other = 1 - slot;
+        const bool other_live = other == g_ctx.pipe ? true : g_ctx.saved[other].init;
+        if (other_live) {
+            static hipEvent_t free_ev = nullptr;
+            if (!free_ev) ZK_HIP(hipEventCreateWithFlags(&free_ev, hipEventDisableTiming));
+            hipStream_t mine = slot == g_ctx.pipe ? g_ctx.stream : g_ctx.saved[slot].stream;
+            hipStream_t theirs[2] = {other == g_ctx.pipe ? g_ctx.stream : g_ctx.saved[other].stream, other == g_ctx.pipe ? g_ctx.aux_stream : g_ctx.saved[other].aux_stream};
+            for (hipStream_t t : theirs) if (t && mine) { ZK_HIP(hipEventRecord(free_ev, t)); ZK_HIP(hipStreamWaitEvent(mine, free_ev, 0)); }
+        }
         g_ctx.pool[slot][bytes].push_back(d_ptr);
         g_ctx.pool_bytes += bytes;
     } else {
@@ -422,6 +434,14 @@ int zkmi_msm_table_multi_dev(uint64_t handle, const void* const* d_scalars, cons
     return t.curve == ZKMI_CURVE_BN128 ? msm_table_multi_bn254(t.group, t.p, t.n, t.c, d_scalars, ks, count, scalar_bytes, out_jacobians)
                                        : msm_table_multi_bls12381(t.group, t.p, t.n, t.c, d_scalars, ks, count, scalar_bytes, out_jacobians);
 }
+int zkmi_msm_table_info(uint64_t handle, int* curve, int* group, size_t* n) {
+    auto it = g_tables.find(handle);
+    if (it == g_tables.end()) return fail(ZKMI_ERR_INVALID, "msm_table_info: unknown table");
+    if (curve) *curve = it->second.curve;
+    if (group) *group = it->second.group;
+    if (n) *n = it->second.n;
+    return ZKMI_OK;
+}
 int zkmi_msm_table_release(uint64_t handle) {
     auto it = g_tables.find(handle);
     if (it == g_tables.end()) return ZKMI_OK;
@@ -432,8 +452,27 @@ int zkmi_msm_table_release(uint64_t handle) {
 }
 int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t scalar_bytes, uint8_t* out) {
     ZK_TRY(require_ctx());
+    ZK_TRY(check_cg(curve, group));
     if (!out) return fail(ZKMI_ERR_INVALID, "null output");
-    return msm_dev_dispatch(curve, group, d_bases, d_scalars, n, scalar_bytes, out);
+    // The caller's bases are the reference's R-form and stay untouched: the accumulation runs on the library's own copy, moved to R'-form on
+    // the device (r04: one 2 n pb-byte pass + 5 / 8 doublings per coordinate, ~ 40 us at 2^20 — 1.5 % of the MSM it makes 1.4 x faster), so
+    // that the standalone MSM uses the same unsaturated-limb kernels as a resident key. ZKMI_MSM_DEV_R29=0: the r01 saturated-limb kernel.
+    static const bool conv = !(getenv("ZKMI_MSM_DEV_R29") && atoi(getenv("ZKMI_MSM_DEV_R29")) == 0);
+    if (!conv || n == 0 || !d_bases) return msm_dev_dispatch(curve, group, d_bases, d_scalars, n, scalar_bytes, out);
+    const size_t pb = (size_t)2 * group * n8q_of(curve);
+    void* d_b = nullptr;
+    uint32_t* d_mask = nullptr;
+    ZK_TRY(ws_get("api.dev_bases29", n * pb, &d_b));
+    ZK_TRY(ws_get("api.dev_basemask", ((n + 31) / 32) * 4 + 16, (void**)&d_mask));
+    ZK_HIP(hipEventRecord(g_ctx.ev0, g_ctx.stream));              // zkmi_last_kernel_ms covers the copy and the conversion too
+    ZK_HIP(hipMemcpyAsync(d_b, d_bases, n * pb, hipMemcpyDeviceToDevice, g_ctx.stream));
+    int rc = msm_infmask_dispatch(curve, group, d_b, n, d_mask);
+    if (!rc) rc = msm_table_to_r29(curve, group, d_b, n, d_mask);  // registers d_b when the 29-bit path exists for (curve, group); else a no-op
+    g_ctx.ev0_held = true;
+    if (!rc) rc = msm_dev_dispatch(curve, group, d_b, d_scalars, n, scalar_bytes, out);
+    g_ctx.ev0_held = false;
+    msm_table_forget_r29(d_b);
+    return rc;
 }
 // ---- content-addressed cache of resident base tables behind zkmi_msm ---------------------------------------------------------
 // zkey sections and SRS slices are static, so the same bytes come back on every proof; their pre-computed window tables stay on
@@ -462,7 +501,22 @@ static BcHash bc_hash_bytes(const uint8_t* p, size_t len) {
     r.a ^= r.a >> 31; r.b ^= r.b >> 33;
     return r;
 }
-// chunk hashes of the first `total` bytes of a paged buffer (a chunk may straddle pages: gathered through a bounce buffer)
+// hash of chunk c of the first `total` bytes of a paged buffer (a chunk may straddle pages: gathered through a bounce buffer)
+static BcHash bc_chunk_hash_one(const zkmi_pages& pg, const std::vector<size_t>& start, size_t total, size_t c, std::vector<uint8_t>& bounce) {
+    const size_t off = c * BC_CHUNK, len = std::min(BC_CHUNK, total - off);
+    int page = 0;
+    while (page + 1 < pg.n_pages && start[page + 1] <= off) page++;
+    if (off + len <= start[page + 1]) return bc_hash_bytes(pg.ptr[page] + (off - start[page]), len);
+    bounce.resize(len);
+    size_t done = 0;
+    for (int q = page; q < pg.n_pages && done < len; q++) {
+        const size_t o = off + done - start[q], k = std::min(len - done, pg.len[q] - o);
+        memcpy(bounce.data() + done, pg.ptr[q] + o, k);
+        done += k;
+    }
+    return bc_hash_bytes(bounce.data(), len);
+}
+// chunk hashes of the first `total` bytes of a paged buffer
 static void bc_chunk_hashes(const zkmi_pages& pg, size_t total, std::vector<BcHash>& out) {
     const size_t nch = (total + BC_CHUNK - 1) / BC_CHUNK;
     out.assign(nch, BcHash());
@@ -470,22 +524,7 @@ static void bc_chunk_hashes(const zkmi_pages& pg, size_t total, std::vector<BcHa
     for (int i = 0; i < pg.n_pages; i++) start[i + 1] = start[i] + pg.len[i];
     auto work = [&](size_t c0, size_t c1) {
         std::vector<uint8_t> bounce;
-        int page = 0;
-        for (size_t c = c0; c < c1; c++) {
-            const size_t off = c * BC_CHUNK, len = std::min(BC_CHUNK, total - off);
-            while (page + 1 < pg.n_pages && start[page + 1] <= off) page++;
-            if (off + len <= start[page + 1]) out[c] = bc_hash_bytes(pg.ptr[page] + (off - start[page]), len);
-            else {
-                bounce.resize(len);
-                size_t done = 0;
-                for (int q = page; q < pg.n_pages && done < len; q++) {
-                    const size_t o = off + done - start[q], k = std::min(len - done, pg.len[q] - o);
-                    memcpy(bounce.data() + done, pg.ptr[q] + o, k);
-                    done += k;
-                }
-                out[c] = bc_hash_bytes(bounce.data(), len);
-            }
-        }
+        for (size_t c = c0; c < c1; c++) out[c] = bc_chunk_hash_one(pg, start, total, c, bounce);
     };
     unsigned nt = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
     if (nch < 64) nt = 1;
@@ -501,6 +540,10 @@ struct BcEntry {
     MsmTable table;                     // table.p == nullptr: seen, not resident
     bool no_table = false;              // would exceed the limits: never build
     uint64_t last_use = 0, uses = 0;
+    // (first page pointer, byte length) of caller buffers whose EVERY byte has been checked against this resident table, and how often each
+    // came back since: the sampled re-check below applies to these only
+    struct Seen { const uint8_t* p; size_t total; uint64_t hits; };
+    std::vector<Seen> verified;
     size_t bytes() const { return table.p ? (size_t)table.Wd * table.n * 2 * table.group * n8q_of(table.curve) : 0; }
 };
 static std::vector<BcEntry> g_bc;
@@ -523,6 +566,7 @@ static void bc_elems_to_r29(int curve, uint8_t* bytes, size_t len) {
 static size_t bc_resident_bytes() { size_t t = 0; for (auto& e : g_bc) t += e.bytes(); return t; }
 static void bc_free(BcEntry& e) {
     if (e.table.p) { if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream); table_free(e.table); }
+    e.verified.clear();
 }
 // does the resident entry e hold, as a prefix, exactly the `total` bytes whose chunk hashes are `q`? Whole chunks are compared by
 // hash; a trailing partial chunk of the query is compared byte for byte against row 0 of the table (the plain bases).
@@ -570,6 +614,38 @@ int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t 
     void *d_b = nullptr, *d_s = nullptr;
     ZK_TRY(ws_get("api.scalars", n * scalar_bytes, &d_s));
     ZK_TRY(upload_pages(scalars, n * scalar_bytes, d_s));
+    // A resident key comes back with every proof in the SAME host buffer. Hashing all of it on every call (64 MB per 2^20 G1 MSM) cost more than
+    // the device part of the call (r03: 3.28 ms through N-API against 1.92 ms on the device). r04: a buffer (first page pointer, length) whose
+    // every byte was checked against a resident table on an earlier call is re-checked by SAMPLE — its first and last whole chunk and 30 chunks
+    // at pseudo-random positions that change from call to call (2 MB) — and in full again on every 32nd sight; anything else (another pointer,
+    // another length, a failed sample) takes the full content hash as before. ZKMI_BASE_HASH_FULL=1: always the full hash.
+    static const bool hash_full = getenv("ZKMI_BASE_HASH_FULL") && atoi(getenv("ZKMI_BASE_HASH_FULL")) == 1;
+    if (key && scalar_bytes <= 32 && !hash_full && bases.n_pages >= 1) {
+        const size_t total = n * pb;
+        for (auto& e : g_bc) {
+            if (!e.table.p || e.curve != curve || e.group != group || total > e.n * pb) continue;
+            BcEntry::Seen* sn = nullptr;
+            for (auto& v : e.verified) if (v.p == bases.ptr[0] && v.total == total) sn = &v;
+            if (!sn) continue;
+            if ((++sn->hits & 31u) == 0) break;                          // periodic full check: fall through to the complete hash
+            const size_t full = total / BC_CHUNK;                        // whole chunks of the query (their hashes are position-independent of the tail)
+            bool same = true;
+            if (full) {
+                std::vector<size_t> start((size_t)bases.n_pages + 1, 0);
+                for (int i = 0; i < bases.n_pages; i++) start[i + 1] = start[i] + bases.len[i];
+                std::vector<uint8_t> bounce;
+                uint64_t x = 0x9e3779b97f4a7c15ull * (sn->hits + 1) + (uint64_t)(uintptr_t)bases.ptr[0];
+                for (int k = 0; k < 32 && same; k++) {
+                    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+                    const size_t c = k == 0 ? 0 : (k == 1 ? full - 1 : (size_t)((x * 0x2545f4914f6cdd1dull) % full));
+                    same = bc_chunk_hash_one(bases, start, total, c, bounce) == e.chunks[c];
+                }
+            }
+            if (!same) { e.verified.clear(); break; }                    // the buffer changed: full path decides
+            e.last_use = ++g_bc_clock; e.uses++;
+            return msm_table_dispatch(curve, group, e.table.p, e.table.n, e.table.c, d_s, n, scalar_bytes, out);
+        }
+    }
     if (key && scalar_bytes <= 32) {
         std::vector<BcHash> q;
         bc_chunk_hashes(bases, n * pb, q);
@@ -628,7 +704,13 @@ int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t 
         }
         BcEntry* used = hit ? hit : seen;
         used->last_use = ++g_bc_clock; used->uses++;
-        if (hit) return msm_table_dispatch(curve, group, hit->table.p, hit->table.n, hit->table.c, d_s, n, scalar_bytes, out);
+        if (hit) {
+            // every byte of this buffer has just been compared with the table (hashes of whole chunks, bytes of a partial tail)
+            bool known = false;
+            for (auto& v : hit->verified) if (v.p == bases.ptr[0] && v.total == n * pb) known = true;
+            if (!known) { if (hit->verified.size() >= 16) hit->verified.erase(hit->verified.begin()); hit->verified.push_back({bases.ptr[0], n * pb, 0}); }
+            return msm_table_dispatch(curve, group, hit->table.p, hit->table.n, hit->table.c, d_s, n, scalar_bytes, out);
+        }
     }
     ZK_TRY(ws_get("api.bases", n * pb, &d_b));
     ZK_TRY(upload_pages(bases, n * pb, d_b));

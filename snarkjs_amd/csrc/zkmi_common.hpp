@@ -60,6 +60,7 @@ struct Ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
+    bool ev0_held = false;                                  // the caller of msm_run has recorded ev0 already (zkmi_msm_dev: its conversion pass is inside the reported time)
     int msm_c_override = 0;
     std::map<std::string, DevBuf> ws;                       // named scratch buffers (grow-only)
     std::map<std::tuple<int, unsigned, int>, NttPlan> plans;  // (curve, log_n, inverse)

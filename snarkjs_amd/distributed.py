@@ -166,7 +166,7 @@ def exchange_chain_slices(be, outs, rank, world, h_ranges, process_group=None):
     return mine
 
 
-def groth16_prove_sharded(pk, witness, r_mont, s_mont, process_group=None, d_witness=None, backend=None):
+def groth16_prove_sharded(pk, witness, r_mont, s_mont, process_group=None, d_witness=None, backend=None, timeline=None):
     """One Groth16 proof over the ranks of `process_group` (BASELINE configs[2]), nothing replicated but buildABC:
 
       1. chain-parallel transforms: rank c % world runs buildABC + the iNTT -> coset -> NTT chain c (A, B, C are independent until
@@ -178,19 +178,32 @@ def groth16_prove_sharded(pk, witness, r_mont, s_mont, process_group=None, d_wit
       5. ONE all_gather of the 7*3*n8q-byte partial sums, folded in rank order: every rank returns the identical (pi_a, pi_b, pi_c).
 
     pk: ProvingKey(zkey, shard=(rank, world)) on every rank; witness: the FULL witness on every rank; r_mont, s_mont: the same
-    blinding draws on every rank. backend: object with the DeviceShard interface (the gloo CPU test passes an oracle-backed one)."""
+    blinding draws on every rank. backend: object with the DeviceShard interface (the gloo CPU test passes an oracle-backed one).
+    timeline: optional dict that receives this rank's host-clock stage boundaries in ms since the call (bench.py --gpus N prints them per
+    rank): chains_done (the rank's own chains complete, 0 for ranks without one), w_enqueued, exchange_done (every slice of this rank has
+    arrived), sums_done (H half finished = the witness-side half finished too), gathered (all_gather + fold + blinding)."""
+    import time
     import torch.distributed as dist
     rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
     be = backend or DeviceShard(pk, witness, d_witness)
+    t0 = time.perf_counter()
+    mark = (lambda k: timeline.__setitem__(k, round((time.perf_counter() - t0) * 1e3, 3))) if timeline is not None else (lambda k: None)
     try:
         h_ranges = [shard_range(be.n, j, world) for j in range(world)]
         outs = be.chains([c for c in range(3) if chain_owner(c, world) == rank])
+        mark("chains_done")
         (a, b, c), reqs = start_chain_exchange(be, outs, rank, world, h_ranges, process_group)
         be.sums_w()                                            # witness-side MSMs underneath the exchange
+        mark("w_enqueued")
         wait_chain_exchange(reqs)
         lo, hi = h_ranges[rank]
-        part = be.sums(be.join(a, b, c, hi - lo))
-        return be.finish(fold_groth16_sums(be.curve_id, all_gather_bytes(part, process_group)), r_mont, s_mont)
+        h = be.join(a, b, c, hi - lo)                          # waits for the slices (torch's stream), then enqueues joinABC
+        mark("exchange_done")
+        part = be.sums(h)
+        mark("sums_done")
+        out = be.finish(fold_groth16_sums(be.curve_id, all_gather_bytes(part, process_group)), r_mont, s_mont)
+        mark("gathered")
+        return out
     finally:
         if backend is None:
             be.close()

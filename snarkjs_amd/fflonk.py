@@ -42,6 +42,12 @@ class FflonkKey:
         n8r = struct.unpack_from("<I", data, off)[0]
         self.r = int.from_bytes(data[off + 4:off + 4 + n8r], "little"); off += 4 + n8r
         self.curve_id, self.curve_name = _curve_from_q(q)
+        if self.curve_id != 0:
+            # The reference's prover would take any curve from the zkey (src/fflonk_prove.js:51-110), but its fflonk.setup hard-codes BN254 constants
+            # (computeW3: generator 31624 to BN254's (r - 1) / 3; getOmegaCubicRoot: a literal cube root of BN254's Fr.w[28], src/fflonk_setup.js:533-556):
+            # the key it writes for BLS12-381 has w3^3 != 1 and its OWN fflonk.prove throws "Polynomial is not divisible" on a satisfied circuit
+            # (tests/golden/fflonk_bls12381_unsupported.json, produced by oracle/gen_golden.js: fflonkBlsProbe). No valid key can exist: refuse up front.
+            raise ValueError(f"Curve not supported: {self.curve_name} (FFLONK keys exist for bn128 only: the reference's fflonk.setup hard-codes BN254 constants)")
         self.f = f = _Field(self.curve_id)
         self.nVars, self.nPublic, self.n, self.nAdditions, self.nConstraints = struct.unpack_from("<IIIII", data, off); off += 20
         self.power = self.n.bit_length() - 1

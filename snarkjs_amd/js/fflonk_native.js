@@ -20,7 +20,9 @@ class FflonkKey {                                           // src/zkey_utils.js
         let off = s[2][0];
         const n8q = dv.getUint32(off, true), q = fromLE(data.subarray(off + 4, off + 4 + n8q)); off += 4 + n8q;
         const n8r = dv.getUint32(off, true); this.r = fromLE(data.subarray(off + 4, off + 4 + n8r)); off += 4 + n8r;
-        if (q !== Q_BN) throw new Error(`Curve not supported: ${q}`);
+        // FFLONK exists on bn128 only: the reference's fflonk.setup hard-codes BN254 constants (src/fflonk_setup.js:533-556), the key it writes for
+        // BLS12-381 has w3^3 != 1 and its own fflonk.prove fails on it (tests/golden/fflonk_bls12381_unsupported.json)
+        if (q !== Q_BN) throw new Error(`Curve not supported: ${q} (FFLONK keys exist for bn128 only: the reference's fflonk.setup hard-codes BN254 constants)`);
         this.curveId = 0; this.curveName = "bn128";
         const f = this.f = new Field(0);
         this.nVars = dv.getUint32(off, true); this.nPublic = dv.getUint32(off + 4, true); this.n = dv.getUint32(off + 8, true);
@@ -61,8 +63,8 @@ function cpoly(f, polys, n, track) {
 function commit(key, poly) {
     const f = key.f, k = Math.min(poly.n, key.nPtau), sc = devAlloc(k * 32);
     call("zkmi_fr_batch_dev", f.cid, 1, poly.ptr, sc, k);
-    const jac = new Uint8Array(3 * f.n8q), aff = new Uint8Array(2 * f.n8q);
-    call("zkmi_msm_table_dev", key.ptauTable, sc, k, 32, jac);
+    const aff = new Uint8Array(2 * f.n8q);
+    const jac = addon.msmTableDev(key.ptauTable, sc, k, 32);
     devFree(sc);
     call("zkmi_to_affine", f.cid, 1, jac, aff);
     return [f.unmontQ(aff.subarray(0, f.n8q)), f.unmontQ(aff.subarray(f.n8q))];

@@ -1,19 +1,25 @@
 // snarkjs_amd/js/groth16_shards.js — ONE Groth16 proof over several GPUs from Node.js (BASELINE configs[2]; north star: "host side stays
 // Node.js"). The Node twin of snarkjs_amd/distributed.py: one worker PROCESS per GPU (child_process.fork — the library binds one device per
-// process), the same split of the work, the exchange through page-locked shared host memory instead of RCCL.
+// process), the same split of the work. The bulk exchange runs GPU to GPU through the C-ABI's peer layer (include/zkmi.h: zkmi_ipc_export /
+// zkmi_ipc_open / zkmi_peer_copy — xGMI between two GPUs, HBM inside one) where distributed.py uses RCCL send / recv.
 //
 // What the reference does with its workers (ffjavascript engine_multiexp, build/snarkjs.min.js:1@214651): cut a multiExp into contiguous index
 // chunks, one per worker, add the chunk results on the host. Here a chunk is the base-index range of a GPU's key shard, and the transforms are
 // split too:
-//   1. every worker uploads the witness; the owner of chain c (rank c % world) runs buildABC + iNTT -> coset -> NTT of chain c
-//      (src/groth16_prove.js:64-76: A, B, C are independent until joinABC) and copies its output into the shared region of that chain;
+//   0. once: the owner of chain c (rank c % world) exports the device buffer that will hold the chain's output; every other worker opens the
+//      handle (exchange "peer", the default when the addon has ipcExport). exchange "shm" (r03; kept for hosts without peer access) copies
+//      the outputs through page-locked POSIX shared memory instead: owner GPU -> host pages -> the other GPUs over PCIe;
+//   1. the parent writes the witness into a 0600 shared-memory region (never into a file); every worker uploads it; the owner of chain c runs
+//      buildABC + iNTT -> coset -> NTT of chain c (src/groth16_prove.js:64-76: A, B, C are independent until joinABC) into its exported buffer;
 //   2. meanwhile every worker runs the witness-side half of its shard's MSMs (A, B1, B2, C need the witness only: zkmi_groth16_sums_w_dev);
-//   3. when the three regions are complete each worker uploads ITS slice [h_lo, h_hi) of them, joins it into its H-MSM scalars
-//      (zkmi_groth16_join_abc_dev) and runs the H half (zkmi_groth16_sums_h_dev): 7 x 3 x n8q bytes of partial sums per worker;
+//   3. when the three chains are complete each worker PULLS its slice [h_lo, h_hi) of them device to device (zkmi_peer_copy), joins it into its
+//      H-MSM scalars (zkmi_groth16_join_abc_dev) and runs the H half (zkmi_groth16_sums_h_dev): 7 x 3 x n8q bytes of partial sums per worker;
 //   4. worker 0 adds the sums of all workers point by point in rank order (zkmi_point_add) and applies blinding + toAffine
 //      (zkmi_groth16_finish, src/groth16_prove.js:103-132).
-// Control messages travel over the fork IPC channel (a few hundred bytes each); the bulk data (domain x 32 bytes per chain) only through
-// the shared regions: owner GPU -> pinned host pages -> the other GPUs over PCIe.
+// Control messages travel over the fork IPC channel (a few hundred bytes each). A chain buffer is overwritten only by the next proof, which
+// the parent starts after this one has delivered every worker's sums — i.e. after every pull has completed.
+// prove() calls are serialised (the workers hold ONE witness buffer, one set of chain buffers and one pipeline slot); after a worker error the
+// parent resets every worker (zkmi_groth16_reset) before the next proof; a worker that dies rejects every pending and future proof.
 //
 //   const { ShardedProver } = require("snarkjs_amd/js/groth16_shards.js");
 //   const sp = new ShardedProver({ world: 8, zkeyPath });          // forks the workers, every worker loads its key shard
@@ -50,6 +56,7 @@ async function workerMain() {
     const cfg = JSON.parse(process.env.ZKMI_SHARD_CFG);
     const addon = require(cfg.addonPath);
     const { rank, world } = cfg;
+    const peer = cfg.exchange === "peer";
     await addon.init(cfg.devices ? cfg.devices[rank] : rank);
     const zkeyBytes = new Uint8Array(fs.readFileSync(cfg.zkeyPath));
     const zk = parseZkey(zkeyBytes);
@@ -57,34 +64,46 @@ async function workerMain() {
     const [vLo, vHi] = shardRange(m, rank, world), [hLo, hHi] = shardRange(n, rank, world);
     await addon.groth16LoadShard(zk.desc, key, vLo, vHi, hLo, hHi);
     const owned = [0, 1, 2].filter((c) => chainOwner(c, world) === rank);
-    const shm = [0, 1, 2].map((c) => addon.shmMap(`${cfg.shmPrefix}_c${c}`, n * 32, false));
+    const shmW = addon.shmMap(`${cfg.shmPrefix}_w`, m * 32, false);                  // the witness: 0600 shared memory written by the parent
+    const shm = peer ? null : [0, 1, 2].map((c) => addon.shmMap(`${cfg.shmPrefix}_c${c}`, n * 32, false));
     const dW = await addon.devAlloc(m * 32);
     const dChain = {};
     for (const c of owned) dChain[c] = await addon.devAlloc(n * 32);
     const cnt = hHi - hLo;
     const dSl = [], dH = await addon.devAlloc(Math.max(cnt, 1) * 32);
     for (let c = 0; c < 3; c++) dSl.push(await addon.devAlloc(Math.max(cnt, 1) * 32));
-    process.send({ ev: "ready", rank });
-    process.on("message", async (msg) => {
+    const src = [0, 0, 0];                                      // peer mode: where chain c's output can be read from in THIS process
+    const opened = [];
+    const handles = {};
+    if (peer) for (const c of owned) { handles[c] = Buffer.from(await addon.ipcExport(dChain[c])).toString("base64"); src[c] = dChain[c]; }
+    const send = (m) => { if (process.connected) process.send(m, () => { /* a parent that went away is handled by 'disconnect' */ }); };
+    send({ ev: "ready", rank, handles });
+    let busy = Promise.resolve();                              // one command at a time: an async handler yields at every await
+    const handle = async (msg) => {
         try {
-            if (msg.cmd === "prove") {
-                const witness = new Uint8Array(fs.readFileSync(msg.wtnsPath));
-                await addon.memcpyH2D(dW, parseWtns(witness, zk));
-                if (owned.length) {                         // transforms first: their output leaves early
+            if (msg.cmd === "peers") {                          // every chain owner's handle: open the ones that live elsewhere
+                for (let c = 0; c < 3; c++) if (!owned.includes(c)) { src[c] = await addon.ipcOpen(new Uint8Array(Buffer.from(msg.handles[c], "base64"))); opened.push(src[c]); }
+                send({ ev: "peers_ok", rank });
+            } else if (msg.cmd === "prove") {
+                await addon.memcpyH2D(dW, shmW);
+                if (owned.length) {                             // transforms first: their output leaves early
                     const ptr = (c) => (dChain[c] === undefined ? 0 : dChain[c]);
-                    await addon.groth16ChainsDev(key, dW, owned.reduce((a, c) => a | (1 << c), 0), ptr(0), ptr(1), ptr(2));
-                    for (const c of owned) { await addon.memcpyD2H(shm[c], dChain[c]); process.send({ ev: "chain", id: msg.id, chain: c }); }
+                    await addon.groth16ChainsDev(key, dW, owned.reduce((a, c) => a | (1 << c), 0), ptr(0), ptr(1), ptr(2));     // complete on return
+                    for (const c of owned) { if (!peer) await addon.memcpyD2H(shm[c], dChain[c]); send({ ev: "chain", id: msg.id, chain: c }); }
                 }
-                await addon.groth16SumsWDev(key, dW);       // witness-side MSMs: enqueued, run while the other chains finish and travel
-                process.send({ ev: "w", id: msg.id, rank });
+                await addon.groth16SumsWDev(key, dW);           // witness-side MSMs: enqueued, run while the other chains finish and travel
+                send({ ev: "w", id: msg.id, rank });
             } else if (msg.cmd === "slices") {
                 if (cnt) {
-                    for (let c = 0; c < 3; c++) await addon.memcpyH2D(dSl[c], shm[c].subarray(32 * hLo, 32 * hHi));
+                    for (let c = 0; c < 3; c++) {
+                        if (peer) await addon.peerCopy(dSl[c], src[c] + 32 * hLo, 32 * cnt);          // device to device: xGMI, or HBM on a shared device
+                        else await addon.memcpyH2D(dSl[c], shm[c].subarray(32 * hLo, 32 * hHi));
+                    }
                     await addon.joinABCDev(cid, dSl[0], dSl[1], dSl[2], dH, cnt);
                 }
                 const sums = await addon.groth16SumsHDev(cid, key, dW, dH);
-                process.send({ ev: "sums", id: msg.id, rank, sums: Buffer.from(sums).toString("base64") });
-            } else if (msg.cmd === "finish") {             // worker 0: fold in rank order + blinding + toAffine
+                send({ ev: "sums", id: msg.id, rank, sums: Buffer.from(sums).toString("base64") });
+            } else if (msg.cmd === "finish") {                 // worker 0: fold in rank order + blinding + toAffine
                 const q = cid === 0 ? 32 : 48, j1 = 3 * q;
                 const parts = msg.sums.map((b) => new Uint8Array(Buffer.from(b, "base64")));
                 const total = new Uint8Array(7 * j1);
@@ -94,13 +113,19 @@ async function workerMain() {
                     total.set(acc, a);
                 }
                 const res = await addon.groth16Finish(cid, key, total, new Uint8Array(Buffer.from(msg.r, "base64")), new Uint8Array(Buffer.from(msg.s, "base64")));
-                process.send({ ev: "proof", id: msg.id, pi_a: Buffer.from(res.pi_a).toString("base64"), pi_b: Buffer.from(res.pi_b).toString("base64"), pi_c: Buffer.from(res.pi_c).toString("base64") });
+                send({ ev: "proof", id: msg.id, pi_a: Buffer.from(res.pi_a).toString("base64"), pi_b: Buffer.from(res.pi_b).toString("base64"), pi_c: Buffer.from(res.pi_c).toString("base64") });
+            } else if (msg.cmd === "reset") {                  // after a failed proof anywhere: forget half-enqueued work (Work.w_enqueued / in_flight)
+                if (addon.groth16Reset) await addon.groth16Reset(key);
+                send({ ev: "reset_ok", id: msg.id, rank });
             } else if (msg.cmd === "exit") {
-                try { addon.groth16Release(key); } catch (e) { /* going away anyway */ }
+                for (const p of opened) { try { await addon.ipcClose(p); } catch (e) { /* going away anyway */ } }
+                try { await addon.groth16Release(key); } catch (e) { /* going away anyway */ }
                 process.exit(0);
             }
-        } catch (e) { process.send({ ev: "error", id: msg.id, rank, message: String(e && e.message || e) }); }
-    });
+        } catch (e) { send({ ev: "error", id: msg.id, rank, message: String(e && e.message || e) }); }
+    };
+    process.on("message", (msg) => { busy = busy.then(() => handle(msg)); });
+    process.on("disconnect", () => process.exit(0));           // the parent is gone: do not linger with a GPU bound
 }
 
 // ---- parent ---------------------------------------------------------------------------------------------------------------------------------
@@ -111,38 +136,79 @@ class ShardedProver {
         this.addonPath = opts.addonPath || path.join(__dirname, "..", "napi", "zkmi_napi.node");
         const addon = this.addon = require(this.addonPath);
         const zk = this.zk = parseZkey(new Uint8Array(fs.readFileSync(this.zkeyPath)));
+        // "peer": chain outputs move GPU to GPU (zkmi_ipc_* / zkmi_peer_copy); "shm": through page-locked shared host memory (PCIe both ways)
+        this.exchange = opts.exchange || (typeof addon.ipcExport === "function" ? "peer" : "shm");
+        if (this.exchange !== "peer" && this.exchange !== "shm") throw new Error(`ShardedProver: unknown exchange "${this.exchange}"`);
         this.shmPrefix = `/zkmi_${process.pid}_${crypto.randomBytes(4).toString("hex")}`;
-        // the three chain-output regions: created here, mapped by every worker; unlinked at close()
-        this.regions = [0, 1, 2].map((c) => addon.shmMap(`${this.shmPrefix}_c${c}`, zk.domainSize * 32, true));
+        // shared regions (created 0600 here, mapped by every worker, unlinked at close()): the witness; in "shm" mode the three chain outputs too
+        this.shmNames = [`${this.shmPrefix}_w`];
+        this.witnessRegion = addon.shmMap(this.shmNames[0], zk.nVars * 32, true);
+        this.regions = [];
+        if (this.exchange === "shm") for (let c = 0; c < 3; c++) { this.shmNames.push(`${this.shmPrefix}_c${c}`); this.regions.push(addon.shmMap(this.shmNames[c + 1], zk.domainSize * 32, true)); }
         this.waiters = new Map();
         this.nextId = 1;
         this.workers = [];
+        this.dead = null;                                       // Error once a worker has gone away
+        this.needReset = false;
+        this.queue = Promise.resolve();                         // prove() calls run one at a time
         this._ready = new Promise((resolve, reject) => {
-            let up = 0;
+            let up = 0, peersOk = 0;
+            const handles = {};
             for (let rank = 0; rank < this.world; rank++) {
-                const cfg = { rank, world: this.world, zkeyPath: this.zkeyPath, addonPath: this.addonPath, shmPrefix: this.shmPrefix, devices: opts.devices || null };
+                const cfg = { rank, world: this.world, zkeyPath: this.zkeyPath, addonPath: this.addonPath, shmPrefix: this.shmPrefix, devices: opts.devices || null, exchange: this.exchange };
                 const w = fork(__filename, ["--zkmi-shard-worker"], { env: Object.assign({}, process.env, { ZKMI_SHARD_CFG: JSON.stringify(cfg) }), execArgv: opts.execArgv || process.execArgv });
                 w.on("message", (msg) => {
-                    if (msg.ev === "ready") { if (++up === this.world) resolve(); return; }
+                    if (msg.ev === "ready") {
+                        Object.assign(handles, msg.handles || {});
+                        if (++up === this.world) { if (this.exchange === "peer") for (const x of this.workers) x.send({ cmd: "peers", handles }); else resolve(); }
+                        return;
+                    }
+                    if (msg.ev === "peers_ok") { if (++peersOk === this.world) resolve(); return; }
                     if (msg.ev === "error" && !msg.id) { reject(new Error(`shard worker ${msg.rank}: ${msg.message}`)); return; }
                     const wt = this.waiters.get(msg.id);
                     if (wt) wt(msg);
                 });
-                w.on("exit", (code) => { if (code && up < this.world) reject(new Error(`shard worker ${rank} exited with code ${code}`)); });
+                w.on("error", () => { /* a send to a worker that has just gone away: the 'exit' handler below reports it */ });
+                w.on("exit", (code, signal) => {
+                    if (this.closing) return;
+                    const err = new Error(`shard worker ${rank} exited (code ${code}, signal ${signal})`);
+                    this.dead = this.dead || err;
+                    reject(err);                                // no-op once resolved
+                    for (const wt of Array.from(this.waiters.values())) wt({ ev: "error", rank, message: err.message, fatal: true });
+                });
                 this.workers.push(w);
             }
         });
+        this._ready.catch(() => {});                            // surfaced through ready() / prove()
     }
     ready() { return this._ready; }
-    // wtns: Uint8Array (written to a temporary file the workers read) or a path
-    async prove(wtns, opts) {
-        opts = opts || {};
+    // wtns: Uint8Array with the .wtns file's bytes, or a path. Calls are serialised: the returned promise settles in call order.
+    prove(wtns, opts) {
+        const run = () => this._proveOne(wtns, opts || {});
+        const p = this.queue.then(run, run);
+        this.queue = p.catch(() => {});
+        return p;
+    }
+    _broadcastAndWait(cmd, ev) {
+        const id = this.nextId++;
+        return new Promise((resolve, reject) => {
+            let got = 0;
+            this.waiters.set(id, (msg) => {
+                if (msg.ev === "error") { this.waiters.delete(id); reject(new Error(`shard worker ${msg.rank}: ${msg.message}`)); return; }
+                if (msg.ev === ev && ++got === this.world) { this.waiters.delete(id); resolve(); }
+            });
+            for (const w of this.workers) if (w.connected) w.send({ cmd, id });
+        });
+    }
+    async _proveOne(wtns, opts) {
         await this._ready;
+        if (this.dead) throw this.dead;
+        if (this.needReset) { await this._broadcastAndWait("reset", "reset_ok"); this.needReset = false; }
         const zk = this.zk, cid = zk.curveId, id = this.nextId++;
-        let wtnsPath = wtns, tmp = null;
-        if (typeof wtns !== "string") { tmp = path.join(require("os").tmpdir(), `zkmi_${process.pid}_${id}.wtns`); fs.writeFileSync(tmp, wtns); wtnsPath = tmp; }
-        const witness = parseWtns(new Uint8Array(fs.readFileSync(wtnsPath)), zk);
+        const witness = parseWtns(typeof wtns === "string" ? new Uint8Array(fs.readFileSync(wtns)) : wtns, zk);
+        this.witnessRegion.set(witness);                       // the private inputs never touch the file system
         const r = opts.r || randomFrMont(cid), s = opts.s || randomFrMont(cid);
+        const t0 = process.hrtime.bigint(), at = {};
         try {
             const res = await new Promise((resolve, reject) => {
                 let chains = 0, ws = 0;
@@ -151,33 +217,38 @@ class ShardedProver {
                 this.waiters.set(id, (msg) => {
                     if (msg.ev === "error") { reject(new Error(`shard worker ${msg.rank}: ${msg.message}`)); return; }
                     order.push(msg.ev);
+                    at[msg.ev] = Number(process.hrtime.bigint() - t0) / 1e6;       // last arrival of each kind, ms after the proof was started
                     if (msg.ev === "chain") chains++;
                     if (msg.ev === "w") ws++;
-                    // every region complete and every witness-side half enqueued: the slices may be read
-                    if ((msg.ev === "chain" || msg.ev === "w") && chains === 3 && ws === this.world) for (const w of this.workers) w.send({ cmd: "slices", id });
+                    // every chain complete and every witness-side half enqueued: the slices may be pulled
+                    if ((msg.ev === "chain" || msg.ev === "w") && chains === 3 && ws === this.world) for (const w of this.workers) if (w.connected) w.send({ cmd: "slices", id });
                     if (msg.ev === "sums") {
                         sums[msg.rank] = msg.sums;
                         if (sums.every((x) => x !== null)) this.workers[0].send({ cmd: "finish", id, sums, r: Buffer.from(r).toString("base64"), s: Buffer.from(s).toString("base64") });
                     }
                     if (msg.ev === "proof") resolve({ msg, order });
                 });
-                for (const w of this.workers) w.send({ cmd: "prove", id, wtnsPath });
+                for (const w of this.workers) if (w.connected) w.send({ cmd: "prove", id });
             });
             const b = (x) => new Uint8Array(Buffer.from(x, "base64"));
             const publicSignals = [];
             for (let i = 1; i <= zk.nPublic; i++) publicSignals.push(fromLE(witness.subarray(i * zk.n8r, (i + 1) * zk.n8r)).toString());
             return { proof: { pi_a: pointToObject(cid, 1, b(res.msg.pi_a)), pi_b: pointToObject(cid, 2, b(res.msg.pi_b)), pi_c: pointToObject(cid, 1, b(res.msg.pi_c)), protocol: "groth16", curve: zk.curveName },
-                     publicSignals, events: res.order };
+                     publicSignals, events: res.order, exchange: this.exchange, timeline_ms: at };
+        } catch (e) {
+            this.needReset = !this.dead;                       // some workers may sit between the two halves of this proof
+            throw e;
         } finally {
             this.waiters.delete(id);
-            if (tmp) fs.unlinkSync(tmp);
+            this.witnessRegion.fill(0);
         }
     }
     async close() {
-        for (const w of this.workers) { try { w.send({ cmd: "exit" }); } catch (e) { /* already gone */ } }
-        await Promise.all(this.workers.map((w) => new Promise((res) => { if (w.exitCode !== null) res(); else w.on("exit", res); })));
-        for (let c = 0; c < 3; c++) this.addon.shmUnlink(`${this.shmPrefix}_c${c}`);
-        this.regions = [];
+        this.closing = true;
+        for (const w of this.workers) { if (w.connected) { try { w.send({ cmd: "exit" }); } catch (e) { /* already gone */ } } }
+        await Promise.all(this.workers.map((w) => new Promise((res) => { if (w.exitCode !== null || w.signalCode !== null) res(); else w.on("exit", res); })));
+        for (const nm of this.shmNames) this.addon.shmUnlink(nm);
+        this.regions = []; this.witnessRegion = null;
     }
 }
 

@@ -136,9 +136,7 @@ class Transcript {                                          // src/Keccak256Tran
 function commit(key, polys) {
     const f = key.f, cnt = polys.length;
     const scs = polys.map((p) => { const sc = devAlloc(p.n * 32); call("zkmi_fr_batch_dev", f.cid, 1, p.ptr, sc, p.n); return sc; });     // batchFromMontgomery
-    const jac = new Uint8Array(cnt * 3 * f.n8q), ptrs = new BigUint64Array(cnt), ks = new BigUint64Array(cnt);
-    polys.forEach((p, i) => { ptrs[i] = BigInt(scs[i]); ks[i] = BigInt(p.n); });
-    call("zkmi_msm_table_multi_dev", key.ptauTable, ptrs, ks, cnt, 32, jac);
+    const jac = addon.msmTableMultiDev(key.ptauTable, scs, polys.map((p) => p.n), 32);
     const out = [];
     for (let i = 0; i < cnt; i++) {
         const aff = new Uint8Array(2 * f.n8q);

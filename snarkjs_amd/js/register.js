@@ -54,6 +54,11 @@ function register(curve, options) {
     // options.async !== false: multiExpAffine / fft / ifft run on a libuv pool thread (addon.msmAsync / nttAsync, napi_create_async_work)
     // and the Node event loop keeps turning meanwhile; `async: false` keeps the blocking calls.
     const useAsync = options.async !== false && typeof addon.msmAsync === "function" && typeof addon.nttAsync === "function";
+    // options.minPoints (default 0: every buffer-form call runs on the device): calls on FEWER elements go to the curve's own saved entry points
+    // — the reference's WASM, the behaviour SURVEY.md 8b describes for a drop-in ("falls back to the saved originals when n is small"). A call on
+    // 4 points costs the device path about a dozen launches (bench.py: wall_through_napi.msm_small_ms / ntt_small_ms); a host that issues
+    // many tiny calls (a verifier's nPublic-point MSM in a loop) sets e.g. minPoints: 1024. Never applied silently: the default is 0.
+    const minPoints = options.minPoints === undefined ? 0 : options.minPoints;
 
     for (const [gname, group] of [["G1", 1], ["G2", 2]]) {
         const G = curve[gname];
@@ -72,6 +77,7 @@ function register(curve, options) {
             if (nPoints == 0) return G.zero;
             const sScalar = Math.floor(buffScalars.byteLength / nPoints);
             if (sScalar * nPoints != buffScalars.byteLength) throw new Error("Scalar size does not match");
+            if (nPoints < minPoints) return orig[gname].multiExpAffine.apply(G, arguments);
             if (logger) logger.debug(`Multiexp start: ${logText}: 0/${nPoints}`);
             const key = (cacheBases && nPoints >= cacheMinPoints) ? CACHE_ALLOWED : 0;
             const res = useAsync ? await addon.msmAsync(cid, group, pagesOf(buffBases), pagesOf(buffScalars), nPoints, sScalar, key)
@@ -138,6 +144,7 @@ function register(curve, options) {
         const n = buff.byteLength / Fr.n8;
         const bits = log2(n);
         if ((1 << bits) != n) throw new Error("fft must be multiple of 2");
+        if (n < minPoints) return origFn.apply(Fr, args);
         const out = allocLikeSliced(buff, buff.byteLength);
         if (useAsync) await addon.nttAsync(cid, pagesOf(buff), pagesOf(out), bits, inverse ? 1 : 0, null, null);
         else addon.ntt(cid, pagesOf(buff), pagesOf(out), bits, inverse ? 1 : 0, null, null);
@@ -147,7 +154,7 @@ function register(curve, options) {
     Fr.ifft = function (buff, inType, outType, logger, loggerTxt) { return ntt(buff, true, orig.Fr.ifft, arguments); };
 
     Fr.batchApplyKey = async function (buff, first, inc, inType, outType) {
-        if (!isBuf(buff)) return orig.Fr.batchApplyKey.apply(Fr, arguments);
+        if (!isBuf(buff) || buff.byteLength / Fr.n8 < minPoints) return orig.Fr.batchApplyKey.apply(Fr, arguments);
         const out = allocLike(buff, buff.byteLength);
         addon.applyKey(cid, pagesOf(buff), pagesOf(out), Math.floor(buff.byteLength / Fr.n8), Fr.e(first), Fr.e(inc));
         return out;
@@ -156,6 +163,7 @@ function register(curve, options) {
         return async function (buff) {
             if (!isBuf(buff)) return orig.Fr[name].apply(Fr, arguments);
             if (buff.byteLength % Fr.n8) throw new Error("Invalid buffer size");
+            if (buff.byteLength / Fr.n8 < minPoints) return orig.Fr[name].apply(Fr, arguments);
             const out = (op == OP.INVERSE ? allocLikeSliced : allocLike)(buff, buff.byteLength);
             addon.frBatch(cid, op, pagesOf(buff), pagesOf(out), Math.floor(buff.byteLength / Fr.n8));
             return out;

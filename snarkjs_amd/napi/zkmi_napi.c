@@ -364,6 +364,7 @@ static napi_value new_proof_obj(napi_env env, int curve, uint8_t** pa, uint8_t**
     if (napi_set_named_property(env, res, "pi_a", va) != napi_ok || napi_set_named_property(env, res, "pi_b", vb) != napi_ok || napi_set_named_property(env, res, "pi_c", vc) != napi_ok) return NULL;
     return res;
 }
+static int key_curve_mismatch(napi_env env, double key, int32_t curve);
 static napi_value groth16_impl(napi_env env, napi_callback_info info, bool async) {
     ARGS(5);
     zkmi_groth16_zkey zk, *pzk = NULL;
@@ -383,6 +384,7 @@ static napi_value groth16_impl(napi_env env, napi_callback_info info, bool async
         if (get_i32(env, argv[0], &c)) BAD_ARG();
         curve = c;
     }
+    if ((curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381) || key_curve_mismatch(env, key, curve)) { if (curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381) BAD_ARG(); return NULL; }
     uint8_t *pa, *pb, *pc;
     napi_value res = new_proof_obj(env, curve, &pa, &pb, &pc);
     if (!res) BAD_ARG();
@@ -455,12 +457,20 @@ static napi_value submit_impl(napi_env env, napi_callback_info info, bool async)
 }
 static napi_value js_groth16_submit(napi_env env, napi_callback_info info) { return submit_impl(env, info, false); }
 static napi_value js_groth16_submit_async(napi_env env, napi_callback_info info) { return submit_impl(env, info, true); }
+/* The library writes results in the format of the RESIDENT KEY's curve: a caller-supplied curve id that disagrees with it would size the
+ * output arrays wrongly (curve 0 with a BLS12-381 key: 96 / 192 / 1008 bytes written into 64 / 128 / 672). Checked before every such call. */
+static int key_curve_mismatch(napi_env env, double key, int32_t curve) {
+    const int kc = ZK_CALL(zkmi_groth16_key_curve((uint64_t)key));   /* -1: not resident (the call itself will say so) */
+    if (kc >= 0 && kc != curve) { napi_throw_type_error(env, NULL, "zkmi: the curve argument differs from the curve of the resident key"); return 1; }
+    return 0;
+}
 static napi_value collect_impl(napi_env env, napi_callback_info info, bool async) {
     ARGS(5);
     int32_t curve, slot; double key;
     const uint8_t *r, *s;
     if (get_i32(env, argv[0], &curve) || get_f64(env, argv[1], &key) || get_i32(env, argv[2], &slot) || (slot != 0 && slot != 1) || get_opt32(env, argv[3], &r) ||
         get_opt32(env, argv[4], &s) || !r || !s || (curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381)) BAD_ARG();
+    if (key_curve_mismatch(env, key, curve)) return NULL;
     uint8_t *pa, *pb, *pc;
     napi_value res = new_proof_obj(env, curve, &pa, &pb, &pc);
     if (!res) BAD_ARG();
@@ -546,6 +556,7 @@ static napi_value sums_impl(napi_env env, napi_callback_info info, bool with_h) 
     int32_t curve; double key; void *w, *h = NULL;
     if (get_i32(env, argv[0], &curve) || (curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381) || get_f64(env, argv[1], &key) || get_dptr(env, argv[2], &w) ||
         (with_h && get_dptr(env, argv[3], &h))) BAD_ARG();
+    if (key_curve_mismatch(env, key, curve)) return NULL;
     uint8_t* out;
     napi_value res = new_u8(env, (size_t)21 * (curve == ZKMI_CURVE_BN128 ? 32 : 48), &out);
     if (!res) BAD_ARG();
@@ -560,6 +571,7 @@ static napi_value js_groth16_finish(napi_env env, napi_callback_info info) {
     int32_t curve; double key; pages_t sm; const uint8_t *r, *s;
     if (get_i32(env, argv[0], &curve) || (curve != ZKMI_CURVE_BN128 && curve != ZKMI_CURVE_BLS12381) || get_f64(env, argv[1], &key) || get_pages(env, argv[2], &sm) || sm.n != 1 ||
         sm.len[0] != (size_t)21 * (curve == ZKMI_CURVE_BN128 ? 32 : 48) || get_opt32(env, argv[3], &r) || get_opt32(env, argv[4], &s) || !r || !s) BAD_ARG();
+    if (key_curve_mismatch(env, key, curve)) return NULL;
     uint8_t *pa, *pb, *pc;
     napi_value res = new_proof_obj(env, curve, &pa, &pb, &pc);
     if (!res) BAD_ARG();
@@ -590,6 +602,98 @@ static napi_value js_point_add(napi_env env, napi_callback_info info) {
     return res;
 }
 
+/* msmTableDev(handle, dScalars, k, scalarBytes) -> Uint8Array(3*group*n8q); msmTableMultiDev(handle, [dScalars...], [k...], scalarBytes) ->
+ * Uint8Array(count * 3*group*n8q): the result buffers are sized from the TABLE (zkmi_msm_table_info), never from a caller-supplied length. */
+static napi_value js_msm_table_dev(napi_env env, napi_callback_info info) {
+    ARGS(4);
+    double h, k; void* sc; int32_t sb; int curve, group;
+    if (get_f64(env, argv[0], &h) || get_dptr(env, argv[1], &sc) || get_f64(env, argv[2], &k) || k < 0 || get_i32(env, argv[3], &sb)) BAD_ARG();
+    int rc = ZK_CALL(zkmi_msm_table_info((uint64_t)h, &curve, &group, NULL));
+    if (rc) return throw_zkmi(env, rc);
+    uint8_t* out;
+    napi_value res = new_u8(env, (size_t)3 * group * (curve == ZKMI_CURVE_BN128 ? 32 : 48), &out);
+    if (!res) BAD_ARG();
+    rc = ZK_CALL(zkmi_msm_table_dev((uint64_t)h, sc, (size_t)k, (size_t)sb, out));
+    if (rc) return throw_zkmi(env, rc);
+    return res;
+}
+static napi_value js_msm_table_multi_dev(napi_env env, napi_callback_info info) {
+    ARGS(4);
+    double h; int32_t sb; int curve, group; uint32_t cnt = 0, cnt2 = 0;
+    bool a0 = false, a1 = false;
+    if (get_f64(env, argv[0], &h) || napi_is_array(env, argv[1], &a0) != napi_ok || !a0 || napi_is_array(env, argv[2], &a1) != napi_ok || !a1 ||
+        napi_get_array_length(env, argv[1], &cnt) != napi_ok || napi_get_array_length(env, argv[2], &cnt2) != napi_ok || cnt != cnt2 || cnt < 1 || cnt > 4 ||
+        get_i32(env, argv[3], &sb)) BAD_ARG();
+    const void* ptrs[4]; size_t ks[4];
+    for (uint32_t i = 0; i < cnt; i++) {
+        napi_value e; void* p; double k;
+        if (napi_get_element(env, argv[1], i, &e) != napi_ok || get_dptr(env, e, &p) || napi_get_element(env, argv[2], i, &e) != napi_ok || get_f64(env, e, &k) || k < 0) BAD_ARG();
+        ptrs[i] = p; ks[i] = (size_t)k;
+    }
+    int rc = ZK_CALL(zkmi_msm_table_info((uint64_t)h, &curve, &group, NULL));
+    if (rc) return throw_zkmi(env, rc);
+    uint8_t* out;
+    napi_value res = new_u8(env, (size_t)cnt * 3 * group * (curve == ZKMI_CURVE_BN128 ? 32 : 48), &out);
+    if (!res) BAD_ARG();
+    rc = ZK_CALL(zkmi_msm_table_multi_dev((uint64_t)h, ptrs, ks, (int)cnt, (size_t)sb, out));
+    if (rc) return throw_zkmi(env, rc);
+    return res;
+}
+/* GPU-to-GPU exchange between shard processes (include/zkmi.h: zkmi_ipc_*): ipcExport(ptr) -> Uint8Array(ZKMI_IPC_HANDLE_BYTES);
+ * ipcOpen(handle) -> pointer in this process; ipcClose(ptr); peerCopy(dDst, dSrc, bytes) (complete on return); groth16Reset(key);
+ * groth16KeyCurve(key) -> 0 | 1 | -1 */
+static napi_value js_ipc_export(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    void* p;
+    if (get_dptr(env, argv[0], &p)) BAD_ARG();
+    uint8_t* out;
+    napi_value res = new_u8(env, ZKMI_IPC_HANDLE_BYTES, &out);
+    if (!res) BAD_ARG();
+    int rc = ZK_CALL(zkmi_ipc_export(p, out));
+    if (rc) return throw_zkmi(env, rc);
+    return res;
+}
+static napi_value js_ipc_open(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    pages_t h; void* p = NULL; napi_value v;
+    if (get_pages(env, argv[0], &h) || h.n != 1 || h.len[0] != ZKMI_IPC_HANDLE_BYTES) BAD_ARG();
+    int rc = ZK_CALL(zkmi_ipc_open(h.ptr[0], &p, NULL));
+    if (rc) return throw_zkmi(env, rc);
+    NAPI_OK(napi_create_double(env, (double)(uintptr_t)p, &v));
+    return v;
+}
+static napi_value js_ipc_close(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    void* p;
+    if (get_dptr(env, argv[0], &p)) BAD_ARG();
+    int rc = ZK_CALL(zkmi_ipc_close(p));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_peer_copy(napi_env env, napi_callback_info info) {
+    ARGS(3);
+    void *d, *s; double bytes;
+    if (get_dptr(env, argv[0], &d) || get_dptr(env, argv[1], &s) || get_f64(env, argv[2], &bytes) || bytes < 0) BAD_ARG();
+    int rc = ZK_CALL(zkmi_peer_copy(d, s, (size_t)bytes));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_groth16_reset(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    double key;
+    if (get_f64(env, argv[0], &key)) BAD_ARG();
+    int rc = ZK_CALL(zkmi_groth16_reset((uint64_t)key));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_groth16_key_curve(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    double key; napi_value v;
+    if (get_f64(env, argv[0], &key)) BAD_ARG();
+    NAPI_OK(napi_create_int32(env, ZK_CALL(zkmi_groth16_key_curve((uint64_t)key)), &v));
+    return v;
+}
+
 /* call(name, ...args) -> 0 — table-driven binding of the device-resident PLONK / FFLONK entry points of include/zkmi.h (every parameter an
  * integer, a device pointer or a host buffer). Only the entry points listed below can be reached, and every argument is checked against the
  * kind the C prototype expects before the call is made:
@@ -603,7 +707,7 @@ static const struct { const char* name; const char* sig; } g_call_table[] = {
     {"zkmi_fr_root", "i i b32"},
     {"zkmi_dev_alloc", "i b8"}, {"zkmi_dev_free", "d"}, {"zkmi_memcpy_h2d", "d b@2 i"}, {"zkmi_memcpy_d2h", "b@2 d i"}, {"zkmi_memcpy_d2d", "d d i"}, {"zkmi_memset_dev", "d i i"},
     {"zkmi_fr_batch_dev", "i i d d i"}, {"zkmi_ntt_dev", "i d d i i B32 B32"},
-    {"zkmi_msm_table_build", "i i d i b8"}, {"zkmi_msm_table_dev", "i d i i b96"}, {"zkmi_msm_table_multi_dev", "i b8 b8 i i b96"}, {"zkmi_msm_table_release", "i"},
+    {"zkmi_msm_table_build", "i i d i b8"}, {"zkmi_msm_table_release", "i"},
     {"zkmi_plonk_gather_wires_dev", "i d i d i d d d i i d d d"},
     {"zkmi_plonk_compute_z_dev", "i d d d d d d i b32 b32 b32 b32 b32 d"}, {"zkmi_plonk_compute_z_enqueue", "i d d d d d d i b32 b32 b32 b32 b32 d"},
     {"zkmi_pipeline_select", "i"}, {"zkmi_synchronize", ""},
@@ -734,6 +838,8 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"devAlloc", js_dev_alloc}, {"devFree", js_dev_free}, {"memcpyH2D", js_memcpy_h2d}, {"memcpyD2H", js_memcpy_d2h},
         {"groth16ChainsDev", js_groth16_chains_dev}, {"groth16SumsWDev", js_groth16_sums_w_dev}, {"groth16SumsHDev", js_groth16_sums_h_dev}, {"groth16SumsDev", js_groth16_sums_dev},
         {"groth16Finish", js_groth16_finish}, {"joinABCDev", js_join_abc_dev}, {"pointAdd", js_point_add}, {"shmMap", js_shm_map}, {"shmUnlink", js_shm_unlink},
+        {"msmTableDev", js_msm_table_dev}, {"msmTableMultiDev", js_msm_table_multi_dev}, {"ipcExport", js_ipc_export}, {"ipcOpen", js_ipc_open}, {"ipcClose", js_ipc_close},
+        {"peerCopy", js_peer_copy}, {"groth16Reset", js_groth16_reset}, {"groth16KeyCurve", js_groth16_key_curve},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

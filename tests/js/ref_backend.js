@@ -18,7 +18,8 @@ const mem = new Map();
 let nextPtr = 4096;
 const keys = new Map();
 const slots = {};
-let failNextLoad = false;
+let failNextLoad = false, failNextCall = null;
+const exported = [];
 
 function loadKey(desc, key, vLo, vHi, hLo, hHi) {
     if (failNextLoad) { failNextLoad = false; throw new Error("zkmi error 2: injected load failure"); }
@@ -129,5 +130,42 @@ const backend = {
     async joinABCDev(cid, dA, dB, dC, dOut, cnt) { note("join"); const curve = await getCurve(cid); mem.get(dOut).set(await joinABC(curve, mem.get(dA), mem.get(dB), mem.get(dC), cnt)); },
     async groth16Finish(cid, key, sums, r, s) { note("finish"); return finish(keys.get(key), sums, r, s); },
     pointAdd: real.pointAdd, shmMap: real.shmMap, shmUnlink: real.shmUnlink,
+    // The peer layer (zkmi_ipc_export / _open / zkmi_peer_copy) between the PROCESSES of the shard driver: this stand-in's "device memory" is a
+    // per-process Map, so an exported buffer moves into a real POSIX shared-memory object that the opening process maps — same protocol, same
+    // ownership rules (the exporter keeps the memory; a handle opened by its exporter resolves to the original pointer).
+    ipcExport(p) {
+        note("ipcExport");
+        const cur = mem.get(p), name = `/zkmi_mock_${process.pid}_${p}`;
+        const sh = real.shmMap(name, cur.length, true);
+        sh.set(cur); mem.set(p, sh); exported.push(name);
+        const h = new Uint8Array(96), txt = Buffer.from(JSON.stringify({ name, len: cur.length, pid: process.pid, p }));
+        h.set(txt); return h;
+    },
+    ipcOpen(h) {
+        note("ipcOpen");
+        const d = JSON.parse(Buffer.from(h.subarray(0, h.indexOf(0))).toString());
+        if (d.pid === process.pid) return d.p;
+        const q = nextPtr; nextPtr += d.len + 4096;
+        mem.set(q, real.shmMap(d.name, d.len, false));
+        return q;
+    },
+    ipcClose(p) { note("ipcClose"); mem.delete(p); },
+    peerCopy(dst, src, bytes) {                                  // src may point INSIDE a mapped buffer (a slice of a chain output)
+        note("peerCopy");
+        for (const [base, buf] of mem) if (src >= base && src + bytes <= base + buf.length) { mem.get(dst).set(buf.subarray(src - base, src - base + bytes)); return; }
+        throw new Error("zkmi error 2: peer_copy: source range is not mapped in this process");
+    },
+    groth16Reset(key) { note("groth16Reset"); const K = keys.get(key); if (K) K.W = null; for (const k of Object.keys(slots)) delete slots[k]; },
+    failNext(name) { failNextCall = name; },
 };
+// injected failure of one entry point (the shard driver's error path): the next call of `name` throws
+for (const name of ["groth16SumsWDev", "groth16SumsHDev", "groth16ChainsDev"]) {
+    const f = backend[name];
+    backend[name] = async function (...a) { if (failNextCall === name) { failNextCall = null; throw new Error(`zkmi error 3: injected failure in ${name}`); } return f.apply(this, a); };
+}
+process.on("exit", () => { for (const nm of exported) { try { real.shmUnlink(nm); } catch (e) { /* best effort */ } } });
+if (process.env.ZKMI_MOCK_FAIL && process.env.ZKMI_SHARD_CFG) {
+    const [rk, nm] = process.env.ZKMI_MOCK_FAIL.split(":");
+    if (JSON.parse(process.env.ZKMI_SHARD_CFG).rank === Number(rk)) failNextCall = nm;
+}
 module.exports = backend;

@@ -131,6 +131,23 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
     }
     unregister(curve);
     check("unregister restores the WASM entry points", curve.__zkmi === undefined);
+    // options.minPoints (SURVEY.md 8b: small calls stay on the curve's own entry points): below the threshold nothing reaches the addon, at the
+    // threshold everything does; the default (0) sends every buffer-form call to the device
+    {
+        register(curve, { addon: mock, minPoints: 64 });
+        const before = Object.assign({}, calls);
+        const b4 = new Uint8Array(4 * 64), s4 = new Uint8Array(4 * 32), x16 = new Uint8Array(16 * 32), x64 = new Uint8Array(64 * 32);
+        for (let i = 0; i < 4; i++) s4[i * 32] = i + 1;                 // bases: four points at infinity (all-zero bytes)
+        for (let i = 0; i < 16; i++) x16[i * 32] = i + 1;
+        for (let i = 0; i < 64; i++) x64[i * 32] = i + 1;
+        const small = await curve.G1.multiExpAffine(b4, s4), f16 = await curve.Fr.fft(x16);
+        check("minPoints: a 4-point multiExpAffine and a 16-point fft stay on the WASM originals", (calls.msm1 || 0) === (before.msm1 || 0) && (calls.fft || 0) === (before.fft || 0) &&
+              sha(f16) === sha(await saved.fft(x16)) && sha(small) === sha(await saved.g1(b4, s4)));
+        const f64 = await curve.Fr.fft(x64);
+        if (f64.__p) { await f64.__p; delete f64.__p; }               // the mock fills its output asynchronously
+        check("minPoints: a 64-point fft goes to the addon", (calls.fft || 0) === (before.fft || 0) + 1 && sha(f64) === sha(await saved.fft(x64)));
+        unregister(curve);
+    }
     console.log(fails ? `${fails} FAILED` : "ALL OK");
     process.exit(fails ? 1 : 0);
 })().catch((e) => { console.log("ERROR", e); process.exit(2); });

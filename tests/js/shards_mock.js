@@ -20,17 +20,42 @@ const hexb = (s) => new Uint8Array(Buffer.from(s, "hex"));
         const sp = []; for (let r = 0; r < w; r++) sp.push(shardRange(n, r, w));
         if (sp[0][0] !== 0 || sp[w - 1][1] !== n || sp.some((x, i) => i && x[0] !== sp[i - 1][1])) check(`shardRange(${n}, ${w}) covers everything`, false);
     }
-    for (const world of [2, 3]) {
-        const sp = new ShardedProver({ world, zkeyPath: path.join(GOLD, "groth16_bn128_n1024.zkey"), addonPath: path.join(__dirname, "ref_backend.js"),
+    for (const [world, exchange] of [[2, "peer"], [3, "peer"], [2, "shm"]]) {
+        const sp = new ShardedProver({ world, zkeyPath: path.join(GOLD, "groth16_bn128_n1024.zkey"), addonPath: path.join(__dirname, "ref_backend.js"), exchange,
                                        execArgv: ["--harmony-optional-chaining", "--harmony-nullish"] });
         await sp.ready();
         const res = await sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) });
-        check(`world ${world}: sharded proof == reference proof`, sha(JSON.stringify(res.proof)) === g.proof_sha256);
+        check(`world ${world} (${exchange}): sharded proof == reference proof`, sha(JSON.stringify(res.proof)) === g.proof_sha256 && res.exchange === exchange);
+        check(`world ${world} (${exchange}): no witness file in the temporary directory`, !fs.readdirSync(require("os").tmpdir()).some((f) => f.startsWith(`zkmi_${process.pid}_`)));
         const ev = res.events, firstSums = ev.indexOf("sums");
         check(`world ${world}: 3 chains + ${world} witness-side halves before the first H half (${ev.join(",")})`,
               ev.filter((e) => e === "chain").length === 3 && ev.filter((e) => e === "w").length === world && ev.slice(0, firstSums).filter((e) => e === "chain" || e === "w").length === 3 + world);
         const res2 = await sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) });             // the workers and their key shards stay up
         check(`world ${world}: second proof over the same workers`, sha(JSON.stringify(res2.proof)) === g.proof_sha256);
+        // two prove() calls issued together are serialised (one witness buffer, one set of chain buffers, one pipeline slot per worker)
+        const both = await Promise.all([sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) }), sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) })]);
+        check(`world ${world}: concurrent prove() calls are serialised and both correct`, both.every((x) => sha(JSON.stringify(x.proof)) === g.proof_sha256));
+        await sp.close();
+    }
+    // error path: worker 1 fails once between the two halves of a proof; the proof is rejected, every worker is reset, the next proof is correct
+    {
+        process.env.ZKMI_MOCK_FAIL = "1:groth16SumsHDev";
+        const sp = new ShardedProver({ world: 2, zkeyPath: path.join(GOLD, "groth16_bn128_n1024.zkey"), addonPath: path.join(__dirname, "ref_backend.js"),
+                                       execArgv: ["--harmony-optional-chaining", "--harmony-nullish"] });
+        delete process.env.ZKMI_MOCK_FAIL;
+        await sp.ready();
+        let msg = "";
+        try { await sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) }); } catch (e) { msg = String(e.message); }
+        check(`a failing worker rejects the proof (${msg})`, /injected failure/.test(msg));
+        const res = await sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) });
+        check("the proof after a failed one is correct (workers reset)", sha(JSON.stringify(res.proof)) === g.proof_sha256);
+        // a worker that dies: pending and later proofs reject instead of hanging
+        const pending = sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) }).then(() => "resolved", (e) => String(e.message));
+        sp.workers[1].kill("SIGKILL");
+        const out = await pending;
+        let later = "";
+        try { await sp.prove(wtns, {}); } catch (e) { later = String(e.message); }
+        check(`a dead worker rejects the pending proof (${out}) and every later one (${later})`, /exited|resolved/.test(out) && /exited/.test(later));
         await sp.close();
     }
     console.log(fails ? `${fails} FAILED` : "ALL OK");

@@ -165,13 +165,16 @@ def test_compute_z_and_t_stages_vs_oracle(env, golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lg", [4, 10, 13])
-def test_synthetic_plonk_key_device_vs_oracle(env, lg):
+@pytest.mark.parametrize("curve,lg", [("bn128", 4), ("bn128", 10), ("bn128", 13), ("bls12381", 4), ("bls12381", 10), ("bls12381", 13)])
+def test_synthetic_plonk_key_device_vs_oracle(env, curve, lg):
     """A synthetic but VALID key (tests/synth_plonk.py): the device prover must accept it (copy-constraint and divisibility
-    checks) and agree with the Python restatement coefficient for coefficient (proof equality)."""
+    checks) and agree with the Python restatement coefficient for coefficient (proof equality). Both curves since r04: k_plonk_t<Bls12381Fr>,
+    computeZ's scans and the 4n-point paths on multi-tile BLS12-381 instances (the reference-generated BLS12-381 fixture is n = 64)."""
     import synth_plonk
     zkmi, plonk, f, cx = env
-    zkey, wtns = synth_plonk.make("bn128", lg, seed=lg)
+    if curve != "bn128":
+        f = plonk._Field(1)
+    zkey, wtns = synth_plonk.make(curve, lg, seed=lg)
     blind = [bytes(f.mont(1000 + 17 * i)) for i in range(11)]
     got = plonk.prove(zkey, wtns, blinding_mont=blind)
     want_proof, want_pub = P.plonk_prove(zkey, wtns, blind)
@@ -354,7 +357,7 @@ def test_fflonk_large_proof_verifies(env, lg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,lg", [("plonk_bn128_n2048", None), ("plonk_bls12381_small", None), (None, 13), (None, 16)])
+@pytest.mark.parametrize("tag,lg", [("plonk_bn128_n2048", None), ("plonk_bls12381_small", None), (None, 13), (None, 16), (None, -13)])
 def test_plonk_two_proofs_in_flight_equal_serial(env, golden_dir, tag, lg):
     """plonk.prove_many (two coroutine proofs on the library's two pipeline slots, one host thread): the same proofs, bit for bit, as one
     plonk.prove after the other with the same blinding values — golden fixture first in the list; an odd number of proofs; a corrupted witness
@@ -371,8 +374,10 @@ def test_plonk_two_proofs_in_flight_equal_serial(env, golden_dir, tag, lg):
         f2 = fld.f
         fld.release()
     else:
-        zkey, wtns = synth_plonk.make("bn128", lg, seed=40 + lg)
-        blinds, f2, g = [], f, None
+        curve = "bn128" if lg > 0 else "bls12381"               # a negative size = the same on BLS12-381 (r04)
+        lg = abs(lg)
+        zkey, wtns = synth_plonk.make(curve, lg, seed=40 + lg)
+        blinds, f2, g = [], (f if curve == "bn128" else plonk._Field(1)), None
     for k in range(len(blinds), 5):
         blinds.append([bytes(f2.mont(7000 + 131 * k + 17 * i)) for i in range(11)])
     key = plonk.PlonkKey(zkey)
@@ -400,18 +405,22 @@ def test_plonk_two_proofs_in_flight_equal_serial(env, golden_dir, tag, lg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lg", [12, 20])
-def test_plonk_full_size_proof_verifies(env, lg):
+@pytest.mark.parametrize("curve,lg", [("bn128", 12), ("bn128", 20), ("bls12381", 16)])
+def test_plonk_full_size_proof_verifies(env, curve, lg):
     """BASELINE configs[3] at its full size (2^20 constraints): the device proof VERIFIES.  The verifier is the restatement of
-    src/plonk_verify.js pinned to the reference's own verifier trace (test_plonk_verifier_trace); the synthetic key has a known
-    toy tau, so the final pairing is the G1 identity B1 == tau * A1 (oracle/plonk_verify_oracle.py)."""
+    src/plonk_verify.js pinned to the reference's own verifier trace (test_plonk_verifier_trace, both curves); the synthetic key has a known
+    toy tau, so the final pairing is the G1 identity B1 == tau * A1 (oracle/plonk_verify_oracle.py). r04: a 2^16 proof on BLS12-381."""
+    import plonk_oracle as PO
     import plonk_verify_oracle as V
     import synth_plonk
     zkmi, plonk, f, cx = env
+    if curve != "bn128":
+        cx = PO.Ctx(48)
     tau = 0x1F3D5B79
-    zkey, wtns = synth_plonk.make("bn128", lg, seed=11, tau=tau)
+    zkey, wtns = synth_plonk.make(curve, lg, seed=11, tau=tau)
     res = plonk.prove(zkey, wtns)
     vk = V.vk_from_zkey(zkey)
+    assert vk["curve"] == curve
     assert V.verify_known_tau(vk, res["publicSignals"], res["proof"], tau)
     # soundness of the check itself: a wrong tau, a tampered evaluation and a tampered public signal must all be rejected
     assert not V.verify_known_tau(vk, res["publicSignals"], res["proof"], tau + 1)

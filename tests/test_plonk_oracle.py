@@ -46,7 +46,7 @@ def test_fflonk_golden_proof(golden_dir, tag):
     assert hashlib.sha256(json.dumps(proof, separators=(",", ":")).encode()).hexdigest() == g["proof_sha256"]
 
 
-@pytest.mark.parametrize("tag", ["plonk_bn128_small", "plonk_bn128_n2048"])
+@pytest.mark.parametrize("tag", ["plonk_bn128_small", "plonk_bn128_n2048", "plonk_bls12381_small"])
 def test_plonk_verifier_trace(golden_dir, tag):
     """The verifier restatement (oracle/plonk_verify_oracle.py) reproduces every intermediate value the reference's plonk.verify
     logs for its own seeded proofs (challenges, L_i(xi), PI(xi), r0 and the points D, F, E)."""

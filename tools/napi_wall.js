@@ -7,6 +7,9 @@
 //            pipelined = two proofs in flight (addon.groth16Submit / groth16Collect), the witness upload of proof k+1 under proof k
 //   msm      addon.msm on the A section (nVars points): cold (bases uploaded every call, cache not allowed) / resident (3rd+ call)
 //   ntt      addon.ntt of domainSize elements (32 B x n in, 32 B x n out)
+//   small    addon.msm / addon.ntt at 4, 64 and 1024 elements (what the drop-in boundary costs below the sizes the device is built for)
+//   sharded  one proof over two worker processes (js/groth16_shards.js), chain outputs exchanged device to device ("peer") and through shared
+//            host memory ("shm")
 // Prints ONE JSON line.
 "use strict";
 const fs = require("fs"), path = require("path");
@@ -83,4 +86,42 @@ const out = { n_vars: nVars, domain: domainSize, reps };
     out.ntt_ms = +med(t.slice(1)).toFixed(3);
     out.ntt_bytes_over_pcie = 2 * n * 32;
 }
-console.log(JSON.stringify(out));
+// small inputs at the drop-in boundary (VERDICT r03 weak #2: what does a 3-point G1.multiExpAffine — the verifier's nPublic-point MSM, PLONK's tiny
+// Lagrange transforms — cost through sort + accumulate + reduce?): host buffers in and out, median of 20 calls each
+{
+    const sm = {}, sn = {};
+    for (const k of [4, 64, 1024]) {
+        const bases = zs[5].subarray(0, k * 2 * n8q), scalars = witness.subarray(32, 32 + k * 32);
+        let t = [];
+        for (let i = 0; i < 22; i++) { const t0 = now(); addon.msm(cid, 1, bases, scalars, k, 32, 0); t.push(now() - t0); }
+        sm[k] = +med(t.slice(2)).toFixed(4);
+        const lg = Math.round(Math.log2(k)), x = new Uint8Array(k * 32), y = new Uint8Array(k * 32);
+        x.set(witness.subarray(0, k * 32));
+        t = [];
+        for (let i = 0; i < 22; i++) { const t0 = now(); addon.ntt(cid, x, y, lg, 0, null, null); t.push(now() - t0); }
+        sn[k] = +med(t.slice(2)).toFixed(4);
+    }
+    out.msm_small_ms = sm;                                   // G1.multiExpAffine of 4 / 64 / 1024 points, bases not cached
+    out.ntt_small_ms = sn;                                   // Fr.fft of 4 / 64 / 1024 elements
+}
+// ONE proof over two worker PROCESSES (js/groth16_shards.js), both on device 0 when the box has one GPU: the protocol and the peer copies are
+// the multi-GPU ones, the placement is not. exchange "peer" = zkmi_ipc_* + zkmi_peer_copy (device to device), "shm" = through pinned host pages.
+async function sharded() {
+    const { ShardedProver } = require(path.join(__dirname, "..", "snarkjs_amd", "js", "groth16_shards.js"));
+    const ndev = addon.deviceCount();
+    for (const exchange of ["peer", "shm"]) {
+        let sp = null;
+        try {
+            sp = new ShardedProver({ world: 2, zkeyPath, exchange, devices: ndev >= 2 ? [0, 1] : [0, 0] });
+            await sp.ready();
+            const t = [];
+            let tl = null;
+            for (let i = 0; i < reps + 1; i++) { const t0 = now(); const res = await sp.prove(wtns, { r, s }); t.push(now() - t0); tl = res.timeline_ms; }
+            out[exchange === "peer" ? "groth16_sharded_2proc_ms" : "groth16_sharded_2proc_shm_ms"] = +med(t.slice(1)).toFixed(3);
+            if (exchange === "peer") { out.groth16_sharded_2proc_timeline_ms = tl; out.groth16_sharded_2proc_devices = ndev >= 2 ? [0, 1] : [0, 0]; }
+        } catch (e) { out[`groth16_sharded_2proc_${exchange}_error`] = String(e && e.message || e).slice(0, 300); }
+        if (sp) { try { await sp.close(); } catch (e) { /* best effort */ } }
+    }
+}
+if (process.env.ZKMI_NAPI_WALL_NO_SHARDS) { console.log(JSON.stringify(out)); process.exit(0); }
+sharded().then(() => { console.log(JSON.stringify(out)); process.exit(0); }, (e) => { out.groth16_sharded_error = String(e); console.log(JSON.stringify(out)); process.exit(0); });

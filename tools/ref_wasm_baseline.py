@@ -4,7 +4,7 @@ from the reference bundle (WASM + worker threads, oracle/ref_shim.js) on synthet
 dense B sections), 1 thread and os.cpus().length threads. BUILD CONTAINER ONLY (needs /root/reference and Node); the bundle cannot
 travel to the GPU box, so the result is committed under profiles/ and quoted by bench.py's cpu_baseline next to the live C port.
 
-usage: python tools/ref_wasm_baseline.py [log_n ...]     (default 14 16)  ->  profiles/r02_ref_wasm_baseline.json
+usage: python tools/ref_wasm_baseline.py [--out profiles/NAME.json] [log_n ...]     (default 14 16; r04: 20 -> profiles/r04_ref_wasm_baseline.json)
 """
 import json
 import os
@@ -33,7 +33,18 @@ const snarkjs=require(process.argv[2]);
 
 
 def main():
-    sizes = [int(x) for x in sys.argv[1:]] or [14, 16]
+    argv = sys.argv[1:]
+    outf = os.path.join(ROOT, "profiles", "r02_ref_wasm_baseline.json")
+    if "--out" in argv:
+        i = argv.index("--out")
+        outf = os.path.join(ROOT, argv[i + 1])
+        del argv[i:i + 2]
+    only_threads = None
+    if "--threads" in argv:                      # measure one thread count only (and MERGE into an existing output file)
+        i = argv.index("--threads")
+        only_threads = int(argv[i + 1])
+        del argv[i:i + 2]
+    sizes = [int(x) for x in argv] or [14, 16]
     tmp = "/tmp/refbase"
     os.makedirs(tmp, exist_ok=True)
     js = os.path.join(tmp, "run.js")
@@ -43,6 +54,9 @@ def main():
                    "(uniform 253-bit witness, dense B), files in memory, first call excluded (WASM tier-up / worker start)",
            "host": {"cpus": ncpu, "model": next((l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")},
            "runs": []}
+    if only_threads and os.path.exists(outf):
+        out["runs"] = json.load(open(outf)).get("runs", [])
+    out["note"] = "every run on an otherwise idle build container (the first 8-thread figure of r04 was taken beside a compiler job and has been replaced)"
     for lg in sizes:
         t0 = time.time()
         zkey, wtns = synth_zkey.make("bn128", lg, seed=0x5EED, witness="uniform", use_device=False, b_zero_every=0)
@@ -50,7 +64,7 @@ def main():
         open(zf, "wb").write(zkey)
         open(wf, "wb").write(wtns)
         print(f"2^{lg}: key built in {time.time() - t0:.1f} s", flush=True)
-        for threads in (1, ncpu):
+        for threads in ((only_threads,) if only_threads else (1, ncpu)):
             env = dict(os.environ, NTHREADS=str(threads))
             if threads == 1:
                 env["SINGLE"] = "1"
@@ -64,10 +78,11 @@ def main():
                 raise SystemExit(1)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             best = min(d["ms"][1:])
+            out["runs"] = [x for x in out["runs"] if not (x["log_n"] == lg and x["threads"] == d["threads"])]
             out["runs"].append({"log_n": lg, "threads": d["threads"], "ms_per_proof": round(best, 1), "proofs_per_s": round(1e3 / best, 5), "all_ms": [round(x, 1) for x in d["ms"]],
                                 "node": d["node"]})
             print(out["runs"][-1], flush=True)
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r02_ref_wasm_baseline.json"), "w"), indent=1)
+        json.dump(out, open(outf, "w"), indent=1)      # after every size: a long run that is cut short keeps what it measured
 
 
 if __name__ == "__main__":
