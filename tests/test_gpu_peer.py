@@ -13,9 +13,11 @@ pytestmark = pytest.mark.gpu
 HB = 96                                                       # ZKMI_IPC_HANDLE_BYTES
 
 
-def _child(handle_bytes, lo, cnt, device, q):
+def _child(handle_bytes, lo, cnt, device, with_torch, q):
     try:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if with_torch:
+            import torch  # noqa: F401  — see the note in the test: both ends of a handle must run the same HIP runtime
         from snarkjs_amd import zkmi
         zkmi.init(device)
         L = zkmi.lib()
@@ -33,7 +35,6 @@ def _child(handle_bytes, lo, cnt, device, q):
 
 
 def test_ipc_export_open_peer_copy_between_processes():
-    import torch
     from snarkjs_amd import zkmi
     zkmi.init()
     L = zkmi.lib()
@@ -51,12 +52,16 @@ def test_ipc_export_open_peer_copy_between_processes():
     same = zkmi.DeviceBuffer(1000)
     zkmi.check(L.zkmi_peer_copy(same.ptr, p.value + 77, 1000))
     assert np.array_equal(same.to_host(), data[77:1077])
-    # another process (on the second GPU when there is one) pulls a slice
-    dev = 1 if torch.cuda.device_count() > 1 else 0
+    # another process (on the second GPU when there is one) pulls a slice. A pytest session has torch imported (conftest, other tests), and the
+    # torch wheel brings its own HIP runtime into the process: a handle exported under it cannot be opened by a process that runs the system
+    # runtime alone (r04 probe: hipIpcOpenMemHandle "invalid argument" exactly then, tools/lab/r4_ipc_probe.py). The product's shard processes are
+    # Node processes without torch; here the child simply loads what the parent has loaded.
+    dev = 1 if L.zkmi_device_count() > 1 else 0
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     lo, cnt = 123 * 32, 65536 * 32
-    pr = ctx.Process(target=_child, args=(h.tobytes(), lo, cnt, dev, q))
+    import sys
+    pr = ctx.Process(target=_child, args=(h.tobytes(), lo, cnt, dev, "torch" in sys.modules, q))
     pr.start()
     status, payload, visible = q.get(timeout=300)
     pr.join(60)
