@@ -616,7 +616,7 @@ def main():
                        "parallelism": f"replica x{world} (one proof stream per GPU, {args.pipeline} proof(s) in flight)"},
             "submetrics": {"g1_msm_mscalar_per_s": round(n / msm_ms / 1e3, 2), "g1_msm_ms": round(msm_ms, 4),
                            "g1_msm_resident_tables_mscalar_per_s": round(n / msm_tab_ms / 1e3, 2), "g1_msm_resident_tables_ms": round(msm_tab_ms, 4),
-                           "g1_msm_note": "g1_msm_*: zkmi_msm_dev on caller-owned plain bases (R-form), the library's R'-form copy and its conversion pass inside the time, digit sorts of the 4 pieces underneath the accumulations; resident_tables: the same MSM over pre-computed window tables (how a key holds its bases)",
+                           "g1_msm_note": "g1_msm_*: zkmi_msm_dev on caller-owned plain bases (R-form): the library's R'-form copy and its conversion pass are inside the time, sort / accumulate / reduce on one stream (r04 measured the MSM in 2 and 4 pieces with the sorts underneath the accumulations: slower, profiles/NOTES.md); resident_tables: the same MSM over pre-computed window tables (how a key holds its bases)",
                            "g1_msm_hbm_frac": round((2 * q8 + 32) * n / (msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                            "ntt_melem_per_s": round(n / ntt_ms / 1e3, 2), "ntt_ms": round(ntt_ms, 4),
                            "ntt_hbm_frac": round(64 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},

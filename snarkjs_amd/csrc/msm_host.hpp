@@ -438,72 +438,11 @@ template <class F> void msm_fold(const MsmJob& job, uint8_t* out_jac) {
     msm_fold_windows<F>(win.data(), tot.data(), job.W, job.c, job.cbits, out_jac);
 }
 
-// The standalone G1 MSM in P pieces of the base-index range (r04). In one piece the digit sort (memory- and LDS-bound, ~1 ms for 2^20 32-byte
-// scalars) runs BEFORE the accumulation (ALU-bound) on the same stream; in pieces the sorts run back to back on the auxiliary stream and piece
-// k+1 is sorted while piece k accumulates — all pieces into ONE bucket set (the merge mode the Groth16 pipeline uses for H into C), so the
-// bucket reduction is paid once. Needs the R'-form registration of the bases (zkmi_msm / zkmi_msm_dev provide it) for the infinity bitmap.
-template <class F> int msm_run_split(const void* d_bases, const uint32_t* d_mask, const void* d_scalars, size_t n, size_t sb, int P, uint8_t* out_jac) {
-    constexpr int FW = FieldWords<F>::value;
-    constexpr size_t PB = (size_t)2 * FW * 4;                              // bytes per affine G1 point
-    Ctx& cx = ctx();
-    hipStream_t st = cx.stream;
-    ZK_TRY(ensure_aux_stream());
-    hipStream_t aux = cx.aux_stream;
-    if (!cx.sort_ev[0]) for (int i = 0; i < 5; i++) ZK_HIP(hipEventCreateWithFlags(&cx.sort_ev[i], hipEventDisableTiming));
-    const size_t chunk = (((n + P - 1) / P) + 1023) & ~(size_t)1023;      // whole words of the infinity bitmap per piece
-    MsmPlan pl[4];
-    MsmJob job[4];
-    // one window width for every piece: that of the whole MSM (the pieces share the bucket set)
-    static const int c_env = getenv("ZKMI_MSM_SPLIT_C") ? atoi(getenv("ZKMI_MSM_SPLIT_C")) : 0;
-    const int c_saved = cx.msm_c_override;
-    cx.msm_c_override = c_saved ? c_saved : (c_env ? c_env : std::max(msm_pick_c(n), ilog2_sz(n) >= 19 ? 16 : 0));
-    if (!cx.ev0_held) ZK_HIP(hipEventRecord(cx.ev0, st));
-    ZK_HIP(hipEventRecord(cx.sort_ev[0], st));                            // the scalars are ready on the main stream at this point
-    ZK_HIP(hipStreamWaitEvent(aux, cx.sort_ev[0], 0));
-    cx.stream = aux;
-    int rc = ZKMI_OK, pieces = 0;
-    for (int k = 0; k < P && !rc; k++) {
-        const size_t lo = (size_t)k * chunk;
-        if (lo >= n) break;
-        rc = msm_sort((const uint8_t*)d_scalars + lo * sb, std::min(chunk, n - lo), sb, pl[k], k);
-        if (!rc && hipEventRecord(cx.sort_ev[1 + k], aux) != hipSuccess) rc = fail(ZKMI_ERR_HIP, "hipEventRecord");
-        pieces = k + 1;
-    }
-    cx.stream = st;
-    cx.msm_c_override = c_saved;
-    ZK_TRY(rc);
-    for (int k = 0; k < pieces; k++) {
-        const size_t lo = (size_t)k * chunk;
-        const uint8_t* pb = (const uint8_t*)d_bases + lo * PB;
-        ZK_TRY(msm_job_slot(k, job[k]));
-        ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[1 + k], 0));
-        if (k) cx.r29_tables[pb] = d_mask + lo / 32;                       // the piece as a registered R'-form base array of its own, for this launch
-        rc = msm_accumulate<F>(pb, pl[k], 0, job[k], d_mask + lo / 32, k ? &job[0] : nullptr);
-        if (k) cx.r29_tables.erase(pb);
-        ZK_TRY(rc);
-    }
-    MsmJob* jp = &job[0];
-    ZK_TRY(msm_reduce<F>(&jp, 1));
-    ZK_HIP(hipEventRecord(cx.ev1, st));
-    ZK_HIP(hipStreamSynchronize(st));
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, cx.ev0, cx.ev1) == hipSuccess) cx.last_ms = ms;
-    msm_fold<F>(job[0], out_jac);
-    return ZKMI_OK;
-}
-
 // Full device MSM: bases (affine, device), scalars (plain integers, device) -> Jacobian point on the host.
 template <class F> int msm_run(const void* d_bases, const void* d_scalars, size_t n, size_t sb, uint8_t* out_jac) {
     constexpr int FW = FieldWords<F>::value;
     Ctx& cx = ctx();
     if (n == 0) { memset(out_jac, 0, 3 * 4 * FW); return ZKMI_OK; }
-    if constexpr (FW <= 12) {                                             // G1 (the merge mode of the accumulation is G1-only)
-        // ZKMI_MSM_SPLIT=1: one piece (the r03 sequence); k: k pieces; default: 4 pieces from 2^19 terms, 2 from 2^17
-        static const int split_env = getenv("ZKMI_MSM_SPLIT") ? atoi(getenv("ZKMI_MSM_SPLIT")) : 0;
-        const int P = std::min(4, split_env > 0 ? split_env : (n >= ((size_t)1 << 19) ? 4 : (n >= ((size_t)1 << 17) ? 2 : 1)));
-        auto r29 = cx.r29_tables.find(d_bases);
-        if (P > 1 && r29 != cx.r29_tables.end() && r29->second) return msm_run_split<F>(d_bases, r29->second, d_scalars, n, sb, P, out_jac);
-    }
     hipStream_t st = cx.stream;
     MsmPlan pl;
     MsmJob job;
