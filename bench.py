@@ -23,13 +23,15 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# VALU instructions of one mixed addition, main path of the shipped code objects (tools/isa_counts.py -> profiles/r03_isa_counts.md):
-# k_msm_accum29 / k_msm_accum29_g2 per curve
-VALU_PER_ADD = {"bn128": {"g1": 2238, "g2": 5944}, "bls12381": {"g1": 5012, "g2": 14902}}
+# VALU instructions of one mixed addition, main path of the shipped code objects (tools/isa_counts.py -> profiles/r04_isa_counts.md: the fetch /
+# unpack segment + the addition segment of k_msm_accum29 / k_msm_accum29_g2 per curve; r04: multiply-adds in plain C, no s_nop padding —
+# 4 - 6 % more VALU instructions than r03's inline-asm build, 40 % fewer instructions overall)
+VALU_PER_ADD = {"bn128": {"g1": 2375, "g2": 6200}, "bls12381": {"g1": 5237, "g2": 15730}}
 VALU_ISSUE_PEAK_G = 614.4                      # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave instruction
 # measured Montgomery-multiply ceilings of the chip, Gmul/s at 8 waves per SIMD, in the limb form the accumulation kernels of the curve use
 # (tools/fieldbench29 on the library's own mul29): BN254 Fq 9 x 29-bit limbs, BLS12-381 Fq 14 x 28-bit limbs; the saturated 32-bit forms they
-# replaced measured 130 and 58.6 (tools/fieldbench, profiles/r01_fieldbench.txt). profiles/r03_fieldbench29.txt holds this round's run.
+# replaced measured 130 and 58.6 (tools/fieldbench, profiles/r01_fieldbench.txt). profiles/r04_fieldbench29.txt holds this round's run (plain-C
+# multiply-adds: 169 / 78.6 at 8 waves per SIMD, 137 / 77.6 at 2; the r03 inline-asm build beside it: 176 / 77.7 and 144 / 73.8).
 FIELD_MUL_PEAK_G = {"bn128": 175.0, "bls12381": 78.3}
 FIELD_MUL_PEAK_32 = {"bn128": 130.0, "bls12381": 58.6}
 
@@ -369,7 +371,7 @@ def multi_rank_extras(args, rank, world, dist, torch, barrier, cid, q8, lg, r_m,
         sec = max_over_ranks(time.perf_counter() - ts)
         tl = {}
         D.groth16_prove_sharded(pks, None, r_m, s_m, d_witness=d_w0.ptr, timeline=tl)      # one more, with this rank's host-clock stage marks
-        keys = ["chains_done", "w_enqueued", "exchange_done", "sums_done", "gathered"]
+        keys = ["chains_done", "w_enqueued", "slices_requested_done", "exchange_done", "sums_done", "gathered"]
         t = torch.tensor([tl.get(kk, 0.0) for kk in keys], device="cuda", dtype=torch.float64)
         allt = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(allt, t)

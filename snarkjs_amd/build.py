@@ -30,7 +30,11 @@ def _depfile(obj):
         return None
     txt = open(d).read().replace("\\\n", " ")
     deps = txt.split(":", 1)[1].split() if ":" in txt else []
-    return [x for x in deps if x.startswith(os.path.dirname(HERE)) or x.startswith(CSRC)]
+    # a unit compiled from another working directory lists its own headers RELATIVE to it (r04: calib.d / plonk.d did, were filtered out below and
+    # the two objects never went stale): resolve against this package directory first
+    deps = [x if os.path.isabs(x) else os.path.normpath(os.path.join(HERE, x)) for x in deps]
+    own = [x for x in deps if x.startswith(os.path.dirname(HERE)) or x.startswith(CSRC)]
+    return own if own else None                           # no header of ours in the list: treat as unknown (depend on every header)
 
 
 def build(verbose=False, force=False):

@@ -191,7 +191,7 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
         a.rowinc = d_rowinc ? d_rowinc + rowoff[i] * 8 : nullptr;
         a.log_ch = std::min<unsigned>(NTT_TILE_LOG - P->l[i], logS);
         const size_t N = (size_t)1 << P->l[i], E = N << a.log_ch;
-        const size_t lds = use29 ? (size_t)9 * (E + N / 2 + N) * 4 : (2 * E + N + 2 * N) * 16;
+        const size_t lds = use29 ? (size_t)(Tile29::words((uint32_t)E) + Tile29::words((uint32_t)(N / 2)) + Tile29::words((uint32_t)N)) * 4 : (2 * E + N + 2 * N) * 16;
         const unsigned tiles = (unsigned)(n >> (P->l[i] + a.log_ch));
         const uint32_t* src = (i == 0) ? (const uint32_t*)d_in : work;
         a.in_bs = (i == 0) ? (uint64_t)in_stride * 8 : (uint64_t)n * rec; a.out_bs = (uint64_t)n * rec;
@@ -206,7 +206,7 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
         a.scale = (p == 1 && inverse) ? (use29 ? P->n_inv29 : P->n_inv) : nullptr;
         a.log_ch = (p == 1) ? 0 : std::min<unsigned>(NTT_TILE_LOG - P->l[i], P->l[0]);
         const size_t N = (size_t)1 << P->l[i];
-        const size_t lds = use29 ? (size_t)9 * (((N + 1) << a.log_ch) + std::max<size_t>(N / 2, 1)) * 4 : (2 * ((N + 1) << a.log_ch) + N) * 16;
+        const size_t lds = use29 ? (size_t)(Tile29::words((uint32_t)((N + 1) << a.log_ch)) + Tile29::words((uint32_t)std::max<size_t>(N / 2, 1))) * 4 : (2 * ((N + 1) << a.log_ch) + N) * 16;
         const unsigned tiles = (unsigned)(n >> (P->l[i] + a.log_ch));
         const uint32_t* src = (p == 1) ? (const uint32_t*)d_in : work;
         uint32_t* dst = (uint32_t*)d_out;

@@ -17,7 +17,6 @@
 //     lane and ran the middle passes 8x slower); only the last pass brings
 //     every value to the canonical range (reduce29_small: quotient estimate from the top limb, one multiply-subtract pass, <= 3 conditional
 //     subtractions) and writes the reference's 32 bytes.
-// Tile storage in LDS: limb k of element e at plane k (E words per plane): consecutive lanes -> consecutive words, conflict-free.
 #pragma once
 #include "field29.cuh"
 #include "ntt.cuh"
@@ -60,16 +59,28 @@ template <class C> ZK_HD void ntt29_bfly(Fp29<C>& x, Fp29<C>& y, const Fp29<C>& 
     norm29(x); norm29(y);
 }
 
-// tile planes in LDS: limb k of element e at p[k * stride + e]
-template <class C> ZK_DEV Fp29<C> lds29_get(const uint32_t* p, uint32_t stride, uint32_t e) {
+// Tile storage in LDS (r04): THREE planes per region — limbs 0..3 of element e as one 16-byte slot of plane a, limbs 4..7 of plane b, limb 8 as
+// one word of plane c — so that an element moves with 2 x ds_*_b128 + 1 x ds_*_b32 instead of the nine 4-byte accesses of r03's limb planes
+// (45 LDS instructions per butterfly, which ate what the cheaper product saved; now 15). Consecutive lanes touch consecutive slots: 16
+// consecutive lanes of a b128 access cover all 64 banks once, like the two 16-byte planes of ntt.cuh. Regions are padded to whole groups of
+// four elements so that every plane starts 16-byte aligned.
+ZK_HD constexpr uint32_t ntt29_al4(uint32_t n) { return (n + 3u) & ~3u; }
+struct Tile29 {
+    uint4 *a, *b;
+    uint32_t* c;
+    ZK_DEV Tile29(uint32_t* base, uint32_t n_elems) : a(reinterpret_cast<uint4*>(base)), b(a + ntt29_al4(n_elems)), c(reinterpret_cast<uint32_t*>(b + ntt29_al4(n_elems))) {}
+    __host__ __device__ static constexpr uint32_t words(uint32_t n_elems) { return 9u * ntt29_al4(n_elems); }
+};
+template <class C> ZK_DEV Fp29<C> lds29_get(const Tile29& t, uint32_t e) {
+    const uint4 x = t.a[e], y = t.b[e];
     Fp29<C> r;
-#pragma unroll
-    for (int k = 0; k < 9; k++) r.l[k] = p[k * stride + e];
+    r.l[0] = x.x; r.l[1] = x.y; r.l[2] = x.z; r.l[3] = x.w; r.l[4] = y.x; r.l[5] = y.y; r.l[6] = y.z; r.l[7] = y.w; r.l[8] = t.c[e];
     return r;
 }
-template <class C> ZK_DEV void lds29_put(uint32_t* p, uint32_t stride, uint32_t e, const Fp29<C>& v) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) p[k * stride + e] = v.l[k];
+template <class C> ZK_DEV void lds29_put(const Tile29& t, uint32_t e, const Fp29<C>& v) {
+    t.a[e] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    t.b[e] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    t.c[e] = v.l[8];
 }
 // element `i` of an array of 48-byte records (the work array between passes)
 template <class C> ZK_DEV Fp29<C> rec29_load(const uint32_t* base, uint64_t i) {
@@ -90,7 +101,7 @@ template <class C> ZK_DEV Fp29<C> ntt29_pow(const NttPassArgs& a, uint64_t e) {
 
 // radix-2 DIT stages on an LDS tile, natural order in, bit-reversed order out. ROWMAJOR: element (row j, col c) at j*CH + c (strided
 // passes); otherwise at c*(N+1) + j (last pass; +1 pad keeps the transposed store conflict-free). U: local twiddles in bit-reversed order.
-template <class C, bool ROWMAJOR> ZK_DEV void ntt29_tile_stages(uint32_t* p, uint32_t stride, const uint32_t* U, uint32_t l, uint32_t log_ch) {
+template <class C, bool ROWMAJOR> ZK_DEV void ntt29_tile_stages(const Tile29& p, const Tile29& U, uint32_t l, uint32_t log_ch) {
     const uint32_t half_elems = 1u << (l + log_ch - 1);
     const uint32_t N = 1u << l, HN = N >> 1;
     for (int s = (int)l - 1; s >= 0; s--) {
@@ -103,11 +114,11 @@ template <class C, bool ROWMAJOR> ZK_DEV void ntt29_tile_stages(uint32_t* p, uin
             const uint32_t j = (blk << (s + 1)) | jl;
             const uint32_t e0 = ROWMAJOR ? (j << log_ch) + c : c * (N + 1) + j;
             const uint32_t e1 = ROWMAJOR ? ((j + h) << log_ch) + c : c * (N + 1) + j + h;
-            Fp29<C> x = lds29_get<C>(p, stride, e0), y = lds29_get<C>(p, stride, e1);
-            if (s < (int)l - 1) y = mul29(y, lds29_get<C>(U, HN, blk));        // first stage: one block, w = 1, the operand is a fresh product or canonical
+            Fp29<C> x = lds29_get<C>(p, e0), y = lds29_get<C>(p, e1);
+            if (s < (int)l - 1) y = mul29(y, lds29_get<C>(U, blk));            // first stage: one block, w = 1, the operand is a fresh product or canonical
             ntt29_bfly(x, y, Fp29<C>(y));
-            lds29_put<C>(p, stride, e0, x);
-            lds29_put<C>(p, stride, e1, y);
+            lds29_put<C>(p, e0, x);
+            lds29_put<C>(p, e1, y);
         }
         __syncthreads();
     }
@@ -120,9 +131,9 @@ k_ntt29_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds29[];
     in += (size_t)blockIdx.y * a.in_bs; out += (size_t)blockIdx.y * a.out_bs;
     const uint32_t l = a.l[a.pass], N = 1u << l, CH = 1u << a.log_ch, E = N << a.log_ch, HN = N >> 1;
-    uint32_t* p = lds29;                   // 9 planes of E words
-    uint32_t* U = p + 9 * E;               // 9 planes of N/2 words: local twiddles (bit-reversed order)
-    uint32_t* rf = U + 9 * HN;             // 9 planes of N words: row factors
+    const Tile29 p(lds29, E);                                             // the tile: E elements
+    const Tile29 U(lds29 + Tile29::words(E), HN);                         // N/2 local twiddles (bit-reversed order)
+    const Tile29 rf(lds29 + Tile29::words(E) + Tile29::words(HN), N);     // N row factors
     uint32_t log_S = 0;
     for (uint32_t m = a.pass + 1; m < a.n_pass; m++) log_S += a.l[m];
     const uint64_t tiles_per_u = (1ull << log_S) >> a.log_ch;
@@ -138,24 +149,24 @@ k_ntt29_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
                 f = ntt29_pow<C>(a, e);
                 if (a.rowinc) f = mul29(f, load29_packed<C>(a.rowinc + (size_t)j * C::N));
             } else f = load29_packed<C>(a.rowinc + (size_t)j * C::N);
-            lds29_put<C>(rf, N, j, f);
+            lds29_put<C>(rf, j, f);
         }
     }
-    for (uint32_t k = threadIdx.x; k < HN; k += NTT_THREADS) lds29_put<C>(U, HN, k, load29_packed<C>(a.LT + (size_t)k * C::N));
+    for (uint32_t k = threadIdx.x; k < HN; k += NTT_THREADS) lds29_put<C>(U, k, load29_packed<C>(a.LT + (size_t)k * C::N));
     __syncthreads();
     for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
         const uint32_t c = idx & (CH - 1), j = idx >> a.log_ch;
         const uint64_t src = base + ((uint64_t)j << log_S) + c;
         Fp29<C> x = IN_REC ? rec29_load<C>(in, src) : load29_packed<C>(in + src * C::N);
-        if (has_fac) x = mul29(x, lds29_get<C>(rf, N, j));
-        lds29_put<C>(p, E, idx, x);
+        if (has_fac) x = mul29(x, lds29_get<C>(rf, j));
+        lds29_put<C>(p, idx, x);
     }
     __syncthreads();
-    ntt29_tile_stages<C, true>(p, E, U, l, a.log_ch);
+    ntt29_tile_stages<C, true>(p, U, l, a.log_ch);
     for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
         const uint32_t c = idx & (CH - 1), k = idx >> a.log_ch;
         const uint32_t j = __brev(k) >> (32 - l);
-        rec29_store<C>(out, base + ((uint64_t)k << log_S) + c, lds29_get<C>(p, E, (j << a.log_ch) + c));
+        rec29_store<C>(out, base + ((uint64_t)k << log_S) + c, lds29_get<C>(p, (j << a.log_ch) + c));
     }
 }
 
@@ -165,8 +176,8 @@ k_ntt29_pass_last(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds29[];
     in += (size_t)blockIdx.y * a.in_bs; out += (size_t)blockIdx.y * a.out_bs;
     const uint32_t l = a.l[a.pass], N = 1u << l, CH = 1u << a.log_ch, E = N << a.log_ch, PL = (N + 1) << a.log_ch, HN = N >> 1;
-    uint32_t* p = lds29;                   // 9 planes of (N+1)*CH words
-    uint32_t* U = p + 9 * PL;
+    const Tile29 p(lds29, PL);                                            // the tile, transposed: (N+1)*CH elements
+    const Tile29 U(lds29 + Tile29::words(PL), HN > 0 ? HN : 1);
     const bool multi = a.n_pass > 1;
     const uint32_t l1 = a.l[0];
     uint64_t r = 0, c0 = 0, Krest = 0;
@@ -178,7 +189,7 @@ k_ntt29_pass_last(const uint32_t* in, uint32_t* out, NttPassArgs a) {
         Krest = ntt_digit_reverse(a, r, 1, a.n_pass - 2);
         log_S1 = a.log_n - l1;
     }
-    for (uint32_t k = threadIdx.x; k < HN; k += NTT_THREADS) lds29_put<C>(U, HN > 0 ? HN : 1, k, load29_packed<C>(a.LT + (size_t)k * C::N));
+    for (uint32_t k = threadIdx.x; k < HN; k += NTT_THREADS) lds29_put<C>(U, k, load29_packed<C>(a.LT + (size_t)k * C::N));
     Fp29<C> sc;
     if (a.scale) sc = load29_packed<C>(a.scale);
     for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
@@ -191,16 +202,16 @@ k_ntt29_pass_last(const uint32_t* in, uint32_t* out, NttPassArgs a) {
         }
         if (a.rowinc) x = mul29(x, load29_packed<C>(a.rowinc + (size_t)j * C::N));
         if (a.scale) x = mul29(x, sc);
-        lds29_put<C>(p, PL, c * (N + 1) + j, x);
+        lds29_put<C>(p, c * (N + 1) + j, x);
     }
     __syncthreads();
-    ntt29_tile_stages<C, false>(p, PL, U, l, a.log_ch);
+    ntt29_tile_stages<C, false>(p, U, l, a.log_ch);
     for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
         const uint32_t c = idx & (CH - 1), k = idx >> a.log_ch;
         const uint32_t j = l ? (__brev(k) >> (32 - l)) : 0u;
         const uint64_t K = (c0 + c) + (Krest << l1);
         const uint64_t addr = multi ? (K + ((uint64_t)k << (a.log_n - l))) : k;
-        Fp29<C> v = lds29_get<C>(p, PL, c * (N + 1) + j);
+        Fp29<C> v = lds29_get<C>(p, c * (N + 1) + j);
         reduce29_small(v);
         uint32_t w[C::N];
         pack29<C>(w, v);

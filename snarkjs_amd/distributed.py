@@ -180,8 +180,8 @@ def groth16_prove_sharded(pk, witness, r_mont, s_mont, process_group=None, d_wit
     pk: ProvingKey(zkey, shard=(rank, world)) on every rank; witness: the FULL witness on every rank; r_mont, s_mont: the same
     blinding draws on every rank. backend: object with the DeviceShard interface (the gloo CPU test passes an oracle-backed one).
     timeline: optional dict that receives this rank's host-clock stage boundaries in ms since the call (bench.py --gpus N prints them per
-    rank): chains_done (the rank's own chains complete, 0 for ranks without one), w_enqueued, exchange_done (every slice of this rank has
-    arrived), sums_done (H half finished = the witness-side half finished too), gathered (all_gather + fold + blinding)."""
+    rank): chains_done (the rank's own chains complete, 0 for ranks without one), w_enqueued, slices_requested_done, exchange_done (every slice of
+    this rank has arrived: the copies share the device with the witness-side accumulations already running), sums_done (H half finished = the witness-side half finished too), gathered (all_gather + fold + blinding)."""
     import time
     import torch.distributed as dist
     rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
@@ -196,8 +196,9 @@ def groth16_prove_sharded(pk, witness, r_mont, s_mont, process_group=None, d_wit
         be.sums_w()                                            # witness-side MSMs underneath the exchange
         mark("w_enqueued")
         wait_chain_exchange(reqs)
+        mark("slices_requested_done")                          # every send / receive of this rank has been waited for (host side)
         lo, hi = h_ranges[rank]
-        h = be.join(a, b, c, hi - lo)                          # waits for the slices (torch's stream), then enqueues joinABC
+        h = be.join(a, b, c, hi - lo)                          # waits for the slices on torch's stream, then enqueues joinABC
         mark("exchange_done")
         part = be.sums(h)
         mark("sums_done")

@@ -2,9 +2,9 @@
 # Collect the round's judged evidence on the GPU box (run through gpurun): bench JSON (dense B, 2 proofs in flight = the default line),
 # serial and sparse-B variants, rocprofv3 kernel stats of the SERIAL command, the two PMC passes (separate runs, --kernel-trace only),
 # PLONK / BLS12-381 / 2^24 / FFLONK side benches, the PLONK kernel trace, the mul ceilings of the library's own field arithmetic.
-# usage (repo root):  gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r03'   then   python tools/publish_profiles.py r03
+# usage (repo root):  gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r04'   then   python tools/publish_profiles.py r04
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG; mkdir -p $O
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
@@ -23,10 +23,12 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bls
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/stats_plonk -o plonk -- python bench.py --workload plonk --log-n 20 --steps 4 --warmup 3 --pipeline 1 --no-cpu-baseline > $O/bench_plonk_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-napi-wall > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-napi-wall > /dev/null 2>&1
-tools/bin/fieldbench29 > $O/fieldbench29.txt 2>&1; tools/bin/maddbench29 >> $O/fieldbench29.txt 2>&1
+{ echo "== multiply-adds in plain C (the shipped build)"; tools/bin/fieldbench29; echo "== multiply-adds as inline-asm statements (-DZK_MAD_ASM, the r03 build: one s_nop per multiply-add)"; tools/bin/fieldbench29_asm; tools/bin/maddbench29; } > $O/fieldbench29.txt 2>&1
+# the multi-rank code path of bench.py on this ONE GPU (a 1-rank RCCL communicator): sharded MSM over resident tables, one proof over all ranks at 2^20 and at 2^24 (BASELINE configs[2])
+ZKMI_FORCE_DIST=1 timeout 1200 python bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-napi-wall > $O/bench_force_dist.json 2>/dev/null
 # keep the merge under the gpurun limit: the per-dispatch traces are large, the stats files are what gets published
 rm -f $O/stats/*kernel_trace.csv $O/stats_bls/*kernel_trace.csv $O/pmc_fetch/*kernel_trace.csv $O/pmc_write/*kernel_trace.csv
-for f in bench bench_serial bench_sparse_b bench_mixed_witness bench_plonk_2p20 bench_plonk_2p20_serial bench_bls12381_2p20 bench_fflonk_2p18 bench_bn128_2p24; do python - "$O/$f.json" <<'PY'
+for f in bench bench_serial bench_sparse_b bench_mixed_witness bench_plonk_2p20 bench_plonk_2p20_serial bench_bls12381_2p20 bench_fflonk_2p18 bench_bn128_2p24 bench_force_dist; do python - "$O/$f.json" <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], d["value"], d["unit"], d["ms_per_step"], "ms")

@@ -11,10 +11,10 @@ import shutil
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
-for f in ("bench", "bench_serial", "bench_sparse_b", "bench_mixed_witness", "bench_plonk_2p20", "bench_plonk_2p20_serial", "bench_bls12381_2p20", "bench_bn128_2p24", "bench_fflonk_2p18"):
+for f in ("bench", "bench_serial", "bench_sparse_b", "bench_mixed_witness", "bench_plonk_2p20", "bench_plonk_2p20_serial", "bench_bls12381_2p20", "bench_bn128_2p24", "bench_fflonk_2p18", "bench_force_dist"):
     if os.path.exists(f"{src}/{f}.json"):
         shutil.copy(f"{src}/{f}.json", f"{dst}/{tag}_{f}.json")
 line = lambda f: json.loads(open(f).read().strip().splitlines()[-1])
@@ -99,14 +99,17 @@ if fc and wc:
 
 if os.path.exists(f"{src}/fieldbench29.txt"):
     shutil.copy(f"{src}/fieldbench29.txt", f"{dst}/{tag}_fieldbench29.txt")
+if os.path.exists(f"{src}/pytest_gpu.log"):
+    shutil.copy(f"{src}/pytest_gpu.log", f"{dst}/{tag}_pytest_gpu.log")
 with open(f"{dst}/{tag}_isa_counts.md", "w") as f:
     for obj in ("snarkjs_amd/build/msm_bn254.o", "snarkjs_amd/build/msm_bls12381.o"):
         f.write(subprocess.run([sys.executable, "tools/isa_counts.py", obj], capture_output=True, text=True).stdout + "\n")
-    f.write("Reading (r03 build). Each kernel is: gather + unpack + the head of the addition (first big segment), the rare equal-points doubling (the\n"
-            "segment skipped by a forward branch right after it), the body of the addition (the segment that ends in the backward jump), then three\n"
-            "copies of the once-per-lane store (lane partial in R-form, bucket in R-form, bucket in R'-form). Main path of ONE mixed addition = head +\n"
-            "body (+ the small gather / loop-control segments): BN254 G1 616 + 1 559 (+ ~60) = 2 238 VALU (1 467 MACs); BN254 G2 1 354 + 4 446 (+ ~140) =\n"
-            "5 944 (4 374 MACs); BLS12-381 G1 1 224 + 3 414 (+ ~370) = 5 012 (3 543 + MACs of the small segments); BLS12-381 G2 (packed Jacobian accumulator,\n"
-            "8M + 3S) 5 438 + 9 464 = 14 902 VALU (11 760 MACs = 8 x 1 176 + 3 x 784). Code size of the main path at ~8 bytes per instruction: 28 KB, 81 KB,\n"
-            "64 KB and 209 KB against a 64 KB instruction cache shared by two CUs (see `box_calibration.code_fetch` in the bench lines and DESIGN.md 5).\n")
+    f.write("Reading (r04 build: multiply-adds in plain C — no `s_nop` padding between inline-asm statements, r03 carried one per multiply-add). Each kernel\n"
+            "is: gather + unpack + the head of the addition (first big segment), the rare equal-points doubling (the segment skipped by a forward branch\n"
+            "right after it), the body of the addition (the segment that ends in the backward jump), then three copies of the once-per-lane store. Main\n"
+            "path of ONE mixed addition = head + body (+ the small gather / loop-control segments): BN254 G1 653 + 1 659 (+ ~60) = 2 375 VALU (1 467 MACs;\n"
+            "r03: 2 238 VALU + 1 307 s_nop); BN254 G2 1 414 + 4 642 (+ ~140) = 6 200 (4 374 MACs; r03: 5 944 + 4 113 s_nop); BLS12-381 G1 1 284 + 3 579 (+ ~370) =\n"
+            "5 237 (r03: 5 012 + 3 262 s_nop); BLS12-381 G2 (packed Jacobian accumulator, 8M + 3S) 5 947 + 9 783 = 15 730 VALU (r03: 14 902 + 11 242 s_nop).\n"
+            "Code size of the main path: 17 KB, 47 KB, 38 KB and 118 KB (r03: 28, 81, 64 and 209 KB) against a 64 KB instruction cache shared by two CUs: the\n"
+            "BN254 loops now fit it (see `box_calibration.code_fetch` in the bench lines and DESIGN.md 5).\n")
 print(json.dumps({k: bench[k] for k in ("value", "ms_per_step", "roofline", "int_alu") if k in bench}, indent=1)[:2500])
