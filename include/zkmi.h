@@ -79,6 +79,11 @@ int zkmi_memset_dev(void* d_dst, int value, size_t bytes);
  * pre-computed window table of a buffer is built on its SECOND sight, an MSM over a prefix of a resident buffer re-uses its
  * table, tables that cannot fit are never built (plain bases instead), and least-recently-used tables are evicted under a
  * byte budget (env ZKMI_BASE_CACHE_BYTES, default 64 GiB). zkmi_release_bases drops every cached table.
+ * r04: a buffer that comes back at the SAME first-page address and length as one that has been checked byte for byte against a resident table
+ * is re-checked by SAMPLE (its first and last whole chunk and 30 chunks at positions that change from call to call) and in full on every 32nd
+ * sight; every other buffer, and every failed sample, takes the full hash. Consequence for the caller: do not edit a resident base buffer IN
+ * PLACE between calls — such an edit is noticed for certain only by the next full check (at most 31 calls later; another zkey in the same
+ * buffer differs in every chunk and is noticed at once). ZKMI_BASE_HASH_FULL=1 restores the full hash on every call.
  * out_jacobian: 3*group*n8q bytes. */
 int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t n, size_t scalar_bytes,
              uint64_t base_cache_key, uint8_t* out_jacobian);

@@ -268,6 +268,22 @@ def test_msm_base_cache_is_content_addressed(zk):
     k = 9000
     wk2 = O.to_affine(c, 1, O.msm(c, 1, B2[:k * 64], sc[:k * 32], k))
     assert np.array_equal(aff(cv.G1.multiExpAffine(B2[:k * 64].copy(), sc[:k * 32], cache_key=1)), wk2)
+    # r04: a buffer that comes back at the SAME address and length as one already checked byte for byte against a resident table is re-checked
+    # by sample (first, last and 30 pseudo-random chunks; here 19 whole chunks: practically all of them) and in full on every 32nd sight
+    # (include/zkmi.h: zkmi_msm). A caller must not edit a resident buffer in place — but if it does, the edit is noticed at the latest by that
+    # full check, and from then on the results are the edited buffer's.
+    Bm = B.copy()
+    for _ in range(3):
+        assert np.array_equal(aff(cv.G1.multiExpAffine(Bm, sc, cache_key=1)), want)        # full check on first sight of this address, then samples
+    Bm[i * 64:(i + 1) * 64] = B[(i + 1) * 64:(i + 2) * 64]                                   # in place: the content of B2 at Bm's address
+    seen_new = False
+    for _ in range(40):
+        got = aff(cv.G1.multiExpAffine(Bm, sc, cache_key=1))
+        if np.array_equal(got, want2):
+            seen_new = True
+        else:
+            assert not seen_new and np.array_equal(got, want)                                # stale only BEFORE the edit was noticed, never after
+    assert seen_new
     # without the permission bit nothing is cached
     zkmi.check(L.zkmi_release_bases(0))
     for _ in range(3):
