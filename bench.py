@@ -130,23 +130,39 @@ def reference_wasm_baseline():
 
 
 def reference_wasm_baseline_plonk(proto, lg):
-    """The reference's own plonk.prove / fflonk.prove (WASM + worker threads), measured in the BUILD container at 2^8 .. 2^12 by
-    tools/ref_wasm_baseline_plonk.js and committed under profiles/; the figure for the bench size is a LINEAR EXTRAPOLATION from the largest
-    measured size and is labelled as such."""
-    f = os.path.join(ROOT, "profiles", "r03_ref_wasm_baseline_plonk.json")
-    if not os.path.exists(f):
-        return None
-    d = json.load(open(f))
-    runs = [r for r in d["runs"] if r["proto"] == proto]
+    """The reference's own plonk.prove / fflonk.prove (WASM + worker threads), measured in the BUILD container and committed under profiles/.
+    Sizes are PLONK DOMAINS (what --log-n means here). PLONK: r04 measured domains 2^11 and 2^16 (and 2^20 when the long run finished) on keys from
+    the reference's setup over a known-tau ptau (tools/ref_wasm_baseline_plonk_big.js); r03's runs (real JS ceremony, 2^9 .. 2^13 as domains: that
+    file labels them by r1cs constraints, one less) are listed beside them. A figure for a domain that was not measured is a LINEAR extrapolation
+    from the largest measured one and says so."""
+    runs = []
+    f4 = os.path.join(ROOT, "profiles", "r04_ref_wasm_baseline_plonk.json")
+    f3 = os.path.join(ROOT, "profiles", "r03_ref_wasm_baseline_plonk.json")
+    host = None
+    if os.path.exists(f4):
+        d = json.load(open(f4))
+        host = d["host"]
+        runs += [{"log_domain": r["log_domain"], "threads": r["threads"], "ms_per_proof": r["ms_per_proof"], "node": r.get("node"), "source": "profiles/r04_ref_wasm_baseline_plonk.json"} for r in d["runs"] if r["proto"] == proto]
+    if os.path.exists(f3):
+        d = json.load(open(f3))
+        host = host or d["host"]
+        runs += [{"log_domain": r["log_n"] + 1, "threads": r["threads"], "ms_per_proof": r["ms_per_proof"], "node": r.get("node"), "source": "profiles/r03_ref_wasm_baseline_plonk.json (labelled log_n %d there)" % r["log_n"]}
+                 for r in d["runs"] if r["proto"] == proto]
     if not runs:
         return None
-    best = max(runs, key=lambda r: (r["log_n"], r["threads"]))
-    scale = 1 << (lg - best["log_n"])
-    return {"where": f"build container, {d['host']['cpus']} cpus ({d['host']['model']}), Node {best['node']}; NOT this box",
-            "measured": [{k: r[k] for k in ("log_n", "threads", "ms_per_proof")} for r in runs],
-            "extrapolated_proofs_per_s": round(1e3 / (best["ms_per_proof"] * scale), 6),
-            "extrapolation": f"linear x{scale} from the measured 2^{best['log_n']} proof ({best['threads']} threads, {best['ms_per_proof']} ms) - not a measurement at 2^{lg}",
-            "source": "profiles/r03_ref_wasm_baseline_plonk.json"}
+    many = [r for r in runs if r["threads"] > 1] or runs
+    exact = [r for r in many if r["log_domain"] == lg]
+    out = {"where": f"build container, {host['cpus']} cpus ({host['model']}), Node {runs[0]['node']}; NOT this box",
+           "measured": [{k: r[k] for k in ("log_domain", "threads", "ms_per_proof", "source")} for r in runs]}
+    if exact:
+        best = min(exact, key=lambda r: r["ms_per_proof"])
+        out["measured_at_bench_size"] = {"log_domain": lg, "threads": best["threads"], "ms_per_proof": best["ms_per_proof"], "proofs_per_s": round(1e3 / best["ms_per_proof"], 6)}
+    else:
+        best = max(many, key=lambda r: r["log_domain"])
+        scale = 2.0 ** (lg - best["log_domain"])
+        out["extrapolated_proofs_per_s"] = round(1e3 / (best["ms_per_proof"] * scale), 6)
+        out["extrapolation"] = f"linear x{scale:g} from the measured domain 2^{best['log_domain']} ({best['threads']} threads, {best['ms_per_proof']} ms) - not a measurement at 2^{lg}"
+    return out
 
 
 def cpu_baseline(args, zkey, wtns, log_n_full):

@@ -68,12 +68,13 @@ int zkmi_ipc_close(void* d_ptr) {
     auto it = g_ipc_ptr.find(d_ptr);
     if (it == g_ipc_ptr.end()) return ZKMI_OK;                   // our own export, or closed already
     auto mt = g_ipc_open.find(it->second);
-    if (mt != g_ipc_open.end() && --mt->second.refs <= 0) {
-        if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
-        (void)hipIpcCloseMemHandle(mt->second.base);
-        g_ipc_open.erase(mt);
-    }
-    g_ipc_ptr.erase(it);
+    if (mt == g_ipc_open.end()) { g_ipc_ptr.erase(it); return ZKMI_OK; }
+    if (--mt->second.refs > 0) return ZKMI_OK;                  // opened more than once (the same handle gives the same pointer): the last close unmaps
+    if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+    (void)hipIpcCloseMemHandle(mt->second.base);
+    const std::string key = it->second;
+    g_ipc_open.erase(mt);
+    for (auto p = g_ipc_ptr.begin(); p != g_ipc_ptr.end();) { if (p->second == key) p = g_ipc_ptr.erase(p); else ++p; }      // interior pointers of the same mapping
     return ZKMI_OK;
 }
 
