@@ -349,16 +349,20 @@ int zkmi_host_unregister(void* host_ptr);
  *   zkmi_ipc_open:   device pointer in THIS process for a handle (peer access is enabled on first use); *bytes_visible (optional) = bytes
  *                    from the pointer to the end of the exported allocation. A handle exported by the calling process resolves to the
  *                    original pointer. zkmi_ipc_close drops the mapping (the exporter keeps the memory).
- *   zkmi_peer_copy:  d_dst <- d_src for `bytes` bytes on the library stream, complete on return; zkmi_peer_copy_async: queued only
- *                    (zkmi_synchronize). The exporter must have finished writing (its zkmi_groth16_chains_dev returned) before a peer
- *                    reads, and must not overwrite the buffer until every peer has reported its copy complete: the host orders this
- *                    (js/groth16_shards.js: "chain" / "pulled" messages). */
+ *   zkmi_peer_copy:  d_dst <- d_src for `bytes` bytes, complete on return. The copies run on a stream of their own, NOT behind what the library
+ *                    stream has queued (a shard process has its witness-side accumulations there when the slices arrive).
+ *                    zkmi_peer_copy_async: queued only; zkmi_peer_fence() makes the library stream wait (an event, no host wait) for every
+ *                    copy queued so far, so that the next call (zkmi_groth16_join_abc_dev) sees the data. The exporter must have finished
+ *                    writing (its zkmi_groth16_chains_dev returned) before a peer reads, and must not overwrite the buffer until every peer
+ *                    has finished its copy: the host orders this (js/groth16_shards.js: a chain is announced when complete; the next proof
+ *                    starts only after every worker has delivered its sums). */
 #define ZKMI_IPC_HANDLE_BYTES 96
 int zkmi_ipc_export(const void* d_ptr, uint8_t* handle);
 int zkmi_ipc_open(const uint8_t* handle, void** d_ptr, size_t* bytes_visible);
 int zkmi_ipc_close(void* d_ptr);
 int zkmi_peer_copy(void* d_dst, const void* d_src, size_t bytes);
 int zkmi_peer_copy_async(void* d_dst, const void* d_src, size_t bytes);
+int zkmi_peer_fence(void);
 /* Curve of a resident Groth16 key (ZKMI_CURVE_*), -1 when the key is not loaded: bindings size their output buffers from the KEY, not from
  * a caller-supplied curve id. */
 int zkmi_groth16_key_curve(uint64_t key);

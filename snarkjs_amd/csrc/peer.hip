@@ -78,22 +78,41 @@ int zkmi_ipc_close(void* d_ptr) {
     return ZKMI_OK;
 }
 
-// d_dst (this process's device) <- d_src (a pointer from zkmi_ipc_open, or any device pointer of this process), stream-ordered on the
-// library stream and complete on return: the caller tells the exporter afterwards that its buffer may be overwritten.
-int zkmi_peer_copy(void* d_dst, const void* d_src, size_t bytes) {
-    ZK_TRY(require_ctx());
-    if (!bytes) return ZKMI_OK;
-    if (!d_dst || !d_src) return fail(ZKMI_ERR_INVALID, "peer_copy: null argument");
-    ZK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
-    ZK_HIP(hipStreamSynchronize(ctx().stream));
+// d_dst (this process's device) <- d_src (a pointer from zkmi_ipc_open, or any device pointer of this process). The copies run on a stream of
+// their own: the library stream of a shard process is full of the witness-side accumulations at the moment the slices are pulled
+// (zkmi_groth16_sums_w_dev was enqueued first, on purpose), and a copy queued behind them would cross xGMI only after they have finished — on the
+// critical path of the H half instead of underneath the witness half.
+//   zkmi_peer_copy        complete on return (waits for the copy stream only);
+//   zkmi_peer_copy_async  queued; zkmi_peer_fence() then makes the LIBRARY stream wait for everything queued so far (an event, no host wait):
+//                         what is enqueued on the library stream afterwards (zkmi_groth16_join_abc_dev) sees the data.
+static hipStream_t g_copy_stream = nullptr;
+static hipEvent_t g_copy_ev = nullptr;
+static int copy_stream_ready() {
+    if (g_copy_stream) return ZKMI_OK;
+    int lo = 0, hi = 0;
+    ZK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    ZK_HIP(hipStreamCreateWithPriority(&g_copy_stream, hipStreamNonBlocking, hi));
+    ZK_HIP(hipEventCreateWithFlags(&g_copy_ev, hipEventDisableTiming));
     return ZKMI_OK;
 }
-// the same without the wait: several slices queued back to back (the caller synchronises once, zkmi_synchronize)
 int zkmi_peer_copy_async(void* d_dst, const void* d_src, size_t bytes) {
     ZK_TRY(require_ctx());
     if (!bytes) return ZKMI_OK;
-    if (!d_dst || !d_src) return fail(ZKMI_ERR_INVALID, "peer_copy_async: null argument");
-    ZK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+    if (!d_dst || !d_src) return fail(ZKMI_ERR_INVALID, "peer_copy: null argument");
+    ZK_TRY(copy_stream_ready());
+    ZK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, g_copy_stream));
+    return ZKMI_OK;
+}
+int zkmi_peer_copy(void* d_dst, const void* d_src, size_t bytes) {
+    ZK_TRY(zkmi_peer_copy_async(d_dst, d_src, bytes));
+    if (bytes) ZK_HIP(hipStreamSynchronize(g_copy_stream));
+    return ZKMI_OK;
+}
+int zkmi_peer_fence(void) {
+    ZK_TRY(require_ctx());
+    if (!g_copy_stream) return ZKMI_OK;                          // nothing was ever queued
+    ZK_HIP(hipEventRecord(g_copy_ev, g_copy_stream));
+    ZK_HIP(hipStreamWaitEvent(ctx().stream, g_copy_ev, 0));
     return ZKMI_OK;
 }
 

@@ -96,9 +96,12 @@ async function workerMain() {
             } else if (msg.cmd === "slices") {
                 if (cnt) {
                     for (let c = 0; c < 3; c++) {
-                        if (peer) await addon.peerCopy(dSl[c], src[c] + 32 * hLo, 32 * cnt);          // device to device: xGMI, or HBM on a shared device
+                        // device to device (xGMI, or HBM on a shared device), on the library's copy stream: not queued behind the witness-side
+                        // accumulations already on the library stream; the fence below orders the join after the three copies
+                        if (peer) await (addon.peerCopyAsync ? addon.peerCopyAsync : addon.peerCopy)(dSl[c], src[c] + 32 * hLo, 32 * cnt);
                         else await addon.memcpyH2D(dSl[c], shm[c].subarray(32 * hLo, 32 * hHi));
                     }
+                    if (peer && addon.peerFence) await addon.peerFence();
                     await addon.joinABCDev(cid, dSl[0], dSl[1], dSl[2], dH, cnt);
                 }
                 const sums = await addon.groth16SumsHDev(cid, key, dW, dH);

@@ -678,6 +678,21 @@ static napi_value js_peer_copy(napi_env env, napi_callback_info info) {
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
+/* peerCopyAsync(dDst, dSrc, bytes): queued on the copy stream; peerFence(): the library stream waits for everything queued so far */
+static napi_value js_peer_copy_async(napi_env env, napi_callback_info info) {
+    ARGS(3);
+    void *d, *s; double bytes;
+    if (get_dptr(env, argv[0], &d) || get_dptr(env, argv[1], &s) || get_f64(env, argv[2], &bytes) || bytes < 0) BAD_ARG();
+    int rc = ZK_CALL(zkmi_peer_copy_async(d, s, (size_t)bytes));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_peer_fence(napi_env env, napi_callback_info info) {
+    (void)info;
+    int rc = ZK_CALL(zkmi_peer_fence());
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
 static napi_value js_groth16_reset(napi_env env, napi_callback_info info) {
     ARGS(1);
     double key;
@@ -839,7 +854,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"groth16ChainsDev", js_groth16_chains_dev}, {"groth16SumsWDev", js_groth16_sums_w_dev}, {"groth16SumsHDev", js_groth16_sums_h_dev}, {"groth16SumsDev", js_groth16_sums_dev},
         {"groth16Finish", js_groth16_finish}, {"joinABCDev", js_join_abc_dev}, {"pointAdd", js_point_add}, {"shmMap", js_shm_map}, {"shmUnlink", js_shm_unlink},
         {"msmTableDev", js_msm_table_dev}, {"msmTableMultiDev", js_msm_table_multi_dev}, {"ipcExport", js_ipc_export}, {"ipcOpen", js_ipc_open}, {"ipcClose", js_ipc_close},
-        {"peerCopy", js_peer_copy}, {"groth16Reset", js_groth16_reset}, {"groth16KeyCurve", js_groth16_key_curve},
+        {"peerCopy", js_peer_copy}, {"peerCopyAsync", js_peer_copy_async}, {"peerFence", js_peer_fence}, {"groth16Reset", js_groth16_reset}, {"groth16KeyCurve", js_groth16_key_curve},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -21,7 +21,7 @@ SYMBOLS = [
     "zkmi_init", "zkmi_device_count", "zkmi_last_error", "zkmi_version", "zkmi_set_stream", "zkmi_synchronize",
     "zkmi_dev_alloc", "zkmi_dev_free", "zkmi_memcpy_h2d", "zkmi_memcpy_d2h", "zkmi_memcpy_d2d", "zkmi_memset_dev",
     "zkmi_msm", "zkmi_release_bases", "zkmi_msm_dev", "zkmi_msm_set_window_bits", "zkmi_msm_accum_ms", "zkmi_msm_stats", "zkmi_msm_accum_additions", "zkmi_msm_table_build", "zkmi_msm_table_dev", "zkmi_msm_table_multi_dev", "zkmi_msm_table_release", "zkmi_msm_table_info",
-    "zkmi_ipc_export", "zkmi_ipc_open", "zkmi_ipc_close", "zkmi_peer_copy", "zkmi_peer_copy_async", "zkmi_groth16_key_curve", "zkmi_groth16_reset",
+    "zkmi_ipc_export", "zkmi_ipc_open", "zkmi_ipc_close", "zkmi_peer_copy", "zkmi_peer_copy_async", "zkmi_peer_fence", "zkmi_groth16_key_curve", "zkmi_groth16_reset",
     "zkmi_ntt", "zkmi_ntt_dev",
     "zkmi_fr_batch_apply_key", "zkmi_fr_batch_apply_key_dev", "zkmi_fr_batch", "zkmi_fr_batch_dev",
     "zkmi_groth16_join_abc", "zkmi_groth16_join_abc_dev",
@@ -107,6 +107,7 @@ def lib():
     L.zkmi_ipc_close.argtypes = [vp]
     L.zkmi_peer_copy.argtypes = [vp, vp, sz]
     L.zkmi_peer_copy_async.argtypes = [vp, vp, sz]
+    L.zkmi_peer_fence.argtypes = []
     L.zkmi_groth16_key_curve.argtypes = [C.c_uint64]
     L.zkmi_groth16_reset.argtypes = [C.c_uint64]
     L.zkmi_msm_accum_ms.argtypes = [C.c_int]

@@ -155,6 +155,8 @@ const backend = {
         for (const [base, buf] of mem) if (src >= base && src + bytes <= base + buf.length) { mem.get(dst).set(buf.subarray(src - base, src - base + bytes)); return; }
         throw new Error("zkmi error 2: peer_copy: source range is not mapped in this process");
     },
+    peerCopyAsync(dst, src, bytes) { note("peerCopyAsync"); backend.peerCopy(dst, src, bytes); },
+    peerFence() { note("peerFence"); },
     groth16Reset(key) { note("groth16Reset"); const K = keys.get(key); if (K) K.W = null; for (const k of Object.keys(slots)) delete slots[k]; },
     failNext(name) { failNextCall = name; },
 };

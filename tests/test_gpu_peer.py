@@ -52,6 +52,13 @@ def test_ipc_export_open_peer_copy_between_processes():
     same = zkmi.DeviceBuffer(1000)
     zkmi.check(L.zkmi_peer_copy(same.ptr, p.value + 77, 1000))
     assert np.array_equal(same.to_host(), data[77:1077])
+    # queued copies + fence: what is enqueued on the library stream after the fence sees the data (to_host copies on that stream)
+    two = zkmi.DeviceBuffer(4096)
+    zkmi.check(L.zkmi_peer_copy_async(two.ptr, p.value + 1000, 2048))
+    zkmi.check(L.zkmi_peer_copy_async(two.ptr + 2048, p.value + 5000, 2048))
+    zkmi.check(L.zkmi_peer_fence())
+    assert np.array_equal(two.to_host(), np.concatenate([data[1000:3048], data[5000:7048]]))
+    two.free()
     # another process (on the second GPU when there is one) pulls a slice. A pytest session has torch imported (conftest, other tests), and the
     # torch wheel brings its own HIP runtime into the process: a handle exported under it cannot be opened by a process that runs the system
     # runtime alone (r04 probe: hipIpcOpenMemHandle "invalid argument" exactly then, tools/lab/r4_ipc_probe.py). The product's shard processes are
