@@ -9,10 +9,13 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libzkmi.so")
+# ZKMI_BUILD_VARIANT=<name> ZKMI_EXTRA_FLAGS="-D..." builds an A/B variant beside the product: objects in build_<name>/, libzkmi_<name>.so (loaded
+# with ZKMI_LIB=<path>, snarkjs_amd/zkmi.py); the addon is only built for the product library
+VARIANT = os.environ.get("ZKMI_BUILD_VARIANT", "")
+OBJ = os.path.join(HERE, "build" + ("_" + VARIANT if VARIANT else ""))
+LIB = os.path.join(HERE, "libzkmi" + ("_" + VARIANT if VARIANT else "") + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"] + os.environ.get("ZKMI_EXTRA_FLAGS", "").split()
 UNITS = ["zkmi_api.hip", "ntt.hip", "msm_sort.hip", "msm_bn254.hip", "msm_bls12381.hip", "groth16.hip", "plonk.hip", "gfft.hip", "gconv.hip", "calib.hip", "peer.hip"]
 
 
@@ -67,7 +70,8 @@ def build(verbose=False, force=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-    build_addon(verbose)
+    if not VARIANT:
+        build_addon(verbose)
     return LIB
 
 
