@@ -127,7 +127,12 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
     // 2^24 chain 22.2 vs 20.9 ms: a pass is bound by instruction issue INCLUDING its LDS traffic, and nine 4-byte limb planes cost 45 LDS
     // instructions per butterfly where two 16-byte planes cost 10, which eats what the cheaper product (207 vs ~290 instructions) saves.
     // The 32-bit passes stay the default; the 29-bit ones are kept behind this switch with their own parity test.
-    static const bool use29 = getenv("ZKMI_NTT29") && atoi(getenv("ZKMI_NTT29")) == 1;
+    // r04 (three vector planes per tile, column-statement products): the 29-bit passes are faster up to 2^22 (2^16 0.0275 vs 0.033 ms, 2^20 0.151 vs 0.165,
+    // 2^22 0.571 vs 0.618 forward) and slower from 2^24 (their 48-byte records between passes are 1.5 x the traffic: 2.66 vs 2.59 ms), profiles/r04_ntt29_ab.txt.
+    // ZKMI_NTT29=1 / 0 forces one form; unset: the 29-bit passes up to ZKMI_NTT29_MAX_LOG (default 22).
+    static const int env29 = getenv("ZKMI_NTT29") ? atoi(getenv("ZKMI_NTT29")) : -1;
+    static const unsigned max29 = getenv("ZKMI_NTT29_MAX_LOG") ? (unsigned)atoi(getenv("ZKMI_NTT29_MAX_LOG")) : 22u;
+    const bool use29 = env29 >= 0 ? env29 == 1 : L <= max29;
     uint32_t* d_rowinc = nullptr;
     size_t rowoff[4] = {0, 0, 0, 0};
     if (first) {

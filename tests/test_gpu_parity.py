@@ -61,9 +61,11 @@ def test_ntt_all_sizes_vs_oracle(zk, name):
         assert np.array_equal(cv.Fr.ifft(x), O.ntt(c, x, True)), f"ifft 2^{lg}"
 
 
-def test_ntt29_passes_opt_in_parity():
-    """The NTT passes on 9 x 29-bit limbs (csrc/ntt29.cuh; opt-in, ZKMI_NTT29=1 — measured no faster than the 32-bit passes in r03): the same
-    bytes as the oracle for every size, both curves, forward / inverse / fused pre-scale, in a process of its own (the switch is read once)."""
+@pytest.mark.parametrize("force", ["1", "0"])
+def test_ntt29_passes_opt_in_parity(force):
+    """Both forms of the NTT passes forced for EVERY size (the default picks the 9 x 29-bit passes of csrc/ntt29.cuh up to 2^22 and the saturated
+    32-bit ones of ntt.cuh above, r04): the same bytes as the oracle for every size, both curves, forward / inverse / fused pre-scale, in a
+    process of its own (ZKMI_NTT29 is read once)."""
     import subprocess
     import sys
     code = (
@@ -82,7 +84,7 @@ def test_ntt29_passes_opt_in_parity():
         "    first, inc = O.fr_e(c, 7), O.fr_e(c, 11)\n"
         "    assert np.array_equal(cv.Fr.fft(cv.Fr.batchApplyKey(x, first, inc)), O.ntt(c, O.apply_key(c, x, first, inc)))\n"
         "print('ntt29 ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, ZKMI_NTT29="1"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, ZKMI_NTT29=force))
     assert r.returncode == 0 and "ntt29 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
