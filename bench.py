@@ -24,14 +24,14 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU instructions of one mixed addition, main path of the shipped code objects (tools/isa_counts.py -> profiles/r04_isa_counts.md: the fetch /
-# unpack segment + the addition segment of k_msm_accum29 / k_msm_accum29_g2 per curve). r04: BN254 with one asm statement per column of the product
-# scanning (the hand order of r03, 283 / 767 s_nop per addition instead of 1 307 / 4 113), BLS12-381 with multiply-adds in plain C (no s_nop, 4 - 6 % more VALU)
-VALU_PER_ADD = {"bn128": {"g1": 2230, "g2": 5930}, "bls12381": {"g1": 5237, "g2": 15730}}
+# unpack segment + the addition segment of k_msm_accum29 / k_msm_accum29_g2 per curve). r04: one asm statement per column of the product scanning
+# (the hand order of r03 — the same VALU counts — with 283 / 767 / 453 / 1 387 s_nop per addition instead of 1 307 / 4 113 / 3 262 / 11 242)
+VALU_PER_ADD = {"bn128": {"g1": 2230, "g2": 5930}, "bls12381": {"g1": 5002, "g2": 14880}}
 VALU_ISSUE_PEAK_G = 614.4                      # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave instruction
 # measured Montgomery-multiply ceilings of the chip, Gmul/s at 8 waves per SIMD, in the limb form the accumulation kernels of the curve use
 # (tools/fieldbench29 on the library's own mul29): BN254 Fq 9 x 29-bit limbs, BLS12-381 Fq 14 x 28-bit limbs; the saturated 32-bit forms they
-# replaced measured 130 and 58.6 (tools/fieldbench, profiles/r01_fieldbench.txt). profiles/r04_fieldbench29.txt holds this round's run (BN254 column
-# statements 171 at 8 waves per SIMD, 149 at 2; BLS12-381 plain C 78.7 / 77.4; the r03 per-instruction asm build beside it: 176 / 77.7 and 144 / 73.8).
+# replaced measured 130 and 58.6 (tools/fieldbench, profiles/r01_fieldbench.txt). profiles/r04_fieldbench29.txt holds this round's run (column
+# statements: BN254 171 at 8 waves per SIMD, 149 at 2; BLS12-381 81.7 / 76.8; the r03 per-instruction asm build beside it: 176 / 77.7 and 144 / 73.8).
 FIELD_MUL_PEAK_G = {"bn128": 175.0, "bls12381": 78.3}
 FIELD_MUL_PEAK_32 = {"bn128": 130.0, "bls12381": 58.6}
 

@@ -25,7 +25,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-napi-wall > /dev/null 2>&1
 # tools/bin/fieldbench29 = the shipped arithmetic (9-limb fields: one asm statement per column; 14-limb: plain C); _plain = -DZK_MAD_PLAIN (plain C
 # everywhere); _asm = -DZK_MAD_PLAIN -DZK_MAD_ASM (one asm statement per multiply-add: the r03 build)
-{ echo "== the shipped build: 9-limb fields one asm statement per COLUMN of the product scanning, 14-limb field plain C"; tools/bin/fieldbench29;
+{ echo "== the shipped build: one asm statement per COLUMN of the product scanning (every field)"; tools/bin/fieldbench29;
   echo "== -DZK_MAD_PLAIN: multiply-adds in plain C everywhere"; tools/bin/fieldbench29_plain;
   echo "== -DZK_MAD_PLAIN -DZK_MAD_ASM: one inline-asm statement per multiply-add (the r03 build: one s_nop behind each)"; tools/bin/fieldbench29_asm; tools/bin/maddbench29; } > $O/fieldbench29.txt 2>&1
 # the multi-rank code path of bench.py on this ONE GPU (a 1-rank RCCL communicator): sharded MSM over resident tables, one proof over all ranks at 2^20 and at 2^24 (BASELINE configs[2])
