@@ -104,12 +104,12 @@ if os.path.exists(f"{src}/pytest_gpu.log"):
 with open(f"{dst}/{tag}_isa_counts.md", "w") as f:
     for obj in ("snarkjs_amd/build/msm_bn254.o", "snarkjs_amd/build/msm_bls12381.o"):
         f.write(subprocess.run([sys.executable, "tools/isa_counts.py", obj], capture_output=True, text=True).stdout + "\n")
-    f.write("Reading (r04 build: multiply-adds in plain C — no `s_nop` padding between inline-asm statements, r03 carried one per multiply-add). Each kernel\n"
-            "is: gather + unpack + the head of the addition (first big segment), the rare equal-points doubling (the segment skipped by a forward branch\n"
-            "right after it), the body of the addition (the segment that ends in the backward jump), then three copies of the once-per-lane store. Main\n"
-            "path of ONE mixed addition = head + body (+ the small gather / loop-control segments): BN254 G1 653 + 1 659 (+ ~60) = 2 375 VALU (1 467 MACs;\n"
-            "r03: 2 238 VALU + 1 307 s_nop); BN254 G2 1 414 + 4 642 (+ ~140) = 6 200 (4 374 MACs; r03: 5 944 + 4 113 s_nop); BLS12-381 G1 1 284 + 3 579 (+ ~370) =\n"
-            "5 237 (r03: 5 012 + 3 262 s_nop); BLS12-381 G2 (packed Jacobian accumulator, 8M + 3S) 5 947 + 9 783 = 15 730 VALU (r03: 14 902 + 11 242 s_nop).\n"
-            "Code size of the main path: 17 KB, 47 KB, 38 KB and 118 KB (r03: 28, 81, 64 and 209 KB) against a 64 KB instruction cache shared by two CUs: the\n"
-            "BN254 loops now fit it (see `box_calibration.code_fetch` in the bench lines and DESIGN.md 5).\n")
+    f.write("Reading (r04 build: the multiply-adds of one COLUMN of the product scanning are one asm statement — one `s_nop` per column where r03 carried one per\n"
+            "multiply-add). Each kernel is: gather + unpack + the head of the addition (first big segment), the rare equal-points doubling (the segment skipped\n"
+            "by a forward branch right after it), the body of the addition (the segment that ends in the backward jump), then three copies of the once-per-lane\n"
+            "store. Main path of ONE mixed addition = head + body (+ the small gather / loop-control segments): BN254 G1 616 + 1 554 (+ ~60) = 2 230 VALU\n"
+            "(1 467 MACs, 283 s_nop; r03: 2 238 VALU + 1 307 s_nop); BN254 G2 1 354 + 4 434 (+ ~140) = 5 930 (4 374 MACs, 767 s_nop; r03: 5 944 + 4 113 s_nop);\n"
+            "BLS12-381 G1 1 224 + 3 404 (+ ~370) = 5 002 (453 s_nop; r03: 5 012 + 3 262 s_nop); BLS12-381 G2 (packed Jacobian accumulator, 8M + 3S) 5 438 + 9 442 =\n"
+            "14 880 VALU (1 387 s_nop; r03: 14 902 + 11 242 s_nop). These are the constants `bench.py` divides by (`VALU_PER_ADD`). Plain C multiply-adds\n"
+            "(measured, not shipped: `-DZK_MAD_PLAIN`) carry no s_nop but 4-6 % more VALU (64-bit merge adds of the partial chains): 2 375 / 6 200 / 5 237 / 15 730.\n")
 print(json.dumps({k: bench[k] for k in ("value", "ms_per_step", "roofline", "int_alu") if k in bench}, indent=1)[:2500])
