@@ -16,19 +16,18 @@
 #include <type_traits>
 #include "host_field.hpp"
 #include "ntt.cuh"
+#include "plonk29.cuh"
 #include "zkmi_common.hpp"
 
 namespace zkmi {
 
+#ifndef ZKMI_PLONK_T29_DEFAULT
+#define ZKMI_PLONK_T29_DEFAULT 0
+#endif
 typedef host::HField<4> HFr;
 typedef host::HFp<4> HE;
 
-// base^e = lo[e & (2^lb - 1)] * hi[e >> lb]
-struct PowTab {
-    const uint32_t* lo;
-    const uint32_t* hi;
-    uint32_t lb;
-};
+// base^e = lo[e & (2^lb - 1)] * hi[e >> lb]   (struct PowTab: plonk29.cuh)
 template <class C> ZK_DEV Fp<C> pow_tab(const PowTab& t, uint64_t e) {
     Fp<C> a = fp_load<C>(t.lo + (size_t)(e & ((1ull << t.lb) - 1)) * C::N);
     Fp<C> b = fp_load<C>(t.hi + (size_t)(e >> t.lb) * C::N);
@@ -162,8 +161,7 @@ template <class C> __global__ void k_plonk_gather(const uint32_t* __restrict__ w
 }
 
 // ---- computeZ -------------------------------------------------------------------------------------------------------------
-// constants block (device): [0] beta [1] gamma [2] k1 [3] k2 [4] alpha [5] alpha^2 [6] w_n [7..17] b1..b11 [18..21] Z1 [22..25] Z2 [26..29] Z3 [30] one
-enum { PK_BETA = 0, PK_GAMMA, PK_K1, PK_K2, PK_ALPHA, PK_ALPHA2, PK_WN, PK_B1, PK_Z1 = PK_B1 + 11, PK_Z2 = PK_Z1 + 4, PK_Z3 = PK_Z2 + 4, PK_ONE = PK_Z3 + 4, PK_COUNT };
+// constants block (device): enum PK_* in plonk29.cuh
 template <class C> ZK_DEV Fp<C> kc(const uint32_t* k, int i) { return fp_load<C>(k + (size_t)i * 8); }
 
 template <class C> __global__ void __launch_bounds__(256)
@@ -192,14 +190,7 @@ template <class C> __global__ void k_plonk_z_finish(const uint32_t* __restrict__
 }
 
 // ---- computeT ---------------------------------------------------------------------------------------------------------------
-struct PlonkTArgs {
-    const uint32_t *a, *b, *c, *z, *qm, *ql, *qr, *qo, *qc, *s1, *s2, *s3;     // 4n evaluations each
-    const uint32_t* lagrange;     // section 13 on the device: per public input 5n elements (n coefficients, 4n evaluations)
-    const uint32_t* pub_a;        // buffers.A (Montgomery): A[j], j < nPublic
-    const uint32_t* k;            // constants block
-    uint32_t domain, n_public;
-    uint32_t *t, *tz;
-};
+// struct PlonkTArgs: plonk29.cuh
 // CALLS: the field product as a CALL (16 argument registers, no stack traffic): k_plonk_t is 63 - 82 KB of straight-line code per part against
 // a 64 KB instruction cache, 2.8 x slower on a slow-fetch box (field29.cuh: Compact; r03: 2.8 / 3.0 ms per part there against 1.0 ms)
 template <class C> __device__ __attribute__((noinline)) Fp<C> fp_mul_call(Fp<C> a, Fp<C> b) { return fp_mul(a, b); }
@@ -317,6 +308,14 @@ template <class C, int PART, bool CALLS = false> __global__ void __launch_bounds
             fp_store<C>(ptz, fp_sub(fp_load<C>(ptz), fp_mulx<C, CALLS>(ez, alpha)));
         }
     }
+}
+
+// The same numerator on 9 x 29-bit limbs (plonk29.cuh): same three launches, same buffers, the same bytes out. F = the field, or Compact<field>
+// with the products behind calls.
+template <class F, int PART> __global__ void __launch_bounds__(256, 2) k_plonk_t29(PlonkTArgs g, PowTab w4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * g.domain) return;
+    plonk_t29_point<Fp29<F>, PART>(g, w4, i);
 }
 
 // ---- FFLONK quotient numerators (src/fflonk_prove.js) ------------------------------------------------------------------------
@@ -556,12 +555,16 @@ template <class C> struct PlonkOps {
         std::vector<HE> kv(PK_COUNT, Fh.zero());
         kv[PK_BETA] = he(beta); kv[PK_GAMMA] = he(gamma); kv[PK_K1] = he(k1); kv[PK_K2] = he(k2); kv[PK_ALPHA] = he(alpha); kv[PK_ALPHA2] = Fh.sqr(he(alpha)); kv[PK_WN] = he(w_n);
         for (int j = 0; j < 11; j++) kv[PK_B1 + j] = he(blind + 32 * j);
-        kv[PK_ONE] = Fh.One();
+        kv[PK_ONE] = Fh.One(); kv[PK_NALPHA] = Fh.neg(he(alpha));
         // MulZ constants (mul_z.js:21-47), w2 = Fr.w[2]
         const HE w2 = he(w_2), one = Fh.One(), two = Fh.from_u64(2), m1 = Fh.neg(one), m2 = Fh.neg(two);
         kv[PK_Z1 + 1] = Fh.add(m1, w2); kv[PK_Z1 + 2] = m2; kv[PK_Z1 + 3] = Fh.sub(m1, w2);
         kv[PK_Z2 + 1] = Fh.mul(m2, w2); kv[PK_Z2 + 2] = Fh.from_u64(4); kv[PK_Z2 + 3] = Fh.neg(Fh.mul(m2, w2));
         kv[PK_Z3 + 1] = Fh.add(two, Fh.mul(two, w2)); kv[PK_Z3 + 2] = Fh.neg(Fh.from_u64(8)); kv[PK_Z3 + 3] = Fh.sub(two, Fh.mul(two, w2));
+        // the 29-bit kernels read every constant in R'-form as well (x 2^261 = 32 x in R-form): second half of the block
+        const HE k32 = Fh.from_u64(32);
+        kv.resize(2 * PK_COUNT, Fh.zero());
+        for (int j = 0; j < PK_COUNT; j++) kv[PK_COUNT + j] = Fh.mul(kv[j], k32);
         uint32_t* dk;
         ZK_TRY(upload_consts(kv, "plonk.kt", &dk));
         PowTab w4;
@@ -570,7 +573,7 @@ template <class C> struct PlonkOps {
         g.a = (const uint32_t*)ev->a; g.b = (const uint32_t*)ev->b; g.c = (const uint32_t*)ev->c; g.z = (const uint32_t*)ev->z;
         g.qm = (const uint32_t*)ev->qm; g.ql = (const uint32_t*)ev->ql; g.qr = (const uint32_t*)ev->qr; g.qo = (const uint32_t*)ev->qo; g.qc = (const uint32_t*)ev->qc;
         g.s1 = (const uint32_t*)ev->s1; g.s2 = (const uint32_t*)ev->s2; g.s3 = (const uint32_t*)ev->s3;
-        g.lagrange = (const uint32_t*)ev->lagrange; g.pub_a = (const uint32_t*)ev->pub_a; g.k = dk;
+        g.lagrange = (const uint32_t*)ev->lagrange; g.pub_a = (const uint32_t*)ev->pub_a; g.k = dk; g.k29 = dk + (size_t)PK_COUNT * 8;
         g.domain = dom; g.n_public = n_public; g.t = (uint32_t*)T; g.tz = (uint32_t*)Tz;
         const dim3 grid((4 * dom + 255) / 256);
         // default: three launches (the merged e2 + e3 kernel measured the same on a healthy box and is twice the code); ZKMI_PLONK_T_PARTS=2 merges
@@ -579,7 +582,18 @@ template <class C> struct PlonkOps {
         // instruction fetch is healthy (38.4 / 37.9 against 38.0 / 38.3 proofs/s, same box), 2.6 x faster where it is not; an explicit
         // ZKMI_COMPACT_CODE mask without bit 4 selects the inlined kernels
         static const bool calls = getenv("ZKMI_COMPACT_CODE") ? (compact_code() & 16) != 0 : true;
-        if (calls) {
+        // ZKMI_PLONK_T29: 1 = the 29-bit-limb kernels, products inlined; 2 = with the products behind calls; 0 = the 32-bit-limb kernels below
+        const char* t29_env = getenv("ZKMI_PLONK_T29");                 // read per call (once per proof): the tests switch it
+        const int t29 = t29_env ? atoi(t29_env) : ZKMI_PLONK_T29_DEFAULT;
+        if (t29 == 1) {
+            hipLaunchKernelGGL((k_plonk_t29<C, 0>), grid, dim3(256), 0, cx.stream, g, w4);
+            hipLaunchKernelGGL((k_plonk_t29<C, 1>), grid, dim3(256), 0, cx.stream, g, w4);
+            hipLaunchKernelGGL((k_plonk_t29<C, 2>), grid, dim3(256), 0, cx.stream, g, w4);
+        } else if (t29 == 2) {
+            hipLaunchKernelGGL((k_plonk_t29<Compact<C>, 0>), grid, dim3(256), 0, cx.stream, g, w4);
+            hipLaunchKernelGGL((k_plonk_t29<Compact<C>, 1>), grid, dim3(256), 0, cx.stream, g, w4);
+            hipLaunchKernelGGL((k_plonk_t29<Compact<C>, 2>), grid, dim3(256), 0, cx.stream, g, w4);
+        } else if (calls) {
             hipLaunchKernelGGL((k_plonk_t<C, 0, true>), grid, dim3(256), 0, cx.stream, g, w4);
             hipLaunchKernelGGL((k_plonk_t<C, 1, true>), grid, dim3(256), 0, cx.stream, g, w4);
             hipLaunchKernelGGL((k_plonk_t<C, 2, true>), grid, dim3(256), 0, cx.stream, g, w4);

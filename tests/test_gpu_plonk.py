@@ -133,8 +133,11 @@ def test_plonk_stages_and_golden_proof(env, golden_dir, tag):
 
 
 @pytest.mark.gpu
-def test_compute_z_and_t_stages_vs_oracle(env, golden_dir):
-    """computeZ / computeT kernels against the oracle's intermediate arrays on the n = 2048 fixture."""
+@pytest.mark.parametrize("t29", ["1", "2", "0"])
+def test_compute_z_and_t_stages_vs_oracle(env, golden_dir, t29, monkeypatch):
+    """computeZ / computeT kernels against the oracle's intermediate arrays on the n = 2048 fixture; computeT in its three builds (ZKMI_PLONK_T29: 29-bit
+    limbs with the products inlined / behind calls, 32-bit limbs — csrc/plonk.hip reads the variable at every call)."""
+    monkeypatch.setenv("ZKMI_PLONK_T29", t29)
     zkmi, plonk, f, cx = env
     L = zkmi.lib()
     tag = "plonk_bn128_n2048"
