@@ -4,7 +4,7 @@
 // (src/plonk_prove.js, src/mul_z.js, src/polynomial/polynomial.js); here each is a data-parallel kernel over Fr:
 //   computeWirePolynomials gather  (plonk_prove.js:267-283)   k_plonk_gather
 //   computeZ                       (plonk_prove.js:361-455)   k_plonk_z_factors + multiplicative scan + batch inverse
-//   computeT + MulZ.mul2/mul4      (plonk_prove.js:516-628, mul_z.js:49-148)   k_plonk_t   (one lane per evaluation point)
+//   computeT + MulZ.mul2/mul4      (plonk_prove.js:516-628, mul_z.js:49-148)   k_plonk_t29 (plonk29.cuh: 29-bit limbs; one lane per evaluation point), k_plonk_t (32-bit limbs)
 //   Polynomial.add/sub/mulScalar   (polynomial.js:218-284)    k_poly_axpy / k_poly_scale
 //   Polynomial.evaluate (Horner)   (polynomial.js:174-184)    k_poly_eval_partial + k_poly_sum   (parallel reduction)
 //   Polynomial.divZh               (polynomial.js:592-615)    k_poly_div_zh          (stride-n recurrence, one lane per residue)
@@ -21,9 +21,6 @@
 
 namespace zkmi {
 
-#ifndef ZKMI_PLONK_T29_DEFAULT
-#define ZKMI_PLONK_T29_DEFAULT 0
-#endif
 typedef host::HField<4> HFr;
 typedef host::HFp<4> HE;
 
@@ -582,9 +579,12 @@ template <class C> struct PlonkOps {
         // instruction fetch is healthy (38.4 / 37.9 against 38.0 / 38.3 proofs/s, same box), 2.6 x faster where it is not; an explicit
         // ZKMI_COMPACT_CODE mask without bit 4 selects the inlined kernels
         static const bool calls = getenv("ZKMI_COMPACT_CODE") ? (compact_code() & 16) != 0 : true;
-        // ZKMI_PLONK_T29: 1 = the 29-bit-limb kernels, products inlined; 2 = with the products behind calls; 0 = the 32-bit-limb kernels below
+        // Default (r04): the 29-bit-limb kernels of plonk29.cuh with the products inlined — 41 - 52 KB per part, inside the instruction cache, 0.66 + 0.75 +
+        // 0.80 ms at 2^20 with two proofs in flight against 0.96 + 1.27 + 1.30 ms for the 32-bit kernels below (same box, same run: 39.5 / 39.9 against
+        // 37.9 / 38.4 proofs/s; with the products behind calls 36.8: the operands of the three- and four-product sums travel through the stack).
+        // ZKMI_PLONK_T29: 1 = that, 2 = products behind calls (also chosen by an explicit ZKMI_COMPACT_CODE mask with bit 4), 0 = the 32-bit-limb kernels
         const char* t29_env = getenv("ZKMI_PLONK_T29");                 // read per call (once per proof): the tests switch it
-        const int t29 = t29_env ? atoi(t29_env) : ZKMI_PLONK_T29_DEFAULT;
+        const int t29 = t29_env ? atoi(t29_env) : ((getenv("ZKMI_COMPACT_CODE") && (compact_code() & 16)) ? 2 : 1);
         if (t29 == 1) {
             hipLaunchKernelGGL((k_plonk_t29<C, 0>), grid, dim3(256), 0, cx.stream, g, w4);
             hipLaunchKernelGGL((k_plonk_t29<C, 1>), grid, dim3(256), 0, cx.stream, g, w4);
