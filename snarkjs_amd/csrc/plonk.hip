@@ -362,14 +362,21 @@ template <class C> __global__ void __launch_bounds__(256) k_fflonk_t2(FflonkT2Ar
     fp_store<C>(g.t2 + (size_t)i * 8, fp_sub(fp_mul(p1, z), fp_mul(p2, zW)));
     fp_store<C>(g.t2z + (size_t)i * 8, fp_sub(fp_mul(p1, zp), fp_mul(p2, zWp)));
 }
-// highest index of a non-zero element (0 when all vanish): Polynomial.degree (polynomial.js:163-172)
-static __global__ void k_poly_degree(const uint32_t* __restrict__ p, size_t n, unsigned long long* __restrict__ deg) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// highest index of a non-zero element (0 when all vanish): Polynomial.degree (polynomial.js:163-172). One ballot per wave finds the wave's highest
+// non-zero lane; the blocks walk the array from its END, so that the first waves to finish already hold the answer and the rest see a larger value and
+// skip their atomic (r04: one atomicMax per non-zero element on one address took 190 us per call at 2^20 - 2^22 elements, 15 calls per FFLONK proof).
+static __global__ void __launch_bounds__(256) k_poly_degree(const uint32_t* __restrict__ p, size_t n, unsigned long long* __restrict__ deg) {
+    const size_t i = (size_t)(gridDim.x - 1 - blockIdx.x) * blockDim.x + threadIdx.x;
     uint32_t o = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) o |= p[i * 8 + k];
-    if (o) atomicMax(deg, (unsigned long long)i);
+    if (i < n) {
+        const uint4* q = reinterpret_cast<const uint4*>(p + i * 8);
+        const uint4 a = q[0], b = q[1];
+        o = a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w;
+    }
+    const unsigned long long m = __ballot(o != 0);
+    if (m == 0 || (threadIdx.x & 63) != 0) return;
+    const unsigned long long cand = (unsigned long long)i + (unsigned long long)(63 - __clzll((long long)m));        // lanes of a wave hold consecutive indices
+    if (cand > __atomic_load_n(deg, __ATOMIC_RELAXED)) atomicMax(deg, cand);
 }
 
 // ---- polynomial ops ---------------------------------------------------------------------------------------------------------

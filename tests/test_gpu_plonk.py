@@ -233,7 +233,7 @@ def test_cpoly_interleave(env):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,deg", [(1, 0), (1000, 999), (1000, 17), (70000, 65536), (4096, 0), (300, None)])
+@pytest.mark.parametrize("n,deg", [(1, 0), (1000, 999), (1000, 17), (70000, 65536), (4096, 0), (300, None), (1000, 63), (1000, 64), (257, 256), (256, 255), (65, 64), (300000, 1)])
 def test_poly_degree(env, n, deg):
     """Polynomial.degree (polynomial.js:165-172): index of the highest non-zero coefficient, 0 for the zero polynomial"""
     zkmi, plonk, f, cx = env
