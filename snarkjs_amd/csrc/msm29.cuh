@@ -16,6 +16,15 @@
 
 namespace zkmi {
 
+#if defined(ZK29_SHADOW)
+}  // namespace zkmi
+#include <map>
+namespace zkmi {
+namespace b29 {
+struct Parked { double bv, bl, bt; };
+inline std::map<const void*, Parked>& parked() { static std::map<const void*, Parked> m; return m; }
+}  // namespace b29
+#endif
 template <class C> struct Aff29 { Fp29<C> x, y; };
 template <class C> struct XYZZ29 { Fp29<C> X, Y, ZZ, ZZZ; };          // invariants: X <= 7.3, Y <= 3.3, ZZ, ZZZ <= 1.1; all normalised
 
@@ -337,8 +346,22 @@ template <class C, int T, bool PACK> struct LdsAcc29 {
 #pragma unroll
             for (int i = 0; i < NL; i++) v.l[i] = base[(slot * EW + i) * T];
         }
+#if defined(ZK29_SHADOW)
+        {   // the bounds a parked value was stored with travel beside the "LDS" array of the host test (keyed by the slot's first word)
+            auto it = b29::parked().find(&base[(size_t)slot * EW * T]);
+            b29::need(it != b29::parked().end(), "LdsAcc29: slot read before it was written", slot, 0);
+            if (it != b29::parked().end()) { v.bv = it->second.bv; v.bl = it->second.bl; v.bt = it->second.bt; }
+        }
+#endif
     }
     ZK_HD void put1(int slot, const Fp29<C>& v) const {
+#if defined(ZK29_SHADOW)
+        {
+            b29::need(b29::normalised(v), "LdsAcc29: a parked value is not normalised", v.bl, b29::lowmax<C>());
+            b29::Parked pk; pk.bv = v.bv; pk.bl = v.bl; pk.bt = v.bt;
+            b29::parked()[&base[(size_t)slot * EW * T]] = pk;
+        }
+#endif
         if constexpr (PACK) {
             uint32_t w[C::N];
             pack29<C>(w, v);
@@ -367,7 +390,12 @@ template <class C, int T, bool PACK> struct LdsAcc29 {
 #else
 #define ZK_SFENCE() ((void)0)
 #endif
-// acc += q over Fq2. Invariants (units of p, per component): X <= 8.4, Y <= 3.8, ZZ, ZZZ <= 1.1, all normalised. q.x canonical, q.y <= 2.
+// acc += q over Fq2. Invariants (units of p, per component): X <= 8.4, Y <= 3.8, ZZ <= 2.2, ZZZ <= 1.2, all normalised. q.x canonical, q.y <= 2.
+// (ZZ, ZZZ <= 1.1 on the main path; the doubling branch leaves ZZ = V — a square, whose c1 is a doubled product: up to 2.19 — and ZZZ = W as they
+// come. Nothing here ever NEGATES a component of ZZ or ZZZ, so the wider bound costs nothing; the bucket leaves through store_r256, canonical. The
+// reduction kernels' padd29_lds does negate them with offset 2 p: its operands are canonical words or results of padd29_lds / dbl29_lds, where ZZ and
+// ZZZ are products, <= 1.1. Both contracts are checked for the worst case by tests/test_field29_host.py::test_worst_case_bounds_of_the_point_formulas,
+// which found the difference.)
 template <class C, class Acc> ZK_HD void madd29_lds(const Acc& A, bool& inf, const F2x<C>& qx, const F2x<C>& qy) {
     F2x<C> t;
     if (inf) {

@@ -30,6 +30,10 @@ template <class C> ZK_HD void reduce29_small(Fp29<C>& v) {
     using L = Lim29<C>;
     constexpr int NL = L::NL, B = L::B;
     static_assert(NL == 9 && B == 29, "Fr form");
+#if defined(ZK29_SHADOW)
+    b29::need(b29::normalised(v) && v.bv <= 32.0, "reduce29_small: operand not normalised or not below 32 r", v.bv, 32.0);
+    b29::set(v, 1.0, b29::lowmax<C>(), -1.0);
+#endif
     // q' <= floor(v / r) <= q' + 2: floor(top limb / (top limb of r + 1)) by a 40-bit reciprocal
     constexpr uint64_t MAGIC = (1ull << 40) / ((uint64_t)L::p(NL - 1) + 1);
     const uint32_t q = (uint32_t)(((uint64_t)v.l[NL - 1] * MAGIC) >> 40);

@@ -58,6 +58,9 @@ template <class C> ZK_HD Fp29<C> load29_shl(const uint32_t* p) {
         if (wi + 1 < C::N) v |= (uint64_t)w[wi + 1] << 32;
         r.l[k] = (k == NL - 1) ? (uint32_t)(v >> sh) : ((uint32_t)(v >> sh) & mask29<C>());
     }
+#if defined(ZK29_SHADOW)
+    b29::set(r, ldexp(1.0, S), b29::lowmax<C>(), -1.0);          // canonical words times 2^S
+#endif
     return r;
 }
 

@@ -35,7 +35,7 @@ def tool():
     deps = [SRC] + [os.path.join(ROOT, "snarkjs_amd", "csrc", f) for f in ("field.cuh", "field29.cuh", "ntt29.cuh", "ntt.cuh", "plonk29.cuh", "mac_cols.inc")]
     if not os.path.exists(TOOL) or any(os.path.getmtime(d) > os.path.getmtime(TOOL) for d in deps):
         os.makedirs(os.path.dirname(TOOL), exist_ok=True)
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-DZK29_CHECK", "-I" + os.path.join(ROOT, "snarkjs_amd", "csrc"), SRC, "-o", TOOL])
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "--cuda-host-only", "-O0", "-std=c++17", "-DZK29_CHECK", "-DZK29_BOUNDS", "-I" + os.path.join(ROOT, "snarkjs_amd", "csrc"), SRC, "-o", TOOL])
     return TOOL
 
 

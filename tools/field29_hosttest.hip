@@ -3,7 +3,7 @@
 // GPU: this is how the unsaturated-limb code (9 x 29 bits, 14 x 28 bits) is verified before it is sent to one. Only the MAC differs between
 // the two compilations (inline v_mad_u64_u32 on the device, a 64-bit multiply-add here); limb bounds, offsets, carries and formulas are shared.
 //
-// build: hipcc --offload-arch=gfx950 -O1 -std=c++17 -Isnarkjs_amd/csrc tools/field29_hosttest.hip -o tools/bin/field29_hosttest
+// build: hipcc --offload-arch=gfx950 --cuda-host-only -O0 -std=c++17 -DZK29_CHECK [-DZK29_BOUNDS] -Isnarkjs_amd/csrc tools/field29_hosttest.hip -o tools/bin/field29_hosttest
 // protocol: one request per line "<op> <curve> <hex words...>", one reply line of hex words (or "ERR ...").
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,6 +23,31 @@ template <class C> static Fp29<C> rd(const std::vector<uint32_t>& v, size_t& at)
     return r;
 }
 template <class C> static void wr(std::vector<uint32_t>& o, const Fp29<C>& a) { for (int i = 0; i < Lim29<C>::NL; i++) o.push_back(a.l[i]); }
+
+// -DZK29_BOUNDS (field29.cuh): the harness states the CONTRACT of each function under test as worst-case bounds of its inputs and checks the bounds the
+// arithmetic derives for the outputs against the invariants the function promises; without the flag these do nothing
+#if defined(ZK29_SHADOW)
+template <class C> static void bound_in(Fp29<C>& x, double bv) { x.bv = bv; x.bl = b29::lowmax<C>(); x.bt = -1.0; }      // normalised, value <= bv p
+template <class C> static void bound_out(const Fp29<C>& x, double lim, const char* what) { b29::need(b29::normalised(x) && x.bv <= lim, what, x.bv, lim); }
+#else
+template <class C> static void bound_in(Fp29<C>&, double) {}
+template <class C> static void bound_out(const Fp29<C>&, double, const char*) {}
+#endif
+// invariants of the accumulators (units of p; msm29.cuh): G1 XYZZ; G2 XYZZ (LDS-parked) of the reduction kernels; the same in the accumulation kernel, whose
+// doubling branch leaves ZZ = V (a square: its c1 is a doubled product) and ZZZ = W as they come; G2 Jacobian (LDS-parked, 14-limb curve)
+static const double INV_G1[4] = {7.3, 3.3, 1.1, 1.1}, INV_G2[4] = {8.4, 3.8, 1.1, 1.1}, INV_G2A[4] = {8.4, 3.8, 2.2, 1.2}, INV_G2J[3] = {8.4, 3.8, 1.1};
+template <class C> static void bound_in(XYZZ29<C>& a) { bound_in(a.X, INV_G1[0]); bound_in(a.Y, INV_G1[1]); bound_in(a.ZZ, INV_G1[2]); bound_in(a.ZZZ, INV_G1[3]); }
+template <class C> static void bound_out(const XYZZ29<C>& a) {
+    bound_out(a.X, INV_G1[0], "G1 accumulator: X over its invariant"); bound_out(a.Y, INV_G1[1], "G1 accumulator: Y over its invariant");
+    bound_out(a.ZZ, INV_G1[2], "G1 accumulator: ZZ over its invariant"); bound_out(a.ZZZ, INV_G1[3], "G1 accumulator: ZZZ over its invariant");
+}
+// a parked Fq2 accumulator: every coordinate read, given its invariant as bound, written back / read and checked
+template <class C, class Acc> static void park_in(const Acc& A, int ncoord, const double* inv) {
+    for (int k = 0; k < ncoord; k++) { F2x<C> v; A.get(k, v); bound_in(v.c0, inv[k]); bound_in(v.c1, inv[k]); A.put(k, v); }
+}
+template <class C, class Acc> static void park_out(const Acc& A, int ncoord, const double* inv) {
+    for (int k = 0; k < ncoord; k++) { F2x<C> v; A.get(k, v); bound_out(v.c0, inv[k], "G2 accumulator: a coordinate over its invariant"); bound_out(v.c1, inv[k], "G2 accumulator: a coordinate over its invariant"); }
+}
 
 template <class C, int K> static Fp29<C> sub_k(const Fp29<C>& t, const Fp29<C>& b) { return sub29<C, K>(t, b); }
 template <class C> static bool sub_any(int K, const Fp29<C>& t, const Fp29<C>& b, Fp29<C>& r) {
@@ -64,8 +89,10 @@ template <class C> static std::string run(const std::string& op, const std::vect
         bool inf = v.at(at++) != 0;
         XYZZ29<C> acc;
         acc.X = rd<C>(v, at); acc.Y = rd<C>(v, at); acc.ZZ = rd<C>(v, at); acc.ZZZ = rd<C>(v, at);
-        if (op == "madd") { Aff29<C> q; q.x = rd<C>(v, at); q.y = rd<C>(v, at); madd29(acc, inf, q); }
-        else { XYZZ29<C> p; p.X = rd<C>(v, at); p.Y = rd<C>(v, at); p.ZZ = rd<C>(v, at); p.ZZZ = rd<C>(v, at); padd29(acc, inf, p); }
+        bound_in(acc);
+        if (op == "madd") { Aff29<C> q; q.x = rd<C>(v, at); q.y = rd<C>(v, at); bound_in(q.x, 1.0); bound_in(q.y, 2.0); madd29(acc, inf, q); }
+        else { XYZZ29<C> p; p.X = rd<C>(v, at); p.Y = rd<C>(v, at); p.ZZ = rd<C>(v, at); p.ZZZ = rd<C>(v, at); bound_in(p); padd29(acc, inf, p); }
+        if (!inf) bound_out(acc);
         o.push_back(inf ? 1u : 0u);
         wr(o, acc.X); wr(o, acc.Y); wr(o, acc.ZZ); wr(o, acc.ZZZ);
     }
@@ -96,9 +123,15 @@ template <class C> static std::string run(const std::string& op, const std::vect
             F2x<C> qx, qy;
             qx.c0 = rd<C>(v, at); qx.c1 = rd<C>(v, at); qy.c0 = rd<C>(v, at); qy.c1 = rd<C>(v, at);
             if (neg) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }
+            constexpr int NCO = Accum29G2<C>::JAC ? 3 : 4;
+            const double* inv = Accum29G2<C>::JAC ? INV_G2J : INV_G2A;
+            bound_in(qx.c0, 1.0); bound_in(qx.c1, 1.0); bound_in(qy.c0, 2.0); bound_in(qy.c1, 2.0);
+            if (!inf) park_in<C>(A, NCO, inv);
             Accum29G2<C>::madd(A, inf, qx, qy, [&](F2x<C>& x2, F2x<C>& y2) { x2 = qx; y2 = qy; });
+            if (!inf) park_out<C>(A, NCO, inv);
         }
         alignas(16) uint32_t w[8 * N];
+        if (!inf) park_in<C>(A, Accum29G2<C>::JAC ? 3 : 4, Accum29G2<C>::JAC ? INV_G2J : INV_G2A);
         Accum29G2<C>::template store<false>(w, A, inf);
         o.push_back(inf ? 1u : 0u);
         for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
@@ -123,15 +156,29 @@ template <class C> static std::string run(const std::string& op, const std::vect
                 F2x<C> qx, qy;
                 qx.c0 = rd<C>(v, at); qx.c1 = rd<C>(v, at); qy.c0 = rd<C>(v, at); qy.c1 = rd<C>(v, at);
                 if (neg) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }
+                bound_in(qx.c0, 1.0); bound_in(qx.c1, 1.0); bound_in(qy.c0, 2.0); bound_in(qy.c1, 2.0);
+                if (!inf) park_in<C>(A, Accum29G2<C>::JAC ? 3 : 4, Accum29G2<C>::JAC ? INV_G2J : INV_G2A);
                 Accum29G2<C>::madd(A, inf, qx, qy, [&](F2x<C>& x2, F2x<C>& y2) { x2 = qx; y2 = qy; });
             }
             alignas(16) uint32_t w[8 * N];
+            if (!inf) park_in<C>(A, Accum29G2<C>::JAC ? 3 : 4, Accum29G2<C>::JAC ? INV_G2J : INV_G2A);
             Accum29G2<C>::template store<true>(w, A, inf);
             if (!xyzz29_words_inf_g2<C>(w) != !inf) return "ERR infinity encoding";
-            if (!inf) padd29_lds<C>(Rr, rinf, [&](int k, F2x<C>& x) { x.c0 = load29_packed<C>(w + k * 2 * N); x.c1 = load29_packed<C>(w + k * 2 * N + N); });
+            if (!inf) {
+                if (!rinf) park_in<C>(Rr, 4, INV_G2);
+                padd29_lds<C>(Rr, rinf, [&](int k, F2x<C>& x) { x.c0 = load29_packed<C>(w + k * 2 * N); x.c1 = load29_packed<C>(w + k * 2 * N + N); });
+                if (!rinf) park_out<C>(Rr, 4, INV_G2);
+            }
         }
         for (int rep = 0; rep < 2; rep++)
-            if (!rinf) padd29_lds<C>(Dd, dinf, [&](int k, F2x<C>& x) { Rr.get(k, x); });
+            if (!rinf) {
+                park_in<C>(Rr, 4, INV_G2);                                   // the operand: any accumulator within the invariants
+                if (!dinf) park_in<C>(Dd, 4, INV_G2);
+                padd29_lds<C>(Dd, dinf, [&](int k, F2x<C>& x) { Rr.get(k, x); });
+                if (!dinf) park_out<C>(Dd, 4, INV_G2);
+            }
+        if (!rinf) park_in<C>(Rr, 4, INV_G2);
+        if (!dinf) park_in<C>(Dd, 4, INV_G2);
         alignas(16) uint32_t w[8 * N];
         store_xyzz29_lds<C, AccR, false>(w, Rr, rinf);
         o.push_back(rinf ? 1u : 0u);
@@ -160,10 +207,14 @@ template <class C> static std::string run(const std::string& op, const std::vect
             for (int l = 0; l < T; l++)
                 if ((l & (2 * d - 1)) == 0 && !inf[l + d]) {
                     const Acc A{lds.data() + l}, Pn{lds.data() + l + d};
+                    park_in<C>(Pn, 4, INV_G2);
+                    if (!inf[l]) park_in<C>(A, 4, INV_G2);
                     padd29_lds<C>(A, inf[l], [&](int k, F2x<C>& x) { Pn.get(k, x); });
+                    if (!inf[l]) park_out<C>(A, 4, INV_G2);
                 }
         alignas(16) uint32_t w[8 * N];
         const Acc A0{lds.data()};
+        if (!inf[0]) park_in<C>(A0, 4, INV_G2);
         store_xyzz29_lds<C, Acc, false>(w, A0, inf[0]);
         o.push_back(inf[0] ? 1u : 0u);
         for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
@@ -175,10 +226,22 @@ template <class C> static std::string run(const std::string& op, const std::vect
         if constexpr (Lim29<C>::NL == 9) {
             auto x = rd<C>(v, at), y = rd<C>(v, at), w = rd<C>(v, at);
             const bool has_w = v.at(at++) != 0;
+            // contract of a tile stage (ntt29.cuh): x and y lazy values of earlier stages (at most 1.3 r + 2 r per stage before them: 17.3 r ahead of the
+            // ninth and last), the twiddle canonical; without a twiddle (first stage) y is a fresh product or canonical (1.3 r)
+            bound_in(x, 17.3); bound_in(y, has_w ? 17.3 : 1.3); bound_in(w, 1.0);
             if (has_w) y = mul29(y, w);
             ntt29_bfly(x, y, Fp29<C>(y));
+            bound_out(x, 19.3, "NTT butterfly: x over 19.3 r"); bound_out(y, 19.3, "NTT butterfly: y over 19.3 r");
+            { Fp29<C> z = x; reduce29_small(z); }          // what the last pass does with it: the range of the final reduction
             wr(o, x); wr(o, y);
         } else return "ERR form";
+    }
+    else if (op == "bounds") {              // violations recorded so far by the worst-case tracking (-DZK29_BOUNDS builds), log2 of the largest column x 1000
+#if defined(ZK29_SHADOW)
+        o.push_back((uint32_t)b29::failures()); o.push_back((uint32_t)(b29::max_column() > 0 ? log2(b29::max_column()) * 1000.0 : 0.0)); o.push_back(1u);
+#else
+        o.push_back(0u); o.push_back(0u); o.push_back(0u);
+#endif
     }
     else if (op == "consts") {
         o.push_back(NL); o.push_back(Lim29<C>::B); o.push_back(N); o.push_back(Lim29<C>::NP); o.push_back(Lim29<C>::PINV);

@@ -6,7 +6,7 @@
 //                                                      of r, limb bound, normalised?) and every precondition of field29.cuh is checked for the WORST case —
 //                                                      operand limbs of the products, column sums below 2^64, offsets, ranges of the final reductions.
 // The build container has no GPU; only the multiply-add differs between this compilation and the device's.
-// build: hipcc --offload-arch=gfx950 -O1 -std=c++17 -DZK29_CHECK -Isnarkjs_amd/csrc tools/plonk29_hosttest.hip -o tools/bin/plonk29_hosttest
+// build: hipcc --offload-arch=gfx950 --cuda-host-only -O0 -std=c++17 -DZK29_CHECK [-DZK29_BOUNDS] -Isnarkjs_amd/csrc tools/plonk29_hosttest.hip -o tools/bin/plonk29_hosttest
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -141,6 +141,10 @@ template <class C> static int run_points(const char* in_path, const char* out_pa
     if (!f) { perror(out_path); return 2; }
     fwrite(g.t, 32, n4, f); fwrite(g.tz, 32, n4, f);
     fclose(f);
+#if defined(ZK29_SHADOW)
+    // -DZK29_BOUNDS: the arithmetic itself carried worst-case bounds through every primitive (field29.cuh): a second, independent check of what `bounds` models
+    if (b29::failures()) { fprintf(stderr, "%d precondition(s) violated in the worst case\n", b29::failures()); return 3; }
+#endif
     return 0;
 }
 
