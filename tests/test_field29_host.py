@@ -550,4 +550,13 @@ def test_worst_case_bounds_of_the_point_formulas(tool_bounds, curve):
 @pytest.mark.parametrize("curve", FR_CURVES)
 def test_worst_case_bounds_of_the_ntt_butterfly(tool_bounds, curve):
     test_ntt_butterfly_and_final_reduction(tool_bounds, curve)
+    # what a pass does to an element before its first stage: the record of the pass before (any lazy value) times the pass twiddle (a product of two table
+    # entries), the caller's row factor and 1/n — and the 1.3 r the first stage's contract starts from
+    F = Form(curve)
+    rng = random.Random(7)
+    r = F.p
+    for _ in range(10):
+        x, a, b, c, d = rng.randrange(19 * r), rng.randrange(r), rng.randrange(r), rng.randrange(r), rng.randrange(r)
+        out = tool_bounds("nttin", curve, F.limbs(x) + F.to29(a) + F.to29(b) + F.to29(c) + F.to29(d))
+        assert F.value(out) % r == x * a * b * c * d % r and F.normalised(out) and F.value(out) < 1.3 * r
     _no_violations(tool_bounds, curve)

@@ -236,6 +236,18 @@ template <class C> static std::string run(const std::string& op, const std::vect
             wr(o, x); wr(o, y);
         } else return "ERR form";
     }
+    else if (op == "nttin") {               // in: x (a record of an earlier pass), t_lo, t_hi, rowinc, scale (R'-form constants); out: the tile element a pass starts from
+        if constexpr (Lim29<C>::NL == 9) {
+            auto x = rd<C>(v, at), tlo = rd<C>(v, at), thi = rd<C>(v, at), inc = rd<C>(v, at), sc = rd<C>(v, at);
+            // contract (ntt29.cuh: k_ntt29_pass_strided / _last): x any lazy value a pass can leave (19.3 r), the table entries canonical
+            bound_in(x, 19.3); bound_in(tlo, 1.0); bound_in(thi, 1.0); bound_in(inc, 1.0); bound_in(sc, 1.0);
+            x = mul29(x, mul29(tlo, thi));                 // ntt29_pow
+            x = mul29(x, inc);
+            x = mul29(x, sc);
+            bound_out(x, 1.3, "NTT tile element: over the 1.3 r the first stage assumes");
+            wr(o, x);
+        } else return "ERR form";
+    }
     else if (op == "bounds") {              // violations recorded so far by the worst-case tracking (-DZK29_BOUNDS builds), log2 of the largest column x 1000
 #if defined(ZK29_SHADOW)
         o.push_back((uint32_t)b29::failures()); o.push_back((uint32_t)(b29::max_column() > 0 ? log2(b29::max_column()) * 1000.0 : 0.0)); o.push_back(1u);
