@@ -567,6 +567,7 @@ template <class C> struct PlonkOps {
         kv[PK_Z3 + 1] = Fh.add(two, Fh.mul(two, w2)); kv[PK_Z3 + 2] = Fh.neg(Fh.from_u64(8)); kv[PK_Z3 + 3] = Fh.sub(two, Fh.mul(two, w2));
         // the 29-bit kernels read every constant in R'-form as well (x 2^261 = 32 x in R-form): second half of the block
         const HE k32 = Fh.from_u64(32);
+        static_assert(2 * PK_COUNT * 32 <= SLOT_BYTES, "both forms of the constants block share one ring slot");
         kv.resize(2 * PK_COUNT, Fh.zero());
         for (int j = 0; j < PK_COUNT; j++) kv[PK_COUNT + j] = Fh.mul(kv[j], k32);
         uint32_t* dk;
