@@ -590,9 +590,11 @@ template <class C> struct PlonkOps {
         // Default (r04): the 29-bit-limb kernels of plonk29.cuh with the products inlined — 41 - 52 KB per part, inside the instruction cache, 0.66 + 0.75 +
         // 0.80 ms at 2^20 with two proofs in flight against 0.96 + 1.27 + 1.30 ms for the 32-bit kernels below (same box, same run: 39.5 / 39.9 against
         // 37.9 / 38.4 proofs/s; with the products behind calls 36.8: the operands of the three- and four-product sums travel through the stack).
-        // ZKMI_PLONK_T29: 1 = that, 2 = products behind calls (also chosen by an explicit ZKMI_COMPACT_CODE mask with bit 4), 0 = the 32-bit-limb kernels
+        // ZKMI_PLONK_T29: 1 = that, 2 = products behind calls, 0 = the 32-bit-limb kernels (products called; also chosen by bit 4 of the ZKMI_COMPACT_CODE mask or of the box probe)
         const char* t29_env = getenv("ZKMI_PLONK_T29");                 // read per call (once per proof): the tests switch it
-        const int t29 = t29_env ? atoi(t29_env) : ((getenv("ZKMI_COMPACT_CODE") && (compact_code() & 16)) ? 2 : 1);
+        // no variable: the inlined 29-bit kernels, except on a box whose instruction fetch beyond the cache the library's probe found slow (compact_code():
+        // all bits set) — they were never measured on such a box, the called 32-bit kernels below were (r03: same speed there as on a healthy one)
+        const int t29 = t29_env ? atoi(t29_env) : ((compact_code() & 16) ? 0 : 1);
         if (t29 == 1) {
             hipLaunchKernelGGL((k_plonk_t29<C, 0>), grid, dim3(256), 0, cx.stream, g, w4);
             hipLaunchKernelGGL((k_plonk_t29<C, 1>), grid, dim3(256), 0, cx.stream, g, w4);
