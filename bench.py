@@ -129,6 +129,71 @@ def reference_wasm_baseline():
             "note": "snarkjs groth16.prove of the reference bundle (WASM + worker threads) on the bench's own synthetic key recipe; the 2^20 figure is MEASURED (r04: one proof takes about a minute on the container's 8 threads), nothing here is extrapolated"}
 
 
+def _ref_bundle():
+    """the reference's bundle where a box has it: the staged copy oracle/_ref (make -C oracle _ref; git-ignored, shipped by gpurun), else /root/reference"""
+    for p in (os.path.join(ROOT, "oracle", "_ref", "build", "snarkjs.min.js"), "/root/reference/build/snarkjs.min.js"):
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def reference_wasm_same_box(proto, cases, curve="bn128", budget_s=200.0, warm=None):
+    """The REFERENCE's own prover (snarkjs bundle: WASM + worker threads) on THIS box's host cores, after the timed region, rank 0 only
+    (tools/ref_wasm_same_box.js; test / measurement infrastructure, never the product path). `cases` = [(log_n, zkey, wtns, draws_mont, device_proof_json)],
+    smallest first; a case is run only while the remaining budget covers ~5x the previous one (a 2^20 Groth16 proof takes the reference 10 - 60 s
+    depending on the host). The proof the reference emits for the same blinding draws must be the device's proof, byte for byte (`bit_identical`)."""
+    import hashlib
+    import shutil
+    import subprocess
+    import tempfile
+    node, bundle = shutil.which("node"), _ref_bundle()
+    if node is None or bundle is None:
+        return {"skipped": "node or the reference bundle (oracle/_ref: `make -C oracle _ref` in the build container) is missing on this box"}
+    threads = min(os.cpu_count() or 1, 64)                       # ffjavascript's own cap (threadman: concurrency > 64 -> 64)
+    runs, t_start, last = [], time.perf_counter(), None
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=base) as td:
+        warm_args = []
+        if warm is not None:
+            open(os.path.join(td, "w.zkey"), "wb").write(warm[0])
+            open(os.path.join(td, "w.wtns"), "wb").write(warm[1])
+            warm_args = [os.path.join(td, "w.zkey"), os.path.join(td, "w.wtns")]
+        for lg, zkey, wtns, draws, dev_json in cases:
+            left = budget_s - (time.perf_counter() - t_start)
+            if last is not None and last * 5.5 > left:
+                runs.append({"log_n": lg, "skipped": f"budget: the previous size took {last:.1f} s, {left:.0f} s left of {budget_s:.0f}"})
+                continue
+            zf, wf = os.path.join(td, "k.zkey"), os.path.join(td, "k.wtns")
+            open(zf, "wb").write(zkey)
+            open(wf, "wb").write(wtns)
+            env = dict(os.environ, NTHREADS=str(threads), SNARKJS_REF_BUNDLE=bundle, CURVE=curve)
+            env.pop("SINGLE", None)
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run([node, "--harmony-optional-chaining", "--harmony-nullish", "--max-old-space-size=24000", os.path.join(ROOT, "tools", "ref_wasm_same_box.js"),
+                                    proto, zf, wf, ",".join(bytes(d).hex() for d in draws)] + warm_args, capture_output=True, text=True, env=env, timeout=max(30.0, left))
+            except subprocess.TimeoutExpired:
+                runs.append({"log_n": lg, "error": f"timed out after {left:.0f} s"})
+                break
+            last = time.perf_counter() - t0
+            if r.returncode != 0:
+                runs.append({"log_n": lg, "error": (r.stderr or r.stdout)[-300:]})
+                break
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            run = {"log_n": lg, "threads": d["threads"], "ms_per_proof": round(d["ms"], 1), "proofs_per_s": round(1e3 / d["ms"], 5), "warmup_proof_ms": round(d.get("warm_ms", 0.0), 1),
+                   "process_wall_s": round(last, 1)}
+            if dev_json is not None:
+                run["bit_identical_to_device_proof"] = bool(hashlib.sha256(dev_json.encode()).hexdigest() == d["proof_json_sha256"])
+            runs.append(run)
+            host = {"cpus": d["cpus"], "model": d["cpu_model"], "node": d["node"]}
+    done = [x for x in runs if "ms_per_proof" in x]
+    if not done:
+        return {"runs": runs}
+    return {"where": f"THIS box: {host['cpus']} host cpus ({host['model']}), Node {host['node']}, {done[0]['threads']} worker threads (ffjavascript caps at 64)",
+            "what": f"snarkjs {proto}.prove of the reference bundle (oracle/_ref) on the bench's own key, files in memory, one small untimed proof first (worker start, WASM tier-up), then ONE timed proof per size",
+            "runs": runs, "at_bench_size": next((x for x in done if x["log_n"] == cases[-1][0]), None)}
+
+
 def reference_wasm_baseline_plonk(proto, lg):
     """The reference's own plonk.prove / fflonk.prove (WASM + worker threads), measured in the BUILD container and committed under profiles/.
     Sizes are PLONK DOMAINS (what --log-n means here). PLONK: r04 measured domains 2^11 and 2^16 (and 2^20 when the long run finished) on keys from
@@ -174,6 +239,7 @@ def cpu_baseline(args, zkey, wtns, log_n_full):
     from snarkjs_amd.workloads import synth_zkey
     threads = O.threads()
     lg = args.cpu_log_n if args.cpu_log_n else (log_n_full if threads >= 16 else min(18, log_n_full))
+    zkey_full, wtns_full = zkey, wtns
     if lg != log_n_full:
         zkey, wtns = synth_zkey.make("bn128", lg, seed=0xBA5E, witness="uniform", b_zero_every=args.b_zero_every)
     zk, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)["witness"]
@@ -182,10 +248,22 @@ def cpu_baseline(args, zkey, wtns, log_n_full):
     ref = O.groth16_prove(0, zk, w, r_m, s_m)
     dt = time.perf_counter() - t0
     scale = 1 << (log_n_full - lg)
+    ref_wasm = reference_wasm_baseline() or {}
+    if not args.no_ref_wasm:
+        # the reference itself on this box's host cores: 2^18 and the bench size, its proof for the same (r, s) compared with the device's
+        from snarkjs_amd import groth16 as G
+        cases = []
+        for l2 in sorted({min(18, log_n_full), log_n_full}):
+            zk2, wt2 = (zkey_full, wtns_full) if l2 == log_n_full else synth_zkey.make("bn128", l2, seed=0xBA5E, witness="uniform", b_zero_every=args.b_zero_every)
+            pk2 = G.ProvingKey(zk2)
+            dev = G.proof_to_json(G.raw_to_proof(pk2, *pk2.prove_raw(binfile.read_wtns(wt2)["witness"], r_m, s_m)))
+            pk2.release()
+            cases.append((l2, zk2, wt2, [r_m, s_m], dev))
+        ref_wasm["same_box"] = reference_wasm_same_box("groth16", cases, warm=synth_zkey.make("bn128", min(14, log_n_full), seed=0xBA5E, witness="uniform"), budget_s=args.ref_wasm_budget)
     base = {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": threads, "kind": "port",
             "sample": f"one full Groth16 proof at 2^{lg} constraints by oracle/zk_oracle.c ({threads} OpenMP threads, {dt:.1f} s wall)"
                       + (f", scaled linearly x{scale} to 2^{log_n_full} (optimistic: NTT is n log n)" if scale > 1 else ", no scaling"),
-            "reference_wasm": reference_wasm_baseline()}
+            "reference_wasm": ref_wasm}
     return base, (zkey, wtns, ref, r_m, s_m)
 
 
@@ -442,6 +520,8 @@ def main():
     ap.add_argument("--no-napi-wall", action="store_true")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2], help="proofs in flight per GPU (2: the tail of proof k overlaps the front of proof k+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-wasm", action="store_true", help="skip the reference's own WASM prover on this box's host cores (cpu_baseline.reference_wasm.same_box)")
+    ap.add_argument("--ref-wasm-budget", type=float, default=200.0, help="seconds the same-box WASM leg may take; a size is skipped when ~5x the previous one does not fit")
     ap.add_argument("--witness", default="uniform", choices=["uniform", "mixed"])
     ap.add_argument("--curve", default="bn128", choices=["bn128", "bls12381"])
     ap.add_argument("--configs2-log-n", type=int, default=24, help="multi-rank runs only: size of the one-proof-over-all-ranks extra of BASELINE configs[2] (0 = skip)")

@@ -102,7 +102,7 @@ async function record(tag, curve, files, run) {
     {   // setup side: a power-8 ceremony (new -> contribute -> preparePhase2), then plonk.setup and groth16 zKey.newZKey of the reference's
         // small PLONK test circuit over it (src/powersoftau_*.js, src/plonk_setup.js:323-403, src/zkey_new.js)
         const mem = () => ({ type: 'mem' });
-        const r1cs = new Uint8Array(fs.readFileSync('/root/reference/test/plonk_circuit/circuit.r1cs'));
+        const r1cs = new Uint8Array(fs.readFileSync(path.join(snarkjs.refRoot, 'test/plonk_circuit/circuit.r1cs')));
         const r = await record('setup_bn128_p8', curve, {}, async () => {
             const p0 = mem(), p1 = mem(), pf = mem(), zp = mem(), zg = mem();
             await snarkjs.powersOfTau.newAccumulator(curve, 8, p0);

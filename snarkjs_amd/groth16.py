@@ -158,16 +158,21 @@ def prove(zkey, witness_file, logger=None, options=None, r_mont=None, s_mont=Non
         raise ValueError(f"Invalid witness length. Circuit: {zk['nVars']}, witness: {wt['nWitness']}")   # :45-47
     r = r_mont if r_mont is not None else _fr_random_mont(pk.curve_id)
     s = s_mont if s_mont is not None else _fr_random_mont(pk.curve_id)
-    pi_a, pi_b, pi_c = pk.prove_raw(wt["witness"], r, s)
-    n8q = zk["n8q"]
-    to_le = lambda vals: b"".join(int(v).to_bytes(n8q, "little") for v in vals)
-    proof, _ = binfile.proof_json(pk.curve_name, n8q, to_le(_from_mont_q(pk.curve_id, pi_a)), to_le(_from_mont_q(pk.curve_id, pi_b)),
-                                  to_le(_from_mont_q(pk.curve_id, pi_c)))
+    proof = raw_to_proof(pk, *pk.prove_raw(wt["witness"], r, s))
     w = wt["witness"]
     public = [str(int.from_bytes(bytes(w[i * 32:(i + 1) * 32]), "little")) for i in range(1, zk["nPublic"] + 1)]   # :123-128
     if not isinstance(zkey, ProvingKey):
         pk.release()
     return {"proof": proof, "publicSignals": public}
+
+
+def raw_to_proof(pk, pi_a, pi_b, pi_c):
+    """(pi_a, pi_b, pi_c) affine Montgomery bytes -> the reference's proof object (src/groth16_prove.js:130-141)"""
+    n8q = pk.zk["n8q"]
+    to_le = lambda vals: b"".join(int(v).to_bytes(n8q, "little") for v in vals)
+    proof, _ = binfile.proof_json(pk.curve_name, n8q, to_le(_from_mont_q(pk.curve_id, pi_a)), to_le(_from_mont_q(pk.curve_id, pi_b)),
+                                  to_le(_from_mont_q(pk.curve_id, pi_c)))
+    return proof
 
 
 def proof_to_json(proof):

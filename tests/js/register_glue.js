@@ -1,5 +1,5 @@
 // tests/js/register_glue.js — CPU-only check of snarkjs_amd/js/register.js against the REAL reference bundle.
-// Needs /root/reference (build container only).  The HIP addon is replaced by a MOCK whose entry points call the
+// Needs the reference bundle (/root/reference in the build container, or the staged oracle/_ref/).  The HIP addon is replaced by a MOCK whose entry points call the
 // reference's own (saved) WASM functions, so what is tested is exactly the glue: which calls snarkjs makes through the
 // patched surface, container types (Uint8Array vs BigBuffer), argument conventions and that a seeded groth16 /
 // plonk proof through the patched curve is byte-identical to the unpatched one.
@@ -97,7 +97,7 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
           calls.msm1 === 4 && calls.msm2 === 1 && calls.ifft === 3 && calls.fft === 3 && calls.applyKey === 3);
 
     // 3. PLONK through the patched surface still verifies (exercises batchToMontgomery / FromMontgomery / Inverse + BigBuffer ffts)
-    const pz = "/root/reference/test/circuit2/circuit.zkey", pw = "/root/reference/test/circuit2/witness.wtns";
+    const pz = path.join(snarkjs.refRoot, "test/circuit2/circuit.zkey"), pw = path.join(snarkjs.refRoot, "test/circuit2/witness.wtns");
     if (fs.existsSync(pz)) {
         for (const k of Object.keys(calls)) delete calls[k];
         const zk = new Uint8Array(fs.readFileSync(pz)), wt = new Uint8Array(fs.readFileSync(pw));
@@ -109,7 +109,7 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
     // 4. setup-side callers (SURVEY.md 8 f3): plonk.setup / fflonk.setup reach the bulk ops through the same patched methods
     //    (src/plonk_setup.js:322-330,395-403; src/fflonk_setup.js via Polynomial.to4T / multiExponentiation) — the zkey written
     //    through the patched surface must equal the unpatched one byte for byte. A small seeded ptau is made with the originals.
-    const r1cs = "/root/reference/test/plonk_circuit/circuit.r1cs";
+    const r1cs = path.join(snarkjs.refRoot, "test/plonk_circuit/circuit.r1cs");
     if (fs.existsSync(r1cs)) {
         const mem = () => ({ type: "mem" });
         const mkPtau = async () => { const p0 = mem(), p1 = mem(), pf = mem(); await snarkjs.powersOfTau.newAccumulator(curve, 7, p0); await snarkjs.powersOfTau.contribute(p0, p1, "C1", "Entropy1"); await snarkjs.powersOfTau.preparePhase2(p1, pf); return pf; };

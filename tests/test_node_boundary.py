@@ -8,12 +8,16 @@
 import os
 import shutil
 import subprocess
+import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ADDON = os.path.join(ROOT, "snarkjs_amd", "napi", "zkmi_napi.node")
 NODE = shutil.which("node")
+# the reference's bundle: /root/reference in the build container, or its staged copy oracle/_ref/ (make -C oracle _ref; git-ignored, travels with gpurun)
+BUNDLE = next((p for p in (os.path.join(ROOT, "oracle", "_ref", "build", "snarkjs.min.js"), "/root/reference/build/snarkjs.min.js") if os.path.exists(p)), None)
+need_bundle = pytest.mark.skipif(BUNDLE is None, reason="reference bundle not present: run `make -C oracle _ref` where /root/reference exists")
 need_node = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON), reason="node or the built addon is missing")
 FLAGS = ["--harmony-optional-chaining", "--harmony-nullish"]
 
@@ -29,14 +33,14 @@ def test_addon_exports_and_no_silent_fallback():
 
 
 @need_node
-@pytest.mark.skipif(not os.path.exists("/root/reference/build/snarkjs.min.js"), reason="reference bundle not present (GPU box)")
+@need_bundle
 def test_register_glue_against_reference_bundle():
     r = subprocess.run([NODE] + FLAGS + [os.path.join(ROOT, "tests", "js", "register_glue.js")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @need_node
-@pytest.mark.skipif(not os.path.exists("/root/reference/build/snarkjs.min.js"), reason="reference bundle not present (GPU box)")
+@need_bundle
 def test_make_prover_against_reference_bundle():
     """js/groth16_native.js (makeProver: parsing, key life cycle, throughput-mode order) with the real bundle as `snarkjs` and a
     reference-backed stand-in for the addon (tests/js/ref_backend.js)"""
@@ -45,7 +49,7 @@ def test_make_prover_against_reference_bundle():
 
 
 @need_node
-@pytest.mark.skipif(not os.path.exists("/root/reference/build/snarkjs.min.js"), reason="reference bundle not present (GPU box)")
+@need_bundle
 def test_node_shard_driver_processes_on_cpu():
     """js/groth16_shards.js: 2 and 3 worker PROCESSES, the exchange through POSIX shared memory mapped by the real addon, the arithmetic by the
     reference's own curve: the sharded proof equals the reference's proof and the protocol runs in the overlapped order"""
@@ -77,6 +81,30 @@ def test_addon_checked_call_table():
           "console.log('ok')") % ADDON
     r = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@need_node
+@need_bundle
+def test_unmodified_flow_with_mock_addon():
+    """tests/js/unmodified_gpu.js with a stand-in for the addon (the reference's own WASM behind the addon's entry points): the logic of the
+    patched-vs-unpatched comparison itself, on a GPU-less box"""
+    r = subprocess.run([NODE] + FLAGS + [os.path.join(ROOT, "tests", "js", "unmodified_gpu.js")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, ZKMI_MOCK_ADDON="1"))
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@need_node
+def test_unmodified_snarkjs_with_real_addon_on_gpu():
+    """UNMODIFIED snarkjs (the reference's bundle from oracle/_ref) + register.js + the REAL addon in one process: groth16 / plonk / fflonk prove and
+    fullProve on both curves, a power-8 ceremony and the three setups, each patched and unpatched with the same draws: proofs and key bytes
+    identical, the reference's verifier accepts (north_star: "run unmodified and emit proofs bit-identical to the WASM path")."""
+    if BUNDLE is None:
+        pytest.fail("oracle/_ref is absent on this box: `make -C oracle _ref` (or __graft_entry__.build()) stages it in the build container and gpurun ships it; "
+                    "without it the unmodified-snarkjs claim is unchecked")
+    r = subprocess.run([NODE] + FLAGS + [os.path.join(ROOT, "tests", "js", "unmodified_gpu.js")], capture_output=True, text=True, timeout=1500)
+    sys.stdout.write(r.stdout[-6000:])
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu
