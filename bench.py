@@ -289,16 +289,17 @@ def napi_wall(zkey, wtns, reps=5):
 def bench_plonk(args, rank, world, dist, torch):
     """BASELINE configs[3]: BN254 PLONK prove at 2^log_n constraints on a synthetic VALID key (snarkjs_amd/workloads/synth_plonk.py); one proof
     stream per GPU. Key and witness are resident in HBM when the timed region starts (PlonkWitness; the figure with the 32 MB witness parsed and
-    uploaded per proof, as the reference reads it from a file, is reported beside: latency_ms_with_witness_upload)."""
+    uploaded per proof, as the reference reads it from a file, is reported beside: latency_ms_with_witness_upload). The circuit has addition gates
+    (--plonk-additions per multiplication gate): the internal signals are per-proof work and are computed on the device inside every timed proof."""
     from snarkjs_amd.workloads import synth_plonk
     from snarkjs_amd import fflonk, plonk, zkmi
     lg = args.log_n
     proto = args.workload
     if proto == "fflonk":               # not a BASELINE config; same kernels, MSMs over 8n / 16n coefficients (SURVEY.md 2 row 5)
-        zkey, wtns = synth_plonk.make_fflonk(lg, seed=3 + rank)
+        zkey, wtns = synth_plonk.make_fflonk(lg, seed=3 + rank, additions=args.plonk_additions)
         key, plonk = fflonk.FflonkKey(zkey), fflonk
     else:
-        zkey, wtns = synth_plonk.make("bn128", lg, seed=3 + rank)
+        zkey, wtns = synth_plonk.make("bn128", lg, seed=3 + rank, additions=args.plonk_additions)
         key = plonk.PlonkKey(zkey)
     wtns_host = wtns
     if hasattr(plonk, "PlonkWitness"):
@@ -359,7 +360,9 @@ def bench_plonk(args, rank, world, dist, torch):
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"BN254 {proto.upper()} prove, 2^{lg} constraints, synthetic valid key" + (" (BASELINE configs[3])" if proto == "plonk" else "") + "; key " + ("and witness resident" if wtns is not wtns_host else "resident, witness uploaded per proof"),
-                       "curve": "bn128", "log_n": lg, "parallelism": f"replica x{world}"},
+                       "curve": "bn128", "log_n": lg, "n_constraints": int(key.nConstraints), "n_additions": int(key.nAdditions),
+                       "additions": f"{args.plonk_additions} addition gate(s) per multiplication gate, internal signals in chains of that depth (plonk_setup.js reduceCoefs on an `x^2 + b` circuit gives 1); calculateAdditions (plonk_prove.js:174-204) runs on the device INSIDE every timed proof",
+                       "parallelism": f"replica x{world}"},
             "roofline": roof,
             "proofs_in_flight": 2 if two else 1, "host_gc": "Python's cyclic collector is off inside the timed region (timeit's convention)", "latency_ms_single_proof": round(min(lat) * 1e3, 3) if lat else None, "latency_ms_serial_proofs": [round(x * 1e3, 2) for x in lat], "timed_region_ms_per_proof": [round(x * 1e3, 2) for x in per_proof],
             "latency_ms_with_witness_upload": [round(x * 1e3, 2) for x in lat_up],
@@ -525,6 +528,7 @@ def main():
     ap.add_argument("--witness", default="uniform", choices=["uniform", "mixed"])
     ap.add_argument("--curve", default="bn128", choices=["bn128", "bls12381"])
     ap.add_argument("--configs2-log-n", type=int, default=24, help="multi-rank runs only: size of the one-proof-over-all-ranks extra of BASELINE configs[2] (0 = skip)")
+    ap.add_argument("--plonk-additions", type=int, default=1, help="PLONK / FFLONK workloads: addition gates (and internal signals) per multiplication gate of the synthetic circuit; 0 = none")
     ap.add_argument("--workload", default="groth16", choices=["groth16", "plonk", "fflonk"], help="plonk = BASELINE configs[3] (not the default metric)")
     args = ap.parse_args()
     relaunch_if_needed(args)

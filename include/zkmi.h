@@ -235,6 +235,13 @@ int zkmi_fr_root(int curve, unsigned i, uint8_t* out32);
 int zkmi_plonk_gather_wires_dev(int curve, const void* d_witness, uint32_t n_witness, const void* d_internal, uint32_t n_additions,
                                 const void* d_map_a, const void* d_map_b, const void* d_map_c, uint32_t n_constraints, uint32_t domain,
                                 void* d_a, void* d_b, void* d_c);
+/* calculateAdditions (src/plonk_prove.js:174-204, src/fflonk_prove.js:269-300): the internal signals of a PLONK / FFLONK key,
+ *   internal[i] = factor1_i * getWitness(id1_i) + factor2_i * getWitness(id2_i),   getWitness as in :207-215 (n_vars = n_witness + n_additions),
+ * computed on the device in ONE launch although an addition may read internal signals created before it (a dependency DAG; chains of any
+ * depth). d_additions: the zkey's additions section as it lies in the file (n_additions records of 72 bytes: u32 id1, u32 id2, factor1,
+ * factor2 in Montgomery form). d_witness as for zkmi_plonk_gather_wires_dev. d_internal: n_additions elements, normal form (the
+ * reference's buffInternalWitness). Stream-ordered: returns once enqueued. */
+int zkmi_plonk_additions_dev(int curve, const void* d_additions, uint32_t n_additions, const void* d_witness, uint32_t n_witness, void* d_internal);
 /* computeZ (plonk_prove.js:361-455): grand-product evaluations Z[0..domain) from the wire buffers (Montgomery) and the 4n
  * sigma evaluations (sampled at stride 4). Fails with "Copy constraints does not match" if Z[0] != 1. w_n = Fr.w[power]. */
 int zkmi_plonk_compute_z_dev(int curve, const void* d_a, const void* d_b, const void* d_c, const void* d_s1e, const void* d_s2e,

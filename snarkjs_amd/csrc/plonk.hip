@@ -157,6 +157,70 @@ template <class C> __global__ void k_plonk_gather(const uint32_t* __restrict__ w
     }
 }
 
+// ---- calculateAdditions (plonk_prove.js:174-204, fflonk_prove.js:269-300) -------------------------------------------------------------------
+// internal[i] = factor1_i * getWitness(id1_i) + factor2_i * getWitness(id2_i), i = 0 .. nAdditions-1, in index order in the reference: an
+// operand may be an internal signal created EARLIER (id - nWitness < i), so the loop is a dependency DAG — chains as deep as the longest linear
+// combination plonk_setup.js:180-210 folded pairwise. One launch computes all of it: a lane owns addition i and polls a ready flag per
+// internal operand; blocks take a ticket when they START, so a lane only ever waits for lanes of blocks that started before its own (resident
+// or finished: forward progress without assuming an order of block dispatch). The poll loop's condition is WAVE-uniform (ballot) and the
+// result is published INSIDE the loop: a lane that published keeps iterating, masked, until its whole wave is done — with a per-lane exit
+// the compiler may sink the publish behind the loop's reconvergence point, where it waits for the very lanes that wait for it.
+// Factors are Montgomery, signals normal form: the Montgomery product of the two is the normal-form product, as in the reference
+// (Fr.mul(factor, witness) on the zkey's bytes). Records are 72 bytes (u32 id1, u32 id2, 2 x 32): word loads. An operand id at or beyond
+// the addition's own slot reads what the reference reads there — its zero-initialised buffer, i.e. 0 — and ids >= nVars read Fr.zero (:213).
+template <class C> ZK_DEV Fp<C> fp_load_words(const uint32_t* p) {
+    Fp<C> a;
+#pragma unroll
+    for (int k = 0; k < C::N; k++) a.l[k] = p[k];
+    return a;
+}
+template <class C> __global__ void __launch_bounds__(256)
+k_plonk_additions(const uint32_t* __restrict__ rec, uint32_t n_add, const uint32_t* __restrict__ wit, uint32_t n_wit, uint32_t* internal, uint32_t* flags, uint32_t* ticket) {
+    __shared__ uint32_t bid_s;
+    if (threadIdx.x == 0) bid_s = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t i = bid_s * 256u + threadIdx.x;
+    const bool active = i < n_add;
+    Fp<C> f[2], w[2];
+    bool ready[2] = {true, true};
+    uint32_t dep[2] = {0, 0};
+    if (active) {
+        const uint32_t* r = rec + (size_t)i * 18;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t id = r[k];
+            f[k] = fp_load_words<C>(r + 2 + 8 * k);
+            w[k] = fp_zero<C>();
+            if (id < n_wit) w[k] = fp_load<C>(wit + (size_t)id * 8);
+            else if (id - n_wit < i) { ready[k] = false; dep[k] = id - n_wit; }       // an earlier internal signal: wait for it
+        }
+    }
+    bool done = !active;
+    while (__ballot(!done) != 0ull) {
+        bool progressed = false;
+        if (!done) {
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                if (!ready[k] && __hip_atomic_load(flags + dep[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    const uint32_t* src = internal + (size_t)dep[k] * 8;
+#pragma unroll
+                    for (int j = 0; j < C::N; j++) w[k].l[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ready[k] = true;
+                }
+            if (ready[0] && ready[1]) {
+                const Fp<C> v = fp_add(fp_mul(f[0], w[0]), fp_mul(f[1], w[1]));
+                uint32_t* dst = internal + (size_t)i * 8;
+#pragma unroll
+                for (int j = 0; j < C::N; j++) __hip_atomic_store(dst + j, v.l[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(flags + i, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                done = true;
+                progressed = true;
+            }
+        }
+        if (__ballot(progressed) == 0ull) __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 // ---- computeZ -------------------------------------------------------------------------------------------------------------
 // constants block (device): enum PK_* in plonk29.cuh
 template <class C> ZK_DEV Fp<C> kc(const uint32_t* k, int i) { return fp_load<C>(k + (size_t)i * 8); }
@@ -494,6 +558,16 @@ template <class C> struct PlonkOps {
     static int gather(const void* w, uint32_t nw, const void* in, uint32_t na, const void* ma, const void* mb, const void* mc, uint32_t ncon, uint32_t dom, void* A, void* B, void* Cc) {
         hipLaunchKernelGGL((k_plonk_gather<C>), dim3((dom + 255) / 256), dim3(256), 0, ctx().stream, (const uint32_t*)w, nw, (const uint32_t*)in, na, (const uint32_t*)ma, (const uint32_t*)mb,
                            (const uint32_t*)mc, ncon, dom, (uint32_t*)A, (uint32_t*)B, (uint32_t*)Cc);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int additions(const void* rec, uint32_t na, const void* w, uint32_t nw, void* internal) {
+        if (!na) return ZKMI_OK;
+        Ctx& cx = ctx();
+        uint32_t* flags;
+        ZK_TRY(ws_get("plonk.addflags", ((size_t)na + 1) * 4, (void**)&flags));
+        ZK_HIP(hipMemsetAsync(flags, 0, ((size_t)na + 1) * 4, cx.stream));                 // ready flags + the block ticket behind them
+        hipLaunchKernelGGL((k_plonk_additions<C>), dim3((na + 255) / 256), dim3(256), 0, cx.stream, (const uint32_t*)rec, na, (const uint32_t*)w, nw, (uint32_t*)internal, flags, flags + na);
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
@@ -836,6 +910,11 @@ int zkmi_keccak256(const uint8_t* data, size_t len, uint8_t* out32) {
 int zkmi_plonk_gather_wires_dev(int curve, const void* d_witness, uint32_t n_witness, const void* d_internal, uint32_t n_additions, const void* d_map_a, const void* d_map_b,
                                 const void* d_map_c, uint32_t n_constraints, uint32_t domain, void* d_a, void* d_b, void* d_c) {
     PLONK_DISPATCH(curve, gather(d_witness, n_witness, d_internal, n_additions, d_map_a, d_map_b, d_map_c, n_constraints, domain, d_a, d_b, d_c));
+}
+int zkmi_plonk_additions_dev(int curve, const void* d_additions, uint32_t n_additions, const void* d_witness, uint32_t n_witness, void* d_internal) {
+    if (n_additions && (!d_additions || !d_witness || !d_internal)) return fail(ZKMI_ERR_INVALID, "zkmi_plonk_additions_dev: null buffer");
+    if ((uint64_t)n_additions + n_witness > 0xffffffffull) return fail(ZKMI_ERR_INVALID, "zkmi_plonk_additions_dev: more than 2^32 signals");
+    PLONK_DISPATCH(curve, additions(d_additions, n_additions, d_witness, n_witness, d_internal));
 }
 int zkmi_plonk_compute_z_dev(int curve, const void* d_a, const void* d_b, const void* d_c, const void* d_s1e, const void* d_s2e, const void* d_s3e, uint32_t domain, const uint8_t* beta,
                              const uint8_t* gamma, const uint8_t* k1, const uint8_t* k2, const uint8_t* w_n, void* d_z) {

@@ -56,8 +56,10 @@ class FflonkKey:
         off += 4 * n8q                                                                    # X_2
         self.C0 = (f.unmont_q(data[off:off + n8q]), f.unmont_q(data[off + n8q:off + 2 * n8q]))
         zkmi.init()
-        self.additions = data[s[3][0]:s[3][0] + s[3][1]]
-        self.dev = {t: zkmi.DeviceBuffer.from_host(np.frombuffer(data, np.uint8, s[t][1], s[t][0])) for t in range(4, 18) if s[t][1]}
+        if s[3][1] < 72 * self.nAdditions:
+            raise ValueError("zkey additions section is shorter than its header says")
+        # section 3 (additions) too, as it lies in the file: calculateAdditions runs on the device, once per proof (zkmi_plonk_additions_dev)
+        self.dev = {t: zkmi.DeviceBuffer.from_host(np.frombuffer(data, np.uint8, s[t][1], s[t][0])) for t in range(3, 18) if s[t][1]}
         self.n_ptau = s[16][1] // (2 * f.n8q)                                             # 9n + 18 points (fflonk_setup.js:430-438)
         self.ptau_table = C.c_uint64(0)
         zkmi.check(zkmi.lib().zkmi_msm_table_build(self.curve_id, 1, self.dev[16].ptr, self.n_ptau, C.byref(self.ptau_table)))
@@ -185,18 +187,10 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
         bm = [None] + [bytes(x) for x in blinding_mont]
     b = [0] + [f.unmont(x) for x in bm[1:]]                                               # logical values of b1..b9
 
-    internal = []
-
-    def get_witness(idx):
-        if idx < nW:
-            return int.from_bytes(bytes(wit[32 * idx:32 * idx + 32]), "little")
-        return internal[idx - nW] if idx < key.nVars else 0
-    for i in range(key.nAdditions):                                                       # calculateAdditions (:271-300), sequential
-        s1, s2 = struct.unpack_from("<II", key.additions, 72 * i)
-        f1, f2 = f.unmont(key.additions[72 * i + 8:72 * i + 40]), f.unmont(key.additions[72 * i + 40:72 * i + 72])
-        internal.append((f1 * get_witness(s1) + f2 * get_witness(s2)) % r)
     d_wit = zkmi.DeviceBuffer.from_host(wit)
-    d_int = zkmi.DeviceBuffer.from_host(np.frombuffer(b"".join(v.to_bytes(32, "little") for v in internal) or bytes(32), np.uint8))
+    d_int = zkmi.DeviceBuffer(32 * max(key.nAdditions, 1))
+    if key.nAdditions:                                                                    # calculateAdditions (:271-300) on the device, one launch
+        zkmi.check(L.zkmi_plonk_additions_dev(f.cid, key.sec(3), key.nAdditions, d_wit.ptr, nW, d_int.ptr))
     mont = f.mont
     mp = lambda v: zkmi.ptr(mont(v))
     w_n, w_2n, w_4n = f.root(power), f.root(power + 1), f.root(power + 2)

@@ -32,9 +32,9 @@ class FflonkKey {                                           // src/zkey_utils.js
         off += 4 * n8q;                                                                                      // X_2
         this.C0 = [f.unmontQ(data.subarray(off, off + n8q)), f.unmontQ(data.subarray(off + n8q, off + 2 * n8q))];
         addon.init(0);
-        this.additions = data.subarray(s[3][0], s[3][0] + s[3][1]);
-        this.dev = {};
-        for (let t = 4; t <= 17; t++) if (s[t] && s[t][1]) this.dev[t] = devFrom(data.subarray(s[t][0], s[t][0] + s[t][1]));
+        if (s[3][1] < 72 * this.nAdditions) throw new Error("zkey additions section is shorter than its header says");
+        this.dev = {};                                      // section 3 (additions) too, as it lies in the file: calculateAdditions runs on the device
+        for (let t = 3; t <= 17; t++) if (s[t] && s[t][1]) this.dev[t] = devFrom(data.subarray(s[t][0], s[t][0] + s[t][1]));
         this.nPtau = s[16][1] / (2 * n8q);                                                                   // 9n + 18 points
         const h = new Uint8Array(8);
         call("zkmi_msm_table_build", 0, 1, this.dev[16], this.nPtau, h);
@@ -114,16 +114,9 @@ function proveWith(key, wt, blindingMont, track) {
     const bm = [null];                                       // the 9 Fr.random() draws (:321-324) as Montgomery bytes
     for (let i = 0; i < 9; i++) bm.push(blindingMont ? Uint8Array.from(blindingMont[i]) : f.mont(fromLE(crypto.randomBytes(40))));
     const b = [0n].concat(bm.slice(1).map((x) => f.unmont(x)));
-    const internal = [];
-    const getWitness = (idx) => idx < nW ? fromLE(wit.subarray(32 * idx, 32 * idx + 32)) : (idx < key.nVars ? internal[idx - nW] : 0n);
-    const adv = new DataView(key.additions.buffer, key.additions.byteOffset, key.additions.byteLength);
-    for (let i = 0; i < key.nAdditions; i++) {               // calculateAdditions (:271-300), sequential
-        const o = 72 * i, f1 = f.unmont(key.additions.subarray(o + 8, o + 40)), f2 = f.unmont(key.additions.subarray(o + 40, o + 72));
-        internal.push((f1 * getWitness(adv.getUint32(o, true)) + f2 * getWitness(adv.getUint32(o + 4, true))) % r);
-    }
-    const intBytes = new Uint8Array(Math.max(32, 32 * internal.length));
-    internal.forEach((v, i) => intBytes.set(toLE(v, 32), 32 * i));
-    const dWit = devFrom(wit), dInt = devFrom(intBytes);
+    // calculateAdditions (:271-300): the internal signals, ONE launch on the device (zkmi_plonk_additions_dev)
+    const dWit = devFrom(wit), dInt = I.devAlloc(32 * Math.max(key.nAdditions, 1));
+    if (key.nAdditions) call("zkmi_plonk_additions_dev", f.cid, key.sec(3), key.nAdditions, dWit, nW, dInt);
     try {
         const mont = (v) => f.mont(v), wN = f.root(power), w2N = f.root(power + 1), w4N = f.root(power + 2), wv = f.unmont(wN);
         const pts = {}, evs = {}, big = (a) => new BigUint64Array(a.map((x) => BigInt(x || 0)));

@@ -107,9 +107,9 @@ class PlonkKey {
         this.commit = {};
         for (const nm of ["Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"]) { this.commit[nm] = [f.unmontQ(data.subarray(off, off + n8q)), f.unmontQ(data.subarray(off + n8q, off + 2 * n8q))]; off += 2 * n8q; }
         addon.init(0);
-        this.additions = data.subarray(s[3][0], s[3][0] + s[3][1]);
-        this.dev = {};
-        for (let t = 4; t <= 14; t++) if (s[t] && s[t][1]) this.dev[t] = devFrom(data.subarray(s[t][0], s[t][0] + s[t][1]));
+        if (s[3][1] < 72 * this.nAdditions) throw new Error("zkey additions section is shorter than its header says");
+        this.dev = {};                                      // section 3 (additions) too, as it lies in the file: calculateAdditions runs on the device
+        for (let t = 3; t <= 14; t++) if (s[t] && s[t][1]) this.dev[t] = devFrom(data.subarray(s[t][0], s[t][0] + s[t][1]));
         this.nPtau = s[14][1] / (2 * n8q);
         const h = new Uint8Array(8);
         call("zkmi_msm_table_build", this.curveId, 1, this.dev[14], this.nPtau, h);     // the SRS is static: window tables, built once
@@ -203,7 +203,7 @@ function* proveSteps(key, wt, blindingMont, P, track) {
     const f = key.f, r = f.r, n = key.n, power = key.power;
     const own = !(wt instanceof PlonkWitness);
     const wres = own ? new PlonkWitness(key, wt) : wt;
-    const { pub, dWit, dInt, nW } = wres;
+    const { pub, dWit, nW } = wres;
     const b = [0n];
     for (let i = 0; i < 11; i++) b.push(blindingMont ? f.unmont(blindingMont[i]) : fromLE(crypto.randomBytes(64)) % r);
     try {
@@ -211,6 +211,9 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         const wN = f.root(power), w4N = f.root(power + 2), w2 = f.root(2), mont = (v) => f.mont(v);
 
         // ---- ROUND 1 (:222-313)
+        // calculateAdditions (:174-204): the internal signals, ONE launch on the device into this proof's own buffer (two proofs may be in flight)
+        const internal = P(Math.max(key.nAdditions, 1), false), dInt = internal.ptr;
+        if (key.nAdditions) call("zkmi_plonk_additions_dev", f.cid, key.sec(3), key.nAdditions, dWit, nW, dInt);
         const A = P(n, false), B = P(n, false), Cw = P(n, false);
         call("zkmi_plonk_gather_wires_dev", f.cid, dWit, nW, dInt, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n, A.ptr, B.ptr, Cw.ptr);
         for (const p of [A, B, Cw]) call("zkmi_fr_batch_dev", f.cid, 0, p.ptr, p.ptr, n);                  // batchToMontgomery
@@ -334,21 +337,12 @@ class PlonkWitness {
         this.pub = [];
         for (let i = 1; i <= key.nPublic; i++) this.pub.push(fromLE(wit.subarray(32 * i, 32 * i + 32)));
         wit.fill(0, 0, 32);                                                                                 // :94-96
-        const internal = [], nW = key.nVars - key.nAdditions;
-        const getWitness = (idx) => idx < nW ? fromLE(wit.subarray(32 * idx, 32 * idx + 32)) : (idx < key.nVars ? internal[idx - nW] : 0n);
-        const adv = new DataView(key.additions.buffer, key.additions.byteOffset, key.additions.byteLength);
-        for (let i = 0; i < key.nAdditions; i++) {
-            const o = 72 * i, s1 = adv.getUint32(o, true), s2 = adv.getUint32(o + 4, true);
-            const f1 = f.unmont(key.additions.subarray(o + 8, o + 40)), f2 = f.unmont(key.additions.subarray(o + 40, o + 72));
-            internal.push((f1 * getWitness(s1) + f2 * getWitness(s2)) % r);
-        }
-        const intBytes = new Uint8Array(Math.max(32, 32 * internal.length));
-        internal.forEach((v, i) => intBytes.set(toLE(v, 32), 32 * i));
-        this.nW = nW;
+        // calculateAdditions (src/plonk_prove.js:174-204) is per-proof work of the reference: it runs on the device at the start of every proof
+        // (zkmi_plonk_additions_dev in proveSteps), not here
+        this.nW = key.nVars - key.nAdditions;
         this.dWit = devFrom(wit);
-        this.dInt = devFrom(intBytes);
     }
-    release() { if (this.dWit) { devFree(this.dWit); devFree(this.dInt); this.dWit = this.dInt = 0; } }
+    release() { if (this.dWit) { devFree(this.dWit); this.dWit = 0; } }
 }
 
 module.exports = { prove, proveMany, PlonkKey, PlonkWitness,

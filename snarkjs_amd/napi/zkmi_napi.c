@@ -724,6 +724,7 @@ static const struct { const char* name; const char* sig; } g_call_table[] = {
     {"zkmi_fr_batch_dev", "i i d d i"}, {"zkmi_ntt_dev", "i d d i i B32 B32"},
     {"zkmi_msm_table_build", "i i d i b8"}, {"zkmi_msm_table_release", "i"},
     {"zkmi_plonk_gather_wires_dev", "i d i d i d d d i i d d d"},
+    {"zkmi_plonk_additions_dev", "i d i d i d"},
     {"zkmi_plonk_compute_z_dev", "i d d d d d d i b32 b32 b32 b32 b32 d"}, {"zkmi_plonk_compute_z_enqueue", "i d d d d d d i b32 b32 b32 b32 b32 d"},
     {"zkmi_pipeline_select", "i"}, {"zkmi_synchronize", ""},
     {"zkmi_plonk_compute_t_dev", "i b112 i i b352 b32 b32 b32 b32 b32 b32 b32 b32 d d"},

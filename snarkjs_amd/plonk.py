@@ -160,8 +160,10 @@ class PlonkKey:
         for nm in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):                       # src/zkey_utils.js:283-290
             self.commit[nm] = (f.unmont_q(data[off:off + n8q]), f.unmont_q(data[off + n8q:off + 2 * n8q])); off += 2 * n8q
         zkmi.init()
-        self.additions = data[s[3][0]:s[3][0] + s[3][1]]
-        self.dev = {t: zkmi.DeviceBuffer.from_host(np.frombuffer(data, np.uint8, s[t][1], s[t][0])) for t in (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14) if s[t][1]}
+        if s[3][1] < 72 * self.nAdditions:
+            raise ValueError("zkey additions section is shorter than its header says")
+        # section 3 (additions) goes to the device as it lies in the file: calculateAdditions runs there, once per proof (zkmi_plonk_additions_dev)
+        self.dev = {t: zkmi.DeviceBuffer.from_host(np.frombuffer(data, np.uint8, s[t][1], s[t][0])) for t in (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14) if s[t][1]}
         # the SRS is static: pre-computed window tables for the nine commitments of every proof (all use a prefix of PTau)
         self.n_ptau = s[14][1] // (2 * f.n8q)
         self.ptau_table = C.c_uint64(0)
@@ -181,8 +183,9 @@ class PlonkKey:
 
 class PlonkWitness:
     """A witness resident on the device for any number of proofs against `key` (the reference reads the .wtns file once per proof,
-    src/plonk_prove.js:83-97): header checks, the public signals, calculateAdditions (:174-204, sequential on the host: each internal signal may
-    depend on earlier ones), the signals and the internal signals uploaded once. Read-only afterwards: proofs on both pipeline slots share it."""
+    src/plonk_prove.js:83-97): header checks, the public signals, the signals uploaded once. Read-only afterwards: proofs on both pipeline
+    slots share it. calculateAdditions (:174-204) is NOT done here: it is per-proof work of the reference and runs on the device at the
+    start of every prove() (zkmi_plonk_additions_dev), inside whatever the caller times."""
 
     def __init__(self, key, wt):
         f, r = key.f, key.f.r
@@ -201,26 +204,13 @@ class PlonkWitness:
             raise ValueError(f"Invalid witness length. Circuit: {key.nVars}, witness: {n_witness}, {key.nAdditions}")
         wit = np.frombuffer(wt, np.uint8, n_witness * 32, ws[2][0])                       # a view: the signal 0 slot is cleared on the device
         self.public = [int.from_bytes(bytes(wit[32 * i:32 * i + 32]), "little") for i in range(1, key.nPublic + 1)]
-        internal = []
-        self.nW = nW = key.nVars - key.nAdditions
-
-        def get_witness(idx):
-            if idx < nW:
-                return int.from_bytes(bytes(wit[32 * idx:32 * idx + 32]), "little") if idx else 0    # signal 0 reads as 0 (:94-96)
-            return internal[idx - nW] if idx < key.nVars else 0
-        for i in range(key.nAdditions):
-            o = 72 * i
-            s1, s2 = struct.unpack_from("<II", key.additions, o)
-            f1, f2 = f.unmont(key.additions[o + 8:o + 40]), f.unmont(key.additions[o + 40:o + 72])
-            internal.append((f1 * get_witness(s1) + f2 * get_witness(s2)) % r)
+        self.nW = key.nVars - key.nAdditions
         self.d_wit = zkmi.DeviceBuffer.from_host(wit)
         zkmi.check(zkmi.lib().zkmi_memset_dev(self.d_wit.ptr, 0, 32))                     # :94-96
-        self.d_int = zkmi.DeviceBuffer.from_host(np.frombuffer(b"".join(v.to_bytes(32, "little") for v in internal) or bytes(32), np.uint8))
         zkmi.check(zkmi.lib().zkmi_synchronize())
 
     def release(self):
         self.d_wit.free()
-        self.d_int.free()
 
 
 class _Transcript:
@@ -329,7 +319,7 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     key = zkey if isinstance(zkey, PlonkKey) else PlonkKey(data(zkey))
     f, L, r, n, power = key.f, zkmi.lib(), key.f.r, key.n, key.power
     wres = witness_file if isinstance(witness_file, PlonkWitness) else PlonkWitness(key, data(witness_file))
-    public, d_wit, d_int, nW = wres.public, wres.d_wit, wres.d_int, wres.nW
+    public, d_wit, nW = wres.public, wres.d_wit, wres.nW
     if blinding_mont is None:
         b = [0] + [int.from_bytes(os.urandom(64), "little") % r for _ in range(11)]
     else:
@@ -341,9 +331,14 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     mont = f.mont
 
     # ---- ROUND 1 (:222-313)
+    # calculateAdditions (:174-204): the internal signals, one launch on the device (this slot's own buffer: two proofs may be in flight)
+    d_int = zkmi.DeviceBuffer(32 * max(key.nAdditions, 1))
+    if key.nAdditions:
+        zkmi.check(L.zkmi_plonk_additions_dev(f.cid, key.sec(3), key.nAdditions, d_wit.ptr, nW, d_int.ptr))
     A, B, Cw = _Poly(f, n, False), _Poly(f, n, False), _Poly(f, n, False)
     zkmi.check(L.zkmi_plonk_gather_wires_dev(f.cid, d_wit.ptr, nW, d_int.ptr, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n,
                                              A.ptr, B.ptr, Cw.ptr))
+    d_int.free()                                                                          # stream-ordered: the gather above is the last reader
     for p in (A, B, Cw):
         zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_TO_MONTGOMERY, p.ptr, p.ptr, n))
     pA, pB, pC = A.ntt(True), B.ntt(True), Cw.ntt(True)

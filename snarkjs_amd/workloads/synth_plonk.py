@@ -2,11 +2,17 @@
 
 The PLONK prover throws on inconsistent inputs ("Copy constraints does not match", "Polynomial is not divisible",
 polynomial.js:607-611), so unlike Groth16 the key must describe a satisfiable circuit.  Circuit: one public input x,
-then the squaring chain w[i+1] = w[i]^2 (the Multiplier(n) shape of the reference's test/groth16/circuit.circom):
+then the chain w[i+1] = w[i]^2 + sum_{j=1..d} alpha_j w[i-j], i = 1..m — the `x^2 + b` shape of the reference's test circuits, whose R1CS
+constraint w[i] * w[i] = w[i+1] - sum_j alpha_j w[i-j] has a (d+1)-term linear combination on its C side. plonk.setup folds such a combination
+pairwise (src/plonk_setup.js:180-210, reduceCoefs): every fold creates an internal signal, an ADDITION GATE row and an ADDITIONS record
+(s_1 = c_1 x_1 + c_2 x_2, then s_j = c_{j+1} x_{j+1} + 1 s_{j-1}: a chain of depth d), and the prover recomputes the internal signals for
+every proof (calculateAdditions, src/plonk_prove.js:174-204). `additions` = d (default 1: one addition gate per multiplication gate, what
+plonk.setup emits for `x^2 + b`; 0: the plain squaring chain, no additions section).
 
-    row 0            : a = w[1]                ql = 1                    (public-input row, PI(X) = -L_1(X) w[1])
-    row i (1..nc-1)  : a = b = w[i], c = w[i+1]   qm = 1, qo = -1
-    rows nc..n-1     : a = b = c = 0 (signal 0)
+    row 0                      : a = w[1]                       ql = 1            (public-input row, PI(X) = -L_1(X) w[1])
+    constraint i, rows of j<=d : a = x, b = y, c = s_j          ql = -c_x, qr = -c_y, qo = 1       (addition gates)
+    constraint i, last row     : a = b = w[i], c = s_d          qm = 1, qo = -1                    (c = w[i+1] when d = 0)
+    rows nc..n-1               : a = b = c = 0 (signal 0)
 
 SRS: [tau^i] G1, i < n + 6, for a KNOWN tau (never do this in production).  Layout follows src/plonk_setup.js /
 src/zkey_utils.js:261-299: each Q / sigma / Lagrange section = n coefficients then 4n evaluations, Montgomery form.
@@ -21,7 +27,7 @@ import numpy as np
 from .synth_zkey import PRIMES, _binfile
 
 
-def _pieces(name, lg, seed, tau, n_srs, free_rows=0):
+def _pieces(name, lg, seed, tau, n_srs, free_rows=0, additions=1):
     """everything both PLONK-family key layouts share: witness, signal maps, selector / sigma / Lagrange sections, SRS, commit()"""
     from .. import zkmi
     zkmi.init()
@@ -39,19 +45,51 @@ def _pieces(name, lg, seed, tau, n_srs, free_rows=0):
         zkmi.check(L.zkmi_fr_root(cid, i, zkmi.ptr(out)))
         return out
 
-    # ---- witness: w[0] = 1 (ignored by the prover), w[1] = x, w[i+1] = w[i]^2
+    # ---- witness: w[0] = 1 (ignored by the prover), w[1] = x, w[i+1] = w[i]^2 + sum_j alpha_j w[i-j]   (w[k] = 0 for k < 1: signal 0 reads as 0)
+    d = int(additions)
+    m = (nc - 1) // (d + 1)                       # multiplication gates (R1CS constraints); each brings d addition gates
+    nc = 1 + m * (d + 1)                          # rows in use
+    alpha = [(seed * 7919 + 104729 * j + 3) % r for j in range(1, d + 1)]
     w = [1, (seed * 0x9E3779B97F4A7C15 + 12345) % r]
-    for _ in range(1, nc):
-        w.append(w[-1] * w[-1] % r)
-    n_vars = nc + 1
-    assert len(w) == n_vars
-    wt = _binfile(b"wtns", [(1, struct.pack("<I", 32) + r.to_bytes(32, "little") + struct.pack("<I", n_vars)),
+    for i in range(1, m + 1):
+        v = w[i] * w[i]
+        for j in range(1, d + 1):
+            if i - j >= 1:
+                v += alpha[j - 1] * w[i - j]
+        w.append(v % r)
+    n_wit = m + 2                                 # signals of the .wtns file
+    n_add = d * m
+    n_vars = n_wit + n_add                        # the zkey header's nVars counts the internal signals too (plonk_setup.js: plonkNVars)
+    assert len(w) == n_wit
+    wt = _binfile(b"wtns", [(1, struct.pack("<I", 32) + r.to_bytes(32, "little") + struct.pack("<I", n_wit)),
                             (2, b"".join(v.to_bytes(32, "little") for v in w))])
-    # ---- signal maps (sections 4-6)
-    rows = np.arange(nc, dtype=np.uint32)
-    map_a = rows.copy(); map_a[0] = 1
-    map_b = rows.copy(); map_b[0] = 0
-    map_c = rows + 1; map_c[0] = 0
+    # ---- rows, signal maps (sections 4-6), selector evaluations and the additions section (section 3: 72-byte records u32 id1, u32 id2,
+    #      factor1, factor2 in Montgomery form). Constraint i owns the internal signals n_wit + d (i-1) .. + d - 1 and the rows 1 + (i-1)(d+1) .. + d.
+    map_a, map_b, map_c = (np.zeros(nc, np.uint32) for _ in range(3))
+    sel = {k: np.zeros((n, 32), np.uint8) for k in ("qm", "ql", "qr", "qo", "qc")}
+    bv = lambda b: np.frombuffer(b, np.uint8)
+    map_a[0] = 1
+    sel["ql"][0] = bv(one_m)
+    ii = np.arange(1, m + 1, dtype=np.int64)
+    base = 1 + (ii - 1) * (d + 1)
+    rec = np.zeros((m, max(d, 1)), dtype=[("id1", "<u4"), ("id2", "<u4"), ("f1", "V32"), ("f2", "V32")])
+    for j in range(1, d + 1):
+        internal = n_wit + d * (ii - 1) + (j - 1)
+        if j == 1:
+            id1, id2, f1, f2 = ii + 1, np.maximum(ii - 1, 0), 1, r - alpha[0]
+        else:
+            id1, id2, f1, f2 = np.maximum(ii - j, 0), internal - 1, r - alpha[j - 1], 1
+        rec["id1"][:, j - 1], rec["id2"][:, j - 1] = id1, id2
+        rec["f1"][:, j - 1], rec["f2"][:, j - 1] = np.void(mont(f1)), np.void(mont(f2))
+        rows_j = base + (j - 1)
+        map_a[rows_j], map_b[rows_j], map_c[rows_j] = id1, id2, internal
+        sel["ql"][rows_j], sel["qr"][rows_j], sel["qo"][rows_j] = bv(mont(r - f1)), bv(mont(r - f2)), bv(one_m)
+    mul_rows = base + d
+    map_a[mul_rows] = map_b[mul_rows] = ii
+    map_c[mul_rows] = (n_wit + d * (ii - 1) + (d - 1)) if d else (ii + 1)
+    sel["qm"][mul_rows], sel["qo"][mul_rows] = bv(one_m), bv(mone_m)
+    add_sec = rec.tobytes() if d else b""
+    assert len(add_sec) == 72 * n_add
     # ---- permutation: positions p = col*n + row, grouped by signal id, sigma = next position in the cycle
     sig = np.zeros((3, n), np.int64)
     sig[0, :nc], sig[1, :nc], sig[2, :nc] = map_a, map_b, map_c
@@ -104,16 +142,9 @@ def _pieces(name, lg, seed, tau, n_srs, free_rows=0):
         zkmi.check(L.zkmi_to_affine(cid, 1, zkmi.ptr(jac), zkmi.ptr(aff)))
         return aff.tobytes()
 
-    def const_rows(first_row, body):
-        e = np.zeros((n, 32), np.uint8)
-        e[0] = np.frombuffer(first_row, np.uint8)
-        e[1:nc] = np.frombuffer(body, np.uint8)
-        return e.reshape(-1)
-
     secs, commits = {}, {}
-    for t, nm, ev in ((7, "Qm", const_rows(zero_m, one_m)), (8, "Ql", const_rows(one_m, zero_m)), (9, "Qr", const_rows(zero_m, zero_m)),
-                      (10, "Qo", const_rows(zero_m, mone_m)), (11, "Qc", const_rows(zero_m, zero_m))):
-        secs[t] = section(ev)
+    for t, nm, key in ((7, "Qm", "qm"), (8, "Ql", "ql"), (9, "Qr", "qr"), (10, "Qo", "qo"), (11, "Qc", "qc")):
+        secs[t] = section(sel[key].reshape(-1))
         commits[nm] = commit()
     for k, nm in enumerate(("S1", "S2", "S3")):
         secs[nm] = section(sigma_ev[k].reshape(-1))
@@ -132,31 +163,31 @@ def _pieces(name, lg, seed, tau, n_srs, free_rows=0):
         zkmi.check(L.zkmi_to_affine(cid, 1, zkmi.ptr(jac), zkmi.ptr(aff)))
         dc.free(); ds.free()
         return aff.tobytes()
-    out = dict(q8=q8, q=q, r=r, n=n, nc=nc, n_vars=n_vars, wt=wt, maps=(map_a, map_b, map_c), secs=secs, commits=commits, x2=x2.tobytes(), srs=srs,
+    out = dict(q8=q8, q=q, r=r, n=n, nc=nc, n_vars=n_vars, n_add=n_add, add_sec=add_sec, wt=wt, maps=(map_a, map_b, map_c), secs=secs, commits=commits, x2=x2.tobytes(), srs=srs,
                k1=k1, k2=k2, mont=mont, commit_coefs=commit_coefs, free=lambda: [b.free() for b in (d_in, d_out, d4, d_srs, d_g2, d_sc)])
     return out
 
 
-def make(name, lg, seed=7, tau=0x1F3D5B79):
-    """PLONK zkey (protocol id 2, src/zkey_utils.js:261-299) + wtns"""
-    P = _pieces(name, lg, seed, tau, (1 << lg) + 6)
+def make(name, lg, seed=7, tau=0x1F3D5B79, additions=1):
+    """PLONK zkey (protocol id 2, src/zkey_utils.js:261-299) + wtns; `additions` = addition gates per multiplication gate (module docstring)"""
+    P = _pieces(name, lg, seed, tau, (1 << lg) + 6, additions=additions)
     q8, q, r, n, nc, secs, commits, mont = P["q8"], P["q"], P["r"], P["n"], P["nc"], P["secs"], P["commits"], P["mont"]
     map_a, map_b, map_c = P["maps"]
     hdr = (struct.pack("<I", q8) + q.to_bytes(q8, "little") + struct.pack("<I", 32) + r.to_bytes(32, "little")
-           + struct.pack("<IIIII", P["n_vars"], 1, n, 0, nc) + mont(P["k1"]) + mont(P["k2"])
+           + struct.pack("<IIIII", P["n_vars"], 1, n, P["n_add"], nc) + mont(P["k1"]) + mont(P["k2"])
            + b"".join(commits[nm] for nm in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3")) + P["x2"])
-    zkey = _binfile(b"zkey", [(1, struct.pack("<I", 2)), (2, hdr), (3, b""), (4, map_a.astype("<u4").tobytes()), (5, map_b.astype("<u4").tobytes()),
+    zkey = _binfile(b"zkey", [(1, struct.pack("<I", 2)), (2, hdr), (3, P["add_sec"]), (4, map_a.astype("<u4").tobytes()), (5, map_b.astype("<u4").tobytes()),
                               (6, map_c.astype("<u4").tobytes()), (7, secs[7]), (8, secs[8]), (9, secs[9]), (10, secs[10]), (11, secs[11]),
                               (12, secs["S1"] + secs["S2"] + secs["S3"]), (13, secs[13]), (14, P["srs"])])
     P["free"]()
     return zkey, P["wt"]
 
 
-def make_fflonk(lg, seed=7, tau=0x1F3D5B79):
+def make_fflonk(lg, seed=7, tau=0x1F3D5B79, additions=1):
     """FFLONK zkey (protocol id 10; src/fflonk_setup.js:213-500, src/zkey_utils.js:301-339) + wtns for the same circuit. BN254 only
     (the reference hard-codes w3 / wr for that field, fflonk_setup.js:525-547)."""
     n = 1 << lg
-    P = _pieces("bn128", lg, seed, tau, 9 * n + 18, free_rows=2)
+    P = _pieces("bn128", lg, seed, tau, 9 * n + 18, free_rows=2, additions=additions)
     q8, q, r, nc, secs, mont = P["q8"], P["q"], P["r"], P["nc"], P["secs"], P["mont"]
     map_a, map_b, map_c = P["maps"]
     coef = lambda key: np.frombuffer(secs[key][:n * 32], np.uint8).reshape(n, 32)
@@ -169,10 +200,10 @@ def make_fflonk(lg, seed=7, tau=0x1F3D5B79):
     zkmi.check(zkmi.lib().zkmi_fr_root(0, 3, zkmi.ptr(w8)))
     wr = pow(467799165886069610036046866799264026481344299079011762026774533774345988080, 2 ** (28 - lg), r)
     hdr = (struct.pack("<I", q8) + q.to_bytes(q8, "little") + struct.pack("<I", 32) + r.to_bytes(32, "little")
-           + struct.pack("<IIIII", P["n_vars"], 1, n, 0, nc) + mont(P["k1"]) + mont(P["k2"]) + mont(w3) + w4.tobytes() + w8.tobytes() + mont(wr)
+           + struct.pack("<IIIII", P["n_vars"], 1, n, P["n_add"], nc) + mont(P["k1"]) + mont(P["k2"]) + mont(w3) + w4.tobytes() + w8.tobytes() + mont(wr)
            + P["x2"] + P["commit_coefs"](c0))
     # FFLONK section ids (src/fflonk_constants.js): 7 QL, 8 QR, 9 QM, 10 QO, 11 QC, 12-14 sigma, 15 Lagrange, 16 PTau, 17 C0
-    zkey = _binfile(b"zkey", [(1, struct.pack("<I", 10)), (2, hdr), (3, b""), (4, map_a.astype("<u4").tobytes()), (5, map_b.astype("<u4").tobytes()),
+    zkey = _binfile(b"zkey", [(1, struct.pack("<I", 10)), (2, hdr), (3, P["add_sec"]), (4, map_a.astype("<u4").tobytes()), (5, map_b.astype("<u4").tobytes()),
                               (6, map_c.astype("<u4").tobytes()), (7, secs[8]), (8, secs[9]), (9, secs[7]), (10, secs[10]), (11, secs[11]),
                               (12, secs["S1"]), (13, secs["S2"]), (14, secs["S3"]), (15, secs[13]), (16, P["srs"]), (17, c0)])
     P["free"]()

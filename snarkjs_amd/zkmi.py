@@ -27,7 +27,7 @@ SYMBOLS = [
     "zkmi_groth16_join_abc", "zkmi_groth16_join_abc_dev",
     "zkmi_base_cache_stats", "zkmi_gen_bases_from_scalars_dev", "zkmi_group_fft", "zkmi_group_fft_dev", "zkmi_group_batch_apply_key", "zkmi_group_batch_apply_key_dev", "zkmi_group_convert", "zkmi_group_convert_dev", "zkmi_calibrate_box", "zkmi_calibrate_code_fetch", "zkmi_compact_code", "zkmi_groth16_load", "zkmi_groth16_prove", "zkmi_groth16_prove_dev", "zkmi_groth16_submit_dev", "zkmi_groth16_submit", "zkmi_groth16_sums_w_dev", "zkmi_groth16_collect", "zkmi_groth16_release", "zkmi_groth16_load_shard", "zkmi_groth16_sums_dev", "zkmi_groth16_chains_dev", "zkmi_groth16_sums_h_dev", "zkmi_groth16_finish", "zkmi_groth16_stage_ms",
     "zkmi_gen_geometric_bases_dev", "zkmi_host_register", "zkmi_host_unregister", "zkmi_to_affine", "zkmi_point_add", "zkmi_fr_root",
-    "zkmi_plonk_gather_wires_dev", "zkmi_plonk_compute_z_dev", "zkmi_plonk_compute_z_enqueue", "zkmi_pipeline_select", "zkmi_pipeline_active", "zkmi_plonk_compute_t_dev", "zkmi_fflonk_t0_dev", "zkmi_fflonk_t1_dev",
+    "zkmi_plonk_gather_wires_dev", "zkmi_plonk_additions_dev", "zkmi_plonk_compute_z_dev", "zkmi_plonk_compute_z_enqueue", "zkmi_pipeline_select", "zkmi_pipeline_active", "zkmi_plonk_compute_t_dev", "zkmi_fflonk_t0_dev", "zkmi_fflonk_t1_dev",
     "zkmi_fflonk_t2_dev", "zkmi_poly_degree_dev", "zkmi_keccak256", "zkmi_poly_blind_dev", "zkmi_poly_add_scalar_dev", "zkmi_poly_axpy_dev", "zkmi_poly_scale_dev",
     "zkmi_poly_evaluate_dev", "zkmi_poly_is_zero_dev", "zkmi_poly_div_zh_dev", "zkmi_cpoly_interleave_dev", "zkmi_poly_div_by_zerofier_dev", "zkmi_last_kernel_ms",
 ]
@@ -129,6 +129,7 @@ def lib():
     L.zkmi_fr_root.argtypes = [C.c_int, C.c_uint, u8p]
     u32 = C.c_uint32
     L.zkmi_plonk_gather_wires_dev.argtypes = [C.c_int, vp, u32, vp, u32, vp, vp, vp, u32, u32, vp, vp, vp]
+    L.zkmi_plonk_additions_dev.argtypes = [C.c_int, vp, u32, vp, u32, vp]
     L.zkmi_plonk_compute_z_dev.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, u32, u8p, u8p, u8p, u8p, u8p, vp]
     L.zkmi_plonk_compute_z_enqueue.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, u32, u8p, u8p, u8p, u8p, u8p, vp]
     L.zkmi_pipeline_select.argtypes = [C.c_int]

@@ -168,8 +168,79 @@ def test_compute_z_and_t_stages_vs_oracle(env, golden_dir, t29, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("curve,lg", [("bn128", 4), ("bn128", 10), ("bn128", 13), ("bls12381", 4), ("bls12381", 10), ("bls12381", 13)])
-def test_synthetic_plonk_key_device_vs_oracle(env, curve, lg):
+@pytest.mark.parametrize("curve", ["bn128", "bls12381"])
+def test_calculate_additions_device_vs_oracle(env, curve):
+    """zkmi_plonk_additions_dev == the reference's sequential calculateAdditions loop (oracle/plonk_oracle.py: calculate_additions,
+    src/plonk_prove.js:174-204), bit for bit, on (a) the additions section of a synthetic key with > 2^16 additions in chains of depth 3 and
+    (b) a random dependency DAG of 70 001 records: operands drawn from the witness, from EARLIER internal signals (near and far, so that lanes
+    wait within a wave, across waves and across blocks), one chain of depth 6 000 through consecutive records, and the edge cases of getWitness
+    (:207-215): signal 0, ids at / beyond the record's own slot (the reference reads its zero-initialised buffer: 0), ids >= nVars (Fr.zero)."""
+    import struct
+    import synth_plonk
+    zkmi, plonk, f, cx = env
+    cid = 0 if curve == "bn128" else 1
+    if cid:
+        f, cx = plonk._Field(1), P.Ctx(48)
+    L, r = zkmi.lib(), cx.r
+
+    def run(add_buf, n_add, wit):
+        n_wit = len(wit)
+        d_add = zkmi.DeviceBuffer.from_host(np.frombuffer(add_buf, np.uint8))
+        d_wit = zkmi.DeviceBuffer.from_host(np.frombuffer(b"".join(v.to_bytes(32, "little") for v in wit), np.uint8))
+        d_int = zkmi.DeviceBuffer(32 * n_add)
+        zkmi.check(L.zkmi_memset_dev(d_int.ptr, 0xA5, 32 * n_add))                 # stale contents must not leak into a result
+        for _ in range(2):                                                        # twice: the ready flags of the first call must not satisfy the second
+            zkmi.check(L.zkmi_plonk_additions_dev(cid, d_add.ptr, n_add, d_wit.ptr, n_wit, d_int.ptr))
+        zkmi.check(L.zkmi_synchronize())
+        got = [int.from_bytes(bytes(x), "little") for x in d_int.to_host(32 * n_add).reshape(n_add, 32)]
+        for b in (d_add, d_wit, d_int):
+            b.free()
+        return got
+
+    # (a) the section a key carries
+    zkey, wtns = synth_plonk.make(curve, 17, seed=5, additions=3)
+    zk = P.read_plonk_zkey(zkey, cx)
+    assert zk["nAdditions"] > 1 << 16
+    ws = P.read_sections(wtns)
+    o = ws[2][0]
+    n_wit = zk["nVars"] - zk["nAdditions"]
+    wit = [int.from_bytes(wtns[o + 32 * i:o + 32 * i + 32], "little") for i in range(n_wit)]
+    wit[0] = 0
+    add_buf = P.sec(zk, 3)
+    assert run(add_buf, zk["nAdditions"], wit) == P.calculate_additions(cx, add_buf, zk["nAdditions"], wit, zk["nVars"])
+
+    # (b) random DAG
+    rng = np.random.default_rng(0xADD + cid)
+    n_wit, n_add = 5000, 70001
+    n_vars = n_wit + n_add
+    wit = [0] + _rand(0x77 + cid, n_wit - 1, r)
+    facs = [bytes(f.mont(v)) for v in [0, 1, r - 1, 2, 12345678901234567890 % r] + _rand(0x78, 27, r)]
+    recs = bytearray()
+    for i in range(n_add):
+        ids = []
+        for k in range(2):
+            t = int(rng.integers(0, 100))
+            if i and 1000 <= i < 7000 and k == 0:
+                ids.append(n_wit + i - 1)                                         # one long chain: record i reads record i-1
+            elif t < 40 or i == 0:
+                ids.append(int(rng.integers(0, n_wit)))                           # a witness signal (incl. signal 0)
+            elif t < 70:
+                ids.append(n_wit + int(rng.integers(max(0, i - 64), i)))          # a recent internal signal (same wave / block)
+            elif t < 94:
+                ids.append(n_wit + int(rng.integers(0, i)))                       # any earlier internal signal
+            elif t < 97:
+                ids.append(n_wit + int(rng.integers(i, n_add)))                   # its own slot or a later one: reads 0
+            else:
+                ids.append(n_vars + int(rng.integers(0, 1000)))                   # beyond nVars: Fr.zero
+        recs += struct.pack("<II", *ids) + facs[int(rng.integers(0, len(facs)))] + facs[int(rng.integers(0, len(facs)))]
+    want = P.calculate_additions(cx, bytes(recs), n_add, wit, n_vars)
+    assert run(bytes(recs), n_add, wit) == want
+    assert len(set(want)) > n_add // 2                                            # the DAG did not collapse to zeros
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve,lg,depth", [("bn128", 4, 1), ("bn128", 10, 0), ("bn128", 10, 1), ("bn128", 13, 3), ("bls12381", 4, 2), ("bls12381", 10, 1), ("bls12381", 13, 1)])
+def test_synthetic_plonk_key_device_vs_oracle(env, curve, lg, depth):
     """A synthetic but VALID key (tests/synth_plonk.py): the device prover must accept it (copy-constraint and divisibility
     checks) and agree with the Python restatement coefficient for coefficient (proof equality). Both curves since r04: k_plonk_t<Bls12381Fr>,
     computeZ's scans and the 4n-point paths on multi-tile BLS12-381 instances (the reference-generated BLS12-381 fixture is n = 64)."""
@@ -177,7 +248,7 @@ def test_synthetic_plonk_key_device_vs_oracle(env, curve, lg):
     zkmi, plonk, f, cx = env
     if curve != "bn128":
         f = plonk._Field(1)
-    zkey, wtns = synth_plonk.make(curve, lg, seed=lg)
+    zkey, wtns = synth_plonk.make(curve, lg, seed=lg, additions=depth)    # `depth` addition gates per multiplication gate, internal signals in chains
     blind = [bytes(f.mont(1000 + 17 * i)) for i in range(11)]
     got = plonk.prove(zkey, wtns, blinding_mont=blind)
     want_proof, want_pub = P.plonk_prove(zkey, wtns, blind)
