@@ -72,19 +72,26 @@ int zkmi_memset_dev(void* d_dst, int value, size_t bytes);
 /* ---- G.multiExpAffine ------------------------------------------------------------------------------------------- */
 /* curve.G1.multiExpAffine / curve.G2.multiExpAffine (min.js:1@214996 -> @214651 -> _multiExpChunk @213360; kernel
  * g1m_/g2m_multiexpAffine_chunk @75966).  group = 1 | 2.  n bases of 2*group*n8q bytes, n scalars of scalar_bytes.
- * base_cache_key != 0 ALLOWS the library to keep these bases resident (zkey sections / SRS slices are static per circuit,
+ * base_cache_key & ZKMI_BASES_CACHE ALLOWS the library to keep these bases resident (zkey sections / SRS slices are static per circuit,
  * src/groth16_prove.js:84-100); its value carries no identity. The cache is content-addressed: the library hashes the whole base
  * buffer on every call (128 bits per 64 KiB chunk, a fast NON-cryptographic mix: accidental changes — another zkey, an edited section —
  * are told apart, deliberately constructed colliding buffers are not; callers that take bases from an untrusted party pass key 0). The
  * pre-computed window table of a buffer is built on its SECOND sight, an MSM over a prefix of a resident buffer re-uses its
  * table, tables that cannot fit are never built (plain bases instead), and least-recently-used tables are evicted under a
  * byte budget (env ZKMI_BASE_CACHE_BYTES, default 64 GiB). zkmi_release_bases drops every cached table.
- * r04: a buffer that comes back at the SAME first-page address and length as one that has been checked byte for byte against a resident table
- * is re-checked by SAMPLE (its first and last whole chunk and 30 chunks at positions that change from call to call) and in full on every 32nd
- * sight; every other buffer, and every failed sample, takes the full hash. Consequence for the caller: do not edit a resident base buffer IN
- * PLACE between calls — such an edit is noticed for certain only by the next full check (at most 31 calls later; another zkey in the same
- * buffer differs in every chunk and is noticed at once). ZKMI_BASE_HASH_FULL=1 restores the full hash on every call.
+ * base_cache_key is a set of permission bits (any other bit is ignored):
+ *   ZKMI_BASES_CACHE (1)      resident tables allowed; identity = the FULL content hash, on every call: the result is always a function of the
+ *                             bytes passed, like the reference's (min.js:1@213360) — an in-place edit of a resident buffer is seen by the next call.
+ *   ZKMI_BASES_IMMUTABLE (2)  (with bit 1) the caller PROMISES that a buffer it passes again at the same first-page address with the same length
+ *                             still holds the same bytes (a zkey section it never writes to). Only then a buffer that has been checked byte for
+ *                             byte against a resident table is re-checked by SAMPLE (its first and last whole chunk and 30 chunks at positions that
+ *                             change from call to call; 2 MB instead of 64 MB hashed at 2^20 points) and in full on every 32nd sight. A caller that
+ *                             breaks the promise can be handed the old buffer's result for up to 31 calls. Never assumed by default (r04 did; r05:
+ *                             opt-in): register(curve, {immutableBases: true}) in js/register.js, cache_key=3 in the Python mirror.
+ * ZKMI_BASE_HASH_FULL=1 in the environment forces the full hash whatever the caller promised.
  * out_jacobian: 3*group*n8q bytes. */
+#define ZKMI_BASES_CACHE 1ull
+#define ZKMI_BASES_IMMUTABLE 2ull
 int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t n, size_t scalar_bytes,
              uint64_t base_cache_key, uint8_t* out_jacobian);
 int zkmi_release_bases(uint64_t base_cache_key);

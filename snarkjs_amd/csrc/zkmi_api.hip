@@ -83,6 +83,15 @@ int ws_get(const std::string& name, size_t bytes, void** out) {
     return ZKMI_OK;
 }
 
+// drop the scratch buffer `name` of the active pipeline slot (a large one-off: the copy of a standalone MSM's bases)
+static void ws_drop(const std::string& name) {
+    auto it = g_ctx.ws.find(g_ctx.pipe ? "P1:" + name : name);
+    if (it == g_ctx.ws.end() || !it->second.p) return;
+    (void)hipStreamSynchronize(g_ctx.stream);
+    (void)hipFree(it->second.p);
+    g_ctx.ws.erase(it);
+}
+
 static size_t pages_total(const zkmi_pages& pg) { size_t t = 0; for (int i = 0; i < pg.n_pages; i++) t += pg.len[i]; return t; }
 
 int upload_pages(const zkmi_pages& pg, size_t total_bytes, void* d_dst) {
@@ -485,16 +494,25 @@ int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalar
     const size_t pb = (size_t)2 * group * n8q_of(curve);
     void* d_b = nullptr;
     uint32_t* d_mask = nullptr;
-    ZK_TRY(ws_get("api.dev_bases29", n * pb, &d_b));
-    ZK_TRY(ws_get("api.dev_basemask", ((n + 31) / 32) * 4 + 16, (void**)&d_mask));
+    // The copy is scratch the caller never asked for (n pb bytes: 4 - 6 GB at 2^26 G1 points). When it cannot be had, the MSM still runs — on the
+    // caller's own bases with the saturated-limb kernel, as before r04 — instead of failing with out-of-memory; and a copy beyond
+    // ZKMI_MSM_DEV_KEEP_BYTES (default 2 GiB) is released after the call rather than kept for the life of the process.
+    static const size_t keep_limit = [] { const char* e = getenv("ZKMI_MSM_DEV_KEEP_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)2 << 30); }();
+    if (ws_get("api.dev_bases29", n * pb, &d_b) != ZKMI_OK || ws_get("api.dev_basemask", ((n + 31) / 32) * 4 + 16, (void**)&d_mask) != ZKMI_OK) {
+        (void)hipGetLastError();                                   // the failed allocation is not this call's result
+        ws_drop("api.dev_bases29");
+        return msm_dev_dispatch(curve, group, d_bases, d_scalars, n, scalar_bytes, out);
+    }
     ZK_HIP(hipEventRecord(g_ctx.ev0, g_ctx.stream));              // zkmi_last_kernel_ms covers the copy and the conversion too
     ZK_HIP(hipMemcpyAsync(d_b, d_bases, n * pb, hipMemcpyDeviceToDevice, g_ctx.stream));
     int rc = msm_infmask_dispatch(curve, group, d_b, n, d_mask);
     if (!rc) rc = msm_table_to_r29(curve, group, d_b, n, d_mask);  // registers d_b when the 29-bit path exists for (curve, group); else a no-op
-    g_ctx.ev0_held = true;
-    if (!rc) rc = msm_dev_dispatch(curve, group, d_b, d_scalars, n, scalar_bytes, out);
-    g_ctx.ev0_held = false;
+    if (!rc) {
+        struct Ev0Held { Ev0Held() { g_ctx.ev0_held = true; } ~Ev0Held() { g_ctx.ev0_held = false; } } held;      // msm_run: "the start event is recorded already", for exactly this dispatch
+        rc = msm_dev_dispatch(curve, group, d_b, d_scalars, n, scalar_bytes, out);
+    }
     msm_table_forget_r29(d_b);
+    if (n * pb > keep_limit) ws_drop("api.dev_bases29");
     return rc;
 }
 // ---- content-addressed cache of resident base tables behind zkmi_msm ---------------------------------------------------------
@@ -637,13 +655,16 @@ int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t 
     void *d_b = nullptr, *d_s = nullptr;
     ZK_TRY(ws_get("api.scalars", n * scalar_bytes, &d_s));
     ZK_TRY(upload_pages(scalars, n * scalar_bytes, d_s));
-    // A resident key comes back with every proof in the SAME host buffer. Hashing all of it on every call (64 MB per 2^20 G1 MSM) cost more than
-    // the device part of the call (r03: 3.28 ms through N-API against 1.92 ms on the device). r04: a buffer (first page pointer, length) whose
-    // every byte was checked against a resident table on an earlier call is re-checked by SAMPLE — its first and last whole chunk and 30 chunks
-    // at pseudo-random positions that change from call to call (2 MB) — and in full again on every 32nd sight; anything else (another pointer,
-    // another length, a failed sample) takes the full content hash as before. ZKMI_BASE_HASH_FULL=1: always the full hash.
+    // A resident key comes back with every proof in the SAME host buffer. Hashing all of it on every call (64 MB per 2^20 G1 MSM) costs more than
+    // the device part of the call (3.28 ms through N-API against 1.92 ms on the device). A caller that PROMISES not to edit such a buffer
+    // (ZKMI_BASES_IMMUTABLE, include/zkmi.h) gets a sampled re-check instead: a buffer (first page pointer, length) whose every byte was checked
+    // against a resident table on an earlier call is re-checked by its first and last whole chunk and 30 chunks at pseudo-random positions that
+    // change from call to call (2 MB), and in full again on every 32nd sight; anything else (another pointer, another length, a failed sample)
+    // takes the full content hash. Without the promise (the default since r05) EVERY call takes the full hash: the result always follows the
+    // bytes passed, as the reference's does. ZKMI_BASE_HASH_FULL=1: the full hash whatever was promised.
+    const bool allow_cache = (key & ZKMI_BASES_CACHE) != 0, promised = allow_cache && (key & ZKMI_BASES_IMMUTABLE) != 0;
     static const bool hash_full = getenv("ZKMI_BASE_HASH_FULL") && atoi(getenv("ZKMI_BASE_HASH_FULL")) == 1;
-    if (key && scalar_bytes <= 32 && !hash_full && bases.n_pages >= 1) {
+    if (promised && scalar_bytes <= 32 && !hash_full && bases.n_pages >= 1) {
         const size_t total = n * pb;
         for (auto& e : g_bc) {
             if (!e.table.p || e.curve != curve || e.group != group || total > e.n * pb) continue;
@@ -669,7 +690,7 @@ int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t 
             return msm_table_dispatch(curve, group, e.table.p, e.table.n, e.table.c, d_s, n, scalar_bytes, out);
         }
     }
-    if (key && scalar_bytes <= 32) {
+    if (allow_cache && scalar_bytes <= 32) {
         std::vector<BcHash> q;
         bc_chunk_hashes(bases, n * pb, q);
         BcEntry* hit = nullptr;                      // resident table that holds these bases as a prefix

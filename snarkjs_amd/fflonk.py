@@ -42,17 +42,24 @@ class FflonkKey:
         n8r = struct.unpack_from("<I", data, off)[0]
         self.r = int.from_bytes(data[off + 4:off + 4 + n8r], "little"); off += 4 + n8r
         self.curve_id, self.curve_name = _curve_from_q(q)
-        if self.curve_id != 0:
-            # The reference's prover would take any curve from the zkey (src/fflonk_prove.js:51-110), but its fflonk.setup hard-codes BN254 constants
-            # (computeW3: generator 31624 to BN254's (r - 1) / 3; getOmegaCubicRoot: a literal cube root of BN254's Fr.w[28], src/fflonk_setup.js:533-556):
-            # the key it writes for BLS12-381 has w3^3 != 1 and its OWN fflonk.prove throws "Polynomial is not divisible" on a satisfied circuit
-            # (tests/golden/fflonk_bls12381_unsupported.json, produced by oracle/gen_golden.js: fflonkBlsProbe). No valid key can exist: refuse up front.
-            raise ValueError(f"Curve not supported: {self.curve_name} (FFLONK keys exist for bn128 only: the reference's fflonk.setup hard-codes BN254 constants)")
         self.f = f = _Field(self.curve_id)
         self.nVars, self.nPublic, self.n, self.nAdditions, self.nConstraints = struct.unpack_from("<IIIII", data, off); off += 20
         self.power = self.n.bit_length() - 1
         for nm in ("k1", "k2", "w3", "w4", "w8", "wr"):                                   # src/zkey_utils.js:322-328
             setattr(self, nm, f.unmont(data[off:off + 32])); off += 32
+        if self.curve_id != 0:
+            # The reference's prover takes the curve and its roots from the zkey (src/fflonk_prove.js:51-110) — only its fflonk.setup hard-codes BN254
+            # constants (computeW3: generator 31624 to BN254's (r - 1) / 3; getOmegaCubicRoot: a literal cube root of BN254's Fr.w[28],
+            # src/fflonk_setup.js:533-556): the key THAT writes for BLS12-381 has w3^3 != 1 and the reference's own fflonk.prove throws "Polynomial is
+            # not divisible" on a satisfied circuit (tests/golden/fflonk_bls12381_unsupported.json, oracle/gen_golden.js: fflonkBlsProbe). So the key is
+            # held to what the protocol needs of it, not to its curve: a consistent key from a repaired or third-party setup takes the generic path
+            # below, an inconsistent one fails here with the reference's own words, before the device is touched.
+            r = self.r
+            ok = (self.w3 != 1 and pow(self.w3, 3, r) == 1 and pow(self.w4, 2, r) == r - 1 and pow(self.w8, 4, r) == r - 1
+                  and pow(self.wr, 3, r) == f.unmont(f.root(self.power)))
+            if not ok:
+                raise ValueError(f"Polynomial is not divisible: this {self.curve_name} FFLONK key is inconsistent (w3^3 != 1 or w4 / w8 / wr of the wrong order) — what the "
+                                 "reference's fflonk.setup writes off bn128, where it hard-codes BN254 constants; the reference's fflonk.prove fails on such a key the same way")
         off += 4 * n8q                                                                    # X_2
         self.C0 = (f.unmont_q(data[off:off + n8q]), f.unmont_q(data[off + n8q:off + 2 * n8q]))
         zkmi.init()

@@ -10,7 +10,7 @@
 "use strict";
 const crypto = require("crypto");
 const { _internals: I } = require("./plonk_native.js");
-const { addon, call, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN } = I;
+const { addon, call, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN, Q_BLS } = I;
 
 class FflonkKey {                                           // src/zkey_utils.js:301-339, sections of src/fflonk_constants.js
     constructor(zkey) {
@@ -20,15 +20,20 @@ class FflonkKey {                                           // src/zkey_utils.js
         let off = s[2][0];
         const n8q = dv.getUint32(off, true), q = fromLE(data.subarray(off + 4, off + 4 + n8q)); off += 4 + n8q;
         const n8r = dv.getUint32(off, true); this.r = fromLE(data.subarray(off + 4, off + 4 + n8r)); off += 4 + n8r;
-        // FFLONK exists on bn128 only: the reference's fflonk.setup hard-codes BN254 constants (src/fflonk_setup.js:533-556), the key it writes for
-        // BLS12-381 has w3^3 != 1 and its own fflonk.prove fails on it (tests/golden/fflonk_bls12381_unsupported.json)
-        if (q !== Q_BN) throw new Error(`Curve not supported: ${q} (FFLONK keys exist for bn128 only: the reference's fflonk.setup hard-codes BN254 constants)`);
-        this.curveId = 0; this.curveName = "bn128";
-        const f = this.f = new Field(0);
+        if (q === Q_BN) { this.curveId = 0; this.curveName = "bn128"; } else if (q === Q_BLS) { this.curveId = 1; this.curveName = "bls12381"; } else throw new Error(`Curve not supported: ${q}`);
+        const f = this.f = new Field(this.curveId);
         this.nVars = dv.getUint32(off, true); this.nPublic = dv.getUint32(off + 4, true); this.n = dv.getUint32(off + 8, true);
         this.nAdditions = dv.getUint32(off + 12, true); this.nConstraints = dv.getUint32(off + 16, true); off += 20;
         this.power = Math.log2(this.n);
         for (const nm of ["k1", "k2", "w3", "w4", "w8", "wr"]) { this[nm] = f.unmont(data.subarray(off, off + 32)); off += 32; }
+        if (this.curveId !== 0) {
+            // The reference's prover takes the curve and its roots from the zkey; only its fflonk.setup hard-codes BN254 constants (src/fflonk_setup.js:
+            // 533-556) — the key THAT writes for BLS12-381 has w3^3 != 1 and the reference's own fflonk.prove fails on it with "Polynomial is not divisible"
+            // (tests/golden/fflonk_bls12381_unsupported.json). The key is held to what the protocol needs, not to its curve.
+            const r = this.r, ok = this.w3 !== 1n && modpow(this.w3, 3n, r) === 1n && modpow(this.w4, 2n, r) === r - 1n && modpow(this.w8, 4n, r) === r - 1n &&
+                                   modpow(this.wr, 3n, r) === f.unmont(f.root(this.power));
+            if (!ok) throw new Error(`Polynomial is not divisible: this ${this.curveName} FFLONK key is inconsistent (w3^3 != 1 or w4 / w8 / wr of the wrong order), as the reference's fflonk.setup writes it off bn128`);
+        }
         off += 4 * n8q;                                                                                      // X_2
         this.C0 = [f.unmontQ(data.subarray(off, off + n8q)), f.unmontQ(data.subarray(off + n8q, off + 2 * n8q))];
         addon.init(0);
@@ -37,7 +42,7 @@ class FflonkKey {                                           // src/zkey_utils.js
         for (let t = 3; t <= 17; t++) if (s[t] && s[t][1]) this.dev[t] = devFrom(data.subarray(s[t][0], s[t][0] + s[t][1]));
         this.nPtau = s[16][1] / (2 * n8q);                                                                   // 9n + 18 points
         const h = new Uint8Array(8);
-        call("zkmi_msm_table_build", 0, 1, this.dev[16], this.nPtau, h);
+        call("zkmi_msm_table_build", this.curveId, 1, this.dev[16], this.nPtau, h);
         this.ptauTable = Number(new DataView(h.buffer).getBigUint64(0, true));
     }
     sec(t, elemOff = 0) { return this.dev[t] + 32 * elemOff; }

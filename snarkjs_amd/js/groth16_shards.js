@@ -75,14 +75,23 @@ async function workerMain() {
     const src = [0, 0, 0];                                      // peer mode: where chain c's output can be read from in THIS process
     const opened = [];
     const handles = {};
-    if (peer) for (const c of owned) { handles[c] = Buffer.from(await addon.ipcExport(dChain[c])).toString("base64"); src[c] = dChain[c]; }
     const send = (m) => { if (process.connected) process.send(m, () => { /* a parent that went away is handled by 'disconnect' */ }); };
+    if (peer) {
+        // a host without HSA IPC (some containers) or with mixed HIP runtimes fails here or in "peers" below: reported without an id, the parent
+        // then restarts every worker with exchange "shm" when the exchange was not asked for explicitly
+        try { for (const c of owned) { handles[c] = Buffer.from(await addon.ipcExport(dChain[c])).toString("base64"); src[c] = dChain[c]; } }
+        catch (e) { send({ ev: "error", rank, phase: "peer", message: `ipcExport: ${String(e && e.message || e)}` }); return; }
+    }
     send({ ev: "ready", rank, handles });
     let busy = Promise.resolve();                              // one command at a time: an async handler yields at every await
     const handle = async (msg) => {
         try {
             if (msg.cmd === "peers") {                          // every chain owner's handle: open the ones that live elsewhere
-                for (let c = 0; c < 3; c++) if (!owned.includes(c)) { src[c] = await addon.ipcOpen(new Uint8Array(Buffer.from(msg.handles[c], "base64"))); opened.push(src[c]); }
+                try {
+                    for (let c = 0; c < 3; c++) if (!owned.includes(c)) { src[c] = await addon.ipcOpen(new Uint8Array(Buffer.from(msg.handles[c], "base64"))); opened.push(src[c]); }
+                    // one small pull from every mapping now: peer access that does not work must show up in the handshake, not in the first proof
+                    for (let c = 0; c < 3; c++) if (!owned.includes(c)) await addon.peerCopy(dSl[0], src[c], 32);
+                } catch (e) { send({ ev: "error", rank, phase: "peer", message: `peer handshake: ${String(e && e.message || e)}` }); return; }
                 send({ ev: "peers_ok", rank });
             } else if (msg.cmd === "prove") {
                 await addon.memcpyH2D(dW, shmW);
@@ -139,41 +148,65 @@ class ShardedProver {
         this.addonPath = opts.addonPath || path.join(__dirname, "..", "napi", "zkmi_napi.node");
         const addon = this.addon = require(this.addonPath);
         const zk = this.zk = parseZkey(new Uint8Array(fs.readFileSync(this.zkeyPath)));
-        // "peer": chain outputs move GPU to GPU (zkmi_ipc_* / zkmi_peer_copy); "shm": through page-locked shared host memory (PCIe both ways)
+        // "peer": chain outputs move GPU to GPU (zkmi_ipc_* / zkmi_peer_copy); "shm": through page-locked shared host memory (PCIe both ways).
+        // Not given: "peer" when the addon has the entry points, and — should the peer handshake fail on this host (no HSA IPC in the container,
+        // processes on different HIP runtimes, no peer access between two GPUs) — every worker is restarted with "shm"; the path taken is in
+        // this.exchange and on every proof, the reason in this.exchangeFallback. An exchange asked for explicitly is never replaced.
+        const auto = !opts.exchange;
         this.exchange = opts.exchange || (typeof addon.ipcExport === "function" ? "peer" : "shm");
         if (this.exchange !== "peer" && this.exchange !== "shm") throw new Error(`ShardedProver: unknown exchange "${this.exchange}"`);
+        this.exchangeFallback = null;
+        this.log = opts.log || ((m) => console.error(m));
+        this.opts = opts;
         this.shmPrefix = `/zkmi_${process.pid}_${crypto.randomBytes(4).toString("hex")}`;
         // shared regions (created 0600 here, mapped by every worker, unlinked at close()): the witness; in "shm" mode the three chain outputs too
         this.shmNames = [`${this.shmPrefix}_w`];
         this.witnessRegion = addon.shmMap(this.shmNames[0], zk.nVars * 32, true);
         this.regions = [];
-        if (this.exchange === "shm") for (let c = 0; c < 3; c++) { this.shmNames.push(`${this.shmPrefix}_c${c}`); this.regions.push(addon.shmMap(this.shmNames[c + 1], zk.domainSize * 32, true)); }
         this.waiters = new Map();
         this.nextId = 1;
         this.workers = [];
+        this.gen = 0;                                           // generation of the worker set: events of a set that was torn down are ignored
         this.dead = null;                                       // Error once a worker has gone away
         this.needReset = false;
         this.queue = Promise.resolve();                         // prove() calls run one at a time
-        this._ready = new Promise((resolve, reject) => {
+        this._ready = this._start().catch(async (err) => {
+            if (!(auto && this.exchange === "peer" && err && err.peerPhase)) throw err;
+            this.log(`ShardedProver: peer exchange unavailable (${err.message}); restarting the workers with exchange "shm"`);
+            this.exchangeFallback = err.message;
+            await this._stopWorkers();
+            this.exchange = "shm";
+            this.dead = null;
+            return this._start();
+        });
+        this._ready.catch(() => {});                            // surfaced through ready() / prove()
+    }
+    // fork one worker per rank with the current exchange; resolves when every worker has loaded its shard (and, "peer", opened and probed its peers)
+    _start() {
+        const opts = this.opts, addon = this.addon, zk = this.zk, gen = ++this.gen;
+        if (this.exchange === "shm" && !this.regions.length) for (let c = 0; c < 3; c++) { this.shmNames.push(`${this.shmPrefix}_c${c}`); this.regions.push(addon.shmMap(this.shmNames[this.shmNames.length - 1], zk.domainSize * 32, true)); }
+        this.workers = [];
+        return new Promise((resolve, reject) => {
             let up = 0, peersOk = 0;
             const handles = {};
             for (let rank = 0; rank < this.world; rank++) {
                 const cfg = { rank, world: this.world, zkeyPath: this.zkeyPath, addonPath: this.addonPath, shmPrefix: this.shmPrefix, devices: opts.devices || null, exchange: this.exchange };
                 const w = fork(__filename, ["--zkmi-shard-worker"], { env: Object.assign({}, process.env, { ZKMI_SHARD_CFG: JSON.stringify(cfg) }), execArgv: opts.execArgv || process.execArgv });
                 w.on("message", (msg) => {
+                    if (gen !== this.gen) return;
                     if (msg.ev === "ready") {
                         Object.assign(handles, msg.handles || {});
                         if (++up === this.world) { if (this.exchange === "peer") for (const x of this.workers) x.send({ cmd: "peers", handles }); else resolve(); }
                         return;
                     }
                     if (msg.ev === "peers_ok") { if (++peersOk === this.world) resolve(); return; }
-                    if (msg.ev === "error" && !msg.id) { reject(new Error(`shard worker ${msg.rank}: ${msg.message}`)); return; }
+                    if (msg.ev === "error" && !msg.id) { const e = new Error(`shard worker ${msg.rank}: ${msg.message}`); e.peerPhase = msg.phase === "peer"; reject(e); return; }
                     const wt = this.waiters.get(msg.id);
                     if (wt) wt(msg);
                 });
                 w.on("error", () => { /* a send to a worker that has just gone away: the 'exit' handler below reports it */ });
                 w.on("exit", (code, signal) => {
-                    if (this.closing) return;
+                    if (this.closing || gen !== this.gen) return;
                     const err = new Error(`shard worker ${rank} exited (code ${code}, signal ${signal})`);
                     this.dead = this.dead || err;
                     reject(err);                                // no-op once resolved
@@ -182,7 +215,18 @@ class ShardedProver {
                 this.workers.push(w);
             }
         });
-        this._ready.catch(() => {});                            // surfaced through ready() / prove()
+    }
+    // tear the current worker set down (peer -> shm restart): its late events are ignored from here on
+    async _stopWorkers() {
+        this.gen++;
+        const old = this.workers;
+        this.workers = [];
+        for (const w of old) { if (w.connected) { try { w.send({ cmd: "exit" }); } catch (e) { /* already gone */ } } }
+        await Promise.all(old.map((w) => new Promise((res) => {
+            if (w.exitCode !== null || w.signalCode !== null) { res(); return; }
+            const t = setTimeout(() => { try { w.kill("SIGKILL"); } catch (e) { /* gone */ } }, 10000);
+            w.on("exit", () => { clearTimeout(t); res(); });
+        })));
     }
     ready() { return this._ready; }
     // wtns: Uint8Array with the .wtns file's bytes, or a path. Calls are serialised: the returned promise settles in call order.
@@ -237,7 +281,7 @@ class ShardedProver {
             const publicSignals = [];
             for (let i = 1; i <= zk.nPublic; i++) publicSignals.push(fromLE(witness.subarray(i * zk.n8r, (i + 1) * zk.n8r)).toString());
             return { proof: { pi_a: pointToObject(cid, 1, b(res.msg.pi_a)), pi_b: pointToObject(cid, 2, b(res.msg.pi_b)), pi_c: pointToObject(cid, 1, b(res.msg.pi_c)), protocol: "groth16", curve: zk.curveName },
-                     publicSignals, events: res.order, exchange: this.exchange, timeline_ms: at };
+                     publicSignals, events: res.order, exchange: this.exchange, exchangeFallback: this.exchangeFallback, timeline_ms: at };
         } catch (e) {
             this.needReset = !this.dead;                       // some workers may sit between the two halves of this proof
             throw e;

@@ -346,4 +346,4 @@ class PlonkWitness {
 }
 
 module.exports = { prove, proveMany, PlonkKey, PlonkWitness,
-                   _internals: { addon, call, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN } };
+                   _internals: { addon, call, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN, Q_BLS } };

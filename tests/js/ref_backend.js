@@ -161,7 +161,7 @@ const backend = {
     failNext(name) { failNextCall = name; },
 };
 // injected failure of one entry point (the shard driver's error path): the next call of `name` throws
-for (const name of ["groth16SumsWDev", "groth16SumsHDev", "groth16ChainsDev"]) {
+for (const name of ["groth16SumsWDev", "groth16SumsHDev", "groth16ChainsDev", "ipcExport", "ipcOpen", "peerCopy"]) {
     const f = backend[name];
     backend[name] = async function (...a) { if (failNextCall === name) { failNextCall = null; throw new Error(`zkmi error 3: injected failure in ${name}`); } return f.apply(this, a); };
 }

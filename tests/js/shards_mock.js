@@ -58,6 +58,30 @@ const hexb = (s) => new Uint8Array(Buffer.from(s, "hex"));
         check(`a dead worker rejects the pending proof (${out}) and every later one (${later})`, /exited|resolved/.test(out) && /exited/.test(later));
         await sp.close();
     }
+    // peer exchange that does not work on this host (no HSA IPC, mixed runtimes): with the exchange NOT asked for explicitly the parent restarts the
+    // workers with "shm" and says so; asked for explicitly, ready() rejects instead of silently taking another path
+    for (const failing of ["1:ipcOpen", "0:ipcExport", "1:peerCopy"]) {
+        process.env.ZKMI_MOCK_FAIL = failing;
+        const logs = [];
+        const sp = new ShardedProver({ world: 2, zkeyPath: path.join(GOLD, "groth16_bn128_n1024.zkey"), addonPath: path.join(__dirname, "ref_backend.js"), log: (m) => logs.push(m),
+                                       execArgv: ["--harmony-optional-chaining", "--harmony-nullish"] });
+        await sp.ready();
+        delete process.env.ZKMI_MOCK_FAIL;
+        const res = await sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) });
+        check(`peer handshake fails (${failing}): workers restarted with "shm", proof correct, path reported (${res.exchangeFallback})`,
+              sha(JSON.stringify(res.proof)) === g.proof_sha256 && res.exchange === "shm" && /injected failure/.test(res.exchangeFallback || "") && logs.length === 1);
+        await sp.close();
+    }
+    {
+        process.env.ZKMI_MOCK_FAIL = "1:ipcOpen";
+        const sp = new ShardedProver({ world: 2, zkeyPath: path.join(GOLD, "groth16_bn128_n1024.zkey"), addonPath: path.join(__dirname, "ref_backend.js"), exchange: "peer",
+                                       execArgv: ["--harmony-optional-chaining", "--harmony-nullish"] });
+        delete process.env.ZKMI_MOCK_FAIL;
+        let msg = "";
+        try { await sp.ready(); } catch (e) { msg = String(e.message); }
+        check(`an explicitly requested peer exchange that fails rejects ready() (${msg})`, /injected failure/.test(msg));
+        await sp.close();
+    }
     console.log(fails ? `${fails} FAILED` : "ALL OK");
     process.exit(fails ? 1 : 0);
 })().catch((e) => { console.log("ERROR", e); process.exit(2); });

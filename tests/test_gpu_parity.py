@@ -270,22 +270,37 @@ def test_msm_base_cache_is_content_addressed(zk):
     k = 9000
     wk2 = O.to_affine(c, 1, O.msm(c, 1, B2[:k * 64], sc[:k * 32], k))
     assert np.array_equal(aff(cv.G1.multiExpAffine(B2[:k * 64].copy(), sc[:k * 32], cache_key=1)), wk2)
-    # r04: a buffer that comes back at the SAME address and length as one already checked byte for byte against a resident table is re-checked
-    # by sample (first, last and 30 pseudo-random chunks; here 19 whole chunks: practically all of them) and in full on every 32nd sight
-    # (include/zkmi.h: zkmi_msm). A caller must not edit a resident buffer in place — but if it does, the edit is noticed at the latest by that
-    # full check, and from then on the results are the edited buffer's.
+    # The default (cache_key = 1 = ZKMI_BASES_CACHE): the full content hash on EVERY call, so the result always follows the bytes passed — a resident
+    # buffer edited IN PLACE gives the edited buffer's result on the very next call, and the original's when the edit is undone (the reference's
+    # contract: the result is a function of the bytes, min.js:1@213360).
+    Bd = B.copy()
+    for _ in range(3):
+        assert np.array_equal(aff(cv.G1.multiExpAffine(Bd, sc, cache_key=1)), want)
+    for _ in range(3):
+        Bd[i * 64:(i + 1) * 64] = B[(i + 1) * 64:(i + 2) * 64]                               # in place: the content of B2 at Bd's address
+        for _ in range(2):
+            assert np.array_equal(aff(cv.G1.multiExpAffine(Bd, sc, cache_key=1)), want2)     # never the stale table's result
+        Bd[i * 64:(i + 1) * 64] = B[i * 64:(i + 1) * 64]
+        assert np.array_equal(aff(cv.G1.multiExpAffine(Bd, sc, cache_key=1)), want)
+    # Opt-in (cache_key = 3: ZKMI_BASES_CACHE | ZKMI_BASES_IMMUTABLE, the caller's promise not to edit): a buffer that comes back at the SAME address
+    # and length as one already checked byte for byte against a resident table is re-checked by sample (first, last and 30 pseudo-random chunks;
+    # here 19 whole chunks: practically all of them) and in full on every 32nd sight (include/zkmi.h: zkmi_msm). A caller that breaks its promise
+    # is noticed at the latest by that full check, and from then on the results are the edited buffer's.
     Bm = B.copy()
     for _ in range(3):
-        assert np.array_equal(aff(cv.G1.multiExpAffine(Bm, sc, cache_key=1)), want)        # full check on first sight of this address, then samples
+        assert np.array_equal(aff(cv.G1.multiExpAffine(Bm, sc, cache_key=3)), want)        # full check on first sight of this address, then samples
     Bm[i * 64:(i + 1) * 64] = B[(i + 1) * 64:(i + 2) * 64]                                   # in place: the content of B2 at Bm's address
     seen_new = False
     for _ in range(40):
-        got = aff(cv.G1.multiExpAffine(Bm, sc, cache_key=1))
+        got = aff(cv.G1.multiExpAffine(Bm, sc, cache_key=3))
         if np.array_equal(got, want2):
             seen_new = True
         else:
             assert not seen_new and np.array_equal(got, want)                                # stale only BEFORE the edit was noticed, never after
     assert seen_new
+    # the promise is per call: the same edited-in-place buffer passed WITHOUT it is hashed in full at once
+    Bm[i * 64:(i + 1) * 64] = B[i * 64:(i + 1) * 64]
+    assert np.array_equal(aff(cv.G1.multiExpAffine(Bm, sc, cache_key=1)), want)
     # without the permission bit nothing is cached
     zkmi.check(L.zkmi_release_bases(0))
     for _ in range(3):
