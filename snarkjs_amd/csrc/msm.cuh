@@ -333,25 +333,44 @@ template <class F> ZK_DEV void pt_scale32(XYZZ<F>& p) {
 #pragma unroll 1
     for (int k = 0; k < r29_shift<typename F::Cfg>(); k++) { p.X = f_dbl(p.X); p.Y = f_dbl(p.Y); p.ZZ = f_dbl(p.ZZ); p.ZZZ = f_dbl(p.ZZZ); }
 }
+// r05: every block walks a contiguous run of buckets (grid-stride inside the run) instead of 256 buckets per block: with uniform scalars the bucket sizes
+// fall into ~30 key classes, and 2 048 blocks each adding its ~30 class counts to the same ~30 global words serialised in the L2 (classify 57 us,
+// assign 115 us per sort of a 2^20-term MSM, r04 trace); a few hundred blocks issue a sixteenth of those atomics.
+constexpr uint32_t MSM_SCHED_BLOCKS = 256;
+ZK_DEV void msm_sched_run(uint32_t total, uint32_t& lo, uint32_t& hi) {
+    const uint32_t per = ((total + gridDim.x - 1) / gridDim.x + 255u) & ~255u;
+    lo = min(total, blockIdx.x * per);
+    hi = min(total, lo + per);
+}
 static __global__ void __launch_bounds__(256) k_msm_classify(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[MSM_NKEYS];
     for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < total) { uint32_t k = msm_key(counts[g], cap); if (k) atomicAdd(&h[k], 1u); }
+    uint32_t lo, hi;
+    msm_sched_run(total, lo, hi);
+    for (uint32_t g = lo + threadIdx.x; g < hi; g += blockDim.x) { const uint32_t k = msm_key(counts[g], cap); if (k) atomicAdd(&h[k], 1u); }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) if (h[i]) atomicAdd(&hist[i], h[i]);
 }
-// single lane: first lane of every key class in descending key order
-static __global__ void k_msm_class_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ meta, uint32_t cap) {
-    if (threadIdx.x || blockIdx.x) return;
-    uint32_t run = 0, multi = 0;
-    for (int k = (int)MSM_NKEYS - 1; k >= 1; k--) {
-        off[k] = run;
-        run += hist[k] << msm_key_lanes_log((uint32_t)k, cap);
-        if ((uint32_t)k == 2 * cap) multi = run;
+// first lane of every key class in descending key order: one wave, an exclusive suffix scan of the classes' lane counts (r04: one lane walking
+// 544 dependent global loads, 40 us)
+static __global__ void __launch_bounds__(64) k_msm_class_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ meta, uint32_t cap) {
+    __shared__ uint32_t lanes[MSM_NKEYS + 1];
+    if (blockIdx.x) return;
+    for (uint32_t k = threadIdx.x; k < MSM_NKEYS; k += 64) lanes[k] = k ? hist[k] << msm_key_lanes_log(k, cap) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0, multi = 0;
+        for (int k = (int)MSM_NKEYS - 1; k >= 1; k--) {
+            const uint32_t c = lanes[k];
+            lanes[k] = run;
+            run += c;
+            if ((uint32_t)k == 2 * cap) multi = run;
+        }
+        meta[0] = run; meta[1] = multi;
     }
-    meta[0] = run; meta[1] = multi;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < MSM_NKEYS; k += 64) if (k) off[k] = lanes[k];
 }
 static __global__ void __launch_bounds__(256)
 k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, uint32_t log_tb, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
@@ -359,19 +378,24 @@ k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, 
     __shared__ uint32_t h[MSM_NKEYS], base[MSM_NKEYS];
     for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t k = g < total ? msm_key(counts[g], cap) : 0u, lr = 0;
-    if (k) lr = atomicAdd(&h[k], 1u);
+    uint32_t lo, hi;
+    msm_sched_run(total, lo, hi);
+    // pass 1: this block's class counts; ONE global atomic per class present reserves the block's ranks; pass 2 hands them out (any bijection
+    // will do: the order of the buckets inside a class is not part of the result)
+    for (uint32_t g = lo + threadIdx.x; g < hi; g += blockDim.x) { const uint32_t k = msm_key(counts[g], cap); if (k) atomicAdd(&h[k], 1u); }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) if (h[i]) base[i] = atomicAdd(&cursor[i], h[i]);
+    for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) { if (h[i]) base[i] = atomicAdd(&cursor[i], h[i]); h[i] = 0; }
     __syncthreads();
-    if (!k) return;
-    const uint32_t j = msm_key_lanes_log(k, cap), rank = base[k] + lr;
-    const uint32_t lane0 = off[k] + (rank << j);
-    for (uint32_t l = 0; l < (1u << j); l++) { lane_g[lane0 + l] = g; lane_sub[lane0 + l] = l; }
-    if (j > log_tb) {
-        uint32_t idx = atomicAdd(&meta[2], 1u);
-        giants[3 * idx] = g; giants[3 * idx + 1] = lane0 >> log_tb; giants[3 * idx + 2] = 1u << (j - log_tb);
+    for (uint32_t g = lo + threadIdx.x; g < hi; g += blockDim.x) {
+        const uint32_t k = msm_key(counts[g], cap);
+        if (!k) continue;
+        const uint32_t j = msm_key_lanes_log(k, cap), rank = base[k] + atomicAdd(&h[k], 1u);
+        const uint32_t lane0 = off[k] + (rank << j);
+        for (uint32_t l = 0; l < (1u << j); l++) { lane_g[lane0 + l] = g; lane_sub[lane0 + l] = l; }
+        if (j > log_tb) {
+            uint32_t idx = atomicAdd(&meta[2], 1u);
+            giants[3 * idx] = g; giants[3 * idx + 1] = lane0 >> log_tb; giants[3 * idx + 2] = 1u << (j - log_tb);
+        }
     }
 }
 // Threads per accumulation block. The LDS-parked Fq2 accumulators cost 4*FW words per lane: 256 B (BN254: 2 blocks of 256 lanes

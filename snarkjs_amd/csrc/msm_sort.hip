@@ -106,7 +106,7 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     else if (sb <= 32) msm_launch_digits<8>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, d_dropmask, st);
     else msm_launch_digits<16>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, d_dropmask, st);
     }
-    const unsigned tb = (unsigned)((total + 255) / 256);
+    const unsigned tb = std::min<unsigned>((unsigned)((total + 255) / 256), MSM_SCHED_BLOCKS);      // contiguous runs of buckets per block (msm.cuh: msm_sched_run)
     hipLaunchKernelGGL(k_msm_classify, dim3(tb), dim3(256), 0, st, pl.counts, (uint32_t)total, cap, hist);
     hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(64), 0, st, hist, koff, pl.meta, cap);
     hipLaunchKernelGGL(k_msm_assign, dim3(tb), dim3(256), 0, st, pl.counts, (uint32_t)total, cap, (uint32_t)MSM_LOG_TB, koff, kcur, pl.lane_g, pl.lane_sub, pl.giants, pl.meta);

@@ -168,10 +168,13 @@ template <class C> __global__ void k_plonk_gather(const uint32_t* __restrict__ w
 // Factors are Montgomery, signals normal form: the Montgomery product of the two is the normal-form product, as in the reference
 // (Fr.mul(factor, witness) on the zkey's bytes). Records are 72 bytes (u32 id1, u32 id2, 2 x 32): word loads. An operand id at or beyond
 // the addition's own slot reads what the reference reads there — its zero-initialised buffer, i.e. 0 — and ids >= nVars read Fr.zero (:213).
-template <class C> ZK_DEV Fp<C> fp_load_words(const uint32_t* p) {
+// a field element at an 8-byte aligned address (the factors of a 72-byte record): four 8-byte loads
+template <class C> ZK_DEV Fp<C> fp_load_u2(const uint32_t* p) {
+    static_assert(C::N == 8, "Fr is eight words on both curves");
     Fp<C> a;
+    const uint2* q = reinterpret_cast<const uint2*>(p);
 #pragma unroll
-    for (int k = 0; k < C::N; k++) a.l[k] = p[k];
+    for (int k = 0; k < 4; k++) { const uint2 v = q[k]; a.l[2 * k] = v.x; a.l[2 * k + 1] = v.y; }
     return a;
 }
 template <class C> __global__ void __launch_bounds__(256)
@@ -186,10 +189,11 @@ k_plonk_additions(const uint32_t* __restrict__ rec, uint32_t n_add, const uint32
     uint32_t dep[2] = {0, 0};
     if (active) {
         const uint32_t* r = rec + (size_t)i * 18;
+        const uint2 ids = *reinterpret_cast<const uint2*>(r);
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const uint32_t id = r[k];
-            f[k] = fp_load_words<C>(r + 2 + 8 * k);
+            const uint32_t id = k ? ids.y : ids.x;
+            f[k] = fp_load_u2<C>(r + 2 + 8 * k);
             w[k] = fp_zero<C>();
             if (id < n_wit) w[k] = fp_load<C>(wit + (size_t)id * 8);
             else if (id - n_wit < i) { ready[k] = false; dep[k] = id - n_wit; }       // an earlier internal signal: wait for it
@@ -202,22 +206,23 @@ k_plonk_additions(const uint32_t* __restrict__ rec, uint32_t n_add, const uint32
 #pragma unroll
             for (int k = 0; k < 2; k++)
                 if (!ready[k] && __hip_atomic_load(flags + dep[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    const uint32_t* src = internal + (size_t)dep[k] * 8;
-#pragma unroll
-                    for (int j = 0; j < C::N; j++) w[k].l[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // published with a release store of the flag behind plain vector stores: the acquire above orders these loads behind it
+                    const uint4* src = reinterpret_cast<const uint4*>(internal + (size_t)dep[k] * 8);
+                    const uint4 lo = src[0], hi = src[1];
+                    w[k].l[0] = lo.x; w[k].l[1] = lo.y; w[k].l[2] = lo.z; w[k].l[3] = lo.w; w[k].l[4] = hi.x; w[k].l[5] = hi.y; w[k].l[6] = hi.z; w[k].l[7] = hi.w;
                     ready[k] = true;
                 }
             if (ready[0] && ready[1]) {
                 const Fp<C> v = fp_add(fp_mul(f[0], w[0]), fp_mul(f[1], w[1]));
-                uint32_t* dst = internal + (size_t)i * 8;
-#pragma unroll
-                for (int j = 0; j < C::N; j++) __hip_atomic_store(dst + j, v.l[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint4* dst = reinterpret_cast<uint4*>(internal + (size_t)i * 8);
+                dst[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+                dst[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
                 __hip_atomic_store(flags + i, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 done = true;
                 progressed = true;
             }
         }
-        if (__ballot(progressed) == 0ull) __builtin_amdgcn_s_sleep(2);
+        if (__ballot(progressed) == 0ull) __builtin_amdgcn_s_sleep(1);
     }
 }
 
