@@ -196,13 +196,14 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
         a.rowinc = d_rowinc ? d_rowinc + rowoff[i] * 8 : nullptr;
         a.log_ch = std::min<unsigned>(NTT_TILE_LOG - P->l[i], logS);
         const size_t N = (size_t)1 << P->l[i], E = N << a.log_ch;
-        const size_t lds = use29 ? (size_t)(Tile29::words((uint32_t)E) + Tile29::words((uint32_t)(N / 2)) + Tile29::words((uint32_t)N)) * 4 : (2 * E + N + 2 * N) * 16;
+        const size_t tile29 = ZKMI_NTT_VARIANT >= 1 ? ((N + 1) << a.log_ch) : E;                      // ntt29.cuh: the variants keep the strided tiles transposed
+        const size_t lds = use29 ? (size_t)(Tile29::words((uint32_t)tile29) + Tile29::words((uint32_t)(N / 2)) + Tile29::words((uint32_t)N)) * 4 : (2 * E + N + 2 * N) * 16;
         const unsigned tiles = (unsigned)(n >> (P->l[i] + a.log_ch));
         const uint32_t* src = (i == 0) ? (const uint32_t*)d_in : work;
         a.in_bs = (i == 0) ? (uint64_t)in_stride * 8 : (uint64_t)n * rec; a.out_bs = (uint64_t)n * rec;
         if (!use29) hipLaunchKernelGGL((k_ntt_pass_strided<C>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, work, a);
-        else if (i == 0) hipLaunchKernelGGL((k_ntt29_pass_strided<C, false>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, work, a);
-        else hipLaunchKernelGGL((k_ntt29_pass_strided<C, true>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, work, a);
+        else if (i == 0) hipLaunchKernelGGL((k_ntt29_pass_strided<C, false>), dim3(tiles, batch), dim3(NTT29_THREADS), lds, st, src, work, a);
+        else hipLaunchKernelGGL((k_ntt29_pass_strided<C, true>), dim3(tiles, batch), dim3(NTT29_THREADS), lds, st, src, work, a);
     }
     {
         const int i = p - 1;
@@ -218,8 +219,8 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
         if (p == 1 && d_in == d_out) { /* single tile: loads complete before stores */ }
         a.in_bs = (p == 1) ? (uint64_t)in_stride * 8 : (uint64_t)n * rec; a.out_bs = (uint64_t)out_stride * 8;
         if (!use29) hipLaunchKernelGGL((k_ntt_pass_last<C>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, dst, a);
-        else if (p == 1) hipLaunchKernelGGL((k_ntt29_pass_last<C, false>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, dst, a);
-        else hipLaunchKernelGGL((k_ntt29_pass_last<C, true>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, src, dst, a);
+        else if (p == 1) hipLaunchKernelGGL((k_ntt29_pass_last<C, false>), dim3(tiles, batch), dim3(NTT29_THREADS), lds, st, src, dst, a);
+        else hipLaunchKernelGGL((k_ntt29_pass_last<C, true>), dim3(tiles, batch), dim3(NTT29_THREADS), lds, st, src, dst, a);
     }
     ZK_HIP(hipEventRecord(cx.ev1, st));
     ZK_HIP(hipGetLastError());

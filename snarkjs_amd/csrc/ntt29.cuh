@@ -24,6 +24,16 @@
 namespace zkmi {
 
 constexpr int NTT29_REC = 12;                 // words per element of the work array between passes (9 limbs + 3 words of padding)
+// r05 measured two restructurings of the stage loop against the shipped one (profiles/NOTES.md "Round 5", profiles/r05_ntt_ab.txt; both bit-identical,
+// neither faster). They stay buildable for the A/B (ZKMI_BUILD_VARIANT=<v> ZKMI_EXTRA_FLAGS=-DZKMI_NTT_VARIANT=<k>, tools/lab/r5_ntt_ab.sh):
+//   0  shipped: row-major tile in the strided passes, one block barrier per stage
+//   1  transposed tile in the strided passes too; a column is worked on by ONE wave in every stage, the barrier between stages becomes a
+//      wavefront-scope fence (one block barrier after the last stage)                                             2^20: 0.1497 vs 0.1505 ms
+//   2  = 1 with radix-4 groups held in registers (two stages per LDS round trip), 128-thread blocks                2^20: 0.187 ms
+#ifndef ZKMI_NTT_VARIANT
+#define ZKMI_NTT_VARIANT 0
+#endif
+constexpr int NTT29_THREADS = ZKMI_NTT_VARIANT == 2 ? 128 : NTT_THREADS;
 
 // v (normalised, < 32 r) -> v mod r, canonical limbs
 template <class C> ZK_HD void reduce29_small(Fp29<C>& v) {
@@ -108,9 +118,12 @@ template <class C> ZK_DEV Fp29<C> ntt29_pow(const NttPassArgs& a, uint64_t e) {
 template <class C, bool ROWMAJOR> ZK_DEV void ntt29_tile_stages(const Tile29& p, const Tile29& U, uint32_t l, uint32_t log_ch) {
     const uint32_t half_elems = 1u << (l + log_ch - 1);
     const uint32_t N = 1u << l, HN = N >> 1;
+    // variant 1: with at most 64 pairs per column, butterfly b = (column b >> (l-1), pair b & (N/2-1)) of lane b mod 256 keeps every column inside one
+    // wave through all stages; LDS operations of one wave execute in program order
+    const bool wave_private = ZKMI_NTT_VARIANT >= 1 && !ROWMAJOR && HN <= 64u && (NTT29_THREADS % 64) == 0;       // block-uniform
     for (int s = (int)l - 1; s >= 0; s--) {
         const uint32_t h = 1u << s;
-        for (uint32_t b = threadIdx.x; b < half_elems; b += NTT_THREADS) {
+        for (uint32_t b = threadIdx.x; b < half_elems; b += NTT29_THREADS) {
             uint32_t c, pr;
             if (ROWMAJOR) { c = b & ((1u << log_ch) - 1); pr = b >> log_ch; }
             else { pr = b & (HN - 1); c = b >> (l - 1); }
@@ -124,20 +137,105 @@ template <class C, bool ROWMAJOR> ZK_DEV void ntt29_tile_stages(const Tile29& p,
             lds29_put<C>(p, e0, x);
             lds29_put<C>(p, e1, y);
         }
-        __syncthreads();
+        if (wave_private) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+        } else __syncthreads();
     }
+    if (wave_private && l) __syncthreads();
+}
+
+#if ZKMI_NTT_VARIANT == 2
+// variant 2: the same stages two at a time (transposed layout): a lane holds the four elements j, j + h/2, j + h, j + 3h/2 of stages s and s - 1
+// (h = 2^s) in registers — stage s pairs (x0, x2), (x1, x3) under U[blk], stage s - 1 pairs (x0, x1) under U[2 blk] and (x2, x3) under U[2 blk + 1] —
+// and touches LDS once per TWO stages. Element for element the operations (product, then lazy butterfly) are those of the radix-2 loop, so the
+// values and their proven bounds are the same; a last single stage remains when l is odd, on the SAME groups (a lane takes the two adjacent pairs
+// 4 pr .. 4 pr + 3 of its column) so that a column stays with the wave that ran its radix-4 steps.
+template <class C> ZK_DEV void ntt29_tile_stages_r4(const Tile29& p, const Tile29& U, uint32_t l, uint32_t log_ch) {
+    const uint32_t N = 1u << l, QN = N >> 2;
+    const bool wave_private = (N >> 1) <= 64u && (NTT29_THREADS % 64) == 0;
+    auto step_sync = [&]() {
+        if (wave_private) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+        } else __syncthreads();
+    };
+    int s = (int)l - 1;
+    if (l >= 2) {
+        const uint32_t quarter_elems = 1u << (l + log_ch - 2);
+        for (; s >= 1; s -= 2) {
+            const uint32_t h = 1u << s, h2 = h >> 1;
+            for (uint32_t q = threadIdx.x; q < quarter_elems; q += NTT29_THREADS) {
+                const uint32_t pr = q & (QN - 1), c = q >> (l - 2);
+                const uint32_t jl = pr & (h2 - 1), blk = pr >> (s - 1);
+                const uint32_t e = c * (N + 1) + ((blk << (s + 1)) | jl);
+                Fp29<C> x0 = lds29_get<C>(p, e), x1 = lds29_get<C>(p, e + h2), x2 = lds29_get<C>(p, e + h), x3 = lds29_get<C>(p, e + h + h2);
+                if (s < (int)l - 1) { const Fp29<C> w = lds29_get<C>(U, blk); x2 = mul29(x2, w); x3 = mul29(x3, w); }
+                ntt29_bfly(x0, x2, Fp29<C>(x2));
+                ntt29_bfly(x1, x3, Fp29<C>(x3));
+                x1 = mul29(x1, lds29_get<C>(U, 2 * blk));
+                x3 = mul29(x3, lds29_get<C>(U, 2 * blk + 1));
+                ntt29_bfly(x0, x1, Fp29<C>(x1));
+                ntt29_bfly(x2, x3, Fp29<C>(x3));
+                lds29_put<C>(p, e, x0); lds29_put<C>(p, e + h2, x1); lds29_put<C>(p, e + h, x2); lds29_put<C>(p, e + h + h2, x3);
+            }
+            step_sync();
+        }
+    }
+    if (s == 0 && l >= 3) {
+        const uint32_t quarter_elems = 1u << (l + log_ch - 2);
+        for (uint32_t q = threadIdx.x; q < quarter_elems; q += NTT29_THREADS) {
+            const uint32_t pr = q & (QN - 1), c = q >> (l - 2);
+            const uint32_t e = c * (N + 1) + (pr << 2);
+            Fp29<C> x0 = lds29_get<C>(p, e), x1 = lds29_get<C>(p, e + 1), x2 = lds29_get<C>(p, e + 2), x3 = lds29_get<C>(p, e + 3);
+            x1 = mul29(x1, lds29_get<C>(U, 2 * pr));
+            x3 = mul29(x3, lds29_get<C>(U, 2 * pr + 1));
+            ntt29_bfly(x0, x1, Fp29<C>(x1));
+            ntt29_bfly(x2, x3, Fp29<C>(x3));
+            lds29_put<C>(p, e, x0); lds29_put<C>(p, e + 1, x1); lds29_put<C>(p, e + 2, x2); lds29_put<C>(p, e + 3, x3);
+        }
+        step_sync();
+    } else if (s == 0) {                                                   // l = 1: one butterfly per column, w = 1
+        const uint32_t half_elems = 1u << (l + log_ch - 1);
+        for (uint32_t b = threadIdx.x; b < half_elems; b += NTT29_THREADS) {
+            const uint32_t e0 = b * (N + 1);
+            Fp29<C> x = lds29_get<C>(p, e0), y = lds29_get<C>(p, e0 + 1);
+            ntt29_bfly(x, y, Fp29<C>(y));
+            lds29_put<C>(p, e0, x);
+            lds29_put<C>(p, e0 + 1, y);
+        }
+        step_sync();
+    }
+    if (wave_private && l) __syncthreads();
+}
+#endif
+// the stage loop of a transposed tile in the variant this build selects
+template <class C> ZK_DEV void ntt29_stages_t(const Tile29& p, const Tile29& U, uint32_t l, uint32_t log_ch) {
+#if ZKMI_NTT_VARIANT == 2
+    ntt29_tile_stages_r4<C>(p, U, l, log_ch);
+#else
+    ntt29_tile_stages<C, false>(p, U, l, log_ch);
+#endif
 }
 
 // IN_REC: the input array holds 48-byte lazy records (the work array; strided passes always write it) instead of the caller's canonical 32-byte elements
 // ---- passes 1 .. p-1 (in place over the FFT digit, columns contiguous in memory) ------------------------------------
-template <class C, bool IN_REC> __global__ void __launch_bounds__(NTT_THREADS)
+template <class C, bool IN_REC> __global__ void __launch_bounds__(NTT29_THREADS)
 k_ntt29_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds29[];
     in += (size_t)blockIdx.y * a.in_bs; out += (size_t)blockIdx.y * a.out_bs;
     const uint32_t l = a.l[a.pass], N = 1u << l, CH = 1u << a.log_ch, E = N << a.log_ch, HN = N >> 1;
-    const Tile29 p(lds29, E);                                             // the tile: E elements
-    const Tile29 U(lds29 + Tile29::words(E), HN);                         // N/2 local twiddles (bit-reversed order)
-    const Tile29 rf(lds29 + Tile29::words(E) + Tile29::words(HN), N);     // N row factors
+    constexpr bool TR = ZKMI_NTT_VARIANT >= 1;                            // transposed tile: element (row j, column c) at c (N+1) + j instead of j CH + c
+    const uint32_t PL = TR ? (N + 1) << a.log_ch : E;
+    const Tile29 p(lds29, PL);                                            // the tile
+    const Tile29 U(lds29 + Tile29::words(PL), HN);                        // N/2 local twiddles (bit-reversed order)
+    const Tile29 rf(lds29 + Tile29::words(PL) + Tile29::words(HN), N);    // N row factors
     uint32_t log_S = 0;
     for (uint32_t m = a.pass + 1; m < a.n_pass; m++) log_S += a.l[m];
     const uint64_t tiles_per_u = (1ull << log_S) >> a.log_ch;
@@ -146,7 +244,7 @@ k_ntt29_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     const bool has_fac = (a.pass > 0) || (a.rowinc != nullptr);
     if (has_fac) {
         const uint64_t K = a.pass > 0 ? ntt_digit_reverse(a, u, 0, a.pass) : 0;
-        for (uint32_t j = threadIdx.x; j < N; j += NTT_THREADS) {
+        for (uint32_t j = threadIdx.x; j < N; j += NTT29_THREADS) {
             Fp29<C> f;
             if (a.pass > 0) {
                 const uint64_t e = (((uint64_t)j * K) << log_S) & ((1ull << a.log_n) - 1);
@@ -156,26 +254,26 @@ k_ntt29_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
             lds29_put<C>(rf, j, f);
         }
     }
-    for (uint32_t k = threadIdx.x; k < HN; k += NTT_THREADS) lds29_put<C>(U, k, load29_packed<C>(a.LT + (size_t)k * C::N));
+    for (uint32_t k = threadIdx.x; k < HN; k += NTT29_THREADS) lds29_put<C>(U, k, load29_packed<C>(a.LT + (size_t)k * C::N));
     __syncthreads();
-    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT29_THREADS) {
         const uint32_t c = idx & (CH - 1), j = idx >> a.log_ch;
         const uint64_t src = base + ((uint64_t)j << log_S) + c;
         Fp29<C> x = IN_REC ? rec29_load<C>(in, src) : load29_packed<C>(in + src * C::N);
         if (has_fac) x = mul29(x, lds29_get<C>(rf, j));
-        lds29_put<C>(p, idx, x);
+        lds29_put<C>(p, TR ? c * (N + 1) + j : idx, x);
     }
     __syncthreads();
-    ntt29_tile_stages<C, true>(p, U, l, a.log_ch);
-    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+    if constexpr (TR) ntt29_stages_t<C>(p, U, l, a.log_ch); else ntt29_tile_stages<C, true>(p, U, l, a.log_ch);
+    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT29_THREADS) {
         const uint32_t c = idx & (CH - 1), k = idx >> a.log_ch;
         const uint32_t j = __brev(k) >> (32 - l);
-        rec29_store<C>(out, base + ((uint64_t)k << log_S) + c, lds29_get<C>(p, (j << a.log_ch) + c));
+        rec29_store<C>(out, base + ((uint64_t)k << log_S) + c, lds29_get<C>(p, TR ? c * (N + 1) + j : (j << a.log_ch) + c));
     }
 }
 
 // ---- last pass: contiguous j_p runs in, natural order out, canonical bytes ------------------------------------------------
-template <class C, bool IN_REC> __global__ void __launch_bounds__(NTT_THREADS)
+template <class C, bool IN_REC> __global__ void __launch_bounds__(NTT29_THREADS)
 k_ntt29_pass_last(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds29[];
     in += (size_t)blockIdx.y * a.in_bs; out += (size_t)blockIdx.y * a.out_bs;
@@ -193,10 +291,10 @@ k_ntt29_pass_last(const uint32_t* in, uint32_t* out, NttPassArgs a) {
         Krest = ntt_digit_reverse(a, r, 1, a.n_pass - 2);
         log_S1 = a.log_n - l1;
     }
-    for (uint32_t k = threadIdx.x; k < HN; k += NTT_THREADS) lds29_put<C>(U, k, load29_packed<C>(a.LT + (size_t)k * C::N));
+    for (uint32_t k = threadIdx.x; k < HN; k += NTT29_THREADS) lds29_put<C>(U, k, load29_packed<C>(a.LT + (size_t)k * C::N));
     Fp29<C> sc;
     if (a.scale) sc = load29_packed<C>(a.scale);
-    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT29_THREADS) {
         const uint32_t j = idx & (N - 1), c = idx >> l;
         const uint64_t addr = multi ? (((c0 + c) << log_S1) + (r << l) + j) : j;
         Fp29<C> x = IN_REC ? rec29_load<C>(in, addr) : load29_packed<C>(in + addr * C::N);
@@ -209,8 +307,8 @@ k_ntt29_pass_last(const uint32_t* in, uint32_t* out, NttPassArgs a) {
         lds29_put<C>(p, c * (N + 1) + j, x);
     }
     __syncthreads();
-    ntt29_tile_stages<C, false>(p, U, l, a.log_ch);
-    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+    ntt29_stages_t<C>(p, U, l, a.log_ch);
+    for (uint32_t idx = threadIdx.x; idx < E; idx += NTT29_THREADS) {
         const uint32_t c = idx & (CH - 1), k = idx >> a.log_ch;
         const uint32_t j = l ? (__brev(k) >> (32 - l)) : 0u;
         const uint64_t K = (c0 + c) + (Krest << l1);
