@@ -194,6 +194,23 @@ def reference_wasm_same_box(proto, cases, curve="bn128", budget_s=200.0, warm=No
             "runs": runs, "at_bench_size": next((x for x in done if x["log_n"] == cases[-1][0]), None)}
 
 
+def _plonk_same_box_into(base, same_box, proto, lg):
+    """cpu_baseline of a PLONK / FFLONK line from the same-box reference run: the largest domain that was timed, scaled LINEARLY to the bench domain"""
+    if not same_box:
+        return
+    base.setdefault("reference_wasm", {})
+    base["reference_wasm"] = dict(base["reference_wasm"] or {}, same_box=same_box)
+    done = [x for x in same_box.get("runs", []) if "ms_per_proof" in x]
+    if not done:
+        return
+    big = max(done, key=lambda x: x["log_n"])
+    scale = 2.0 ** (lg - big["log_n"])
+    base.update({"value": round(1e3 / (big["ms_per_proof"] * scale), 6), "cores": big["threads"], "kind": "reference",
+                 "bit_identical_to_device_proof": all(x.get("bit_identical_to_device_proof") for x in done),
+                 "sample": f"ONE snarkjs {proto}.prove (the reference's bundle: WASM + {big['threads']} worker threads, Node) at the domain 2^{big['log_n']} on this box's host: {big['ms_per_proof'] / 1e3:.1f} s"
+                           + (f", scaled linearly x{scale:g} to 2^{lg} (measured once at 2^18 / 2^20 by hand: profiles/r05_plonk_vs_reference.txt)" if scale != 1 else "")})
+
+
 def reference_wasm_baseline_plonk(proto, lg):
     """The reference's own plonk.prove / fflonk.prove (WASM + worker threads), measured in the BUILD container and committed under profiles/.
     Sizes are PLONK DOMAINS (what --log-n means here). PLONK: r04 measured domains 2^11 and 2^16 (and 2^20 when the long run finished) on keys from
@@ -428,9 +445,24 @@ def bench_plonk(args, rank, world, dist, torch):
             "proofs_in_flight": 2 if two else 1, "host_gc": "Python's cyclic collector is off inside the timed region (timeit's convention)", "latency_ms_single_proof": round(min(lat) * 1e3, 3) if lat else None, "latency_ms_serial_proofs": [round(x * 1e3, 2) for x in lat], "timed_region_ms_per_proof": [round(x * 1e3, 2) for x in per_proof],
             "latency_ms_with_witness_upload": [round(x * 1e3, 2) for x in lat_up],
             "public_signal": res["publicSignals"][0][:24] + "..."}
+        same_box = None
+        if world == 1 and not args.no_cpu_baseline and not args.no_ref_wasm:
+            # the reference's own prover on this box's host cores at bounded domains (a reference PLONK proof at 2^20 takes minutes: mostly single-threaded
+            # JS loops), its proofs for the same draws compared with the device's; scaled linearly to the bench size and labelled as such
+            mod = fflonk if proto == "fflonk" else plonk
+            nd = 9 if proto == "fflonk" else 11
+            fld = plonk._Field(0) if hasattr(plonk, "_Field") else fflonk._Field(0)
+            draws = [bytes(fld.mont(4242 + 17 * i)) for i in range(nd)]
+            cases = []
+            for l2 in sorted({min(14, lg), min(16, lg)}):
+                zk2, wt2 = (synth_plonk.make_fflonk(l2, seed=3, additions=args.plonk_additions) if proto == "fflonk" else synth_plonk.make("bn128", l2, seed=3, additions=args.plonk_additions))
+                dev = json.dumps(mod.prove(zk2, wt2, blinding_mont=draws)["proof"], separators=(",", ":"))
+                cases.append((l2, zk2, wt2, draws, dev))
+            same_box = reference_wasm_same_box(proto, cases, budget_s=min(args.ref_wasm_budget, 120.0))
         if world == 1 and not args.no_cpu_baseline and proto == "fflonk":
             out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "reference", "sample": "no live CPU leg for FFLONK: see reference_wasm",
                                    "reference_wasm": reference_wasm_baseline_plonk(proto, lg)}
+            _plonk_same_box_into(out["cpu_baseline"], same_box, proto, lg)
         if world == 1 and not args.no_cpu_baseline and proto == "plonk":
             # CPU port: the Python restatement of src/plonk_prove.js (oracle/plonk_oracle.py, pure-Python field loops, 1 thread) on a
             # small valid key, scaled linearly — the reference's own PLONK prover spends most of its time in single-threaded JS loops too
@@ -454,6 +486,7 @@ def bench_plonk(args, rank, world, dist, torch):
             out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 1, "kind": "port",
                                    "sample": f"one PLONK proof at 2^{slg} constraints by oracle/plonk_oracle.py (pure Python, 1 thread, {dt:.1f} s): used as the in-run parity check only, not scaled to the bench size",
                                    "parity_on_sample": bool(got["proof"] == ref_proof), "reference_wasm": reference_wasm_baseline_plonk(proto, lg)}
+            _plonk_same_box_into(out["cpu_baseline"], same_box, proto, lg)
         out["box_calibration"] = box_calibration(zkmi.lib())
         drain_c_stdout_to_stderr()
         print(json.dumps(out), flush=True)

@@ -501,3 +501,46 @@ def test_plonk_full_size_proof_verifies(env, curve, lg):
     bad = dict(res["proof"]); bad["eval_a"] = str((int(bad["eval_a"]) + 1) % cx.r)
     assert not V.verify_known_tau(vk, res["publicSignals"], bad, tau)
     assert not V.verify_known_tau(vk, [str((int(res["publicSignals"][0]) + 1) % cx.r)], res["proof"], tau)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("proto,lg", [("plonk", 14), ("fflonk", 12)])
+def test_device_prover_equals_the_reference_wasm_prover_on_this_box(env, proto, lg):
+    """The reference's OWN prover (snarkjs bundle staged in oracle/_ref: WASM + worker threads, single-threaded JS loops) on the box's host cores
+    against the device-resident prover, on a synthetic valid key with addition gates, same blinding draws: proof JSON and public signals byte for
+    byte. Beyond the reference-generated fixtures (n <= 2048) this is the largest size a PLONK / FFLONK proof is compared with the reference itself
+    inside the suite (a reference plonk.prove takes ~1 s per 2^10 rows; tools/lab/r5_plonk_vs_ref.py runs 2^16 / 2^18 as a one-off,
+    profiles/r05_plonk_vs_reference.txt)."""
+    import hashlib
+    import json
+    import shutil
+    import subprocess
+    import tempfile
+    import synth_plonk
+    zkmi, plonk, f, cx = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    node, bundle = shutil.which("node"), os.path.join(root, "oracle", "_ref", "build", "snarkjs.min.js")
+    if node is None or not os.path.exists(bundle):
+        pytest.fail("node or oracle/_ref is absent on this box: `make -C oracle _ref` stages the reference's bundle in the build container and gpurun ships it")
+    if proto == "plonk":
+        zkey, wtns = synth_plonk.make("bn128", lg, seed=21, additions=2)
+        n_draws, mod = 11, plonk
+    else:
+        from snarkjs_amd import fflonk as mod
+        zkey, wtns = synth_plonk.make_fflonk(lg, seed=21, additions=2)
+        n_draws = 9
+    blind = [bytes(f.mont(77000 + 131 * i)) for i in range(n_draws)]
+    got = mod.prove(zkey, wtns, blinding_mont=blind)
+    with tempfile.TemporaryDirectory() as td:
+        zf, wf = os.path.join(td, "k.zkey"), os.path.join(td, "k.wtns")
+        open(zf, "wb").write(zkey)
+        open(wf, "wb").write(wtns)
+        r = subprocess.run([node, "--harmony-optional-chaining", "--harmony-nullish", "--max-old-space-size=16000", os.path.join(root, "tools", "ref_wasm_same_box.js"),
+                            proto, zf, wf, ",".join(b.hex() for b in blind)], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, NTHREADS="16", SNARKJS_REF_BUNDLE=bundle, VERIFY="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["draws_used"] == n_draws and d["verified"] is True
+    sha = lambda o: hashlib.sha256(json.dumps(o, separators=(",", ":")).encode()).hexdigest()
+    assert sha(got["proof"]) == d["proof_json_sha256"], "device proof differs from the reference's WASM proof for the same draws"
+    assert sha(got["publicSignals"]) == d["public_signals_sha256"]
