@@ -93,6 +93,21 @@ def test_unmodified_flow_with_mock_addon():
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@need_node
+@need_bundle
+def test_same_box_reference_tool_reproduces_the_golden_proof():
+    """tools/ref_wasm_same_box.js (bench.py's cpu_baseline leg: the reference's own prover under the worker shim, blinding draws handed to
+    curve.Fr.random) on the reference-generated fixture: the proof hash it reports is the golden one, the reference's verifier accepts"""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_bn128_n1024.json")))
+    zk, wt = (os.path.join(ROOT, "tests", "golden", "groth16_bn128_n1024." + e) for e in ("zkey", "wtns"))
+    r = subprocess.run([NODE] + FLAGS + [os.path.join(ROOT, "tools", "ref_wasm_same_box.js"), "groth16", zk, wt, g["r_mont"] + "," + g["s_mont"]], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, VERIFY="1", NTHREADS="4"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["proof_json_sha256"] == g["proof_sha256"] and d["draws_used"] == 2 and d["verified"] is True and d["threads"] == 4
+
+
 @pytest.mark.gpu
 @need_node
 def test_unmodified_snarkjs_with_real_addon_on_gpu():
