@@ -148,6 +148,35 @@ function spread(src, dst) { if (dst instanceof Uint8Array) { dst.set(src); retur
         check("minPoints: a 64-point fft goes to the addon", (calls.fft || 0) === (before.fft || 0) + 1 && sha(f64) === sha(await saved.fft(x64)));
         unregister(curve);
     }
+    // the permission bits handed to zkmi_msm (include/zkmi.h): default = ZKMI_BASES_CACHE alone (full content hash on every call: the result follows
+    // the bytes passed), immutableBases: true adds ZKMI_BASES_IMMUTABLE (the caller's promise), cacheBases: false / small calls pass 0
+    {
+        const keys = [];
+        const spy = Object.assign({}, mock, { msm(cid, group, bases, scalars, n, sb, key) { keys.push(key); return mock.msm(cid, group, bases, scalars, n, sb, key); } });
+        const nb = 4096, bb = new Uint8Array(nb * 64), sb = new Uint8Array(nb * 32);
+        for (const [opts, want] of [[{}, 1], [{ immutableBases: true }, 3], [{ cacheBases: false }, 0], [{ immutableBases: true, cacheMinPoints: 1 << 20 }, 0]]) {
+            register(curve, Object.assign({ addon: spy }, opts));
+            const r = await curve.G1.multiExpAffine(bb, sb);
+            if (r.__p) { await r.__p; delete r.__p; }
+            unregister(curve);
+            check(`register(${JSON.stringify(opts)}) passes base_cache_key ${want}`, keys[keys.length - 1] === want);
+        }
+    }
+    // a transform of more than 2^Fr.s elements (the reference's "extended" FFT, min.js:1@216148) is forwarded to the saved WASM entry point, not refused:
+    // checked by lowering Fr.s for the duration of one call (a real 2^29-element buffer is 16 GiB) and watching which side is called
+    {
+        let origCalls = 0;
+        const realFft = curve.Fr.fft;
+        curve.Fr.fft = async function () { origCalls++; return new Uint8Array(arguments[0].byteLength); };       // stands in for the WASM original
+        register(curve, { addon: mock });
+        const before = calls.fft || 0, sKeep = curve.Fr.s;
+        curve.Fr.s = 3;
+        const out = await curve.Fr.fft(new Uint8Array(16 * 32));
+        curve.Fr.s = sKeep;
+        check("Fr.fft of 2^(s+1) elements goes to the saved original, not to the addon", origCalls === 1 && (calls.fft || 0) === before && out.byteLength === 16 * 32);
+        unregister(curve);
+        curve.Fr.fft = realFft;
+    }
     console.log(fails ? `${fails} FAILED` : "ALL OK");
     process.exit(fails ? 1 : 0);
 })().catch((e) => { console.log("ERROR", e); process.exit(2); });
