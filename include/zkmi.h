@@ -336,8 +336,10 @@ int zkmi_calibrate_box(double* mul29_gmul_per_s, double* gather128_gb_per_s);
  * instruction fetch beyond the 64 KB instruction cache on this box (the accumulation loops of the 14-limb curve are that large). */
 int zkmi_calibrate_code_fetch(double* small_loop_gmul_per_s, double* big_loop_gmul_per_s);
 /* Which MSM kernels run their compact instantiation (products called instead of inlined: loops that fit the instruction cache) on this box:
- * bit 0 G1 accumulation of the 14-limb curve, 1 its G2 accumulation, 2 G1 row/column sums, 3 Fq2 row/column sums by the generic kernel, 4 PLONK's quotient kernel (called products are its default everywhere); decided once from the probe
- * above (all bits when big / small < 0.85) unless ZKMI_COMPACT_CODE=<mask> is set. Results are bit-identical either way. -1: no device. */
+ * bit 0 G1 accumulation of the 14-limb curve, 1 its G2 accumulation, 2 G1 row/column sums, 3 Fq2 row/column sums by the generic kernel, 4 PLONK's quotient
+ * numerator by the 32-bit kernels with called products; decided once from the probe above — bits 1, 2, 3 when big / small < 0.85 (r05: the loops behind bits 0
+ * and 4 fit the instruction cache since r04 and measured faster inlined on such a box) — unless ZKMI_COMPACT_CODE=<mask> is set. Results are bit-identical
+ * either way. -1: no device. */
 int zkmi_compact_code(void);
 
 /* ---- utilities --------------------------------------------------------------------------------------------------- */

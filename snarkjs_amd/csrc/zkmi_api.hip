@@ -57,7 +57,11 @@ int compact_code() {
     if (getenv("ZKMI_COMPACT_CODE")) return g_compact_code = atoi(getenv("ZKMI_COMPACT_CODE")) & 31;
     double small = 0, big = 0;
     if (zkmi_calibrate_code_fetch(&small, &big) != ZKMI_OK || small <= 0) return g_compact_code = 0;
-    return g_compact_code = (big / small < 0.85) ? 31 : 0;
+    // r05 (profiles/r05_slow_fetch_box_ab.txt, a box with ratio 0.80): since r04 shrank the inlined loops, the 14-limb G1 accumulation (38 KB loop) and
+    // PLONK's 29-bit quotient kernels (41-52 KB per part) fit the instruction cache and run FASTER inlined on such a box than with called products
+    // (BLS12-381 38.8-39.1 against 35.5-35.7 proofs/s, PLONK 38.2-38.3 against 36.7-37.1); the 14-limb G2 accumulation (118 KB) and the row / column
+    // sums still want the called products there (all inlined: 28.5 proofs/s). So a slow-fetch box gets bits 1, 2, 3 — not 0 and 4.
+    return g_compact_code = (big / small < 0.85) ? 14 : 0;
 }
 extern "C" int zkmi_compact_code(void) { return g_ctx.ready ? compact_code() : -1; }
 int dev_alloc_big(void** p, size_t bytes) {

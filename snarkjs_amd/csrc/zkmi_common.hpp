@@ -85,7 +85,8 @@ int select_pipe(int p);
 // What changes on a box that fetches instructions slowly beyond the instruction cache — bit 0: G1 accumulation of the 14-limb curve runs its
 // Compact instantiation (field29.cuh), 1: the same for its G2 accumulation, 2: Compact G1 row/column sums of that curve, 3: the Fq2 row/column
 // sums go back to the generic 32-bit kernel, 4: PLONK's quotient numerator by the 32-bit kernels with called products (8 - 12 KB per part) instead of the inlined 29-bit ones (41 - 52 KB). ZKMI_COMPACT_CODE=<mask> fixes it; otherwise the box is probed once
-// (zkmi_calibrate_code_fetch: a 210 KB loop against a 17 KB loop of the same products) and every bit is set when the big loop runs below 0.85.
+// (zkmi_calibrate_code_fetch: a 210 KB loop against a 17 KB loop of the same products) and bits 1, 2, 3 are set when the big loop runs below 0.85 (r05: bits 0 and 4 no longer —
+// those loops fit the instruction cache since r04 and measured faster inlined on a slow-fetch box, profiles/r05_slow_fetch_box_ab.txt).
 int compact_code();
 int dev_alloc_big(void** p, size_t bytes);                // hipMalloc; ZKMI_CONTIG=1: physically contiguous VRAM first (zkmi_api.hip: measured slower)
 int ensure_aux_stream();                                  // creates Ctx::aux_stream (+ aux_ev) on first use                                     // make pipeline slot p (0 | 1) the active one
