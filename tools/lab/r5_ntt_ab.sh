@@ -1,5 +1,6 @@
 #!/bin/bash
-# r05 A/B of the 29-bit NTT passes: the shipped library against variant builds (ZKMI_BUILD_VARIANT=<v> -> snarkjs_amd/libzkmi_<v>.so, loaded with ZKMI_LIB):
+# r05 A/B of the 29-bit NTT passes: the shipped library against variant builds (ZKMI_BUILD_VARIANT=<v> ZKMI_EXTRA_FLAGS=-DZKMI_NTT_VARIANT=1|2 python -m snarkjs_amd.build
+# -> snarkjs_amd/libzkmi_<v>.so, loaded with ZKMI_LIB; csrc/ntt29.cuh says what the variants are):
 # standalone transforms (tools/lab/r4_ntt_probe.py: device events, sha of the last output — must be equal across builds), the all-sizes parity test,
 # and the in-proof chain / proofs per second of a short bench run. usage: tools/lab/r5_ntt_ab.sh out_dir variant...
 out=$1; shift
