@@ -18,9 +18,28 @@ template <int NW> static int msm_launch_digits(const uint8_t* d_scalars, const M
 }
 
 // Two-level LDS radix partition (msm.cuh: k_rsort_*): same outputs (counts, starts, sorted) without global atomics.
+// lb = bits of the low key (2^lb buckets per partition); fused_cap != 0: partitions of at most that many pairs are finished by k_rsort_part.
+// pairs staged in LDS by k_rsort_part, by low-key width: 2^10-bucket partitions 36 000 (4 B each + 2^lb + 1024 words = 152 KB: one block per CU),
+// 2^9-bucket partitions 15 000 (66 KB: two blocks per CU, and room beside an LDS-parked G2 accumulation block)
+static uint32_t rsort_part_cap(uint32_t lb) { return lb == 10 ? 36000u : 15000u; }
+static bool rsort_fused_on() {
+    static const bool on = !(getenv("ZKMI_RSORT_FUSED") && atoi(getenv("ZKMI_RSORT_FUSED")) == 0);
+    return on;
+}
+// low-key bits for this shape: 10 (ZKMI_RSORT_LB=9: 9) when the fused level 2 can take a typical partition (entries / partitions <= 0.9 cap), else 11
+static uint32_t rsort_low_bits(const MsmShape& sh) {
+    static const uint32_t want = getenv("ZKMI_RSORT_LB") ? (uint32_t)atoi(getenv("ZKMI_RSORT_LB")) : 10u;
+    const size_t total = (size_t)sh.W * sh.nb, entries = (size_t)sh.Wd * sh.n;
+    if (rsort_fused_on() && (want == 9 || want == 10) && (uint32_t)sh.c > want && (total >> want) <= RSORT_MAX_PARTS && (total >> want) >= 1 &&
+        entries / (total >> want) <= (size_t)rsort_part_cap(want) * 9 / 10)
+        return want;
+    return RSORT_LOW_BITS;
+}
 template <int NW> static int msm_launch_digits_radix(const uint8_t* d_scalars, const MsmShape& sh, uint32_t* counts, uint32_t* starts, uint32_t* sorted,
                                                      const uint32_t* dropmask, hipStream_t st) {
-    const uint32_t total = (uint32_t)sh.W * sh.nb, P = total >> RSORT_LOW_BITS;
+    const uint32_t lb = rsort_low_bits(sh);
+    const uint32_t fused_cap = (lb < (uint32_t)RSORT_LOW_BITS) ? rsort_part_cap(lb) : 0u;
+    const uint32_t total = (uint32_t)sh.W * sh.nb, P = total >> lb;
     const uint32_t nblk = (uint32_t)((sh.n + RSORT_TILE - 1) / RSORT_TILE);
     const size_t nbh = (size_t)P * nblk + 1, emax = (size_t)sh.Wd * sh.n, nch_max = emax / RSORT_CHUNK + P + 1;
     uint32_t *bh, *part, *ck, *h2;
@@ -34,15 +53,21 @@ template <int NW> static int msm_launch_digits_radix(const uint8_t* d_scalars, c
     uint32_t *pchunk0 = ck + 3 * nch_max, *meta = pchunk0 + P + 2;
     ZK_TRY(ws_get("msm.rs_h2", nch_max * RSORT_BINS * 4, (void**)&h2));
     ZK_HIP(hipMemsetAsync(bh + nbh - 1, 0, 4, st));
-    hipLaunchKernelGGL((k_rsort_hist1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, bh);
+    hipLaunchKernelGGL((k_rsort_hist1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, lb, bh);
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(nsp), dim3(256), 0, st, bh, (uint32_t)nbh, part);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, st, part, nsp);
     hipLaunchKernelGGL(k_msm_scan_final, dim3(nsp), dim3(256), 0, st, bh, (uint32_t)nbh, part, bhoff);
-    hipLaunchKernelGGL((k_rsort_scatter1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, bhoff, tmp);
-    hipLaunchKernelGGL(k_rsort_chunks, dim3(1), dim3(1024), 0, st, bhoff, P, nblk, pchunk0, ck, meta);
+    hipLaunchKernelGGL((k_rsort_scatter1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, lb, bhoff, tmp);
+    hipLaunchKernelGGL(k_rsort_chunks, dim3(1), dim3(1024), 0, st, bhoff, P, nblk, fused_cap, pchunk0, ck, meta);
+    if (fused_cap) {
+        const size_t lds = ((size_t)(1u << lb) + 1024 + fused_cap) * 4;
+        static bool attr = false;
+        if (!attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_rsort_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)RSORT_BINS + 1024 + rsort_part_cap(10)) * 4))); attr = true; }
+        hipLaunchKernelGGL(k_rsort_part, dim3(P), dim3(1024), lds, st, tmp, bhoff, nblk, lb, fused_cap, counts, starts, sorted);
+    }
     hipLaunchKernelGGL(k_rsort_hist2, dim3((unsigned)nch_max), dim3(256), 0, st, tmp, ck, meta, h2);
-    hipLaunchKernelGGL(k_rsort_scan2, dim3(P), dim3(1024), 0, st, bhoff, nblk, pchunk0, h2, counts, starts);
-    hipLaunchKernelGGL(k_rsort_scatter2, dim3((unsigned)nch_max), dim3(256), 0, st, tmp, ck, meta, h2, starts, sorted);
+    hipLaunchKernelGGL(k_rsort_scan2, dim3(P), dim3(1024), 0, st, bhoff, nblk, lb, fused_cap ? 1u : 0u, pchunk0, h2, counts, starts);
+    hipLaunchKernelGGL(k_rsort_scatter2, dim3((unsigned)nch_max), dim3(256), 0, st, tmp, ck, meta, h2, starts, lb, sorted);
     return ZKMI_OK;
 }
 static bool msm_use_radix(const MsmShape& sh) {
