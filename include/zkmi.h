@@ -18,6 +18,12 @@
  *     entry point fails with ZKMI_ERR_NO_DEVICE.
  *   - "pages": a logical buffer given as an array of (pointer,length) host segments, because ffjavascript's
  *     BigBuffer (min.js:1@183423) keeps > 1 GiB buffers as a list of <= 1 GiB Uint8Arrays.
+ *   - ONE CALLER PER PROCESS. The library keeps one context per process (one process per GPU): the active pipeline slot, its streams
+ *     and its scratch buffers are process-global state, and an entry point may swap them while it runs. Calls must therefore be
+ *     serialised by the host: the N-API addon takes a mutex around every entry point (main thread and libuv pool threads alike),
+ *     the Python mirror a threading.RLock (snarkjs_amd/zkmi.py). zkmi_last_error() is per thread.
+ *   - statistics, calibration probes, synthetic-base generators and tuning knobs (no reference counterpart) are declared in
+ *     zkmi_diag.h, not here.
  */
 #ifndef ZKMI_H
 #define ZKMI_H
@@ -95,20 +101,9 @@ int zkmi_memset_dev(void* d_dst, int value, size_t bytes);
 int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t n, size_t scalar_bytes,
              uint64_t base_cache_key, uint8_t* out_jacobian);
 int zkmi_release_bases(uint64_t base_cache_key);
-/* resident tables / their bytes / buffers seen once (no table yet) — for tests and diagnostics; any pointer may be NULL */
-int zkmi_base_cache_stats(uint64_t* n_tables, uint64_t* table_bytes, uint64_t* n_seen);
 /* Same with bases and scalars already resident in device memory (bench.py, fused pipelines). */
 int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t scalar_bytes,
                  uint8_t* out_jacobian);
-/* Device time (ms, HIP events on the library stream) of the bucket-accumulation kernel of the last MSM that used job
- * slot `slot`: zkmi_msm / zkmi_msm_dev use slot 0; zkmi_groth16_prove uses 0..4 = A, B1, B2, C, H. -1 if never run. */
-double zkmi_msm_accum_ms(int slot);
-/* Diagnostics for the roofline accounting (bench.py int_alu): with zkmi_msm_stats(1) every bucket-accumulation launch is followed by a
- * small kernel that counts the mixed additions the launch performed (list entries of the digit sort whose base is not skipped and not the
- * point at infinity); zkmi_msm_accum_additions(slot) returns the count of the last MSM that used the job slot once the stream has been
- * synchronised (-1: never counted). Off by default; costs one pass over the sorted lists (~20 us at 2^20 terms) per MSM. */
-int zkmi_msm_stats(int enable);
-double zkmi_msm_accum_additions(int slot);
 /* Resident bases with pre-computed window tables T[k][i] = 2^(c*k) * P_i (static per zkey / SRS: src/groth16_prove.js:84-100,
  * src/polynomial/polynomial.js:970-977 slices the same PTau for every commitment). Build once from n device-resident affine
  * points; each MSM then uses the first k <= n bases with k scalars of at most 32 bytes. */
@@ -122,8 +117,6 @@ int zkmi_msm_table_release(uint64_t handle);
 /* Curve, group and number of resident points of a table (any pointer may be NULL): a binding sizes the result buffers of the two calls above
  * — 3*group*n8q bytes per MSM — from the TABLE instead of trusting its caller. */
 int zkmi_msm_table_info(uint64_t handle, int* curve, int* group, size_t* n);
-/* Window width used for n terms (tuning knob; 0 restores the built-in table). */
-int zkmi_msm_set_window_bits(int c);
 
 /* ---- Fr.fft / Fr.ifft ------------------------------------------------------------------------------------------- */
 /* curve.Fr.fft / curve.Fr.ifft (min.js:1@215859; kernels frm_fftMix/_fftJoin/_fftFinal @103755):
@@ -171,8 +164,30 @@ typedef struct zkmi_groth16_zkey {
      * reference gets the same protection from bounds-checked JS buffers). The vk_* points are 2*n8q (G1) / 4*n8q (G2) bytes. */
     size_t bases_a_len, bases_b1_len, bases_b2_len, bases_c_len, bases_h_len;
 } zkmi_groth16_zkey;
-/* Upload the proving key under `zkey_cache_key` (!= 0): base tables + CSR form of the coefficient section. */
+/* Upload the proving key under `zkey_cache_key` (!= 0): base tables + the coefficient section as a length-sorted sliced layout. */
 int zkmi_groth16_load(const zkmi_groth16_zkey* zkey, uint64_t zkey_cache_key);
+/* The same with every bulk section given as PAGES: what the reference holds after binFileUtils.readSection (src/groth16_prove.js:29-33, :57-59,
+ * :84-100) — a Uint8Array below 2^30 bytes, a BigBuffer of <= 1 GiB pages from there on (sections 4-9 of a 2^24-constraint key are 1 - 2 GB
+ * each; one Node buffer ends at 2 GiB - 1). Section lengths are the page totals; they are checked against the header like the flat form's.
+ * A page whose POINTER is NULL is a gap of `len` bytes the caller did not read: zkmi_groth16_load_shard_paged only touches the byte ranges of
+ * its own variables / H bases, so a shard process reads just those from the file (js/groth16_shards.js) and passes the rest as gaps; a load
+ * that needs a byte inside a gap fails with ZKMI_ERR_INVALID. The coefficient section is needed whole by every loader. */
+typedef struct zkmi_groth16_zkey_paged {
+    int curve;
+    uint32_t n_vars, n_public, domain_size;
+    zkmi_pages coeffs, bases_a, bases_b1, bases_b2, bases_c, bases_h;      /* zkey sections 4, 5, 6, 7, 8, 9 */
+    const uint8_t *vk_alpha_1, *vk_beta_1, *vk_beta_2, *vk_delta_1, *vk_delta_2;
+} zkmi_groth16_zkey_paged;
+int zkmi_groth16_load_paged(const zkmi_groth16_zkey_paged* zkey, uint64_t zkey_cache_key);
+int zkmi_groth16_load_shard_paged(const zkmi_groth16_zkey_paged* zkey, uint64_t zkey_cache_key, uint32_t var_lo, uint32_t var_hi, uint32_t h_lo, uint32_t h_hi);
+/* zkmi_groth16_prove (below) with the paged descriptor: same key semantics (load on first use, descriptor checked against a resident key, key 0 =
+ * load, prove, release). */
+int zkmi_groth16_prove_paged(const zkmi_groth16_zkey_paged* zkey, uint64_t zkey_cache_key, const uint8_t* witness, size_t witness_len,
+                             const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
+/* buildABC1 (src/groth16_prove.js:147-187) alone, on a resident key: A_T, B_T, C_T = A_T * B_T (domain x 32 bytes each, Montgomery) from the
+ * witness in device memory (normal form); any output may be NULL. Rows are balanced by length: a 10^5-term row of a real circuit is spread
+ * over thousands of lanes (csrc/groth16.hip). zkmi_last_kernel_ms() = the device time of the three kernels. */
+int zkmi_groth16_build_abc_dev(uint64_t zkey_cache_key, const void* d_witness, void* d_a, void* d_b, void* d_c);
 /* One proof. zkey_cache_key != 0: the key is loaded on first use (zkey may be NULL afterwards) and stays resident; a descriptor
  * given together with an already resident key must describe the same circuit (curve, nVars, nPublic, domainSize, nCoef), else the
  * call fails with ZKMI_ERR_INVALID — release the key first to replace it. zkey_cache_key == 0: load, prove, release.
@@ -224,12 +239,6 @@ int zkmi_groth16_chains_dev(uint64_t zkey_cache_key, const void* d_witness, unsi
 int zkmi_groth16_sums_w_dev(uint64_t zkey_cache_key, const void* d_witness);
 int zkmi_groth16_sums_h_dev(uint64_t zkey_cache_key, const void* d_witness, const void* d_h_scalars, uint8_t* sums);
 int zkmi_groth16_finish(uint64_t zkey_cache_key, const uint8_t* sums, const uint8_t* r_mont, const uint8_t* s_mont, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
-/* Device time (ms, HIP events) of the stages of the last proof, in order: buildABC, 6 NTTs, joinABC, sort(witness),
- * bucket accumulation of MSM B2, B1 (+ the second witness sort), A, C, sort(H scalars), accumulation of MSM H, batched G1 bucket reductions (the B2
- * reduction runs on a second stream underneath the G1 accumulations).
- * Writes min(n, ZKMI_GROTH16_STAGES) values. */
-#define ZKMI_GROTH16_STAGES 11
-int zkmi_groth16_stage_ms(double* out, int n);
 
 /* ---- PLONK prover: the per-element loops of src/plonk_prove.js and src/polynomial/polynomial.js as device kernels ---------
  * (SURVEY.md 8a rows a10-a12). All buffers are DEVICE pointers to Montgomery Fr elements; 32-byte constants are host
@@ -328,28 +337,8 @@ int zkmi_group_batch_apply_key_dev(int curve, int group, const void* d_in, void*
 int zkmi_group_convert(int curve, int group, int kind, zkmi_pages in, uint8_t* const* out_ptr, const size_t* out_len, int n_out_pages, size_t n);
 int zkmi_group_convert_dev(int curve, int group, int kind, const void* d_in, void* d_out, size_t n);
 
-/* Two short probes of the device a run landed on, for reading benchmark lines (no reference counterpart): Montgomery products per second on
- * 29-bit limbs (two dependent chains per lane, 8 workgroups per CU: about 150 G products/s on a healthy MI355X) and 16 dependent random 128-byte
- * gathers per lane over a 2 GiB table (about 6 TB/s on a healthy box). */
-int zkmi_calibrate_box(double* mul29_gmul_per_s, double* gather128_gb_per_s);
-/* Third probe: the same product chain as straight-line loops of ~17 KB and ~210 KB of code at two waves per SIMD; big / small < 1 is the cost of
- * instruction fetch beyond the 64 KB instruction cache on this box (the accumulation loops of the 14-limb curve are that large). */
-int zkmi_calibrate_code_fetch(double* small_loop_gmul_per_s, double* big_loop_gmul_per_s);
-/* Which MSM kernels run their compact instantiation (products called instead of inlined: loops that fit the instruction cache) on this box:
- * bit 0 G1 accumulation of the 14-limb curve, 1 its G2 accumulation, 2 G1 row/column sums, 3 Fq2 row/column sums by the generic kernel, 4 PLONK's quotient
- * numerator by the 32-bit kernels with called products; decided once from the probe above — bits 1, 2, 3 when big / small < 0.85 (r05: the loops behind bits 0
- * and 4 fit the instruction cache since r04 and measured faster inlined on such a box) — unless ZKMI_COMPACT_CODE=<mask> is set. Results are bit-identical
- * either way. -1: no device. */
-int zkmi_compact_code(void);
 
 /* ---- utilities --------------------------------------------------------------------------------------------------- */
-/* Synthetic base table of SURVEY.md §8d: P_i = (f*g^i mod r)*G written to device memory as affine Montgomery points
- * (what G.batchApplyKey(G repeated n, Fr.e(f), Fr.e(g)) returns).  For benchmarks and tests. */
-int zkmi_gen_geometric_bases_dev(int curve, int group, size_t n, uint64_t f, uint64_t g, void* d_out);
-/* P_i = k_i * G for n caller-supplied scalars (device, 32-byte little-endian integers, normal form), affine Montgomery points out:
- * the base sections of synthetic VALID proving keys built from a known trapdoor (src/zkey_new.js:182-201, :338-502
- * compute the same points from a ptau file). For tests and benchmarks. */
-int zkmi_gen_bases_from_scalars_dev(int curve, int group, const void* d_scalars, size_t n, void* d_out);
 /* Page-lock caller-owned host memory for device transfers (hipHostRegister): shared-memory regions through which the processes of a
  * multi-GPU proof exchange chain outputs (js/groth16_shards.js). Optional: transfers from unregistered memory work, slower. */
 int zkmi_host_register(void* host_ptr, size_t bytes);
@@ -390,8 +379,6 @@ int zkmi_to_affine(int curve, int group, const uint8_t* jacobian, uint8_t* affin
 /* G.add on host for two Jacobian points (O(1)): folds the per-GPU partial results of a sharded MSM
  * (reference: host-side `G.add` over chunk results, min.js:1@214651). Needs no device. */
 int zkmi_point_add(int curve, int group, const uint8_t* a_jacobian, const uint8_t* b_jacobian, uint8_t* out_jacobian);
-/* Wall-clock-free device timing of the last call of each kind, in milliseconds (HIP events on the library stream). */
-double zkmi_last_kernel_ms(void);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,7 @@ def _depfile(obj):
 def build(verbose=False, force=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".hpp"))]
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "zkmi.h"))
+    headers += [os.path.join(os.path.dirname(HERE), "include", h) for h in ("zkmi.h", "zkmi_diag.h")]
     units = [u for u in UNITS if os.path.exists(os.path.join(CSRC, u))]
     jobs = []
     for u in units:

@@ -18,10 +18,24 @@
 
 namespace zkmi {
 
-// ---- coefficient section -> CSR -------------------------------------------------------------------------------------
+// ---- coefficient section -> sliced ELL with split rows (buildABC1, src/groth16_prove.js:147-187) ----------------------------------------
 // zkey section 4: u32 nCoef, then nCoef x { u32 matrix, u32 constraint, u32 signal, Fr value (x R^2) } (44-byte records,
-// src/zkey_utils.js:108-118 / src/zkey_new.js:320-333). Row id = matrix * domain + constraint.
+// src/zkey_utils.js:108-118 / src/zkey_new.js:320-333). Row id = matrix * domain + constraint: A_T | B_T are one vector of 2 * domain rows.
+//
+// The rows of a compiled circuit are heavy-tailed: nine in ten hold one term, a few hold 10^3 - 10^5 (Num2Bits, packing, long linear
+// combinations). One lane per constraint (r01 - r05) leaves a 10^5-term row to ONE lane — 10^5 dependent gathers and products while the rest of
+// the chip idles. Layout built once per key, on the device:
+//   * every row is cut into SEGMENTS of at most ABC_SEG terms (an empty row is one segment of length 0: it writes the zero);
+//   * the segments are sorted by length, longest first (stable counting sort: per-wave bin counts, one flat scan, ranks), and every 64
+//     consecutive ones form a SLICE, as wide as its first = longest segment (SELL-64-sigma with sigma = everything): lanes of a wave run
+//     the same trip count, and term k of lane l of a slice lies at (slice_off + k) * 64 + l — the wave reads 2 KB of values and 256 B of
+//     signal ids contiguously per step;
+//   * a segment of a single-segment row writes its sum straight into A_T | B_T; the segments of a cut row write partial sums, which one wave
+//     per such row adds up afterwards (k_abc_long); C_T = A_T * B_T is an element-wise pass (k_abc_mulc).
+// Field addition is exact, so the order in which a row's terms meet its segments (atomic cursors below) does not change a single bit.
 constexpr int COEF_REC_WORDS = 11;
+constexpr uint32_t ABC_SEG = 32;                 // terms per segment: a slice of full width is 32 dependent product-accumulates per lane
+constexpr uint32_t ABC_PART = 0x80000000u;       // s_out: the segment writes partial sum (s_out & ~ABC_PART) instead of row s_out
 static __global__ void k_coef_count(const uint32_t* __restrict__ raw, uint32_t n_coef, uint32_t domain, uint32_t n_vars, uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ bad) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_coef) return;
@@ -30,20 +44,7 @@ static __global__ void k_coef_count(const uint32_t* __restrict__ raw, uint32_t n
     if (m > 1 || c >= domain || s >= n_vars) { atomicAdd(bad, 1u); return; }
     atomicAdd(&row_cnt[m * domain + c], 1u);
 }
-static __global__ void k_coef_scatter(const uint32_t* __restrict__ raw, uint32_t n_coef, uint32_t domain, uint32_t n_vars, const uint32_t* __restrict__ row_start,
-                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sig, uint32_t* __restrict__ val) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_coef) return;
-    const uint32_t* rec = raw + 1 + (size_t)i * COEF_REC_WORDS;
-    uint32_t m = rec[0], c = rec[1], s = rec[2];
-    if (m > 1 || c >= domain || s >= n_vars) return;
-    uint32_t row = m * domain + c;
-    uint32_t pos = row_start[row] + atomicAdd(&cursor[row], 1u);
-    sig[pos] = s;
-#pragma unroll
-    for (int k = 0; k < 8; k++) val[(size_t)pos * 8 + k] = rec[3 + k];
-}
-// exclusive scan of `n` counters by one workgroup (n <= 2^26 in practice; one-off per zkey)
+// exclusive scan of `n` counters by one workgroup (one-off per zkey); out must not alias in
 static __global__ void k_scan_u32(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
     __shared__ uint32_t part[1024];
     const uint32_t per = (n + blockDim.x - 1) / blockDim.x;
@@ -61,28 +62,154 @@ static __global__ void k_scan_u32(const uint32_t* __restrict__ in, uint32_t* __r
     uint32_t run = part[threadIdx.x] - sum;
     for (uint32_t b = lo; b < hi; b++) { out[b] = run; run += in[b]; }
 }
-// A_T[c] = sum coef*w[s] over matrix 0, B_T[c] likewise over matrix 1, C_T[c] = A_T[c]*B_T[c]  (buildABC1).
-// coef is stored x R^2 and the witness is in normal form, so the Montgomery product is (coef*w) x R.
-template <class C> __global__ void __launch_bounds__(256)
-k_build_abc(const uint32_t* __restrict__ row_start, const uint32_t* __restrict__ row_cnt, const uint32_t* __restrict__ sig, const uint32_t* __restrict__ val,
-            const uint32_t* __restrict__ witness, uint32_t domain, uint32_t* __restrict__ A, uint32_t* __restrict__ B, uint32_t* __restrict__ Cc) {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= domain) return;
-    Fp<C> ab[2];
+// per row: its number of segments and, for rows cut into several, of partial-sum slots
+static __global__ void k_abc_row_segs(const uint32_t* __restrict__ row_cnt, uint32_t rows, uint32_t* __restrict__ nseg, uint32_t* __restrict__ npart) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint32_t c = row_cnt[r], ns = c ? (c + ABC_SEG - 1) / ABC_SEG : 1u;
+    nseg[r] = ns;
+    npart[r] = ns > 1 ? ns : 0u;
+}
+// one lane per row: lengths and targets of its segments; cut rows join the list of long rows (row, first partial slot, segments)
+static __global__ void k_abc_seg_fill(const uint32_t* __restrict__ row_cnt, const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ part_base, uint32_t rows,
+                                      uint32_t* __restrict__ seg_len, uint32_t* __restrict__ seg_out, uint32_t* __restrict__ long_rows, uint32_t* __restrict__ n_long) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint32_t c = row_cnt[r], sb = seg_base[r];
+    if (c <= ABC_SEG) { seg_len[sb] = c; seg_out[sb] = r; return; }
+    const uint32_t ns = (c + ABC_SEG - 1) / ABC_SEG, pb = part_base[r];
+    for (uint32_t j = 0; j < ns; j++) { seg_len[sb + j] = min(ABC_SEG, c - j * ABC_SEG); seg_out[sb + j] = ABC_PART | (pb + j); }
+    const uint32_t k = atomicAdd(n_long, 1u);
+    long_rows[3 * (size_t)k] = r; long_rows[3 * (size_t)k + 1] = pb; long_rows[3 * (size_t)k + 2] = ns;
+}
+// Stable counting sort of the segments by length, longest first. One wave per 64 segments (blockDim = 64): the lanes that share a length are found
+// by ballots; counts[(ABC_SEG - len) * n_waves + wave] = their number. One flat exclusive scan over that [bin][wave] array is every (bin, wave)'s
+// first position in the sorted order; the rank inside the wave is the number of lower lanes of the same length.
+static __global__ void __launch_bounds__(64) k_abc_wave_hist(const uint32_t* __restrict__ seg_len, uint32_t n_seg, uint32_t n_waves, uint32_t* __restrict__ counts) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    const bool live = s < n_seg;
+    const uint32_t len = live ? seg_len[s] : 0xffffffffu;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t v = __shfl(len, leader);
+        const unsigned long long same = __ballot(live && len == v);
+        if ((int)threadIdx.x == leader) counts[(size_t)(ABC_SEG - v) * n_waves + blockIdx.x] = (uint32_t)__popcll(same);
+        todo &= ~same;
+    }
+}
+static __global__ void __launch_bounds__(64) k_abc_wave_rank(const uint32_t* __restrict__ seg_len, const uint32_t* __restrict__ seg_out, uint32_t n_seg, uint32_t n_waves,
+                                                            const uint32_t* __restrict__ offs, uint32_t* __restrict__ s_len, uint32_t* __restrict__ s_out, uint32_t* __restrict__ pos_of_seg) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    const bool live = s < n_seg;
+    const uint32_t len = live ? seg_len[s] : 0xffffffffu;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t v = __shfl(len, leader);
+        const unsigned long long same = __ballot(live && len == v);
+        if (live && len == v) {
+            const uint32_t pos = offs[(size_t)(ABC_SEG - v) * n_waves + blockIdx.x] + (uint32_t)__popcll(same & ((1ull << threadIdx.x) - 1ull));
+            s_len[pos] = len; s_out[pos] = seg_out[s]; pos_of_seg[s] = pos;
+        }
+        todo &= ~same;
+    }
+}
+static __global__ void k_abc_slice_w(const uint32_t* __restrict__ s_len, uint32_t n_slices, uint32_t* __restrict__ slice_w) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_slices) slice_w[i] = s_len[(size_t)i * 64];       // sorted longest first: the slice's first segment is its widest
+}
+// one lane per coefficient record: its place in the sliced layout
+static __global__ void k_abc_sell_fill(const uint32_t* __restrict__ raw, uint32_t n_coef, uint32_t domain, uint32_t n_vars, const uint32_t* __restrict__ seg_base,
+                                       const uint32_t* __restrict__ pos_of_seg, const uint32_t* __restrict__ slice_off, uint32_t* __restrict__ cursor,
+                                       uint32_t* __restrict__ sell_sig, uint32_t* __restrict__ sell_val) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_coef) return;
+    const uint32_t* rec = raw + 1 + (size_t)i * COEF_REC_WORDS;
+    uint32_t m = rec[0], c = rec[1], s = rec[2];
+    if (m > 1 || c >= domain || s >= n_vars) return;
+    const uint32_t row = m * domain + c, rank = atomicAdd(&cursor[row], 1u);
+    const uint32_t pos = pos_of_seg[seg_base[row] + rank / ABC_SEG];
+    const size_t e = ((size_t)slice_off[pos >> 6] + rank % ABC_SEG) * 64 + (pos & 63u);
+    sell_sig[e] = s;
 #pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const uint32_t row = m * domain + c, st = row_start[row], cnt = row_cnt[row];
-        Fp<C> acc = fp_zero<C>();
-        for (uint32_t k = 0; k < cnt; k++) {
-            Fp<C> v = fp_load<C>(val + (size_t)(st + k) * 8);
-            Fp<C> w = fp_load<C>(witness + (size_t)sig[st + k] * 8);
+    for (int k = 0; k < 8; k++) sell_val[e * 8 + k] = rec[3 + k];
+}
+// ---- per proof -------------------------------------------------------------------------------------------------------------------------------
+// One lane per segment, one wave per slice: sum of coef * w[signal] over the segment's terms. coef is stored x R^2 and the witness is in normal
+// form, so the Montgomery product is (coef * w) x R (buildABC1 :166-178).
+template <class C> __global__ void __launch_bounds__(256)
+k_abc_sell(const uint32_t* __restrict__ s_len, const uint32_t* __restrict__ s_out, const uint32_t* __restrict__ slice_off, uint32_t n_seg, const uint32_t* __restrict__ sell_sig,
+           const uint32_t* __restrict__ sell_val, const uint32_t* __restrict__ witness, uint32_t* __restrict__ AB, uint32_t* __restrict__ part) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x, slice = p >> 6;
+    if ((size_t)slice * 64 >= n_seg) return;                         // the whole wave
+    const uint32_t width = __builtin_amdgcn_readfirstlane(s_len[(size_t)slice * 64]);
+    const uint32_t len = p < n_seg ? s_len[p] : 0u;
+    size_t e = (size_t)__builtin_amdgcn_readfirstlane(slice_off[slice]) * 64 + (p & 63u);
+    Fp<C> acc = fp_zero<C>();
+    for (uint32_t k = 0; k < width; k++, e += 64) {
+        if (k < len) {
+            const Fp<C> v = fp_load<C>(sell_val + e * 8);
+            const Fp<C> w = fp_load<C>(witness + (size_t)sell_sig[e] * 8);
             acc = fp_add(acc, fp_mul(v, w));
         }
-        ab[m] = acc;
     }
-    fp_store<C>(A + (size_t)c * 8, ab[0]);
-    fp_store<C>(B + (size_t)c * 8, ab[1]);
-    fp_store<C>(Cc + (size_t)c * 8, fp_mul(ab[0], ab[1]));
+    if (p < n_seg) {
+        const uint32_t o = s_out[p];
+        fp_store<C>((o & ABC_PART) ? part + (size_t)(o & ~ABC_PART) * 8 : AB + (size_t)o * 8, acc);
+    }
+}
+// one wave per cut row: adds its partial sums
+template <class C> __global__ void __launch_bounds__(256)
+k_abc_long(const uint32_t* __restrict__ long_rows, uint32_t n_long, const uint32_t* __restrict__ part, uint32_t* __restrict__ AB) {
+    const uint32_t wv = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (wv >= n_long) return;
+    const uint32_t r = long_rows[3 * (size_t)wv], pb = long_rows[3 * (size_t)wv + 1], ns = long_rows[3 * (size_t)wv + 2];
+    Fp<C> acc = fp_zero<C>();
+    for (uint32_t j = lane; j < ns; j += 64) acc = fp_add(acc, fp_load<C>(part + (size_t)(pb + j) * 8));
+    for (int off = 32; off; off >>= 1) {
+        Fp<C> o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], off);
+        acc = fp_add(acc, o);
+    }
+    if (lane == 0) fp_store<C>(AB + (size_t)r * 8, acc);
+}
+// C_T[c] = A_T[c] * B_T[c] (buildABC1 :180-184)
+template <class C> __global__ void __launch_bounds__(256)
+k_abc_mulc(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, uint32_t* __restrict__ Cc, uint32_t domain) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= domain) return;
+    fp_store<C>(Cc + (size_t)c * 8, fp_mul(fp_load<C>(A + (size_t)c * 8), fp_load<C>(B + (size_t)c * 8)));
+}
+
+// ---- paged host sections (zkmi_groth16_zkey_paged) -----------------------------------------------------------------------------------------------
+static size_t pg_total(const zkmi_pages& pg) { size_t t = 0; for (int i = 0; i < pg.n_pages; i++) t += pg.len[i]; return t; }
+// bytes [off, off + len) of a paged host buffer -> device (stream-ordered) / -> host. A page with a NULL pointer is a GAP: bytes the caller did not
+// read (a shard loader reads only its slice of a section); a range that needs one fails.
+template <class F> static int pg_walk(const zkmi_pages& pg, size_t off, size_t len, F&& f) {
+    size_t start = 0, done = 0;
+    for (int i = 0; i < pg.n_pages && done < len; i++) {
+        const size_t pl = pg.len[i], lo = off + done;
+        if (lo < start + pl) {
+            const size_t in = lo - start, k = std::min(pl - in, len - done);
+            if (!pg.ptr[i]) return fail(ZKMI_ERR_INVALID, "groth16: a needed byte range of a zkey section lies in a gap page (not provided by the caller)");
+            ZK_TRY(f(pg.ptr[i] + in, done, k));
+            done += k;
+        }
+        start += pl;
+    }
+    if (done < len) return fail(ZKMI_ERR_INVALID, "groth16: a zkey section is shorter than the range read from it");
+    return ZKMI_OK;
+}
+static int pg_upload(const zkmi_pages& pg, size_t off, size_t len, void* d_dst, hipStream_t st) {
+    return pg_walk(pg, off, len, [&](const uint8_t* src, size_t at, size_t k) -> int {
+        ZK_HIP(hipMemcpyAsync((uint8_t*)d_dst + at, src, k, hipMemcpyHostToDevice, st));
+        return ZKMI_OK;
+    });
+}
+static int pg_read(const zkmi_pages& pg, size_t off, size_t len, uint8_t* dst) {
+    return pg_walk(pg, off, len, [&](const uint8_t* src, size_t at, size_t k) -> int { memcpy(dst + at, src, k); return ZKMI_OK; });
 }
 
 // ---- resident proving key ---------------------------------------------------------------------------------------------
@@ -101,11 +228,15 @@ struct G16Key {
     // variables [v_lo, v_lo + v_cnt) and H bases [h_lo, h_lo + h_cnt); the full key has v_lo = h_lo = 0, v_cnt = nVars, h_cnt = n
     uint32_t v_lo = 0, v_cnt = 0, h_lo = 0, h_cnt = 0;
     bool full() const { return v_lo == 0 && h_lo == 0 && v_cnt == n_vars && h_cnt == domain; }
-    uint32_t *row_cnt = nullptr, *row_start = nullptr, *sig = nullptr, *val = nullptr;
+    // the coefficient section as sliced ELL with split rows (above): lengths / targets of the sorted segments, slice offsets (units of 64 terms),
+    // signal ids and values of the terms, the list of cut rows (row, first partial slot, segments)
+    uint32_t *s_len = nullptr, *s_out = nullptr, *slice_off = nullptr, *sell_sig = nullptr, *sell_val = nullptr, *long_rows = nullptr;
+    uint32_t n_seg = 0, n_long = 0, n_part = 0;
+    size_t sell_terms = 0;            // padded terms held (64 x the sum of the slice widths)
     // per pipeline slot (two proofs may be in flight, zkmi_groth16_submit_dev): work buffers, stage events, the MSM jobs of the
     // proof in flight. Slot 1 is allocated on first use.
     struct Work {
-        uint32_t *w = nullptr, *A = nullptr, *B = nullptr, *C = nullptr, *T = nullptr;
+        uint32_t *w = nullptr, *A = nullptr, *B = nullptr, *C = nullptr, *T = nullptr, *part = nullptr;     // part: partial sums of the cut rows of buildABC
         hipEvent_t ev[ST_COUNT + 1] = {};
         MsmJob job[5];
         bool in_flight = false, ov = false;
@@ -119,9 +250,10 @@ struct G16Key {
     mutable std::vector<uint8_t> fb_delta1, fb_delta2;   // host fixed-base tables of delta (g16_finish), built on first use
     double stage_ms[ST_COUNT] = {};
     void release() {
-        void** ptrs[] = {&bA, &bB1, &bB2, &bC, &bH, (void**)&row_cnt, (void**)&row_start, (void**)&sig, (void**)&val, (void**)&mask[0], (void**)&mask[1], (void**)&mask[2],
-                         (void**)&mask[3], (void**)&mask[4], (void**)&drop_b, (void**)&wk[0].w, (void**)&wk[0].A, (void**)&wk[0].T,
-                         (void**)&wk[1].w, (void**)&wk[1].A, (void**)&wk[1].T};        // B and C live inside the A allocation
+        void** ptrs[] = {&bA, &bB1, &bB2, &bC, &bH, (void**)&s_len, (void**)&s_out, (void**)&slice_off, (void**)&sell_sig, (void**)&sell_val, (void**)&long_rows,
+                         (void**)&mask[0], (void**)&mask[1], (void**)&mask[2],
+                         (void**)&mask[3], (void**)&mask[4], (void**)&drop_b, (void**)&wk[0].w, (void**)&wk[0].A, (void**)&wk[0].T, (void**)&wk[0].part,
+                         (void**)&wk[1].w, (void**)&wk[1].A, (void**)&wk[1].T, (void**)&wk[1].part};        // B and C live inside the A allocation
         for (void* t : {bA, bB1, bB2, bC, bH}) if (t) msm_table_forget_r29(t);
         for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
         for (auto& wkk : wk) for (auto& e : wkk.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -145,38 +277,106 @@ static int g16_work_alloc(G16Key& K, int slot) {
     ZK_TRY(dev_alloc_big((void**)&W.A, (size_t)K.domain * 32 * 3));
     W.B = W.A + (size_t)K.domain * 8; W.C = W.B + (size_t)K.domain * 8;
     ZK_TRY(dev_alloc_big((void**)&W.T, (size_t)K.domain * 32 * 3));
+    ZK_TRY(dev_alloc_big((void**)&W.part, std::max<size_t>(K.n_part, 1) * 32));
     for (auto& e : W.ev) ZK_HIP(hipEventCreate(&e));
     return ZKMI_OK;
 }
-static int upload(void** d, const uint8_t* h, size_t bytes, hipStream_t st) {
-    ZK_HIP(hipMalloc(d, bytes ? bytes : 16));
-    if (bytes) ZK_HIP(hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, st));
+// The resident form of the coefficient section (layout above), built on the device from the raw records
+static int g16_build_sell(G16Key& K, const zkmi_pages& coeffs, size_t coeffs_len, hipStream_t st) {
+    const uint32_t n = K.domain, n_coef = K.n_coef;
+    const size_t rows = 2 * (size_t)n;
+    DevTmp raw_t, cnt_t, nseg_t, npart_t, segb_t, partb_t, seglen_t, segout_t, counts_t, offs_t, pos_t, slw_t, misc_t;
+    ZK_HIP(hipMalloc(&raw_t.p, coeffs_len + 16));
+    ZK_TRY(pg_upload(coeffs, 0, coeffs_len, raw_t.p, st));
+    const uint32_t* raw = (const uint32_t*)raw_t.p;
+    for (DevTmp* t : {&cnt_t, &nseg_t, &npart_t, &segb_t, &partb_t}) ZK_HIP(hipMalloc(&t->p, rows * 4 + 16));
+    ZK_HIP(hipMalloc(&misc_t.p, 64));                                   // [0] bad records, [1] cut rows
+    uint32_t *row_cnt = (uint32_t*)cnt_t.p, *nseg = (uint32_t*)nseg_t.p, *npart = (uint32_t*)npart_t.p, *seg_base = (uint32_t*)segb_t.p, *part_base = (uint32_t*)partb_t.p,
+             *misc = (uint32_t*)misc_t.p;
+    ZK_HIP(hipMemsetAsync(row_cnt, 0, rows * 4, st)); ZK_HIP(hipMemsetAsync(misc, 0, 64, st));
+    const unsigned cblocks = (n_coef + 255) / 256, rblocks = (unsigned)((rows + 255) / 256);
+    if (n_coef) hipLaunchKernelGGL(k_coef_count, dim3(cblocks), dim3(256), 0, st, raw, n_coef, n, K.n_vars, row_cnt, misc);
+    hipLaunchKernelGGL(k_abc_row_segs, dim3(rblocks), dim3(256), 0, st, row_cnt, (uint32_t)rows, nseg, npart);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, nseg, seg_base, (uint32_t)rows);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, npart, part_base, (uint32_t)rows);
+    uint32_t tail[5] = {0, 0, 0, 0, 0};                                 // bad, last seg_base, last nseg, last part_base, last npart
+    ZK_HIP(hipMemcpyAsync(&tail[0], misc, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(&tail[1], seg_base + rows - 1, 4, hipMemcpyDeviceToHost, st)); ZK_HIP(hipMemcpyAsync(&tail[2], nseg + rows - 1, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(&tail[3], part_base + rows - 1, 4, hipMemcpyDeviceToHost, st)); ZK_HIP(hipMemcpyAsync(&tail[4], npart + rows - 1, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    if (tail[0]) return fail(ZKMI_ERR_INVALID, "groth16: coefficient record out of range (matrix > 1, constraint >= domain or signal >= nVars)");
+    const size_t n_seg = (size_t)tail[1] + tail[2], n_part = (size_t)tail[3] + tail[4];
+    if (n_seg >= 0x7fffffffu || n_part >= 0x7fffffffu) return fail(ZKMI_ERR_UNSUPPORTED, "groth16: coefficient section too large for the 31-bit segment indices");
+    K.n_seg = (uint32_t)n_seg; K.n_part = (uint32_t)n_part;
+    const uint32_t n_waves = (uint32_t)((n_seg + 63) / 64);             // = slices
+    ZK_HIP(hipMalloc(&seglen_t.p, n_seg * 4 + 16)); ZK_HIP(hipMalloc(&segout_t.p, n_seg * 4 + 16)); ZK_HIP(hipMalloc(&pos_t.p, n_seg * 4 + 16));
+    const size_t n_counts = (size_t)(ABC_SEG + 1) * n_waves;
+    if (n_counts >= 0xffffffffu) return fail(ZKMI_ERR_UNSUPPORTED, "groth16: coefficient section too large for the segment sort");
+    ZK_HIP(hipMalloc(&counts_t.p, n_counts * 4 + 16)); ZK_HIP(hipMalloc(&offs_t.p, n_counts * 4 + 16)); ZK_HIP(hipMalloc(&slw_t.p, (size_t)n_waves * 4 + 16));
+    ZK_HIP(hipMalloc((void**)&K.long_rows, (size_t)(n_coef / (ABC_SEG + 1) + 1) * 12));
+    ZK_TRY(dev_alloc_big((void**)&K.s_len, n_seg * 4 + 16)); ZK_TRY(dev_alloc_big((void**)&K.s_out, n_seg * 4 + 16));
+    ZK_HIP(hipMalloc((void**)&K.slice_off, (size_t)n_waves * 4 + 16));
+    uint32_t *seg_len = (uint32_t*)seglen_t.p, *seg_out = (uint32_t*)segout_t.p, *pos_of_seg = (uint32_t*)pos_t.p, *counts = (uint32_t*)counts_t.p, *offs = (uint32_t*)offs_t.p,
+             *slice_w = (uint32_t*)slw_t.p;
+    hipLaunchKernelGGL(k_abc_seg_fill, dim3(rblocks), dim3(256), 0, st, row_cnt, seg_base, part_base, (uint32_t)rows, seg_len, seg_out, K.long_rows, misc + 1);
+    ZK_HIP(hipMemsetAsync(counts, 0, n_counts * 4, st));
+    hipLaunchKernelGGL(k_abc_wave_hist, dim3(n_waves), dim3(64), 0, st, seg_len, (uint32_t)n_seg, n_waves, counts);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, counts, offs, (uint32_t)n_counts);
+    hipLaunchKernelGGL(k_abc_wave_rank, dim3(n_waves), dim3(64), 0, st, seg_len, seg_out, (uint32_t)n_seg, n_waves, offs, K.s_len, K.s_out, pos_of_seg);
+    hipLaunchKernelGGL(k_abc_slice_w, dim3((n_waves + 255) / 256), dim3(256), 0, st, K.s_len, n_waves, slice_w);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, slice_w, K.slice_off, n_waves);
+    uint32_t t2[4] = {0, 0, 0, 0};                                      // cut rows, last slice_off, last slice_w, longest segment count is not needed
+    ZK_HIP(hipMemcpyAsync(&t2[0], misc + 1, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(&t2[1], K.slice_off + n_waves - 1, 4, hipMemcpyDeviceToHost, st)); ZK_HIP(hipMemcpyAsync(&t2[2], slice_w + n_waves - 1, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    K.n_long = t2[0];
+    K.sell_terms = ((size_t)t2[1] + t2[2]) * 64;
+    ZK_TRY(dev_alloc_big((void**)&K.sell_sig, std::max<size_t>(K.sell_terms, 1) * 4)); ZK_TRY(dev_alloc_big((void**)&K.sell_val, std::max<size_t>(K.sell_terms, 1) * 32));
+    ZK_HIP(hipMemsetAsync(row_cnt, 0, rows * 4, st));                   // re-used as the per-row cursors of the fill
+    if (n_coef) hipLaunchKernelGGL(k_abc_sell_fill, dim3(cblocks), dim3(256), 0, st, raw, n_coef, n, K.n_vars, seg_base, pos_of_seg, K.slice_off, row_cnt, K.sell_sig, K.sell_val);
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
     return ZKMI_OK;
 }
+// buildABC1 of one proof into the slot's A | B | C
+template <class FrC> static void g16_build_abc(const G16Key& K, const G16Key::Work& Wk, const uint32_t* w, hipStream_t st) {
+    const uint32_t n = K.domain;
+    hipLaunchKernelGGL((k_abc_sell<FrC>), dim3((K.n_seg + 255) / 256), dim3(256), 0, st, K.s_len, K.s_out, K.slice_off, K.n_seg, K.sell_sig, K.sell_val, w, Wk.A, Wk.part);
+    if (K.n_long) hipLaunchKernelGGL((k_abc_long<FrC>), dim3((K.n_long + 3) / 4), dim3(256), 0, st, K.long_rows, K.n_long, Wk.part, Wk.A);
+    hipLaunchKernelGGL((k_abc_mulc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, Wk.A, Wk.B, Wk.C, n);
+}
 
-static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, uint32_t v_hi, uint32_t h_lo, uint32_t h_hi) {
+static int g16_load(const zkmi_groth16_zkey_paged* zk, uint64_t key, uint32_t v_lo, uint32_t v_hi, uint32_t h_lo, uint32_t h_hi) {
     Ctx& cx = ctx();
     hipStream_t st = cx.stream;
     if (zk->curve != ZKMI_CURVE_BN128 && zk->curve != ZKMI_CURVE_BLS12381) return fail(ZKMI_ERR_INVALID, "unknown curve");
     const uint32_t n = zk->domain_size;
     if (n == 0 || (n & (n - 1))) return fail(ZKMI_ERR_INVALID, "groth16: domain size must be a power of two");
+    if (n > (1u << 28)) return fail(ZKMI_ERR_UNSUPPORTED, "groth16: domain size beyond 2^28");
     if (zk->n_vars <= zk->n_public) return fail(ZKMI_ERR_INVALID, "groth16: nVars must exceed nPublic");
-    if (zk->coeffs_len < 4 || (zk->coeffs_len - 4) % 44) return fail(ZKMI_ERR_INVALID, "groth16: malformed coefficient section");
+    for (const zkmi_pages* pg : {&zk->coeffs, &zk->bases_a, &zk->bases_b1, &zk->bases_b2, &zk->bases_c, &zk->bases_h})
+        if (pg->n_pages < 0 || (pg->n_pages > 0 && (!pg->ptr || !pg->len))) return fail(ZKMI_ERR_INVALID, "groth16: null section pointer");
+    const size_t coeffs_len = pg_total(zk->coeffs);
+    if (coeffs_len < 4 || (coeffs_len - 4) % 44) return fail(ZKMI_ERR_INVALID, "groth16: malformed coefficient section");
+    if ((coeffs_len - 4) / 44 > 0xffffffffull) return fail(ZKMI_ERR_INVALID, "groth16: malformed coefficient section");
     auto K = std::make_unique<G16Key>();
     K->curve = zk->curve; K->n_vars = zk->n_vars; K->n_public = zk->n_public; K->domain = n;
     K->power = (uint32_t)ilog2_sz(n);
-    K->n_coef = (uint32_t)((zk->coeffs_len - 4) / 44);            // buildABC1: nCoef = (byteLength-4)/sCoef (:149-150)
+    K->n_coef = (uint32_t)((coeffs_len - 4) / 44);                // buildABC1: nCoef = (byteLength-4)/sCoef (:149-150)
     const size_t q = n8q_of(zk->curve), g1 = 2 * q, g2 = 4 * q;
     {   // section lengths against the header (src/zkey_utils.js:183-205: nVars points in sections 5-7, nVars-nPublic-1 in 8, domainSize in 9)
         const size_t nv = zk->n_vars, nc = nv - zk->n_public - 1;
-        if (!zk->coeffs || !zk->bases_a || !zk->bases_b1 || !zk->bases_b2 || !zk->bases_c || !zk->bases_h || !zk->vk_alpha_1 || !zk->vk_beta_1 || !zk->vk_beta_2 ||
-            !zk->vk_delta_1 || !zk->vk_delta_2)
+        if (!zk->coeffs.n_pages || !zk->bases_a.n_pages || !zk->bases_b1.n_pages || !zk->bases_b2.n_pages || (nc && !zk->bases_c.n_pages) || !zk->bases_h.n_pages ||
+            !zk->vk_alpha_1 || !zk->vk_beta_1 || !zk->vk_beta_2 || !zk->vk_delta_1 || !zk->vk_delta_2)
             return fail(ZKMI_ERR_INVALID, "groth16: null section pointer");
-        if (zk->bases_a_len < nv * g1 || zk->bases_b1_len < nv * g1 || zk->bases_b2_len < nv * g2 || zk->bases_c_len < nc * g1 || zk->bases_h_len < (size_t)n * g1)
+        if (pg_total(zk->bases_a) < nv * g1 || pg_total(zk->bases_b1) < nv * g1 || pg_total(zk->bases_b2) < nv * g2 || pg_total(zk->bases_c) < nc * g1 ||
+            pg_total(zk->bases_h) < (size_t)n * g1)
             return fail(ZKMI_ERR_INVALID, "groth16: a base section is shorter than nVars / nPublic / domainSize of the header require");
         uint32_t n_coef_hdr = 0;
-        memcpy(&n_coef_hdr, zk->coeffs, 4);
-        if ((size_t)n_coef_hdr != (zk->coeffs_len - 4) / 44) return fail(ZKMI_ERR_INVALID, "groth16: coefficient count does not match the section length");
+        ZK_TRY(pg_read(zk->coeffs, 0, 4, (uint8_t*)&n_coef_hdr));
+        if ((size_t)n_coef_hdr != (coeffs_len - 4) / 44) return fail(ZKMI_ERR_INVALID, "groth16: coefficient count does not match the section length");
     }
     if (v_lo >= v_hi || v_hi > zk->n_vars || h_lo >= h_hi || h_hi > n) return fail(ZKMI_ERR_INVALID, "groth16: empty or out-of-range key shard");
     K->v_lo = v_lo; K->v_cnt = v_hi - v_lo; K->h_lo = h_lo; K->h_cnt = h_hi - h_lo;
@@ -190,13 +390,14 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
     const int pc = pe ? atoi(pe) : -1;
     K->cw = pc == 0 ? 0 : (pc > 0 ? pc : msm_precomp_c(m));
     K->ch = pc == 0 ? 0 : (pc > 0 ? pc : msm_precomp_c(K->h_cnt));
-    auto put_table = [&](void** dst, uint32_t** mask, const uint8_t* src, size_t cnt, size_t pad_front, int group, int c) -> int {
+    // src: the section's pages; first: index of its first point wanted here (only that byte range is read: the other pages may be gaps)
+    auto put_table = [&](void** dst, uint32_t** mask, const zkmi_pages& src, size_t first, size_t cnt, size_t pad_front, int group, int c) -> int {
         const size_t pb = group == 1 ? g1 : g2, tot = cnt + pad_front;
         DevTmp tmp;
         ZK_TRY(dev_alloc_big(&tmp.p, tot * pb ? tot * pb : 16));
         void* raw = tmp.p;
         if (pad_front) ZK_HIP(hipMemsetAsync(raw, 0, pad_front * pb, st));             // all-zero bytes = point at infinity
-        if (cnt) ZK_HIP(hipMemcpyAsync((uint8_t*)raw + pad_front * pb, src, cnt * pb, hipMemcpyHostToDevice, st));
+        if (cnt) ZK_TRY(pg_upload(src, first * pb, cnt * pb, (uint8_t*)raw + pad_front * pb, st));
         const int Wd = c ? msm_digits(32, c) : 1;
         if (!c) { *dst = raw; tmp.p = nullptr; }
         else {
@@ -209,13 +410,13 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
         ZK_HIP(hipStreamSynchronize(st));
         return ZKMI_OK;                                    // ~DevTmp frees the plain copy when a table was built from it
     };
-    ZK_TRY(put_table(&K->bA, &K->mask[0], zk->bases_a + (size_t)v_lo * g1, m, 0, 1, K->cw));
-    ZK_TRY(put_table(&K->bB1, &K->mask[1], zk->bases_b1 + (size_t)v_lo * g1, m, 0, 1, K->cw));
-    ZK_TRY(put_table(&K->bB2, &K->mask[2], zk->bases_b2 + (size_t)v_lo * g2, m, 0, 2, K->cw));
+    ZK_TRY(put_table(&K->bA, &K->mask[0], zk->bases_a, v_lo, m, 0, 1, K->cw));
+    ZK_TRY(put_table(&K->bB1, &K->mask[1], zk->bases_b1, v_lo, m, 0, 1, K->cw));
+    ZK_TRY(put_table(&K->bB2, &K->mask[2], zk->bases_b2, v_lo, m, 0, 2, K->cw));
     // with tables C is padded in front so that it shares the witness indices of this range
-    ZK_TRY(put_table(&K->bC, &K->mask[3], zk->bases_c + c_src0 * g1, mc, K->cw ? c_front : 0, 1, K->cw));
+    ZK_TRY(put_table(&K->bC, &K->mask[3], zk->bases_c, c_src0, mc, K->cw ? c_front : 0, 1, K->cw));
     K->c_skip = K->cw ? 0 : (uint32_t)c_front;
-    ZK_TRY(put_table(&K->bH, &K->mask[4], zk->bases_h + (size_t)h_lo * g1, (size_t)K->h_cnt, 0, 1, K->ch));
+    ZK_TRY(put_table(&K->bH, &K->mask[4], zk->bases_h, h_lo, (size_t)K->h_cnt, 0, 1, K->ch));
     {   // B is sparse in real circuits (a signal absent from the B matrix has the point at infinity in BOTH B1 and B2, section
         // layout src/zkey_utils.js:183-193): those witness entries are dropped from the digit sort that feeds the B MSMs
         const size_t words = (m + 31) / 32;
@@ -233,33 +434,31 @@ static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, ui
     K->vk_alpha_1.assign(zk->vk_alpha_1, zk->vk_alpha_1 + g1); K->vk_beta_1.assign(zk->vk_beta_1, zk->vk_beta_1 + g1);
     K->vk_beta_2.assign(zk->vk_beta_2, zk->vk_beta_2 + g2); K->vk_delta_1.assign(zk->vk_delta_1, zk->vk_delta_1 + g1);
     K->vk_delta_2.assign(zk->vk_delta_2, zk->vk_delta_2 + g2);
-    // CSR conversion of the coefficient section, on the device
-    DevTmp raw_t, cursor_t;
-    ZK_TRY(upload(&raw_t.p, zk->coeffs, zk->coeffs_len, st));
-    void* raw = raw_t.p;
-    const size_t rows = 2 * (size_t)n;
-    ZK_HIP(hipMalloc((void**)&K->row_cnt, rows * 4)); ZK_HIP(hipMalloc((void**)&K->row_start, rows * 4));
-    ZK_HIP(hipMalloc(&cursor_t.p, rows * 4 + 16));
-    uint32_t* cursor = (uint32_t*)cursor_t.p;
-    ZK_TRY(dev_alloc_big((void**)&K->sig, std::max<size_t>(K->n_coef, 1) * 4)); ZK_TRY(dev_alloc_big((void**)&K->val, std::max<size_t>(K->n_coef, 1) * 32));
-    ZK_HIP(hipMemsetAsync(K->row_cnt, 0, rows * 4, st)); ZK_HIP(hipMemsetAsync(cursor, 0, rows * 4 + 16, st));
-    uint32_t* bad = cursor + rows;
-    if (K->n_coef) {
-        const unsigned blocks = (K->n_coef + 255) / 256;
-        hipLaunchKernelGGL(k_coef_count, dim3(blocks), dim3(256), 0, st, (const uint32_t*)raw, K->n_coef, n, zk->n_vars, K->row_cnt, bad);
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, K->row_cnt, K->row_start, (uint32_t)rows);
-        hipLaunchKernelGGL(k_coef_scatter, dim3(blocks), dim3(256), 0, st, (const uint32_t*)raw, K->n_coef, n, zk->n_vars, K->row_start, cursor, K->sig, K->val);
-    } else ZK_HIP(hipMemsetAsync(K->row_start, 0, rows * 4, st));
-    uint32_t nbad = 0;
-    ZK_HIP(hipMemcpyAsync(&nbad, bad, 4, hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipStreamSynchronize(st));
-    ZK_HIP(hipGetLastError());
-    if (nbad) { return fail(ZKMI_ERR_INVALID, "groth16: coefficient record out of range (matrix > 1, constraint >= domain or signal >= nVars)"); }
+    ZK_TRY(g16_build_sell(*K, zk->coeffs, coeffs_len, st));
     ZK_TRY(g16_work_alloc(*K, 0));
     auto it = cx.groth16.find(key);
     if (it != cx.groth16.end()) delete (G16Key*)it->second;
     cx.groth16[key] = K.release();
     return ZKMI_OK;
+}
+// the flat descriptor as a paged one of single pages (the arrays live in `hold`)
+struct FlatAsPaged {
+    const uint8_t* ptr[6];
+    size_t len[6];
+    zkmi_groth16_zkey_paged pz;
+    explicit FlatAsPaged(const zkmi_groth16_zkey& z) {
+        const uint8_t* p[6] = {z.coeffs, z.bases_a, z.bases_b1, z.bases_b2, z.bases_c, z.bases_h};
+        const size_t l[6] = {z.coeffs_len, z.bases_a_len, z.bases_b1_len, z.bases_b2_len, z.bases_c_len, z.bases_h_len};
+        zkmi_pages* dst[6] = {&pz.coeffs, &pz.bases_a, &pz.bases_b1, &pz.bases_b2, &pz.bases_c, &pz.bases_h};
+        for (int i = 0; i < 6; i++) { ptr[i] = p[i]; len[i] = l[i]; dst[i]->ptr = &ptr[i]; dst[i]->len = &len[i]; dst[i]->n_pages = p[i] ? 1 : 0; }
+        pz.curve = z.curve; pz.n_vars = z.n_vars; pz.n_public = z.n_public; pz.domain_size = z.domain_size;
+        pz.vk_alpha_1 = z.vk_alpha_1; pz.vk_beta_1 = z.vk_beta_1; pz.vk_beta_2 = z.vk_beta_2; pz.vk_delta_1 = z.vk_delta_1; pz.vk_delta_2 = z.vk_delta_2;
+    }
+    FlatAsPaged(const FlatAsPaged&) = delete;
+};
+static int g16_load(const zkmi_groth16_zkey* zk, uint64_t key, uint32_t v_lo, uint32_t v_hi, uint32_t h_lo, uint32_t h_hi) {
+    FlatAsPaged f(*zk);
+    return g16_load(&f.pz, key, v_lo, v_hi, h_lo, h_hi);
 }
 
 // ---- host epilogue: blinding + toAffine (src/groth16_prove.js:103-132) -------------------------------------------------
@@ -384,7 +583,7 @@ template <class FrC> static int g16_enqueue(G16Key& K, const void* d_witness, co
         ZK_TRY(rc);
     }
     if (do_w) ZK_HIP(hipEventRecord(Wk.ev[ST_BUILD], st));
-    if (transforms) hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, w, n, Wk.A, Wk.B, Wk.C);
+    if (transforms) g16_build_abc<FrC>(K, Wk, w, st);
     if (do_w) ZK_HIP(hipEventRecord(Wk.ev[ST_NTT], st));
     if (transforms) {
         // inc = power == Fr.s ? Fr.shift : Fr.w[power+1] (:64); Fr.shift = nqr^2 — both come from the NTT module's root table
@@ -524,7 +723,7 @@ template <class FrC> static int g16_chains(G16Key& K, const void* d_witness, uns
     if (Wk.in_flight) return fail(ZKMI_ERR_INVALID, "groth16_chains: a proof is in flight in this pipeline slot");
     const host::HField<4> Fr = host::HField<4>::from_cfg<FrC>();
     const uint32_t n = K.domain;
-    hipLaunchKernelGGL((k_build_abc<FrC>), dim3((n + 255) / 256), dim3(256), 0, st, K.row_start, K.row_cnt, K.sig, K.val, (const uint32_t*)d_witness, n, Wk.A, Wk.B, Wk.C);
+    g16_build_abc<FrC>(K, Wk, (const uint32_t*)d_witness, st);
     uint8_t one[32], inc[32];
     memcpy(one, Fr.one, 32);
     ZK_TRY(fr_coset_inc(K.curve, K.power, inc));
@@ -561,6 +760,46 @@ int zkmi_groth16_load_shard(const zkmi_groth16_zkey* zkey, uint64_t key, uint32_
     ZK_TRY(require_ctx());
     if (!zkey || !key) return fail(ZKMI_ERR_INVALID, "groth16_load_shard: null zkey or key 0");
     return g16_load(zkey, key, var_lo, var_hi, h_lo, h_hi);
+}
+int zkmi_groth16_load_paged(const zkmi_groth16_zkey_paged* zkey, uint64_t key) {
+    ZK_TRY(require_ctx());
+    if (!zkey || !key) return fail(ZKMI_ERR_INVALID, "groth16_load: null zkey or key 0");
+    return g16_load(zkey, key, 0, zkey->n_vars, 0, zkey->domain_size);
+}
+int zkmi_groth16_load_shard_paged(const zkmi_groth16_zkey_paged* zkey, uint64_t key, uint32_t var_lo, uint32_t var_hi, uint32_t h_lo, uint32_t h_hi) {
+    ZK_TRY(require_ctx());
+    if (!zkey || !key) return fail(ZKMI_ERR_INVALID, "groth16_load_shard: null zkey or key 0");
+    return g16_load(zkey, key, var_lo, var_hi, h_lo, h_hi);
+}
+int zkmi_groth16_build_abc_dev(uint64_t key, const void* d_witness, void* d_a, void* d_b, void* d_c) {
+    ZK_TRY(require_ctx());
+    G16Key* K = g16_find(key);
+    if (!K) return fail(ZKMI_ERR_INVALID, "groth16_build_abc_dev: key not loaded");
+    if (!d_witness) return fail(ZKMI_ERR_INVALID, "groth16_build_abc_dev: null witness");
+    Ctx& cx = ctx();
+    ZK_TRY(g16_work_alloc(*K, cx.pipe));
+    G16Key::Work& Wk = K->wk[cx.pipe];
+    if (Wk.in_flight || Wk.w_enqueued) return fail(ZKMI_ERR_INVALID, "groth16_build_abc_dev: a proof is in flight in this pipeline slot");
+    ZK_HIP(hipEventRecord(cx.ev0, cx.stream));
+    if (K->curve == ZKMI_CURVE_BN128) g16_build_abc<Bn254Fr>(*K, Wk, (const uint32_t*)d_witness, cx.stream);
+    else g16_build_abc<Bls12381Fr>(*K, Wk, (const uint32_t*)d_witness, cx.stream);
+    ZK_HIP(hipEventRecord(cx.ev1, cx.stream));
+    const size_t bytes = (size_t)K->domain * 32;
+    if (d_a) ZK_HIP(hipMemcpyAsync(d_a, Wk.A, bytes, hipMemcpyDeviceToDevice, cx.stream));
+    if (d_b) ZK_HIP(hipMemcpyAsync(d_b, Wk.B, bytes, hipMemcpyDeviceToDevice, cx.stream));
+    if (d_c) ZK_HIP(hipMemcpyAsync(d_c, Wk.C, bytes, hipMemcpyDeviceToDevice, cx.stream));
+    ZK_HIP(hipStreamSynchronize(cx.stream));
+    ZK_HIP(hipGetLastError());
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, cx.ev0, cx.ev1) == hipSuccess) cx.last_ms = ms;
+    return ZKMI_OK;
+}
+int zkmi_groth16_coef_layout(uint64_t key, uint64_t* out, int n) {
+    const G16Key* K = g16_find(key);
+    if (!K || !out) return fail(ZKMI_ERR_INVALID, "groth16_coef_layout: key not loaded");
+    const uint64_t v[5] = {K->n_coef, K->n_seg, K->n_long, K->n_part, (uint64_t)K->sell_terms};
+    for (int i = 0; i < n && i < 5; i++) out[i] = v[i];
+    return ZKMI_OK;
 }
 int zkmi_groth16_sums_dev(uint64_t key, const void* d_witness, uint8_t* sums) {
     ZK_TRY(require_ctx());
@@ -673,8 +912,8 @@ int zkmi_groth16_collect(uint64_t key, int slot, const uint8_t* r_mont, const ui
     g16_finish_dispatch(*K, jA, jB1, jB2, jC, jH, r_mont, s_mont, pi_a, pi_b, pi_c);
     return ZKMI_OK;
 }
-int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_t* witness, size_t witness_len, const uint8_t* r_mont, const uint8_t* s_mont,
-                       uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+static int g16_prove_host(const zkmi_groth16_zkey_paged* zkey, uint64_t key, const uint8_t* witness, size_t witness_len, const uint8_t* r_mont, const uint8_t* s_mont,
+                          uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
     ZK_TRY(require_ctx());
     if (!witness) return fail(ZKMI_ERR_INVALID, "groth16_prove: null witness");
     const uint64_t k = key ? key : 0xffffffffffffffffull;          // key 0: load, prove, release
@@ -685,8 +924,9 @@ int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_
         // a descriptor next to a resident key must describe the same circuit: a caller that re-uses key numbers for different
         // zkeys would otherwise get a proof for the FIRST circuit with rc 0
         const G16Key* R = g16_find(k);
+        const size_t coeffs_len = pg_total(zkey->coeffs);
         if (R->curve != zkey->curve || R->n_vars != zkey->n_vars || R->n_public != zkey->n_public || R->domain != zkey->domain_size ||
-            zkey->coeffs_len < 4 || (size_t)R->n_coef != (zkey->coeffs_len - 4) / 44)
+            coeffs_len < 4 || (size_t)R->n_coef != (coeffs_len - 4) / 44)
             return fail(ZKMI_ERR_INVALID, "groth16_prove: the resident key under this cache key belongs to a different circuit (release it first)");
         // same shape is not the same key: another phase-2 contribution of the same circuit has other delta / bases. The header points are cheap
         // to compare and change with every contribution
@@ -707,6 +947,16 @@ int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_
     int rc = zkmi_groth16_prove_dev(k, K->wk[0].w, r_mont, s_mont, pi_a, pi_b, pi_c);
     if (!key) zkmi_groth16_release(k);
     return rc;
+}
+int zkmi_groth16_prove(const zkmi_groth16_zkey* zkey, uint64_t key, const uint8_t* witness, size_t witness_len, const uint8_t* r_mont, const uint8_t* s_mont,
+                       uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+    if (!zkey) return g16_prove_host(nullptr, key, witness, witness_len, r_mont, s_mont, pi_a, pi_b, pi_c);
+    FlatAsPaged f(*zkey);
+    return g16_prove_host(&f.pz, key, witness, witness_len, r_mont, s_mont, pi_a, pi_b, pi_c);
+}
+int zkmi_groth16_prove_paged(const zkmi_groth16_zkey_paged* zkey, uint64_t key, const uint8_t* witness, size_t witness_len, const uint8_t* r_mont, const uint8_t* s_mont,
+                             uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c) {
+    return g16_prove_host(zkey, key, witness, witness_len, r_mont, s_mont, pi_a, pi_b, pi_c);
 }
 int zkmi_groth16_key_curve(uint64_t key) {
     const G16Key* K = g16_find(key);

@@ -7,6 +7,7 @@
 #include <tuple>
 #include <vector>
 #include "../../include/zkmi.h"
+#include "../../include/zkmi_diag.h"
 
 namespace zkmi {
 

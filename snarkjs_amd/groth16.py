@@ -48,9 +48,12 @@ class ProvingKey:
     """A Groth16 zkey resident on the device (base tables + CSR coefficient table)."""
     _next = 1
 
-    def __init__(self, zkey_bytes, shard=None):
+    def __init__(self, zkey_bytes, shard=None, page_bytes=None, gaps=False):
         """shard = (rank, world): keep only this rank's index range of the five base sections on the device (multi-GPU proofs,
-        BASELINE configs[2]); prove with snarkjs_amd.distributed.groth16_prove_sharded. Default: the whole key."""
+        BASELINE configs[2]); prove with snarkjs_amd.distributed.groth16_prove_sharded. Default: the whole key.
+        page_bytes: hand the bulk sections over as pages of that many bytes (zkmi_groth16_load_paged: what the reference holds after
+        readSection of a section beyond 2^30 bytes, src/groth16_prove.js:57-59); gaps (with shard and page_bytes): pages that lie wholly outside
+        this shard's byte ranges are passed as gaps (NULL pointer), as a loader does that reads only its slice of the file."""
         self.zk = zk = binfile.read_groth16_zkey(zkey_bytes)
         self.curve_id, self.curve_name = _curve_from_q(zk["q"])
         self.key = ProvingKey._next
@@ -59,22 +62,71 @@ class ProvingKey:
         self._keep = {k: np.ascontiguousarray(zk[k]) for k in
                       ("coeffs", "A", "B1", "B2", "C", "H", "vk_alpha_1", "vk_beta_1", "vk_beta_2", "vk_delta_1", "vk_delta_2")}
         p = lambda k: self._keep[k].ctypes.data
-        self.desc = zkmi.Groth16Zkey(self.curve_id, zk["nVars"], zk["nPublic"], zk["domainSize"], p("coeffs"), self._keep["coeffs"].size,
-                                     p("A"), p("B1"), p("B2"), p("C"), p("H"),
-                                     p("vk_alpha_1"), p("vk_beta_1"), p("vk_beta_2"), p("vk_delta_1"), p("vk_delta_2"),
-                                     *(self._keep[k].size for k in ("A", "B1", "B2", "C", "H")))
         q8 = zk["n8q"]
         for k, cnt, g in (("A", zk["nVars"], 2), ("B1", zk["nVars"], 2), ("B2", zk["nVars"], 4), ("C", zk["nVars"] - zk["nPublic"] - 1, 2), ("H", zk["domainSize"], 2)):
             if self._keep[k].size < cnt * g * q8:          # the library checks again (ZKMI_ERR_INVALID)
                 raise ValueError(f"zkey section {k} is shorter than the header requires ({self._keep[k].size} < {cnt * g * q8} bytes)")
         self.shard = shard
-        if shard is None:
-            zkmi.check(zkmi.lib().zkmi_groth16_load(C.byref(self.desc), self.key))
-        else:
+        rng = None
+        if shard is not None:
             from .distributed import shard_range
             rank, world = shard
-            (v_lo, v_hi), (h_lo, h_hi) = shard_range(zk["nVars"], rank, world), shard_range(zk["domainSize"], rank, world)
-            zkmi.check(zkmi.lib().zkmi_groth16_load_shard(C.byref(self.desc), self.key, v_lo, v_hi, h_lo, h_hi))
+            rng = shard_range(zk["nVars"], rank, world) + shard_range(zk["domainSize"], rank, world)
+        L = zkmi.lib()
+        if page_bytes:
+            (v_lo, v_hi, h_lo, h_hi) = rng if rng is not None else (0, zk["nVars"], 0, zk["domainSize"])
+            first_c = zk["nPublic"] + 1
+            need = {"coeffs": (0, self._keep["coeffs"].size), "A": (v_lo * 2 * q8, v_hi * 2 * q8), "B1": (v_lo * 2 * q8, v_hi * 2 * q8), "B2": (v_lo * 4 * q8, v_hi * 4 * q8),
+                    "C": (max(0, v_lo - first_c) * 2 * q8, max(0, v_hi - first_c) * 2 * q8), "H": (h_lo * 2 * q8, h_hi * 2 * q8)}
+            self._pages = {}
+            for k in ("coeffs", "A", "B1", "B2", "C", "H"):
+                a = self._keep[k]
+                pg = [a[o:o + page_bytes] for o in range(0, a.size, page_bytes)] or [a]
+                ptrs = (C.c_void_p * len(pg))(*[x.ctypes.data for x in pg])
+                if gaps and rng is not None:                 # pages wholly outside the byte range this shard reads: not provided
+                    lo, hi = need[k]
+                    for i in range(len(pg)):
+                        if (i + 1) * page_bytes <= lo or i * page_bytes >= hi:
+                            ptrs[i] = None
+                lens = (C.c_size_t * len(pg))(*[x.size for x in pg])
+                self._pages[k] = (pg, ptrs, lens, zkmi.Pages(C.cast(ptrs, C.POINTER(C.c_void_p)), C.cast(lens, C.POINTER(C.c_size_t)), len(pg)))
+            P = lambda k: self._pages[k][3]
+            self.desc = zkmi.Groth16ZkeyPaged(self.curve_id, zk["nVars"], zk["nPublic"], zk["domainSize"], P("coeffs"), P("A"), P("B1"), P("B2"), P("C"), P("H"),
+                                              p("vk_alpha_1"), p("vk_beta_1"), p("vk_beta_2"), p("vk_delta_1"), p("vk_delta_2"))
+            if rng is None:
+                zkmi.check(L.zkmi_groth16_load_paged(C.byref(self.desc), self.key))
+            else:
+                zkmi.check(L.zkmi_groth16_load_shard_paged(C.byref(self.desc), self.key, *rng))
+            return
+        self.desc = zkmi.Groth16Zkey(self.curve_id, zk["nVars"], zk["nPublic"], zk["domainSize"], p("coeffs"), self._keep["coeffs"].size,
+                                     p("A"), p("B1"), p("B2"), p("C"), p("H"),
+                                     p("vk_alpha_1"), p("vk_beta_1"), p("vk_beta_2"), p("vk_delta_1"), p("vk_delta_2"),
+                                     *(self._keep[k].size for k in ("A", "B1", "B2", "C", "H")))
+        if rng is None:
+            zkmi.check(L.zkmi_groth16_load(C.byref(self.desc), self.key))
+        else:
+            zkmi.check(L.zkmi_groth16_load_shard(C.byref(self.desc), self.key, *rng))
+
+    def build_abc(self, witness=None, d_witness=None):
+        """buildABC1 (src/groth16_prove.js:147-187) alone -> (A_T, B_T, C_T) as uint8 arrays of domainSize x 32 bytes (Montgomery)"""
+        n = self.zk["domainSize"]
+        buf = None
+        if d_witness is None:
+            buf = zkmi.DeviceBuffer.from_host(zkmi.u8(witness))
+            d_witness = buf.ptr
+        out = zkmi.DeviceBuffer(3 * n * 32)
+        zkmi.check(zkmi.lib().zkmi_groth16_build_abc_dev(self.key, d_witness, out.ptr, out.ptr + n * 32, out.ptr + 2 * n * 32))
+        h = out.to_host()
+        out.free()
+        if buf is not None:
+            buf.free()
+        return h[:n * 32], h[n * 32:2 * n * 32], h[2 * n * 32:]
+
+    def coef_layout(self):
+        """(records, segments, cut rows, partial-sum slots, padded terms) of the resident coefficient layout (include/zkmi_diag.h)"""
+        out = (C.c_uint64 * 5)()
+        zkmi.check(zkmi.lib().zkmi_groth16_coef_layout(self.key, out, 5))
+        return dict(zip(("n_coef", "segments", "cut_rows", "partial_slots", "padded_terms"), [int(x) for x in out]))
 
     def sums_raw(self, witness, d_witness=None):
         """The five MSM sums of this key (shard) for `witness` (full witness): jA | jB1 | jB2 | jC | jH Jacobian bytes."""

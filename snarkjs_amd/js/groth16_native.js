@@ -27,26 +27,104 @@ function sections(data, magic) {                           // @iden3/binfileutil
     return out;
 }
 
-// zkey header + sections -> the descriptor the addon takes (src/zkey_utils.js:229-259); throws the reference's messages
-function parseZkey(zkeyBytes) {
-    const zs = sections(zkeyBytes, "zkey");
-    if (new DataView(zs[1][0].buffer, zs[1][0].byteOffset, 4).getUint32(0, true) != 1) throw new Error("zkey file is not groth16");
-    const hdr = zs[2][0], hv = new DataView(hdr.buffer, hdr.byteOffset, hdr.byteLength);
-    const n8q = hv.getUint32(0, true), n8r = hv.getUint32(4 + n8q, true);
-    let o = 8 + n8q + n8r;
-    const nVars = hv.getUint32(o, true), nPublic = hv.getUint32(o + 4, true), domainSize = hv.getUint32(o + 8, true);
-    o += 12;
-    const pt = (k) => { const v = hdr.subarray(o, o + k * n8q); o += k * n8q; return v; };
-    const alpha1 = pt(2), beta1 = pt(2), beta2 = pt(4); pt(4); const delta1 = pt(2), delta2 = pt(4);
-    for (const [sec, cnt, g] of [[5, nVars, 2], [6, nVars, 2], [7, nVars, 4], [8, nVars - nPublic - 1, 2], [9, domainSize, 2]])
-        if (!zs[sec] || zs[sec][0].byteLength < cnt * g * n8q) throw new Error(`zkey section ${sec} is shorter than its header requires`);
-    const curveName = n8q == 32 ? "bn128" : "bls12381";
-    return { n8q, n8r, nVars, nPublic, domainSize, curveName, curveId: n8q == 32 ? 0 : 1,
-             desc: { curve: n8q == 32 ? 0 : 1, nVars, nPublic, domainSize, coeffs: zs[4][0], A: zs[5][0], B1: zs[6][0], B2: zs[7][0], C: zs[8][0], H: zs[9][0],
-                     alpha1, beta1, beta2, delta1, delta2 } };
+// ---- reading a zkey the way the reference does: section by section, by offset (src/groth16_prove.js:29-33, :57-59, :84-100) -----------------
+// groth16Prove opens the file with binFileUtils.readBinFile and pulls each section with readSection, which hands back a Uint8Array below 2^30
+// bytes and a BigBuffer (pages of <= 1 GiB) from there on: sections 4 - 9 of a 2^24-constraint key are 1 - 2 GB each and the whole file is
+// 9.4 GB, more than one Node buffer can hold (2 GiB - 1 under Node 12). A source is
+//   a Uint8Array with the file's bytes | a path | { type: "file", fileName } | { type: "mem", data } (fastfile's descriptors; data may be a BigBuffer).
+function readerOf(src) {
+    if (typeof src === "string") src = { type: "file", fileName: src };
+    if (src instanceof Uint8Array) src = { type: "mem", data: src };
+    if (src && src.type === "mem" && src.data) {
+        const d = src.data;
+        if (d instanceof Uint8Array) return { size: d.byteLength, read: (pos, len) => d.subarray(pos, pos + len), close() {} };
+        if (Array.isArray(d.buffers) && typeof d.slice === "function")                 // ffjavascript BigBuffer (min.js:1@183423)
+            return { size: d.byteLength, read: (pos, len) => { const x = d.slice(pos, pos + len); if (x.buffers) throw new Error("zkey: page larger than a BigBuffer page"); return x; }, close() {} };
+    }
+    if (src && src.type === "file" && src.fileName) {
+        const fs = require("fs");
+        const fd = fs.openSync(src.fileName, "r");
+        return { size: fs.fstatSync(fd).size, close() { fs.closeSync(fd); },
+                 read(pos, len) {
+                     const b = Buffer.allocUnsafe(len);
+                     for (let got = 0; got < len;) { const k = fs.readSync(fd, b, got, len - got, pos + got); if (k <= 0) throw new Error(src.fileName + ": Invalid File format (truncated)"); got += k; }
+                     return new Uint8Array(b.buffer, b.byteOffset, len);
+                 } };
+    }
+    throw new Error("zkey: expected a Uint8Array, a path, { type: \"file\", fileName } or { type: \"mem\", data }");
+}
+// section table of an @iden3/binfileutils container: type -> [{ pos, len }]
+function sectionTable(rd, magic) {
+    const h = rd.read(0, 12);
+    for (let i = 0; i < 4; i++) if (h[i] != magic.charCodeAt(i)) throw new Error(rd.size + ": Invalid File format");
+    const n = new DataView(h.buffer, h.byteOffset, 12).getUint32(8, true), tab = {};
+    let pos = 12;
+    for (let i = 0; i < n; i++) {
+        if (pos + 12 > rd.size) throw new Error(rd.size + ": Invalid File format");
+        const sh = rd.read(pos, 12), dv = new DataView(sh.buffer, sh.byteOffset, 12);
+        const t = dv.getUint32(0, true), len = Number(dv.getBigUint64(4, true));
+        (tab[t] = tab[t] || []).push({ pos: pos + 12, len });
+        pos += 12 + len;
+    }
+    return tab;
+}
+const BIG_PAGE = 1 << 30;                                 // ffjavascript's BigBuffer page; readSection returns a plain Uint8Array below it
+// one section as the addon takes it: a Uint8Array, or an array of pages; with `need` = [lo, hi) only that byte range is read and the rest of the
+// section is passed as gaps (numbers) — a shard worker reads 1/world of the base sections
+function sectionPages(rd, s, pageBytes, need) {
+    if (!need && s.len <= pageBytes) return rd.read(s.pos, s.len);
+    const [lo, hi] = need || [0, s.len], out = [];
+    if (lo > 0) out.push(lo);
+    for (let o = lo; o < hi; o += pageBytes) out.push(rd.read(s.pos + o, Math.min(pageBytes, hi - o)));
+    if (hi < s.len) out.push(s.len - hi);
+    if (!out.length) out.push(new Uint8Array(0));
+    return out;
+}
+// what a caller that has ALREADY read the sections with the reference's readSection passes on: Uint8Array stays, BigBuffer -> its pages
+const toPages = (x) => (x && Array.isArray(x.buffers)) ? x.buffers : x;
+
+// zkey header + sections -> the descriptor the addon takes (src/zkey_utils.js:229-259); throws the reference's messages.
+// opts.pageBytes: page size of the bulk sections (default 2^30); opts.shard = { vLo, vHi, hLo, hHi }: read only this shard's ranges of sections 5 - 9;
+// opts.headerOnly: no bulk section is read (desc = null).
+function openZkey(src, opts) {
+    opts = opts || {};
+    const rd = readerOf(src);
+    try {
+        const tab = sectionTable(rd, "zkey");
+        for (const id of [1, 2, 4, 5, 6, 7, 8, 9]) if (!tab[id]) throw new Error(`zkey: Missing section ${id}`);
+        const s1 = rd.read(tab[1][0].pos, 4);
+        if (new DataView(s1.buffer, s1.byteOffset, 4).getUint32(0, true) != 1) throw new Error("zkey file is not groth16");
+        const hdr = Uint8Array.from(rd.read(tab[2][0].pos, tab[2][0].len)), hv = new DataView(hdr.buffer, hdr.byteOffset, hdr.byteLength);
+        const n8q = hv.getUint32(0, true), n8r = hv.getUint32(4 + n8q, true);
+        let o = 8 + n8q + n8r;
+        const nVars = hv.getUint32(o, true), nPublic = hv.getUint32(o + 4, true), domainSize = hv.getUint32(o + 8, true);
+        o += 12;
+        const pt = (k) => { const v = hdr.subarray(o, o + k * n8q); o += k * n8q; return v; };
+        const alpha1 = pt(2), beta1 = pt(2), beta2 = pt(4); pt(4); const delta1 = pt(2), delta2 = pt(4);
+        for (const [sec, cnt, g] of [[5, nVars, 2], [6, nVars, 2], [7, nVars, 4], [8, nVars - nPublic - 1, 2], [9, domainSize, 2]])
+            if (tab[sec][0].len < cnt * g * n8q) throw new Error(`zkey section ${sec} is shorter than its header requires`);
+        const curveName = n8q == 32 ? "bn128" : "bls12381";
+        const zk = { n8q, n8r, nVars, nPublic, domainSize, curveName, curveId: n8q == 32 ? 0 : 1, desc: null };
+        if (opts.headerOnly) return zk;
+        const page = opts.pageBytes || BIG_PAGE, sh = opts.shard || null, g1 = 2 * n8q, fc = nPublic + 1;
+        const need = sh ? { 5: [sh.vLo * g1, sh.vHi * g1], 6: [sh.vLo * g1, sh.vHi * g1], 7: [sh.vLo * 2 * g1, sh.vHi * 2 * g1],
+                            8: [Math.max(0, sh.vLo - fc) * g1, Math.max(0, sh.vHi - fc) * g1], 9: [sh.hLo * g1, sh.hHi * g1] } : {};
+        const sec = (id) => sectionPages(rd, tab[id][0], page, need[id]);
+        zk.desc = { curve: zk.curveId, nVars, nPublic, domainSize, coeffs: sec(4), A: sec(5), B1: sec(6), B2: sec(7), C: sec(8), H: sec(9), alpha1, beta1, beta2, delta1, delta2 };
+        return zk;
+    } finally { rd.close(); }
+}
+const parseZkey = (zkeyBytes, opts) => openZkey(zkeyBytes, opts);
+// the same descriptor from sections a caller read itself with the reference's binFileUtils.readSection (Uint8Array | BigBuffer each)
+function descFromSections(zk, secs) {
+    return { curve: zk.curveId, nVars: zk.nVars, nPublic: zk.nPublic, domainSize: zk.domainSize, coeffs: toPages(secs[4]), A: toPages(secs[5]), B1: toPages(secs[6]),
+             B2: toPages(secs[7]), C: toPages(secs[8]), H: toPages(secs[9]), alpha1: secs.alpha1, beta1: secs.beta1, beta2: secs.beta2, delta1: secs.delta1, delta2: secs.delta2 };
 }
 // wtns sections -> the witness buffer (src/wtns_utils.js:62-72), checked against the circuit like src/groth16_prove.js:45-47
 function parseWtns(wtnsBytes, zk) {
+    if (typeof wtnsBytes === "string") wtnsBytes = new Uint8Array(require("fs").readFileSync(wtnsBytes));
+    else if (wtnsBytes && wtnsBytes.type === "file") wtnsBytes = new Uint8Array(require("fs").readFileSync(wtnsBytes.fileName));
+    else if (wtnsBytes && wtnsBytes.type === "mem") wtnsBytes = wtnsBytes.data;
     const ws = sections(wtnsBytes, "wtns");
     const wh = new DataView(ws[1][0].buffer, ws[1][0].byteOffset, ws[1][0].byteLength);
     const nWitness = wh.getUint32(4 + wh.getUint32(0, true), true);
@@ -66,16 +144,18 @@ function makeProver(snarkjs, options) {
     const addon = options.addon || loadAddon();
     addon.init(options.device === undefined ? 0 : options.device);
     const useAsync = options.async !== false;
-    // zkey Uint8Array -> Promise of its resident key. The promise is stored BEFORE the load is awaited: concurrent prove() calls on a
+    // zkey source (Uint8Array | path | fastfile descriptor: readerOf above) -> Promise of its resident key. The promise is stored BEFORE the load is awaited: concurrent prove() calls on a
     // zkey that is not resident yet share ONE load (two loads would leave a key — GBs of window tables at 2^20 — on the device that
     // release() never frees); a load that fails is forgotten and whatever it left on the device is released.
     const resident = new Map();
 
-    function ensureKey(zkeyBytes) {
+    const keyOf = (src) => (src && typeof src === "object" && !(src instanceof Uint8Array) && src.type === "file") ? "file:" + src.fileName : (src && src.type === "mem" ? src.data : src);
+    function ensureKey(zkeySrc) {
+        const zkeyBytes = keyOf(zkeySrc);
         let p = resident.get(zkeyBytes);
         if (p) return p;
         p = (async () => {
-            const zk = parseZkey(zkeyBytes);
+            const zk = openZkey(zkeySrc, { pageBytes: options.pageBytes });     // sections read by offset, in pages: any key size (2^24: 9.4 GB)
             zk.key = nextKey++;
             zk.curve = await snarkjs.curves.getCurveFromName(zk.curveName);
             try {
@@ -86,6 +166,7 @@ function makeProver(snarkjs, options) {
                 try { addon.groth16Release(zk.key); } catch (e2) { /* nothing was loaded */ }
                 throw e;
             }
+            zk.desc = null;                                       // the host copy of the sections is not needed once the key is resident
             return zk;
         })();
         resident.set(zkeyBytes, p);
@@ -105,7 +186,8 @@ function makeProver(snarkjs, options) {
                  publicSignals };
     }
 
-    // one proof; the event loop keeps turning while it runs (options.async !== false: the call runs on a libuv pool thread)
+    // one proof; the event loop keeps turning while it runs (options.async !== false: the call runs on a libuv pool thread).
+    // zkeyBytes / wtnsBytes: the files' bytes, paths, or fastfile descriptors — what snarkjs.groth16.prove takes (src/groth16_prove.js:28)
     async function prove(zkeyBytes, wtnsBytes) {
         const zk = await ensureKey(zkeyBytes);
         const witness = parseWtns(wtnsBytes, zk);
@@ -149,4 +231,4 @@ function makeProver(snarkjs, options) {
     return { prove, proveMany, release };
 }
 
-module.exports = { makeProver, parseZkey, parseWtns, sections };
+module.exports = { makeProver, parseZkey, openZkey, descFromSections, toPages, parseWtns, sections };

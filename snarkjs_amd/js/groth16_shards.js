@@ -29,7 +29,7 @@
 "use strict";
 const path = require("path"), fs = require("fs"), crypto = require("crypto");
 const { fork } = require("child_process");
-const { parseZkey, parseWtns } = require("./groth16_native.js");
+const { openZkey, parseWtns } = require("./groth16_native.js");
 
 const R = { 0: 21888242871839275222246405745257275088548364400416034343698204186575808495617n, 1: 52435875175126190479447740508185965837690552500527637822603658699938581184513n };
 const Q = { 0: 21888242871839275222246405745257275088696311157297823662689037894645226208583n,
@@ -57,12 +57,15 @@ async function workerMain() {
     const addon = require(cfg.addonPath);
     const { rank, world } = cfg;
     const peer = cfg.exchange === "peer";
-    await addon.init(cfg.devices ? cfg.devices[rank] : rank);
-    const zkeyBytes = new Uint8Array(fs.readFileSync(cfg.zkeyPath));
-    const zk = parseZkey(zkeyBytes);
-    const n = zk.domainSize, m = zk.nVars, cid = zk.curveId, key = 1;
+    await addon.init(cfg.devices[rank]);
+    // the header first, then ONLY this shard's byte ranges of the five base sections (1 / world of them; the rest is passed as gaps) and the whole
+    // coefficient section, by offset from the file: a 2^24 key (9.4 GB) never exists in one buffer, and 8 workers read it once between them
+    const hd = openZkey(cfg.zkeyPath, { headerOnly: true });
+    const n = hd.domainSize, m = hd.nVars, cid = hd.curveId, key = 1;
     const [vLo, vHi] = shardRange(m, rank, world), [hLo, hHi] = shardRange(n, rank, world);
+    let zk = openZkey(cfg.zkeyPath, { shard: { vLo, vHi, hLo, hHi }, pageBytes: cfg.pageBytes || undefined });
     await addon.groth16LoadShard(zk.desc, key, vLo, vHi, hLo, hHi);
+    zk = null;
     const owned = [0, 1, 2].filter((c) => chainOwner(c, world) === rank);
     const shmW = addon.shmMap(`${cfg.shmPrefix}_w`, m * 32, false);                  // the witness: 0600 shared memory written by the parent
     const shm = peer ? null : [0, 1, 2].map((c) => addon.shmMap(`${cfg.shmPrefix}_c${c}`, n * 32, false));
@@ -147,7 +150,17 @@ class ShardedProver {
         this.zkeyPath = opts.zkeyPath;
         this.addonPath = opts.addonPath || path.join(__dirname, "..", "napi", "zkmi_napi.node");
         const addon = this.addon = require(this.addonPath);
-        const zk = this.zk = parseZkey(new Uint8Array(fs.readFileSync(this.zkeyPath)));
+        const zk = this.zk = openZkey(this.zkeyPath, { headerOnly: true });
+        // worker rank -> HIP device ordinal: opts.devices, else ZKMI_SHARD_DEVICES="0,1,2,..." in the environment, else rank modulo the devices this
+        // process can see (HIP_VISIBLE_DEVICES renumbers the visible ones from 0: the identity over deviceCount() honours it; more workers than
+        // devices share them round robin and say so)
+        const envMap = process.env.ZKMI_SHARD_DEVICES ? process.env.ZKMI_SHARD_DEVICES.split(",").map((x) => parseInt(x, 10)) : null;
+        let devices = opts.devices || envMap;
+        const visible = typeof addon.deviceCount === "function" ? addon.deviceCount() : 0;
+        if (!devices) { devices = []; for (let r = 0; r < this.world; r++) devices.push(visible > 0 ? r % visible : r); }
+        if (devices.length < this.world || devices.some((d) => !Number.isInteger(d) || d < 0)) throw new Error(`ShardedProver: device map ${JSON.stringify(devices)} does not cover ${this.world} workers`);
+        if (visible > 0 && devices.some((d) => d >= visible)) throw new Error(`ShardedProver: device map ${JSON.stringify(devices)} names a device beyond the ${visible} visible to this process (HIP_VISIBLE_DEVICES=${process.env.HIP_VISIBLE_DEVICES || ""})`);
+        this.devices = devices.slice(0, this.world);
         // "peer": chain outputs move GPU to GPU (zkmi_ipc_* / zkmi_peer_copy); "shm": through page-locked shared host memory (PCIe both ways).
         // Not given: "peer" when the addon has the entry points, and — should the peer handshake fail on this host (no HSA IPC in the container,
         // processes on different HIP runtimes, no peer access between two GPUs) — every worker is restarted with "shm"; the path taken is in
@@ -190,7 +203,7 @@ class ShardedProver {
             let up = 0, peersOk = 0;
             const handles = {};
             for (let rank = 0; rank < this.world; rank++) {
-                const cfg = { rank, world: this.world, zkeyPath: this.zkeyPath, addonPath: this.addonPath, shmPrefix: this.shmPrefix, devices: opts.devices || null, exchange: this.exchange };
+                const cfg = { rank, world: this.world, zkeyPath: this.zkeyPath, addonPath: this.addonPath, shmPrefix: this.shmPrefix, devices: this.devices, exchange: this.exchange, pageBytes: opts.pageBytes || null };
                 const w = fork(__filename, ["--zkmi-shard-worker"], { env: Object.assign({}, process.env, { ZKMI_SHARD_CFG: JSON.stringify(cfg) }), execArgv: opts.execArgv || process.execArgv });
                 w.on("message", (msg) => {
                     if (gen !== this.gen) return;
@@ -281,7 +294,7 @@ class ShardedProver {
             const publicSignals = [];
             for (let i = 1; i <= zk.nPublic; i++) publicSignals.push(fromLE(witness.subarray(i * zk.n8r, (i + 1) * zk.n8r)).toString());
             return { proof: { pi_a: pointToObject(cid, 1, b(res.msg.pi_a)), pi_b: pointToObject(cid, 2, b(res.msg.pi_b)), pi_c: pointToObject(cid, 1, b(res.msg.pi_c)), protocol: "groth16", curve: zk.curveName },
-                     publicSignals, events: res.order, exchange: this.exchange, exchangeFallback: this.exchangeFallback, timeline_ms: at };
+                     publicSignals, events: res.order, exchange: this.exchange, exchangeFallback: this.exchangeFallback, devices: this.devices, timeline_ms: at };
         } catch (e) {
             this.needReset = !this.dead;                       // some workers may sit between the two halves of this proof
             throw e;

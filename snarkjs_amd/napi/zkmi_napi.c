@@ -18,7 +18,7 @@
 #include <string.h>
 #include "../../include/zkmi.h"
 
-#define MAX_PAGES 64
+#define MAX_PAGES 256
 
 /* The library serves one caller at a time (include/zkmi.h): every entry point is taken under this lock, on the main thread and on
  * the libuv pool threads of the *Async functions alike. */
@@ -45,8 +45,9 @@ typedef struct {
     size_t total;
 } pages_t;
 
-/* v: Uint8Array | Array<Uint8Array> */
-static int get_pages(napi_env env, napi_value v, pages_t* out) {
+/* v: Uint8Array | Array<Uint8Array>; with gaps != 0 an array element may also be a NUMBER = a gap of that many bytes the caller did not read
+ * (pointer NULL: include/zkmi.h, zkmi_groth16_zkey_paged); a BigBuffer of ffjavascript is passed as its .buffers array by the JS side */
+static int get_pages_ex(napi_env env, napi_value v, pages_t* out, int gaps) {
     bool is_arr = false, is_ta = false;
     out->n = 0; out->total = 0;
     if (napi_is_typedarray(env, v, &is_ta) != napi_ok) return -1;
@@ -60,14 +61,22 @@ static int get_pages(napi_env env, napi_value v, pages_t* out) {
     uint32_t k = 0;
     if (napi_get_array_length(env, v, &k) != napi_ok || k > MAX_PAGES) return -1;
     for (uint32_t i = 0; i < k; i++) {
-        napi_value e; napi_typedarray_type t; size_t len; void* data; napi_value ab; size_t off;
-        if (napi_get_element(env, v, i, &e) != napi_ok) return -1;
+        napi_value e; napi_typedarray_type t; size_t len; void* data; napi_value ab; size_t off; napi_valuetype vt;
+        if (napi_get_element(env, v, i, &e) != napi_ok || napi_typeof(env, e, &vt) != napi_ok) return -1;
+        if (vt == napi_number) {
+            double g;
+            if (!gaps || napi_get_value_double(env, e, &g) != napi_ok || g < 0 || g > 9007199254740992.0) return -1;
+            out->ptr[i] = NULL; out->len[i] = (size_t)g; out->total += (size_t)g;
+            continue;
+        }
         if (napi_get_typedarray_info(env, e, &t, &len, &data, &ab, &off) != napi_ok || t != napi_uint8_array) return -1;
-        out->ptr[i] = (const uint8_t*)data; out->len[i] = len; out->total += len;
+        /* an empty typed array may report a NULL data pointer: keep the page, never as a gap */
+        out->ptr[i] = len ? (const uint8_t*)data : (const uint8_t*)""; out->len[i] = len; out->total += len;
     }
     out->n = (int)k;
     return 0;
 }
+static int get_pages(napi_env env, napi_value v, pages_t* out) { return get_pages_ex(env, v, out, 0); }
 static zkmi_pages as_zk(const pages_t* p) { zkmi_pages z; z.ptr = p->ptr; z.len = p->len; z.n_pages = p->n; return z; }
 
 static int get_i32(napi_env env, napi_value v, int32_t* o) { return napi_get_value_int32(env, v, o) == napi_ok ? 0 : -1; }
@@ -96,6 +105,25 @@ static napi_value new_u8(napi_env env, size_t n, uint8_t** data) {
     if (argc < N) { napi_throw_type_error(env, NULL, "zkmi: too few arguments"); return NULL; }
 #define BAD_ARG() do { napi_throw_type_error(env, NULL, "zkmi: bad argument"); return NULL; } while (0)
 
+/* A Groth16 zkey descriptor as the addon holds it: the paged C struct plus the page arrays its zkmi_pages point into (a copy must re-point them:
+ * zkey_desc_fix). Sections 4 - 9 arrive as Uint8Array | Array<Uint8Array | gapBytes> — what binFileUtils.readSection returns (a Uint8Array, or a
+ * BigBuffer's .buffers from 2^30 bytes on; src/groth16_prove.js:57-59). */
+typedef struct zkey_desc {
+    zkmi_groth16_zkey_paged z;
+    pages_t sec[6];                        /* coeffs, A, B1, B2, C, H */
+} zkey_desc;
+static void zkey_desc_fix(zkey_desc* d) {
+    zkmi_pages* dst[6] = {&d->z.coeffs, &d->z.bases_a, &d->z.bases_b1, &d->z.bases_b2, &d->z.bases_c, &d->z.bases_h};
+    for (int i = 0; i < 6; i++) { dst[i]->ptr = d->sec[i].ptr; dst[i]->len = d->sec[i].len; dst[i]->n_pages = d->sec[i].n; }
+}
+static zkey_desc* zkey_desc_dup(const zkey_desc* d) {
+    zkey_desc* c = (zkey_desc*)malloc(sizeof *c);
+    if (!c) return NULL;
+    memcpy(c, d, sizeof *c);
+    zkey_desc_fix(c);
+    return c;
+}
+
 /* ---- asynchronous calls (napi_create_async_work; SURVEY.md 8 b) -----------------------------------------------------------------
  * msmAsync / nttAsync / groth16ProveAsync take the arguments of msm / ntt / groth16Prove and return a Promise: arguments are parsed
  * on the main thread, the library call runs on a libuv pool thread (the Node event loop keeps turning), the promise is settled
@@ -111,7 +139,7 @@ typedef struct {
     pages_t a, b;
     double n, sb, key;
     uint8_t first[32], inc[32]; bool has_first, has_inc;
-    zkmi_groth16_zkey zk; bool has_zk;
+    struct zkey_desc* zk; bool has_zk;      /* heap copy of the paged descriptor (freed in job_complete) */
     uint8_t *o0, *o1, *o2;
     int rc; char err[400];
 } job_t;
@@ -120,10 +148,10 @@ static int job_run(job_t* j) {
     switch (j->kind) {
     case 0: return zkmi_msm(j->curve, j->group, as_zk(&j->a), as_zk(&j->b), (size_t)j->n, (size_t)j->sb, (uint64_t)j->key, j->o0);
     case 1: return zkmi_ntt(j->curve, as_zk(&j->a), (uint8_t* const*)j->b.ptr, j->b.len, j->b.n, (unsigned)j->logn, j->inverse, j->has_first ? j->first : NULL, j->has_inc ? j->inc : NULL);
-    case 2: return zkmi_groth16_prove(j->has_zk ? &j->zk : NULL, (uint64_t)j->key, j->a.ptr[0], j->a.len[0], j->first, j->inc, j->o0, j->o1, j->o2);
+    case 2: return zkmi_groth16_prove_paged(j->has_zk ? &j->zk->z : NULL, (uint64_t)j->key, j->a.ptr[0], j->a.len[0], j->first, j->inc, j->o0, j->o1, j->o2);
     case 3: return zkmi_groth16_submit((uint64_t)j->key, j->a.ptr[0], j->a.len[0], j->slot);
     case 4: return zkmi_groth16_collect((uint64_t)j->key, j->slot, j->first, j->inc, j->o0, j->o1, j->o2);
-    default: return zkmi_groth16_load(&j->zk, (uint64_t)j->key);
+    default: return zkmi_groth16_load_paged(&j->zk->z, (uint64_t)j->key);
     }
 }
 static void job_execute(napi_env env, void* data) {
@@ -148,12 +176,13 @@ static void job_complete(napi_env env, napi_status status, void* data) {
     for (int i = 0; i < j->n_keep; i++) napi_delete_reference(env, j->keep[i]);
     if (j->result) napi_delete_reference(env, j->result);
     napi_delete_async_work(env, j->work);
+    free(j->zk);
     free(j);
 }
 /* queue `j` (heap, filled by the caller); keeps argv[0..argc) and `result` alive; returns the promise */
 static napi_value job_queue(napi_env env, job_t* j, const char* name, napi_value* argv, size_t argc, napi_value result) {
     napi_value promise, rname;
-    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) { free(j); napi_throw_error(env, NULL, "zkmi: cannot create a promise"); return NULL; }
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) { free(j->zk); free(j); napi_throw_error(env, NULL, "zkmi: cannot create a promise"); return NULL; }
     for (size_t i = 0; i < argc && j->n_keep < 8; i++) {
         napi_valuetype t;
         if (napi_typeof(env, argv[i], &t) == napi_ok && t == napi_object && napi_create_reference(env, argv[i], 1, &j->keep[j->n_keep]) == napi_ok) j->n_keep++;
@@ -167,6 +196,7 @@ static napi_value job_queue(napi_env env, job_t* j, const char* name, napi_value
         napi_reject_deferred(env, j->deferred, err);
         for (int i = 0; i < j->n_keep; i++) napi_delete_reference(env, j->keep[i]);
         if (j->result) napi_delete_reference(env, j->result);
+        free(j->zk);
         free(j);
     }
     return promise;
@@ -327,7 +357,7 @@ static napi_value js_to_affine(napi_env env, napi_callback_info info) {
     return res;
 }
 /* groth16Prove({curve,nVars,nPublic,domainSize,coeffs,A,B1,B2,C,H,alpha1,beta1,beta2,delta1,delta2} | null, key, witness, r, s)
- *   -> {pi_a, pi_b, pi_c} (affine Montgomery bytes). Sections must be single Uint8Arrays (< 2 GiB each). */
+ *   -> {pi_a, pi_b, pi_c} (affine Montgomery bytes). A section is a Uint8Array or an array of Uint8Array pages (ffjavascript BigBuffer.buffers). */
 static int get_named_u8(napi_env env, napi_value obj, const char* name, const uint8_t** p, size_t* len) {
     napi_value v; pages_t pg;
     if (napi_get_named_property(env, obj, name, &v) != napi_ok || get_pages(env, v, &pg) || pg.n != 1) return -1;
@@ -338,17 +368,23 @@ static int get_named_u32(napi_env env, napi_value obj, const char* name, uint32_
     napi_value v;
     return (napi_get_named_property(env, obj, name, &v) == napi_ok && napi_get_value_uint32(env, v, o) == napi_ok) ? 0 : -1;
 }
-/* {curve,nVars,nPublic,domainSize,coeffs,A,B1,B2,C,H,alpha1,beta1,beta2,delta1,delta2} -> zkmi_groth16_zkey (pointers into the typed arrays) */
-static int get_zkey_desc(napi_env env, napi_value obj, zkmi_groth16_zkey* zk) {
+/* {curve,nVars,nPublic,domainSize,coeffs,A,B1,B2,C,H,alpha1,beta1,beta2,delta1,delta2} -> zkey_desc (pointers into the typed arrays); the six
+ * sections may be single Uint8Arrays or page arrays, base sections also with gaps (numbers) for a shard load */
+static int get_named_pages(napi_env env, napi_value obj, const char* name, pages_t* pg, int gaps) {
+    napi_value v;
+    return (napi_get_named_property(env, obj, name, &v) == napi_ok && get_pages_ex(env, v, pg, gaps) == 0) ? 0 : -1;
+}
+static int get_zkey_desc(napi_env env, napi_value obj, zkey_desc* d) {
     uint32_t c;
-    memset(zk, 0, sizeof *zk);
+    memset(d, 0, sizeof *d);
+    zkmi_groth16_zkey_paged* zk = &d->z;
     if (get_named_u32(env, obj, "curve", &c) || get_named_u32(env, obj, "nVars", &zk->n_vars) || get_named_u32(env, obj, "nPublic", &zk->n_public) ||
-        get_named_u32(env, obj, "domainSize", &zk->domain_size) || get_named_u8(env, obj, "coeffs", &zk->coeffs, &zk->coeffs_len) ||
-        get_named_u8(env, obj, "A", &zk->bases_a, &zk->bases_a_len) || get_named_u8(env, obj, "B1", &zk->bases_b1, &zk->bases_b1_len) ||
-        get_named_u8(env, obj, "B2", &zk->bases_b2, &zk->bases_b2_len) || get_named_u8(env, obj, "C", &zk->bases_c, &zk->bases_c_len) ||
-        get_named_u8(env, obj, "H", &zk->bases_h, &zk->bases_h_len)) return -1;
+        get_named_u32(env, obj, "domainSize", &zk->domain_size) || get_named_pages(env, obj, "coeffs", &d->sec[0], 0) ||
+        get_named_pages(env, obj, "A", &d->sec[1], 1) || get_named_pages(env, obj, "B1", &d->sec[2], 1) || get_named_pages(env, obj, "B2", &d->sec[3], 1) ||
+        get_named_pages(env, obj, "C", &d->sec[4], 1) || get_named_pages(env, obj, "H", &d->sec[5], 1)) return -1;
     if (c != ZKMI_CURVE_BN128 && c != ZKMI_CURVE_BLS12381) return -1;
     zk->curve = (int)c;
+    zkey_desc_fix(d);
     /* header points: 2*n8q (G1) / 4*n8q (G2) bytes each */
     const size_t q = c == ZKMI_CURVE_BN128 ? 32 : 48;
     size_t l1, l2, l3, l4, l5;
@@ -367,7 +403,7 @@ static napi_value new_proof_obj(napi_env env, int curve, uint8_t** pa, uint8_t**
 static int key_curve_mismatch(napi_env env, double key, int32_t curve);
 static napi_value groth16_impl(napi_env env, napi_callback_info info, bool async) {
     ARGS(5);
-    zkmi_groth16_zkey zk, *pzk = NULL;
+    zkey_desc zk, *pzk = NULL;
     napi_valuetype t;
     NAPI_OK(napi_typeof(env, argv[0], &t));
     double key;
@@ -376,7 +412,7 @@ static napi_value groth16_impl(napi_env env, napi_callback_info info, bool async
     int curve = 0;
     if (t == napi_object) {
         if (get_zkey_desc(env, argv[0], &zk)) BAD_ARG();
-        curve = zk.curve; pzk = &zk;
+        curve = zk.z.curve; pzk = &zk;
     }
     if (get_f64(env, argv[1], &key) || get_pages(env, argv[2], &w) || w.n != 1 || get_opt32(env, argv[3], &r) || get_opt32(env, argv[4], &s) || !r || !s) BAD_ARG();
     if (!pzk) {            /* key already resident: the caller passes the curve id in place of the zkey object */
@@ -393,10 +429,10 @@ static napi_value groth16_impl(napi_env env, napi_callback_info info, bool async
         if (!j) BAD_ARG();
         j->kind = 2; j->key = key; j->a = w; j->o0 = pa; j->o1 = pb; j->o2 = pc;
         memcpy(j->first, r, 32); memcpy(j->inc, s, 32);
-        if (pzk) { j->zk = zk; j->has_zk = true; }
+        if (pzk) { j->zk = zkey_desc_dup(pzk); if (!j->zk) { free(j); BAD_ARG(); } j->has_zk = true; }
         return job_queue(env, j, "zkmi.groth16Prove", argv, 5, res);
     }
-    int rc = ZK_CALL(zkmi_groth16_prove(pzk, (uint64_t)key, w.ptr[0], w.len[0], r, s, pa, pb, pc));
+    int rc = ZK_CALL(zkmi_groth16_prove_paged(pzk ? &pzk->z : NULL, (uint64_t)key, w.ptr[0], w.len[0], r, s, pa, pb, pc));
     if (rc) return throw_zkmi(env, rc);
     return res;
 }
@@ -415,15 +451,15 @@ static napi_value js_groth16_release(napi_env env, napi_callback_info info) {
 static napi_value load_impl(napi_env env, napi_callback_info info, bool async) {
     ARGS(2);
     double key;
-    zkmi_groth16_zkey zk;
+    zkey_desc zk;
     if (get_zkey_desc(env, argv[0], &zk) || get_f64(env, argv[1], &key) || key < 1) BAD_ARG();
     if (async) {
         job_t* j = (job_t*)calloc(1, sizeof *j);
         if (!j) BAD_ARG();
-        j->kind = 5; j->key = key; j->zk = zk; j->has_zk = true;
+        j->kind = 5; j->key = key; j->zk = zkey_desc_dup(&zk); if (!j->zk) { free(j); BAD_ARG(); } j->has_zk = true;
         return job_queue(env, j, "zkmi.groth16Load", argv, 2, NULL);
     }
-    int rc = ZK_CALL(zkmi_groth16_load(&zk, (uint64_t)key));
+    int rc = ZK_CALL(zkmi_groth16_load_paged(&zk.z, (uint64_t)key));
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
@@ -432,10 +468,10 @@ static napi_value js_groth16_load_async(napi_env env, napi_callback_info info) {
 static napi_value js_groth16_load_shard(napi_env env, napi_callback_info info) {
     ARGS(6);
     double key, a, b, c, d;
-    zkmi_groth16_zkey zk;
+    zkey_desc zk;
     if (get_zkey_desc(env, argv[0], &zk) || get_f64(env, argv[1], &key) || key < 1 || get_f64(env, argv[2], &a) || get_f64(env, argv[3], &b) || get_f64(env, argv[4], &c) ||
         get_f64(env, argv[5], &d) || a < 0 || b < a || c < 0 || d < c || b > 4294967295.0 || d > 4294967295.0) BAD_ARG();
-    int rc = ZK_CALL(zkmi_groth16_load_shard(&zk, (uint64_t)key, (uint32_t)a, (uint32_t)b, (uint32_t)c, (uint32_t)d));
+    int rc = ZK_CALL(zkmi_groth16_load_shard_paged(&zk.z, (uint64_t)key, (uint32_t)a, (uint32_t)b, (uint32_t)c, (uint32_t)d));
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }

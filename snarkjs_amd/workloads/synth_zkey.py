@@ -46,10 +46,64 @@ def _tables(name, n1, n2, tables):
     return out
 
 
-def make(name, lg, seed=1, n_public=2, witness="mixed", tables=None, coef_per_row=1, b_zero_every=3):
+def real_row_lengths(n, seed, mean, tail=True):
+    """Row lengths of one constraint matrix shaped like a compiled circuit's: most rows hold 1 - 3 terms (P(len = k) ~ k^-2.3 up to 48, rescaled
+    to the wanted mean), and a thin heavy tail on top (Num2Bits / packing / long linear combinations): ~n/2^13 rows of ~10^3 terms and — with
+    `tail` — ~n/2^17 rows of ~10^4 and, from 2^17 constraints, one row of 10^5 (capped by the caller at the signals available)."""
+    k = np.arange(1, 49, dtype=np.float64)
+    pk = k ** -2.3
+    pk /= pk.sum()
+    u = (synth.words(seed, n).astype(np.float64) + 0.5) / 4294967296.0
+    lens = 1 + np.searchsorted(np.cumsum(pk), u).astype(np.int64)
+    have = lens.mean()
+    if mean < have:                                      # thin out: a share of the rows drops to one term
+        drop = (synth.words(seed ^ 0x7777, n) % 1000) < int(1000 * min(1.0, (have - mean) / max(have - 1.0, 1e-9)))
+        lens[drop] = 1
+    heavy = []
+    n += 1                                                # the caller passes domain - 1 rows
+    if n >= 1 << 12:
+        heavy += [(int(x), 1000 + int(x) % 211) for x in synth.words(seed ^ 0x1111, max(1, n >> 13)) % n]
+    if tail and n >= 1 << 15:
+        heavy += [(int(x), 10000 + int(x) % 977) for x in synth.words(seed ^ 0x2222, max(1, n >> 17)) % n]
+    if tail and n >= 1 << 17:
+        heavy += [(int(synth.words(seed ^ 0x3333, 1)[0] % n), 100000)]
+    for row, ln in heavy:
+        lens[min(row, lens.size - 1)] = ln
+    return lens
+
+
+def real_coefs(n, m, n_public, seed):
+    """-> (matrix, constraint, signal, in_b): the coefficient records of a circuit-shaped key over n constraints and m signals.
+    A rows average ~1.5 terms and B rows ~1.0 before the heavy tail (together ~2.7 - 2.9 n with it, SURVEY a8's "2 - 3 n"); a row's signals are a contiguous run (as the terms of a
+    linear combination over an array of signals are), distinct within the row; B rows only draw from the 40 % of the signals that occur in B
+    (in_b: bool per signal). The public-input binding rows of src/zkey_new.js:290-300 are appended like in the flat recipe."""
+    in_b = (np.arange(m) % 5 == 1) | (np.arange(m) % 5 == 3)
+    in_b[0] = True
+    b_sig = np.nonzero(in_b)[0].astype(np.uint64)
+    out_m, out_c, out_s = [], [], []
+    for mat, mean, pool in ((0, 1.5, None), (1, 1.0, b_sig)):
+        avail = (m - 1) if pool is None else b_sig.size
+        lens = np.minimum(real_row_lengths(n - 1, seed ^ (0xA0 + mat), mean, tail=mat == 0), avail)
+        tot = int(lens.sum())
+        rows = np.repeat(np.arange(n - 1, dtype=np.uint64), lens)
+        starts = np.cumsum(lens) - lens
+        kk = np.arange(tot, dtype=np.uint64) - np.repeat(starts, lens).astype(np.uint64)
+        h = np.repeat(synth.words(seed ^ (0xB0 + mat), n - 1).astype(np.uint64), lens)
+        idx = (h + kk) % np.uint64(avail)
+        sig = (np.uint64(1) + idx) if pool is None else pool[idx]
+        out_m.append(np.full(tot, mat, np.uint32)); out_c.append(rows); out_s.append(sig)
+    pub = np.arange(n_public + 1, dtype=np.uint64)
+    out_m.append(np.zeros(n_public + 1, np.uint32)); out_c.append((n - 1 - pub) % n); out_s.append(pub)
+    return np.concatenate(out_m), np.concatenate(out_c), np.concatenate(out_s), in_b
+
+
+def make(name, lg, seed=1, n_public=2, witness="mixed", tables=None, coef_per_row=1, b_zero_every=3, coef_dist="flat"):
     """-> (zkey_bytes, wtns_bytes). domain n = 2^lg, nVars m = n - 5 (min 4).
     b_zero_every = k: every k-th B1/B2 base (i % k == 1) is the point at infinity, as for signals absent from the B matrix of a real
-    circuit (B density 1 - 1/k); 0 = dense B sections (SURVEY.md 8d recipe: every section filled from the geometric table)."""
+    circuit (B density 1 - 1/k); 0 = dense B sections (SURVEY.md 8d recipe: every section filled from the geometric table).
+    coef_dist = "flat": one coefficient per (matrix, constraint) row (n_coef = 2.0 n, the bottom of SURVEY a8's range);
+    "real": the shape of a compiled circom circuit (real_coefs below): n_coef ~ 2.7 n, heavy-tailed rows up to 10^5 terms, B density 0.4
+    (b_zero_every is ignored: the B1 / B2 bases of the signals absent from the B matrix are the point at infinity)."""
     q8, q, r = PRIMES[name]
     n = 1 << lg
     m = max(n - 5, n_public + 2)
@@ -61,7 +115,15 @@ def make(name, lg, seed=1, n_public=2, witness="mixed", tables=None, coef_per_ro
     A = T1[0:m].copy()
     B1 = T1[1:m + 1].copy()
     B2 = T2[0:m].copy()
-    if b_zero_every:
+    real = None
+    if coef_dist == "real":
+        real = real_coefs(n, m, n_public, seed)
+        z = ~real[3]                                   # signals that never occur in the B matrix
+        B1[z] = 0
+        B2[z] = 0
+    elif coef_dist != "flat":
+        raise ValueError(f"coef_dist: {coef_dist!r} (flat | real)")
+    elif b_zero_every:
         z = np.arange(m) % b_zero_every == 1          # real keys hold the point at infinity for signals absent from B
         B1[z] = 0
         B2[z] = 0
@@ -77,6 +139,8 @@ def make(name, lg, seed=1, n_public=2, witness="mixed", tables=None, coef_per_ro
     recs.append((np.zeros(long_row, np.uint32), np.zeros(long_row, np.uint64), np.arange(long_row, dtype=np.uint64) % m))
     pub = np.arange(n_public + 1, dtype=np.uint64)
     recs.append((np.zeros(n_public + 1, np.uint32), (n - 1 - pub) % n, pub))       # src/zkey_new.js:290-300 analogue
+    if real is not None:
+        recs = [real[:3]]
     mm = np.concatenate([x[0] for x in recs]).astype("<u4")
     cc = np.concatenate([x[1] for x in recs]).astype("<u4")
     ss = np.concatenate([x[2] for x in recs]).astype("<u4")

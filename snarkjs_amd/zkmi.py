@@ -1,10 +1,12 @@
-"""ctypes binding of libzkmi.so (include/zkmi.h) — the C-ABI of the MI355X proving backend.
+"""ctypes binding of libzkmi.so (include/zkmi.h, include/zkmi_diag.h) — the C-ABI of the MI355X proving backend.
 
 Thin plumbing only: every function maps 1:1 to a C entry point.  There is NO CPU fallback — if the HIP library is
-missing or no device is visible, calls raise ZkmiError.
+missing or no device is visible, calls raise ZkmiError.  The library serves ONE caller per process (include/zkmi.h, conventions):
+every entry point is taken under one process-wide lock here, as the N-API addon does with its mutex.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -16,8 +18,9 @@ CURVE_ID = {"bn128": 0, "bn254": 0, "bls12381": 1}
 BATCH_TO_MONTGOMERY, BATCH_FROM_MONTGOMERY, BATCH_INVERSE = 0, 1, 2
 ERR_NO_DEVICE = 1
 
-# every symbol include/zkmi.h declares (tests check that the library exports all of them)
+# every symbol include/zkmi.h and include/zkmi_diag.h declare (tests check that the library exports all of them)
 SYMBOLS = [
+    "zkmi_groth16_load_paged", "zkmi_groth16_load_shard_paged", "zkmi_groth16_prove_paged", "zkmi_groth16_build_abc_dev", "zkmi_groth16_coef_layout",
     "zkmi_init", "zkmi_device_count", "zkmi_last_error", "zkmi_version", "zkmi_set_stream", "zkmi_synchronize",
     "zkmi_dev_alloc", "zkmi_dev_free", "zkmi_memcpy_h2d", "zkmi_memcpy_d2h", "zkmi_memcpy_d2d", "zkmi_memset_dev",
     "zkmi_msm", "zkmi_release_bases", "zkmi_msm_dev", "zkmi_msm_set_window_bits", "zkmi_msm_accum_ms", "zkmi_msm_stats", "zkmi_msm_accum_additions", "zkmi_msm_table_build", "zkmi_msm_table_dev", "zkmi_msm_table_multi_dev", "zkmi_msm_table_release", "zkmi_msm_table_info",
@@ -59,6 +62,33 @@ class Groth16Zkey(C.Structure):
                 ("vk_delta_1", C.c_void_p), ("vk_delta_2", C.c_void_p),
                 ("bases_a_len", C.c_size_t), ("bases_b1_len", C.c_size_t), ("bases_b2_len", C.c_size_t), ("bases_c_len", C.c_size_t),
                 ("bases_h_len", C.c_size_t)]
+
+
+class Groth16ZkeyPaged(C.Structure):
+    _fields_ = [("curve", C.c_int), ("n_vars", C.c_uint32), ("n_public", C.c_uint32), ("domain_size", C.c_uint32)] + \
+               [(k, Pages) for k in ("coeffs", "bases_a", "bases_b1", "bases_b2", "bases_c", "bases_h")] + \
+               [(k, C.c_void_p) for k in ("vk_alpha_1", "vk_beta_1", "vk_beta_2", "vk_delta_1", "vk_delta_2")]
+
+
+class _Locked:
+    """The library behind one process-wide re-entrant lock: include/zkmi.h declares it single-caller per process (process-global pipeline
+    slot, streams and scratch), and ctypes drops the GIL for the duration of a call. Attribute access hands out a locking wrapper of the
+    ctypes function (hasattr() works as on the CDLL)."""
+
+    def __init__(self, raw):
+        object.__setattr__(self, "_raw", raw)
+        object.__setattr__(self, "_lock", threading.RLock())
+
+    def __getattr__(self, name):
+        f = getattr(object.__getattribute__(self, "_raw"), name)
+        lock = object.__getattribute__(self, "_lock")
+
+        def call(*a):
+            with lock:
+                return f(*a)
+        call.__name__ = name
+        object.__setattr__(self, name, call)
+        return call
 
 
 _lib = None
@@ -163,8 +193,13 @@ def lib():
     L.zkmi_groth16_sums_h_dev.argtypes = [C.c_uint64, vp, vp, u8p]
     L.zkmi_groth16_finish.argtypes = [C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p]
     L.zkmi_groth16_stage_ms.argtypes = [C.POINTER(C.c_double), C.c_int]
-    _lib = L
-    return L
+    L.zkmi_groth16_load_paged.argtypes = [C.POINTER(Groth16ZkeyPaged), C.c_uint64]
+    L.zkmi_groth16_load_shard_paged.argtypes = [C.POINTER(Groth16ZkeyPaged), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.zkmi_groth16_prove_paged.argtypes = [C.POINTER(Groth16ZkeyPaged), C.c_uint64, u8p, C.c_size_t, u8p, u8p, u8p, u8p, u8p]
+    L.zkmi_groth16_build_abc_dev.argtypes = [C.c_uint64, vp, vp, vp, vp]
+    L.zkmi_groth16_coef_layout.argtypes = [C.c_uint64, C.POINTER(C.c_uint64), C.c_int]
+    _lib = _Locked(L)
+    return _lib
 
 
 def check(rc):

@@ -40,6 +40,31 @@ function stubSnarkjs(cid, name, draws) {
         const after = await prover.proveMany(zkey, [wtns]);
         check(`${name}: an error inside proveMany leaves no proof in flight`, threw && sha(JSON.stringify(after[0].proof)) === g.proof_sha256);
         await prover.release();
+        // r06: the key opened BY OFFSET FROM THE FILE, bulk sections handed to the FUSED load as 64 KiB pages (a 2^24 key's sections arrive like this,
+        // as 1 GiB pages: src/groth16_prove.js:57-59 readSection -> BigBuffer), also with an odd page size that cuts records and points
+        for (const pageBytes of [65536, 4096 + 44]) {
+            const paged = makeProver(stubSnarkjs(cid, name, draws), { pageBytes });
+            draws.length = 0; seed(2);
+            const zkeyPath = path.join(GOLD, tag + ".zkey");
+            const r1 = await paged.prove(zkeyPath, path.join(GOLD, tag + ".wtns"));
+            const r2 = await paged.prove({ type: "file", fileName: zkeyPath }, { type: "mem", data: wtns });
+            check(`${name}: fused load from a file descriptor in ${pageBytes}-byte pages == reference proof (path and fastfile descriptor share one resident key)`,
+                  [r1, r2].every((x) => sha(JSON.stringify(x.proof)) === g.proof_sha256));
+            await paged.release();
+        }
+        {   // sections a caller read itself with the reference's readSection: Uint8Array or BigBuffer (.buffers) each
+            const { openZkey, descFromSections, toPages } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "groth16_native.js"));
+            const addon = require(path.join(__dirname, "..", "..", "snarkjs_amd", "napi", "zkmi_napi.node"));
+            const zk = openZkey(zkey, { pageBytes: 1 << 15 });
+            const big = (x) => Array.isArray(x) ? { buffers: x, byteLength: x.reduce((a, b) => a + b.length, 0) } : x;       // the shape of a BigBuffer
+            const d = descFromSections(zk, { 4: big(zk.desc.coeffs), 5: big(zk.desc.A), 6: big(zk.desc.B1), 7: big(zk.desc.B2), 8: big(zk.desc.C), 9: big(zk.desc.H),
+                                             alpha1: zk.desc.alpha1, beta1: zk.desc.beta1, beta2: zk.desc.beta2, delta1: zk.desc.delta1, delta2: zk.desc.delta2 });
+            const w = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "groth16_native.js")).parseWtns(wtns, zk);
+            const res = addon.groth16Prove(d, 0, w, hexb(g.r_mont), hexb(g.s_mont));          // key 0: load, prove, release
+            const str = (x) => Array.isArray(x) ? x.map(str) : x.toString();
+            const proof = { pi_a: str(pointToObject(cid, 1, res.pi_a)), pi_b: str(pointToObject(cid, 2, res.pi_b)), pi_c: str(pointToObject(cid, 1, res.pi_c)), protocol: "groth16", curve: name };
+            check(`${name}: groth16Prove with BigBuffer-shaped sections (key 0: load, prove, release)`, sha(JSON.stringify(proof)) === g.proof_sha256 && Array.isArray(toPages(big(zk.desc.B2))));
+        }
         // the same proof from key shards held by separate worker processes. On a one-GPU box all of them sit on device 0: what is tested is the
         // PROTOCOL (ownership, order, hipIpc export / open between processes, device-to-device pulls of the slices), not the placement — with
         // two or more devices visible the workers spread over them and the pulls cross xGMI. Both exchanges: "peer" (zkmi_ipc_* + zkmi_peer_copy,
@@ -55,6 +80,19 @@ function stubSnarkjs(cid, name, draws) {
             check(`${name}: ${world} shard processes on devices [${devices}] (${exchange}) == reference proof (twice, then two calls at once)`,
                   r1.exchange === exchange && [r1, r2, both[0], both[1]].every((x) => sha(JSON.stringify(x.proof)) === g.proof_sha256));
             await sp.close();
+        }
+        {   // r06: workers that read ONLY their slice of the base sections (4 KiB pages, the rest as gaps), placed by the environment's device map
+            process.env.ZKMI_SHARD_DEVICES = Array.from({ length: 3 }, (_, k) => (2 - k) % nDev).join(",");      // not the identity where there are devices
+            const sp = new ShardedProver({ world: 3, zkeyPath: path.join(GOLD, tag + ".zkey"), pageBytes: 4096 });
+            delete process.env.ZKMI_SHARD_DEVICES;
+            await sp.ready();
+            const r1 = await sp.prove(wtns, { r: hexb(g.r_mont), s: hexb(g.s_mont) });
+            check(`${name}: 3 shard processes, slices read by offset in 4 KiB pages, ZKMI_SHARD_DEVICES -> [${r1.devices}]`,
+                  sha(JSON.stringify(r1.proof)) === g.proof_sha256 && JSON.stringify(r1.devices) === JSON.stringify([2 % nDev, 1 % nDev, 0]));
+            await sp.close();
+            let threw = false;
+            try { new ShardedProver({ world: 2, zkeyPath: path.join(GOLD, tag + ".zkey"), devices: [0, nDev] }); } catch (e) { threw = /beyond the/.test(e.message); }
+            check(`${name}: a device map that names an invisible device is refused before any worker starts`, threw);
         }
     }
     console.log(fails ? `${fails} FAILED` : "ALL OK");

@@ -21,8 +21,19 @@ const slots = {};
 let failNextLoad = false, failNextCall = null;
 const exported = [];
 
+// a section as the real addon takes it (Uint8Array | Array<Uint8Array | gapBytes>, include/zkmi.h: zkmi_groth16_zkey_paged) -> one flat array of
+// the section's length; bytes inside gaps read as zero here (the real library refuses to read them; a shard never does)
+function flat(x) {
+    if (x instanceof Uint8Array) return x;
+    const len = x.reduce((a, e) => a + (typeof e === "number" ? e : e.length), 0), out = new Uint8Array(len);
+    let o = 0;
+    for (const e of x) { if (typeof e === "number") o += e; else { out.set(e, o); o += e.length; } }
+    return out;
+}
 function loadKey(desc, key, vLo, vHi, hLo, hHi) {
     if (failNextLoad) { failNextLoad = false; throw new Error("zkmi error 2: injected load failure"); }
+    desc = Object.assign({}, desc);
+    for (const k of ["coeffs", "A", "B1", "B2", "C", "H"]) desc[k] = flat(desc[k]);
     keys.set(key, { desc, vLo, vHi, hLo, hHi });
 }
 async function buildABC(curve, K, w) {                       // src/groth16_prove.js:147-187 with the reference's own field operations

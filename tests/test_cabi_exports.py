@@ -1,5 +1,5 @@
-"""The drop-in boundary is the C-ABI of include/zkmi.h: the built library must load (no GPU needed) and export EVERY function the
-header declares; the ctypes mirror must bind them all; and without a device every compute entry point must fail loudly."""
+"""The drop-in boundary is the C-ABI of include/zkmi.h (diagnostics: include/zkmi_diag.h): the built library must load (no GPU needed) and export EVERY function the
+headers declare; the ctypes mirror must bind them all; and without a device every compute entry point must fail loudly."""
 import ctypes
 import os
 import re
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared():
-    src = open(os.path.join(ROOT, "include", "zkmi.h")).read()
+    src = open(os.path.join(ROOT, "include", "zkmi.h")).read() + open(os.path.join(ROOT, "include", "zkmi_diag.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(zkmi_[a-z0-9_]+)\s*\(", src)))
 
@@ -44,6 +44,10 @@ def test_no_cpu_fallback_without_device():
     assert L.zkmi_poly_scale_dev(0, None, 4, zkmi.ptr(out)) != 0
     with pytest.raises(zkmi.ZkmiError):
         zkmi.init(0)
+    # the boundary header holds no diagnostics: statistics, probes, generators and knobs live in zkmi_diag.h
+    boundary = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "zkmi.h")).read(), flags=re.S)
+    for name in ("zkmi_msm_stats", "zkmi_calibrate_box", "zkmi_gen_geometric_bases_dev", "zkmi_msm_set_window_bits", "zkmi_last_kernel_ms"):
+        assert name + "(" not in boundary, name
     # host-only helpers keep working: Fr.w[] and the transcript hash need no device
     assert L.zkmi_fr_root(0, 1, zkmi.ptr(out)) == 0
     h = ctypes.create_string_buffer(32)
