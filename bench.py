@@ -253,70 +253,116 @@ def reference_wasm_baseline_plonk(proto, lg):
     return out
 
 
+def _synth_kw(args):
+    return dict(witness=args.witness, b_zero_every=args.b_zero_every, coef_dist=args.coef_dist)
+
+
 def cpu_baseline(args, zkey, wtns, log_n_full):
-    """The CPU oracle (C restatement of the reference, oracle/zk_oracle.c, OpenMP over the reference's own task split: MSM windows, NTT
-    butterflies) on a bounded sample, rank 0, N=1 only. Sample = the bench's own key when the host has >= 16 threads (one whole proof
-    at full size), else a 2^18 key of the same recipe scaled linearly."""
+    """The CPU legs of a Groth16 line (rank 0, N = 1, after the timed region), by --cpu-baseline-mode:
+      full    (the headline) the C restatement of the reference (oracle/zk_oracle.c, OpenMP over the reference's own task split) on a bounded sample —
+              the bench's own key with >= 16 host threads, else a 2^18 key of the same recipe scaled linearly — AND the reference itself (WASM + worker
+              threads, tools/ref_wasm_same_box.js) at 2^18 and at the bench size, its proof for the bench's (r, s) compared with the device's;
+      ref     the reference itself at the bench size only (one proof, ~15 - 40 s) with the same comparison: the other BASELINE configs inside the
+              driver run (other_configs) carry their OWN same-box reference parity this way; without node / the bundle it falls back to `port`;
+      port    the C restatement alone, parity of the device proof against it on that sample;
+      closed  (2^24: a reference proof would take minutes) the C restatement at 2^18 scaled linearly, and the device's proof AT THE BENCH SIZE checked
+              against its closed form (every base of the synthetic key is a known multiple of the generator: tests/oracle_lib.py groth16_closed_form)."""
     O = _oracle()
     from snarkjs_amd import binfile
+    from snarkjs_amd import groth16 as G
     from snarkjs_amd.workloads import synth_zkey
+    mode = args.cpu_baseline_mode
+    cid = 0 if args.curve == "bn128" else 1
     threads = O.threads()
-    lg = args.cpu_log_n if args.cpu_log_n else (log_n_full if threads >= 16 else min(18, log_n_full))
+    kw = _synth_kw(args)
     zkey_full, wtns_full = zkey, wtns
-    if lg != log_n_full:
-        zkey, wtns = synth_zkey.make("bn128", lg, seed=0xBA5E, witness="uniform", b_zero_every=args.b_zero_every)
-    zk, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)["witness"]
-    r_m, s_m = O.fr_e(0, 0x1234567), O.fr_e(0, 0x7654321)
-    t0 = time.perf_counter()
-    ref = O.groth16_prove(0, zk, w, r_m, s_m)
-    dt = time.perf_counter() - t0
-    scale = 1 << (log_n_full - lg)
-    ref_wasm = reference_wasm_baseline() or {}
-    if not args.no_ref_wasm:
-        # the reference itself on this box's host cores: 2^18 and the bench size, its proof for the same (r, s) compared with the device's
-        from snarkjs_amd import groth16 as G
+    rr, ss = 0x1234567, 0x7654321
+    r_m, s_m = O.fr_e(cid, rr), O.fr_e(cid, ss)
+
+    def device_proof(zk2, wt2):
+        pk2 = G.ProvingKey(zk2)
+        pts = pk2.prove_raw(binfile.read_wtns(wt2)["witness"], r_m, s_m)
+        js = G.proof_to_json(G.raw_to_proof(pk2, *pts))
+        pk2.release()
+        return pts, js
+
+    port, sample = None, None
+    if mode in ("full", "port", "closed") or (mode == "ref" and (_ref_bundle() is None)):
+        lg = args.cpu_log_n if args.cpu_log_n else (log_n_full if (threads >= 16 and mode != "closed" and log_n_full <= 20) else min(18, log_n_full))
+        if lg != log_n_full:
+            zkey, wtns = synth_zkey.make(args.curve, lg, seed=0xBA5E, **kw)
+        zk, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)["witness"]
+        t0 = time.perf_counter()
+        ref = O.groth16_prove(cid, zk, w, r_m, s_m)
+        dt = time.perf_counter() - t0
+        scale = 1 << (log_n_full - lg)
+        port = {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": threads, "kind": "port",
+                "sample": f"one full Groth16 proof at 2^{lg} constraints by oracle/zk_oracle.c ({threads} OpenMP threads, {dt:.1f} s wall)"
+                          + (f", scaled linearly x{scale} to 2^{log_n_full} (optimistic: NTT is n log n)" if scale > 1 else ", no scaling")}
+        sample = (zkey, wtns, ref, r_m, s_m)
+    ref_wasm = (reference_wasm_baseline() or {}) if (cid == 0 and mode == "full") else {}
+    if mode in ("full", "ref") and not args.no_ref_wasm:
+        # the reference itself on this box's host cores, its proof for the same (r, s) compared with the device's
         cases = []
-        for l2 in sorted({min(18, log_n_full), log_n_full}):
-            zk2, wt2 = (zkey_full, wtns_full) if l2 == log_n_full else synth_zkey.make("bn128", l2, seed=0xBA5E, witness="uniform", b_zero_every=args.b_zero_every)
-            pk2 = G.ProvingKey(zk2)
-            dev = G.proof_to_json(G.raw_to_proof(pk2, *pk2.prove_raw(binfile.read_wtns(wt2)["witness"], r_m, s_m)))
-            pk2.release()
-            cases.append((l2, zk2, wt2, [r_m, s_m], dev))
+        for l2 in sorted({min(18, log_n_full), log_n_full} if mode == "full" else {log_n_full}):
+            zk2, wt2 = (zkey_full, wtns_full) if l2 == log_n_full else synth_zkey.make(args.curve, l2, seed=0xBA5E, **kw)
+            cases.append((l2, zk2, wt2, [r_m, s_m], device_proof(zk2, wt2)[1]))
         try:
-            ref_wasm["same_box"] = reference_wasm_same_box("groth16", cases, warm=synth_zkey.make("bn128", min(14, log_n_full), seed=0xBA5E, witness="uniform"), budget_s=args.ref_wasm_budget)
+            ref_wasm["same_box"] = reference_wasm_same_box("groth16", cases, curve=args.curve, warm=synth_zkey.make(args.curve, min(14, log_n_full), seed=0xBA5E, **kw), budget_s=args.ref_wasm_budget)
         except Exception as e:                               # noqa: BLE001 — a baseline leg must never cost the line
             ref_wasm["same_box"] = {"error": repr(e)[:300]}
-    port = {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": threads, "kind": "port",
-            "sample": f"one full Groth16 proof at 2^{lg} constraints by oracle/zk_oracle.c ({threads} OpenMP threads, {dt:.1f} s wall)"
-                      + (f", scaled linearly x{scale} to 2^{log_n_full} (optimistic: NTT is n log n)" if scale > 1 else ", no scaling")}
     sb = (ref_wasm.get("same_box") or {}).get("at_bench_size")
     if sb:
         # the REFERENCE itself on this box's host cores is the baseline (north_star); the C port's figure stays beside it
         base = {"value": sb["proofs_per_s"], "unit": "proofs/s", "cores": sb["threads"], "kind": "reference",
                 "sample": f"ONE snarkjs groth16.prove (the reference's bundle: WASM + {sb['threads']} worker threads, Node) of the bench's own 2^{log_n_full} key on this box's host, {sb['ms_per_proof'] / 1e3:.1f} s; "
                           f"its proof for the bench's (r, s) is {'bit-identical to' if sb.get('bit_identical_to_device_proof') else 'DIFFERENT from'} the device's",
-                "bit_identical_to_device_proof": sb.get("bit_identical_to_device_proof"), "port": port, "reference_wasm": ref_wasm}
+                "bit_identical_to_device_proof": sb.get("bit_identical_to_device_proof"), "reference_wasm": ref_wasm}
+        if port is not None:
+            base["port"] = port
     else:
+        if port is None:                                     # mode ref, the reference leg failed: the port after all
+            args2 = argparse.Namespace(**dict(vars(args), cpu_baseline_mode="port"))
+            base, sample = cpu_baseline(args2, zkey_full, wtns_full, log_n_full)
+            base["reference_wasm"] = ref_wasm
+            return base, sample
         base = dict(port, reference_wasm=ref_wasm)
-    return base, (zkey, wtns, ref, r_m, s_m)
+    if mode == "closed":
+        # the device's proof of the FULL-SIZE key against its closed form (no CPU MSM; buildABC / 6 NTTs / joinABC by the C restatement + O(n) sums)
+        t0 = time.perf_counter()
+        zkd, wv = binfile.read_groth16_zkey(zkey_full), binfile.read_wtns(wtns_full)["witness"]
+        pts, _ = device_proof(zkey_full, wtns_full)
+        a, b, cc = O.groth16_closed_form(cid, args.curve, zkd, wv, log_n_full, zkd["nPublic"], rr, ss, args.b_zero_every)
+        want = (O.to_affine(cid, 1, O.generator_mul(cid, 1, a)), O.to_affine(cid, 2, O.generator_mul(cid, 2, b)), O.to_affine(cid, 1, O.generator_mul(cid, 1, cc)))
+        base["closed_form_at_bench_size"] = bool(all(np.array_equal(x, y) for x, y in zip(pts, want)))
+        base["closed_form_note"] = f"the device's proof of the bench's own 2^{log_n_full} key == the closed-form discrete logs of pi_a, pi_b, pi_c (tests/oracle_lib.py: groth16_closed_form), {time.perf_counter() - t0:.1f} s"
+    return base, sample
 
 
 def other_configs(args):
     """The other BASELINE configs in the SAME driver run (rank 0, N = 1, after the headline line is complete): each is this script again as a child
     process with its own key — BLS12-381 Groth16 2^20 (configs[4]), PLONK 2^20 with addition gates (configs[3]), BN254 Groth16 2^24 on one GPU
-    (configs[2] at N = 1) — >= 5 whole proofs each, the child's own line cut down to value / timing / roofline / int_alu. A wall-clock budget bounds
-    the lot (--other-configs-budget): a config whose expected cost does not fit what is left is reported as skipped, never silently dropped."""
+    (configs[2] at N = 1), and the headline size on a circuit-shaped key (--coef-dist real) — >= 5 whole proofs each, the child's own line cut down to
+    value / timing / roofline / int_alu / cpu_baseline. r06: every child carries its OWN same-box parity: the reference's WASM proof of that config's key
+    (configs[4], real), the reference's plonk.prove at 2^14 / 2^16 (configs[3]), the closed form at full size (configs[2]; plus the same key opened and
+    proved from Node). A wall-clock budget bounds the lot (--other-configs-budget): a config whose expected cost does not fit what is left is reported
+    as skipped, never silently dropped."""
     import subprocess
-    runs = [("configs[4]", ["--curve", "bls12381", "--steps", "8", "--warmup", "1"], 45.0),
-            ("configs[3]", ["--workload", "plonk", "--steps", "8", "--warmup", "1"], 60.0),
-            ("configs[2] at N=1", ["--log-n", "24", "--steps", "5", "--warmup", "1", "--repeats", "1"], 150.0)]
+    runs = [("configs[4]", ["--curve", "bls12381", "--steps", "8", "--warmup", "1", "--cpu-baseline-mode", "ref", "--no-napi-wall"], 75.0),
+            ("configs[3]", ["--workload", "plonk", "--steps", "8", "--warmup", "1", "--no-napi-wall"], 75.0),
+            ("configs[1] on a circuit-shaped key", ["--coef-dist", "real", "--witness", "mixed", "--steps", "10", "--warmup", "1", "--cpu-baseline-mode", "ref", "--no-napi-wall"], 55.0),
+            ("configs[2] at N=1", ["--log-n", "24", "--steps", "5", "--warmup", "1", "--repeats", "1", "--cpu-baseline-mode", "closed", "--napi-wall-reps", "2"], 200.0)]
     t_start, res = time.perf_counter(), {}
     for tag, extra, expect_s in runs:
         left = args.other_configs_budget - (time.perf_counter() - t_start)
         if left < expect_s:
-            res[tag] = {"skipped": f"budget: {left:.0f} s left of {args.other_configs_budget:.0f}, this config needs ~{expect_s:.0f} s (key synthesis + load + proofs)"}
+            res[tag] = {"skipped": f"budget: {left:.0f} s left of {args.other_configs_budget:.0f}, this config needs ~{expect_s:.0f} s (key synthesis + load + proofs + its reference leg)"}
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-napi-wall", "--no-cpu-baseline", "--no-other-configs"] + extra
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-other-configs"] + extra
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        if args.no_ref_wasm:
+            cmd.append("--no-ref-wasm")
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
@@ -330,15 +376,23 @@ def other_configs(args):
             continue
         d = json.loads(line)
         keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "pipeline_depth", "proofs_in_flight", "latency_ms_single_proof", "stages_ms",
-                "accum_kernel_ms", "roofline", "int_alu", "repeats")
+                "accum_kernel_ms", "roofline", "int_alu", "repeats", "cpu_baseline", "wall_through_napi", "coef_layout")
         res[tag] = {k: d[k] for k in keep if k in d}
+        cb = res[tag].get("cpu_baseline") or {}
+        # the parity verdict of this config, on top: same-box reference proof / closed form / restatement sample
+        res[tag]["parity_in_run"] = {k: cb[k] for k in ("bit_identical_to_device_proof", "closed_form_at_bench_size", "parity_on_sample") if k in cb}
+        if isinstance(cb.get("reference_wasm"), dict):       # keep the line readable: the build-container history stays in the headline's cpu_baseline only
+            cb["reference_wasm"] = {k: v for k, v in cb["reference_wasm"].items() if k == "same_box"}
         res[tag]["wall_s"] = round(wall, 1)
         res[tag]["command"] = "python bench.py " + " ".join(cmd[2:])
     return res
 
 
-def napi_wall(zkey, wtns, reps=5):
-    """Wall time through the N-API addon with host buffers (SURVEY.md 8d timing protocol): tools/napi_wall.js under Node."""
+def napi_wall(zkey, wtns, reps=5, draws=None, dropin=False, curve="bn128"):
+    """Wall time through the N-API addon with host buffers (SURVEY.md 8d timing protocol): tools/napi_wall.js under Node. The key goes through a
+    FILE (memory-backed where there is room) and Node opens it by offset, in pages (js/groth16_native.js: openZkey) — also a 2^24 key of 9.4 GB.
+    draws = (r_mont, s_mont): the Node proof's hash for them comes back in `proof_sha256`. dropin: tools/dropin_wall.js too — unmodified snarkjs with
+    the curve patched by register.js (JS buildABC1, every bulk call through the addon): what `snarkjs.groth16.prove` costs a drop-in user."""
     import shutil
     import subprocess
     import tempfile
@@ -346,14 +400,33 @@ def napi_wall(zkey, wtns, reps=5):
     addon = os.path.join(ROOT, "snarkjs_amd", "napi", "zkmi_napi.node")
     if node is None or not os.path.exists(addon):
         return {"skipped": "node or the built addon is missing"}
-    with tempfile.TemporaryDirectory() as td:
+    base = None
+    try:
+        if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * (len(zkey) + len(wtns)) + (64 << 20):
+            base = "/dev/shm"
+    except OSError:
+        pass
+    with tempfile.TemporaryDirectory(dir=base) as td:
         zf, wf = os.path.join(td, "k.zkey"), os.path.join(td, "k.wtns")
-        open(zf, "wb").write(zkey)
-        open(wf, "wb").write(wtns)
-        r = subprocess.run([node, os.path.join(ROOT, "tools", "napi_wall.js"), zf, wf, str(reps)], capture_output=True, text=True, timeout=900)
-    if r.returncode != 0:
-        return {"error": (r.stderr or r.stdout)[-400:]}
-    return json.loads(r.stdout.strip().splitlines()[-1])
+        with open(zf, "wb") as fh:
+            fh.write(zkey)
+        with open(wf, "wb") as fh:
+            fh.write(wtns)
+        dh = ",".join(bytes(d).hex() for d in draws) if draws is not None else ""
+        r = subprocess.run([node, "--max-old-space-size=24000", os.path.join(ROOT, "tools", "napi_wall.js"), zf, wf, str(reps)] + ([dh] if dh else []), capture_output=True, text=True, timeout=1500)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        if dropin and _ref_bundle() is not None and dh:
+            try:
+                r2 = subprocess.run([node, "--harmony-optional-chaining", "--harmony-nullish", "--max-old-space-size=24000", os.path.join(ROOT, "tools", "dropin_wall.js"), zf, wf, dh, "3"],
+                                    capture_output=True, text=True, timeout=600, env=dict(os.environ, SNARKJS_REF_BUNDLE=_ref_bundle(), CURVE=curve))
+                out["dropin"] = json.loads(r2.stdout.strip().splitlines()[-1]) if r2.returncode == 0 else {"error": (r2.stderr or r2.stdout)[-300:]}
+            except Exception as e:                           # noqa: BLE001
+                out["dropin"] = {"error": repr(e)[:300]}
+        elif dropin:
+            out["dropin"] = {"skipped": "the reference bundle (oracle/_ref) is not on this box"}
+    return out
 
 
 def bench_plonk(args, rank, world, dist, torch):
@@ -592,7 +665,7 @@ def multi_rank_extras(args, rank, world, dist, torch, barrier, cid, q8, lg, r_m,
     if rank == 0:
         zkey0, wtns0 = zkey, wtns
     else:
-        zkey0, wtns0 = synth_zkey.make(args.curve, lg, seed=0x5EED, witness=args.witness, b_zero_every=args.b_zero_every)
+        zkey0, wtns0 = synth_zkey.make(args.curve, lg, seed=0x5EED, **_synth_kw(args))
     res["groth16_one_proof_over_all_ranks"] = one_proof_over_all_ranks(lg, zkey0, wtns0, proof_pts)
     del zkey0, wtns0
     lg2 = args.configs2_log_n
@@ -627,7 +700,7 @@ def multi_rank_extras(args, rank, world, dist, torch, barrier, cid, q8, lg, r_m,
             tk = time.perf_counter()
             names = [None, None]
             if rank == 0:
-                zkey2, wtns2 = synth_zkey.make(args.curve, lg2, seed=0x5EED, witness=args.witness, b_zero_every=args.b_zero_every)
+                zkey2, wtns2 = synth_zkey.make(args.curve, lg2, seed=0x5EED, **_synth_kw(args))
                 base = os.path.join(place, "zkmi_bench_%d_%s_k%d" % (os.getpid(), os.environ.get("MASTER_PORT", "0"), lg2))
                 names = [base + ".zkey", base + ".wtns"]
                 for nm, blob in zip(names, (zkey2, wtns2)):
@@ -658,6 +731,40 @@ def multi_rank_extras(args, rank, world, dist, torch, barrier, cid, q8, lg, r_m,
 
 
 
+def preflight(args, rank, local_rank, world, dist, torch):
+    """First contact with a node (VERDICT r05 #5a): what every rank sees, before anything is proved. One JSON line from rank 0."""
+    import ctypes
+    info = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(local_rank), "devices_visible": torch.cuda.device_count(),
+            "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES")}
+    free, total = torch.cuda.mem_get_info(local_rank)
+    info["hbm_free_gb"], info["hbm_total_gb"] = round(free / 2**30, 1), round(total / 2**30, 1)
+    # peer-access row of this rank's device (hipDeviceCanAccessPeer): the Node shard driver pulls chain slices device to device over these links
+    info["peer_access"] = [bool(torch.cuda.can_device_access_peer(local_rank, j)) if j != local_rank else True for j in range(torch.cuda.device_count())]
+    from snarkjs_amd import zkmi
+    info["zkmi"] = zkmi.lib().zkmi_version().decode()
+    info["zkmi_device_count"] = int(zkmi.lib().zkmi_device_count())
+    ok = True
+    if dist is not None:
+        t = torch.tensor([float(rank + 1)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t)                                   # one collective over RCCL: the communicator works
+        info["allreduce_ok"] = bool(abs(float(t.item()) - world * (world + 1) / 2) < 1e-9)
+        ok = info["allreduce_ok"]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, info)
+    else:
+        gathered = [info]
+    if rank == 0:
+        out = {"preflight": True, "n_gpus": world, "world_size_rccl": dist.get_world_size() if dist is not None else 1, "backend": dist.get_backend() if dist is not None else None,
+               "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "ranks": gathered, "ok": bool(ok and all(g is not None for g in gathered)),
+               "distinct_devices": len({(g or {}).get("device") for g in gathered}) == world}
+        drain_c_stdout_to_stderr()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        drain_c_stdout_to_stderr()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -671,7 +778,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=3, help="how often the timed region is run (value = the first; min / median / max of all reported)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[4] / [3] / [2] (child runs after the headline line; default run at N = 1 only)")
-    ap.add_argument("--other-configs-budget", type=float, default=240.0, help="wall-clock seconds the other configs may take together")
+    ap.add_argument("--other-configs-budget", type=float, default=420.0, help="wall-clock seconds the other configs may take together")
     ap.add_argument("--no-ref-wasm", action="store_true", help="skip the reference's own WASM prover on this box's host cores (cpu_baseline.reference_wasm.same_box)")
     ap.add_argument("--ref-wasm-budget", type=float, default=200.0, help="seconds the same-box WASM leg may take; a size is skipped when ~5x the previous one does not fit")
     ap.add_argument("--witness", default="uniform", choices=["uniform", "mixed"])
@@ -680,6 +787,13 @@ def main():
     ap.add_argument("--configs2-log-n", type=int, default=24, help="multi-rank runs only: size of the one-proof-over-all-ranks extra of BASELINE configs[2] (0 = skip)")
     ap.add_argument("--plonk-additions", type=int, default=1, help="PLONK / FFLONK workloads: addition gates (and internal signals) per multiplication gate of the synthetic circuit; 0 = none")
     ap.add_argument("--workload", default="groth16", choices=["groth16", "plonk", "fflonk"], help="plonk = BASELINE configs[3] (not the default metric)")
+    ap.add_argument("--coef-dist", default="flat", choices=["flat", "real"], help="shape of the coefficient section of the synthetic Groth16 key: flat = one term per row (n_coef = 2.0 n); real = a compiled circuit's "
+                    "(n_coef ~ 2.9 n, heavy-tailed rows up to 10^5 terms, B density 0.4; use with --witness mixed)")
+    ap.add_argument("--cpu-baseline-mode", default="full", choices=["full", "ref", "port", "closed"], help="CPU legs of a Groth16 line (see cpu_baseline): full = C restatement + the reference's WASM prover at 2^18 and the bench size; "
+                    "ref = the reference at the bench size only; port = the C restatement only; closed = restatement at 2^18 + the closed form of the full-size proof (2^24)")
+    ap.add_argument("--napi-wall-reps", type=int, default=5)
+    ap.add_argument("--preflight", action="store_true", help="every rank reports its device ordinal, free HBM, the peer-access row of its device and the RCCL world, rank 0 prints ONE JSON line, nothing is proved: "
+                    "cheap first contact with a multi-GPU node before the real run")
     args = ap.parse_args()
     relaunch_if_needed(args)
 
@@ -704,11 +818,13 @@ def main():
     from snarkjs_amd.workloads import synth, synth_zkey
     zkmi.init(local_rank)
     L = zkmi.lib()
+    if args.preflight:
+        return preflight(args, rank, local_rank, world, dist, torch)
 
     lg = args.log_n
     if args.workload in ("plonk", "fflonk"):
         return bench_plonk(args, rank, world, dist, torch)
-    zkey, wtns = synth_zkey.make(args.curve, lg, seed=0x5EED + rank, witness=args.witness, b_zero_every=args.b_zero_every)
+    zkey, wtns = synth_zkey.make(args.curve, lg, seed=0x5EED + rank, **_synth_kw(args))
     cid = 0 if args.curve == "bn128" else 1
     q8 = 32 if cid == 0 else 48
     pk = groth16.ProvingKey(zkey)
@@ -879,9 +995,10 @@ def main():
                                    "proofs_per_s": [round(x, 3) for x in v], "min": round(min(v), 3), "median": round(float(np.median(v)), 3), "max": round(max(v), 3)})(
                 [world * args.steps / x for x in ([elapsed] + region_s[1:])]),
             "config": {"workload": f"{'BN254' if cid == 0 else 'BLS12-381'} Groth16 prove, 2^{lg} constraints, synthetic zkey/wtns (BASELINE configs[{1 if (cid == 0 and lg == 20) else (2 if cid == 0 else 4)}]), "
-                                   f"B density {1.0 if not args.b_zero_every else round(1 - 1 / args.b_zero_every, 3)} ({'every section dense, SURVEY 8d recipe' if not args.b_zero_every else f'every {args.b_zero_every}-th B1/B2 base at infinity'}), "
-                                   f"{args.witness} witness; key + witness resident in HBM",
-                       "curve": args.curve, "log_n": lg, "n_vars": m, "n_coef": int((zk['coeffs'].size - 4) // 44), "witness": args.witness, "b_density": 1.0 if not args.b_zero_every else round(1 - 1 / args.b_zero_every, 4),
+                                   + (f"B density {1.0 if not args.b_zero_every else round(1 - 1 / args.b_zero_every, 3)} ({'every section dense, SURVEY 8d recipe' if not args.b_zero_every else f'every {args.b_zero_every}-th B1/B2 base at infinity'}), "
+                                      if args.coef_dist == "flat" else "circuit-shaped coefficient section (heavy-tailed rows up to 10^5 terms, see coef_layout), B density 0.4, ")
+                                   + f"{args.witness} witness; key + witness resident in HBM",
+                       "curve": args.curve, "log_n": lg, "n_vars": m, "n_coef": int((zk['coeffs'].size - 4) // 44), "witness": args.witness, "coef_dist": args.coef_dist, "b_density": 0.4 if args.coef_dist == "real" else (1.0 if not args.b_zero_every else round(1 - 1 / args.b_zero_every, 4)),
                        "parallelism": f"replica x{world} (one proof stream per GPU, {args.pipeline} proof(s) in flight)"},
             "submetrics": {"g1_msm_mscalar_per_s": round(n / msm_ms / 1e3, 2), "g1_msm_ms": round(msm_ms, 4),
                            "g1_msm_resident_tables_mscalar_per_s": round(n / msm_tab_ms / 1e3, 2), "g1_msm_resident_tables_ms": round(msm_tab_ms, 4),
@@ -896,20 +1013,31 @@ def main():
             "roofline": roof,
             "int_alu": int_alu,
         }
+        out["coef_layout"] = dict(pk.coef_layout(), note="the resident coefficient section: rows cut into segments of <= 32 terms, sorted by length into slices of 64 (csrc/groth16.hip); cut_rows = rows beyond 32 terms")
         if world == 1 and not args.no_napi_wall:
-            # SURVEY.md 8d timing protocol: wall time THROUGH the N-API call with host buffers (H2D of inputs, D2H of results inside)
-            out["wall_through_napi"] = napi_wall(zkey, wtns)
-        if world == 1 and not args.no_cpu_baseline and args.curve == "bn128":
-            base, (zk_s, wt_s, ref, rs, ss) = cpu_baseline(args, zkey, wtns, lg)
+            # SURVEY.md 8d timing protocol: wall time THROUGH the N-API call with host buffers (H2D of inputs, D2H of results inside); the key is opened by
+            # offset from a file, in pages (any size); at the headline config the drop-in (unmodified snarkjs + register.js) is timed beside the fused prover
+            nw = napi_wall(zkey, wtns, reps=args.napi_wall_reps, draws=(r_m, s_m), dropin=(lg <= 20 and cid == 0 and args.coef_dist == "flat"), curve=args.curve)
+            if isinstance(nw, dict) and "proof_sha256" in nw:
+                import hashlib
+                nw["proof_equals_python_mirror"] = bool(nw["proof_sha256"] == hashlib.sha256(b"".join(bytes(x) for x in proof_pts)).hexdigest())
+                if isinstance(nw.get("dropin"), dict) and "proof_json_sha256" in nw["dropin"]:
+                    pj = groth16.proof_to_json(groth16.raw_to_proof(pk, *proof_pts))
+                    nw["dropin"]["proof_equals_fused_prover"] = bool(nw["dropin"]["proof_json_sha256"] == hashlib.sha256(pj.encode()).hexdigest())
+            out["wall_through_napi"] = nw
+        if world == 1 and not args.no_cpu_baseline:
+            base, sample = cpu_baseline(args, zkey, wtns, lg)
             out["cpu_baseline"] = base
-            # the same sample through the device path must give the oracle's proof points (parity inside the bench run)
-            pk_s = groth16.ProvingKey(zk_s)
-            got = pk_s.prove_raw(binfile.read_wtns(wt_s)["witness"], rs, ss)
-            out["cpu_baseline"]["parity_on_sample"] = bool(all(np.array_equal(a, b) for a, b in zip(got, ref)))
-            pk_s.release()
+            if sample is not None:
+                # the same sample through the device path must give the oracle's proof points (parity inside the bench run)
+                zk_s, wt_s, ref, rs, ss = sample
+                pk_s = groth16.ProvingKey(zk_s)
+                got = pk_s.prove_raw(binfile.read_wtns(wt_s)["witness"], rs, ss)
+                out["cpu_baseline"]["parity_on_sample"] = bool(all(np.array_equal(a, b) for a, b in zip(got, ref)))
+                pk_s.release()
     if out is not None:
         out["box_calibration"] = box_calibration(L)
-    if out is not None and world == 1 and not args.no_other_configs and args.curve == "bn128" and lg == 20:
+    if out is not None and world == 1 and not args.no_other_configs and args.curve == "bn128" and lg == 20 and args.coef_dist == "flat":
         # BASELINE configs[4], [3], [2] inside the same driver run, after everything above: this process's key and buffers are released first
         pk.release(); d_w.free()
         out["other_configs"] = other_configs(args)

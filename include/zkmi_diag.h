@@ -60,6 +60,9 @@ int zkmi_gen_bases_from_scalars_dev(int curve, int group, const void* d_scalars,
 
 /* Wall-clock-free device timing of the last call of each kind, in milliseconds (HIP events on the library stream). */
 double zkmi_last_kernel_ms(void);
+/* zkmi_msm_dev calls since start-up that ran on the saturated-limb path because the scratch copy of the bases (n x 2*group*n8q bytes) could not be allocated
+ * (out of memory ONLY: any other failure is reported by the call itself). A non-zero count explains a slow standalone MSM. */
+unsigned long long zkmi_msm_dev_fallbacks(void);
 /* Shape of the resident coefficient layout of a Groth16 key (csrc/groth16.hip: buildABC as a length-sorted sliced layout with split rows):
  * out[0..5) = coefficient records, segments (<= 32 terms each), rows cut into several segments, partial-sum slots, padded terms held. */
 int zkmi_groth16_coef_layout(uint64_t zkey_cache_key, uint64_t* out, int n);

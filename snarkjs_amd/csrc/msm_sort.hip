@@ -1,6 +1,8 @@
 // snarkjs_amd/csrc/msm_sort.hip — field-independent front half of the device Pippenger: signed-digit recoding of the
 // scalars and a counting sort of (point index, sign) into per-(window, bucket) lists; plus bucket ordering by size.
 // One sort can feed several accumulations (msm_accumulate) when MSMs share their scalars.
+#include <string.h>
+#include <mutex>
 #include "msm_host.hpp"
 
 namespace zkmi {
@@ -26,6 +28,25 @@ static bool rsort_fused_on() {
     static const bool on = !(getenv("ZKMI_RSORT_FUSED") && atoi(getenv("ZKMI_RSORT_FUSED")) == 0);
     return on;
 }
+// The fused level 2 stages a partition in up to 152 KB of LDS (gfx950: 160 KB per CU). Checked ONCE per process against the bound device — the library
+// binds one device per process — under std::call_once (zkmi_msm runs on libuv pool threads too): the opt-in attribute is set there, and a device
+// that cannot give that much LDS takes the chunked level 2 (the r04 path) instead of failing at launch.
+static bool rsort_fused_fits() {
+    static std::once_flag once;
+    static bool fits = false;
+    std::call_once(once, [] {
+        const int need = (int)(((size_t)RSORT_BINS + 1024 + rsort_part_cap(10)) * 4);
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) { (void)hipGetLastError(); return; }
+        // gfx950 (MI355X) has 160 KB of LDS per CU; elsewhere the device's own figure decides (64 KB on earlier CDNA: the chunked path)
+        const bool gfx950 = strncmp(pr.gcnArchName, "gfx950", 6) == 0;
+        if (!gfx950 && (size_t)pr.maxSharedMemoryPerMultiProcessor < (size_t)need) return;
+        if (hipFuncSetAttribute((const void*)k_rsort_part, hipFuncAttributeMaxDynamicSharedMemorySize, need) != hipSuccess) { (void)hipGetLastError(); return; }
+        fits = true;
+    });
+    return fits;
+}
 // low-key bits for this shape: 10 (ZKMI_RSORT_LB=9: 9) when the fused level 2 can take a typical partition (entries / partitions <= 0.9 cap), else 11
 static uint32_t rsort_low_bits(const MsmShape& sh) {
     static const uint32_t want = getenv("ZKMI_RSORT_LB") ? (uint32_t)atoi(getenv("ZKMI_RSORT_LB")) : 10u;
@@ -37,7 +58,7 @@ static uint32_t rsort_low_bits(const MsmShape& sh) {
 }
 template <int NW> static int msm_launch_digits_radix(const uint8_t* d_scalars, const MsmShape& sh, uint32_t* counts, uint32_t* starts, uint32_t* sorted,
                                                      const uint32_t* dropmask, hipStream_t st) {
-    const uint32_t lb = rsort_low_bits(sh);
+    const uint32_t lb = rsort_fused_fits() ? rsort_low_bits(sh) : (uint32_t)RSORT_LOW_BITS;
     const uint32_t fused_cap = (lb < (uint32_t)RSORT_LOW_BITS) ? rsort_part_cap(lb) : 0u;
     const uint32_t total = (uint32_t)sh.W * sh.nb, P = total >> lb;
     const uint32_t nblk = (uint32_t)((sh.n + RSORT_TILE - 1) / RSORT_TILE);
@@ -61,8 +82,6 @@ template <int NW> static int msm_launch_digits_radix(const uint8_t* d_scalars, c
     hipLaunchKernelGGL(k_rsort_chunks, dim3(1), dim3(1024), 0, st, bhoff, P, nblk, fused_cap, pchunk0, ck, meta);
     if (fused_cap) {
         const size_t lds = ((size_t)(1u << lb) + 1024 + fused_cap) * 4;
-        static bool attr = false;
-        if (!attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_rsort_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)RSORT_BINS + 1024 + rsort_part_cap(10)) * 4))); attr = true; }
         hipLaunchKernelGGL(k_rsort_part, dim3(P), dim3(1024), lds, st, tmp, bhoff, nblk, lb, fused_cap, counts, starts, sorted);
     }
     hipLaunchKernelGGL(k_rsort_hist2, dim3((unsigned)nch_max), dim3(256), 0, st, tmp, ck, meta, h2);

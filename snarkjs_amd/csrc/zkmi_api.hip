@@ -75,12 +75,19 @@ int dev_alloc_big(void** p, size_t bytes) {
     return ZKMI_OK;
 }
 
+static bool g_ws_oom = false;            // the last ws_get failed in its ALLOCATION with out-of-memory (and in nothing else)
 int ws_get(const std::string& name, size_t bytes, void** out) {
     DevBuf& b = g_ctx.ws[g_ctx.pipe ? "P1:" + name : name];
+    g_ws_oom = false;
     if (b.cap < bytes) {
         if (b.p) { ZK_HIP(hipStreamSynchronize(g_ctx.stream)); ZK_HIP(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
         size_t cap = bytes + bytes / 8 + 256;
-        ZK_TRY(dev_alloc_big(&b.p, cap));
+        const hipError_t e = hipMalloc(&b.p, cap);
+        if (e != hipSuccess) {
+            b.p = nullptr;
+            g_ws_oom = e == hipErrorOutOfMemory;
+            return fail(ZKMI_ERR_HIP, std::string("hipMalloc(") + std::to_string(cap) + " bytes, scratch \"" + name + "\"): " + hipGetErrorString(e));
+        }
         b.cap = cap;
     }
     *out = b.p;
@@ -486,6 +493,8 @@ int zkmi_msm_table_release(uint64_t handle) {
     g_tables.erase(it);
     return ZKMI_OK;
 }
+static unsigned long long g_msm_dev_fallbacks = 0;       // zkmi_msm_dev calls that ran on the saturated-limb path for want of scratch memory
+unsigned long long zkmi_msm_dev_fallbacks(void) { return g_msm_dev_fallbacks; }
 int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalars, size_t n, size_t scalar_bytes, uint8_t* out) {
     ZK_TRY(require_ctx());
     ZK_TRY(check_cg(curve, group));
@@ -503,8 +512,12 @@ int zkmi_msm_dev(int curve, int group, const void* d_bases, const void* d_scalar
     // ZKMI_MSM_DEV_KEEP_BYTES (default 2 GiB) is released after the call rather than kept for the life of the process.
     static const size_t keep_limit = [] { const char* e = getenv("ZKMI_MSM_DEV_KEEP_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)2 << 30); }();
     if (ws_get("api.dev_bases29", n * pb, &d_b) != ZKMI_OK || ws_get("api.dev_basemask", ((n + 31) / 32) * 4 + 16, (void**)&d_mask) != ZKMI_OK) {
+        // ONLY an allocation that ran out of memory takes the slower path on the caller's own bases; anything else (a sticky fault of an earlier
+        // kernel surfacing in the stream sync or the free inside ws_get) is this call's error and is reported as such
+        if (!g_ws_oom) return ZKMI_ERR_HIP;
         (void)hipGetLastError();                                   // the failed allocation is not this call's result
         ws_drop("api.dev_bases29");
+        g_msm_dev_fallbacks++;
         return msm_dev_dispatch(curve, group, d_bases, d_scalars, n, scalar_bytes, out);
     }
     ZK_HIP(hipEventRecord(g_ctx.ev0, g_ctx.stream));              // zkmi_last_kernel_ms covers the copy and the conversion too
@@ -653,6 +666,11 @@ int zkmi_msm(int curve, int group, zkmi_pages bases, zkmi_pages scalars, size_t 
     ZK_TRY(check_cg(curve, group));
     if (!out) return fail(ZKMI_ERR_INVALID, "null output");
     const size_t pb = (size_t)2 * group * n8q_of(curve);
+    // base_cache_key is a set of permission bits (include/zkmi.h). Until r04 any non-zero value meant "may cache": a caller still passing an arbitrary
+    // identity (1002, 1011 ...) would silently get no caching, or the sampled re-check it never asked for — refuse it instead
+    if (key & ~(ZKMI_BASES_CACHE | ZKMI_BASES_IMMUTABLE))
+        return fail(ZKMI_ERR_INVALID, "msm: base_cache_key has unknown bits set (it is a set of permission bits: ZKMI_BASES_CACHE = 1, ZKMI_BASES_IMMUTABLE = 2; it carries no identity)");
+    if ((key & ZKMI_BASES_IMMUTABLE) && !(key & ZKMI_BASES_CACHE)) return fail(ZKMI_ERR_INVALID, "msm: ZKMI_BASES_IMMUTABLE without ZKMI_BASES_CACHE");
     if (n == 0) { memset(out, 0, 3 * group * n8q_of(curve)); return ZKMI_OK; }
     if (pages_total(scalars) != n * scalar_bytes) return fail(ZKMI_ERR_INVALID, "Scalar size does not match");
     if (pages_total(bases) < n * pb) return fail(ZKMI_ERR_INVALID, "input buffer shorter than n elements");

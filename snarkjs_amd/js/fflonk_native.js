@@ -5,15 +5,17 @@
 // polynomials through the addon's generic C-ABI binding.  Host side: the Keccak transcript, the roots bookkeeping, Lagrange
 // interpolation of the tiny R0/R1/R2 polynomials, the batched inverse — all O(1), as in the reference.
 //
-//   const { prove } = require("snarkjs_amd/js/fflonk_native.js");
+//   const { prove, proveAsync } = require("snarkjs_amd/js/fflonk_native.js");
 //   const { proof, publicSignals } = prove(zkeyBytes, wtnsBytes);
+//   const res = await proveAsync(zkeyBytes, wtnsBytes, null, { device: 2 });    // fflonkProve is async in the reference (src/fflonk_prove.js:51): the four
+//                                                                               // commitment waits run on a libuv pool thread
 "use strict";
 const crypto = require("crypto");
 const { _internals: I } = require("./plonk_native.js");
-const { addon, call, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN, Q_BLS } = I;
+const { addon, call, bindDevice, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN, Q_BLS } = I;
 
 class FflonkKey {                                           // src/zkey_utils.js:301-339, sections of src/fflonk_constants.js
-    constructor(zkey) {
+    constructor(zkey, options) {
         const data = zkey instanceof Uint8Array ? zkey : new Uint8Array(zkey);
         const { dv, s } = readSections(data);
         if (dv.getUint32(s[1][0], true) !== 10) throw new Error("zkey file is not fflonk");                 // fflonk_prove.js:71-73
@@ -36,7 +38,7 @@ class FflonkKey {                                           // src/zkey_utils.js
         }
         off += 4 * n8q;                                                                                      // X_2
         this.C0 = [f.unmontQ(data.subarray(off, off + n8q)), f.unmontQ(data.subarray(off + n8q, off + 2 * n8q))];
-        addon.init(0);
+        this.device = bindDevice(options && options.device);       // one device per process, chosen by the first key (plonk_native.js: bindDevice)
         if (s[3][1] < 72 * this.nAdditions) throw new Error("zkey additions section is shorter than its header says");
         this.dev = {};                                      // section 3 (additions) too, as it lies in the file: calculateAdditions runs on the device
         for (let t = 3; t <= 17; t++) if (s[t] && s[t][1]) this.dev[t] = devFrom(data.subarray(s[t][0], s[t][0] + s[t][1]));
@@ -65,15 +67,15 @@ function cpoly(f, polys, n, track) {
 }
 
 // Polynomial.multiExponentiation over PTau: coefficients past the 9n+18 SRS points multiply the point at infinity
-function commit(key, poly) {
-    const f = key.f, k = Math.min(poly.n, key.nPtau), sc = devAlloc(k * 32);
-    call("zkmi_fr_batch_dev", f.cid, 1, poly.ptr, sc, k);
-    const aff = new Uint8Array(2 * f.n8q);
-    const jac = addon.msmTableDev(key.ptauTable, sc, k, 32);
+function commitScalars(key, poly) { const k = Math.min(poly.n, key.nPtau), sc = devAlloc(k * 32); call("zkmi_fr_batch_dev", key.f.cid, 1, poly.ptr, sc, k); return [sc, k]; }
+function commitPoint(key, sc, jac) {
+    const f = key.f, aff = new Uint8Array(2 * f.n8q);
     devFree(sc);
     call("zkmi_to_affine", f.cid, 1, jac, aff);
     return [f.unmontQ(aff.subarray(0, f.n8q)), f.unmontQ(aff.subarray(f.n8q))];
 }
+function commit(key, poly) { const [sc, k] = commitScalars(key, poly); return commitPoint(key, sc, addon.msmTableDev(key.ptauTable, sc, k, 32)); }
+async function commitAsync(key, poly) { const [sc, k] = commitScalars(key, poly); return commitPoint(key, sc, await addon.msmTableMultiDevAsync(key.ptauTable, [sc], [k], 32, 0)); }
 const divZerofier = (p, n, beta) => call("zkmi_poly_div_by_zerofier_dev", p.f.cid, p.ptr, p.n, n, p.f.mont(beta));
 
 // ---- O(1) host algebra on tiny polynomials (arrays of BigInt, lowest coefficient first) ---------------------------------
@@ -92,19 +94,42 @@ function lagrange(xs, ys, r) {                               // Polynomial.lagra
 const zerofier = (xs, r) => xs.reduce((p, x) => mulLinear(p, x, r), [1n]);    // Polynomial.zerofierPolynomial (:932-950)
 function small(f, coefs, track) { const b = new Uint8Array(32 * coefs.length); coefs.forEach((c, i) => b.set(f.mont(c), 32 * i)); const p = track(new Poly(f, coefs.length, false)); call("zkmi_memcpy_h2d", p.ptr, b, b.length); return p; }
 
-function prove(zkey, wtns, blindingMont = null) {
-    const key = zkey instanceof FflonkKey ? zkey : new FflonkKey(zkey);
+// The proof is a generator (proveSteps): `pts.X = yield poly` asks the driver for the commitment of `poly` — the call the host waits in.
+function prove(zkey, wtns, blindingMont = null, options = null) {
+    const key = zkey instanceof FflonkKey ? zkey : new FflonkKey(zkey, options);
     const polys = [];
     const track = (p) => { polys.push(p); return p; };
     try {
-        return proveWith(key, wtns instanceof Uint8Array ? wtns : new Uint8Array(wtns), blindingMont, track);
+        const steps = proveSteps(key, wtns instanceof Uint8Array ? wtns : new Uint8Array(wtns), blindingMont, track);
+        for (let s = steps.next(); ; s = steps.next(commit(key, s.value))) if (s.done) return s.value;
     } finally {
         polys.forEach((p) => p.free());
         if (!(zkey instanceof FflonkKey)) key.release();
     }
 }
+// async like the reference's fflonkProve (src/fflonk_prove.js:51): the commitment waits on a libuv pool thread; serialised per process
+let asyncQueue = Promise.resolve();
+function proveAsync(zkey, wtns, blindingMont = null, options = null) {
+    const run = async () => {
+        const key = zkey instanceof FflonkKey ? zkey : new FflonkKey(zkey, options);
+        const polys = [];
+        const track = (p) => { polys.push(p); return p; };
+        try {
+            const steps = proveSteps(key, wtns instanceof Uint8Array ? wtns : new Uint8Array(wtns), blindingMont, track);
+            let s = steps.next();
+            while (!s.done) { await addon.synchronizeAsync(0); const pt = await commitAsync(key, s.value); s = steps.next(pt); }
+            return s.value;
+        } finally {
+            polys.forEach((p) => p.free());
+            if (!(zkey instanceof FflonkKey)) key.release();
+        }
+    };
+    const p = asyncQueue.then(run, run);
+    asyncQueue = p.catch(() => {});
+    return p;
+}
 
-function proveWith(key, wt, blindingMont, track) {
+function* proveSteps(key, wt, blindingMont, track) {
     const f = key.f, r = f.r, n = key.n, power = key.power;
     const P = (len, zero = true) => track(new Poly(f, len, zero));
     const { dv, s: ws } = readSections(wt);
@@ -120,9 +145,10 @@ function proveWith(key, wt, blindingMont, track) {
     for (let i = 0; i < 9; i++) bm.push(blindingMont ? Uint8Array.from(blindingMont[i]) : f.mont(fromLE(crypto.randomBytes(40))));
     const b = [0n].concat(bm.slice(1).map((x) => f.unmont(x)));
     // calculateAdditions (:271-300): the internal signals, ONE launch on the device (zkmi_plonk_additions_dev)
-    const dWit = devFrom(wit), dInt = I.devAlloc(32 * Math.max(key.nAdditions, 1));
-    if (key.nAdditions) call("zkmi_plonk_additions_dev", f.cid, key.sec(3), key.nAdditions, dWit, nW, dInt);
+    let dWit = 0, dInt = 0;
     try {
+        dWit = devFrom(wit); dInt = I.devAlloc(32 * Math.max(key.nAdditions, 1));
+        if (key.nAdditions) call("zkmi_plonk_additions_dev", f.cid, key.sec(3), key.nAdditions, dWit, nW, dInt);
         const mont = (v) => f.mont(v), wN = f.root(power), w2N = f.root(power + 1), w4N = f.root(power + 2), wv = f.unmont(wN);
         const pts = {}, evs = {}, big = (a) => new BigUint64Array(a.map((x) => BigInt(x || 0)));
 
@@ -144,7 +170,7 @@ function proveWith(key, wt, blindingMont, track) {
         if (degree(pT0) >= 2 * n - 2) throw new Error("T0 Polynomial is not well calculated");
         const C1 = cpoly(f, [pA, pB, pC, pT0], 4, track);
         if (degree(C1) >= 8 * n - 8) throw new Error("C1 Polynomial is not well calculated");
-        pts.C1 = commit(key, C1);
+        pts.C1 = yield C1;
 
         // ---- ROUND 2 (:558-862)
         let tr = new Transcript(f);
@@ -174,7 +200,7 @@ function proveWith(key, wt, blindingMont, track) {
         if (degree(pT2) >= 3 * n) throw new Error("T2 Polynomial is not well calculated");
         const C2 = cpoly(f, [pZ, pT1, pT2], 3, track);
         if (degree(C2) >= 9 * n) throw new Error("C2 Polynomial is not well calculated");
-        pts.C2 = commit(key, C2);
+        pts.C2 = yield C2;
 
         // ---- ROUND 3 (:864-963)
         tr = new Transcript(f);
@@ -212,7 +238,7 @@ function proveWith(key, wt, blindingMont, track) {
         f3.axpy(small(f, R2, track), null, true); f3.scale(alpha * alpha % r); divZerofier(f3, 3, xi); divZerofier(f3, 3, xiw);
         F.axpy(f2); F.axpy(f3);
         if (degree(F) >= 9 * n - 6) throw new Error("F Polynomial is not well calculated");
-        pts.W1 = commit(key, F);
+        pts.W1 = yield F;
 
         // ---- ROUND 5 (:1059-1180)
         tr = new Transcript(f);
@@ -233,7 +259,7 @@ function proveWith(key, wt, blindingMont, track) {
         Lp.scale(modinv(evalSmall(zerofier(S1.concat(S22), r), y, r), r));
         try { divZerofier(Lp, 1, y); } catch (e) { throw new Error("Degree of L(X)/(ZTS2(y)(X-y)) remainder is not 0"); }
         if (degree(Lp) >= 9 * n - 1) throw new Error("Degree of L(X)/(ZTS2(y)(X-y)) is not correct");
-        pts.W2 = commit(key, Lp);
+        pts.W2 = yield Lp;
 
         // ---- getMontgomeryBatchedInverse (:1182-1287)
         toInv.push(["zh", mod(modpow(xi, BigInt(n), r) - 1n, r)]);
@@ -260,4 +286,4 @@ function proveWith(key, wt, blindingMont, track) {
     }
 }
 
-module.exports = { prove, FflonkKey };
+module.exports = { prove, proveAsync, FflonkKey };

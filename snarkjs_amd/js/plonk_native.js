@@ -7,13 +7,27 @@
 // each of their methods one C entry point.  The host keeps what is O(1) in the reference too: the Keccak transcript
 // (zkmi_keccak256), challenges, a handful of field operations (BigInt), and calculateAdditions (a sequential chain).
 //
-//   const { prove } = require("snarkjs_amd/js/plonk_native.js");
+//   const { prove, proveAsync } = require("snarkjs_amd/js/plonk_native.js");
 //   const { proof, publicSignals } = prove(zkeyBytes, wtnsBytes);          // synchronous; throws without a GPU (no fallback)
+//   const res = await proveAsync(zkeyBytes, wtnsBytes, null, { device: 3 });   // like the reference's async plonk16Prove (src/plonk_prove.js:47): the
+//                                                                              // waits run on a libuv pool thread, the event loop keeps turning
 "use strict";
 const path = require("path");
 const crypto = require("crypto");
 const addon = require(path.join(__dirname, "..", "napi", "zkmi_napi.node"));
 const call = (name, ...a) => addon.call(name, ...a);
+// The library binds ONE device per process (include/zkmi.h: zkmi_init). The first key decides: new PlonkKey(zkey, { device }) / prove(.., { device }),
+// default device 0 (HIP_VISIBLE_DEVICES renumbers the visible ones from 0); a later key that asks for another device is refused — PLONK replicas
+// run one process per GPU, like every other multi-GPU path here.
+let boundDevice = null;
+function bindDevice(device) {
+    const d = device === undefined || device === null ? (boundDevice === null ? 0 : boundDevice) : device;
+    if (!Number.isInteger(d) || d < 0) throw new Error(`plonk_native: bad device ${device}`);
+    if (boundDevice !== null && boundDevice !== d) throw new Error(`plonk_native: this process is bound to device ${boundDevice}; device ${d} needs its own process`);
+    addon.init(d);
+    boundDevice = d;
+    return d;
+}
 
 const R_BN = 21888242871839275222246405745257275088548364400416034343698204186575808495617n;
 const Q_BN = 21888242871839275222246405745257275088696311157297823662689037894645226208583n;
@@ -91,7 +105,7 @@ function readSections(data) {
 
 // A PLONK zkey resident on the device (src/zkey_utils.js:261-299)
 class PlonkKey {
-    constructor(zkey) {
+    constructor(zkey, options) {
         const data = zkey instanceof Uint8Array ? zkey : new Uint8Array(zkey);
         const { dv, s } = readSections(data);
         if (dv.getUint32(s[1][0], true) !== 2) throw new Error("zkey file is not plonk");                  // plonk_prove.js:60-62
@@ -106,7 +120,7 @@ class PlonkKey {
         this.k1 = f.unmont(data.subarray(off, off + 32)); this.k2 = f.unmont(data.subarray(off + 32, off + 64)); off += 64;
         this.commit = {};
         for (const nm of ["Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"]) { this.commit[nm] = [f.unmontQ(data.subarray(off, off + n8q)), f.unmontQ(data.subarray(off + n8q, off + 2 * n8q))]; off += 2 * n8q; }
-        addon.init(0);
+        this.device = bindDevice(options && options.device);
         if (s[3][1] < 72 * this.nAdditions) throw new Error("zkey additions section is shorter than its header says");
         this.dev = {};                                      // section 3 (additions) too, as it lies in the file: calculateAdditions runs on the device
         for (let t = 3; t <= 14; t++) if (s[t] && s[t][1]) this.dev[t] = devFrom(data.subarray(s[t][0], s[t][0] + s[t][1]));
@@ -132,13 +146,12 @@ class Transcript {                                          // src/Keccak256Tran
     }
 }
 
-// Polynomial.multiExponentiation (polynomial.js:970-977) for the commitments of one round
-function commit(key, polys) {
-    const f = key.f, cnt = polys.length;
-    const scs = polys.map((p) => { const sc = devAlloc(p.n * 32); call("zkmi_fr_batch_dev", f.cid, 1, p.ptr, sc, p.n); return sc; });     // batchFromMontgomery
-    const jac = addon.msmTableMultiDev(key.ptauTable, scs, polys.map((p) => p.n), 32);
-    const out = [];
-    for (let i = 0; i < cnt; i++) {
+// Polynomial.multiExponentiation (polynomial.js:970-977) for the commitments of one round: batchFromMontgomery of every polynomial (enqueued), ONE
+// call for up to four MSMs against the resident SRS table (the host waits here), toAffine on the host
+function commitScalars(key, polys) { return polys.map((p) => { const sc = devAlloc(p.n * 32); call("zkmi_fr_batch_dev", key.f.cid, 1, p.ptr, sc, p.n); return sc; }); }
+function commitPoints(key, polys, scs, jac) {
+    const f = key.f, out = [];
+    for (let i = 0; i < polys.length; i++) {
         const aff = new Uint8Array(2 * f.n8q);
         call("zkmi_to_affine", f.cid, 1, jac.slice(i * 3 * f.n8q, (i + 1) * 3 * f.n8q), aff);
         out.push([f.unmontQ(aff.subarray(0, f.n8q)), f.unmontQ(aff.subarray(f.n8q))]);
@@ -146,21 +159,62 @@ function commit(key, polys) {
     scs.forEach(devFree);
     return out;
 }
+function commit(key, polys) {
+    const scs = commitScalars(key, polys);
+    return commitPoints(key, polys, scs, addon.msmTableMultiDev(key.ptauTable, scs, polys.map((p) => p.n), 32));
+}
+async function commitAsync(key, polys, slot) {
+    const scs = commitScalars(key, polys);
+    return commitPoints(key, polys, scs, await addon.msmTableMultiDevAsync(key.ptauTable, scs, polys.map((p) => p.n), 32, slot));
+}
+// A proof is a generator (proveSteps): it yields right before each of its long blocking calls. `yield { commit: [polys] }` asks the driver for the
+// commitments of a round and receives the points; a bare `yield` stands before a read-back that waits for everything queued so far.
+const serve = (key, req) => (req && req.commit ? commit(key, req.commit) : undefined);
 
 // plonk.prove(zkey, wtns[, blindingMont]): blindingMont = the 11 Fr.random() draws (:224-227) as 32-byte Montgomery values, for
 // bit-exact reproduction of a reference proof; default = fresh randomness.
-function prove(zkey, wtns, blindingMont = null) {
-    const key = zkey instanceof PlonkKey ? zkey : new PlonkKey(zkey);
+function prove(zkey, wtns, blindingMont = null, options = null) {
+    const key = zkey instanceof PlonkKey ? zkey : new PlonkKey(zkey, options);
     const polys = [];
     const P = (n, zero = true) => { const p = new Poly(key.f, n, zero); polys.push(p); return p; };
     const track = (p) => { polys.push(p); return p; };
     try {
         const steps = proveSteps(key, (wtns instanceof Uint8Array || wtns instanceof PlonkWitness) ? wtns : new Uint8Array(wtns), blindingMont, P, track);
-        for (;;) { const s = steps.next(); if (s.done) return s.value; }
+        for (let s = steps.next(); ; s = steps.next(serve(key, s.value))) if (s.done) return s.value;
     } finally {
         polys.forEach((p) => p.free());
         if (!(zkey instanceof PlonkKey)) key.release();
     }
+}
+// The reference's plonk16Prove is async (src/plonk_prove.js:47): here every wait of the round driver — the commitments of a round, the queued
+// transforms before a read-back — runs on a libuv pool thread (addon.msmTableMultiDevAsync / synchronizeAsync); what is left on the main thread
+// between two awaits only enqueues kernels (tens of microseconds per call). Same result as prove() for the same blinding values. Calls are
+// serialised per process (one device context, pipeline slot 0): a second proveAsync waits for the first.
+let asyncQueue = Promise.resolve();
+function proveAsync(zkey, wtns, blindingMont = null, options = null) {
+    const run = async () => {
+        const key = zkey instanceof PlonkKey ? zkey : new PlonkKey(zkey, options);
+        const polys = [];
+        const P = (n, zero = true) => { const p = new Poly(key.f, n, zero); polys.push(p); return p; };
+        const track = (p) => { polys.push(p); return p; };
+        try {
+            const steps = proveSteps(key, (wtns instanceof Uint8Array || wtns instanceof PlonkWitness) ? wtns : new Uint8Array(wtns), blindingMont, P, track);
+            let s = steps.next();
+            while (!s.done) {
+                const req = s.value;
+                const ans = req && req.commit ? await commitAsync(key, req.commit, 0) : await addon.synchronizeAsync(0);
+                call("zkmi_pipeline_select", 0);
+                s = steps.next(ans);
+            }
+            return s.value;
+        } finally {
+            polys.forEach((p) => p.free());
+            if (!(zkey instanceof PlonkKey)) key.release();
+        }
+    };
+    const p = asyncQueue.then(run, run);
+    asyncQueue = p.catch(() => {});
+    return p;
 }
 
 // Throughput mode: one proof per witness against one key, TWO in flight from this one thread. Every proof is a generator (proveSteps) that
@@ -168,8 +222,8 @@ function prove(zkey, wtns, blindingMont = null) {
 // evaluations); the driver switches the library's pipeline slot (zkmi_pipeline_select: own stream, scratch buffers, allocation pool) and lets
 // the other proof enqueue up to ITS next blocking call first, so the GPU holds queued work of one proof while the host waits for the other.
 // Results come back in input order and equal what prove() returns for the same blinding values.
-function proveMany(zkey, wtnsList, blindingMonts = null) {
-    const key = zkey instanceof PlonkKey ? zkey : new PlonkKey(zkey);
+function proveMany(zkey, wtnsList, blindingMonts = null, options = null) {
+    const key = zkey instanceof PlonkKey ? zkey : new PlonkKey(zkey, options);
     const out = new Array(wtnsList.length), live = [], free = [0, 1];
     let nxt = 0;
     const finish = (ent) => { ent.polys.forEach((p) => p.free()); live.splice(live.indexOf(ent), 1); free.push(ent.slot); };
@@ -179,13 +233,13 @@ function proveMany(zkey, wtnsList, blindingMonts = null) {
                 const polys = [], w = wtnsList[nxt];
                 const P = (n, zero = true) => { const p = new Poly(key.f, n, zero); polys.push(p); return p; };
                 const track = (p) => { polys.push(p); return p; };
-                live.push({ slot: free.shift(), idx: nxt, polys, steps: proveSteps(key, (w instanceof Uint8Array || w instanceof PlonkWitness) ? w : new Uint8Array(w), blindingMonts ? blindingMonts[nxt] : null, P, track) });
+                live.push({ slot: free.shift(), idx: nxt, polys, req: undefined, steps: proveSteps(key, (w instanceof Uint8Array || w instanceof PlonkWitness) ? w : new Uint8Array(w), blindingMonts ? blindingMonts[nxt] : null, P, track) });
                 nxt++;
             }
             for (const ent of live.slice()) {
                 call("zkmi_pipeline_select", ent.slot);
-                const s = ent.steps.next();
-                if (s.done) { out[ent.idx] = s.value; finish(ent); }
+                const s = ent.steps.next(serve(key, ent.req));       // the blocking call this proof stopped in front of, then on to its next one
+                if (s.done) { out[ent.idx] = s.value; finish(ent); } else ent.req = s.value;
             }
         }
     } finally {
@@ -220,8 +274,7 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         let pA = track(A.ntt(true)), pB = track(B.ntt(true)), pC = track(Cw.ntt(true));
         const eA = track(pA.extendedEvals(4)), eB = track(pB.extendedEvals(4)), eC = track(pC.extendedEvals(4));
         pA = track(pA.blinded([b[2], b[1]])); pB = track(pB.blinded([b[4], b[3]])); pC = track(pC.blinded([b[6], b[5]]));
-        yield;
-        [pts.A, pts.B, pts.C] = commit(key, [pA, pB, pC]);
+        [pts.A, pts.B, pts.C] = yield { commit: [pA, pB, pC] };
 
         // ---- ROUND 2 (:315-455)
         tr.reset();
@@ -236,8 +289,7 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         let pZ = track(Zb.ntt(true));
         const eZ = track(pZ.extendedEvals(4));
         pZ = track(pZ.blinded([b[9], b[8], b[7]]));
-        yield;
-        [pts.Z] = commit(key, [pZ]);
+        [pts.Z] = yield { commit: [pZ] };
         if (Zb.get(0) !== 1n) throw new Error("Copy constraints does not match");                        // computeZ's check (:437-439), read behind the commitment's own wait
 
         // ---- ROUND 3 (:457-684)
@@ -258,8 +310,7 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         T1.set(n, b[10]);
         T2.set(0, mod(T2.get(0) - b[10], r)); T2.set(n, b[11]);
         T3.set(0, mod(T3.get(0) - b[11], r));
-        yield;
-        [pts.T1, pts.T2, pts.T3] = commit(key, [T1, T2, T3]);
+        [pts.T1, pts.T2, pts.T3] = yield { commit: [T1, T2, T3] };
 
         // ---- ROUND 4 (:686-708)
         tr.reset(); tr.scalar(alpha);
@@ -307,8 +358,7 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         const Wxiw = P(pZ.n, false).copyFrom(pZ.ptr, pZ.n);
         Wxiw.addScalar(mod(-ezw, r));
         call("zkmi_poly_div_by_zerofier_dev", f.cid, Wxiw.ptr, Wxiw.n, 1, mont(xiw));
-        yield;
-        [pts.Wxi, pts.Wxiw] = commit(key, [Wxi, Wxiw]);
+        [pts.Wxi, pts.Wxiw] = yield { commit: [Wxi, Wxiw] };
 
         const proof = {};
         for (const nm of ["A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"]) proof[nm] = [pts[nm][0].toString(), pts[nm][1].toString(), "1"];   // src/proof.js:61-83
@@ -345,5 +395,5 @@ class PlonkWitness {
     release() { if (this.dWit) { devFree(this.dWit); this.dWit = 0; } }
 }
 
-module.exports = { prove, proveMany, PlonkKey, PlonkWitness,
-                   _internals: { addon, call, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN, Q_BLS } };
+module.exports = { prove, proveAsync, proveMany, PlonkKey, PlonkWitness,
+                   _internals: { addon, call, bindDevice, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN, Q_BLS } };

@@ -133,7 +133,8 @@ typedef struct {
     napi_deferred deferred;
     napi_ref keep[8]; int n_keep;          /* arguments and result kept alive while the job runs */
     napi_ref result;                       /* value the promise resolves to (NULL: undefined) */
-    int kind;                              /* 0 msm, 1 ntt, 2 groth16Prove, 3 groth16Submit, 4 groth16Collect, 5 groth16Load */
+    int kind;                              /* 0 msm, 1 ntt, 2 groth16Prove, 3 groth16Submit, 4 groth16Collect, 5 groth16Load, 6 msmTableMultiDev, 7 synchronize */
+    double handle; const void* dptr[4]; size_t dk[4]; int dcnt;      /* kind 6: table handle, device scalars, term counts */
     int32_t slot;
     int32_t curve, group, logn, inverse;
     pages_t a, b;
@@ -151,7 +152,16 @@ static int job_run(job_t* j) {
     case 2: return zkmi_groth16_prove_paged(j->has_zk ? &j->zk->z : NULL, (uint64_t)j->key, j->a.ptr[0], j->a.len[0], j->first, j->inc, j->o0, j->o1, j->o2);
     case 3: return zkmi_groth16_submit((uint64_t)j->key, j->a.ptr[0], j->a.len[0], j->slot);
     case 4: return zkmi_groth16_collect((uint64_t)j->key, j->slot, j->first, j->inc, j->o0, j->o1, j->o2);
-    default: return zkmi_groth16_load_paged(&j->zk->z, (uint64_t)j->key);
+    case 5: return zkmi_groth16_load_paged(&j->zk->z, (uint64_t)j->key);
+    default: {
+        /* the round drivers of plonk.prove / fflonk.prove (js/plonk_native.js: proveAsync): the call that makes the host WAIT — the commitments of a
+         * round, or the queued work before a read-back — runs here on a pool thread, in the pipeline slot of the proof it belongs to */
+        const int prev = zkmi_pipeline_active();
+        int rc = zkmi_pipeline_select(j->slot);
+        if (!rc) rc = j->kind == 6 ? zkmi_msm_table_multi_dev((uint64_t)j->handle, j->dptr, j->dk, j->dcnt, (size_t)j->sb, j->o0) : zkmi_synchronize();
+        (void)zkmi_pipeline_select(prev);
+        return rc;
+    }
     }
 }
 static void job_execute(napi_env env, void* data) {
@@ -675,6 +685,39 @@ static napi_value js_msm_table_multi_dev(napi_env env, napi_callback_info info) 
     if (rc) return throw_zkmi(env, rc);
     return res;
 }
+/* msmTableMultiDevAsync(handle, [dScalars...], [k...], scalarBytes, slot) -> Promise<Uint8Array>; synchronizeAsync(slot) -> Promise<undefined>: the two calls on
+ * which a host-orchestrated prover waits, on a libuv pool thread (the event loop keeps turning), each in pipeline slot `slot` */
+static napi_value js_msm_table_multi_dev_async(napi_env env, napi_callback_info info) {
+    ARGS(5);
+    double h; int32_t sb, slot; int curve, group; uint32_t cnt = 0, cnt2 = 0;
+    bool a0 = false, a1 = false;
+    if (get_f64(env, argv[0], &h) || napi_is_array(env, argv[1], &a0) != napi_ok || !a0 || napi_is_array(env, argv[2], &a1) != napi_ok || !a1 ||
+        napi_get_array_length(env, argv[1], &cnt) != napi_ok || napi_get_array_length(env, argv[2], &cnt2) != napi_ok || cnt != cnt2 || cnt < 1 || cnt > 4 ||
+        get_i32(env, argv[3], &sb) || get_i32(env, argv[4], &slot) || (slot != 0 && slot != 1)) BAD_ARG();
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    if (!j) BAD_ARG();
+    for (uint32_t i = 0; i < cnt; i++) {
+        napi_value e; void* p; double k;
+        if (napi_get_element(env, argv[1], i, &e) != napi_ok || get_dptr(env, e, &p) || napi_get_element(env, argv[2], i, &e) != napi_ok || get_f64(env, e, &k) || k < 0) { free(j); BAD_ARG(); }
+        j->dptr[i] = p; j->dk[i] = (size_t)k;
+    }
+    int rc = ZK_CALL(zkmi_msm_table_info((uint64_t)h, &curve, &group, NULL));
+    if (rc) { free(j); return throw_zkmi(env, rc); }
+    uint8_t* out;
+    napi_value res = new_u8(env, (size_t)cnt * 3 * group * (curve == ZKMI_CURVE_BN128 ? 32 : 48), &out);
+    if (!res) { free(j); BAD_ARG(); }
+    j->kind = 6; j->handle = h; j->dcnt = (int)cnt; j->sb = sb; j->slot = slot; j->o0 = out;
+    return job_queue(env, j, "zkmi.msmTableMultiDev", argv, 0, res);
+}
+static napi_value js_synchronize_async(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    int32_t slot;
+    if (get_i32(env, argv[0], &slot) || (slot != 0 && slot != 1)) BAD_ARG();
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    if (!j) BAD_ARG();
+    j->kind = 7; j->slot = slot;
+    return job_queue(env, j, "zkmi.synchronize", argv, 0, NULL);
+}
 /* GPU-to-GPU exchange between shard processes (include/zkmi.h: zkmi_ipc_*): ipcExport(ptr) -> Uint8Array(ZKMI_IPC_HANDLE_BYTES);
  * ipcOpen(handle) -> pointer in this process; ipcClose(ptr); peerCopy(dDst, dSrc, bytes) (complete on return); groth16Reset(key);
  * groth16KeyCurve(key) -> 0 | 1 | -1 */
@@ -890,7 +933,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"devAlloc", js_dev_alloc}, {"devFree", js_dev_free}, {"memcpyH2D", js_memcpy_h2d}, {"memcpyD2H", js_memcpy_d2h},
         {"groth16ChainsDev", js_groth16_chains_dev}, {"groth16SumsWDev", js_groth16_sums_w_dev}, {"groth16SumsHDev", js_groth16_sums_h_dev}, {"groth16SumsDev", js_groth16_sums_dev},
         {"groth16Finish", js_groth16_finish}, {"joinABCDev", js_join_abc_dev}, {"pointAdd", js_point_add}, {"shmMap", js_shm_map}, {"shmUnlink", js_shm_unlink},
-        {"msmTableDev", js_msm_table_dev}, {"msmTableMultiDev", js_msm_table_multi_dev}, {"ipcExport", js_ipc_export}, {"ipcOpen", js_ipc_open}, {"ipcClose", js_ipc_close},
+        {"msmTableDev", js_msm_table_dev}, {"msmTableMultiDev", js_msm_table_multi_dev}, {"msmTableMultiDevAsync", js_msm_table_multi_dev_async}, {"synchronizeAsync", js_synchronize_async}, {"ipcExport", js_ipc_export}, {"ipcOpen", js_ipc_open}, {"ipcClose", js_ipc_close},
         {"peerCopy", js_peer_copy}, {"peerCopyAsync", js_peer_copy_async}, {"peerFence", js_peer_fence}, {"groth16Reset", js_groth16_reset}, {"groth16KeyCurve", js_groth16_key_curve},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

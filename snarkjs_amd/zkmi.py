@@ -20,7 +20,7 @@ ERR_NO_DEVICE = 1
 
 # every symbol include/zkmi.h and include/zkmi_diag.h declare (tests check that the library exports all of them)
 SYMBOLS = [
-    "zkmi_groth16_load_paged", "zkmi_groth16_load_shard_paged", "zkmi_groth16_prove_paged", "zkmi_groth16_build_abc_dev", "zkmi_groth16_coef_layout",
+    "zkmi_groth16_load_paged", "zkmi_groth16_load_shard_paged", "zkmi_groth16_prove_paged", "zkmi_groth16_build_abc_dev", "zkmi_groth16_coef_layout", "zkmi_msm_dev_fallbacks",
     "zkmi_init", "zkmi_device_count", "zkmi_last_error", "zkmi_version", "zkmi_set_stream", "zkmi_synchronize",
     "zkmi_dev_alloc", "zkmi_dev_free", "zkmi_memcpy_h2d", "zkmi_memcpy_d2h", "zkmi_memcpy_d2d", "zkmi_memset_dev",
     "zkmi_msm", "zkmi_release_bases", "zkmi_msm_dev", "zkmi_msm_set_window_bits", "zkmi_msm_accum_ms", "zkmi_msm_stats", "zkmi_msm_accum_additions", "zkmi_msm_table_build", "zkmi_msm_table_dev", "zkmi_msm_table_multi_dev", "zkmi_msm_table_release", "zkmi_msm_table_info",
@@ -197,6 +197,8 @@ def lib():
     L.zkmi_groth16_load_shard_paged.argtypes = [C.POINTER(Groth16ZkeyPaged), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.zkmi_groth16_prove_paged.argtypes = [C.POINTER(Groth16ZkeyPaged), C.c_uint64, u8p, C.c_size_t, u8p, u8p, u8p, u8p, u8p]
     L.zkmi_groth16_build_abc_dev.argtypes = [C.c_uint64, vp, vp, vp, vp]
+    L.zkmi_msm_dev_fallbacks.argtypes = []
+    L.zkmi_msm_dev_fallbacks.restype = C.c_ulonglong
     L.zkmi_groth16_coef_layout.argtypes = [C.c_uint64, C.POINTER(C.c_uint64), C.c_int]
     _lib = _Locked(L)
     return _lib

@@ -41,11 +41,17 @@ for (const [tag, cid] of [["bn128", 0], ["bls12381", 1]]) {
     for (const g of [1, 2]) {
         const jac = addon.msm(cid, g, raw(tag, `g${g}_bases`), x, 1024, 32, 0);
         check(`${tag} G${g}.multiExpAffine`, jac.length === 3 * g * n8q && eq(addon.toAffine(cid, g, jac), raw(tag, `g${g}_msm_affine`)));
-        // resident bases (pre-computed window tables under a cache key): first call builds, second call reuses
-        const key = 1000 + 10 * cid + g;
-        const j1 = addon.msm(cid, g, raw(tag, `g${g}_bases`), x, 1024, 32, key), j2 = addon.msm(cid, g, raw(tag, `g${g}_bases`), x, 1024, 32, key);
-        check(`${tag} G${g}.multiExpAffine (resident tables)`, eq(addon.toAffine(cid, g, j1), raw(tag, `g${g}_msm_affine`)) && eq(addon.toAffine(cid, g, j2), raw(tag, `g${g}_msm_affine`)));
-        addon.releaseBases(key);
+        // resident bases: base_cache_key is a set of PERMISSION BITS (include/zkmi.h: ZKMI_BASES_CACHE = 1, ZKMI_BASES_IMMUTABLE = 2), not an identity.
+        // First sight remembers the hashes, second sight builds the window table, third call uses it; with the promise bit (3) the re-check is sampled
+        for (const key of [1, 3]) {
+            const js = [0, 1, 2].map(() => addon.msm(cid, g, raw(tag, `g${g}_bases`), x, 1024, 32, key));
+            check(`${tag} G${g}.multiExpAffine (resident tables, cache key ${key})`, js.every((j) => eq(addon.toAffine(cid, g, j), raw(tag, `g${g}_msm_affine`))));
+        }
+        addon.releaseBases(1);
+        // a legacy caller that passes an arbitrary "identity" (r04 semantics: any non-zero value) is refused, not silently given another mode
+        let threw = false;
+        try { addon.msm(cid, g, raw(tag, `g${g}_bases`), x, 1024, 32, 1000 + 10 * cid + g); } catch (e) { threw = /permission bits/.test(e.message); }
+        check(`${tag} G${g}: a cache key with unknown bits fails loudly`, threw);
     }
     // ceremony side (SURVEY.md 8 f4): group-element FFTs and G.batchApplyKey against the reference's vectors
     {

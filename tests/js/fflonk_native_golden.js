@@ -2,7 +2,7 @@
 // reference's seeded proofs (tests/golden/fflonk_bn128_*.json) bit for bit.   Run:  node tests/js/fflonk_native_golden.js
 "use strict";
 const fs = require("fs"), path = require("path"), crypto = require("crypto");
-const { prove, FflonkKey } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "fflonk_native.js"));
+const { prove, proveAsync, FflonkKey } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "fflonk_native.js"));
 const GOLD = path.join(__dirname, "..", "golden");
 const sha = (b) => crypto.createHash("sha256").update(b).digest("hex");
 let fails = 0;
@@ -27,5 +27,20 @@ for (const tag of ["fflonk_bn128_small", "fflonk_bn128_n256"]) {
 let threw = false;
 try { prove(new Uint8Array(fs.readFileSync(path.join(GOLD, "plonk_bn128_small.zkey"))), new Uint8Array(64)); } catch (e) { threw = e.message === "zkey file is not fflonk"; }
 check("a PLONK zkey is rejected with the reference's message", threw);
-console.log(fails ? `${fails} FAILED` : "ALL OK");
-process.exit(fails ? 1 : 0);
+// r06: proveAsync (fflonkProve is async in the reference, src/fflonk_prove.js:51)
+(async () => {
+    const tag = "fflonk_bn128_n256";
+    const g = JSON.parse(fs.readFileSync(path.join(GOLD, tag + ".json")));
+    const zkey = new Uint8Array(fs.readFileSync(path.join(GOLD, tag + ".zkey"))), wtns = new Uint8Array(fs.readFileSync(path.join(GOLD, tag + ".wtns")));
+    let ticks = 0;
+    const timer = setInterval(() => { ticks++; }, 0);
+    const [a, b] = await Promise.all([proveAsync(zkey, wtns, g.blinding_mont.map(hexb), { device: 0 }), proveAsync(zkey, wtns, g.blinding_mont.map(hexb))]);
+    clearInterval(timer);
+    check(tag + `: proveAsync == reference proof, twice at once; the event loop turned ${ticks} times meanwhile`,
+          sha(JSON.stringify(a.proof)) === g.proof_sha256 && sha(JSON.stringify(b.proof)) === g.proof_sha256 && ticks >= 4);
+    let msg = "";
+    try { await proveAsync(zkey, wtns.subarray(0, wtns.length - 32)); } catch (e) { msg = e.message; }
+    check(tag + ": proveAsync rejects with the reference's message", /Invalid witness length/.test(msg));
+    console.log(fails ? `${fails} FAILED` : "ALL OK");
+    process.exit(fails ? 1 : 0);
+})().catch((e) => { console.log("ERROR", e); process.exit(2); });

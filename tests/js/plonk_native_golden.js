@@ -3,7 +3,7 @@
 // Run:  node tests/js/plonk_native_golden.js
 "use strict";
 const fs = require("fs"), path = require("path"), crypto = require("crypto");
-const { prove, proveMany, PlonkKey, PlonkWitness } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "plonk_native.js"));
+const { prove, proveAsync, proveMany, PlonkKey, PlonkWitness } = require(path.join(__dirname, "..", "..", "snarkjs_amd", "js", "plonk_native.js"));
 const GOLD = path.join(__dirname, "..", "golden");
 const sha = (b) => crypto.createHash("sha256").update(b).digest("hex");
 let fails = 0;
@@ -51,5 +51,28 @@ for (const tag of ["plonk_bn128_n2048", "plonk_bls12381_small"]) {
 let threw = false;
 try { prove(new Uint8Array(fs.readFileSync(path.join(GOLD, "groth16_bn128_n1024.zkey"))), new Uint8Array(64)); } catch (e) { threw = e.message === "zkey file is not plonk"; }
 check("a Groth16 zkey is rejected with the reference's message", threw);
-console.log(fails ? `${fails} FAILED` : "ALL OK");
-process.exit(fails ? 1 : 0);
+// r06: proveAsync (the reference's plonk16Prove is async, src/plonk_prove.js:47): same proof; the event loop turns while the commitments are computed
+// (a timer keeps firing); two calls at once are serialised; errors reject; the device option (one device per process)
+(async () => {
+    for (const tag of ["plonk_bn128_n2048", "plonk_bls12381_small"]) {
+        const g = JSON.parse(fs.readFileSync(path.join(GOLD, tag + ".json")));
+        const zkey = new Uint8Array(fs.readFileSync(path.join(GOLD, tag + ".zkey"))), wtns = new Uint8Array(fs.readFileSync(path.join(GOLD, tag + ".wtns")));
+        let ticks = 0;
+        const timer = setInterval(() => { ticks++; }, 0);
+        const blind = g.blinding_mont.map(hexb);
+        const [a, b] = await Promise.all([proveAsync(zkey, wtns, blind, { device: 0 }), proveAsync(zkey, wtns, blind)]);
+        clearInterval(timer);
+        check(tag + `: proveAsync == reference proof, twice at once; the event loop turned ${ticks} times meanwhile`,
+              sha(JSON.stringify(a.proof)) === g.proof_sha256 && sha(JSON.stringify(b.proof)) === g.proof_sha256 && ticks >= 4);
+        let msg = "";
+        try { await proveAsync(zkey, wtns.subarray(0, wtns.length - 32)); } catch (e) { msg = e.message; }
+        check(tag + ": proveAsync rejects with the reference's message", /Invalid witness length/.test(msg));
+        const again = await proveAsync(zkey, wtns, blind);
+        check(tag + ": and works afterwards", sha(JSON.stringify(again.proof)) === g.proof_sha256);
+    }
+    let msg = "";
+    try { new PlonkKey(new Uint8Array(fs.readFileSync(path.join(GOLD, "plonk_bn128_small.zkey"))), { device: 1 }); } catch (e) { msg = e.message; }
+    check("a key for another device than the one this process is bound to is refused", /bound to device 0/.test(msg));
+    console.log(fails ? `${fails} FAILED` : "ALL OK");
+    process.exit(fails ? 1 : 0);
+})().catch((e) => { console.log("ERROR", e); process.exit(2); });

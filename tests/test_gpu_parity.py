@@ -634,29 +634,7 @@ def test_msm_resident_tables_special_cases(zk, name, group):
     d_b.free()
 
 
-def _groth16_closed_form(c, name, zk_, w, lg, n_public, rr, ss, b_zero_every):
-    """Closed-form discrete logs (a, b, cc) of pi_a, pi_b, pi_c for a tests/synth_zkey.py key: every base is a known multiple of
-    the generator (T[i] = 7*11^i*G), so each MSM result is an O(n) field sum (oracle/zk_oracle.c: orc_fr_geom_dot) over the witness
-    and over h, the odd-coset evaluations of A*B - C from the CPU restatement's buildABC / NTT chain / joinABC (:62-83). The five
-    MSMs themselves are never run on the CPU."""
-    import synth_zkey
-    r = synth_zkey.PRIMES[name][2]
-    n, m = zk_["domainSize"], zk_["nVars"]
-    A, B, Cc = O.build_abc(c, zk_["coeffs"], w, m, n)
-    one, inc = O.fr_one(c), O.fr_w(c, lg + 1)
-    A, B, Cc = (O.ntt(c, O.apply_key(c, O.ntt(c, x, inverse=True), one, inc)) for x in (A, B, Cc))
-    h = O.join_abc(c, A, B, Cc)                                # joinABC already leaves normal form (:362)
-    del A, B, Cc
-    d = lambda i: 7 * pow(11, i, r) % r                        # discrete log of T[i]
-    sa = O.geom_dot(c, w, m)                                   # A_i = T1[i]
-    sb = O.geom_dot(c, w, m, skip_mod=b_zero_every, skip_rem=1) if b_zero_every else sa     # B2_i = T2[i] (or infinity)
-    sc = O.geom_dot(c, w[(n_public + 1) * 32:], m - n_public - 1)                           # C_j = T1[2 + j]: shift applied below
-    sh = O.geom_dot(c, h, n)                                   # H_i = T1[3 + i]
-    a = (d(5) + sa + rr * d(7)) % r                            # alpha1 = T1[5], delta1 = T1[7]
-    b = (d(1) + sb + ss * d(2)) % r                            # beta2 = T2[1], delta2 = T2[2]
-    b1 = (d(6) + sb * 11 + ss * d(7)) % r                      # beta1 = T1[6], B1_i = T1[i + 1]
-    cc = (sc * pow(11, 2, r) + sh * pow(11, 3, r) + ss * a + rr * b1 - rr * ss % r * d(7)) % r
-    return a, b, cc
+_groth16_closed_form = O.groth16_closed_form          # tests/oracle_lib.py (bench.py's configs[2] line checks its 2^24 proof with it in-run)
 
 
 @pytest.mark.parametrize("name,lg,b_zero_every", [("bn128", 20, 3), ("bn128", 20, 0), ("bls12381", 20, 3), ("bls12381", 20, 0), ("bn128", 24, 0)])

@@ -14,31 +14,26 @@
 "use strict";
 const fs = require("fs"), path = require("path");
 const addon = require(path.join(__dirname, "..", "snarkjs_amd", "napi", "zkmi_napi.node"));
-const [zkeyPath, wtnsPath, repsArg] = process.argv.slice(2);
+const [zkeyPath, wtnsPath, repsArg, drawsHex] = process.argv.slice(2);
 const reps = parseInt(repsArg || "5");
 const now = () => Number(process.hrtime.bigint()) / 1e6;
-function sections(data) {
-    const dv = new DataView(data.buffer, data.byteOffset, data.byteLength), n = dv.getUint32(8, true), out = {};
-    let off = 12;
-    for (let i = 0; i < n; i++) { const t = dv.getUint32(off, true), len = Number(dv.getBigUint64(off + 4, true)); off += 12; out[t] = data.subarray(off, off + len); off += len; }
-    return out;
-}
 const med = (a) => { const s = a.slice().sort((x, y) => x - y); return s[s.length >> 1]; };
 addon.init(0);
-const zkey = new Uint8Array(fs.readFileSync(zkeyPath)), wtns = new Uint8Array(fs.readFileSync(wtnsPath));
-const zs = sections(zkey), ws = sections(wtns);
-const hv = new DataView(zs[2].buffer, zs[2].byteOffset, zs[2].byteLength);
-const n8q = hv.getUint32(0, true), n8r = hv.getUint32(4 + n8q, true);
-let o = 8 + n8q + n8r;
-const nVars = hv.getUint32(o, true), nPublic = hv.getUint32(o + 4, true), domainSize = hv.getUint32(o + 8, true);
-o += 12;
-const pt = (k) => { const v = zs[2].subarray(o, o + k * n8q); o += k * n8q; return v; };
-const alpha1 = pt(2), beta1 = pt(2), beta2 = pt(4); pt(4); const delta1 = pt(2), delta2 = pt(4);
-const cid = n8q == 32 ? 0 : 1;
-const desc = { curve: cid, nVars, nPublic, domainSize, coeffs: zs[4], A: zs[5], B1: zs[6], B2: zs[7], C: zs[8], H: zs[9], alpha1, beta1, beta2, delta1, delta2 };
-const r = new Uint8Array(32), s = new Uint8Array(32); r[0] = 3; s[0] = 5;
-const witness = ws[2];
-const out = { n_vars: nVars, domain: domainSize, reps };
+// r06: the key is opened the way js/groth16_native.js opens it — sections read by offset from the file descriptor into pages of <= 1 GiB — so that
+// this tool (and a Node host) can take a 2^24-constraint key (9.4 GB; sections of 1 - 2 GB: beyond one Node buffer)
+const { openZkey, parseWtns } = require(path.join(__dirname, "..", "snarkjs_amd", "js", "groth16_native.js"));
+let tOpen = now();
+const zk = openZkey(zkeyPath);
+tOpen = now() - tOpen;
+const desc = zk.desc, cid = zk.curveId, n8q = zk.n8q, nVars = zk.nVars, nPublic = zk.nPublic, domainSize = zk.domainSize;
+const wtns = new Uint8Array(fs.readFileSync(wtnsPath));
+const witness = parseWtns(wtns, zk);
+const BIG = fs.statSync(zkeyPath).size >= 2147483647 || !!process.env.ZKMI_NAPI_WALL_BIG;
+const zs = { 5: desc.A };
+let r = new Uint8Array(32), s = new Uint8Array(32); r[0] = 3; s[0] = 5;
+if (drawsHex) [r, s] = drawsHex.split(",").map((h) => new Uint8Array(Buffer.from(h, "hex")));        // the caller's blinding draws: its own proof for them must equal ours
+const out = { n_vars: nVars, domain: domainSize, reps, zkey_bytes: fs.statSync(zkeyPath).size, zkey_open_ms: +tOpen.toFixed(1),
+              zkey_pages: ["coeffs", "A", "B1", "B2", "C", "H"].map((k) => (Array.isArray(desc[k]) ? desc[k].length : 1)) };
 {
     const key = 424242;
     let t0 = now();
@@ -62,10 +57,12 @@ const out = { n_vars: nVars, domain: domainSize, reps };
         const last = addon.groth16Collect(cid, key, (N - 1) & 1, r, s);
         out.groth16_pipelined_ms = +((now() - t0) / N).toFixed(3);
         const ref = addon.groth16Prove(cid, key, witness, r, s);
+        out.proof_sha256 = require("crypto").createHash("sha256").update(Buffer.concat([Buffer.from(ref.pi_a), Buffer.from(ref.pi_b), Buffer.from(ref.pi_c)])).digest("hex");
         out.groth16_pipelined_equals_serial = Buffer.from(last.pi_a).equals(Buffer.from(ref.pi_a)) && Buffer.from(last.pi_b).equals(Buffer.from(ref.pi_b)) && Buffer.from(last.pi_c).equals(Buffer.from(ref.pi_c));
     }
     addon.groth16Release(key);
 }
+if (BIG) { console.log(JSON.stringify(out)); process.exit(0); }      // a key beyond one buffer: the fused prover's figures only (the MSM / NTT / shard legs are measured at 2^20)
 {
     const bases = zs[5], scalars = witness;
     const t = [], tr = [];
@@ -95,7 +92,7 @@ const out = { n_vars: nVars, domain: domainSize, reps };
 {
     const sm = {}, sn = {};
     for (const k of [4, 64, 1024]) {
-        const bases = zs[5].subarray(0, k * 2 * n8q), scalars = witness.subarray(32, 32 + k * 32);
+        const bases = (Array.isArray(zs[5]) ? zs[5][0] : zs[5]).subarray(0, k * 2 * n8q), scalars = witness.subarray(32, 32 + k * 32);
         let t = [];
         for (let i = 0; i < 22; i++) { const t0 = now(); addon.msm(cid, 1, bases, scalars, k, 32, 0); t.push(now() - t0); }
         sm[k] = +med(t.slice(2)).toFixed(4);
