@@ -422,7 +422,9 @@ static uint64_t g_next_table = 1;
 static int table_build(int curve, int group, const void* d_bases, size_t n, MsmTable& t) {
     const size_t pb = (size_t)2 * group * n8q_of(curve);
     t.curve = curve; t.group = group; t.n = n;
-    t.c = msm_precomp_c(n);
+    // ZKMI_TABLE_C=<c>: window width of the tables built here (A/B experiments: PLONK's SRS table at c = 17 against the built-in 20)
+    static const int c_env = getenv("ZKMI_TABLE_C") ? atoi(getenv("ZKMI_TABLE_C")) : 0;
+    t.c = c_env > 0 ? c_env : msm_precomp_c(n);
     t.Wd = msm_digits(32, t.c);
     if ((size_t)t.Wd * n >= (1ull << 31)) return fail(ZKMI_ERR_UNSUPPORTED, "msm table: too many points");
     ZK_TRY(dev_alloc_big(&t.p, (size_t)t.Wd * n * pb));
