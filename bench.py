@@ -253,6 +253,21 @@ def reference_wasm_baseline_plonk(proto, lg):
     return out
 
 
+def pmc_traffic(workload_tag, kernel):
+    """HBM bytes per launch of `kernel` from the separate rocprofv3 --pmc passes of THIS workload (tools/collect_profiles.sh -> tools/publish_profiles.py ->
+    profiles/pmc_traffic.json, keyed by workload); a file collected on another workload (size / curve / B density / protocol) is not used: None."""
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tf):
+        return None
+    try:
+        pj = json.load(open(tf))
+        if pj.get("__workload__") == workload_tag and kernel in pj:
+            return pj[kernel]
+        return (pj.get("workloads", {}).get(workload_tag) or {}).get(kernel)
+    except Exception:
+        return None
+
+
 def _synth_kw(args):
     return dict(witness=args.witness, b_zero_every=args.b_zero_every, coef_dist=args.coef_dist)
 
@@ -512,9 +527,10 @@ def bench_plonk(args, rank, world, dist, torch):
             int_alu = {"error": repr(e)[:200]}
         roof = None
         if acc_ms and acc_ms > 0:
-            roof = {"bound": "hbm", "kernel": ("k_msm_accum29<Bn254Fq>" if os.environ.get("ZKMI_R29", "1") != "0" else "k_msm_accum<Fp<Bn254Fq>>") + " (last commitment, n terms)", "achieved": round(alg / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(alg / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms": round(acc_ms, 4), "algorithmic_bytes": alg,
-                    "note": "integer-ALU-bound (256-bit Montgomery carry chains, no MFMA); traffic: no PMC pass for this workload"}
+            kname = "k_msm_accum29<Bn254Fq>" if os.environ.get("ZKMI_R29", "1") != "0" else "k_msm_accum<Fp<Bn254Fq>>"
+            roof = {"bound": "hbm", "kernel": kname + " (last commitment, n terms)", "achieved": round(alg / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(alg / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(f"{proto}:bn128:2^{lg}:additions={int(key.nAdditions)}", kname), "kernel_ms": round(acc_ms, 4), "algorithmic_bytes": alg,
+                    "note": "integer-ALU-bound (256-bit Montgomery carry chains, no MFMA); traffic: average over the accumulation launches of a proof (9 commitments of n .. n + 6 terms)"}
         out = {
             "metric": f"{proto}_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -955,16 +971,8 @@ def main():
         achieved = alg_bytes / (acc[dom] * 1e-3) / 1e9
         # HBM bytes of that launch from separate rocprofv3 --pmc passes of THIS workload (tools/publish_profiles.py tags the file);
         # a file collected on another workload (size / curve / B density) is not used: traffic stays null
-        traffic = None
-        wl_tag = f"groth16:{args.curve}:2^{lg}:b_zero_every={args.b_zero_every}:{args.witness}"
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):
-            try:
-                pj = json.load(open(tf))
-                if pj.get("__workload__") == wl_tag:
-                    traffic = pj.get(names[dom][0].split(" ")[0])
-            except Exception:
-                traffic = None
+        wl_tag = f"groth16:{args.curve}:2^{lg}:" + (f"b_zero_every={args.b_zero_every}" if args.coef_dist == "flat" else "coef_dist=real") + f":{args.witness}"
+        traffic = pmc_traffic(wl_tag, names[dom][0].split(" ")[0])
         roof = {"bound": "hbm", "kernel": names[dom][0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "kernel_ms": round(acc[dom], 4),
                 "algorithmic_bytes": alg_bytes,

@@ -253,8 +253,8 @@ int zkmi_plonk_gather_wires_dev(int curve, const void* d_witness, uint32_t n_wit
                                 void* d_a, void* d_b, void* d_c);
 /* calculateAdditions (src/plonk_prove.js:174-204, src/fflonk_prove.js:269-300): the internal signals of a PLONK / FFLONK key,
  *   internal[i] = factor1_i * getWitness(id1_i) + factor2_i * getWitness(id2_i),   getWitness as in :207-215 (n_vars = n_witness + n_additions),
- * computed on the device in ONE launch although an addition may read internal signals created before it (a dependency DAG; chains of any
- * depth). d_additions: the zkey's additions section as it lies in the file (n_additions records of 72 bytes: u32 id1, u32 id2, factor1,
+ * computed on the device in ONE launch although an addition may read internal signals created before it (a dependency DAG of any depth; time grows
+ * with the depth — a few microseconds per level — which is ceil(log2 k) for a k-term combination in keys written by plonk.setup, src/plonk_setup.js:176-212). d_additions: the zkey's additions section as it lies in the file (n_additions records of 72 bytes: u32 id1, u32 id2, factor1,
  * factor2 in Montgomery form). d_witness as for zkmi_plonk_gather_wires_dev. d_internal: n_additions elements, normal form (the
  * reference's buffInternalWitness). Stream-ordered: returns once enqueued. */
 int zkmi_plonk_additions_dev(int curve, const void* d_additions, uint32_t n_additions, const void* d_witness, uint32_t n_witness, void* d_internal);

@@ -159,8 +159,11 @@ template <class C> __global__ void k_plonk_gather(const uint32_t* __restrict__ w
 
 // ---- calculateAdditions (plonk_prove.js:174-204, fflonk_prove.js:269-300) -------------------------------------------------------------------
 // internal[i] = factor1_i * getWitness(id1_i) + factor2_i * getWitness(id2_i), i = 0 .. nAdditions-1, in index order in the reference: an
-// operand may be an internal signal created EARLIER (id - nWitness < i), so the loop is a dependency DAG — chains as deep as the longest linear
-// combination plonk_setup.js:180-210 folded pairwise. One launch computes all of it: a lane owns addition i and polls a ready flag per
+// operand may be an internal signal created EARLIER (id - nWitness < i), so the loop is a dependency DAG. In the keys the reference writes the DAG is
+// SHALLOW: reduceCoefs (src/plonk_setup.js:176-212) takes two terms from the FRONT of the queue and appends their sum at the BACK, i.e. it folds a
+// k-term linear combination as a balanced tree of depth ceil(log2 k) (17 for 10^5 terms), not as a chain. The latency of this kernel is proportional to
+// the depth (one release / acquire hop through the L2 per level, a few microseconds each): a hand-made key with a chain 10^5 deep would take ~0.3 s per
+// proof here — correct (the tests run chains 6 000 deep), slow, and nothing plonk.setup emits. One launch computes all of it: a lane owns addition i and polls a ready flag per
 // internal operand; blocks take a ticket when they START, so a lane only ever waits for lanes of blocks that started before its own (resident
 // or finished: forward progress without assuming an order of block dispatch). The poll loop's condition is WAVE-uniform (ballot) and the
 // result is published INSIDE the loop: a lane that published keeps iterating, masked, until its whole wave is done — with a per-lane exit

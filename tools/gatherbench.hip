@@ -49,6 +49,11 @@ int main() {
         hipEventElapsedTime(&ms, e0, e1); printf("k_gather<4>  %u lanes x 64 B  = %.1f MB  %.3f ms  %.1f GB/s\n", lanes, lanes * 64.0 / 1e6, ms, lanes * 64.0 / ms / 1e6);
         hipEventRecord(e0); k_gather<8><<<lanes / 256, 256>>>(tab, bytes / 128, out, lanes); hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1); printf("k_gather<8>  %u lanes x 128 B = %.1f MB  %.3f ms  %.1f GB/s\n", lanes, lanes * 128.0 / 1e6, ms, lanes * 128.0 / ms / 1e6);
+        // r06: the 14-limb curve's table entries (BLS12-381: 96 B per G1 point, 192 B per G2 point; entries are 96 / 192-byte aligned only)
+        hipEventRecord(e0); k_gather<6><<<lanes / 256, 256>>>(tab, bytes / 96, out, lanes); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1); printf("k_gather<6>  %u lanes x 96 B  = %.1f MB  %.3f ms  %.1f GB/s\n", lanes, lanes * 96.0 / 1e6, ms, lanes * 96.0 / ms / 1e6);
+        hipEventRecord(e0); k_gather<12><<<lanes / 256, 256>>>(tab, bytes / 192, out, lanes); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1); printf("k_gather<12> %u lanes x 192 B = %.1f MB  %.3f ms  %.1f GB/s\n", lanes, lanes * 192.0 / 1e6, ms, lanes * 192.0 / ms / 1e6);
         for (size_t win_mb : {16, 64, 256}) {
             const size_t n13 = ((size_t)832 << 20) / 64;      // a 2^20-point G1 window table: 13 rows x 64 MB
             hipEventRecord(e0); k_gather_window<<<lanes / 256, 256>>>(tab, n13, (win_mb << 20) / 64, out, lanes); hipEventRecord(e1); hipEventSynchronize(e1);

@@ -14,7 +14,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
-for f in ("bench", "bench_serial", "bench_sparse_b", "bench_mixed_witness", "bench_plonk_2p20", "bench_plonk_2p20_serial", "bench_bls12381_2p20", "bench_bn128_2p24", "bench_fflonk_2p18", "bench_force_dist"):
+for f in ("bench", "bench_serial", "bench_sparse_b", "bench_mixed_witness", "bench_real", "bench_plonk_2p20", "bench_plonk_2p20_serial", "bench_bls12381_2p20", "bench_bn128_2p24", "bench_fflonk_2p18", "bench_force_dist"):
     if os.path.exists(f"{src}/{f}.json"):
         shutil.copy(f"{src}/{f}.json", f"{dst}/{tag}_{f}.json")
 line = lambda f: json.loads(open(f).read().strip().splitlines()[-1])
@@ -33,7 +33,9 @@ def stats_md(csv_path, out, cmd):
 
 
 for sub, name, cmd in (("stats", "bench_kernel_stats", "python bench.py --steps 20 --warmup 3 --pipeline 1 --no-cpu-baseline --no-napi-wall"),
-                       ("stats_bls", "bench_bls12381_kernel_stats", "python bench.py --curve bls12381 --steps 6 --warmup 2 --pipeline 1 --no-cpu-baseline --no-napi-wall")):
+                       ("stats_bls", "bench_bls12381_kernel_stats", "python bench.py --curve bls12381 --steps 6 --warmup 2 --pipeline 1 --no-cpu-baseline --no-napi-wall"),
+                       ("stats_real", "bench_real_kernel_stats", "python bench.py --coef-dist real --witness mixed --steps 10 --warmup 2 --pipeline 1 --no-cpu-baseline --no-napi-wall"),
+                       ("stats_p24", "bench_p24_kernel_stats", "python bench.py --log-n 24 --steps 3 --warmup 1 --pipeline 1 --no-cpu-baseline --no-napi-wall")):
     c = glob.glob(f"{src}/{sub}/**/*kernel_stats.csv", recursive=True)
     if c:
         stats_md(c[0], f"{dst}/{tag}_{name}_summary.md", cmd)
@@ -96,6 +98,102 @@ if fc and wc:
                 "r02 (4-byte list reads, one sector per ENTRY): G1 1 937 MB, G2 3 558 MB under r02's x2-everything correction = 2 870 MB under this one.\n"
                 "The residual over the model (G1 ~15-20 %, G2 ~25 %) is not list traffic any more: page-table walks of 0.9 / 1.7 GB of random gathers are\n"
                 "tallied by the same counter, and the G2 kernel's WRITE_SIZE includes its scratch stores.\n")
+
+# ---- r06: the same for every other config of the driver line -> profiles/pmc_traffic.json["workloads"][<tag>] (bench.py looks its own workload up there)
+# Correction per access class from THIS round's calibration (gatherbench under the same counter: <tag>_gather_calibration.md): a gather of w bytes
+# is tallied at factor(w) of its bytes; G1 / G2 accumulation kernels gather one table entry per mixed addition (BN254 64 / 128 B, BLS12-381 96 / 192 B),
+# so bytes = raw + (1 / factor - 1) x factor x w x additions = raw + (1 - factor) x w x additions; coalesced streaming kernels: x2 (the guide).
+def gather_factors():
+    out = {64: 1.0, 128: 0.5, 96: None, 192: None}
+    g = glob.glob(f"{src}/pmc_gather/**/*counter_collection.csv", recursive=True)
+    if not g:
+        return out, None
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(g[0])):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]) * 1024)
+    lanes = 1 << 22
+    rows = []
+    for v, w in ((4, 64), (6, 96), (8, 128), (12, 192)):
+        k = next((x for x in per if x.startswith(f"k_gather<{v}>")), None)
+        if k:
+            # the first launches of each kernel are over the 4 GiB table (the 832 MB variant of <4> comes later in every repetition: take the maximum)
+            val = max(per[k])
+            out[w] = val / (lanes * w)
+            rows.append((k, lanes * w, val, out[w]))
+    ks = next((x for x in per if x.startswith("k_stream")), None)
+    if ks:
+        rows.append((ks, 1 << 30, max(per[ks]), max(per[ks]) / (1 << 30)))
+    with open(f"{dst}/{tag}_gather_calibration.md", "w") as f:
+        f.write(f"# FETCH_SIZE calibration in the MSM's gather widths ({tag}; tools/gatherbench under rocprofv3 --pmc FETCH_SIZE, 2^22 random gathers over a 4 GiB table)\n\n"
+                "| kernel | bytes actually loaded | FETCH_SIZE x 1024 | tallied fraction |\n|---|---|---|---|\n")
+        for k, b, v, fr in rows:
+            f.write(f"| `{k}` | {b/1e6:.1f} MB | {v/1e6:.1f} MB | {fr:.3f} |\n")
+        f.write("\n64 / 128 B = a BN254 G1 / G2 table entry, 96 / 192 B = a BLS12-381 entry (96 / 192-byte aligned only: half of them straddle a 128-byte line).\n"
+                "`publish_profiles.py` scales the gather share of an accumulation kernel's FETCH_SIZE by 1 / fraction.\n")
+    return out, rows
+
+
+factors, _cal = gather_factors()
+workloads = {}
+try:
+    workloads = json.load(open(f"{dst}/pmc_traffic.json")).get("workloads", {})
+except Exception:
+    workloads = {}
+md_rows = []
+for nm, entry_g1, entry_g2 in (("bls", 96, 192), ("plonk", 64, 128), ("real", 64, 128), ("p24", 64, 128)):
+    fcs, wcs = glob.glob(f"{src}/pmc_{nm}_fetch/**/*counter_collection.csv", recursive=True), glob.glob(f"{src}/pmc_{nm}_write/**/*counter_collection.csv", recursive=True)
+    bj = f"{src}/pmc_{nm}_bench.json"
+    if not (fcs and wcs and os.path.exists(bj)):
+        continue
+    try:
+        b = line(bj)
+    except Exception:
+        continue
+    F, W = agg(fcs[0], "FETCH_SIZE"), agg(wcs[0], "WRITE_SIZE")
+    cfg = b["config"]
+    if b["metric"].startswith("groth16"):
+        wl = f"groth16:{cfg['curve']}:2^{cfg['log_n']}:" + (f"b_zero_every={0 if cfg['b_density'] == 1.0 else round(1 / (1 - cfg['b_density']))}" if cfg.get("coef_dist", "flat") == "flat" else "coef_dist=real") + f":{cfg['witness']}"
+        adds = b.get("accum_mixed_additions", {})
+        g1_adds = max([v for k, v in adds.items() if "(B2)" not in k] or [0])
+        g2_adds = next((v for k, v in adds.items() if "(B2)" in k), 0)
+    else:
+        wl = f"{b['metric'].split('_')[0]}:{cfg['curve']}:2^{cfg['log_n']}:additions={cfg.get('n_additions', 0)}"
+        g1_adds, g2_adds = (b.get("int_alu") or {}).get("mixed_additions", 0), 0
+    out = {}
+    for k in sorted(F):
+        raw, wr = F[k], W.get(k, 0.0)
+        if k.startswith("k_msm_accum29_g2") or k.startswith("k_msm_accum<Fp2"):
+            fr = factors.get(entry_g2) or 0.5
+            corr = raw + (1.0 - fr) * entry_g2 * g2_adds
+        elif k.startswith("k_msm_accum"):
+            fr = factors.get(entry_g1) or 1.0
+            corr = raw + (1.0 - fr) * entry_g1 * g1_adds
+        elif k.startswith("k_ntt") or k.startswith("k_msm_rowcol") or k.startswith("k_abc"):
+            corr = raw
+        else:
+            corr = 2 * raw
+        key = k
+        while key.endswith(">") and any(key.endswith(x) for x in (", true>", ", false>")):
+            key = key[:key.rfind(",")] + ">"
+        out[key] = int(corr + wr)
+        if "accum" in k:
+            md_rows.append((wl, k, raw, wr, corr + wr))
+    workloads[wl] = out
+if workloads:
+    try:
+        top = json.load(open(f"{dst}/pmc_traffic.json"))
+    except Exception:
+        top = {}
+    top["workloads"] = workloads
+    json.dump(top, open(f"{dst}/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+    shutil.copy(f"{dst}/pmc_traffic.json", f"{dst}/{tag}_pmc_traffic.json")
+    with open(f"{dst}/{tag}_pmc_traffic_other_configs.md", "w") as f:
+        f.write(f"# HBM traffic per launch of the accumulation kernels, the other configs of the driver line ({tag}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,\n"
+                "`bench.py <config> --steps 2 --warmup 1 --pipeline 1`). Corrected per access class with this round's gather calibration (" + f"{tag}_gather_calibration.md).\n\n"
+                "| workload | kernel | FETCH raw MB | WRITE MB | corrected total MB |\n|---|---|---|---|---|\n")
+        for wl, k, raw, wr, tot in md_rows:
+            f.write(f"| {wl} | `{k}` | {raw/1e6:.0f} | {wr/1e6:.0f} | {tot/1e6:.0f} |\n")
 
 if os.path.exists(f"{src}/fieldbench29.txt"):
     shutil.copy(f"{src}/fieldbench29.txt", f"{dst}/{tag}_fieldbench29.txt")
