@@ -363,10 +363,10 @@ def other_configs(args):
     proved from Node). A wall-clock budget bounds the lot (--other-configs-budget): a config whose expected cost does not fit what is left is reported
     as skipped, never silently dropped."""
     import subprocess
-    runs = [("configs[4]", ["--curve", "bls12381", "--steps", "8", "--warmup", "1", "--cpu-baseline-mode", "ref", "--no-napi-wall"], 75.0),
-            ("configs[3]", ["--workload", "plonk", "--steps", "8", "--warmup", "1", "--no-napi-wall"], 75.0),
-            ("configs[1] on a circuit-shaped key", ["--coef-dist", "real", "--witness", "mixed", "--steps", "10", "--warmup", "1", "--cpu-baseline-mode", "ref", "--no-napi-wall"], 55.0),
-            ("configs[2] at N=1", ["--log-n", "24", "--steps", "5", "--warmup", "1", "--repeats", "1", "--cpu-baseline-mode", "closed", "--napi-wall-reps", "2"], 200.0)]
+    runs = [("configs[4]", ["--curve", "bls12381", "--steps", "8", "--warmup", "1", "--cpu-baseline-mode", "ref", "--no-napi-wall"], 50.0),
+            ("configs[3]", ["--workload", "plonk", "--steps", "8", "--warmup", "1", "--no-napi-wall"], 55.0),
+            ("configs[1] on a circuit-shaped key", ["--coef-dist", "real", "--witness", "mixed", "--steps", "10", "--warmup", "1", "--cpu-baseline-mode", "ref", "--no-napi-wall"], 30.0),
+            ("configs[2] at N=1", ["--log-n", "24", "--steps", "5", "--warmup", "1", "--repeats", "1", "--cpu-baseline-mode", "closed", "--napi-wall-reps", "2"], 110.0)]
     t_start, res = time.perf_counter(), {}
     for tag, extra, expect_s in runs:
         left = args.other_configs_budget - (time.perf_counter() - t_start)
@@ -794,7 +794,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=3, help="how often the timed region is run (value = the first; min / median / max of all reported)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[4] / [3] / [2] (child runs after the headline line; default run at N = 1 only)")
-    ap.add_argument("--other-configs-budget", type=float, default=420.0, help="wall-clock seconds the other configs may take together")
+    ap.add_argument("--other-configs-budget", type=float, default=330.0, help="wall-clock seconds the other configs may take together")
     ap.add_argument("--no-ref-wasm", action="store_true", help="skip the reference's own WASM prover on this box's host cores (cpu_baseline.reference_wasm.same_box)")
     ap.add_argument("--ref-wasm-budget", type=float, default=200.0, help="seconds the same-box WASM leg may take; a size is skipped when ~5x the previous one does not fit")
     ap.add_argument("--witness", default="uniform", choices=["uniform", "mixed"])

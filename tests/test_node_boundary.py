@@ -33,6 +33,14 @@ def test_addon_exports_and_no_silent_fallback():
 
 
 @need_node
+def test_zkey_opened_by_offset_in_pages_and_shard_gaps():
+    """js/groth16_native.js: openZkey from bytes / a path / fastfile descriptors / a BigBuffer-backed memory file, any page size, a shard's byte ranges with gaps
+    elsewhere — all describe the same bytes as the flat parse (r06: how a 2^24 key reaches the fused Groth16 boundary from Node)"""
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "open_zkey_cpu.js")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@need_node
 @need_bundle
 def test_register_glue_against_reference_bundle():
     r = subprocess.run([NODE] + FLAGS + [os.path.join(ROOT, "tests", "js", "register_glue.js")], capture_output=True, text=True, timeout=900)
