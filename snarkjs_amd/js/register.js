@@ -197,10 +197,75 @@ function unregister(curve) {
 }
 
 // Patch both curves through snarkjs's own getter so that the cached instances are the ones patched.
+// options.fused (r06): ALSO put the fused provers behind snarkjs's own prover entry points (installFused below).
 async function registerAll(snarkjs, options) {
     const out = {};
     for (const name of ["bn128", "bls12381"]) out[name] = register(await snarkjs.curves.getCurveFromName(name), options);
+    if (options && options.fused) out.fused = installFused(snarkjs, options);
     return out;
 }
 
-module.exports = { register, unregister, registerAll, loadAddon };
+// ---- the fused provers behind snarkjs.groth16 / plonk / fflonk (opt-in: registerAll(snarkjs, { fused: true })) ------------------------------------
+// Patching the curve object leaves the reference's own JavaScript around the bulk calls: at 2^20 constraints snarkjs.groth16.prove then takes 2.6 s, 0.08 s of
+// it on the device (buildABC1, src/groth16_prove.js:147-187, is a single-threaded loop of per-element WASM calls). The prover functions themselves are reached
+// through the module object — `snarkjs.groth16` is a frozen namespace, but the PROPERTY snarkjs.groth16 is writable — so a caller of
+// snarkjs.groth16.prove / fullProve, snarkjs.plonk.prove / fullProve, snarkjs.fflonk.prove / fullProve gets the fused device provers (js/groth16_native.js,
+// plonk_native.js, fflonk_native.js) with the reference's signature, inputs (paths, bytes, fastfile descriptors), blinding draws (curve.Fr.random, in the
+// reference's order) and outputs: same proof for the same draws (tests/js/unmodified_gpu.js step 6). Keys stay resident per zkey (path or buffer identity).
+// What is NOT redirected: snarkjs's own CLI (its action table calls the prover functions directly, not through the namespace) and
+// `{ singleThread: true }` calls, which keep their private WASM curve. uninstallFused(snarkjs) restores the namespaces and frees the keys.
+function installFused(snarkjs, options) {
+    if (snarkjs.__zkmiFused) return snarkjs.__zkmiFused;
+    const fs = require("fs");
+    const { makeProver } = require("./groth16_native.js");
+    const plonkN = require("./plonk_native.js"), fflonkN = require("./fflonk_native.js");
+    const orig = { groth16: snarkjs.groth16, plonk: snarkjs.plonk, fflonk: snarkjs.fflonk };
+    const prover = makeProver(snarkjs, options);
+    const keys = new Map();                                  // PLONK / FFLONK keys resident per zkey source
+    const idOf = (src) => (typeof src === "string" ? "file:" + src : (src && src.type === "file" ? "file:" + src.fileName : (src && src.type === "mem" ? src.data : src)));
+    const bytesOf = (src) => {
+        if (typeof src === "string") return new Uint8Array(fs.readFileSync(src));
+        if (src instanceof Uint8Array) return src;
+        if (src && src.type === "file") return new Uint8Array(fs.readFileSync(src.fileName));
+        if (src && src.type === "mem") return (src.data instanceof Uint8Array) ? src.data : src.data.slice(0, src.data.byteLength);
+        throw new Error("expected a path, the file's bytes or a fastfile descriptor");
+    };
+    const residentKey = (Cls, src) => {
+        const id = idOf(src);
+        let k = keys.get(id);
+        if (!k) { k = new Cls(bytesOf(src), options); keys.set(id, k); }
+        return k;
+    };
+    const single = (o) => !!(o && o.singleThread);
+    async function polyProve(mod, Cls, nDraws, zkey, wtns) {
+        const key = residentKey(Cls, zkey);
+        const curve = await snarkjs.curves.getCurveFromName(key.curveName);
+        const draws = [];
+        for (let i = 0; i < nDraws; i++) draws.push(Uint8Array.from(curve.Fr.random()));     // src/plonk_prove.js:222-227 / src/fflonk_prove.js:321-324: all draws first, in order
+        return mod.proveAsync(key, bytesOf(wtns), draws);
+    }
+    const fullOf = (prove) => async function (input, wasmFile, zkey, logger, wtnsCalcOptions, proverOptions) {      // src/groth16_fullprove.js:24-33 and its twins
+        const wtns = { type: "mem" };
+        await snarkjs.wtns.calculate(input, wasmFile, wtns, wtnsCalcOptions);
+        return prove(zkey, wtns, logger, proverOptions);
+    };
+    const g16 = (zkey, wtns, logger, o) => (single(o) ? orig.groth16.prove(zkey, wtns, logger, o) : prover.prove(zkey, wtns));
+    const pl = (zkey, wtns, logger, o) => (single(o) ? orig.plonk.prove(zkey, wtns, logger, o) : polyProve(plonkN, plonkN.PlonkKey, 11, zkey, wtns));
+    const ff = (zkey, wtns, logger, o) => (single(o) ? orig.fflonk.prove(zkey, wtns, logger, o) : polyProve(fflonkN, fflonkN.FflonkKey, 9, zkey, wtns));
+    snarkjs.groth16 = Object.freeze(Object.assign({}, orig.groth16, { prove: g16, fullProve: fullOf(g16) }));
+    snarkjs.plonk = Object.freeze(Object.assign({}, orig.plonk, { prove: pl, fullProve: fullOf(pl) }));
+    snarkjs.fflonk = Object.freeze(Object.assign({}, orig.fflonk, { prove: ff, fullProve: fullOf(ff) }));
+    snarkjs.__zkmiFused = { orig, prover, keys };
+    return snarkjs.__zkmiFused;
+}
+async function uninstallFused(snarkjs) {
+    const st = snarkjs.__zkmiFused;
+    if (!st) return;
+    snarkjs.groth16 = st.orig.groth16; snarkjs.plonk = st.orig.plonk; snarkjs.fflonk = st.orig.fflonk;
+    delete snarkjs.__zkmiFused;
+    for (const k of st.keys.values()) { try { k.release(); } catch (e) { /* already released */ } }
+    st.keys.clear();
+    await st.prover.release();
+}
+
+module.exports = { register, unregister, registerAll, installFused, uninstallFused, loadAddon };

@@ -11,7 +11,7 @@
 const fs = require("fs"), path = require("path"), crypto = require("crypto");
 process.env.NTHREADS = process.env.NTHREADS || "8";             // the WASM workers are idle once the curve is patched
 const snarkjs = require(path.join(__dirname, "..", "oracle", "ref_shim.js"));
-const { register, unregister } = require(path.join(__dirname, "..", "snarkjs_amd", "js", "register.js"));
+const { register, unregister, installFused, uninstallFused } = require(path.join(__dirname, "..", "snarkjs_amd", "js", "register.js"));
 const [zf, wf, drawsHex, repsArg] = process.argv.slice(2);
 const reps = parseInt(repsArg || "3");
 const now = () => Number(process.hrtime.bigint()) / 1e6;
@@ -42,6 +42,19 @@ const med = (a) => { const s = a.slice().sort((x, y) => x - y); return s[s.lengt
     out.inside_device_calls_ms = +med(ins).toFixed(1);
     out.reference_js_ms = +(med(t) - med(ins)).toFixed(1);       // file parsing, buildABC1, the slices and copies between the calls
     out.proof_json_sha256 = crypto.createHash("sha256").update(JSON.stringify(res.proof)).digest("hex");
+    // the same call with the FUSED prover installed behind snarkjs.groth16.prove (registerAll(snarkjs, { fused: true })): files given by PATH as a CLI-style caller would
+    installFused(snarkjs, {});
+    seeded();
+    t0 = now();
+    let fres = await snarkjs.groth16.prove(zf, wf);
+    out.fused_cold_ms = +(now() - t0).toFixed(1);
+    const tf = [];
+    for (let i = 0; i < reps + 2; i++) { seeded(); t0 = now(); fres = await snarkjs.groth16.prove(zf, wf); tf.push(now() - t0); }
+    out.fused_warm_ms = +med(tf).toFixed(1);
+    out.fused_warm_ms_all = tf.map((x) => +x.toFixed(1));
+    out.fused_proof_equals_dropin_proof = crypto.createHash("sha256").update(JSON.stringify(fres.proof)).digest("hex") === out.proof_json_sha256;
+    out.fused_what = "registerAll(snarkjs, { fused: true }): snarkjs.groth16.prove(zkeyPath, wtnsPath) served by js/groth16_native.js (key resident after the first call; the .wtns is read from its path every call)";
+    await uninstallFused(snarkjs);
     curve.Fr.random = real;
     unregister(curve);
     console.log(JSON.stringify(out));
