@@ -97,8 +97,9 @@ def real_coefs(n, m, n_public, seed):
     return np.concatenate(out_m), np.concatenate(out_c), np.concatenate(out_s), in_b
 
 
-def make(name, lg, seed=1, n_public=2, witness="mixed", tables=None, coef_per_row=1, b_zero_every=3, coef_dist="flat"):
-    """-> (zkey_bytes, wtns_bytes). domain n = 2^lg, nVars m = n - 5 (min 4).
+def make(name, lg, seed=1, n_public=2, witness="mixed", tables=None, coef_per_row=1, b_zero_every=3, coef_dist="flat", n_vars=None):
+    """-> (zkey_bytes, wtns_bytes). domain n = 2^lg, nVars m = n - 5 (min 4) unless n_vars is given (real circuits have anything from nVars << domainSize to
+    nVars > domainSize: the witness-side and the H-side tables then differ in size and window width).
     b_zero_every = k: every k-th B1/B2 base (i % k == 1) is the point at infinity, as for signals absent from the B matrix of a real
     circuit (B density 1 - 1/k); 0 = dense B sections (SURVEY.md 8d recipe: every section filled from the geometric table).
     coef_dist = "flat": one coefficient per (matrix, constraint) row (n_coef = 2.0 n, the bottom of SURVEY a8's range);
@@ -106,7 +107,7 @@ def make(name, lg, seed=1, n_public=2, witness="mixed", tables=None, coef_per_ro
     (b_zero_every is ignored: the B1 / B2 bases of the signals absent from the B matrix are the point at infinity)."""
     q8, q, r = PRIMES[name]
     n = 1 << lg
-    m = max(n - 5, n_public + 2)
+    m = max(n - 5, n_public + 2) if n_vars is None else max(int(n_vars), n_public + 2)
     mc = m - n_public - 1
     T1, T2 = _tables(name, max(m + 1, n + 3, 8), max(m, 4), tables)
     g1, g2 = 2 * q8, 4 * q8

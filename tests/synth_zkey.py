@@ -9,6 +9,6 @@ def _oracle_tables(cid, group, n):
     return O.geom_bases(cid, group, n)
 
 
-def make(name, lg, seed=1, n_public=2, witness="mixed", use_device=True, coef_per_row=1, b_zero_every=3, coef_dist="flat"):
+def make(name, lg, seed=1, n_public=2, witness="mixed", use_device=True, coef_per_row=1, b_zero_every=3, coef_dist="flat", n_vars=None):
     return _z.make(name, lg, seed=seed, n_public=n_public, witness=witness, tables=None if use_device else _oracle_tables,
-                   coef_per_row=coef_per_row, b_zero_every=b_zero_every, coef_dist=coef_dist)
+                   coef_per_row=coef_per_row, b_zero_every=b_zero_every, coef_dist=coef_dist, n_vars=n_vars)

@@ -159,3 +159,47 @@ def test_paged_shards_with_gaps(zk):
     assert L.zkmi_groth16_load_paged(C.byref(d), 0x7001) != 0 and b"gap" in L.zkmi_last_error()
     for pk in keys:
         pk.release()
+
+
+@pytest.mark.parametrize("name,lg,n_vars,dist", [("bn128", 12, 300, "flat"), ("bn128", 12, 7000, "real"), ("bn128", 14, 40000, "flat"), ("bls12381", 12, 1500, "real"),
+                                                 ("bn128", 17, 60000, "flat"), ("bn128", 16, 200000, "real")])
+def test_key_shapes_nvars_far_from_domain(zk, name, lg, n_vars, dist):
+    """Real circuits have anything from nVars << domainSize to nVars > domainSize (the bench keys have nVars = domainSize - 5): the witness-side tables and the H table then
+    differ in size, window width and bucket shape (no C / H bucket sharing, separate reductions). Whole proofs against the oracle; at the larger sizes the shard split too."""
+    import synth_zkey
+    from snarkjs_amd import groth16, binfile
+    from snarkjs_amd import distributed as D
+    c = O.CURVE_ID[name]
+    zkey, wtns = synth_zkey.make(name, lg, seed=0x51 + lg, n_vars=n_vars, coef_dist=dist, b_zero_every=0 if dist == "flat" else 3)
+    zkd, w = binfile.read_groth16_zkey(zkey), binfile.read_wtns(wtns)["witness"]
+    assert zkd["nVars"] == n_vars and zkd["domainSize"] == 1 << lg
+    r_m, s_m = O.fr_e(c, 0x77), O.fr_e(c, 0x99)
+    want = O.groth16_prove(c, zkd, w, r_m, s_m)
+    pk = groth16.ProvingKey(zkey)
+    got = pk.prove_raw(w, r_m, s_m)
+    pk.submit(zkmi_dev(w), 1)
+    two = pk.collect(1, r_m, s_m)
+    pk.release()
+    for a, b, t in zip(got, want, two):
+        assert np.array_equal(a, b) and np.array_equal(t, b)
+    if lg >= 16:
+        keys = []
+
+        def make(rank):
+            keys.append(groth16.ProvingKey(zkey, shard=(rank, 3), page_bytes=1 << 20, gaps=True))
+            return D.DeviceShard(keys[-1], w)
+        sh = D.groth16_prove_sharded_local(make, 3, r_m, s_m)
+        for k in keys:
+            k.release()
+        assert all(np.array_equal(a, b) for a, b in zip(sh, want))
+
+
+_held = []
+
+
+def zkmi_dev(w):
+    """the witness in device memory, kept alive for the rest of the module (a submitted proof reads it until it is collected)"""
+    from snarkjs_amd import zkmi
+    b = zkmi.DeviceBuffer.from_host(zkmi.u8(w))
+    _held.append(b)
+    return b.ptr
