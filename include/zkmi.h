@@ -113,6 +113,13 @@ int zkmi_msm_table_dev(uint64_t handle, const void* d_scalars, size_t k, size_t 
  * latency-bound bucket reductions share one set of launches. out_jacobians: count x 3*group*n8q bytes. */
 int zkmi_msm_table_multi_dev(uint64_t handle, const void* const* d_scalars, const size_t* ks, int count, size_t scalar_bytes,
                              uint8_t* out_jacobians);
+/* The same call in two halves (r06), for a host that drives two proofs from one thread (zkmi_pipeline_select): _enqueue_dev puts the digit sorts, accumulations and bucket
+ * reductions of the MSMs on the ACTIVE pipeline slot's streams and returns at once; _collect (same slot, same table, same count) waits for them, folds the window sums and writes
+ * count x 3*group*n8q bytes. Between the two the host can enqueue the other proof's work — its accumulations then run underneath this call's latency-bound reduction tail.
+ * d_scalars must stay valid until the collect; one enqueued call per pipeline slot (an enqueued call that is never collected — its proof was abandoned — is waited for and
+ * dropped by the slot's next enqueue). */
+int zkmi_msm_table_multi_enqueue_dev(uint64_t handle, const void* const* d_scalars, const size_t* ks, int count, size_t scalar_bytes);
+int zkmi_msm_table_multi_collect(uint64_t handle, int count, uint8_t* out_jacobians);
 int zkmi_msm_table_release(uint64_t handle);
 /* Curve, group and number of resident points of a table (any pointer may be NULL): a binding sizes the result buffers of the two calls above
  * — 3*group*n8q bytes per MSM — from the TABLE instead of trusting its caller. */

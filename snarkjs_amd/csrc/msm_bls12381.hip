@@ -54,6 +54,14 @@ int msm_table_multi_bls12381(int group, const void* d_table, size_t stride, int 
     if (group == 1) return msm_run_table_multi<Fp<Bls12381Fq>>(d_table, stride, c, d_scalars, ks, count, sb, outs);
     return msm_run_table_multi<Fp2<Bls12381Fq>>(d_table, stride, c, d_scalars, ks, count, sb, outs);
 }
+int msm_table_multi_enqueue_bls12381(int group, const void* d_table, size_t stride, int c, const void* const* d_scalars, const size_t* ks, int count, size_t sb) {
+    if (group == 1) return msm_run_table_multi_enqueue<Fp<Bls12381Fq>>(d_table, stride, c, d_scalars, ks, count, sb);
+    return msm_run_table_multi_enqueue<Fp2<Bls12381Fq>>(d_table, stride, c, d_scalars, ks, count, sb);
+}
+int msm_table_multi_collect_bls12381(int group, int count, uint8_t* outs) {
+    if (group == 1) return msm_run_table_multi_collect<Fp<Bls12381Fq>>(count, outs);
+    return msm_run_table_multi_collect<Fp2<Bls12381Fq>>(count, outs);
+}
 int msm_reduce_bls12381(int group, MsmJob* const* jobs, int njobs, bool aux) {
     if (group == 1) return msm_reduce<Fp<Bls12381Fq>>(jobs, njobs, aux);
     return msm_reduce<Fp2<Bls12381Fq>>(jobs, njobs, aux);

@@ -53,6 +53,14 @@ int msm_table_multi_bn254(int group, const void* d_table, size_t stride, int c, 
     if (group == 1) return msm_run_table_multi<Fp<Bn254Fq>>(d_table, stride, c, d_scalars, ks, count, sb, outs);
     return msm_run_table_multi<Fp2<Bn254Fq>>(d_table, stride, c, d_scalars, ks, count, sb, outs);
 }
+int msm_table_multi_enqueue_bn254(int group, const void* d_table, size_t stride, int c, const void* const* d_scalars, const size_t* ks, int count, size_t sb) {
+    if (group == 1) return msm_run_table_multi_enqueue<Fp<Bn254Fq>>(d_table, stride, c, d_scalars, ks, count, sb);
+    return msm_run_table_multi_enqueue<Fp2<Bn254Fq>>(d_table, stride, c, d_scalars, ks, count, sb);
+}
+int msm_table_multi_collect_bn254(int group, int count, uint8_t* outs) {
+    if (group == 1) return msm_run_table_multi_collect<Fp<Bn254Fq>>(count, outs);
+    return msm_run_table_multi_collect<Fp2<Bn254Fq>>(count, outs);
+}
 int msm_reduce_bn254(int group, MsmJob* const* jobs, int njobs, bool aux) {
     if (group == 1) return msm_reduce<Fp<Bn254Fq>>(jobs, njobs, aux);
     return msm_reduce<Fp2<Bn254Fq>>(jobs, njobs, aux);

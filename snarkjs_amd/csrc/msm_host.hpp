@@ -522,13 +522,29 @@ template <class F> int msm_run_table(const void* d_table, size_t stride, int c, 
     return ZKMI_OK;
 }
 
-template <class F> int msm_run_table_multi(const void* d_table, size_t stride, int c, const void* const* d_scalars, const size_t* ks, int count, size_t sb, uint8_t* out_jacs) {
+// The MSMs of one zkmi_msm_table_multi call that have been enqueued and not yet collected, per pipeline slot (r06: enqueue / collect split, so that a
+// host that drives two proofs from one thread — plonk.py prove_many, js proveMany — can put the accumulations of proof B on the device underneath the
+// latency-bound bucket reduction of proof A instead of waiting inside A's call)
+struct MsmMultiPending {
+    bool live = false;
+    int count = 0, fw = 0;
+    size_t ks[MSM_MAX_BATCH] = {};
+    MsmJob job[MSM_MAX_BATCH];
+};
+MsmMultiPending& msm_multi_pending(int pipe);              // msm_sort.hip
+
+template <class F> int msm_run_table_multi_enqueue(const void* d_table, size_t stride, int c, const void* const* d_scalars, const size_t* ks, int count, size_t sb) {
     constexpr int FW = FieldWords<F>::value;
     Ctx& cx = ctx();
     if (count < 1 || count > MSM_MAX_BATCH) return fail(ZKMI_ERR_INVALID, "msm_table_multi: 1..4 MSMs per call");
+    MsmMultiPending& P = msm_multi_pending(cx.pipe);
     hipStream_t st = cx.stream;
+    if (P.live) {                                                      // a call that was enqueued and never collected (its proof was abandoned after an error): drop it
+        ZK_HIP(hipStreamSynchronize(st));
+        P.live = false;
+    }
     MsmPlan pl[MSM_MAX_BATCH];
-    MsmJob job[MSM_MAX_BATCH];
+    MsmJob* job = P.job;
     MsmJob* jp[MSM_MAX_BATCH];
     int live = 0;
     ZK_HIP(hipEventRecord(cx.ev0, st));
@@ -555,6 +571,7 @@ template <class F> int msm_run_table_multi(const void* d_table, size_t stride, i
         ZK_TRY(rc);
     }
     for (int i = 0; i < count; i++) {
+        job[i] = MsmJob();
         if (ks[i] == 0) continue;
         ZK_TRY(msm_job_slot(i, job[i]));
         if (ov) ZK_HIP(hipStreamWaitEvent(st, cx.sort_ev[1 + i], 0));
@@ -564,14 +581,30 @@ template <class F> int msm_run_table_multi(const void* d_table, size_t stride, i
     }
     if (live) ZK_TRY(msm_reduce<F>(jp, live));
     ZK_HIP(hipEventRecord(cx.ev1, st));
-    ZK_HIP(hipStreamSynchronize(st));
+    P.live = true; P.count = count; P.fw = FW;
+    for (int i = 0; i < count; i++) P.ks[i] = ks[i];
+    return ZKMI_OK;
+}
+template <class F> int msm_run_table_multi_collect(int count, uint8_t* out_jacs) {
+    constexpr int FW = FieldWords<F>::value;
+    Ctx& cx = ctx();
+    MsmMultiPending& P = msm_multi_pending(cx.pipe);
+    if (!P.live) return fail(ZKMI_ERR_INVALID, "msm_table_multi: nothing enqueued in this pipeline slot");
+    if (P.fw != FW || P.count != count) { return fail(ZKMI_ERR_INVALID, "msm_table_multi: collect does not match what was enqueued (table or count)"); }
+    P.live = false;
+    ZK_HIP(hipStreamSynchronize(cx.stream));
     float ms = 0;
     if (hipEventElapsedTime(&ms, cx.ev0, cx.ev1) == hipSuccess) cx.last_ms = ms;
-    for (int i = 0; i < count; i++) {
-        if (ks[i] == 0) memset(out_jacs + (size_t)i * 12 * FW, 0, 12 * FW);
-        else msm_fold<F>(job[i], out_jacs + (size_t)i * 12 * FW);
+    for (int i = 0; i < P.count; i++) {
+        if (P.ks[i] == 0) memset(out_jacs + (size_t)i * 12 * FW, 0, 12 * FW);
+        else msm_fold<F>(P.job[i], out_jacs + (size_t)i * 12 * FW);
     }
     return ZKMI_OK;
+}
+template <class F> int msm_run_table_multi(const void* d_table, size_t stride, int c, const void* const* d_scalars, const size_t* ks, int count, size_t sb, uint8_t* out_jacs) {
+    int rc = msm_run_table_multi_enqueue<F>(d_table, stride, c, d_scalars, ks, count, sb);
+    if (rc) { msm_multi_pending(ctx().pipe).live = false; return rc; }
+    return msm_run_table_multi_collect<F>(count, out_jacs);
 }
 
 template <class F, class FrC> int gen_bases_run(const uint8_t* gen_affine_host, size_t n, uint64_t f, uint64_t g, void* d_out) {

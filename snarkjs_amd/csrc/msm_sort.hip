@@ -158,6 +158,10 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     return ZKMI_OK;
 }
 
+MsmMultiPending& msm_multi_pending(int pipe) {
+    static MsmMultiPending pend[2];
+    return pend[pipe & 1];
+}
 int msm_job_slot(int slot, MsmJob& job) {
     Ctx& cx = ctx();
     if (slot < 0 || slot >= MSM_JOB_SLOTS) return fail(ZKMI_ERR_INVALID, "msm: bad job slot");

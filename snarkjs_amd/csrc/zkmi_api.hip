@@ -144,6 +144,10 @@ int msm_table_bn254(int group, const void*, size_t, int, const void*, size_t, si
 int msm_table_bls12381(int group, const void*, size_t, int, const void*, size_t, size_t, uint8_t*);
 int msm_table_multi_bn254(int group, const void*, size_t, int, const void* const*, const size_t*, int, size_t, uint8_t*);
 int msm_table_multi_bls12381(int group, const void*, size_t, int, const void* const*, const size_t*, int, size_t, uint8_t*);
+int msm_table_multi_enqueue_bn254(int group, const void*, size_t, int, const void* const*, const size_t*, int, size_t);
+int msm_table_multi_enqueue_bls12381(int group, const void*, size_t, int, const void* const*, const size_t*, int, size_t);
+int msm_table_multi_collect_bn254(int group, int, uint8_t*);
+int msm_table_multi_collect_bls12381(int group, int, uint8_t*);
 int msm_reduce_bls12381(int group, MsmJob* const*, int, bool);
 int msm_fold_bn254(int group, const MsmJob&, uint8_t*);
 int msm_fold_bls12381(int group, const MsmJob&, uint8_t*);
@@ -478,6 +482,25 @@ int zkmi_msm_table_multi_dev(uint64_t handle, const void* const* d_scalars, cons
     for (int i = 0; i < count; i++) if (ks[i] > t.n) return fail(ZKMI_ERR_INVALID, "msm_table_multi_dev: more scalars than resident bases");
     return t.curve == ZKMI_CURVE_BN128 ? msm_table_multi_bn254(t.group, t.p, t.n, t.c, d_scalars, ks, count, scalar_bytes, out_jacobians)
                                        : msm_table_multi_bls12381(t.group, t.p, t.n, t.c, d_scalars, ks, count, scalar_bytes, out_jacobians);
+}
+int zkmi_msm_table_multi_enqueue_dev(uint64_t handle, const void* const* d_scalars, const size_t* ks, int count, size_t scalar_bytes) {
+    ZK_TRY(require_ctx());
+    auto it = g_tables.find(handle);
+    if (it == g_tables.end()) return fail(ZKMI_ERR_INVALID, "msm_table_multi_enqueue_dev: unknown table");
+    const MsmTable& t = it->second;
+    if (!d_scalars || !ks) return fail(ZKMI_ERR_INVALID, "null argument");
+    if (scalar_bytes == 0 || scalar_bytes > 32) return fail(ZKMI_ERR_UNSUPPORTED, "msm_table_multi_enqueue_dev: tables are built for scalars of at most 32 bytes");
+    for (int i = 0; i < count; i++) if (ks[i] > t.n) return fail(ZKMI_ERR_INVALID, "msm_table_multi_enqueue_dev: more scalars than resident bases");
+    return t.curve == ZKMI_CURVE_BN128 ? msm_table_multi_enqueue_bn254(t.group, t.p, t.n, t.c, d_scalars, ks, count, scalar_bytes)
+                                       : msm_table_multi_enqueue_bls12381(t.group, t.p, t.n, t.c, d_scalars, ks, count, scalar_bytes);
+}
+int zkmi_msm_table_multi_collect(uint64_t handle, int count, uint8_t* out_jacobians) {
+    ZK_TRY(require_ctx());
+    auto it = g_tables.find(handle);
+    if (it == g_tables.end()) return fail(ZKMI_ERR_INVALID, "msm_table_multi_collect: unknown table");
+    if (!out_jacobians) return fail(ZKMI_ERR_INVALID, "null argument");
+    const MsmTable& t = it->second;
+    return t.curve == ZKMI_CURVE_BN128 ? msm_table_multi_collect_bn254(t.group, count, out_jacobians) : msm_table_multi_collect_bls12381(t.group, count, out_jacobians);
 }
 int zkmi_msm_table_info(uint64_t handle, int* curve, int* group, size_t* n) {
     auto it = g_tables.find(handle);

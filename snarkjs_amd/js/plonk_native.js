@@ -163,6 +163,14 @@ function commit(key, polys) {
     const scs = commitScalars(key, polys);
     return commitPoints(key, polys, scs, addon.msmTableMultiDev(key.ptauTable, scs, polys.map((p) => p.n), 32));
 }
+// the same in two halves for proveMany (r06): enqueue on the proof's own pipeline slot, collect at its next turn — the other proof's next segment, its commitments
+// included, is enqueued in between and runs underneath this round's latency-bound reduction tail
+function commitEnqueue(key, polys) {
+    const scs = commitScalars(key, polys);
+    addon.msmTableMultiEnqueueDev(key.ptauTable, scs, polys.map((p) => p.n), 32);
+    return { polys, scs };
+}
+const commitCollect = (key, st) => commitPoints(key, st.polys, st.scs, addon.msmTableMultiCollect(key.ptauTable, st.polys.length));
 async function commitAsync(key, polys, slot) {
     const scs = commitScalars(key, polys);
     return commitPoints(key, polys, scs, await addon.msmTableMultiDevAsync(key.ptauTable, scs, polys.map((p) => p.n), 32, slot));
@@ -233,18 +241,20 @@ function proveMany(zkey, wtnsList, blindingMonts = null, options = null) {
                 const polys = [], w = wtnsList[nxt];
                 const P = (n, zero = true) => { const p = new Poly(key.f, n, zero); polys.push(p); return p; };
                 const track = (p) => { polys.push(p); return p; };
-                live.push({ slot: free.shift(), idx: nxt, polys, req: undefined, steps: proveSteps(key, (w instanceof Uint8Array || w instanceof PlonkWitness) ? w : new Uint8Array(w), blindingMonts ? blindingMonts[nxt] : null, P, track) });
+                live.push({ slot: free.shift(), idx: nxt, polys, pending: null, steps: proveSteps(key, (w instanceof Uint8Array || w instanceof PlonkWitness) ? w : new Uint8Array(w), blindingMonts ? blindingMonts[nxt] : null, P, track) });
                 nxt++;
             }
             for (const ent of live.slice()) {
                 call("zkmi_pipeline_select", ent.slot);
-                const s = ent.steps.next(serve(key, ent.req));       // the blocking call this proof stopped in front of, then on to its next one
-                if (s.done) { out[ent.idx] = s.value; finish(ent); } else ent.req = s.value;
+                // the blocking call this proof stopped in front of (a round's commitments were ENQUEUED when it stopped: collected here), then on to its next one
+                const s = ent.steps.next(ent.pending ? commitCollect(key, ent.pending) : undefined);
+                ent.pending = null;
+                if (s.done) { out[ent.idx] = s.value; finish(ent); } else if (s.value && s.value.commit) ent.pending = commitEnqueue(key, s.value.commit);
             }
         }
     } finally {
         for (const ent of live.slice()) {                  // an error in one proof: drop the other one too, leave no queued work behind
-            try { call("zkmi_pipeline_select", ent.slot); ent.steps.return(); call("zkmi_synchronize"); ent.polys.forEach((p) => p.free()); } catch (e) { /* already failing */ }
+            try { call("zkmi_pipeline_select", ent.slot); ent.steps.return(); call("zkmi_synchronize"); if (ent.pending) ent.pending.scs.forEach(devFree); ent.polys.forEach((p) => p.free()); } catch (e) { /* already failing */ }
         }
         call("zkmi_pipeline_select", 0);
         if (!(zkey instanceof PlonkKey)) key.release();

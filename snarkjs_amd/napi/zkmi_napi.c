@@ -685,6 +685,38 @@ static napi_value js_msm_table_multi_dev(napi_env env, napi_callback_info info) 
     if (rc) return throw_zkmi(env, rc);
     return res;
 }
+/* msmTableMultiEnqueueDev(handle, [dScalars...], [k...], scalarBytes): the MSMs of a round are put on the active pipeline slot's streams, nothing waits;
+ * msmTableMultiCollect(handle, count) -> Uint8Array(count * 3*group*n8q) waits for them (zkmi_msm_table_multi_enqueue_dev / _collect) */
+static napi_value js_msm_table_multi_enqueue_dev(napi_env env, napi_callback_info info) {
+    ARGS(4);
+    double h; int32_t sb; uint32_t cnt = 0, cnt2 = 0;
+    bool a0 = false, a1 = false;
+    if (get_f64(env, argv[0], &h) || napi_is_array(env, argv[1], &a0) != napi_ok || !a0 || napi_is_array(env, argv[2], &a1) != napi_ok || !a1 ||
+        napi_get_array_length(env, argv[1], &cnt) != napi_ok || napi_get_array_length(env, argv[2], &cnt2) != napi_ok || cnt != cnt2 || cnt < 1 || cnt > 4 ||
+        get_i32(env, argv[3], &sb)) BAD_ARG();
+    const void* ptrs[4]; size_t ks[4];
+    for (uint32_t i = 0; i < cnt; i++) {
+        napi_value e; void* p; double k;
+        if (napi_get_element(env, argv[1], i, &e) != napi_ok || get_dptr(env, e, &p) || napi_get_element(env, argv[2], i, &e) != napi_ok || get_f64(env, e, &k) || k < 0) BAD_ARG();
+        ptrs[i] = p; ks[i] = (size_t)k;
+    }
+    int rc = ZK_CALL(zkmi_msm_table_multi_enqueue_dev((uint64_t)h, ptrs, ks, (int)cnt, (size_t)sb));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
+static napi_value js_msm_table_multi_collect(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    double h; int32_t cnt; int curve, group;
+    if (get_f64(env, argv[0], &h) || get_i32(env, argv[1], &cnt) || cnt < 1 || cnt > 4) BAD_ARG();
+    int rc = ZK_CALL(zkmi_msm_table_info((uint64_t)h, &curve, &group, NULL));
+    if (rc) return throw_zkmi(env, rc);
+    uint8_t* out;
+    napi_value res = new_u8(env, (size_t)cnt * 3 * group * (curve == ZKMI_CURVE_BN128 ? 32 : 48), &out);
+    if (!res) BAD_ARG();
+    rc = ZK_CALL(zkmi_msm_table_multi_collect((uint64_t)h, cnt, out));
+    if (rc) return throw_zkmi(env, rc);
+    return res;
+}
 /* msmTableMultiDevAsync(handle, [dScalars...], [k...], scalarBytes, slot) -> Promise<Uint8Array>; synchronizeAsync(slot) -> Promise<undefined>: the two calls on
  * which a host-orchestrated prover waits, on a libuv pool thread (the event loop keeps turning), each in pipeline slot `slot` */
 static napi_value js_msm_table_multi_dev_async(napi_env env, napi_callback_info info) {
@@ -933,7 +965,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"devAlloc", js_dev_alloc}, {"devFree", js_dev_free}, {"memcpyH2D", js_memcpy_h2d}, {"memcpyD2H", js_memcpy_d2h},
         {"groth16ChainsDev", js_groth16_chains_dev}, {"groth16SumsWDev", js_groth16_sums_w_dev}, {"groth16SumsHDev", js_groth16_sums_h_dev}, {"groth16SumsDev", js_groth16_sums_dev},
         {"groth16Finish", js_groth16_finish}, {"joinABCDev", js_join_abc_dev}, {"pointAdd", js_point_add}, {"shmMap", js_shm_map}, {"shmUnlink", js_shm_unlink},
-        {"msmTableDev", js_msm_table_dev}, {"msmTableMultiDev", js_msm_table_multi_dev}, {"msmTableMultiDevAsync", js_msm_table_multi_dev_async}, {"synchronizeAsync", js_synchronize_async}, {"ipcExport", js_ipc_export}, {"ipcOpen", js_ipc_open}, {"ipcClose", js_ipc_close},
+        {"msmTableDev", js_msm_table_dev}, {"msmTableMultiDev", js_msm_table_multi_dev}, {"msmTableMultiDevAsync", js_msm_table_multi_dev_async}, {"msmTableMultiEnqueueDev", js_msm_table_multi_enqueue_dev}, {"msmTableMultiCollect", js_msm_table_multi_collect}, {"synchronizeAsync", js_synchronize_async}, {"ipcExport", js_ipc_export}, {"ipcOpen", js_ipc_open}, {"ipcClose", js_ipc_close},
         {"peerCopy", js_peer_copy}, {"peerCopyAsync", js_peer_copy_async}, {"peerFence", js_peer_fence}, {"groth16Reset", js_groth16_reset}, {"groth16KeyCurve", js_groth16_key_curve},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

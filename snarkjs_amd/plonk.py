@@ -232,25 +232,41 @@ class _Transcript:
         return int.from_bytes(keccak256(b"".join(self.parts)), "big") % self.f.r
 
 
-def _commit(key, *polys):
-    """Polynomial.multiExponentiation (polynomial.js:970-977) for the commitments of one round: batchFromMontgomery,
-    G1.multiExpAffine over PTau[0:len] (resident table; the bucket reductions of the round share one set of launches), toAffine."""
+def _commit_enqueue(key, *polys):
+    """Polynomial.multiExponentiation (polynomial.js:970-977) for the commitments of one round, first half: batchFromMontgomery and the MSMs over PTau[0:len] (resident table;
+    the bucket reductions of the round share one set of launches) are ENQUEUED on the active pipeline slot (zkmi_msm_table_multi_enqueue_dev); nothing waits. r06: with two
+    proofs in flight the other proof's next segment — its own commitments included — is enqueued before this one is collected, so its accumulations run underneath this round's
+    latency-bound reduction tail instead of behind a host that sits inside a blocking call."""
     f, L, cnt = key.f, zkmi.lib(), len(polys)
     scs = [zkmi.DeviceBuffer(p.n * 32) for p in polys]
     for p, sc in zip(polys, scs):
         zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_FROM_MONTGOMERY, p.ptr, sc.ptr, p.n))
-    jac = np.zeros(cnt * 3 * f.n8q, np.uint8)
     ptrs = (C.c_void_p * cnt)(*[sc.ptr for sc in scs])
     ks = (C.c_size_t * cnt)(*[p.n for p in polys])
-    zkmi.check(L.zkmi_msm_table_multi_dev(key.ptau_table, ptrs, ks, cnt, 32, zkmi.ptr(jac)))
+    zkmi.check(L.zkmi_msm_table_multi_enqueue_dev(key.ptau_table, ptrs, ks, cnt, 32))
+    return key, scs, cnt
+
+
+def _commit_collect(state):
+    """second half: wait for the round's MSMs, fold, toAffine -> [(x, y)] as integers"""
+    key, scs, cnt = state
+    f, L = key.f, zkmi.lib()
+    jac = np.zeros(cnt * 3 * f.n8q, np.uint8)
+    try:
+        zkmi.check(L.zkmi_msm_table_multi_collect(key.ptau_table, cnt, zkmi.ptr(jac)))
+    finally:
+        for sc in scs:
+            sc.free()
     out = []
     for i in range(cnt):
         aff = np.zeros(2 * f.n8q, np.uint8)
         zkmi.check(L.zkmi_to_affine(f.cid, 1, zkmi.ptr(jac[i * 3 * f.n8q:(i + 1) * 3 * f.n8q].copy()), zkmi.ptr(aff)))
         out.append((f.unmont_q(aff[:f.n8q]), f.unmont_q(aff[f.n8q:])))
-    for sc in scs:
-        sc.free()
     return out
+
+
+def _commit(key, *polys):
+    return _commit_collect(_commit_enqueue(key, *polys))
 
 
 def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
@@ -344,8 +360,9 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     pA, pB, pC = A.ntt(True), B.ntt(True), Cw.ntt(True)
     eA, eB, eC = pA.extended_evals(4), pB.extended_evals(4), pC.extended_evals(4)
     pA, pB, pC = pA.blinded([b[2], b[1]]), pB.blinded([b[4], b[3]]), pC.blinded([b[6], b[5]])
+    cm = _commit_enqueue(key, pA, pB, pC)
     yield
-    pts["A"], pts["B"], pts["C"] = _commit(key, pA, pB, pC)
+    pts["A"], pts["B"], pts["C"] = _commit_collect(cm)
 
     # ---- ROUND 2 (:315-455)
     tr.reset()
@@ -364,8 +381,9 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     pZ = Zb.ntt(True)
     eZ = pZ.extended_evals(4)
     pZ = pZ.blinded([b[9], b[8], b[7]])
+    cm = _commit_enqueue(key, pZ)
     yield
-    pts["Z"], = _commit(key, pZ)
+    pts["Z"], = _commit_collect(cm)
     if Zb.get(0) != 1:                                                                   # computeZ's check (:437-439), read behind the commitment's
         raise ValueError("Copy constraints does not match")                              # own wait: no extra bubble between the transforms and the MSM
 
@@ -391,8 +409,9 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     T1.set(n, b[10])
     T2.set(0, (T2.get(0) - b[10]) % r); T2.set(n, b[11])
     T3.set(0, (T3.get(0) - b[11]) % r)
+    cm = _commit_enqueue(key, T1, T2, T3)
     yield
-    pts["T1"], pts["T2"], pts["T3"] = _commit(key, T1, T2, T3)
+    pts["T1"], pts["T2"], pts["T3"] = _commit_collect(cm)
 
     # ---- ROUND 4 (:686-708)
     tr.reset(); tr.scalar(alpha)
@@ -455,8 +474,9 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     Wxiw = _Poly(f, pZ.n, False).copy_from(pZ.ptr, pZ.n)
     Wxiw.add_scalar(-ezw % r)
     zkmi.check(L.zkmi_poly_div_by_zerofier_dev(f.cid, Wxiw.ptr, Wxiw.n, 1, zkmi.ptr(mont(xiw))))
+    cm = _commit_enqueue(key, Wxi, Wxiw)
     yield
-    pts["Wxi"], pts["Wxiw"] = _commit(key, Wxi, Wxiw)
+    pts["Wxi"], pts["Wxiw"] = _commit_collect(cm)
 
     proof = {}
     for nm in ("A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"):                       # src/proof.js:61-83 (insertion order)

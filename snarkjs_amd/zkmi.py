@@ -23,7 +23,7 @@ SYMBOLS = [
     "zkmi_groth16_load_paged", "zkmi_groth16_load_shard_paged", "zkmi_groth16_prove_paged", "zkmi_groth16_build_abc_dev", "zkmi_groth16_coef_layout", "zkmi_msm_dev_fallbacks",
     "zkmi_init", "zkmi_device_count", "zkmi_last_error", "zkmi_version", "zkmi_set_stream", "zkmi_synchronize",
     "zkmi_dev_alloc", "zkmi_dev_free", "zkmi_memcpy_h2d", "zkmi_memcpy_d2h", "zkmi_memcpy_d2d", "zkmi_memset_dev",
-    "zkmi_msm", "zkmi_release_bases", "zkmi_msm_dev", "zkmi_msm_set_window_bits", "zkmi_msm_accum_ms", "zkmi_msm_stats", "zkmi_msm_accum_additions", "zkmi_msm_table_build", "zkmi_msm_table_dev", "zkmi_msm_table_multi_dev", "zkmi_msm_table_release", "zkmi_msm_table_info",
+    "zkmi_msm", "zkmi_release_bases", "zkmi_msm_dev", "zkmi_msm_set_window_bits", "zkmi_msm_accum_ms", "zkmi_msm_stats", "zkmi_msm_accum_additions", "zkmi_msm_table_build", "zkmi_msm_table_dev", "zkmi_msm_table_multi_dev", "zkmi_msm_table_multi_enqueue_dev", "zkmi_msm_table_multi_collect", "zkmi_msm_table_release", "zkmi_msm_table_info",
     "zkmi_ipc_export", "zkmi_ipc_open", "zkmi_ipc_close", "zkmi_peer_copy", "zkmi_peer_copy_async", "zkmi_peer_fence", "zkmi_groth16_key_curve", "zkmi_groth16_reset",
     "zkmi_ntt", "zkmi_ntt_dev",
     "zkmi_fr_batch_apply_key", "zkmi_fr_batch_apply_key_dev", "zkmi_fr_batch", "zkmi_fr_batch_dev",
@@ -130,6 +130,8 @@ def lib():
     L.zkmi_msm_table_build.argtypes = [C.c_int, C.c_int, vp, sz, C.POINTER(C.c_uint64)]
     L.zkmi_msm_table_dev.argtypes = [C.c_uint64, vp, sz, sz, u8p]
     L.zkmi_msm_table_multi_dev.argtypes = [C.c_uint64, C.POINTER(vp), C.POINTER(sz), C.c_int, sz, u8p]
+    L.zkmi_msm_table_multi_enqueue_dev.argtypes = [C.c_uint64, C.POINTER(vp), C.POINTER(sz), C.c_int, sz]
+    L.zkmi_msm_table_multi_collect.argtypes = [C.c_uint64, C.c_int, u8p]
     L.zkmi_msm_table_release.argtypes = [C.c_uint64]
     L.zkmi_msm_table_info.argtypes = [C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(sz)]
     L.zkmi_ipc_export.argtypes = [vp, u8p]

@@ -203,3 +203,51 @@ def zkmi_dev(w):
     b = zkmi.DeviceBuffer.from_host(zkmi.u8(w))
     _held.append(b)
     return b.ptr
+
+
+def test_table_msm_enqueue_collect_halves(zk):
+    """zkmi_msm_table_multi_enqueue_dev + _collect (r06: the two halves of zkmi_msm_table_multi_dev, for a host that drives two proofs from one thread) == the one-call form;
+    on both pipeline slots at once; a collect without an enqueue and a mismatched count fail; an enqueued call that is never collected is dropped by the next enqueue."""
+    import ctypes as C
+    import synth
+    from snarkjs_amd import zkmi
+    L = zkmi.lib()
+    n, q8 = 1 << 14, 32
+    d_b = zkmi.DeviceBuffer(n * 64)
+    zkmi.check(L.zkmi_gen_geometric_bases_dev(0, 1, n, 7, 11, d_b.ptr))
+    h = C.c_uint64(0)
+    zkmi.check(L.zkmi_msm_table_build(0, 1, d_b.ptr, n, C.byref(h)))
+    sc = [zkmi.DeviceBuffer.from_host(synth.elems(0x900 + i, n)) for i in range(4)]
+    ks = [n, n - 5, 0, 77]
+
+    def arrays(idx):
+        return (C.c_void_p * len(idx))(*[sc[i].ptr for i in idx]), (C.c_size_t * len(idx))(*[ks[i] for i in idx])
+    want = np.zeros(4 * 96, np.uint8)
+    p, k = arrays([0, 1, 2, 3])
+    zkmi.check(L.zkmi_msm_table_multi_dev(h, p, k, 4, 32, zkmi.ptr(want)))
+    got = np.zeros(4 * 96, np.uint8)
+    zkmi.check(L.zkmi_msm_table_multi_enqueue_dev(h, p, k, 4, 32))
+    zkmi.check(L.zkmi_msm_table_multi_collect(h, 4, zkmi.ptr(got)))
+    aff = lambda j: [bytes(O.to_affine(0, 1, j[i * 96:(i + 1) * 96])) for i in range(len(j) // 96)]
+    assert aff(got) == aff(want) and not got[2 * 96:3 * 96].any()
+    # both slots hold an enqueued call at the same time
+    p01, k01 = arrays([0, 1])
+    p3, k3 = arrays([3])
+    zkmi.check(L.zkmi_pipeline_select(0)); zkmi.check(L.zkmi_msm_table_multi_enqueue_dev(h, p01, k01, 2, 32))
+    zkmi.check(L.zkmi_pipeline_select(1)); zkmi.check(L.zkmi_msm_table_multi_enqueue_dev(h, p3, k3, 1, 32))
+    g1, g0 = np.zeros(96, np.uint8), np.zeros(192, np.uint8)
+    zkmi.check(L.zkmi_msm_table_multi_collect(h, 1, zkmi.ptr(g1)))
+    zkmi.check(L.zkmi_pipeline_select(0)); zkmi.check(L.zkmi_msm_table_multi_collect(h, 2, zkmi.ptr(g0)))
+    assert aff(g0) == aff(want)[:2] and aff(g1) == aff(want)[3:]
+    # misuse
+    assert L.zkmi_msm_table_multi_collect(h, 2, zkmi.ptr(g0)) != 0 and b"nothing enqueued" in L.zkmi_last_error()
+    zkmi.check(L.zkmi_msm_table_multi_enqueue_dev(h, p01, k01, 2, 32))
+    assert L.zkmi_msm_table_multi_collect(h, 3, zkmi.ptr(got)) != 0 and b"does not match" in L.zkmi_last_error()
+    zkmi.check(L.zkmi_msm_table_multi_enqueue_dev(h, p01, k01, 2, 32))          # the mismatched collect left the call in place: dropped here
+    zkmi.check(L.zkmi_msm_table_multi_enqueue_dev(h, p3, k3, 1, 32))            # never collected: dropped by this one
+    zkmi.check(L.zkmi_msm_table_multi_collect(h, 1, zkmi.ptr(g1)))
+    assert aff(g1) == aff(want)[3:]
+    zkmi.check(L.zkmi_msm_table_release(h))
+    for b in sc:
+        b.free()
+    d_b.free()
