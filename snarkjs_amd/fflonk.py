@@ -115,6 +115,29 @@ def _commit(key, poly):
     return (f.unmont_q(aff[:f.n8q]), f.unmont_q(aff[f.n8q:]))
 
 
+def _commit_enqueue(key, poly):
+    """first half of _commit: batchFromMontgomery + the MSM enqueued on the active pipeline slot (zkmi_msm_table_multi_enqueue_dev, one MSM), nothing waits"""
+    f, L = key.f, zkmi.lib()
+    k = min(poly.n, key.n_ptau)
+    sc = zkmi.DeviceBuffer(k * 32)
+    zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_FROM_MONTGOMERY, poly.ptr, sc.ptr, k))
+    ptrs, ks = (C.c_void_p * 1)(sc.ptr), (C.c_size_t * 1)(k)
+    zkmi.check(L.zkmi_msm_table_multi_enqueue_dev(key.ptau_table, ptrs, ks, 1, 32))
+    return key, sc
+
+
+def _commit_collect(state):
+    key, sc = state
+    f, L = key.f, zkmi.lib()
+    jac, aff = np.zeros(3 * f.n8q, np.uint8), np.zeros(2 * f.n8q, np.uint8)
+    try:
+        zkmi.check(L.zkmi_msm_table_multi_collect(key.ptau_table, 1, zkmi.ptr(jac)))
+    finally:
+        sc.free()
+    zkmi.check(L.zkmi_to_affine(f.cid, 1, zkmi.ptr(jac), zkmi.ptr(aff)))
+    return (f.unmont_q(aff[:f.n8q]), f.unmont_q(aff[f.n8q:]))
+
+
 def _div_zerofier(p, n, beta):
     zkmi.check(zkmi.lib().zkmi_poly_div_by_zerofier_dev(p.f.cid, p.ptr, p.n, n, zkmi.ptr(p.f.mont(beta))))
 
@@ -164,6 +187,30 @@ def _small(f, coefs):
 
 def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     """fflonk.prove(zkeyFileName, witnessFileName). blinding_mont: the 9 Fr.random() draws (:321-324), Montgomery bytes."""
+    steps = _prove_steps(zkey, witness_file, logger, options, blinding_mont)
+    try:
+        while True:
+            next(steps)
+    except StopIteration as done:
+        return done.value
+
+
+def prove_many(zkey, witness_files, blinding_monts=None, in_flight=2):
+    """Throughput mode (r06), as plonk.prove_many: one proof per witness against one key, TWO in flight from this one host thread, each on its own pipeline slot. An FFLONK proof
+    waits on the device some fifty times (eight degree checks, thirty-three evaluations, four commitments): alone it leaves the GPU idle through every one of those round
+    trips; here the other proof's queued work runs meanwhile. Results in input order, equal to prove() for the same blinding values."""
+    from .plonk import run_many
+    key = zkey if isinstance(zkey, FflonkKey) else FflonkKey(zkey if isinstance(zkey, (bytes, bytearray)) else open(zkey, "rb").read())
+    try:
+        return run_many(lambda i: _prove_steps(key, witness_files[i], None, None, None if blinding_monts is None else blinding_monts[i]), len(witness_files), in_flight)
+    finally:
+        if not isinstance(zkey, FflonkKey):
+            key.release()
+
+
+def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=None):
+    """fflonk.prove as a coroutine: `yield` stands right before every group of blocking calls (degree checks, evaluations, the collects of the four commitments); everything
+    between two yields only enqueues work. The value of the generator is the proof."""
     def data(x):
         if isinstance(x, (bytes, bytearray, memoryview, np.ndarray)):
             return bytes(x)
@@ -219,12 +266,15 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     zkmi.check(L.zkmi_fflonk_t0_dev(f.cid, C.byref(ev), n, key.nPublic, T0.ptr))
     pT0 = T0.ntt(True, out=T0)
     _div_zerofier(pT0, n, 1)
+    yield
     if _degree(pT0) >= 2 * n - 2:
         raise ValueError("T0 Polynomial is not well calculated")
     C1 = _cpoly(f, [pA, pB, pC, pT0], 4)
     if _degree(C1) >= 8 * n - 8:
         raise ValueError("C1 Polynomial is not well calculated")
-    pts["C1"] = _commit(key, C1)
+    cm = _commit_enqueue(key, C1)
+    yield
+    pts["C1"] = _commit_collect(cm)
 
     # ---- ROUND 2 (:558-862)
     tr = _Transcript(f)
@@ -236,8 +286,9 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     tr.reset(); tr.scalar(beta)
     gamma = tr.challenge()
     Zb = _Poly(f, n, False)
-    zkmi.check(L.zkmi_plonk_compute_z_dev(f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(13, n), key.sec(14, n), n, mp(beta), mp(gamma), mp(key.k1), mp(key.k2),
-                                          zkmi.ptr(w_n), Zb.ptr))
+    # enqueue only: Z[0] == 1 ("Copy constraints does not match", :640-642) is read behind the next wait, as plonk.py does
+    zkmi.check(L.zkmi_plonk_compute_z_enqueue(f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(13, n), key.sec(14, n), n, mp(beta), mp(gamma), mp(key.k1), mp(key.k2),
+                                              zkmi.ptr(w_n), Zb.ptr))
     pZ = Zb.ntt(True)
     eZ = pZ.extended_evals(4)
     pZ = pZ.blinded([b[9], b[8], b[7]])
@@ -247,6 +298,9 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     pT1 = T1.ntt(True, out=T1)
     _div_zerofier(pT1, n, 1)
     pT1.axpy(T1z.ntt(True, out=T1z))
+    yield
+    if Zb.get(0) != 1:
+        raise ValueError("Copy constraints does not match")
     if _degree(pT1) >= n + 2:
         raise ValueError("T1 Polynomial is not well calculated")
     ev2 = zkmi.PlonkEvals(eA.ptr, eB.ptr, eC.ptr, eZ.ptr, None, None, None, None, None, key.sec(12, n), key.sec(13, n), key.sec(14, n), None, None)
@@ -255,12 +309,15 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     pT2 = T2.ntt(True, out=T2)
     _div_zerofier(pT2, n, 1)
     pT2.axpy(T2z.ntt(True, out=T2z))
+    yield
     if _degree(pT2) >= 3 * n:
         raise ValueError("T2 Polynomial is not well calculated")
     C2 = _cpoly(f, [pZ, pT1, pT2], 3)
     if _degree(C2) >= 9 * n:
         raise ValueError("C2 Polynomial is not well calculated")
-    pts["C2"] = _commit(key, C2)
+    cm = _commit_enqueue(key, C2)
+    yield
+    pts["C2"] = _commit_collect(cm)
 
     # ---- ROUND 3 (:864-963)
     tr = _Transcript(f)
@@ -313,9 +370,12 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     _div_zerofier(f3, 3, xiw)
     F.axpy(f2)
     F.axpy(f3)
+    yield
     if _degree(F) >= 9 * n - 6:
         raise ValueError("F Polynomial is not well calculated")
-    pts["W1"] = _commit(key, F)
+    cm = _commit_enqueue(key, F)
+    yield
+    pts["W1"] = _commit_collect(cm)
 
     # ---- ROUND 5 (:1059-1180)
     tr = _Transcript(f)
@@ -336,6 +396,7 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
     Lp.axpy(l3, preL2)
     ZT = _zerofier(S0 + S1 + S2 + S2p, r)
     Lp.axpy(F, _ev(ZT, y, r), sub=True)
+    yield
     if _degree(Lp) >= 9 * n:
         raise ValueError("L Polynomial is not well calculated")
     ZTS2 = _zerofier(S1 + S2 + S2p, r)
@@ -346,7 +407,9 @@ def prove(zkey, witness_file, logger=None, options=None, blinding_mont=None):
         raise ValueError("Degree of L(X)/(ZTS2(y)(X-y)) remainder is not 0") from e
     if _degree(Lp) >= 9 * n - 1:
         raise ValueError("Degree of L(X)/(ZTS2(y)(X-y)) is not correct")
-    pts["W2"] = _commit(key, Lp)
+    cm = _commit_enqueue(key, Lp)
+    yield
+    pts["W2"] = _commit_collect(cm)
 
     # ---- getMontgomeryBatchedInverse (:1182-1287)
     to_inv["zh"] = (pow(xi, n, r) - 1) % r

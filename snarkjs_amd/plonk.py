@@ -289,14 +289,22 @@ def prove_many(zkey, witness_files, blinding_monts=None, in_flight=2):
     GPU always holds queued work of the other proof while the host waits. Results come back in input order and are the proofs plonk.prove
     would return for the same blinding values."""
     key = zkey if isinstance(zkey, PlonkKey) else PlonkKey(zkey if isinstance(zkey, (bytes, bytearray)) else open(zkey, "rb").read())
+    try:
+        return run_many(lambda i: _prove_steps(key, witness_files[i], None, None, None if blinding_monts is None else blinding_monts[i]), len(witness_files), in_flight)
+    finally:
+        if not isinstance(zkey, PlonkKey):
+            key.release()
+
+
+def run_many(make_steps, n, in_flight=2):
+    """The two-slot driver shared by plonk.prove_many and fflonk.prove_many: make_steps(i) -> the coroutine of proof i; at most two live, each on its own pipeline slot."""
     L = zkmi.lib()
-    n = len(witness_files)
     out = [None] * n
     live, free, nxt = [], list(range(max(1, min(2, in_flight)))), 0
     try:
         while nxt < n or live:
             while free and nxt < n:
-                live.append((free.pop(0), nxt, _prove_steps(key, witness_files[nxt], None, None, None if blinding_monts is None else blinding_monts[nxt])))
+                live.append((free.pop(0), nxt, make_steps(nxt)))
                 nxt += 1
             for ent in list(live):
                 slot, idx, steps = ent
@@ -316,8 +324,6 @@ def prove_many(zkey, witness_files, blinding_monts=None, in_flight=2):
             except Exception:
                 pass
         L.zkmi_pipeline_select(0)
-        if not isinstance(zkey, PlonkKey):
-            key.release()
     return out
 
 

@@ -545,3 +545,30 @@ def test_device_prover_equals_the_reference_wasm_prover_on_this_box(env, proto, 
     sha = lambda o: hashlib.sha256(json.dumps(o, separators=(",", ":")).encode()).hexdigest()
     assert sha(got["proof"]) == d["proof_json_sha256"], "device proof differs from the reference's WASM proof for the same draws"
     assert sha(got["publicSignals"]) == d["public_signals_sha256"]
+
+
+@pytest.mark.gpu
+def test_fflonk_prove_many_equals_prove(env, golden_dir):
+    """fflonk.prove_many (r06: two coroutine proofs on the library's two pipeline slots, commitments as enqueue + collect) == fflonk.prove, proof by proof; the golden proof
+    first; a bad witness in the middle fails the call and leaves the library usable."""
+    import synth_plonk
+    from snarkjs_amd import fflonk
+    zkmi, plonk, f, cx = env
+    g = json.load(open(os.path.join(golden_dir, "fflonk_bn128_n256.json")))
+    zkey = open(os.path.join(golden_dir, "fflonk_bn128_n256.zkey"), "rb").read()
+    wtns = open(os.path.join(golden_dir, "fflonk_bn128_n256.wtns"), "rb").read()
+    key = fflonk.FflonkKey(zkey)
+    blinds = [[bytes.fromhex(x) for x in g["blinding_mont"]]] + [[bytes(f.mont(5000 + 97 * k + 11 * i)) for i in range(9)] for k in range(1, 5)]
+    serial = [fflonk.prove(key, wtns, blinding_mont=b) for b in blinds]
+    many = fflonk.prove_many(key, [wtns] * 5, blinds)
+    assert many == serial and many[0]["proof"] == g["proof"]
+    bad = bytearray(wtns)
+    bad[-32] ^= 1
+    with pytest.raises(Exception) as ei:
+        fflonk.prove_many(key, [wtns, bytes(bad), wtns, wtns], blinds[:4])
+    assert "Copy constraints does not match" in str(ei.value) or "not divisible" in str(ei.value) or "not well calculated" in str(ei.value)
+    assert fflonk.prove_many(key, [wtns] * 3, blinds[:3]) == serial[:3] and fflonk.prove(key, wtns, blinding_mont=blinds[1]) == serial[1]
+    key.release()
+    zk2, wt2 = synth_plonk.make_fflonk(12, seed=12)
+    b2 = [[bytes(f.mont(300 + 7 * k + i)) for i in range(9)] for k in range(3)]
+    assert fflonk.prove_many(zk2, [wt2] * 3, b2) == [fflonk.prove(zk2, wt2, blinding_mont=b) for b in b2]
