@@ -354,6 +354,9 @@ def cpu_baseline(args, zkey, wtns, log_n_full):
     return base, sample
 
 
+T_PROCESS_START = time.perf_counter()
+
+
 def other_configs(args):
     """The other BASELINE configs in the SAME driver run (rank 0, N = 1, after the headline line is complete): each is this script again as a child
     process with its own key — BLS12-381 Groth16 2^20 (configs[4]), PLONK 2^20 with addition gates (configs[3]), BN254 Groth16 2^24 on one GPU
@@ -363,15 +366,17 @@ def other_configs(args):
     proved from Node). A wall-clock budget bounds the lot (--other-configs-budget): a config whose expected cost does not fit what is left is reported
     as skipped, never silently dropped."""
     import subprocess
-    runs = [("configs[4]", ["--curve", "bls12381", "--steps", "8", "--warmup", "1", "--cpu-baseline-mode", "ref", "--no-napi-wall"], 50.0),
-            ("configs[3]", ["--workload", "plonk", "--steps", "8", "--warmup", "1", "--no-napi-wall"], 55.0),
-            ("configs[1] on a circuit-shaped key", ["--coef-dist", "real", "--witness", "mixed", "--steps", "10", "--warmup", "1", "--cpu-baseline-mode", "ref", "--no-napi-wall"], 30.0),
-            ("configs[2] at N=1", ["--log-n", "24", "--steps", "5", "--warmup", "1", "--repeats", "1", "--cpu-baseline-mode", "closed", "--napi-wall-reps", "2"], 110.0)]
+    runs = [("configs[4]", ["--curve", "bls12381", "--steps", "8", "--warmup", "1", "--cpu-baseline-mode", "ref", "--no-napi-wall"], 42.0),
+            ("configs[3]", ["--workload", "plonk", "--steps", "8", "--warmup", "1", "--no-napi-wall"], 46.0),
+            ("configs[1] on a circuit-shaped key", ["--coef-dist", "real", "--witness", "mixed", "--steps", "10", "--warmup", "1", "--cpu-baseline-mode", "ref", "--no-napi-wall"], 22.0),
+            ("configs[2] at N=1", ["--log-n", "24", "--steps", "5", "--warmup", "1", "--repeats", "1", "--cpu-baseline-mode", "closed", "--napi-wall-reps", "2"], 92.0)]
     t_start, res = time.perf_counter(), {}
+    # two bounds: the budget of this leg, and the whole run's (--total-budget, from process start: the headline part takes 80 - 100 s of it) — whichever ends first
+    deadline = min(t_start + args.other_configs_budget, T_PROCESS_START + args.total_budget)
     for tag, extra, expect_s in runs:
-        left = args.other_configs_budget - (time.perf_counter() - t_start)
+        left = deadline - time.perf_counter()
         if left < expect_s:
-            res[tag] = {"skipped": f"budget: {left:.0f} s left of {args.other_configs_budget:.0f}, this config needs ~{expect_s:.0f} s (key synthesis + load + proofs + its reference leg)"}
+            res[tag] = {"skipped": f"budget: {left:.0f} s left (--other-configs-budget {args.other_configs_budget:.0f} / --total-budget {args.total_budget:.0f}), this config needs ~{expect_s:.0f} s (key synthesis + load + proofs + its reference leg)"}
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-other-configs"] + extra
         if args.no_cpu_baseline:
@@ -795,6 +800,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="how often the timed region is run (value = the first; min / median / max of all reported)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[4] / [3] / [2] (child runs after the headline line; default run at N = 1 only)")
     ap.add_argument("--other-configs-budget", type=float, default=330.0, help="wall-clock seconds the other configs may take together")
+    ap.add_argument("--total-budget", type=float, default=335.0, help="wall-clock seconds the whole default run may take (headline + other configs); a config that does not fit is reported as skipped")
     ap.add_argument("--no-ref-wasm", action="store_true", help="skip the reference's own WASM prover on this box's host cores (cpu_baseline.reference_wasm.same_box)")
     ap.add_argument("--ref-wasm-budget", type=float, default=200.0, help="seconds the same-box WASM leg may take; a size is skipped when ~5x the previous one does not fit")
     ap.add_argument("--witness", default="uniform", choices=["uniform", "mixed"])
