@@ -71,8 +71,17 @@ const count = (nm) => backend.calls.filter((c) => c === nm).length;
     seeded(5);
     const many = await prover.proveMany(zkey, [wtns, wtns, wtns, wtns, wtns]);
     check("proveMany: every proof == reference proof", many.length === 5 && many.every((x) => sha(JSON.stringify(x.proof)) === g.proof_sha256));
-    const seq = backend.calls.filter((c) => /^(submit|collect)/.test(c)).join(" ");
+    let seq = backend.calls.filter((c) => /^(submit|collect)/.test(c)).join(" ");
+    if (seq.startsWith("submit1")) seq = seq.replace(/[01]/g, (d) => (d === "0" ? "1" : "0"));       // the slots alternate process-wide (r06): which one comes first depends on the proofs before
     check("proveMany call order (two slots): " + seq, seq === "submit0 submit1 collect0 submit0 collect1 submit1 collect0 submit0 collect1 collect0");
+    // r06: concurrent prove() calls go through the same queue: four requests at once pipeline exactly like proveMany
+    backend.calls.length = 0;
+    seeded(4);
+    const four = await Promise.all([prover.prove(zkey, wtns), prover.prove(zkey, wtns), prover.prove(zkey, wtns), prover.prove(zkey, wtns)]);
+    let seq4 = backend.calls.filter((c) => /^(submit|collect)/.test(c)).join(" ");
+    if (seq4.startsWith("submit1")) seq4 = seq4.replace(/[01]/g, (d) => (d === "0" ? "1" : "0"));
+    check("four concurrent prove() calls: two in flight, in arrival order: " + seq4, four.every((x) => sha(JSON.stringify(x.proof)) === g.proof_sha256) &&
+          seq4 === "submit0 submit1 collect0 submit0 collect1 submit1 collect0 collect1");
     // an error inside the pipeline leaves no slot occupied
     threw = false;
     try { await prover.proveMany(zkey, [wtns, short, wtns]); } catch (e) { threw = /Invalid witness length/.test(e.message); }
