@@ -120,6 +120,10 @@ int zkmi_msm_table_multi_dev(uint64_t handle, const void* const* d_scalars, cons
  * dropped by the slot's next enqueue). */
 int zkmi_msm_table_multi_enqueue_dev(uint64_t handle, const void* const* d_scalars, const size_t* ks, int count, size_t scalar_bytes);
 int zkmi_msm_table_multi_collect(uint64_t handle, int count, uint8_t* out_jacobians);
+/* Polynomial.multiExponentiation (src/polynomial/polynomial.js:970-977) for the commitments of one round: the `count` coefficient arrays are MONTGOMERY Fr elements; their
+ * batchFromMontgomery (one launch for all of them, into scratch memory of the active pipeline slot) and the MSMs are enqueued as by zkmi_msm_table_multi_enqueue_dev. The
+ * polynomials are read by the conversion launch only, which is stream-ordered before anything the caller enqueues on the slot afterwards. Collect with zkmi_msm_table_multi_collect. */
+int zkmi_msm_table_multi_enqueue_mont_dev(uint64_t handle, const void* const* d_polys, const size_t* ks, int count);
 int zkmi_msm_table_release(uint64_t handle);
 /* Curve, group and number of resident points of a table (any pointer may be NULL): a binding sizes the result buffers of the two calls above
  * — 3*group*n8q bytes per MSM — from the TABLE instead of trusting its caller. */
@@ -136,6 +140,9 @@ int zkmi_ntt(int curve, zkmi_pages in, uint8_t* const* out_ptr, const size_t* ou
              int inverse, const uint8_t* prescale_first, const uint8_t* prescale_inc);
 int zkmi_ntt_dev(int curve, const void* d_in, void* d_out, unsigned log_n, int inverse, const uint8_t* prescale_first,
                  const uint8_t* prescale_inc);
+/* Evaluations.fromPolynomial (src/polynomial/evaluations.js:30-37): the transform of a polynomial of in_len <= 2^log_n coefficients, zero-padded to 2^log_n — the padding is
+ * never written: the first pass reads zeros beyond in_len. d_out: 2^log_n elements (d_in == d_out allowed when that buffer is 2^log_n long). */
+int zkmi_ntt_padded_dev(int curve, const void* d_in, size_t in_len, void* d_out, unsigned log_n, int inverse);
 
 /* ---- Fr batch operations ---------------------------------------------------------------------------------------- */
 /* curve.Fr.batchApplyKey(buf, first, inc) (min.js:1@211529, kernel frm_batchApplyKey @128060): out[i] = in[i]*first*inc^i */
@@ -145,6 +152,8 @@ int zkmi_fr_batch_apply_key_dev(int curve, const void* d_in, void* d_out, size_t
 /* op = ZKMI_BATCH_* */
 int zkmi_fr_batch(int curve, int op, zkmi_pages in, uint8_t* const* out_ptr, const size_t* out_len, int n_out_pages, size_t n);
 int zkmi_fr_batch_dev(int curve, int op, const void* d_in, void* d_out, size_t n);
+/* the two Montgomery conversions on up to four arrays in one launch (ns[i] elements each; in place allowed) */
+int zkmi_fr_batch_multi_dev(int curve, int op, const void* const* d_in, void* const* d_out, const size_t* ns, int count);
 /* joinABC (src/groth16_prove.js:320-374: qap_joinABC min.js:1@123664 + frm_batchFromMontgomery):
  * out[i] = fromMontgomery(a[i]*b[i] - c[i]) */
 int zkmi_groth16_join_abc(int curve, zkmi_pages a, zkmi_pages b, zkmi_pages c, uint8_t* const* out_ptr,
@@ -258,6 +267,10 @@ int zkmi_fr_root(int curve, unsigned i, uint8_t* out32);
 int zkmi_plonk_gather_wires_dev(int curve, const void* d_witness, uint32_t n_witness, const void* d_internal, uint32_t n_additions,
                                 const void* d_map_a, const void* d_map_b, const void* d_map_c, uint32_t n_constraints, uint32_t domain,
                                 void* d_a, void* d_b, void* d_c);
+/* the same with Fr.batchToMontgomery (:278) applied in the same pass: A/B/C come out in Montgomery form */
+int zkmi_plonk_gather_wires_mont_dev(int curve, const void* d_witness, uint32_t n_witness, const void* d_internal, uint32_t n_additions,
+                                     const void* d_map_a, const void* d_map_b, const void* d_map_c, uint32_t n_constraints, uint32_t domain,
+                                     void* d_a, void* d_b, void* d_c);
 /* calculateAdditions (src/plonk_prove.js:174-204, src/fflonk_prove.js:269-300): the internal signals of a PLONK / FFLONK key,
  *   internal[i] = factor1_i * getWitness(id1_i) + factor2_i * getWitness(id2_i),   getWitness as in :207-215 (n_vars = n_witness + n_additions),
  * computed on the device in ONE launch although an addition may read internal signals created before it (a dependency DAG of any depth; time grows
@@ -303,18 +316,36 @@ int zkmi_poly_axpy_dev(int curve, void* d_y, const void* d_x, size_t nx, const u
 /* Polynomial.mulScalar (:278-284) */
 int zkmi_poly_scale_dev(int curve, void* d_p, size_t n, const uint8_t* k);
 /* blindCoefficients (polynomial.js:68-93) on a buffer of n + count elements whose tail is zero: p[n+i] += f_i, p[i] -= f_i.
- * factors: count x 32 bytes (host, Montgomery), count <= 32. No host synchronisation. */
+ * factors: count x 32 bytes (host, Montgomery), count <= 8. No host synchronisation. Per-call constants of every function of this section (factors, k, x, beta) travel as
+ * kernel arguments: none of them costs an upload of its own. */
 int zkmi_poly_blind_dev(int curve, void* d_p, size_t n, const uint8_t* factors, int count);
+/* the same IN PLACE on a buffer with room for n + count elements of which only the first n were written: p[n+i] = f_i, p[i] -= f_i */
+int zkmi_poly_blind_tail_dev(int curve, void* d_p, size_t n, const uint8_t* factors, int count);
+/* A chain of Polynomial.add / sub / mulScalar / addScalar (polynomial.js:218-290) as ONE pass: out[i] = sum_j k_j p_j[i] (i < len_j) + (i == 0 ? constant : 0), i < out_len.
+ * has_k = 0: k_j = 1 (pass -k for a subtraction), constant NULL = none, count <= 16, every len_j <= out_len; out may be one of the operands. Exact field arithmetic: the result is
+ * the one the reference's sequence of calls leaves, whatever their order (src/plonk_prove.js:769-866 builds R and Wxi with 18 such calls). A term is 56 bytes without host
+ * pointers, so that a binding can fill an array of them in one flat buffer (device pointer and length as 64-bit little-endian integers). */
+typedef struct zkmi_poly_term { const void* d_p; uint64_t len; uint8_t k[32]; uint32_t has_k; uint32_t reserved; } zkmi_poly_term;
+int zkmi_poly_lincomb_dev(int curve, void* d_out, size_t out_len, const zkmi_poly_term* terms, int count, const uint8_t* constant);
 /* addScalar (polynomial.js:286-290): p[0] += value. No host synchronisation. */
 int zkmi_poly_add_scalar_dev(int curve, void* d_p, const uint8_t* value);
 /* Polynomial.evaluate (Horner, :174-184) as a parallel reduction; out = 32 bytes (host) */
 int zkmi_poly_evaluate_dev(int curve, const void* d_p, size_t n, const uint8_t* x, uint8_t* out);
+/* count <= 8 evaluations with ONE wait: polynomial q (lens[q] coefficients) at xs[32 q .. 32 q + 32) -> out[32 q ..] (round 4 of PLONK: six evaluations at two points,
+ * src/plonk_prove.js:686-708). The power table of a point is built on the device; points that repeat share it. */
+int zkmi_poly_evaluate_multi_dev(int curve, const void* const* d_polys, const size_t* lens, const uint8_t* xs, int count, uint8_t* out);
 /* *all_zero = 1 iff p[0..n) are all zero (degree checks, plonk_prove.js:298-306, :645-647) */
 int zkmi_poly_is_zero_dev(int curve, const void* d_p, size_t n, int* all_zero);
 /* Polynomial.divZh(domainSize, extensions) (:592-615), in place; "Polynomial is not divisible" on a non-zero tail */
 int zkmi_poly_div_zh_dev(int curve, void* d_p, size_t len, uint32_t domain, uint32_t extensions);
 /* Polynomial.divByZerofier(n, beta) (:617-674): division by X^n - beta, in place (PLONK openings use n = 1, FFLONK n > 1) */
 int zkmi_poly_div_by_zerofier_dev(int curve, void* d_p, size_t len, uint32_t n, const uint8_t* beta);
+/* the same, enqueued only (no wait, no error from the division itself): the reference's divisibility test is "the n highest coefficients of the quotient are zero"
+ * (:665-669) — the caller makes it at its next synchronisation point with zkmi_poly_is_zero_dev(p + len - n, n) and raises "Polynomial is not divisible" itself. */
+int zkmi_poly_div_by_zerofier_enqueue(int curve, void* d_p, size_t len, uint32_t n, const uint8_t* beta);
+/* Round 3 of PLONK (src/plonk_prove.js:649-672): T (t_len >= 3*domain + 6 coefficients, fewer read as zero) split into T1 = T[0, n) + b10 X^n (n + 1 coefficients),
+ * T2 = T[n, 2n) - b10 + b11 X^n (n + 1), T3 = T[2n, 3n + 6) - b11 (n + 6): one launch instead of three zero fills, three copies and five single-coefficient reads / writes */
+int zkmi_plonk_split_t_dev(int curve, const void* d_t, size_t t_len, uint32_t domain, const uint8_t* b10, const uint8_t* b11, void* d_t1, void* d_t2, void* d_t3);
 /* CPolynomial.getPolynomial (src/polynomial/cpolynomial.js:53-73): out[i*n + j] = P_j[i] for i < lens[j] (d_polys[j] may be
  * NULL), zero elsewhere; n <= 16 component polynomials; out_len elements are written. */
 int zkmi_cpoly_interleave_dev(int curve, const void* const* d_polys, const size_t* lens, int n, void* d_out, size_t out_len);

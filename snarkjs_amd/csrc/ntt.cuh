@@ -41,6 +41,7 @@ struct NttPassArgs {
     const uint32_t* LT;                   // local twiddles w_{Ni}^k, k < Ni/2
     const uint32_t* rowinc;               // per-pass pre-scale factors (Ni entries) or nullptr
     const uint32_t* scale;                // single constant applied on load (1/n for single-pass inverse) or nullptr
+    uint64_t in_len;                      // first pass only: elements the caller's input holds (0 = all 2^log_n); the rest reads as zero (Evaluations.fromPolynomial's zero padding)
     uint64_t in_bs, out_bs;               // batched launches (gridDim.y transforms of the same plan): words between the inputs / outputs of consecutive members
 };
 
@@ -138,7 +139,8 @@ k_ntt_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     __syncthreads();
     for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
         uint32_t c = idx & (CH - 1), j = idx >> a.log_ch;
-        Fp<C> x = fp_load<C>(in + (base + ((uint64_t)j << log_S) + c) * C::N);
+        const uint64_t src = base + ((uint64_t)j << log_S) + c;
+        Fp<C> x = (a.pass == 0 && a.in_len && src >= a.in_len) ? fp_zero<C>() : fp_load<C>(in + src * C::N);
         if (has_fac) x = fp_mul(x, lds_get<C>(rf0, rf1, j));
         lds_put<C>(p0, p1, idx, x);
     }
@@ -178,7 +180,7 @@ k_ntt_pass_last(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     for (uint32_t idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
         uint32_t j = idx & (N - 1), c = idx >> l;
         uint64_t addr = multi ? (((c0 + c) << log_S1) + (r << l) + j) : j;
-        Fp<C> x = fp_load<C>(in + addr * C::N);
+        Fp<C> x = (!multi && a.in_len && addr >= a.in_len) ? fp_zero<C>() : fp_load<C>(in + addr * C::N);
         if (multi) {
             uint64_t K = (c0 + c) + (Krest << l1);
             x = fp_mul(x, ntt_pow<C>(a, (uint64_t)j * K));

@@ -101,7 +101,7 @@ template <class C> static int get_plan(int curve, unsigned L, int inverse, NttPl
 // batch > 1: `batch` transforms of the same size in ONE launch per pass (gridDim.y): member k reads d_in + k*in_stride elements and writes
 // d_out + k*out_stride elements (Groth16's A, B, C chains: three times the blocks per launch, a third of the launches and launch tails)
 template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, unsigned L, int inverse, const uint8_t* first, const uint8_t* inc, unsigned batch = 1, size_t in_stride = 0,
-                                      size_t out_stride = 0) {
+                                      size_t out_stride = 0, size_t in_len = 0) {
     Ctx& cx = ctx();
     const FrRoots& R = fr_roots<C>();
     if ((int)L > R.s) return fail(ZKMI_ERR_UNSUPPORTED, "fft: log2(n) exceeds the 2-adicity of Fr (the reference's n = 2^(s+1) coset case is not supported)");
@@ -188,6 +188,7 @@ template <class C> static int ntt_run(int curve, const void* d_in, void* d_out, 
     ZK_HIP(hipEventRecord(cx.ev0, st));
     NttPassArgs a;
     a.log_n = L; a.n_pass = (uint32_t)p; a.log_lb = P->log_lb; a.T_lo = use29 ? P->T_lo29 : P->T_lo;
+    a.in_len = in_len >= n ? 0 : in_len;
     for (int i = 0; i < 4; i++) a.l[i] = P->l[i];
     unsigned logS = L;
     for (int i = 0; i < p - 1; i++) {
@@ -241,6 +242,14 @@ int ntt_power_tables(int curve, unsigned L, int inverse, const uint32_t** T_lo, 
 int ntt_dev_dispatch(int curve, const void* d_in, void* d_out, unsigned log_n, int inverse, const uint8_t* first, const uint8_t* inc) {
     if (curve == ZKMI_CURVE_BN128) return ntt_run<Bn254Fr>(curve, d_in, d_out, log_n, inverse, first, inc);
     if (curve == ZKMI_CURVE_BLS12381) return ntt_run<Bls12381Fr>(curve, d_in, d_out, log_n, inverse, first, inc);
+    return fail(ZKMI_ERR_INVALID, "unknown curve");
+}
+// the input holds in_len < 2^log_n elements, the rest is read as zero (in place allowed when the buffer itself is 2^log_n long: d_in == d_out)
+int ntt_dev_padded_dispatch(int curve, const void* d_in, size_t in_len, void* d_out, unsigned log_n, int inverse) {
+    if (in_len == 0 || (log_n < 63 && in_len > ((size_t)1 << log_n))) return fail(ZKMI_ERR_INVALID, "fft: the input length must be in [1, 2^log_n]");
+    if (log_n == 0) return ntt_dev_dispatch(curve, d_in, d_out, log_n, inverse, nullptr, nullptr);
+    if (curve == ZKMI_CURVE_BN128) return ntt_run<Bn254Fr>(curve, d_in, d_out, log_n, inverse, nullptr, nullptr, 1, 0, 0, in_len);
+    if (curve == ZKMI_CURVE_BLS12381) return ntt_run<Bls12381Fr>(curve, d_in, d_out, log_n, inverse, nullptr, nullptr, 1, 0, 0, in_len);
     return fail(ZKMI_ERR_INVALID, "unknown curve");
 }
 int ntt_dev_batch_dispatch(int curve, const void* d_in, size_t in_stride, void* d_out, size_t out_stride, unsigned batch, unsigned log_n, int inverse, const uint8_t* first,

@@ -259,7 +259,7 @@ k_ntt29_pass_strided(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     for (uint32_t idx = threadIdx.x; idx < E; idx += NTT29_THREADS) {
         const uint32_t c = idx & (CH - 1), j = idx >> a.log_ch;
         const uint64_t src = base + ((uint64_t)j << log_S) + c;
-        Fp29<C> x = IN_REC ? rec29_load<C>(in, src) : load29_packed<C>(in + src * C::N);
+        Fp29<C> x = IN_REC ? rec29_load<C>(in, src) : (a.in_len && src >= a.in_len) ? zero29<C>() : load29_packed<C>(in + src * C::N);
         if (has_fac) x = mul29(x, lds29_get<C>(rf, j));
         lds29_put<C>(p, TR ? c * (N + 1) + j : idx, x);
     }
@@ -297,7 +297,7 @@ k_ntt29_pass_last(const uint32_t* in, uint32_t* out, NttPassArgs a) {
     for (uint32_t idx = threadIdx.x; idx < E; idx += NTT29_THREADS) {
         const uint32_t j = idx & (N - 1), c = idx >> l;
         const uint64_t addr = multi ? (((c0 + c) << log_S1) + (r << l) + j) : j;
-        Fp29<C> x = IN_REC ? rec29_load<C>(in, addr) : load29_packed<C>(in + addr * C::N);
+        Fp29<C> x = IN_REC ? rec29_load<C>(in, addr) : (a.in_len && addr >= a.in_len) ? zero29<C>() : load29_packed<C>(in + addr * C::N);
         if (multi) {
             const uint64_t K = (c0 + c) + (Krest << l1);
             x = mul29(x, ntt29_pow<C>(a, (uint64_t)j * K));

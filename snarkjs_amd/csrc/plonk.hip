@@ -59,6 +59,38 @@ static int build_pow_tab(const HFr& F, const HE& base, unsigned log_count, const
 }
 static inline unsigned clog2(size_t n) { unsigned l = 0; while (((size_t)1 << l) < n) l++; return l; }
 
+// A field element (or a few) as a KERNEL ARGUMENT: per-call constants — challenges, blinding factors, evaluation points — travel in the launch packet instead of
+// through an upload of their own (r06: every upload was one more copy launch on the stream, 80 of a PLONK proof's 376).
+struct alignas(16) FrK { uint32_t v[8]; };
+static inline FrK frk(const uint8_t* p) { FrK k; memcpy(k.v, p, 32); return k; }
+static inline FrK frk(const HE& e) { FrK k; memcpy(k.v, e.v, 32); return k; }
+template <class C> ZK_DEV Fp<C> frk_load(const FrK& k) { return fp_load<C>(k.v); }
+// power table of a point that changes with every call (xi, xi w, their inverses), built ON the device: entry t < nlo is base^t, entry nlo + t is (base^nlo)^t, each by
+// square-and-multiply (at most 2 log2 products per lane, one launch, no host arithmetic and no wait — the host-built table of build_pow_tab costs 2^(L/2+1) host
+// products, an upload and a stream synchronisation, which is right for the roots of unity it caches and wrong for a point used once)
+template <class C> __global__ void k_pow_tab_build(FrK base, uint32_t lb, uint32_t nlo, uint32_t nhi, uint32_t* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlo + nhi) return;
+    Fp<C> b = frk_load<C>(base);
+    uint32_t e = t;
+    if (t >= nlo) { for (uint32_t k = 0; k < lb; k++) b = fp_mul(b, b); e = t - nlo; }
+    Fp<C> r = fp_one<C>();
+    while (e) { if (e & 1u) r = fp_mul(r, b); b = fp_mul(b, b); e >>= 1; }
+    fp_store<C>(out + (size_t)t * 8, r);
+}
+template <class C> static int build_pow_tab_dyn(const HE& base, unsigned log_count, const std::string& name, PowTab* out) {
+    Ctx& cx = ctx();
+    const unsigned lb = (log_count + 1) / 2, hb = log_count - lb;
+    const uint32_t nlo = 1u << lb, nhi = 1u << hb;
+    uint32_t* d;
+    ZK_TRY(ws_get(name, ((size_t)nlo + nhi) * 32, (void**)&d));
+    pow_tab_cache().erase(std::string(cx.pipe ? "P1:" : "") + name);            // the named buffer no longer holds what build_pow_tab may have cached under this name
+    hipLaunchKernelGGL((k_pow_tab_build<C>), dim3((nlo + nhi + 255) / 256), dim3(256), 0, cx.stream, frk(base), lb, nlo, nhi, d);
+    ZK_HIP(hipGetLastError());
+    out->lo = d; out->hi = d + (size_t)nlo * 8; out->lb = lb;
+    return ZKMI_OK;
+}
+
 // ---- scans over Fr (multiplicative or additive), 3 launches: chunk totals, scan of totals, chunk scan with offset -----------
 constexpr int SCAN_T = 256, SCAN_K = 8, SCAN_CHUNK = SCAN_T * SCAN_K;
 template <class C, bool MUL> ZK_DEV Fp<C> scan_op(const Fp<C>& a, const Fp<C>& b) { return MUL ? fp_mul(a, b) : fp_add(a, b); }
@@ -140,7 +172,7 @@ template <class C, bool MUL> static int scan_inclusive(const uint32_t* in, size_
 // ---- wires ---------------------------------------------------------------------------------------------------------------
 template <class C> __global__ void k_plonk_gather(const uint32_t* __restrict__ wit, uint32_t n_wit, const uint32_t* __restrict__ internal, uint32_t n_add,
                                                  const uint32_t* __restrict__ ma, const uint32_t* __restrict__ mb, const uint32_t* __restrict__ mc,
-                                                 uint32_t n_constraints, uint32_t domain, uint32_t* __restrict__ A, uint32_t* __restrict__ B, uint32_t* __restrict__ Cc) {
+                                                 uint32_t n_constraints, uint32_t domain, uint32_t* __restrict__ A, uint32_t* __restrict__ B, uint32_t* __restrict__ Cc, int to_mont) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= domain) return;
     const uint32_t* maps[3] = {ma, mb, mc};
@@ -152,6 +184,7 @@ template <class C> __global__ void k_plonk_gather(const uint32_t* __restrict__ w
             const uint32_t id = maps[k][i];                              // getWitness (:207-215)
             if (id < n_wit) v = fp_load<C>(wit + (size_t)id * 8);
             else if (id < n_wit + n_add) v = fp_load<C>(internal + (size_t)(id - n_wit) * 8);
+            if (to_mont) v = fp_to_mont(v);                              // Fr.batchToMontgomery (:278) in the same pass
         }
         fp_store<C>(outs[k] + (size_t)i * 8, v);
     }
@@ -454,25 +487,70 @@ static __global__ void __launch_bounds__(256) k_poly_degree(const uint32_t* __re
 // ---- polynomial ops ---------------------------------------------------------------------------------------------------------
 // y[i] = y[i] +/- (k ? k*x[i] : x[i]),  i < nx
 // blindCoefficients (polynomial.js:68-93): p[n+i] += f_i, p[i] -= f_i;  addScalar (:286-290): p[0] += f_0 (n = 0, sub = 0)
-template <class C> __global__ void k_poly_blind(uint32_t* __restrict__ p, size_t n, const uint32_t* __restrict__ f, int count, int sub) {
+constexpr int BLIND_MAX = 8;                             // blinding factors of one call (the reference uses 2 or 3; addScalar is count = 1)
+struct BlindArgs { FrK f[BLIND_MAX]; };
+// mode 0: p[n+i] += f_i (addScalar: n = 0, count = 1); 1: and p[i] -= f_i (blindCoefficients on a zero-padded copy); 2: p[n+i] = f_i, p[i] -= f_i (blindCoefficients IN PLACE:
+// the buffer has room for n + count coefficients and nothing was written behind n yet)
+template <class C> __global__ void k_poly_blind(uint32_t* __restrict__ p, size_t n, BlindArgs a, int count, int mode) {
     const int i = threadIdx.x;
     if (i >= count) return;
-    const Fp<C> v = fp_load<C>(f + (size_t)i * 8);
-    fp_store<C>(p + (n + i) * 8, fp_add(fp_load<C>(p + (n + i) * 8), v));
-    if (sub) fp_store<C>(p + (size_t)i * 8, fp_sub(fp_load<C>(p + (size_t)i * 8), v));
+    const Fp<C> v = frk_load<C>(a.f[i]);
+    fp_store<C>(p + (n + i) * 8, mode == 2 ? v : fp_add(fp_load<C>(p + (n + i) * 8), v));
+    if (mode) fp_store<C>(p + (size_t)i * 8, fp_sub(fp_load<C>(p + (size_t)i * 8), v));
 }
-template <class C> __global__ void k_poly_axpy(uint32_t* __restrict__ y, const uint32_t* __restrict__ x, size_t nx, const uint32_t* __restrict__ k, int subtract) {
+template <class C> __global__ void k_poly_axpy(uint32_t* __restrict__ y, const uint32_t* __restrict__ x, size_t nx, FrK k, int has_k, int subtract) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nx) return;
     Fp<C> b = fp_load<C>(x + i * 8);
-    if (k) b = fp_mul(b, fp_load<C>(k));
+    if (has_k) b = fp_mul(b, frk_load<C>(k));
     const Fp<C> a = fp_load<C>(y + i * 8);
     fp_store<C>(y + i * 8, subtract ? fp_sub(a, b) : fp_add(a, b));
 }
-template <class C> __global__ void k_poly_scale(uint32_t* __restrict__ p, size_t n, const uint32_t* __restrict__ k) {
+template <class C> __global__ void k_poly_scale(uint32_t* __restrict__ p, size_t n, FrK k) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fp_store<C>(p + i * 8, fp_mul(fp_load<C>(p + i * 8), fp_load<C>(k)));
+    fp_store<C>(p + i * 8, fp_mul(fp_load<C>(p + i * 8), frk_load<C>(k)));
+}
+// out[i] = sum_j k_j p_j[i] (i < len_j) + (i == 0 ? constant : 0): a whole chain of Polynomial.add / sub / mulScalar / addScalar (polynomial.js:218-290) in ONE pass over the operands.
+// Fr arithmetic is exact, so the order of the additions does not show in the result: the linearisation polynomial and the opening numerators of round 5
+// (plonk_prove.js:769-866: 18 add / sub calls, 2 mulScalar, 5 copies of selector polynomials) come out bit-identical from one launch each.
+constexpr int LINCOMB_MAX = 16;
+struct LincombArgs { const uint32_t* p[LINCOMB_MAX]; uint64_t len[LINCOMB_MAX]; FrK k[LINCOMB_MAX]; FrK constant; uint32_t n, has_k, has_const; };
+template <class C> __global__ void __launch_bounds__(256) k_poly_lincomb(LincombArgs a, uint32_t* __restrict__ out, size_t out_len) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= out_len) return;
+    Fp<C> acc = (i == 0 && a.has_const) ? frk_load<C>(a.constant) : fp_zero<C>();
+    for (uint32_t j = 0; j < a.n; j++) {
+        if (i >= a.len[j]) continue;
+        Fp<C> x = fp_load<C>(a.p[j] + i * 8);
+        if ((a.has_k >> j) & 1u) x = fp_mul(x, frk_load<C>(a.k[j]));
+        acc = fp_add(acc, x);
+    }
+    fp_store<C>(out + i * 8, acc);
+}
+// the split of T into T1 | T2 | T3 with the blinding of round 3 (plonk_prove.js:649-672): T1 = T[0, n) + b10 X^n, T2 = T[n, 2n) - b10 + b11 X^n, T3 = T[2n, 3n+6) - b11
+template <class C> __global__ void k_plonk_split_t(const uint32_t* __restrict__ t, size_t t_len, uint32_t n, FrK b10, FrK b11, uint32_t* __restrict__ t1, uint32_t* __restrict__ t2, uint32_t* __restrict__ t3) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n + 6) return;
+    if (i <= n) {
+        Fp<C> a = i < n ? fp_load<C>(t + (size_t)i * 8) : frk_load<C>(b10);
+        fp_store<C>(t1 + (size_t)i * 8, a);
+        Fp<C> b = i < n ? fp_load<C>(t + ((size_t)n + i) * 8) : frk_load<C>(b11);
+        if (i == 0) b = fp_sub(b, frk_load<C>(b10));
+        fp_store<C>(t2 + (size_t)i * 8, b);
+    }
+    Fp<C> c = 2 * (size_t)n + i < t_len ? fp_load<C>(t + (2 * (size_t)n + i) * 8) : fp_zero<C>();
+    if (i == 0) c = fp_sub(c, frk_load<C>(b11));
+    fp_store<C>(t3 + (size_t)i * 8, c);
+}
+// Fr.batchFromMontgomery of up to four arrays in one launch (blockIdx.y = array): the scalars of a round's commitments
+struct ConvertMultiArgs { const uint32_t* in[4]; uint32_t* out[4]; uint64_t n[4]; };
+template <class C> __global__ void k_fr_convert_multi(ConvertMultiArgs a, int op) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y;
+    if (i >= a.n[j]) return;
+    const Fp<C> x = fp_load<C>(a.in[j] + i * 8);
+    fp_store<C>(a.out[j] + i * 8, op == 0 ? fp_to_mont(x) : fp_from_mont(x));
 }
 static __global__ void k_poly_any_nonzero(const uint32_t* __restrict__ p, size_t n_words, uint32_t* __restrict__ flag) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -492,25 +570,34 @@ template <class C> __global__ void k_poly_div_zh(uint32_t* __restrict__ c, size_
     }
 }
 // Horner by chunks: partial[b] = sum over the block's coefficients c_i x^i
-constexpr int EV_K = 16;
+constexpr int EV_K = 16, EVAL_MAX = 8;
+// up to EVAL_MAX evaluations in one launch (blockIdx.y = which): round 4 of PLONK evaluates six polynomials at two points (plonk_prove.js:686-708)
+struct EvalArgs { const uint32_t* c[EVAL_MAX]; uint64_t n[EVAL_MAX]; FrK x[EVAL_MAX]; PowTab xt[EVAL_MAX]; uint32_t np[EVAL_MAX], off[EVAL_MAX]; };
 template <class C> __global__ void __launch_bounds__(256)
-k_poly_eval_partial(const uint32_t* __restrict__ c, size_t n, const uint32_t* __restrict__ x, PowTab xt, uint32_t* __restrict__ part) {
+k_poly_eval_partial(EvalArgs a, uint32_t* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[256 * 8];
+    const uint32_t q = blockIdx.y;
+    if (blockIdx.x >= a.np[q]) return;
+    const uint32_t* __restrict__ c = a.c[q];
+    const size_t n = a.n[q];
     const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * EV_K;
-    const Fp<C> xv = fp_load<C>(x);
+    const Fp<C> xv = frk_load<C>(a.x[q]);
     Fp<C> acc = fp_zero<C>();
     for (int k = EV_K - 1; k >= 0; k--) { acc = fp_mul(acc, xv); if (base + k < n) acc = fp_add(acc, fp_load<C>(c + (base + k) * 8)); }
-    if (base < n) acc = fp_mul(acc, pow_tab<C>(xt, base)); else acc = fp_zero<C>();
+    if (base < n) acc = fp_mul(acc, pow_tab<C>(a.xt[q], base)); else acc = fp_zero<C>();
     fp_store<C>(lds + threadIdx.x * 8, acc);
     __syncthreads();
     for (int d = 128; d >= 1; d >>= 1) {
         if (threadIdx.x < (uint32_t)d) { acc = fp_add(acc, fp_load<C>(lds + (threadIdx.x + d) * 8)); fp_store<C>(lds + threadIdx.x * 8, acc); }
         __syncthreads();
     }
-    if (threadIdx.x == 0) fp_store<C>(part + (size_t)blockIdx.x * 8, acc);
+    if (threadIdx.x == 0) fp_store<C>(part + ((size_t)a.off[q] + blockIdx.x) * 8, acc);
 }
-template <class C> __global__ void __launch_bounds__(256) k_poly_sum(const uint32_t* __restrict__ part, uint32_t np, uint32_t* __restrict__ out) {
+// out[q] = sum of the partials of evaluation q (one block each)
+template <class C> __global__ void __launch_bounds__(256) k_poly_sum(EvalArgs a, const uint32_t* __restrict__ part, uint32_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[256 * 8];
+    const uint32_t q = blockIdx.x, np = a.np[q];
+    part += (size_t)a.off[q] * 8;
     Fp<C> acc = fp_zero<C>();
     for (uint32_t i = threadIdx.x; i < np; i += 256) acc = fp_add(acc, fp_load<C>(part + (size_t)i * 8));
     fp_store<C>(lds + threadIdx.x * 8, acc);
@@ -519,14 +606,14 @@ template <class C> __global__ void __launch_bounds__(256) k_poly_sum(const uint3
         if (threadIdx.x < (uint32_t)d) { acc = fp_add(acc, fp_load<C>(lds + (threadIdx.x + d) * 8)); fp_store<C>(lds + threadIdx.x * 8, acc); }
         __syncthreads();
     }
-    if (threadIdx.x == 0) fp_store<C>(out, acc);
+    if (threadIdx.x == 0) fp_store<C>(out + (size_t)q * 8, acc);
 }
 // divByZerofier(1, beta): u_i = -c_i * beta^i * (1/beta); S = inclusive prefix sums of u; q_i = S_i * (1/beta)^i
 // (chain k of residue `off` modulo `stride`: element index off + k*stride; stride = 1 for the PLONK openings)
-template <class C> __global__ void k_dz_weight(const uint32_t* __restrict__ c, size_t m, size_t off, size_t stride, PowTab bt, const uint32_t* __restrict__ inv_beta, uint32_t* __restrict__ u) {
+template <class C> __global__ void k_dz_weight(const uint32_t* __restrict__ c, size_t m, size_t off, size_t stride, PowTab bt, FrK inv_beta, uint32_t* __restrict__ u) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
-    fp_store<C>(u + k * 8, fp_neg(fp_mul(fp_mul(fp_load<C>(c + (off + k * stride) * 8), pow_tab<C>(bt, k)), fp_load<C>(inv_beta))));
+    fp_store<C>(u + k * 8, fp_neg(fp_mul(fp_mul(fp_load<C>(c + (off + k * stride) * 8), pow_tab<C>(bt, k)), frk_load<C>(inv_beta))));
 }
 template <class C> __global__ void k_dz_unweight(const uint32_t* __restrict__ s, size_t m, size_t off, size_t stride, PowTab it, uint32_t* __restrict__ q) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -534,10 +621,10 @@ template <class C> __global__ void k_dz_unweight(const uint32_t* __restrict__ s,
     fp_store<C>(q + (off + k * stride) * 8, fp_mul(fp_load<C>(s + k * 8), pow_tab<C>(it, k)));
 }
 // many short chains (n large): one lane per residue, sequential along the chain; bad != 0 if a coefficient that must vanish does not
-template <class C> __global__ void k_dz_chain(uint32_t* __restrict__ c, size_t len, uint32_t n, const uint32_t* __restrict__ inv_beta, uint32_t* __restrict__ bad) {
+template <class C> __global__ void k_dz_chain(uint32_t* __restrict__ c, size_t len, uint32_t n, FrK inv_beta, uint32_t* __restrict__ bad) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n || r >= len) return;
-    const Fp<C> ib = fp_load<C>(inv_beta);
+    const Fp<C> ib = frk_load<C>(inv_beta);
     Fp<C> prev = fp_neg(fp_mul(ib, fp_load<C>(c + (size_t)r * 8)));
     fp_store<C>(c + (size_t)r * 8, prev);
     for (size_t i = (size_t)r + n; i < len; i += n) {
@@ -563,9 +650,10 @@ template <class C> struct PlonkOps {
     static HFr F() { return HFr::from_cfg<C>(); }
     static HE he(const uint8_t* p) { HE e; memcpy(e.v, p, 32); return e; }
 
-    static int gather(const void* w, uint32_t nw, const void* in, uint32_t na, const void* ma, const void* mb, const void* mc, uint32_t ncon, uint32_t dom, void* A, void* B, void* Cc) {
+    static int gather(const void* w, uint32_t nw, const void* in, uint32_t na, const void* ma, const void* mb, const void* mc, uint32_t ncon, uint32_t dom, void* A, void* B, void* Cc,
+                      int to_mont = 0) {
         hipLaunchKernelGGL((k_plonk_gather<C>), dim3((dom + 255) / 256), dim3(256), 0, ctx().stream, (const uint32_t*)w, nw, (const uint32_t*)in, na, (const uint32_t*)ma, (const uint32_t*)mb,
-                           (const uint32_t*)mc, ncon, dom, (uint32_t*)A, (uint32_t*)B, (uint32_t*)Cc);
+                           (const uint32_t*)mc, ncon, dom, (uint32_t*)A, (uint32_t*)B, (uint32_t*)Cc, to_mont);
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
@@ -737,50 +825,90 @@ template <class C> struct PlonkOps {
     }
     static int axpy(void* y, const void* x, size_t nx, const uint8_t* k, int subtract) {
         if (!nx) return ZKMI_OK;
-        uint32_t* dk = nullptr;
-        if (k) { std::vector<HE> kv(1, he(k)); ZK_TRY(upload_consts(kv, "plonk.kaxpy", &dk)); }
-        hipLaunchKernelGGL((k_poly_axpy<C>), dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, ctx().stream, (uint32_t*)y, (const uint32_t*)x, nx, dk, subtract);
+        FrK kk = {};
+        if (k) kk = frk(k);
+        hipLaunchKernelGGL((k_poly_axpy<C>), dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, ctx().stream, (uint32_t*)y, (const uint32_t*)x, nx, kk, k ? 1 : 0, subtract);
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
-    static int blind(void* p, size_t n, const uint8_t* factors, int count, int sub) {
-        if (count < 1 || count > 32) return fail(ZKMI_ERR_INVALID, "poly_blind: 1..32 factors");
-        if (sub && n < (size_t)count) return fail(ZKMI_ERR_INVALID, "poly_blind: polynomial shorter than the blinding factors");
-        std::vector<HE> kv(count);
-        for (int i = 0; i < count; i++) kv[i] = he(factors + 32 * i);
-        uint32_t* dk;
-        ZK_TRY(upload_consts(kv, "plonk.kblind", &dk));
-        hipLaunchKernelGGL((k_poly_blind<C>), dim3(1), dim3(64), 0, ctx().stream, (uint32_t*)p, n, dk, count, sub);
+    // mode: k_poly_blind
+    static int blind(void* p, size_t n, const uint8_t* factors, int count, int mode) {
+        if (count < 1 || count > BLIND_MAX) return fail(ZKMI_ERR_INVALID, "poly_blind: 1..8 factors");
+        if (mode && n < (size_t)count) return fail(ZKMI_ERR_INVALID, "poly_blind: polynomial shorter than the blinding factors");
+        BlindArgs a = {};
+        for (int i = 0; i < count; i++) a.f[i] = frk(factors + 32 * i);
+        hipLaunchKernelGGL((k_poly_blind<C>), dim3(1), dim3(64), 0, ctx().stream, (uint32_t*)p, n, a, count, mode);
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
     static int scale(void* p, size_t n, const uint8_t* k) {
         if (!n) return ZKMI_OK;
-        uint32_t* dk;
-        std::vector<HE> kv(1, he(k));
-        ZK_TRY(upload_consts(kv, "plonk.kaxpy", &dk));
-        hipLaunchKernelGGL((k_poly_scale<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, (uint32_t*)p, n, dk);
+        hipLaunchKernelGGL((k_poly_scale<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx().stream, (uint32_t*)p, n, frk(k));
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int lincomb(void* out, size_t out_len, const zkmi_poly_term* terms, int count, const uint8_t* constant) {
+        if (count < 0 || count > LINCOMB_MAX) return fail(ZKMI_ERR_INVALID, "poly_lincomb: at most 16 terms");
+        if (!out_len) return ZKMI_OK;
+        LincombArgs a = {};
+        a.n = (uint32_t)count;
+        for (int j = 0; j < count; j++) {
+            if (terms[j].len > out_len) return fail(ZKMI_ERR_INVALID, "poly_lincomb: a term is longer than the output");
+            if (terms[j].len && !terms[j].d_p) return fail(ZKMI_ERR_INVALID, "null argument");
+            a.p[j] = (const uint32_t*)terms[j].d_p; a.len[j] = terms[j].len;
+            if (terms[j].has_k) { a.k[j] = frk(terms[j].k); a.has_k |= 1u << j; }
+        }
+        if (constant) { a.constant = frk(constant); a.has_const = 1; }
+        hipLaunchKernelGGL((k_poly_lincomb<C>), dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx().stream, a, (uint32_t*)out, out_len);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int split_t(const void* t, size_t t_len, uint32_t dom, const uint8_t* b10, const uint8_t* b11, void* t1, void* t2, void* t3) {
+        hipLaunchKernelGGL((k_plonk_split_t<C>), dim3((dom + 6 + 255) / 256), dim3(256), 0, ctx().stream, (const uint32_t*)t, t_len, dom, frk(b10), frk(b11), (uint32_t*)t1, (uint32_t*)t2,
+                           (uint32_t*)t3);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    static int convert_multi(const void* const* in, void* const* out, const size_t* n, int count, int op) {
+        if (count < 1 || count > 4) return fail(ZKMI_ERR_INVALID, "fr_convert_multi: 1..4 arrays");
+        ConvertMultiArgs a = {};
+        size_t mx = 0;
+        for (int j = 0; j < count; j++) { a.in[j] = (const uint32_t*)in[j]; a.out[j] = (uint32_t*)out[j]; a.n[j] = n[j]; mx = std::max(mx, n[j]); }
+        if (!mx) return ZKMI_OK;
+        hipLaunchKernelGGL((k_fr_convert_multi<C>), dim3((unsigned)((mx + 255) / 256), (unsigned)count), dim3(256), 0, ctx().stream, a, op);
+        ZK_HIP(hipGetLastError());
+        return ZKMI_OK;
+    }
+    // `count` evaluations, ONE wait: partial sums of all of them in one launch, one block per evaluation for the totals, one read-back. Points that repeat share a power table.
+    static int evaluate_multi(const void* const* polys, const size_t* lens, const uint8_t* xs, int count, uint8_t* out) {
+        Ctx& cx = ctx();
+        if (count < 1 || count > EVAL_MAX) return fail(ZKMI_ERR_INVALID, "poly_evaluate_multi: 1..8 evaluations");
+        EvalArgs a = {};
+        uint32_t tot = 0, np_max = 0;
+        size_t n_max = 1;
+        for (int q = 0; q < count; q++) n_max = std::max(n_max, lens[q]);
+        for (int q = 0; q < count; q++) {
+            a.c[q] = (const uint32_t*)polys[q]; a.n[q] = lens[q]; a.x[q] = frk(xs + 32 * q);
+            a.np[q] = (uint32_t)((lens[q] + 256 * EV_K - 1) / (256 * EV_K)); a.off[q] = tot;
+            tot += a.np[q]; np_max = std::max(np_max, a.np[q]);
+            int same = -1;
+            for (int r = 0; r < q && same < 0; r++) if (!memcmp(xs + 32 * r, xs + 32 * q, 32)) same = r;
+            if (same >= 0) a.xt[q] = a.xt[same];
+            else ZK_TRY((build_pow_tab_dyn<C>(he(xs + 32 * q), std::max(1u, clog2(n_max)), "plonk.powe." + std::to_string(q), &a.xt[q])));
+        }
+        uint32_t* part;
+        ZK_TRY(ws_get("plonk.evpart", ((size_t)tot + EVAL_MAX) * 32, (void**)&part));
+        uint32_t* res = part + (size_t)tot * 8;
+        if (np_max) hipLaunchKernelGGL((k_poly_eval_partial<C>), dim3(np_max, (unsigned)count), dim3(256), 0, cx.stream, a, part);
+        hipLaunchKernelGGL((k_poly_sum<C>), dim3((unsigned)count), dim3(256), 0, cx.stream, a, part, res);
+        ZK_HIP(hipMemcpyAsync(out, res, (size_t)count * 32, hipMemcpyDeviceToHost, cx.stream));
+        ZK_HIP(hipStreamSynchronize(cx.stream));
         ZK_HIP(hipGetLastError());
         return ZKMI_OK;
     }
     static int evaluate(const void* p, size_t n, const uint8_t* x, uint8_t* out) {
-        Ctx& cx = ctx();
-        const HFr Fh = F();
         if (!n) { memset(out, 0, 32); return ZKMI_OK; }
-        uint32_t* dx;
-        std::vector<HE> kv(1, he(x));
-        ZK_TRY(upload_consts(kv, "plonk.kev", &dx));
-        PowTab xt;
-        ZK_TRY(build_pow_tab(Fh, he(x), std::max(1u, clog2(n)), "plonk.powe", &xt));
-        const uint32_t np = (uint32_t)((n + 256 * EV_K - 1) / (256 * EV_K));
-        uint32_t* part;
-        ZK_TRY(ws_get("plonk.evpart", ((size_t)np + 1) * 32, (void**)&part));
-        hipLaunchKernelGGL((k_poly_eval_partial<C>), dim3(np), dim3(256), 0, cx.stream, (const uint32_t*)p, n, dx, xt, part);
-        hipLaunchKernelGGL((k_poly_sum<C>), dim3(1), dim3(256), 0, cx.stream, part, np, part + (size_t)np * 8);
-        ZK_HIP(hipMemcpyAsync(out, part + (size_t)np * 8, 32, hipMemcpyDeviceToHost, cx.stream));
-        ZK_HIP(hipStreamSynchronize(cx.stream));
-        ZK_HIP(hipGetLastError());
-        return ZKMI_OK;
+        return evaluate_multi(&p, &n, x, 1, out);
     }
     static int div_zh(void* p, size_t len, uint32_t dom, uint32_t ext) {
         Ctx& cx = ctx();
@@ -795,47 +923,49 @@ template <class C> struct PlonkOps {
         if (nbad) return fail(ZKMI_ERR_INVALID, "Polynomial is not divisible");            // polynomial.js:607-611
         return ZKMI_OK;
     }
-    static int div_by_zerofier(void* p, size_t len, uint32_t n, const uint8_t* beta) {
+    // check = false: enqueue only. The divisibility test of the reference (polynomial.js:665-669) is "the n highest coefficients of the quotient vanish": the caller reads them at its
+    // next synchronisation point (zkmi_poly_is_zero_dev on p[len - n, len)) — two proofs in flight: the host must not wait here.
+    static int div_by_zerofier(void* p, size_t len, uint32_t n, const uint8_t* beta, bool check = true) {
         Ctx& cx = ctx();
         if (n == 0) return fail(ZKMI_ERR_INVALID, "divByZerofier: n must be positive");
         if (!len) return ZKMI_OK;
         const HFr Fh = F();
         const HE b = he(beta), ib = Fh.inv(b);
-        uint32_t *dib, *bad;
-        std::vector<HE> kv(1, ib);
-        ZK_TRY(upload_consts(kv, "plonk.kib", &dib));
+        uint32_t* bad;
         const size_t chain = (len + n - 1) / n;                    // longest chain
         if (n >= 64 || chain <= 64) {
             // many short chains: one lane per residue class
             ZK_TRY(ws_get("plonk.bad", 16, (void**)&bad));
             ZK_HIP(hipMemsetAsync(bad, 0, 16, cx.stream));
-            hipLaunchKernelGGL((k_dz_chain<C>), dim3((n + 255) / 256), dim3(256), 0, cx.stream, (uint32_t*)p, len, n, dib, bad);
+            hipLaunchKernelGGL((k_dz_chain<C>), dim3((n + 255) / 256), dim3(256), 0, cx.stream, (uint32_t*)p, len, n, frk(ib), bad);
+            ZK_HIP(hipGetLastError());
+            if (!check) return ZKMI_OK;
             uint32_t nbad = 0;
             ZK_HIP(hipMemcpyAsync(&nbad, bad, 4, hipMemcpyDeviceToHost, cx.stream));
             ZK_HIP(hipStreamSynchronize(cx.stream));
-            ZK_HIP(hipGetLastError());
             if (nbad) return fail(ZKMI_ERR_INVALID, "Polynomial is not divisible");
             return ZKMI_OK;
         }
         // few long chains: each residue class r is the linear recurrence q_k = (q_{k-1} - c_k)/beta, solved as a prefix sum
         PowTab bt, it;
-        ZK_TRY(build_pow_tab(Fh, b, std::max(1u, clog2(chain)), "plonk.powb", &bt));
-        ZK_TRY(build_pow_tab(Fh, ib, std::max(1u, clog2(chain)), "plonk.powib", &it));
+        ZK_TRY((build_pow_tab_dyn<C>(b, std::max(1u, clog2(chain)), "plonk.powb", &bt)));
+        ZK_TRY((build_pow_tab_dyn<C>(ib, std::max(1u, clog2(chain)), "plonk.powib", &it)));
         uint32_t* u;
         ZK_TRY(ws_get("plonk.dzu", chain * 32, (void**)&u));
         for (uint32_t r = 0; r < n && r < len; r++) {
             const size_t m = (len - r + n - 1) / n;
             const unsigned blocks = (unsigned)((m + 255) / 256);
-            hipLaunchKernelGGL((k_dz_weight<C>), dim3(blocks), dim3(256), 0, cx.stream, (const uint32_t*)p, m, (size_t)r, (size_t)n, bt, dib, u);
+            hipLaunchKernelGGL((k_dz_weight<C>), dim3(blocks), dim3(256), 0, cx.stream, (const uint32_t*)p, m, (size_t)r, (size_t)n, bt, frk(ib), u);
             ZK_TRY((scan_inclusive<C, false>(u, m, u)));
             hipLaunchKernelGGL((k_dz_unweight<C>), dim3(blocks), dim3(256), 0, cx.stream, u, m, (size_t)r, (size_t)n, it, (uint32_t*)p);
         }
+        ZK_HIP(hipGetLastError());
+        if (!check) return ZKMI_OK;
         // the n highest coefficients must vanish (polynomial.js:665-669)
         const size_t tail = std::min<size_t>(n, len);
         std::vector<HE> last(tail);
         ZK_HIP(hipMemcpyAsync(last.data(), (uint8_t*)p + (len - tail) * 32, tail * 32, hipMemcpyDeviceToHost, cx.stream));
         ZK_HIP(hipStreamSynchronize(cx.stream));
-        ZK_HIP(hipGetLastError());
         for (const HE& e : last) if (!e.is_zero()) return fail(ZKMI_ERR_INVALID, "Polynomial is not divisible");
         return ZKMI_OK;
     }
@@ -849,6 +979,14 @@ template <class C> struct PlonkOps {
         return ZKMI_OK;
     }
 };
+
+int fr_convert_multi_dispatch(int curve, int op, const void* const* d_in, void* const* d_out, const size_t* ns, int count) {
+    if (op != ZKMI_BATCH_TO_MONTGOMERY && op != ZKMI_BATCH_FROM_MONTGOMERY) return fail(ZKMI_ERR_UNSUPPORTED, "fr_batch_multi: the two Montgomery conversions only");
+    const int o = op == ZKMI_BATCH_TO_MONTGOMERY ? 0 : 1;
+    if (curve == ZKMI_CURVE_BN128) return PlonkOps<Bn254Fr>::convert_multi(d_in, d_out, ns, count, o);
+    if (curve == ZKMI_CURVE_BLS12381) return PlonkOps<Bls12381Fr>::convert_multi(d_in, d_out, ns, count, o);
+    return fail(ZKMI_ERR_INVALID, "unknown curve");
+}
 
 }  // namespace zkmi
 
@@ -940,6 +1078,28 @@ int zkmi_plonk_compute_t_dev(int curve, const zkmi_plonk_evals* ev, uint32_t dom
 int zkmi_poly_axpy_dev(int curve, void* d_y, const void* d_x, size_t nx, const uint8_t* k, int subtract) { PLONK_DISPATCH(curve, axpy(d_y, d_x, nx, k, subtract)); }
 int zkmi_poly_scale_dev(int curve, void* d_p, size_t n, const uint8_t* k) { PLONK_DISPATCH(curve, scale(d_p, n, k)); }
 int zkmi_poly_blind_dev(int curve, void* d_p, size_t n, const uint8_t* factors, int count) { PLONK_DISPATCH(curve, blind(d_p, n, factors, count, 1)); }
+int zkmi_poly_blind_tail_dev(int curve, void* d_p, size_t n, const uint8_t* factors, int count) { PLONK_DISPATCH(curve, blind(d_p, n, factors, count, 2)); }
+int zkmi_poly_lincomb_dev(int curve, void* d_out, size_t out_len, const zkmi_poly_term* terms, int count, const uint8_t* constant) {
+    if (!d_out || (count && !terms)) return fail(ZKMI_ERR_INVALID, "null argument");
+    PLONK_DISPATCH(curve, lincomb(d_out, out_len, terms, count, constant));
+}
+int zkmi_poly_evaluate_multi_dev(int curve, const void* const* d_polys, const size_t* lens, const uint8_t* xs, int count, uint8_t* out) {
+    if (!d_polys || !lens || !xs || !out) return fail(ZKMI_ERR_INVALID, "null argument");
+    PLONK_DISPATCH(curve, evaluate_multi(d_polys, lens, xs, count, out));
+}
+int zkmi_plonk_split_t_dev(int curve, const void* d_t, size_t t_len, uint32_t domain, const uint8_t* b10, const uint8_t* b11, void* d_t1, void* d_t2, void* d_t3) {
+    if (!d_t || !b10 || !b11 || !d_t1 || !d_t2 || !d_t3) return fail(ZKMI_ERR_INVALID, "null argument");
+    PLONK_DISPATCH(curve, split_t(d_t, t_len, domain, b10, b11, d_t1, d_t2, d_t3));
+}
+int zkmi_fr_batch_multi_dev(int curve, int op, const void* const* d_in, void* const* d_out, const size_t* ns, int count) {
+    if (!d_in || !d_out || !ns) return fail(ZKMI_ERR_INVALID, "null argument");
+    ZK_TRY(require_ctx());
+    return fr_convert_multi_dispatch(curve, op, d_in, d_out, ns, count);
+}
+int zkmi_plonk_gather_wires_mont_dev(int curve, const void* d_witness, uint32_t n_witness, const void* d_internal, uint32_t n_additions, const void* d_map_a, const void* d_map_b,
+                                     const void* d_map_c, uint32_t n_constraints, uint32_t domain, void* d_a, void* d_b, void* d_c) {
+    PLONK_DISPATCH(curve, gather(d_witness, n_witness, d_internal, n_additions, d_map_a, d_map_b, d_map_c, n_constraints, domain, d_a, d_b, d_c, 1));
+}
 int zkmi_poly_add_scalar_dev(int curve, void* d_p, const uint8_t* value) { PLONK_DISPATCH(curve, blind(d_p, 0, value, 1, 0)); }
 int zkmi_poly_evaluate_dev(int curve, const void* d_p, size_t n, const uint8_t* x, uint8_t* out) { PLONK_DISPATCH(curve, evaluate(d_p, n, x, out)); }
 int zkmi_poly_is_zero_dev(int curve, const void* d_p, size_t n, int* all_zero) {
@@ -988,6 +1148,7 @@ int zkmi_fflonk_t2_dev(int curve, const zkmi_plonk_evals* ev, uint32_t domain, c
 }
 int zkmi_poly_div_zh_dev(int curve, void* d_p, size_t len, uint32_t domain, uint32_t extensions) { PLONK_DISPATCH(curve, div_zh(d_p, len, domain, extensions)); }
 int zkmi_poly_div_by_zerofier_dev(int curve, void* d_p, size_t len, uint32_t n, const uint8_t* beta) { PLONK_DISPATCH(curve, div_by_zerofier(d_p, len, n, beta)); }
+int zkmi_poly_div_by_zerofier_enqueue(int curve, void* d_p, size_t len, uint32_t n, const uint8_t* beta) { PLONK_DISPATCH(curve, div_by_zerofier(d_p, len, n, beta, false)); }
 int zkmi_cpoly_interleave_dev(int curve, const void* const* d_polys, const size_t* lens, int n, void* d_out, size_t out_len) {
     if (!d_polys || !lens) return fail(ZKMI_ERR_INVALID, "null argument");
     PLONK_DISPATCH(curve, interleave(d_polys, lens, n, d_out, out_len));

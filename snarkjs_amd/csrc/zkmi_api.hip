@@ -494,6 +494,21 @@ int zkmi_msm_table_multi_enqueue_dev(uint64_t handle, const void* const* d_scala
     return t.curve == ZKMI_CURVE_BN128 ? msm_table_multi_enqueue_bn254(t.group, t.p, t.n, t.c, d_scalars, ks, count, scalar_bytes)
                                        : msm_table_multi_enqueue_bls12381(t.group, t.p, t.n, t.c, d_scalars, ks, count, scalar_bytes);
 }
+int zkmi_msm_table_multi_enqueue_mont_dev(uint64_t handle, const void* const* d_polys, const size_t* ks, int count) {
+    ZK_TRY(require_ctx());
+    auto it = g_tables.find(handle);
+    if (it == g_tables.end()) return fail(ZKMI_ERR_INVALID, "msm_table_multi_enqueue_mont_dev: unknown table");
+    const MsmTable& t = it->second;
+    if (!d_polys || !ks) return fail(ZKMI_ERR_INVALID, "null argument");
+    if (count < 1 || count > 4) return fail(ZKMI_ERR_INVALID, "msm_table_multi: 1..4 MSMs per call");
+    void* sc[4] = {};
+    for (int i = 0; i < count; i++) {
+        if (ks[i] > t.n) return fail(ZKMI_ERR_INVALID, "msm_table_multi_enqueue_mont_dev: more scalars than resident bases");
+        if (ks[i]) ZK_TRY(ws_get("msm.commit_sc." + std::to_string(i), ks[i] * 32, &sc[i]));
+    }
+    ZK_TRY(fr_convert_multi_dispatch(t.curve, ZKMI_BATCH_FROM_MONTGOMERY, d_polys, sc, ks, count));
+    return t.curve == ZKMI_CURVE_BN128 ? msm_table_multi_enqueue_bn254(t.group, t.p, t.n, t.c, sc, ks, count, 32) : msm_table_multi_enqueue_bls12381(t.group, t.p, t.n, t.c, sc, ks, count, 32);
+}
 int zkmi_msm_table_multi_collect(uint64_t handle, int count, uint8_t* out_jacobians) {
     ZK_TRY(require_ctx());
     auto it = g_tables.find(handle);
@@ -835,6 +850,11 @@ int zkmi_base_cache_stats(uint64_t* n_tables, uint64_t* table_bytes, uint64_t* n
 int zkmi_ntt_dev(int curve, const void* d_in, void* d_out, unsigned log_n, int inverse, const uint8_t* first, const uint8_t* inc) {
     ZK_TRY(require_ctx());
     return ntt_dev_dispatch(curve, d_in, d_out, log_n, inverse, first, inc);
+}
+int zkmi_ntt_padded_dev(int curve, const void* d_in, size_t in_len, void* d_out, unsigned log_n, int inverse) {
+    ZK_TRY(require_ctx());
+    if (!d_in || !d_out) return fail(ZKMI_ERR_INVALID, "null argument");
+    return ntt_dev_padded_dispatch(curve, d_in, in_len, d_out, log_n, inverse);
 }
 int zkmi_ntt(int curve, zkmi_pages in, uint8_t* const* out_ptr, const size_t* out_len, int n_out, unsigned log_n, int inverse,
              const uint8_t* first, const uint8_t* inc) {

@@ -105,6 +105,9 @@ int ntt_dev_dispatch(int curve, const void* d_in, void* d_out, unsigned log_n, i
 // `batch` transforms of one size per launch: member k at d_in + k*in_stride / d_out + k*out_stride ELEMENTS
 int ntt_dev_batch_dispatch(int curve, const void* d_in, size_t in_stride, void* d_out, size_t out_stride, unsigned batch, unsigned log_n, int inverse, const uint8_t* first,
                            const uint8_t* inc);
+int ntt_dev_padded_dispatch(int curve, const void* d_in, size_t in_len, void* d_out, unsigned log_n, int inverse);
+// Fr.batchTo/FromMontgomery on up to four arrays in one launch (plonk.hip)
+int fr_convert_multi_dispatch(int curve, int op, const void* const* d_in, void* const* d_out, const size_t* ns, int count);
 int apply_key_dev_dispatch(int curve, const void* d_in, void* d_out, size_t n, const uint8_t* first, const uint8_t* inc);
 int fr_batch_dev_dispatch(int curve, int op, const void* d_in, void* d_out, size_t n);
 int join_abc_dev_dispatch(int curve, const void* a, const void* b, const void* c, void* out, size_t n);

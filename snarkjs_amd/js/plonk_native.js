@@ -89,7 +89,36 @@ class Poly {
     }
     ntt(inverse, out = null) { out = out || new Poly(this.f, this.n, false); call("zkmi_ntt_dev", this.f.cid, this.ptr, out.ptr, Math.log2(this.n), inverse ? 1 : 0, null, null); return out; }
     extendedEvals(ext) { const e = new Poly(this.f, this.n * ext).copyFrom(this.ptr, this.n); return e.ntt(false, e); }   // Evaluations.fromPolynomial
+    // The pattern of rounds 1 and 2 (plonk_prove.js:285-311, :441-455): coefficients = ifft(this) into a buffer with room for the blinding tail, Evaluations.fromPolynomial(.., 4)
+    // with the zero padding READ instead of written (zkmi_ntt_padded_dev), blindCoefficients in place (zkmi_poly_blind_tail_dev) -> [blinded polynomial, 4n evaluations]
+    ifftBlinded(factors) {
+        const f = this.f, n = this.n, out = new Poly(f, n + factors.length, false), ev = new Poly(f, 4 * n, false);
+        call("zkmi_ntt_dev", f.cid, this.ptr, out.ptr, Math.log2(n), 1, null, null);
+        call("zkmi_ntt_padded_dev", f.cid, out.ptr, n, ev.ptr, Math.log2(4 * n), 0);
+        const fb = new Uint8Array(32 * factors.length);
+        factors.forEach((x, i) => fb.set(f.mont(x), 32 * i));
+        call("zkmi_poly_blind_tail_dev", f.cid, out.ptr, n, fb, factors.length);
+        return [out, ev];
+    }
     free() { devFree(this.ptr); this.ptr = 0; }
+}
+// out[i] = sum_j k_j p_j[i] + (i == 0 ? constant : 0) in one launch (zkmi_poly_lincomb_dev). terms: [device pointer, length, k | null]; a zkmi_poly_term is 56 bytes:
+// pointer and length as 64-bit little-endian integers, k (32 Montgomery bytes), has_k, reserved
+function lincomb(f, out, terms, constant = null) {
+    const buf = new Uint8Array(56 * terms.length), dv = new DataView(buf.buffer);
+    terms.forEach(([ptr, len, k], j) => {
+        dv.setBigUint64(56 * j, BigInt(ptr), true); dv.setBigUint64(56 * j + 8, BigInt(len), true);
+        if (k !== null) { buf.set(f.mont(k), 56 * j + 16); dv.setUint32(56 * j + 48, 1, true); }
+    });
+    call("zkmi_poly_lincomb_dev", f.cid, out.ptr, out.n, buf, terms.length, constant === null ? null : f.mont(constant));
+    return out;
+}
+// [p(x)] for [device pointer, length] pairs and points, one wait (zkmi_poly_evaluate_multi_dev)
+function evaluateMany(f, polys, xs) {
+    const cnt = polys.length, xb = new Uint8Array(32 * cnt), out = new Uint8Array(32 * cnt);
+    xs.forEach((x, i) => xb.set(f.mont(x), 32 * i));
+    call("zkmi_poly_evaluate_multi_dev", f.cid, new BigUint64Array(polys.map(([p]) => BigInt(p))), new BigUint64Array(polys.map(([, n]) => BigInt(n))), xb, cnt, out);
+    return polys.map((_, i) => f.unmont(out.subarray(32 * i, 32 * i + 32)));
 }
 
 function readSections(data) {
@@ -146,34 +175,30 @@ class Transcript {                                          // src/Keccak256Tran
     }
 }
 
-// Polynomial.multiExponentiation (polynomial.js:970-977) for the commitments of one round: batchFromMontgomery of every polynomial (enqueued), ONE
-// call for up to four MSMs against the resident SRS table (the host waits here), toAffine on the host
-function commitScalars(key, polys) { return polys.map((p) => { const sc = devAlloc(p.n * 32); call("zkmi_fr_batch_dev", key.f.cid, 1, p.ptr, sc, p.n); return sc; }); }
-function commitPoints(key, polys, scs, jac) {
+// Polynomial.multiExponentiation (polynomial.js:970-977) for the commitments of one round: batchFromMontgomery of the round's polynomials (one launch) and up to four MSMs
+// against the resident SRS table are ENQUEUED by one call (zkmi_msm_table_multi_enqueue_mont_dev); the collect waits for them; toAffine on the host
+function commitPoints(key, count, jac) {
     const f = key.f, out = [];
-    for (let i = 0; i < polys.length; i++) {
+    for (let i = 0; i < count; i++) {
         const aff = new Uint8Array(2 * f.n8q);
         call("zkmi_to_affine", f.cid, 1, jac.slice(i * 3 * f.n8q, (i + 1) * 3 * f.n8q), aff);
         out.push([f.unmontQ(aff.subarray(0, f.n8q)), f.unmontQ(aff.subarray(f.n8q))]);
     }
-    scs.forEach(devFree);
     return out;
 }
-function commit(key, polys) {
-    const scs = commitScalars(key, polys);
-    return commitPoints(key, polys, scs, addon.msmTableMultiDev(key.ptauTable, scs, polys.map((p) => p.n), 32));
-}
-// the same in two halves for proveMany (r06): enqueue on the proof's own pipeline slot, collect at its next turn — the other proof's next segment, its commitments
-// included, is enqueued in between and runs underneath this round's latency-bound reduction tail
+// two halves (r06): enqueue on the proof's own pipeline slot, collect at its next turn — in proveMany the other proof's next segment, its commitments included, is enqueued in
+// between and runs underneath this round's latency-bound reduction tail
 function commitEnqueue(key, polys) {
-    const scs = commitScalars(key, polys);
-    addon.msmTableMultiEnqueueDev(key.ptauTable, scs, polys.map((p) => p.n), 32);
-    return { polys, scs };
+    addon.msmTableMultiEnqueueMontDev(key.ptauTable, polys.map((p) => p.ptr), polys.map((p) => p.n));
+    return { polys };
 }
-const commitCollect = (key, st) => commitPoints(key, st.polys, st.scs, addon.msmTableMultiCollect(key.ptauTable, st.polys.length));
+const commitCollect = (key, st) => commitPoints(key, st.polys.length, addon.msmTableMultiCollect(key.ptauTable, st.polys.length));
+const commit = (key, polys) => commitCollect(key, commitEnqueue(key, polys));
 async function commitAsync(key, polys, slot) {
-    const scs = commitScalars(key, polys);
-    return commitPoints(key, polys, scs, await addon.msmTableMultiDevAsync(key.ptauTable, scs, polys.map((p) => p.n), 32, slot));
+    const st = commitEnqueue(key, polys);
+    await addon.synchronizeAsync(slot);                                  // the wait, on a libuv pool thread
+    call("zkmi_pipeline_select", slot);
+    return commitCollect(key, st);                                       // everything is finished: folds the window sums
 }
 // A proof is a generator (proveSteps): it yields right before each of its long blocking calls. `yield { commit: [polys] }` asks the driver for the
 // commitments of a round and receives the points; a bare `yield` stands before a read-back that waits for everything queued so far.
@@ -254,7 +279,7 @@ function proveMany(zkey, wtnsList, blindingMonts = null, options = null) {
         }
     } finally {
         for (const ent of live.slice()) {                  // an error in one proof: drop the other one too, leave no queued work behind
-            try { call("zkmi_pipeline_select", ent.slot); ent.steps.return(); call("zkmi_synchronize"); if (ent.pending) ent.pending.scs.forEach(devFree); ent.polys.forEach((p) => p.free()); } catch (e) { /* already failing */ }
+            try { call("zkmi_pipeline_select", ent.slot); ent.steps.return(); call("zkmi_synchronize"); ent.polys.forEach((p) => p.free()); } catch (e) { /* already failing */ }
         }
         call("zkmi_pipeline_select", 0);
         if (!(zkey instanceof PlonkKey)) key.release();
@@ -279,11 +304,8 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         const internal = P(Math.max(key.nAdditions, 1), false), dInt = internal.ptr;
         if (key.nAdditions) call("zkmi_plonk_additions_dev", f.cid, key.sec(3), key.nAdditions, dWit, nW, dInt);
         const A = P(n, false), B = P(n, false), Cw = P(n, false);
-        call("zkmi_plonk_gather_wires_dev", f.cid, dWit, nW, dInt, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n, A.ptr, B.ptr, Cw.ptr);
-        for (const p of [A, B, Cw]) call("zkmi_fr_batch_dev", f.cid, 0, p.ptr, p.ptr, n);                  // batchToMontgomery
-        let pA = track(A.ntt(true)), pB = track(B.ntt(true)), pC = track(Cw.ntt(true));
-        const eA = track(pA.extendedEvals(4)), eB = track(pB.extendedEvals(4)), eC = track(pC.extendedEvals(4));
-        pA = track(pA.blinded([b[2], b[1]])); pB = track(pB.blinded([b[4], b[3]])); pC = track(pC.blinded([b[6], b[5]]));
+        call("zkmi_plonk_gather_wires_mont_dev", f.cid, dWit, nW, dInt, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n, A.ptr, B.ptr, Cw.ptr);   // buffers + batchToMontgomery in one pass
+        const [pA, eA] = A.ifftBlinded([b[2], b[1]]).map(track), [pB, eB] = B.ifftBlinded([b[4], b[3]]).map(track), [pC, eC] = Cw.ifftBlinded([b[6], b[5]]).map(track);
         [pts.A, pts.B, pts.C] = yield { commit: [pA, pB, pC] };
 
         // ---- ROUND 2 (:315-455)
@@ -296,9 +318,7 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         const gamma = tr.challenge();
         const Zb = P(n, false);
         call("zkmi_plonk_compute_z_enqueue", f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), n, mont(beta), mont(gamma), mont(key.k1), mont(key.k2), wN, Zb.ptr);
-        let pZ = track(Zb.ntt(true));
-        const eZ = track(pZ.extendedEvals(4));
-        pZ = track(pZ.blinded([b[9], b[8], b[7]]));
+        const [pZ, eZ] = Zb.ifftBlinded([b[9], b[8], b[7]]).map(track);
         [pts.Z] = yield { commit: [pZ] };
         if (Zb.get(0) !== 1n) throw new Error("Copy constraints does not match");                        // computeZ's check (:437-439), read behind the commitment's own wait
 
@@ -316,20 +336,18 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         pT.axpy(pTz);
         yield;
         if (!pT.tailIsZero(3 * n + 6)) throw new Error("T Polynomial is not well calculated");            // :645-647
-        const T1 = P(n + 1).copyFrom(pT.at(0), n), T2 = P(n + 1).copyFrom(pT.at(n), n), T3 = P(n + 6).copyFrom(pT.at(2 * n), n + 6);
-        T1.set(n, b[10]);
-        T2.set(0, mod(T2.get(0) - b[10], r)); T2.set(n, b[11]);
-        T3.set(0, mod(T3.get(0) - b[11], r));
+        const T1 = P(n + 1, false), T2 = P(n + 1, false), T3 = P(n + 6, false);
+        call("zkmi_plonk_split_t_dev", f.cid, pT.ptr, 4 * n, n, mont(b[10]), mont(b[11]), T1.ptr, T2.ptr, T3.ptr);                                     // :649-672 in one launch
         [pts.T1, pts.T2, pts.T3] = yield { commit: [T1, T2, T3] };
 
         // ---- ROUND 4 (:686-708)
         tr.reset(); tr.scalar(alpha);
         for (const nm of ["T1", "T2", "T3"]) tr.point(pts[nm]);
         const xi = tr.challenge(), wv = f.unmont(wN), xiw = xi * wv % r;
-        const S1c = P(n, false).copyFrom(key.sec(12, 0), n), S2c = P(n, false).copyFrom(key.sec(12, 5 * n), n), S3c = P(n, false).copyFrom(key.sec(12, 10 * n), n);
+        const S1 = key.sec(12, 0), S2 = key.sec(12, 5 * n), S3 = key.sec(12, 10 * n);                      // the coefficient halves of the sigma section, read where they lie
         yield;
-        evs.eval_a = pA.evaluate(xi); evs.eval_b = pB.evaluate(xi); evs.eval_c = pC.evaluate(xi);
-        evs.eval_s1 = S1c.evaluate(xi); evs.eval_s2 = S2c.evaluate(xi); evs.eval_zw = pZ.evaluate(xiw);
+        [evs.eval_a, evs.eval_b, evs.eval_c, evs.eval_s1, evs.eval_s2, evs.eval_zw] =
+            evaluateMany(f, [[pA.ptr, pA.n], [pB.ptr, pB.n], [pC.ptr, pC.n], [S1, n], [S2, n], [pZ.ptr, pZ.n]], [xi, xi, xi, xi, xi, xiw]);               // six evaluations, one wait
 
         // ---- ROUND 5 (:710-888)
         tr.reset(); tr.scalar(xi);
@@ -348,27 +366,21 @@ function* proveSteps(key, wt, blindingMont, P, track) {
         const e2 = (ea + betaxi + gamma) * (eb + betaxi * key.k1 + gamma) % r * (ec + betaxi * key.k2 + gamma) % r * alpha % r;
         const e3 = (ea + beta * es1 + gamma) * (eb + beta * es2 + gamma) % r * ezw % r * alpha % r;
         const e4 = evalL1 * alpha2 % r;
-        const Rp = P(n + 6);
-        for (const [t, k] of [[7, ea * eb % r], [8, ea], [9, eb], [10, ec], [11, null]]) { const qp = new Poly(f, n, false).copyFrom(key.sec(t, 0), n); Rp.axpy(qp, k); qp.free(); }
-        Rp.axpy(pZ, e2);
-        Rp.axpy(S3c, e3 * beta % r, true);
-        Rp.axpy(pZ, e4);
-        const tmp = P(n + 6).copyFrom(T3.ptr, n + 6);
-        tmp.scale(xin * xin % r);
-        tmp.axpy(T2, xin);
-        tmp.axpy(T1);
-        tmp.scale(zh);
-        Rp.axpy(tmp, null, true);
-        Rp.addScalar(mod(evalPi - e3 * mod(ec + gamma, r) - e4, r));
-        const Wxi = P(n + 6);
-        Wxi.axpy(Rp);
-        for (const [p, k] of [[pA, v[1]], [pB, v[2]], [pC, v[3]], [S1c, v[4]], [S2c, v[5]]]) Wxi.axpy(p, k);
-        Wxi.addScalar(mod(-(v[1] * ea + v[2] * eb + v[3] * ec + v[4] * es1 + v[5] * es2), r));
-        call("zkmi_poly_div_by_zerofier_dev", f.cid, Wxi.ptr, Wxi.n, 1, mont(xi));
-        const Wxiw = P(pZ.n, false).copyFrom(pZ.ptr, pZ.n);
-        Wxiw.addScalar(mod(-ezw, r));
-        call("zkmi_poly_div_by_zerofier_dev", f.cid, Wxiw.ptr, Wxiw.n, 1, mont(xiw));
+        // The linearisation polynomial R (:769-838) and the opening numerator Wxi = R + v1 (A - a) + ... (:840-866) are ONE linear combination of fifteen resident polynomials:
+        // a single launch (zkmi_poly_lincomb_dev) instead of 18 add / sub, 2 mulScalar and 5 copies of selector polynomials; exact arithmetic, same coefficients
+        const zhN = mod(-zh, r), xin2 = xin * xin % r;
+        const r0 = mod(evalPi - e3 * mod(ec + gamma, r) - e4, r);
+        const Wxi = lincomb(f, P(n + 6, false), [
+            [key.sec(7, 0), n, ea * eb % r], [key.sec(8, 0), n, ea], [key.sec(9, 0), n, eb], [key.sec(10, 0), n, ec], [key.sec(11, 0), n, null],
+            [pZ.ptr, pZ.n, (e2 + e4) % r], [S3, n, mod(-(e3 * beta), r)],
+            [T1.ptr, T1.n, zhN], [T2.ptr, T2.n, zhN * xin % r], [T3.ptr, T3.n, zhN * xin2 % r],
+            [pA.ptr, pA.n, v[1]], [pB.ptr, pB.n, v[2]], [pC.ptr, pC.n, v[3]], [S1, n, v[4]], [S2, n, v[5]]],
+            mod(r0 - (v[1] * ea + v[2] * eb + v[3] * ec + v[4] * es1 + v[5] * es2), r));
+        call("zkmi_poly_div_by_zerofier_enqueue", f.cid, Wxi.ptr, Wxi.n, 1, mont(xi));
+        const Wxiw = lincomb(f, P(pZ.n, false), [[pZ.ptr, pZ.n, null]], mod(-ezw, r));
+        call("zkmi_poly_div_by_zerofier_enqueue", f.cid, Wxiw.ptr, Wxiw.n, 1, mont(xiw));
         [pts.Wxi, pts.Wxiw] = yield { commit: [Wxi, Wxiw] };
+        if (!(Wxi.tailIsZero(Wxi.n - 1) && Wxiw.tailIsZero(Wxiw.n - 1))) throw new Error("Polynomial is not divisible");   // divByZerofier's test (polynomial.js:665-669), read behind the commitments' wait
 
         const proof = {};
         for (const nm of ["A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"]) proof[nm] = [pts[nm][0].toString(), pts[nm][1].toString(), "1"];   // src/proof.js:61-83
@@ -406,4 +418,4 @@ class PlonkWitness {
 }
 
 module.exports = { prove, proveAsync, proveMany, PlonkKey, PlonkWitness,
-                   _internals: { addon, call, bindDevice, Field, Poly, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN, Q_BLS } };
+                   _internals: { addon, call, bindDevice, Field, Poly, lincomb, evaluateMany, Transcript, readSections, devAlloc, devFree, devFrom, mod, modinv, modpow, toLE, fromLE, Q_BN, Q_BLS } };

@@ -704,6 +704,24 @@ static napi_value js_msm_table_multi_enqueue_dev(napi_env env, napi_callback_inf
     if (rc) return throw_zkmi(env, rc);
     return NULL;
 }
+/* msmTableMultiEnqueueMontDev(handle, [dPolys...], [k...]): the same for Montgomery coefficient arrays — their batchFromMontgomery (one launch for the round) and the MSMs
+ * (zkmi_msm_table_multi_enqueue_mont_dev); collected by msmTableMultiCollect */
+static napi_value js_msm_table_multi_enqueue_mont_dev(napi_env env, napi_callback_info info) {
+    ARGS(3);
+    double h; uint32_t cnt = 0, cnt2 = 0;
+    bool a0 = false, a1 = false;
+    if (get_f64(env, argv[0], &h) || napi_is_array(env, argv[1], &a0) != napi_ok || !a0 || napi_is_array(env, argv[2], &a1) != napi_ok || !a1 ||
+        napi_get_array_length(env, argv[1], &cnt) != napi_ok || napi_get_array_length(env, argv[2], &cnt2) != napi_ok || cnt != cnt2 || cnt < 1 || cnt > 4) BAD_ARG();
+    const void* ptrs[4]; size_t ks[4];
+    for (uint32_t i = 0; i < cnt; i++) {
+        napi_value e; void* p; double k;
+        if (napi_get_element(env, argv[1], i, &e) != napi_ok || get_dptr(env, e, &p) || napi_get_element(env, argv[2], i, &e) != napi_ok || get_f64(env, e, &k) || k < 0) BAD_ARG();
+        ptrs[i] = p; ks[i] = (size_t)k;
+    }
+    int rc = ZK_CALL(zkmi_msm_table_multi_enqueue_mont_dev((uint64_t)h, ptrs, ks, (int)cnt));
+    if (rc) return throw_zkmi(env, rc);
+    return NULL;
+}
 static napi_value js_msm_table_multi_collect(napi_env env, napi_callback_info info) {
     ARGS(2);
     double h; int32_t cnt; int curve, group;
@@ -824,7 +842,8 @@ static napi_value js_groth16_key_curve(napi_env env, napi_callback_info info) {
  * integer, a device pointer or a host buffer). Only the entry points listed below can be reached, and every argument is checked against the
  * kind the C prototype expects before the call is made:
  *   i  integer (a JS number)                       d  device pointer (a JS number; null / 0 where the prototype allows NULL)
- *   bN host buffer (typed array) of at least N bytes; b@K: at least as many bytes as the integer argument K; BN / B@K: the same, or null
+ *   bN host buffer (typed array) of at least N bytes; b@K: at least as many bytes as the integer argument K; b*K:N: at least N bytes per unit of the integer argument K
+ *   (arrays of `count` records); BN / B@K: the same, or null
  * Used by js/plonk_native.js and js/fflonk_native.js, which drive the device-resident provers from Node the way snarkjs_amd/plonk.py does
  * from Python. Throws Error(zkmi_last_error()) on a non-zero return. */
 typedef int (*zk_fn16)(uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t,
@@ -844,6 +863,10 @@ static const struct { const char* name; const char* sig; } g_call_table[] = {
     {"zkmi_poly_axpy_dev", "i d d i B32 i"}, {"zkmi_poly_scale_dev", "i d i b32"}, {"zkmi_poly_blind_dev", "i d i b32 i"}, {"zkmi_poly_add_scalar_dev", "i d b32"},
     {"zkmi_poly_evaluate_dev", "i d i b32 b32"}, {"zkmi_poly_is_zero_dev", "i d i b4"}, {"zkmi_poly_div_zh_dev", "i d i i i"}, {"zkmi_poly_div_by_zerofier_dev", "i d i i b32"},
     {"zkmi_cpoly_interleave_dev", "i b8 b8 i d i"}, {"zkmi_to_affine", "i i b96 b64"},
+    /* r06: fused forms (one launch where the calls above take a chain of them) */
+    {"zkmi_plonk_gather_wires_mont_dev", "i d i d i d d d i i d d d"}, {"zkmi_ntt_padded_dev", "i d i d i i"}, {"zkmi_poly_blind_tail_dev", "i d i b*4:32 i"},
+    {"zkmi_poly_lincomb_dev", "i d i b*4:56 i B32"}, {"zkmi_poly_evaluate_multi_dev", "i b*4:8 b*4:8 b*4:32 i b*4:32"}, {"zkmi_poly_div_by_zerofier_enqueue", "i d i i b32"},
+    {"zkmi_plonk_split_t_dev", "i d i i b32 b32 d d d"},
 };
 static void* zk_lib_handle(void) {
     static void* h = NULL;
@@ -867,13 +890,15 @@ static napi_value js_call(napi_env env, napi_callback_info info) {
     if (!fn) { napi_throw_error(env, NULL, "zkmi.call: no such entry point"); return NULL; }
     uintptr_t a[16] = {0};
     size_t blen[16] = {0};
-    struct { int arg; int ref; } at_checks[16];
+    struct { int arg; int ref; size_t mul; } at_checks[16];
     int n_at = 0;
     size_t k = 0;
     for (const char* c = sig; *c; k++) {
         const char kind = *c++;
-        size_t min_len = 0; int ref = -1;
-        if (*c == '@') { c++; ref = (int)strtol(c, (char**)&c, 10); } else if (*c >= '0' && *c <= '9') min_len = (size_t)strtol(c, (char**)&c, 10);
+        size_t min_len = 0, mul = 1; int ref = -1;
+        if (*c == '@') { c++; ref = (int)strtol(c, (char**)&c, 10); }
+        else if (*c == '*') { c++; ref = (int)strtol(c, (char**)&c, 10); if (*c == ':') { c++; mul = (size_t)strtol(c, (char**)&c, 10); } }
+        else if (*c >= '0' && *c <= '9') min_len = (size_t)strtol(c, (char**)&c, 10);
         while (*c == ' ') c++;
         if (k + 1 >= argc || k >= 16) { napi_throw_type_error(env, NULL, "zkmi.call: too few arguments for this entry point"); return NULL; }
         napi_valuetype t;
@@ -885,7 +910,7 @@ static napi_value js_call(napi_env env, napi_callback_info info) {
             if (t != napi_number || napi_get_value_double(env, argv[k + 1], &d) != napi_ok || (kind == 'd' && (d < 0 || d > 9007199254740992.0))) BAD_ARG();
             a[k] = (uintptr_t)(int64_t)d;
         } else {                                            /* b / B */
-            if (is_null) { if (kind != 'B') BAD_ARG(); a[k] = 0; blen[k] = 0; if (ref >= 0) { at_checks[n_at].arg = (int)k; at_checks[n_at++].ref = ref; } continue; }
+            if (is_null) { if (kind != 'B') BAD_ARG(); a[k] = 0; blen[k] = 0; if (ref >= 0) { at_checks[n_at].arg = (int)k; at_checks[n_at].mul = mul; at_checks[n_at++].ref = ref; } continue; }
             bool is_ta = false;
             if (napi_is_typedarray(env, argv[k + 1], &is_ta) != napi_ok || !is_ta) BAD_ARG();
             napi_typedarray_type tt; size_t len; void* data; napi_value ab; size_t off;
@@ -894,13 +919,13 @@ static napi_value js_call(napi_env env, napi_callback_info info) {
                                (tt == napi_uint32_array || tt == napi_int32_array || tt == napi_float32_array) ? 4 : 8;
             blen[k] = len * esz;
             if (blen[k] < min_len) { napi_throw_type_error(env, NULL, "zkmi.call: a host buffer is shorter than the entry point requires"); return NULL; }
-            if (ref >= 0) { at_checks[n_at].arg = (int)k; at_checks[n_at++].ref = ref; }
+            if (ref >= 0) { at_checks[n_at].arg = (int)k; at_checks[n_at].mul = mul; at_checks[n_at++].ref = ref; }
             a[k] = (uintptr_t)data;
         }
     }
     if (k + 1 != argc) { napi_throw_type_error(env, NULL, "zkmi.call: too many arguments for this entry point"); return NULL; }
     for (int i = 0; i < n_at; i++)
-        if ((uint64_t)blen[at_checks[i].arg] < (uint64_t)a[at_checks[i].ref]) { napi_throw_type_error(env, NULL, "zkmi.call: a host buffer is shorter than its length argument"); return NULL; }
+        if ((uint64_t)blen[at_checks[i].arg] < (uint64_t)a[at_checks[i].ref] * at_checks[i].mul) { napi_throw_type_error(env, NULL, "zkmi.call: a host buffer is shorter than its length argument"); return NULL; }
     int rc = ZK_CALL(fn(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]));
     if (rc) return throw_zkmi(env, rc);
     napi_value z;
@@ -965,7 +990,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"devAlloc", js_dev_alloc}, {"devFree", js_dev_free}, {"memcpyH2D", js_memcpy_h2d}, {"memcpyD2H", js_memcpy_d2h},
         {"groth16ChainsDev", js_groth16_chains_dev}, {"groth16SumsWDev", js_groth16_sums_w_dev}, {"groth16SumsHDev", js_groth16_sums_h_dev}, {"groth16SumsDev", js_groth16_sums_dev},
         {"groth16Finish", js_groth16_finish}, {"joinABCDev", js_join_abc_dev}, {"pointAdd", js_point_add}, {"shmMap", js_shm_map}, {"shmUnlink", js_shm_unlink},
-        {"msmTableDev", js_msm_table_dev}, {"msmTableMultiDev", js_msm_table_multi_dev}, {"msmTableMultiDevAsync", js_msm_table_multi_dev_async}, {"msmTableMultiEnqueueDev", js_msm_table_multi_enqueue_dev}, {"msmTableMultiCollect", js_msm_table_multi_collect}, {"synchronizeAsync", js_synchronize_async}, {"ipcExport", js_ipc_export}, {"ipcOpen", js_ipc_open}, {"ipcClose", js_ipc_close},
+        {"msmTableDev", js_msm_table_dev}, {"msmTableMultiDev", js_msm_table_multi_dev}, {"msmTableMultiDevAsync", js_msm_table_multi_dev_async}, {"msmTableMultiEnqueueDev", js_msm_table_multi_enqueue_dev}, {"msmTableMultiEnqueueMontDev", js_msm_table_multi_enqueue_mont_dev}, {"msmTableMultiCollect", js_msm_table_multi_collect}, {"synchronizeAsync", js_synchronize_async}, {"ipcExport", js_ipc_export}, {"ipcOpen", js_ipc_open}, {"ipcClose", js_ipc_close},
         {"peerCopy", js_peer_copy}, {"peerCopyAsync", js_peer_copy_async}, {"peerFence", js_peer_fence}, {"groth16Reset", js_groth16_reset}, {"groth16KeyCurve", js_groth16_key_curve},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

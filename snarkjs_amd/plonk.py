@@ -127,8 +127,45 @@ class _Poly:
         e.copy_from(self.ptr, self.n)
         return e.ntt(False, out=e)
 
+    def ifft_blinded(self, factors):
+        """The pattern of rounds 1 and 2 (plonk_prove.js:285-311, :441-455) in four launches less per polynomial: coefficients = ifft(self) into a buffer with room for the
+        blinding tail, Evaluations.fromPolynomial(coefficients, 4) with the zero padding READ instead of written (zkmi_ntt_padded_dev), then blindCoefficients in place
+        (zkmi_poly_blind_tail_dev) -> (blinded polynomial of n + len(factors) coefficients, 4n evaluations of the unblinded one)"""
+        L, f, n, k = zkmi.lib(), self.f, self.n, len(factors)
+        out = _Poly(f, n + k, zero=False)
+        zkmi.check(L.zkmi_ntt_dev(f.cid, self.ptr, out.ptr, n.bit_length() - 1, 1, None, None))
+        ev = _Poly(f, 4 * n, zero=False)
+        zkmi.check(L.zkmi_ntt_padded_dev(f.cid, out.ptr, n, ev.ptr, (4 * n).bit_length() - 1, 0))
+        fb = np.concatenate([f.mont(fct) for fct in factors])
+        zkmi.check(L.zkmi_poly_blind_tail_dev(f.cid, out.ptr, n, zkmi.ptr(fb), k))
+        return out, ev
+
     def free(self):
         self.buf.free()
+
+
+def lincomb(f, out, terms, constant=None):
+    """out[i] = sum_j k_j p_j[i] + (i == 0 ? constant : 0) in one launch (zkmi_poly_lincomb_dev). terms: (device pointer, length, k as an integer or None for 1)"""
+    arr = (zkmi.PolyTerm * len(terms))()
+    for t, (ptr, ln, k) in zip(arr, terms):
+        t.d_p, t.len = ptr, ln
+        if k is not None:
+            t.has_k = 1
+            C.memmove(t.k, zkmi.ptr(f.mont(k)), 32)
+    cb = None if constant is None else zkmi.ptr(f.mont(constant))
+    zkmi.check(zkmi.lib().zkmi_poly_lincomb_dev(f.cid, out.ptr, out.n, arr, len(terms), cb))
+    return out
+
+
+def evaluate_many(f, polys, xs):
+    """[p(x)] for (device pointer, length) pairs and points, one wait (zkmi_poly_evaluate_multi_dev)"""
+    cnt = len(polys)
+    ptrs = (C.c_void_p * cnt)(*[p for p, _ in polys])
+    lens = (C.c_size_t * cnt)(*[ln for _, ln in polys])
+    xb = np.concatenate([f.mont(x) for x in xs])
+    out = np.empty(32 * cnt, np.uint8)
+    zkmi.check(zkmi.lib().zkmi_poly_evaluate_multi_dev(f.cid, ptrs, lens, zkmi.ptr(xb), cnt, zkmi.ptr(out)))
+    return [f.unmont(out[32 * i:32 * i + 32]) for i in range(cnt)]
 
 
 class PlonkKey:
@@ -237,26 +274,20 @@ def _commit_enqueue(key, *polys):
     the bucket reductions of the round share one set of launches) are ENQUEUED on the active pipeline slot (zkmi_msm_table_multi_enqueue_dev); nothing waits. r06: with two
     proofs in flight the other proof's next segment — its own commitments included — is enqueued before this one is collected, so its accumulations run underneath this round's
     latency-bound reduction tail instead of behind a host that sits inside a blocking call."""
-    f, L, cnt = key.f, zkmi.lib(), len(polys)
-    scs = [zkmi.DeviceBuffer(p.n * 32) for p in polys]
-    for p, sc in zip(polys, scs):
-        zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_FROM_MONTGOMERY, p.ptr, sc.ptr, p.n))
-    ptrs = (C.c_void_p * cnt)(*[sc.ptr for sc in scs])
+    L, cnt = zkmi.lib(), len(polys)
+    ptrs = (C.c_void_p * cnt)(*[p.ptr for p in polys])
     ks = (C.c_size_t * cnt)(*[p.n for p in polys])
-    zkmi.check(L.zkmi_msm_table_multi_enqueue_dev(key.ptau_table, ptrs, ks, cnt, 32))
-    return key, scs, cnt
+    # r06: the conversions of the round in one launch into the slot's scratch memory, inside the call (zkmi_msm_table_multi_enqueue_mont_dev)
+    zkmi.check(L.zkmi_msm_table_multi_enqueue_mont_dev(key.ptau_table, ptrs, ks, cnt))
+    return key, polys, cnt
 
 
 def _commit_collect(state):
     """second half: wait for the round's MSMs, fold, toAffine -> [(x, y)] as integers"""
-    key, scs, cnt = state
+    key, _polys, cnt = state
     f, L = key.f, zkmi.lib()
     jac = np.zeros(cnt * 3 * f.n8q, np.uint8)
-    try:
-        zkmi.check(L.zkmi_msm_table_multi_collect(key.ptau_table, cnt, zkmi.ptr(jac)))
-    finally:
-        for sc in scs:
-            sc.free()
+    zkmi.check(L.zkmi_msm_table_multi_collect(key.ptau_table, cnt, zkmi.ptr(jac)))
     out = []
     for i in range(cnt):
         aff = np.zeros(2 * f.n8q, np.uint8)
@@ -358,14 +389,10 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     if key.nAdditions:
         zkmi.check(L.zkmi_plonk_additions_dev(f.cid, key.sec(3), key.nAdditions, d_wit.ptr, nW, d_int.ptr))
     A, B, Cw = _Poly(f, n, False), _Poly(f, n, False), _Poly(f, n, False)
-    zkmi.check(L.zkmi_plonk_gather_wires_dev(f.cid, d_wit.ptr, nW, d_int.ptr, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n,
-                                             A.ptr, B.ptr, Cw.ptr))
+    zkmi.check(L.zkmi_plonk_gather_wires_mont_dev(f.cid, d_wit.ptr, nW, d_int.ptr, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n,
+                                                  A.ptr, B.ptr, Cw.ptr))                 # buffers + Fr.batchToMontgomery (:267-283) in one pass
     d_int.free()                                                                          # stream-ordered: the gather above is the last reader
-    for p in (A, B, Cw):
-        zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_TO_MONTGOMERY, p.ptr, p.ptr, n))
-    pA, pB, pC = A.ntt(True), B.ntt(True), Cw.ntt(True)
-    eA, eB, eC = pA.extended_evals(4), pB.extended_evals(4), pC.extended_evals(4)
-    pA, pB, pC = pA.blinded([b[2], b[1]]), pB.blinded([b[4], b[3]]), pC.blinded([b[6], b[5]])
+    (pA, eA), (pB, eB), (pC, eC) = A.ifft_blinded([b[2], b[1]]), B.ifft_blinded([b[4], b[3]]), Cw.ifft_blinded([b[6], b[5]])
     cm = _commit_enqueue(key, pA, pB, pC)
     yield
     pts["A"], pts["B"], pts["C"] = _commit_collect(cm)
@@ -384,9 +411,7 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     Zb = _Poly(f, n, False)
     zkmi.check(L.zkmi_plonk_compute_z_enqueue(f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(12, 6 * n), key.sec(12, 11 * n), n, zkmi.ptr(mont(beta)),
                                               zkmi.ptr(mont(gamma)), zkmi.ptr(mont(key.k1)), zkmi.ptr(mont(key.k2)), zkmi.ptr(w_n), Zb.ptr))
-    pZ = Zb.ntt(True)
-    eZ = pZ.extended_evals(4)
-    pZ = pZ.blinded([b[9], b[8], b[7]])
+    pZ, eZ = Zb.ifft_blinded([b[9], b[8], b[7]])
     cm = _commit_enqueue(key, pZ)
     yield
     pts["Z"], = _commit_collect(cm)
@@ -409,12 +434,8 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     yield
     if not pT.tail_is_zero(3 * n + 6):
         raise ValueError("T Polynomial is not well calculated")                          # :645-647
-    T1 = _Poly(f, n + 1).copy_from(pT.at(0), n)
-    T2 = _Poly(f, n + 1).copy_from(pT.at(n), n)
-    T3 = _Poly(f, n + 6).copy_from(pT.at(2 * n), n + 6)
-    T1.set(n, b[10])
-    T2.set(0, (T2.get(0) - b[10]) % r); T2.set(n, b[11])
-    T3.set(0, (T3.get(0) - b[11]) % r)
+    T1, T2, T3 = _Poly(f, n + 1, False), _Poly(f, n + 1, False), _Poly(f, n + 6, False)
+    zkmi.check(L.zkmi_plonk_split_t_dev(f.cid, pT.ptr, 4 * n, n, zkmi.ptr(mont(b[10])), zkmi.ptr(mont(b[11])), T1.ptr, T2.ptr, T3.ptr))      # :649-672 in one launch
     cm = _commit_enqueue(key, T1, T2, T3)
     yield
     pts["T1"], pts["T2"], pts["T3"] = _commit_collect(cm)
@@ -425,12 +446,11 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
         tr.point(pts[nm])
     xi = tr.challenge()
     xiw = xi * f.unmont(w_n) % r
-    S1c = _Poly(f, n, False).copy_from(key.sec(12, 0), n)
-    S2c = _Poly(f, n, False).copy_from(key.sec(12, 5 * n), n)
-    S3c = _Poly(f, n, False).copy_from(key.sec(12, 10 * n), n)
+    S1, S2, S3 = key.sec(12, 0), key.sec(12, 5 * n), key.sec(12, 10 * n)                  # the coefficient halves of the sigma section, read where they lie
     yield
-    evs["eval_a"], evs["eval_b"], evs["eval_c"] = pA.evaluate(xi), pB.evaluate(xi), pC.evaluate(xi)
-    evs["eval_s1"], evs["eval_s2"], evs["eval_zw"] = S1c.evaluate(xi), S2c.evaluate(xi), pZ.evaluate(xiw)
+    vals = evaluate_many(f, [(pA.ptr, pA.n), (pB.ptr, pB.n), (pC.ptr, pC.n), (S1, n), (S2, n), (pZ.ptr, pZ.n)], [xi, xi, xi, xi, xi, xiw])    # six evaluations, one wait
+    for k, v_ in zip(("eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw"), vals):
+        evs[k] = v_
 
     # ---- ROUND 5 (:710-888)
     tr.reset(); tr.scalar(xi)
@@ -455,34 +475,24 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     e2 = (ea + betaxi + gamma) * (eb + betaxi * key.k1 + gamma) % r * (ec + betaxi * key.k2 + gamma) % r * alpha % r
     e3 = (ea + beta * es1 + gamma) * (eb + beta * es2 + gamma) % r * ezw % r * alpha % r
     e4 = eval_l1 * alpha2 % r
-    Rp = _Poly(f, n + 6)
-    q_coef = lambda t: _Poly(f, n, False).copy_from(key.sec(t, 0), n)
-    for t, k in ((7, ea * eb % r), (8, ea), (9, eb), (10, ec), (11, None)):
-        qp = q_coef(t)
-        Rp.axpy(qp, k)
-        qp.free()
-    Rp.axpy(pZ, e2)
-    Rp.axpy(S3c, e3 * beta % r, sub=True)
-    Rp.axpy(pZ, e4)
-    tmp = _Poly(f, n + 6).copy_from(T3.ptr, n + 6)
-    tmp.scale(xin * xin % r)
-    tmp.axpy(T2, xin)
-    tmp.axpy(T1)
-    tmp.scale(zh)
-    Rp.axpy(tmp, sub=True)
-    Rp.add_scalar((eval_pi - e3 * (ec + gamma) - e4) % r)
-    Wxi = _Poly(f, n + 6)
-    Wxi.axpy(Rp)
-    for p, k in ((pA, v[1]), (pB, v[2]), (pC, v[3]), (S1c, v[4]), (S2c, v[5])):
-        Wxi.axpy(p, k)
-    Wxi.add_scalar(-(v[1] * ea + v[2] * eb + v[3] * ec + v[4] * es1 + v[5] * es2) % r)
-    zkmi.check(L.zkmi_poly_div_by_zerofier_dev(f.cid, Wxi.ptr, Wxi.n, 1, zkmi.ptr(mont(xi))))
-    Wxiw = _Poly(f, pZ.n, False).copy_from(pZ.ptr, pZ.n)
-    Wxiw.add_scalar(-ezw % r)
-    zkmi.check(L.zkmi_poly_div_by_zerofier_dev(f.cid, Wxiw.ptr, Wxiw.n, 1, zkmi.ptr(mont(xiw))))
+    # The linearisation polynomial R (:769-838) and the opening numerator Wxi = R + v1 (A - a) + ... (:840-866) are ONE linear combination of fifteen resident polynomials:
+    # a single launch (zkmi_poly_lincomb_dev) instead of 18 add / sub, 2 mulScalar and 5 copies of selector polynomials; exact arithmetic, same coefficients.
+    zh_n, xin2 = -zh % r, xin * xin % r
+    r0 = (eval_pi - e3 * (ec + gamma) - e4) % r
+    Wxi = lincomb(f, _Poly(f, n + 6, False), [
+        (key.sec(7, 0), n, ea * eb % r), (key.sec(8, 0), n, ea), (key.sec(9, 0), n, eb), (key.sec(10, 0), n, ec), (key.sec(11, 0), n, None),
+        (pZ.ptr, pZ.n, (e2 + e4) % r), (S3, n, -(e3 * beta) % r),
+        (T1.ptr, T1.n, zh_n), (T2.ptr, T2.n, zh_n * xin % r), (T3.ptr, T3.n, zh_n * xin2 % r),
+        (pA.ptr, pA.n, v[1]), (pB.ptr, pB.n, v[2]), (pC.ptr, pC.n, v[3]), (S1, n, v[4]), (S2, n, v[5])],
+        (r0 - (v[1] * ea + v[2] * eb + v[3] * ec + v[4] * es1 + v[5] * es2)) % r)
+    zkmi.check(L.zkmi_poly_div_by_zerofier_enqueue(f.cid, Wxi.ptr, Wxi.n, 1, zkmi.ptr(mont(xi))))
+    Wxiw = lincomb(f, _Poly(f, pZ.n, False), [(pZ.ptr, pZ.n, None)], -ezw % r)
+    zkmi.check(L.zkmi_poly_div_by_zerofier_enqueue(f.cid, Wxiw.ptr, Wxiw.n, 1, zkmi.ptr(mont(xiw))))
     cm = _commit_enqueue(key, Wxi, Wxiw)
     yield
     pts["Wxi"], pts["Wxiw"] = _commit_collect(cm)
+    if not (Wxi.tail_is_zero(Wxi.n - 1) and Wxiw.tail_is_zero(Wxiw.n - 1)):             # divByZerofier's test (polynomial.js:665-669), read behind the commitments' wait
+        raise ValueError("Polynomial is not divisible")
 
     proof = {}
     for nm in ("A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"):                       # src/proof.js:61-83 (insertion order)

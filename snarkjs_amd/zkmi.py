@@ -32,6 +32,8 @@ SYMBOLS = [
     "zkmi_gen_geometric_bases_dev", "zkmi_host_register", "zkmi_host_unregister", "zkmi_to_affine", "zkmi_point_add", "zkmi_fr_root",
     "zkmi_plonk_gather_wires_dev", "zkmi_plonk_additions_dev", "zkmi_plonk_compute_z_dev", "zkmi_plonk_compute_z_enqueue", "zkmi_pipeline_select", "zkmi_pipeline_active", "zkmi_plonk_compute_t_dev", "zkmi_fflonk_t0_dev", "zkmi_fflonk_t1_dev",
     "zkmi_fflonk_t2_dev", "zkmi_poly_degree_dev", "zkmi_keccak256", "zkmi_poly_blind_dev", "zkmi_poly_add_scalar_dev", "zkmi_poly_axpy_dev", "zkmi_poly_scale_dev",
+    "zkmi_msm_table_multi_enqueue_mont_dev", "zkmi_ntt_padded_dev", "zkmi_fr_batch_multi_dev", "zkmi_plonk_gather_wires_mont_dev", "zkmi_poly_blind_tail_dev", "zkmi_poly_lincomb_dev",
+    "zkmi_poly_evaluate_multi_dev", "zkmi_poly_div_by_zerofier_enqueue", "zkmi_plonk_split_t_dev",
     "zkmi_poly_evaluate_dev", "zkmi_poly_is_zero_dev", "zkmi_poly_div_zh_dev", "zkmi_cpoly_interleave_dev", "zkmi_poly_div_by_zerofier_dev", "zkmi_last_kernel_ms",
 ]
 
@@ -47,6 +49,11 @@ class ZkmiError(RuntimeError):
 
 class Pages(C.Structure):
     _fields_ = [("ptr", C.POINTER(C.c_void_p)), ("len", C.POINTER(C.c_size_t)), ("n_pages", C.c_int)]
+
+
+class PolyTerm(C.Structure):
+    """zkmi_poly_term: one operand of zkmi_poly_lincomb_dev (56 bytes, no host pointers)"""
+    _fields_ = [("d_p", C.c_void_p), ("len", C.c_uint64), ("k", C.c_uint8 * 32), ("has_k", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class PlonkEvals(C.Structure):
@@ -177,6 +184,15 @@ def lib():
     L.zkmi_poly_axpy_dev.argtypes = [C.c_int, vp, vp, sz, u8p, C.c_int]
     L.zkmi_poly_scale_dev.argtypes = [C.c_int, vp, sz, u8p]
     L.zkmi_poly_evaluate_dev.argtypes = [C.c_int, vp, sz, u8p, u8p]
+    L.zkmi_poly_evaluate_multi_dev.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(sz), u8p, C.c_int, u8p]
+    L.zkmi_poly_lincomb_dev.argtypes = [C.c_int, vp, sz, C.POINTER(PolyTerm), C.c_int, u8p]
+    L.zkmi_poly_blind_tail_dev.argtypes = [C.c_int, vp, sz, vp, C.c_int]
+    L.zkmi_poly_div_by_zerofier_enqueue.argtypes = [C.c_int, vp, sz, u32, u8p]
+    L.zkmi_plonk_split_t_dev.argtypes = [C.c_int, vp, sz, u32, u8p, u8p, vp, vp, vp]
+    L.zkmi_plonk_gather_wires_mont_dev.argtypes = [C.c_int, vp, u32, vp, u32, vp, vp, vp, u32, u32, vp, vp, vp]
+    L.zkmi_msm_table_multi_enqueue_mont_dev.argtypes = [C.c_uint64, C.POINTER(vp), C.POINTER(sz), C.c_int]
+    L.zkmi_ntt_padded_dev.argtypes = [C.c_int, vp, sz, vp, C.c_uint, C.c_int]
+    L.zkmi_fr_batch_multi_dev.argtypes = [C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.c_int]
     L.zkmi_poly_is_zero_dev.argtypes = [C.c_int, vp, sz, C.POINTER(C.c_int)]
     L.zkmi_poly_div_zh_dev.argtypes = [C.c_int, vp, sz, u32, u32]
     L.zkmi_poly_div_by_zerofier_dev.argtypes = [C.c_int, vp, sz, u32, u8p]

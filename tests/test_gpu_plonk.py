@@ -87,6 +87,125 @@ def test_poly_ops_vs_oracle(env, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 300, 4099, 70001])
+def test_fused_poly_forms_vs_oracle(env, n):
+    """r06 launch diet: one-launch forms of chains the reference makes call by call, against the restatement of those calls (oracle/plonk_oracle.py):
+    zkmi_poly_lincomb_dev == a sequence of Polynomial.add / sub / mulScalar / addScalar, zkmi_poly_evaluate_multi_dev == Polynomial.evaluate per polynomial,
+    zkmi_poly_blind_tail_dev == blindCoefficients, zkmi_poly_div_by_zerofier_enqueue + the caller's tail test == divByZerofier, zkmi_fr_batch_multi_dev == batchFromMontgomery."""
+    zkmi, plonk, f, cx = env
+    L, r = zkmi.lib(), cx.r
+    lens = [n, max(1, n - 3), n + 6, 1, n + 2]
+    polys = [_rand(500 + 10 * j + n, ln, r) for j, ln in enumerate(lens)]
+    ks = [_rand(9, 5, r)[j] if j != 1 else None for j in range(5)]
+    const = _rand(11, 1, r)[0]
+    out_len = n + 6
+    want = [0] * out_len
+    for p_, k in zip(polys, ks):
+        want = P.poly_add(want, p_, r, k, 1)
+    devs = [_dev(zkmi, cx, p_) for p_ in polys]
+    for with_const in (False, True):
+        out = plonk._Poly(f, out_len, zero=False)
+        plonk.lincomb(f, out, [(d.ptr, ln, k) for d, ln, k in zip(devs, lens, ks)], const if with_const else None)
+        w = list(want)
+        if with_const:
+            w[0] = (w[0] + const) % r
+        assert _host(cx, out.buf, out_len) == w
+    # in place: the output is the first operand
+    acc = plonk._Poly(f, out_len)
+    acc.copy_from(devs[2].ptr, lens[2])
+    plonk.lincomb(f, acc, [(acc.ptr, out_len, None), (devs[0].ptr, lens[0], (r - 1))])
+    assert _host(cx, acc.buf, out_len) == P.poly_add(polys[2], polys[0], r, None, -1)
+    # too long a term, too many terms
+    with pytest.raises(zkmi.ZkmiError):
+        plonk.lincomb(f, plonk._Poly(f, 2, zero=False), [(devs[2].ptr, lens[2], None)])
+    with pytest.raises(zkmi.ZkmiError):
+        plonk.lincomb(f, out, [(devs[0].ptr, lens[0], None)] * 17)
+    # evaluations: five polynomials, two points, one of them shared by four
+    x, y = _rand(13, 2, r)
+    xs = [x, x, y, x, x]
+    assert plonk.evaluate_many(f, [(d.ptr, ln) for d, ln in zip(devs, lens)], xs) == [P.evaluate(p_, v, r) for p_, v in zip(polys, xs)]
+    # blindCoefficients in place on a buffer whose tail was never written
+    for cnt in (1, 2, 3):
+        if n < cnt:
+            continue
+        fac = _rand(17 + cnt, cnt, r)
+        big = plonk._Poly(f, n + cnt, zero=False)
+        zkmi.check(L.zkmi_memset_dev(big.ptr, 0xA5, (n + cnt) * 32))
+        big.copy_from(devs[0].ptr, n)
+        fb = np.concatenate([f.mont(v) for v in fac])
+        zkmi.check(L.zkmi_poly_blind_tail_dev(0, big.ptr, n, zkmi.ptr(fb), cnt))
+        assert _host(cx, big.buf, n + cnt) == P.blind(polys[0], fac, r)
+    # the enqueued division leaves the quotient and a zero top coefficient iff divisible
+    if n >= 2:
+        q = polys[0][:n - 1]
+        p_ = [0] * n
+        for i, c in enumerate(q):
+            p_[i] = (p_[i] - x * c) % r
+            p_[i + 1] = (p_[i + 1] + c) % r
+        for bump in (0, 1):
+            p_[0] = (p_[0] + bump) % r
+            dp = plonk._Poly(f, n, zero=False)
+            dp.copy_from(_dev(zkmi, cx, p_).ptr, n)
+            zkmi.check(L.zkmi_poly_div_by_zerofier_enqueue(0, dp.ptr, n, 1, zkmi.ptr(f.mont(x))))
+            if bump == 0:
+                assert dp.tail_is_zero(n - 1) and _host(cx, dp.buf, n) == P.div_by_zerofier(p_, 1, x, r)
+            else:
+                assert not dp.tail_is_zero(n - 1)
+    # conversions of several arrays in one launch
+    outs = [zkmi.DeviceBuffer(ln * 32) for ln in lens[:4]]
+    ptrs_in = (C.c_void_p * 4)(*[d.ptr for d in devs[:4]])
+    ptrs_out = (C.c_void_p * 4)(*[o.ptr for o in outs])
+    ns = (C.c_size_t * 4)(*lens[:4])
+    zkmi.check(L.zkmi_fr_batch_multi_dev(0, zkmi.BATCH_FROM_MONTGOMERY, ptrs_in, ptrs_out, ns, 4))
+    for o, p_, ln in zip(outs, polys, lens):
+        assert [int.from_bytes(bytes(o.to_host(ln * 32)[32 * i:32 * i + 32]), "little") for i in range(ln)] == p_
+    zkmi.check(L.zkmi_fr_batch_multi_dev(0, zkmi.BATCH_TO_MONTGOMERY, ptrs_out, ptrs_out, ns, 4))
+    for o, p_, ln in zip(outs, polys, lens):
+        assert _host(cx, o, ln) == p_
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve,lg,in_len", [(0, 4, 4), (0, 4, 5), (0, 10, 256), (0, 10, 1), (0, 14, 4096), (0, 14, 4099), (0, 18, 65536 + 3), (1, 12, 1024), (0, 8, 256), (0, 23, (1 << 21) + 1)])
+def test_ntt_padded_equals_ntt_of_zero_padded_copy(env, curve, lg, in_len):
+    """zkmi_ntt_padded_dev (Evaluations.fromPolynomial, evaluations.js:30-37): reading zeros behind in_len == transforming a zero-padded copy, both limb forms of the passes"""
+    zkmi, plonk, _, _ = env
+    L = zkmi.lib()
+    N = 1 << lg
+    src = zkmi.DeviceBuffer.from_host(synth.elems(4242 + lg + in_len, in_len))                     # values below 2^253: reduced in both scalar fields
+    padded = zkmi.DeviceBuffer(N * 32)
+    zkmi.check(L.zkmi_memset_dev(padded.ptr, 0, N * 32))
+    zkmi.check(L.zkmi_memcpy_d2d(padded.ptr, src.ptr, in_len * 32))
+    for inverse in (0, 1):
+        want = zkmi.DeviceBuffer(N * 32)
+        zkmi.check(L.zkmi_ntt_dev(curve, padded.ptr, want.ptr, lg, inverse, None, None))
+        got = zkmi.DeviceBuffer(N * 32)
+        zkmi.check(L.zkmi_memset_dev(got.ptr, 0x5A, N * 32))
+        zkmi.check(L.zkmi_ntt_padded_dev(curve, src.ptr, in_len, got.ptr, lg, inverse))
+        assert bytes(got.to_host(N * 32)) == bytes(want.to_host(N * 32)), (lg, in_len, inverse)
+    assert L.zkmi_ntt_padded_dev(curve, src.ptr, 0, padded.ptr, lg, 0) != 0
+    assert L.zkmi_ntt_padded_dev(curve, src.ptr, N + 1, padded.ptr, lg, 0) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [8, 64, 1024])
+def test_split_t_vs_the_reference_sequence(env, n):
+    """zkmi_plonk_split_t_dev == the slices, setCoef and blinding of round 3 (plonk_prove.js:649-672)"""
+    zkmi, plonk, f, cx = env
+    L, r = zkmi.lib(), cx.r
+    t = _rand(31 + n, 4 * n, r)
+    b10, b11 = _rand(37, 2, r)
+    dt = _dev(zkmi, cx, t)
+    T1, T2, T3 = plonk._Poly(f, n + 1, False), plonk._Poly(f, n + 1, False), plonk._Poly(f, n + 6, False)
+    zkmi.check(L.zkmi_plonk_split_t_dev(0, dt.ptr, 4 * n, n, zkmi.ptr(f.mont(b10)), zkmi.ptr(f.mont(b11)), T1.ptr, T2.ptr, T3.ptr))
+    w1 = t[:n] + [b10]
+    w2 = t[n:2 * n] + [b11]
+    w2[0] = (w2[0] - b10) % r
+    w3 = t[2 * n:3 * n + 6]
+    w3[0] = (w3[0] - b11) % r
+    assert _host(cx, T1.buf, n + 1) == w1 and _host(cx, T2.buf, n + 1) == w2 and _host(cx, T3.buf, n + 6) == w3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dom", [8, 256, 4096])
 def test_div_zh_vs_oracle(env, dom):
     zkmi, plonk, f, cx = env
