@@ -7,7 +7,7 @@
 //   1. digit sort     signed-digit recoding of every scalar and, per (window, bucket), the list of (point index, sign):
 //                     k_rsort_* (two-level LDS radix partition, large inputs) or k_msm_count/_scan/_scatter (counting sort with
 //                     wave-aggregated global atomics, small inputs)
-//   2. schedule       k_msm_classify/_class_scan/_assign: load-balanced lane groups (big buckets get 2^j lanes)
+//   2. schedule       k_msm_classify/_assign: load-balanced lane groups (big buckets get 2^j lanes)
 //   3. k_msm_accum    gather bases, XYZZ mixed additions (the hot loop: one per non-zero digit), then k_msm_tree/_giant for the
 //                     lane partials of multi-lane buckets; with resident bases the gather reads pre-computed window tables
 //                     T[k][i] = 2^(c k) P_i (k_msm_precompute) and all digits share ONE set of 2^(c-1) buckets
@@ -217,6 +217,7 @@ k_rsort_hist1(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_t* 
     rsort_tile_digits<NW>(scalars, sh, dropmask, [&](uint32_t g, uint32_t) { atomicAdd(&h[g >> lb], 1u); });
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < nparts; p += 256) bh[(size_t)p * gridDim.x + blockIdx.x] = h[p];
+    if (blockIdx.x == 0 && threadIdx.x == 0) bh[(size_t)nparts * gridDim.x] = 0;              // the scan's closing entry (r06: was a fill launch of its own)
 }
 template <int NW> __global__ void __launch_bounds__(256)
 k_rsort_scatter1(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ dropmask, uint32_t nparts, uint32_t lb, const uint32_t* __restrict__ bhoff, uint2* __restrict__ tmp) {
@@ -230,8 +231,10 @@ k_rsort_scatter1(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_
 }
 // chunk table: chunks[3k..3k+2] = (partition, first pair, number of pairs); meta[0] = number of chunks. One block.
 static __global__ void __launch_bounds__(1024)
-k_rsort_chunks(const uint32_t* __restrict__ bhoff, uint32_t nparts, uint32_t nblk, uint32_t fused_cap, uint32_t* __restrict__ pchunk0, uint32_t* __restrict__ chunks, uint32_t* __restrict__ meta) {
+k_rsort_chunks(const uint32_t* __restrict__ bhoff, uint32_t nparts, uint32_t nblk, uint32_t fused_cap, uint32_t* __restrict__ pchunk0, uint32_t* __restrict__ chunks, uint32_t* __restrict__ meta,
+               uint32_t* __restrict__ zero, uint32_t zero_words) {
     __shared__ uint32_t sc[1024];
+    for (uint32_t i = threadIdx.x; i < zero_words; i += 1024) zero[i] = 0;                       // the lane scheduler's histogram / cursors / meta words (r06: was a fill launch of its own)
     uint32_t carry = 0;
     for (uint32_t p0 = 0; p0 < nparts; p0 += 1024) {
         const uint32_t p = p0 + threadIdx.x;
@@ -399,32 +402,24 @@ static __global__ void __launch_bounds__(256) k_msm_classify(const uint32_t* __r
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) if (h[i]) atomicAdd(&hist[i], h[i]);
 }
-// first lane of every key class in descending key order: one wave, an exclusive suffix scan of the classes' lane counts (r04: one lane walking
-// 544 dependent global loads, 40 us)
-static __global__ void __launch_bounds__(64) k_msm_class_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ meta, uint32_t cap) {
-    __shared__ uint32_t lanes[MSM_NKEYS + 1];
-    if (blockIdx.x) return;
-    for (uint32_t k = threadIdx.x; k < MSM_NKEYS; k += 64) lanes[k] = k ? hist[k] << msm_key_lanes_log(k, cap) : 0u;
+// r06: the first lane of every key class (k_msm_class_scan's table) is recomputed by every block in its own LDS — 544 additions by one lane, ~2 us, against a launch
+// of its own between classify and assign (19 us of stream time per sort, nine sorts per PLONK proof); block 0 publishes the totals
+static __global__ void __launch_bounds__(256)
+k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, uint32_t log_tb, const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
+             uint32_t* __restrict__ lane_g, uint32_t* __restrict__ lane_sub, uint32_t* __restrict__ giants, uint32_t* __restrict__ meta) {
+    __shared__ uint32_t h[MSM_NKEYS], base[MSM_NKEYS], off[MSM_NKEYS + 1];
+    for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) { h[i] = 0; off[i] = i ? hist[i] << msm_key_lanes_log(i, cap) : 0u; }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0, multi = 0;
         for (int k = (int)MSM_NKEYS - 1; k >= 1; k--) {
-            const uint32_t c = lanes[k];
-            lanes[k] = run;
+            const uint32_t c = off[k];
+            off[k] = run;
             run += c;
             if ((uint32_t)k == 2 * cap) multi = run;
         }
-        meta[0] = run; meta[1] = multi;
+        if (blockIdx.x == 0) { meta[0] = run; meta[1] = multi; }
     }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < MSM_NKEYS; k += 64) if (k) off[k] = lanes[k];
-}
-static __global__ void __launch_bounds__(256)
-k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, uint32_t log_tb, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
-             uint32_t* __restrict__ lane_g, uint32_t* __restrict__ lane_sub, uint32_t* __restrict__ giants, uint32_t* __restrict__ meta) {
-    __shared__ uint32_t h[MSM_NKEYS], base[MSM_NKEYS];
-    for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) h[i] = 0;
-    __syncthreads();
     uint32_t lo, hi;
     msm_sched_run(total, lo, hi);
     // pass 1: this block's class counts; ONE global atomic per class present reserves the block's ranks; pass 2 hands them out (any bijection

@@ -57,7 +57,7 @@ static uint32_t rsort_low_bits(const MsmShape& sh) {
     return RSORT_LOW_BITS;
 }
 template <int NW> static int msm_launch_digits_radix(const uint8_t* d_scalars, const MsmShape& sh, uint32_t* counts, uint32_t* starts, uint32_t* sorted,
-                                                     const uint32_t* dropmask, hipStream_t st) {
+                                                     const uint32_t* dropmask, hipStream_t st, uint32_t* sched_zero, uint32_t sched_zero_words) {
     const uint32_t lb = rsort_fused_fits() ? rsort_low_bits(sh) : (uint32_t)RSORT_LOW_BITS;
     const uint32_t fused_cap = (lb < (uint32_t)RSORT_LOW_BITS) ? rsort_part_cap(lb) : 0u;
     const uint32_t total = (uint32_t)sh.W * sh.nb, P = total >> lb;
@@ -73,13 +73,12 @@ template <int NW> static int msm_launch_digits_radix(const uint8_t* d_scalars, c
     ZK_TRY(ws_get("msm.rs_chunks", (3 * nch_max + P + 2 + 4) * 4, (void**)&ck));
     uint32_t *pchunk0 = ck + 3 * nch_max, *meta = pchunk0 + P + 2;
     ZK_TRY(ws_get("msm.rs_h2", nch_max * RSORT_BINS * 4, (void**)&h2));
-    ZK_HIP(hipMemsetAsync(bh + nbh - 1, 0, 4, st));
     hipLaunchKernelGGL((k_rsort_hist1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, lb, bh);
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(nsp), dim3(256), 0, st, bh, (uint32_t)nbh, part);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, st, part, nsp);
     hipLaunchKernelGGL(k_msm_scan_final, dim3(nsp), dim3(256), 0, st, bh, (uint32_t)nbh, part, bhoff);
     hipLaunchKernelGGL((k_rsort_scatter1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, lb, bhoff, tmp);
-    hipLaunchKernelGGL(k_rsort_chunks, dim3(1), dim3(1024), 0, st, bhoff, P, nblk, fused_cap, pchunk0, ck, meta);
+    hipLaunchKernelGGL(k_rsort_chunks, dim3(1), dim3(1024), 0, st, bhoff, P, nblk, fused_cap, pchunk0, ck, meta, sched_zero, sched_zero_words);
     if (fused_cap) {
         const size_t lds = ((size_t)(1u << lb) + 1024 + fused_cap) * 4;
         hipLaunchKernelGGL(k_rsort_part, dim3(P), dim3(1024), lds, st, tmp, bhoff, nblk, lb, fused_cap, counts, starts, sorted);
@@ -136,15 +135,16 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     ZK_TRY(ws_get("msm.hist" + sfx, (3 * MSM_NKEYS + 8 + 3 * giant_bound) * 4, (void**)&hist));     // hist | off | cursor | meta | giants
     uint32_t *koff = hist + MSM_NKEYS, *kcur = koff + MSM_NKEYS;
     pl.meta = kcur + MSM_NKEYS; pl.giants = pl.meta + 8;
-    ZK_HIP(hipMemsetAsync(hist, 0, (3 * MSM_NKEYS + 8) * 4, st));
+    const uint32_t sched_words = 3 * MSM_NKEYS + 8;                          // zeroed by the radix sort's chunk kernel on its way (one launch less), by a fill otherwise
     const uint8_t* sc = (const uint8_t*)d_scalars;
     uint32_t* part;
     ZK_TRY(ws_get("msm.scanpart" + sfx, (total / MSM_SCAN_CHUNK + 2) * 4, (void**)&part));
     if (msm_use_radix(sh)) {
-        if (sb <= 4) { ZK_TRY(msm_launch_digits_radix<1>(sc, sh, pl.counts, pl.starts, pl.sorted, d_dropmask, st)); }
-        else if (sb <= 32) { ZK_TRY(msm_launch_digits_radix<8>(sc, sh, pl.counts, pl.starts, pl.sorted, d_dropmask, st)); }
-        else { ZK_TRY(msm_launch_digits_radix<16>(sc, sh, pl.counts, pl.starts, pl.sorted, d_dropmask, st)); }
+        if (sb <= 4) { ZK_TRY(msm_launch_digits_radix<1>(sc, sh, pl.counts, pl.starts, pl.sorted, d_dropmask, st, hist, sched_words)); }
+        else if (sb <= 32) { ZK_TRY(msm_launch_digits_radix<8>(sc, sh, pl.counts, pl.starts, pl.sorted, d_dropmask, st, hist, sched_words)); }
+        else { ZK_TRY(msm_launch_digits_radix<16>(sc, sh, pl.counts, pl.starts, pl.sorted, d_dropmask, st, hist, sched_words)); }
     } else {
+    ZK_HIP(hipMemsetAsync(hist, 0, sched_words * 4, st));
     ZK_HIP(hipMemsetAsync(counts, 0, 3 * total * 4, st));
     if (sb <= 4) msm_launch_digits<1>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, d_dropmask, st);
     else if (sb <= 32) msm_launch_digits<8>(sc, sh, pl.counts, pl.starts, cursor, pl.sorted, part, d_dropmask, st);
@@ -152,8 +152,7 @@ int msm_sort(const void* d_scalars, size_t n, size_t sb, MsmPlan& pl, int plan_s
     }
     const unsigned tb = std::min<unsigned>((unsigned)((total + 255) / 256), MSM_SCHED_BLOCKS);      // contiguous runs of buckets per block (msm.cuh: msm_sched_run)
     hipLaunchKernelGGL(k_msm_classify, dim3(tb), dim3(256), 0, st, pl.counts, (uint32_t)total, cap, hist);
-    hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(64), 0, st, hist, koff, pl.meta, cap);
-    hipLaunchKernelGGL(k_msm_assign, dim3(tb), dim3(256), 0, st, pl.counts, (uint32_t)total, cap, (uint32_t)MSM_LOG_TB, koff, kcur, pl.lane_g, pl.lane_sub, pl.giants, pl.meta);
+    hipLaunchKernelGGL(k_msm_assign, dim3(tb), dim3(256), 0, st, pl.counts, (uint32_t)total, cap, (uint32_t)MSM_LOG_TB, hist, kcur, pl.lane_g, pl.lane_sub, pl.giants, pl.meta);
     ZK_HIP(hipGetLastError());
     return ZKMI_OK;
 }

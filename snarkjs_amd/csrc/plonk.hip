@@ -68,26 +68,35 @@ template <class C> ZK_DEV Fp<C> frk_load(const FrK& k) { return fp_load<C>(k.v);
 // power table of a point that changes with every call (xi, xi w, their inverses), built ON the device: entry t < nlo is base^t, entry nlo + t is (base^nlo)^t, each by
 // square-and-multiply (at most 2 log2 products per lane, one launch, no host arithmetic and no wait — the host-built table of build_pow_tab costs 2^(L/2+1) host
 // products, an upload and a stream synchronisation, which is right for the roots of unity it caches and wrong for a point used once)
-template <class C> __global__ void k_pow_tab_build(FrK base, uint32_t lb, uint32_t nlo, uint32_t nhi, uint32_t* __restrict__ out) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int POWTAB_MAX = 8;
+struct PowTabBuildArgs { FrK base[POWTAB_MAX]; uint32_t* out[POWTAB_MAX]; };
+template <class C> __global__ void k_pow_tab_build(PowTabBuildArgs a, uint32_t lb, uint32_t nlo, uint32_t nhi) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;                     // several tables of one size per launch (blockIdx.y)
     if (t >= nlo + nhi) return;
-    Fp<C> b = frk_load<C>(base);
+    Fp<C> b = frk_load<C>(a.base[q]);
     uint32_t e = t;
     if (t >= nlo) { for (uint32_t k = 0; k < lb; k++) b = fp_mul(b, b); e = t - nlo; }
     Fp<C> r = fp_one<C>();
     while (e) { if (e & 1u) r = fp_mul(r, b); b = fp_mul(b, b); e >>= 1; }
-    fp_store<C>(out + (size_t)t * 8, r);
+    fp_store<C>(a.out[q] + (size_t)t * 8, r);
 }
-template <class C> static int build_pow_tab_dyn(const HE& base, unsigned log_count, const std::string& name, PowTab* out) {
+// `count` tables for exponents < 2^log_count, into the scratch buffers name.0, name.1, ...
+template <class C> static int build_pow_tabs_dyn(const HE* bases, int count, unsigned log_count, const std::string& name, PowTab* out) {
     Ctx& cx = ctx();
+    if (count < 1 || count > POWTAB_MAX) return fail(ZKMI_ERR_INVALID, "power tables: 1..8 per launch");
     const unsigned lb = (log_count + 1) / 2, hb = log_count - lb;
     const uint32_t nlo = 1u << lb, nhi = 1u << hb;
-    uint32_t* d;
-    ZK_TRY(ws_get(name, ((size_t)nlo + nhi) * 32, (void**)&d));
-    pow_tab_cache().erase(std::string(cx.pipe ? "P1:" : "") + name);            // the named buffer no longer holds what build_pow_tab may have cached under this name
-    hipLaunchKernelGGL((k_pow_tab_build<C>), dim3((nlo + nhi + 255) / 256), dim3(256), 0, cx.stream, frk(base), lb, nlo, nhi, d);
+    PowTabBuildArgs a = {};
+    for (int q = 0; q < count; q++) {
+        const std::string nm = name + "." + std::to_string(q);
+        uint32_t* d;
+        ZK_TRY(ws_get(nm, ((size_t)nlo + nhi) * 32, (void**)&d));
+        pow_tab_cache().erase(std::string(cx.pipe ? "P1:" : "") + nm);          // the named buffer no longer holds what build_pow_tab may have cached under this name
+        a.base[q] = frk(bases[q]); a.out[q] = d;
+        out[q].lo = d; out[q].hi = d + (size_t)nlo * 8; out[q].lb = lb;
+    }
+    hipLaunchKernelGGL((k_pow_tab_build<C>), dim3((nlo + nhi + 255) / 256, (unsigned)count), dim3(256), 0, cx.stream, a, lb, nlo, nhi);
     ZK_HIP(hipGetLastError());
-    out->lo = d; out->hi = d + (size_t)nlo * 8; out->lb = lb;
     return ZKMI_OK;
 }
 
@@ -887,15 +896,20 @@ template <class C> struct PlonkOps {
         uint32_t tot = 0, np_max = 0;
         size_t n_max = 1;
         for (int q = 0; q < count; q++) n_max = std::max(n_max, lens[q]);
+        HE pts[EVAL_MAX];
+        int which[EVAL_MAX], n_pts = 0;
         for (int q = 0; q < count; q++) {
             a.c[q] = (const uint32_t*)polys[q]; a.n[q] = lens[q]; a.x[q] = frk(xs + 32 * q);
             a.np[q] = (uint32_t)((lens[q] + 256 * EV_K - 1) / (256 * EV_K)); a.off[q] = tot;
             tot += a.np[q]; np_max = std::max(np_max, a.np[q]);
-            int same = -1;
-            for (int r = 0; r < q && same < 0; r++) if (!memcmp(xs + 32 * r, xs + 32 * q, 32)) same = r;
-            if (same >= 0) a.xt[q] = a.xt[same];
-            else ZK_TRY((build_pow_tab_dyn<C>(he(xs + 32 * q), std::max(1u, clog2(n_max)), "plonk.powe." + std::to_string(q), &a.xt[q])));
+            const HE x = he(xs + 32 * q);
+            which[q] = -1;
+            for (int r = 0; r < n_pts && which[q] < 0; r++) if (pts[r] == x) which[q] = r;
+            if (which[q] < 0) { which[q] = n_pts; pts[n_pts++] = x; }
         }
+        PowTab tabs[EVAL_MAX];
+        ZK_TRY((build_pow_tabs_dyn<C>(pts, n_pts, std::max(1u, clog2(n_max)), "plonk.powe", tabs)));       // one launch for the distinct points
+        for (int q = 0; q < count; q++) a.xt[q] = tabs[which[q]];
         uint32_t* part;
         ZK_TRY(ws_get("plonk.evpart", ((size_t)tot + EVAL_MAX) * 32, (void**)&part));
         uint32_t* res = part + (size_t)tot * 8;
@@ -947,9 +961,10 @@ template <class C> struct PlonkOps {
             return ZKMI_OK;
         }
         // few long chains: each residue class r is the linear recurrence q_k = (q_{k-1} - c_k)/beta, solved as a prefix sum
-        PowTab bt, it;
-        ZK_TRY((build_pow_tab_dyn<C>(b, std::max(1u, clog2(chain)), "plonk.powb", &bt)));
-        ZK_TRY((build_pow_tab_dyn<C>(ib, std::max(1u, clog2(chain)), "plonk.powib", &it)));
+        const HE both[2] = {b, ib};
+        PowTab tabs[2];
+        ZK_TRY((build_pow_tabs_dyn<C>(both, 2, std::max(1u, clog2(chain)), "plonk.powb", tabs)));          // beta^k and beta^-k in one launch
+        const PowTab bt = tabs[0], it = tabs[1];
         uint32_t* u;
         ZK_TRY(ws_get("plonk.dzu", chain * 32, (void**)&u));
         for (uint32_t r = 0; r < n && r < len; r++) {

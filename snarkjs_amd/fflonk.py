@@ -20,7 +20,7 @@ import numpy as np
 
 from . import zkmi
 from .groth16 import _curve_from_q
-from .plonk import _Field, _Poly, _Transcript
+from .plonk import _Field, _Poly, _Transcript, evaluate_many, lincomb
 
 
 class FflonkKey:
@@ -116,26 +116,29 @@ def _commit(key, poly):
 
 
 def _commit_enqueue(key, poly):
-    """first half of _commit: batchFromMontgomery + the MSM enqueued on the active pipeline slot (zkmi_msm_table_multi_enqueue_dev, one MSM), nothing waits"""
-    f, L = key.f, zkmi.lib()
+    """first half of _commit: batchFromMontgomery + the MSM enqueued on the active pipeline slot (zkmi_msm_table_multi_enqueue_mont_dev, one MSM), nothing waits"""
     k = min(poly.n, key.n_ptau)
-    sc = zkmi.DeviceBuffer(k * 32)
-    zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_FROM_MONTGOMERY, poly.ptr, sc.ptr, k))
-    ptrs, ks = (C.c_void_p * 1)(sc.ptr), (C.c_size_t * 1)(k)
-    zkmi.check(L.zkmi_msm_table_multi_enqueue_dev(key.ptau_table, ptrs, ks, 1, 32))
-    return key, sc
+    ptrs, ks = (C.c_void_p * 1)(poly.ptr), (C.c_size_t * 1)(k)
+    zkmi.check(zkmi.lib().zkmi_msm_table_multi_enqueue_mont_dev(key.ptau_table, ptrs, ks, 1))
+    return key
 
 
-def _commit_collect(state):
-    key, sc = state
+def _commit_collect(key):
     f, L = key.f, zkmi.lib()
     jac, aff = np.zeros(3 * f.n8q, np.uint8), np.zeros(2 * f.n8q, np.uint8)
-    try:
-        zkmi.check(L.zkmi_msm_table_multi_collect(key.ptau_table, 1, zkmi.ptr(jac)))
-    finally:
-        sc.free()
+    zkmi.check(L.zkmi_msm_table_multi_collect(key.ptau_table, 1, zkmi.ptr(jac)))
     zkmi.check(L.zkmi_to_affine(f.cid, 1, zkmi.ptr(jac), zkmi.ptr(aff)))
     return (f.unmont_q(aff[:f.n8q]), f.unmont_q(aff[f.n8q:]))
+
+
+def _evaluate_all(f, pairs):
+    """[p(x)] for ((device pointer, length), x) pairs, eight per wait (zkmi_poly_evaluate_multi_dev); a generator: yields before every wait"""
+    out = []
+    for i in range(0, len(pairs), 8):
+        chunk = pairs[i:i + 8]
+        yield
+        out += evaluate_many(f, [p for p, _ in chunk], [x for _, x in chunk])
+    return out
 
 
 def _div_zerofier(p, n, beta):
@@ -253,12 +256,12 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
 
     # ---- ROUND 1 (:318-556)
     A, B, Cw = _Poly(f, n, False), _Poly(f, n, False), _Poly(f, n, False)
-    zkmi.check(L.zkmi_plonk_gather_wires_dev(f.cid, d_wit.ptr, nW, d_int.ptr, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n, A.ptr, B.ptr, Cw.ptr))
-    # blinding scalars are written (as their Montgomery bytes) into the normal-form buffers before batchToMontgomery (:377-386)
+    zkmi.check(L.zkmi_plonk_gather_wires_mont_dev(f.cid, d_wit.ptr, nW, d_int.ptr, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n, A.ptr, B.ptr, Cw.ptr))
+    # the reference writes the blinding scalars (their Montgomery bytes) into the normal-form buffers BEFORE batchToMontgomery (:377-386): what ends up in the buffers is
+    # toMontgomery of those bytes read as an integer — written here directly, behind the gather that already converted the rest
     for p, (k0, k1_) in ((A, (1, 2)), (B, (3, 4)), (Cw, (5, 6))):
-        raw = np.frombuffer(bm[k0] + bm[k1_], np.uint8)
+        raw = np.concatenate([mont(int.from_bytes(bm[k0], "little")), mont(int.from_bytes(bm[k1_], "little"))])
         zkmi.check(L.zkmi_memcpy_h2d(p.at(n - 2), zkmi.ptr(raw), 64))
-        zkmi.check(L.zkmi_fr_batch_dev(f.cid, zkmi.BATCH_TO_MONTGOMERY, p.ptr, p.ptr, n))
     pA, pB, pC = A.ntt(True), B.ntt(True), Cw.ntt(True)
     eA, eB, eC = pA.extended_evals(4), pB.extended_evals(4), pC.extended_evals(4)
     ev = zkmi.PlonkEvals(eA.ptr, eB.ptr, eC.ptr, None, key.sec(9, n), key.sec(7, n), key.sec(8, n), key.sec(10, n), key.sec(11, n), None, None, None, key.sec(15), A.ptr)
@@ -289,9 +292,7 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     # enqueue only: Z[0] == 1 ("Copy constraints does not match", :640-642) is read behind the next wait, as plonk.py does
     zkmi.check(L.zkmi_plonk_compute_z_enqueue(f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(13, n), key.sec(14, n), n, mp(beta), mp(gamma), mp(key.k1), mp(key.k2),
                                               zkmi.ptr(w_n), Zb.ptr))
-    pZ = Zb.ntt(True)
-    eZ = pZ.extended_evals(4)
-    pZ = pZ.blinded([b[9], b[8], b[7]])
+    pZ, eZ = Zb.ifft_blinded([b[9], b[8], b[7]])
     b789 = np.concatenate([mont(b[7]), mont(b[8]), mont(b[9])])
     T1, T1z = _Poly(f, 2 * n, False), _Poly(f, 2 * n, False)
     zkmi.check(L.zkmi_fflonk_t1_dev(f.cid, eZ.ptr, key.sec(15), n, zkmi.ptr(b789), zkmi.ptr(w_2n), T1.ptr, T1z.ptr))
@@ -337,13 +338,11 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     S2p = [h3 * x % r for x in w3]
     xi = h2 * h2 % r * h2 % r
     xiw = xi * wv % r
-    coef = lambda t: _Poly(f, n, False).copy_from(key.sec(t, 0), n)
-    for k, t in (("ql", 7), ("qr", 8), ("qm", 9), ("qo", 10), ("qc", 11), ("s1", 12), ("s2", 13), ("s3", 14)):
-        p = coef(t)
-        evs[k] = p.evaluate(xi)
-        p.free()
-    evs["a"], evs["b"], evs["c"], evs["z"] = pA.evaluate(xi), pB.evaluate(xi), pC.evaluate(xi), pZ.evaluate(xi)
-    evs["zw"], evs["t1w"], evs["t2w"] = pZ.evaluate(xiw), pT1.evaluate(xiw), pT2.evaluate(xiw)
+    # fifteen evaluations, two waits; the selector and sigma polynomials are read where they lie in the key
+    names = ("ql", "qr", "qm", "qo", "qc", "s1", "s2", "s3", "a", "b", "c", "z", "zw", "t1w", "t2w")
+    pairs = [((key.sec(t, 0), n), xi) for t in (7, 8, 9, 10, 11, 12, 13, 14)] + [((p.ptr, p.n), xi) for p in (pA, pB, pC, pZ)] + [((p.ptr, p.n), xiw) for p in (pZ, pT1, pT2)]
+    vals = yield from _evaluate_all(f, pairs)
+    evs.update(zip(names, vals))
 
     # ---- ROUND 4 (:965-1057)
     tr = _Transcript(f)
@@ -351,25 +350,22 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     for k in ("ql", "qr", "qm", "qo", "qc", "s1", "s2", "s3", "a", "b", "c", "z", "zw", "t1w", "t2w"):
         tr.scalar(evs[k])
     alpha = tr.challenge()
-    C0 = _Poly(f, 8 * n, False).copy_from(key.sec(17, 0), 8 * n)
-    R0 = _lagrange(S0, [C0.evaluate(x) for x in S0], r)
-    R1 = _lagrange(S1, [C1.evaluate(x) for x in S1], r)
-    R2 = _lagrange(S2 + S2p, [C2.evaluate(x) for x in S2 + S2p], r)
-    nF = max(C0.n, C1.n, C2.n)
-    F = _Poly(f, nF).copy_from(C0.ptr, C0.n)
-    F.axpy(_small(f, R0), sub=True)
-    zkmi.check(L.zkmi_poly_div_by_zerofier_dev(f.cid, F.ptr, C0.n, 8, mp(xi)))           # the division acts on C0's own length
-    f2 = _Poly(f, C1.n, False).copy_from(C1.ptr, C1.n)
-    f2.axpy(_small(f, R1), sub=True)
-    f2.scale(alpha)
+    C0p, C0n = key.sec(17, 0), 8 * n                                                     # C0 is read where it lies in the key
+    # eighteen evaluations at the opening roots, three waits
+    vals = yield from _evaluate_all(f, [((C0p, C0n), x) for x in S0] + [((C1.ptr, C1.n), x) for x in S1] + [((C2.ptr, C2.n), x) for x in S2 + S2p])
+    R0, R1, R2 = _lagrange(S0, vals[:8], r), _lagrange(S1, vals[8:12], r), _lagrange(S2 + S2p, vals[12:], r)
+    nF = max(C0n, C1.n, C2.n)
+    neg = lambda v: -v % r
+    # F = (C0 - R0) / ZT0 + alpha (C1 - R1) / ZT1 + alpha^2 (C2 - R2) / ZT2 (:1009-1042): each numerator one launch (zkmi_poly_lincomb_dev)
+    F = lincomb(f, _Poly(f, nF, False), [(C0p, C0n, None), (_small(f, R0).ptr, len(R0), neg(1))])
+    zkmi.check(L.zkmi_poly_div_by_zerofier_dev(f.cid, F.ptr, C0n, 8, mp(xi)))             # the division acts on C0's own length
+    f2 = lincomb(f, _Poly(f, C1.n, False), [(C1.ptr, C1.n, alpha), (_small(f, R1).ptr, len(R1), neg(alpha))])
     _div_zerofier(f2, 4, xi)
-    f3 = _Poly(f, C2.n, False).copy_from(C2.ptr, C2.n)
-    f3.axpy(_small(f, R2), sub=True)
-    f3.scale(alpha * alpha % r)
+    a2 = alpha * alpha % r
+    f3 = lincomb(f, _Poly(f, C2.n, False), [(C2.ptr, C2.n, a2), (_small(f, R2).ptr, len(R2), neg(a2))])
     _div_zerofier(f3, 3, xi)
     _div_zerofier(f3, 3, xiw)
-    F.axpy(f2)
-    F.axpy(f3)
+    lincomb(f, F, [(F.ptr, nF, None), (f2.ptr, f2.n, None), (f3.ptr, f3.n, None)])
     yield
     if _degree(F) >= 9 * n - 6:
         raise ValueError("F Polynomial is not well calculated")
@@ -385,22 +381,16 @@ def _prove_steps(zkey, witness_file, logger=None, options=None, blinding_mont=No
     mulL0, mulL1, mulL2 = prod(S0), prod(S1), prod(S2 + S2p)
     preL0, preL1, preL2 = mulL1 * mulL2 % r, alpha * mulL0 % r * mulL2 % r, alpha * alpha % r * mulL0 % r * mulL1 % r
     to_inv = {"denH1": mulL1, "denH2": mulL2}
-    Lp = _Poly(f, nF).copy_from(C0.ptr, C0.n)
-    Lp.add_scalar(-_ev(R0, y, r) % r)
-    Lp.scale(preL0)
-    l2 = _Poly(f, C1.n, False).copy_from(C1.ptr, C1.n)
-    l2.add_scalar(-_ev(R1, y, r) % r)
-    Lp.axpy(l2, preL1)
-    l3 = _Poly(f, C2.n, False).copy_from(C2.ptr, C2.n)
-    l3.add_scalar(-_ev(R2, y, r) % r)
-    Lp.axpy(l3, preL2)
+    # L = preL0 (C0 - R0(y)) + preL1 (C1 - R1(y)) + preL2 (C2 - R2(y)) - ZT(y) F, times 1 / ZTS2(y) (:1061-1083): one launch. The scalar does not move the degree the
+    # reference tests before it multiplies by it
     ZT = _zerofier(S0 + S1 + S2 + S2p, r)
-    Lp.axpy(F, _ev(ZT, y, r), sub=True)
+    ZTS2 = _zerofier(S1 + S2 + S2p, r)
+    inv2 = pow(_ev(ZTS2, y, r), -1, r)
+    Lp = lincomb(f, _Poly(f, nF, False), [(C0p, C0n, preL0 * inv2 % r), (C1.ptr, C1.n, preL1 * inv2 % r), (C2.ptr, C2.n, preL2 * inv2 % r), (F.ptr, nF, neg(_ev(ZT, y, r) * inv2 % r))],
+                 neg((preL0 * _ev(R0, y, r) + preL1 * _ev(R1, y, r) + preL2 * _ev(R2, y, r)) % r * inv2 % r))
     yield
     if _degree(Lp) >= 9 * n:
         raise ValueError("L Polynomial is not well calculated")
-    ZTS2 = _zerofier(S1 + S2 + S2p, r)
-    Lp.scale(pow(_ev(ZTS2, y, r), -1, r))
     try:
         _div_zerofier(Lp, 1, y)                     # L / (X - y): exact, so Euclidean division (:1085) = division by the zerofier
     except zkmi.ZkmiError as e:

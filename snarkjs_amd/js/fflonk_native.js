@@ -67,15 +67,14 @@ function cpoly(f, polys, n, track) {
 }
 
 // Polynomial.multiExponentiation over PTau: coefficients past the 9n+18 SRS points multiply the point at infinity
-function commitScalars(key, poly) { const k = Math.min(poly.n, key.nPtau), sc = devAlloc(k * 32); call("zkmi_fr_batch_dev", key.f.cid, 1, poly.ptr, sc, k); return [sc, k]; }
-function commitPoint(key, sc, jac) {
+function commitEnqueue(key, poly) { addon.msmTableMultiEnqueueMontDev(key.ptauTable, [poly.ptr], [Math.min(poly.n, key.nPtau)]); }   // batchFromMontgomery + the MSM, enqueued
+function commitCollect(key) {
     const f = key.f, aff = new Uint8Array(2 * f.n8q);
-    devFree(sc);
-    call("zkmi_to_affine", f.cid, 1, jac, aff);
+    call("zkmi_to_affine", f.cid, 1, addon.msmTableMultiCollect(key.ptauTable, 1), aff);
     return [f.unmontQ(aff.subarray(0, f.n8q)), f.unmontQ(aff.subarray(f.n8q))];
 }
-function commit(key, poly) { const [sc, k] = commitScalars(key, poly); return commitPoint(key, sc, addon.msmTableDev(key.ptauTable, sc, k, 32)); }
-async function commitAsync(key, poly) { const [sc, k] = commitScalars(key, poly); return commitPoint(key, sc, await addon.msmTableMultiDevAsync(key.ptauTable, [sc], [k], 32, 0)); }
+function commit(key, poly) { commitEnqueue(key, poly); return commitCollect(key); }
+async function commitAsync(key, poly) { commitEnqueue(key, poly); await addon.synchronizeAsync(0); call("zkmi_pipeline_select", 0); return commitCollect(key); }   // the wait on a libuv pool thread
 const divZerofier = (p, n, beta) => call("zkmi_poly_div_by_zerofier_dev", p.f.cid, p.ptr, p.n, n, p.f.mont(beta));
 
 // ---- O(1) host algebra on tiny polynomials (arrays of BigInt, lowest coefficient first) ---------------------------------
@@ -117,7 +116,7 @@ function proveAsync(zkey, wtns, blindingMont = null, options = null) {
         try {
             const steps = proveSteps(key, wtns instanceof Uint8Array ? wtns : new Uint8Array(wtns), blindingMont, track);
             let s = steps.next();
-            while (!s.done) { await addon.synchronizeAsync(0); const pt = await commitAsync(key, s.value); s = steps.next(pt); }
+            while (!s.done) { const pt = await commitAsync(key, s.value); s = steps.next(pt); }
             return s.value;
         } finally {
             polys.forEach((p) => p.free());
@@ -154,12 +153,12 @@ function* proveSteps(key, wt, blindingMont, track) {
 
         // ---- ROUND 1 (:318-556)
         const A = P(n, false), B = P(n, false), Cw = P(n, false);
-        call("zkmi_plonk_gather_wires_dev", f.cid, dWit, nW, dInt, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n, A.ptr, B.ptr, Cw.ptr);
-        // the blinding scalars are written (as their Montgomery bytes) into the normal-form buffers before batchToMontgomery (:377-386)
+        call("zkmi_plonk_gather_wires_mont_dev", f.cid, dWit, nW, dInt, key.nAdditions, key.sec(4), key.sec(5), key.sec(6), key.nConstraints, n, A.ptr, B.ptr, Cw.ptr);
+        // the reference writes the blinding scalars (their Montgomery bytes) into the normal-form buffers BEFORE batchToMontgomery (:377-386): what ends up in the buffers is
+        // toMontgomery of those bytes read as an integer — written here directly, behind the gather that already converted the rest
         for (const [p, k0, k1] of [[A, 1, 2], [B, 3, 4], [Cw, 5, 6]]) {
-            const raw = new Uint8Array(64); raw.set(bm[k0], 0); raw.set(bm[k1], 32);
+            const raw = new Uint8Array(64); raw.set(mont(fromLE(bm[k0])), 0); raw.set(mont(fromLE(bm[k1])), 32);
             call("zkmi_memcpy_h2d", p.at(n - 2), raw, 64);
-            call("zkmi_fr_batch_dev", f.cid, 0, p.ptr, p.ptr, n);
         }
         const pA = track(A.ntt(true)), pB = track(B.ntt(true)), pC = track(Cw.ntt(true));
         const eA = track(pA.extendedEvals(4)), eB = track(pB.extendedEvals(4)), eC = track(pC.extendedEvals(4));
@@ -182,9 +181,7 @@ function* proveSteps(key, wt, blindingMont, track) {
         const gamma = tr.challenge();
         const Zb = P(n, false);
         call("zkmi_plonk_compute_z_dev", f.cid, A.ptr, B.ptr, Cw.ptr, key.sec(12, n), key.sec(13, n), key.sec(14, n), n, mont(beta), mont(gamma), mont(key.k1), mont(key.k2), wN, Zb.ptr);
-        let pZ = track(Zb.ntt(true));
-        const eZ = track(pZ.extendedEvals(4));
-        pZ = track(pZ.blinded([b[9], b[8], b[7]]));
+        const [pZ, eZ] = Zb.ifftBlinded([b[9], b[8], b[7]]).map(track);
         const b789 = new Uint8Array(96); b789.set(mont(b[7]), 0); b789.set(mont(b[8]), 32); b789.set(mont(b[9]), 64);
         const T1 = P(2 * n, false), T1z = P(2 * n, false);
         call("zkmi_fflonk_t1_dev", f.cid, eZ.ptr, key.sec(15), n, b789, w2N, T1.ptr, T1z.ptr);
@@ -212,31 +209,30 @@ function* proveSteps(key, wt, blindingMont, track) {
         const h2 = h1 * xs2 % r, S2 = pw(key.w3, 3).map((x) => h2 * x % r);
         const h3 = h2 * key.wr % r, S2p = pw(key.w3, 3).map((x) => h3 * x % r);
         const xi = h2 * h2 % r * h2 % r, xiw = xi * wv % r;
-        for (const [k, t] of [["ql", 7], ["qr", 8], ["qm", 9], ["qo", 10], ["qc", 11], ["s1", 12], ["s2", 13], ["s3", 14]]) {
-            const p = new Poly(f, n, false).copyFrom(key.sec(t, 0), n);
-            evs[k] = p.evaluate(xi);
-            p.free();
-        }
-        evs.a = pA.evaluate(xi); evs.b = pB.evaluate(xi); evs.c = pC.evaluate(xi); evs.z = pZ.evaluate(xi);
-        evs.zw = pZ.evaluate(xiw); evs.t1w = pT1.evaluate(xiw); evs.t2w = pT2.evaluate(xiw);
+        // fifteen evaluations, two waits (zkmi_poly_evaluate_multi_dev); the selector and sigma polynomials are read where they lie in the key
+        const EV = ["ql", "qr", "qm", "qo", "qc", "s1", "s2", "s3", "a", "b", "c", "z", "zw", "t1w", "t2w"];
+        const evalAll = (pairs) => { let out = []; for (let i = 0; i < pairs.length; i += 8) { const c = pairs.slice(i, i + 8); out = out.concat(I.evaluateMany(f, c.map(([p]) => p), c.map(([, x]) => x))); } return out; };
+        evalAll([7, 8, 9, 10, 11, 12, 13, 14].map((t) => [[key.sec(t, 0), n], xi]).concat([pA, pB, pC, pZ].map((p) => [[p.ptr, p.n], xi]), [pZ, pT1, pT2].map((p) => [[p.ptr, p.n], xiw])))
+            .forEach((v, i) => { evs[EV[i]] = v; });
 
         // ---- ROUND 4 (:965-1057)
         tr = new Transcript(f);
         tr.scalar(xiSeed);
-        const EV = ["ql", "qr", "qm", "qo", "qc", "s1", "s2", "s3", "a", "b", "c", "z", "zw", "t1w", "t2w"];
         for (const k of EV) tr.scalar(evs[k]);
         const alpha = tr.challenge();
-        const C0 = P(8 * n, false).copyFrom(key.sec(17, 0), 8 * n);
-        const S22 = S2.concat(S2p);
-        const R0 = lagrange(S0, S0.map((x) => C0.evaluate(x)), r), R1 = lagrange(S1, S1.map((x) => C1.evaluate(x)), r), R2 = lagrange(S22, S22.map((x) => C2.evaluate(x)), r);
-        const nF = Math.max(C0.n, C1.n, C2.n), F = P(nF).copyFrom(C0.ptr, C0.n);
-        F.axpy(small(f, R0, track), null, true);
-        call("zkmi_poly_div_by_zerofier_dev", f.cid, F.ptr, C0.n, 8, mont(xi));                       // the division acts on C0's own length
-        const f2 = P(C1.n, false).copyFrom(C1.ptr, C1.n);
-        f2.axpy(small(f, R1, track), null, true); f2.scale(alpha); divZerofier(f2, 4, xi);
-        const f3 = P(C2.n, false).copyFrom(C2.ptr, C2.n);
-        f3.axpy(small(f, R2, track), null, true); f3.scale(alpha * alpha % r); divZerofier(f3, 3, xi); divZerofier(f3, 3, xiw);
-        F.axpy(f2); F.axpy(f3);
+        const C0p = key.sec(17, 0), C0n = 8 * n, S22 = S2.concat(S2p), neg = (v) => mod(-v, r);   // C0 is read where it lies in the key
+        // eighteen evaluations at the opening roots, three waits
+        const vals = evalAll(S0.map((x) => [[C0p, C0n], x]).concat(S1.map((x) => [[C1.ptr, C1.n], x]), S22.map((x) => [[C2.ptr, C2.n], x])));
+        const R0 = lagrange(S0, vals.slice(0, 8), r), R1 = lagrange(S1, vals.slice(8, 12), r), R2 = lagrange(S22, vals.slice(12), r);
+        // F = (C0 - R0) / ZT0 + alpha (C1 - R1) / ZT1 + alpha^2 (C2 - R2) / ZT2 (:1009-1042): each numerator one launch (zkmi_poly_lincomb_dev)
+        const nF = Math.max(C0n, C1.n, C2.n), a2 = alpha * alpha % r;
+        const F = I.lincomb(f, P(nF, false), [[C0p, C0n, null], [small(f, R0, track).ptr, R0.length, neg(1n)]]);
+        call("zkmi_poly_div_by_zerofier_dev", f.cid, F.ptr, C0n, 8, mont(xi));                         // the division acts on C0's own length
+        const f2 = I.lincomb(f, P(C1.n, false), [[C1.ptr, C1.n, alpha], [small(f, R1, track).ptr, R1.length, neg(alpha)]]);
+        divZerofier(f2, 4, xi);
+        const f3 = I.lincomb(f, P(C2.n, false), [[C2.ptr, C2.n, a2], [small(f, R2, track).ptr, R2.length, neg(a2)]]);
+        divZerofier(f3, 3, xi); divZerofier(f3, 3, xiw);
+        I.lincomb(f, F, [[F.ptr, nF, null], [f2.ptr, f2.n, null], [f3.ptr, f3.n, null]]);
         if (degree(F) >= 9 * n - 6) throw new Error("F Polynomial is not well calculated");
         pts.W1 = yield F;
 
@@ -248,15 +244,12 @@ function* proveSteps(key, wt, blindingMont, track) {
         const mulL0 = prod(S0), mulL1 = prod(S1), mulL2 = prod(S22);
         const preL0 = mulL1 * mulL2 % r, preL1 = alpha * mulL0 % r * mulL2 % r, preL2 = alpha * alpha % r * mulL0 % r * mulL1 % r;
         const toInv = [["denH1", mulL1], ["denH2", mulL2]];
-        const Lp = P(nF).copyFrom(C0.ptr, C0.n);
-        Lp.addScalar(mod(-evalSmall(R0, y, r), r)); Lp.scale(preL0);
-        const l2 = P(C1.n, false).copyFrom(C1.ptr, C1.n);
-        l2.addScalar(mod(-evalSmall(R1, y, r), r)); Lp.axpy(l2, preL1);
-        const l3 = P(C2.n, false).copyFrom(C2.ptr, C2.n);
-        l3.addScalar(mod(-evalSmall(R2, y, r), r)); Lp.axpy(l3, preL2);
-        Lp.axpy(F, evalSmall(zerofier(S0.concat(S1, S22), r), y, r), true);
+        // L = preL0 (C0 - R0(y)) + preL1 (C1 - R1(y)) + preL2 (C2 - R2(y)) - ZT(y) F, times 1 / ZTS2(y) (:1061-1083): one launch. The scalar does not move the degree the
+        // reference tests before it multiplies by it
+        const inv2 = modinv(evalSmall(zerofier(S1.concat(S22), r), y, r), r), zty = evalSmall(zerofier(S0.concat(S1, S22), r), y, r);
+        const Lp = I.lincomb(f, P(nF, false), [[C0p, C0n, preL0 * inv2 % r], [C1.ptr, C1.n, preL1 * inv2 % r], [C2.ptr, C2.n, preL2 * inv2 % r], [F.ptr, nF, neg(zty * inv2 % r)]],
+                             neg((preL0 * evalSmall(R0, y, r) + preL1 * evalSmall(R1, y, r) + preL2 * evalSmall(R2, y, r)) % r * inv2 % r));
         if (degree(Lp) >= 9 * n) throw new Error("L Polynomial is not well calculated");
-        Lp.scale(modinv(evalSmall(zerofier(S1.concat(S22), r), y, r), r));
         try { divZerofier(Lp, 1, y); } catch (e) { throw new Error("Degree of L(X)/(ZTS2(y)(X-y)) remainder is not 0"); }
         if (degree(Lp) >= 9 * n - 1) throw new Error("Degree of L(X)/(ZTS2(y)(X-y)) is not correct");
         pts.W2 = yield Lp;

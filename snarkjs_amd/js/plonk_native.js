@@ -88,7 +88,11 @@ class Poly {
         return out;
     }
     ntt(inverse, out = null) { out = out || new Poly(this.f, this.n, false); call("zkmi_ntt_dev", this.f.cid, this.ptr, out.ptr, Math.log2(this.n), inverse ? 1 : 0, null, null); return out; }
-    extendedEvals(ext) { const e = new Poly(this.f, this.n * ext).copyFrom(this.ptr, this.n); return e.ntt(false, e); }   // Evaluations.fromPolynomial
+    extendedEvals(ext) {                                                 // Evaluations.fromPolynomial: the zero padding is read by the first pass, never written
+        const e = new Poly(this.f, this.n * ext, false);
+        call("zkmi_ntt_padded_dev", this.f.cid, this.ptr, this.n, e.ptr, Math.log2(this.n * ext), 0);
+        return e;
+    }
     // The pattern of rounds 1 and 2 (plonk_prove.js:285-311, :441-455): coefficients = ifft(this) into a buffer with room for the blinding tail, Evaluations.fromPolynomial(.., 4)
     // with the zero padding READ instead of written (zkmi_ntt_padded_dev), blindCoefficients in place (zkmi_poly_blind_tail_dev) -> [blinded polynomial, 4n evaluations]
     ifftBlinded(factors) {

@@ -123,9 +123,9 @@ class _Poly:
 
     def extended_evals(self, ext):
         """Evaluations.fromPolynomial(p, 4): zero-pad to ext*n coefficients, then fft (evaluations.js:30-37)"""
-        e = _Poly(self.f, self.n * ext)
-        e.copy_from(self.ptr, self.n)
-        return e.ntt(False, out=e)
+        e = _Poly(self.f, self.n * ext, zero=False)                                       # the padding is read as zero by the first pass, never written (zkmi_ntt_padded_dev)
+        zkmi.check(zkmi.lib().zkmi_ntt_padded_dev(self.f.cid, self.ptr, self.n, e.ptr, (self.n * ext).bit_length() - 1, 0))
+        return e
 
     def ifft_blinded(self, factors):
         """The pattern of rounds 1 and 2 (plonk_prove.js:285-311, :441-455) in four launches less per polynomial: coefficients = ifft(self) into a buffer with room for the
