@@ -193,10 +193,10 @@ constexpr uint32_t RSORT_TILE = 1024;            // scalars per level-1 block (2
 constexpr uint32_t RSORT_CHUNK = 8192;           // pairs per level-2 block
 constexpr uint32_t RSORT_MAX_PARTS = 4096;
 
-template <int NW, class Fn> ZK_DEV void rsort_tile_digits(const uint8_t* __restrict__ scalars, const MsmShape& sh, const uint32_t* __restrict__ dropmask, Fn f) {
+template <int NW, int BS = 256, class Fn> ZK_DEV void rsort_tile_digits(const uint8_t* __restrict__ scalars, const MsmShape& sh, const uint32_t* __restrict__ dropmask, Fn f) {
 #pragma unroll 1
-    for (uint32_t j = 0; j < RSORT_TILE / 256; j++) {
-        const size_t i = (size_t)blockIdx.x * RSORT_TILE + j * 256 + threadIdx.x;
+    for (uint32_t j = 0; j < RSORT_TILE / BS; j++) {
+        const size_t i = (size_t)blockIdx.x * RSORT_TILE + j * BS + threadIdx.x;
         if (i >= sh.n) break;
         if (dropmask && ((dropmask[i >> 5] >> (i & 31)) & 1u)) continue;
         uint32_t s[NW];
@@ -228,6 +228,53 @@ k_rsort_scatter1(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_
         const uint32_t pos = atomicAdd(&cur[g >> lb], 1u);
         tmp[pos] = make_uint2(ent, g & ((1u << lb) - 1));
     });
+}
+// r06: the same scatter with the block's pairs ranked in LDS first and written out in partition order. The direct version above issues one 8-byte store per
+// pair to wherever its partition's cursor stands: 64 lanes, 64 partitions, 64 write transactions per wave instruction — 13.6 M of them for a 2^20-term table
+// MSM, 109 us standalone against 35 us for k_rsort_hist1, which does the same digit work. Here a lane of the copy-out loop writes the pair next to its
+// neighbour's: a block's share of a partition (26 pairs on uniform scalars) leaves as one contiguous run. This block's count per partition is the difference
+// of two neighbouring entries of the scanned matrix (entry p nblk + blk + 1 follows entry p nblk + blk in scan order, across the partition boundary too).
+// LDS: cursor[P] | delta[P] | scan[1024] | entry[cap] | key[cap], cap = Wd x RSORT_TILE pairs (110 KB for 13 digits and 512 partitions: one 1024-lane block per CU).
+template <int NW> __global__ void __launch_bounds__(1024)
+k_rsort_scatter1_staged(const uint8_t* __restrict__ scalars, MsmShape sh, const uint32_t* __restrict__ dropmask, uint32_t nparts, uint32_t lb, const uint32_t* __restrict__ bhoff,
+                        uint32_t cap, uint2* __restrict__ tmp) {
+    extern __shared__ uint32_t rs1_lds[];
+    uint32_t *cur = rs1_lds, *delta = cur + nparts, *sc = delta + nparts, *s_ent = sc + 1024, *s_key = s_ent + cap;
+    // partitions per lane of the block scan (nparts <= RSORT_MAX_PARTS = 4 x 1024)
+    const uint32_t per = (nparts + 1023) / 1024, p0 = threadIdx.x * per;
+    uint32_t gb[4], cn[4], sum = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        gb[q] = 0; cn[q] = 0;
+        if (q < per && p0 + q < nparts) {
+            const size_t at = (size_t)(p0 + q) * gridDim.x + blockIdx.x;
+            gb[q] = bhoff[at]; cn[q] = bhoff[at + 1] - gb[q];
+            sum += cn[q];
+        }
+    }
+    sc[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t t = threadIdx.x >= d ? sc[threadIdx.x - d] : 0u;
+        __syncthreads();
+        sc[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = sc[threadIdx.x] - sum;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) if (q < per && p0 + q < nparts) { cur[p0 + q] = run; delta[p0 + q] = gb[q] - run; run += cn[q]; }
+    const uint32_t mine = sc[1023];
+    __syncthreads();
+    rsort_tile_digits<NW, 1024>(scalars, sh, dropmask, [&](uint32_t g, uint32_t ent) {
+        const uint32_t pos = atomicAdd(&cur[g >> lb], 1u);
+        s_ent[pos] = ent; s_key[pos] = g;
+    });
+    __syncthreads();
+    const uint32_t low = (1u << lb) - 1;
+    for (uint32_t j = threadIdx.x; j < mine; j += 1024) {
+        const uint32_t g = s_key[j];
+        tmp[delta[g >> lb] + j] = make_uint2(s_ent[j], g & low);
+    }
 }
 // chunk table: chunks[3k..3k+2] = (partition, first pair, number of pairs); meta[0] = number of chunks. One block.
 static __global__ void __launch_bounds__(1024)
@@ -266,14 +313,19 @@ k_rsort_chunks(const uint32_t* __restrict__ bhoff, uint32_t nparts, uint32_t nbl
 }
 static __global__ void __launch_bounds__(256)
 k_rsort_hist2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ chunks, const uint32_t* __restrict__ meta, uint32_t* __restrict__ h2) {
-    if (blockIdx.x >= meta[0]) return;
+    // r06: the grid is a few hundred blocks walking the chunk table, not one block per POSSIBLE chunk: with the fused level 2 (k_rsort_part) the table is
+    // usually empty, and 2 177 blocks that read meta[0] and leave cost 17 us per launch
     __shared__ uint32_t h[RSORT_BINS];
-    for (uint32_t b = threadIdx.x; b < RSORT_BINS; b += 256) h[b] = 0;
-    __syncthreads();
-    const uint32_t first = chunks[3 * blockIdx.x + 1], len = chunks[3 * blockIdx.x + 2];
-    for (uint32_t j = threadIdx.x; j < len; j += 256) atomicAdd(&h[tmp[first + j].y], 1u);
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < RSORT_BINS; b += 256) h2[(size_t)blockIdx.x * RSORT_BINS + b] = h[b];
+    const uint32_t nch = meta[0];
+    for (uint32_t ch = blockIdx.x; ch < nch; ch += gridDim.x) {
+        for (uint32_t b = threadIdx.x; b < RSORT_BINS; b += 256) h[b] = 0;
+        __syncthreads();
+        const uint32_t first = chunks[3 * ch + 1], len = chunks[3 * ch + 2];
+        for (uint32_t j = threadIdx.x; j < len; j += 256) atomicAdd(&h[tmp[first + j].y], 1u);
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < RSORT_BINS; b += 256) h2[(size_t)ch * RSORT_BINS + b] = h[b];
+        __syncthreads();
+    }
 }
 // one block per partition: h2[chunk][bin] <- exclusive prefix over the partition's chunks; counts / starts of the partition's buckets
 static __global__ void __launch_bounds__(1024)
@@ -307,14 +359,17 @@ k_rsort_scan2(const uint32_t* __restrict__ bhoff, uint32_t nblk, uint32_t lb, ui
 static __global__ void __launch_bounds__(256)
 k_rsort_scatter2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ chunks, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ h2,
                  const uint32_t* __restrict__ starts, uint32_t lb, uint32_t* __restrict__ sorted) {
-    if (blockIdx.x >= meta[0]) return;
     __shared__ uint32_t cur[RSORT_BINS];
-    const uint32_t p = chunks[3 * blockIdx.x], first = chunks[3 * blockIdx.x + 1], len = chunks[3 * blockIdx.x + 2], bins = 1u << lb;
-    for (uint32_t b = threadIdx.x; b < bins; b += 256) cur[b] = starts[(size_t)p * bins + b] + h2[(size_t)blockIdx.x * RSORT_BINS + b];
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < len; j += 256) {
-        const uint2 e = tmp[first + j];
-        sorted[atomicAdd(&cur[e.y], 1u)] = e.x;
+    const uint32_t nch = meta[0], bins = 1u << lb;
+    for (uint32_t ch = blockIdx.x; ch < nch; ch += gridDim.x) {                 // r06: a walk over the chunk table, as in k_rsort_hist2
+        const uint32_t p = chunks[3 * ch], first = chunks[3 * ch + 1], len = chunks[3 * ch + 2];
+        for (uint32_t b = threadIdx.x; b < bins; b += 256) cur[b] = starts[(size_t)p * bins + b] + h2[(size_t)ch * RSORT_BINS + b];
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < len; j += 256) {
+            const uint2 e = tmp[first + j];
+            sorted[atomicAdd(&cur[e.y], 1u)] = e.x;
+        }
+        __syncthreads();
     }
 }
 // r05: level 2 in ONE kernel for a partition whose pairs fit an LDS staging buffer (one block per partition): histogram of the low keys, scan
@@ -402,7 +457,7 @@ static __global__ void __launch_bounds__(256) k_msm_classify(const uint32_t* __r
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) if (h[i]) atomicAdd(&hist[i], h[i]);
 }
-// r06: the first lane of every key class (k_msm_class_scan's table) is recomputed by every block in its own LDS — 544 additions by one lane, ~2 us, against a launch
+// r06: the first lane of every key class (k_msm_class_scan's table) is recomputed by every block in its own LDS by its first wave, against a launch
 // of its own between classify and assign (19 us of stream time per sort, nine sorts per PLONK proof); block 0 publishes the totals
 static __global__ void __launch_bounds__(256)
 k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, uint32_t log_tb, const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
@@ -410,15 +465,23 @@ k_msm_assign(const uint32_t* __restrict__ counts, uint32_t total, uint32_t cap, 
     __shared__ uint32_t h[MSM_NKEYS], base[MSM_NKEYS], off[MSM_NKEYS + 1];
     for (uint32_t i = threadIdx.x; i < MSM_NKEYS; i += blockDim.x) { h[i] = 0; off[i] = i ? hist[i] << msm_key_lanes_log(i, cap) : 0u; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0, multi = 0;
-        for (int k = (int)MSM_NKEYS - 1; k >= 1; k--) {
-            const uint32_t c = off[k];
-            off[k] = run;
-            run += c;
-            if ((uint32_t)k == 2 * cap) multi = run;
-        }
-        if (blockIdx.x == 0) { meta[0] = run; meta[1] = multi; }
+    if (threadIdx.x < 64) {
+        // exclusive suffix scan over the classes in descending key order by ONE wave: lane L owns the KPL keys below MSM_NKEYS - KPL L (the walk of
+        // one lane over all 544 classes was 15 us of every block's start)
+        constexpr int KPL = (MSM_NKEYS + 63) / 64;
+        const int top = (int)MSM_NKEYS - 1 - KPL * (int)threadIdx.x;
+        uint32_t s = 0;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) { const int k = top - q; if (k >= 1) s += off[k]; }
+        uint32_t incl = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += t; }
+        uint32_t run = incl - s;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) { const int k = top - q; if (k >= 1) { const uint32_t c = off[k]; off[k] = run; run += c; } }
+        const uint32_t all = __shfl(incl, 63);
+        // lanes of multi-lane groups = classes 2 cap and above = the first lane of class 2 cap - 1 (cap >= 8: that class exists and is a single-lane one)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { meta[0] = all; meta[1] = off[2 * cap - 1]; }
     }
     uint32_t lo, hi;
     msm_sched_run(total, lo, hi);

@@ -47,6 +47,22 @@ static bool rsort_fused_fits() {
     });
     return fits;
 }
+// The staged level-1 scatter (msm.cuh: k_rsort_scatter1_staged) needs Wd x RSORT_TILE pairs of LDS beside its cursors: taken where that fits the device
+// (checked once per instantiation, like the fused level 2 above), the direct scatter otherwise.
+template <int NW> static bool rsort_staged_fits(size_t lds) {
+    static std::once_flag once;
+    static size_t limit = 0;
+    std::call_once(once, [] {
+        if (getenv("ZKMI_RSORT_STAGED") && atoi(getenv("ZKMI_RSORT_STAGED")) == 0) return;
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) { (void)hipGetLastError(); return; }
+        const size_t want = strncmp(pr.gcnArchName, "gfx950", 6) == 0 ? (size_t)156 * 1024 : (size_t)pr.maxSharedMemoryPerMultiProcessor;
+        if (hipFuncSetAttribute((const void*)k_rsort_scatter1_staged<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) { (void)hipGetLastError(); return; }
+        limit = want;
+    });
+    return lds <= limit;
+}
 // low-key bits for this shape: 10 (ZKMI_RSORT_LB=9: 9) when the fused level 2 can take a typical partition (entries / partitions <= 0.9 cap), else 11
 static uint32_t rsort_low_bits(const MsmShape& sh) {
     static const uint32_t want = getenv("ZKMI_RSORT_LB") ? (uint32_t)atoi(getenv("ZKMI_RSORT_LB")) : 10u;
@@ -77,15 +93,22 @@ template <int NW> static int msm_launch_digits_radix(const uint8_t* d_scalars, c
     hipLaunchKernelGGL(k_msm_scan_sums, dim3(nsp), dim3(256), 0, st, bh, (uint32_t)nbh, part);
     hipLaunchKernelGGL(k_msm_scan_top, dim3(1), dim3(1024), 0, st, part, nsp);
     hipLaunchKernelGGL(k_msm_scan_final, dim3(nsp), dim3(256), 0, st, bh, (uint32_t)nbh, part, bhoff);
-    hipLaunchKernelGGL((k_rsort_scatter1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, lb, bhoff, tmp);
+    // level-1 scatter: ranked in LDS and written as runs where a block's pairs fit (ZKMI_RSORT_STAGED=0: the direct scatter everywhere)
+    const uint32_t stage_cap = (uint32_t)sh.Wd * RSORT_TILE;
+    const size_t stage_lds = ((size_t)2 * P + 1024 + (size_t)2 * stage_cap) * 4;
+    if (rsort_staged_fits<NW>(stage_lds))
+        hipLaunchKernelGGL((k_rsort_scatter1_staged<NW>), dim3(nblk), dim3(1024), stage_lds, st, d_scalars, sh, dropmask, P, lb, bhoff, stage_cap, tmp);
+    else
+        hipLaunchKernelGGL((k_rsort_scatter1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, lb, bhoff, tmp);
     hipLaunchKernelGGL(k_rsort_chunks, dim3(1), dim3(1024), 0, st, bhoff, P, nblk, fused_cap, pchunk0, ck, meta, sched_zero, sched_zero_words);
     if (fused_cap) {
         const size_t lds = ((size_t)(1u << lb) + 1024 + fused_cap) * 4;
         hipLaunchKernelGGL(k_rsort_part, dim3(P), dim3(1024), lds, st, tmp, bhoff, nblk, lb, fused_cap, counts, starts, sorted);
     }
-    hipLaunchKernelGGL(k_rsort_hist2, dim3((unsigned)nch_max), dim3(256), 0, st, tmp, ck, meta, h2);
+    const unsigned chunk_blocks = (unsigned)std::min<size_t>(nch_max, 1024);                       // the chunk kernels walk the table (meta[0] chunks)
+    hipLaunchKernelGGL(k_rsort_hist2, dim3(chunk_blocks), dim3(256), 0, st, tmp, ck, meta, h2);
     hipLaunchKernelGGL(k_rsort_scan2, dim3(P), dim3(1024), 0, st, bhoff, nblk, lb, fused_cap ? 1u : 0u, pchunk0, h2, counts, starts);
-    hipLaunchKernelGGL(k_rsort_scatter2, dim3((unsigned)nch_max), dim3(256), 0, st, tmp, ck, meta, h2, starts, lb, sorted);
+    hipLaunchKernelGGL(k_rsort_scatter2, dim3(chunk_blocks), dim3(256), 0, st, tmp, ck, meta, h2, starts, lb, sorted);
     return ZKMI_OK;
 }
 static bool msm_use_radix(const MsmShape& sh) {
