@@ -163,6 +163,23 @@ struct ListReader {
         return sel == 0 ? buf.x : (sel == 1 ? buf.y : (sel == 2 ? buf.z : buf.w));
     }
 };
+// r06: one list entry taken SPECULATIVELY. The accumulation loops used to read a list entry, wait for the word of the infinity bitmap it points at, and only
+// then issue the gather of the table entry — a dependent wait (an L2 round trip) in front of every mixed addition, in the wave that is about to issue it.
+// Now the bitmap word and the table entry are requested together and the bit is looked at one addition later, when the point is consumed: by then both
+// have arrived. Entries of points at infinity (and entries below `skip`, which belong to another slice of the table) are rare in a list — the sort drops
+// the bases a key knows to be zero — and cost one pass of the catch-up loop, which waits the way the old code always did.
+// Measured (profiles/r06_spec_gather_ab.txt, one box, product against a -DZK_SPEC_GATHER=0 build, interleaved, two runs each): G1 accumulation 1.072 / 1.074 against
+// 1.079 / 1.099 ms, 14-limb G2 6.96 / 7.05 against 7.09 / 7.25 ms, but BN254 G2 2.90 / 2.96 against 2.86 / 2.85 ms (three more live registers at 245 of 256) —
+// so the G1 kernels and the 14-limb G2 kernel take it, BN254 G2 keeps the waiting loop. End to end nothing moves by more than the run-to-run spread: the
+// kernels are bound by integer issue, not by this wait.
+#ifndef ZK_SPEC_GATHER
+#define ZK_SPEC_GATHER 1
+#endif
+#ifndef ZK_SPEC_GATHER_G2
+#define ZK_SPEC_GATHER_G2(C) (ZK_SPEC_GATHER && Lim29<C>::NL > 9)
+#endif
+struct SpecEntry { uint32_t e, m, s; };                            // list entry, bitmap word, bit number in it (32: not in this slice of the table)
+ZK_DEV bool spec_dead(const SpecEntry& x) { return x.s >= 32u || ((x.m >> x.s) & 1u); }
 // an affine coordinate (C::N words = C::N / 4 vectors) of a gathered table entry -> limbs
 template <class C> ZK_DEV Fp29<C> unpack29_v(const uint4* v) {
     uint32_t w[C::N];
@@ -222,6 +239,35 @@ k_msm_accum29(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ i
         }
         return false;
     };
+#if ZK_SPEC_GATHER
+    auto fetch_spec = [&](SpecEntry& x, Raw& r_out) -> bool {
+        if (!list.more()) return false;
+        const uint32_t e = list.next();
+        uint32_t idx = e & 0x7fffffffu;
+        const bool mine = idx >= skip;
+        idx = mine ? idx - skip : 0u;
+        x.e = e; x.s = mine ? (idx & 31u) : 32u;
+        x.m = infmask[idx >> 5];
+        const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)idx * (2 * N));
+#pragma unroll
+        for (int i = 0; i < AV; i++) r_out.v[i] = p[i];
+        return true;
+    };
+    SpecEntry x_next{0, 0, 32};
+    Raw r_next;
+    bool have = fetch_spec(x_next, r_next);
+    while (have) {
+        SpecEntry x = x_next;
+        Raw r = r_next;
+        have = fetch_spec(x_next, r_next);                  // the next bitmap word and gather are in flight during this addition
+        while (spec_dead(x) && have) { x = x_next; r = r_next; have = fetch_spec(x_next, r_next); }
+        if (spec_dead(x)) break;
+        Aff29<C> q;
+        q.x = unpack29_v<C>(r.v); q.y = unpack29_v<C>(r.v + AV / 2);
+        if (x.e >> 31) { q.y = sub29<C, 2>(zero29<C>(), q.y); norm29(q.y); }    // 2p - y
+        madd29(acc, inf, q);
+    }
+#else
     uint32_t e_next = 0;
     Raw r_next;
     bool have = fetch(e_next, r_next);
@@ -234,6 +280,7 @@ k_msm_accum29(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ i
         if (e >> 31) { q.y = sub29<C, 2>(zero29<C>(), q.y); norm29(q.y); }      // 2p - y
         madd29(acc, inf, q);
     }
+#endif
     // lane partials of multi-lane buckets go to k_msm_tree in the reference's R-form; finished buckets stay in R'-form for the row /
     // column sums on the same limbs (k_msm_rowcol_wave29) and for a later merge into the same buckets
     if (j) store_xyzz29<C, false>(lane_partials + (size_t)lane * PW, acc, inf);
@@ -647,7 +694,35 @@ k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict_
         qx.c0 = unpack29_v<C>(v); qx.c1 = unpack29_v<C>(v + AV / 4); qy.c0 = unpack29_v<C>(v + AV / 2); qy.c1 = unpack29_v<C>(v + 3 * AV / 4);
         if (e >> 31) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }
     };
-    if constexpr (ZK_G2_PREFETCH(C)) {
+    if constexpr (ZK_G2_PREFETCH(C) && ZK_SPEC_GATHER_G2(C)) {
+        auto fetch_spec = [&](SpecEntry& x, Raw& r_out) -> bool {
+            if (!list.more()) return false;
+            const uint32_t e = list.next();
+            uint32_t idx = e & 0x7fffffffu;
+            const bool mine = idx >= skip;
+            idx = mine ? idx - skip : 0u;
+            x.e = e; x.s = mine ? (idx & 31u) : 32u;
+            x.m = infmask[idx >> 5];
+            const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)idx * (4 * N));
+#pragma unroll
+            for (int i = 0; i < AV; i++) r_out.v[i] = p[i];
+            return true;
+        };
+        SpecEntry x_next{0, 0, 32};
+        Raw r_next;
+        bool have = fetch_spec(x_next, r_next);
+        while (have) {
+            SpecEntry x = x_next;
+            Raw r = r_next;
+            have = fetch_spec(x_next, r_next);                      // the next bitmap word and gather are in flight during this addition
+            while (spec_dead(x) && have) { x = x_next; r = r_next; have = fetch_spec(x_next, r_next); }
+            if (spec_dead(x)) break;
+            const uint32_t e = x.e;
+            F2x<C> qx{unpack29_v<C>(r.v), unpack29_v<C>(r.v + AV / 4)}, qy{unpack29_v<C>(r.v + AV / 2), unpack29_v<C>(r.v + 3 * AV / 4)};
+            if (e >> 31) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }      // 2p - y
+            Accum29G2<C>::madd(A, inf, qx, qy, [&](F2x<C>& x2, F2x<C>& y2) { regather(e, x2, y2); });
+        }
+    } else if constexpr (ZK_G2_PREFETCH(C)) {
         uint32_t e_next = 0;
         Raw r_next;
         bool have = fetch(e_next, r_next);

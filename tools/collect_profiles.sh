@@ -48,6 +48,8 @@ rm -f $O/stats_real/*/*kernel_trace.csv $O/stats_p24/*/*kernel_trace.csv $O/stat
 { echo "== the shipped build: one asm statement per COLUMN of the product scanning (every field)"; tools/bin/fieldbench29;
   echo "== -DZK_MAD_PLAIN: multiply-adds in plain C everywhere"; tools/bin/fieldbench29_plain;
   echo "== -DZK_MAD_PLAIN -DZK_MAD_ASM: one inline-asm statement per multiply-add (the r03 build: one s_nop behind each)"; tools/bin/fieldbench29_asm; tools/bin/maddbench29; } > $O/fieldbench29.txt 2>&1
+# r06: every kernel of ONE table MSM by itself (sort and accumulation on one stream: the sort kernels' own durations)
+bash tools/lab/r6_sort_probe.sh > $O/sort_probe.txt 2>&1
 # the multi-rank code path of bench.py on this ONE GPU (a 1-rank RCCL communicator): sharded MSM over resident tables, one proof over all ranks at 2^20 and at 2^24 (BASELINE configs[2])
 ZKMI_FORCE_DIST=1 timeout 1200 python bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-napi-wall --no-other-configs > $O/bench_force_dist.json 2>/dev/null
 # the whole GPU suite on this box
