@@ -749,6 +749,185 @@ k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict_
     else Accum29G2<C>::template store<false>(buckets + (size_t)g * (8 * N), A, inf);
 }
 
+// ---- r06: G2 accumulation with ONE Fq2 COMPONENT PER LANE (9-limb moduli) ------------------------------------------------------------------
+// The two components of a bucket sit eight lanes apart in a row of sixteen (lanes 0-7 of a row: c0, lanes 8-15: c1). The accumulator is half as wide
+// and stays in REGISTERS (151 VGPRs, three waves per SIMD, no LDS), and every Fq2 product fetches the partner's operands with DPP moves (row_ror:8; the
+// move's bank mask does the per-component selection, no v_cndmask is spent): (a0 + a1 u)(b0 + b1 u) — the c0 lane forms a0 b0 + a1 (K p - b1), the c1
+// lane a1 b0 + a0 b1, each ONE mul29_2 on the operands madd29_lds hands the same product, so every coordinate leaves with the same words. Measured first
+// in isolation (tools/maddbench29_g2, profiles/r06_g2_layout.txt): 5.10 against 4.60 G additions/s for the LDS-parked layout.
+#if defined(__HIP_DEVICE_COMPILE__)
+constexpr int DPP_ROR8 = 0x128;                                      // row_ror:8 — lane i of a row of 16 reads lane i ^ 8
+// the partner's value in every lane
+template <class C> ZK_DEV Fp29<C> xch_all(const Fp29<C>& v) {
+    Fp29<C> r;
+#pragma unroll
+    for (int i = 0; i < Lim29<C>::NL; i++) {
+        r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], DPP_ROR8, 0xF, 0xF, false);
+        // keeps the move a move: folded into its only user (v_subrev_u32_dpp ... bound_ctrl:1 for the a0 - a1 of a square) the difference came out WRONG on
+        // the device, while the unfolded form of the same subtraction was right (tools/maddbench29_g2 -DZK_DPP_FOLD shows it)
+        asm volatile("" : "+v"(r.l[i]));
+    }
+    return r;
+}
+// lanes of the banks in BANKS (0x3: the c0 lanes, 0xC: the c1 lanes) take the PARTNER's src, the others keep `keep`
+template <class C, int BANKS> ZK_DEV Fp29<C> xch_into(const Fp29<C>& keep, const Fp29<C>& src) {
+    Fp29<C> r;
+#pragma unroll
+    for (int i = 0; i < Lim29<C>::NL; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp((int)keep.l[i], (int)src.l[i], DPP_ROR8, 0xF, BANKS, false);
+    return r;
+}
+// both lanes of a pair hold the AND of their flags
+ZK_DEV bool pair_and(bool f) { const int z = f ? 1 : 0; return (z & __builtin_amdgcn_update_dpp(0, z, DPP_ROR8, 0xF, 0xF, false)) != 0; }
+// the two right-hand operands of a split Fq2 product by b (own component bm, K p - bm in nb): y1 = b0 in both lanes, y2 = K p - b1 | b1
+template <class C> struct BRole29 { Fp29<C> y1, y2; };
+template <class C> ZK_DEV BRole29<C> b_role29(const Fp29<C>& bm, const Fp29<C>& nb) { return BRole29<C>{xch_into<C, 0xC>(bm, bm), xch_into<C, 0x3>(bm, nb)}; }
+// own component of a * b: am / ao = own / partner's component of a
+template <class C> ZK_DEV Fp29<C> f2mul_split(const Fp29<C>& am, const Fp29<C>& ao, const BRole29<C>& b) { return mul29_2(am, b.y1, ao, b.y2); }
+// own component of a^2 (components <= KB): the c0 lane forms (a0 + a1)(a0 - a1), the c1 lane 2 a0 a1; c1mask = all ones in the c1 lanes
+template <class C, int KB> ZK_DEV Fp29<C> f2sqr_split(const Fp29<C>& am, const Fp29<C>& ao, uint32_t c1mask) {
+    const Fp29<C> u = add29(am, xch_into<C, 0x3>(zero29<C>(), am));  // c0 lanes: a0 + a1; c1 lanes: a1
+    Fp29<C> d = sub29<C, KB>(am, ao); norm29(d);                      // c0 lanes: a0 - a1 (the c1 lanes' value is replaced)
+    const Fp29<C> v = xch_into<C, 0xC>(d, am);                        // c1 lanes: a0
+    Fp29<C> r = mul29(u, v);
+#pragma unroll
+    for (int i = 0; i < Lim29<C>::NL; i++) r.l[i] += r.l[i] & c1mask;
+    norm29(r);
+    return r;
+}
+template <class C> struct AccS29 { Fp29<C> X, Y, ZZ, ZZZ; };         // own component of every coordinate
+// acc += q: madd29_lds line by line — same formulas, same offsets, the same operands per component (its invariants hold per component: both
+// components of every value share one bound there). Both lanes of a pair take every branch together.
+template <class C> ZK_DEV void madd29_split(AccS29<C>& a, bool& inf, const Fp29<C>& qx, const Fp29<C>& qy, uint32_t c1mask) {
+    constexpr int NL = Lim29<C>::NL;
+    if (inf) {
+        a.X = qx; a.Y = qy;
+        const Fp29<C> one = one29<C>();
+#pragma unroll
+        for (int i = 0; i < NL; i++) a.ZZ.l[i] = a.ZZZ.l[i] = one.l[i] & ~c1mask;                  // (1, 0)
+        inf = false;
+        return;
+    }
+    const Fp29<C> ZZo = xch_all(a.ZZ);
+    const Fp29<C> U2 = f2mul_split(a.ZZ, ZZo, b_role29(qx, neg29<C, 2>(qx)));
+    ZK_SFENCE();
+    Fp29<C> P = sub29<C, 9>(U2, a.X); norm29(P);
+    const Fp29<C> ZZZo = xch_all(a.ZZZ);
+    const Fp29<C> S2 = f2mul_split(a.ZZZ, ZZZo, b_role29(qy, neg29<C, 3>(qy)));
+    ZK_SFENCE();
+    Fp29<C> R = sub29<C, 4>(S2, a.Y); norm29(R);
+    if (pair_and(is_zero29(P))) {
+        if (pair_and(is_zero29(R))) {
+            // acc = 2 q (mdbl-2008-s-1, a = 0); rare: equal points in one bucket
+            Fp29<C> U = add29(qy, qy); norm29(U);
+            const Fp29<C> Uo = xch_all(U), qxo = xch_all(qx);
+            const Fp29<C> V = f2sqr_split<C, 5>(U, Uo, c1mask);
+            const BRole29<C> bV = b_role29(V, neg29<C, 3>(V));
+            const Fp29<C> W = f2mul_split(U, Uo, bV), S = f2mul_split(qx, qxo, bV);
+            const Fp29<C> xx = f2sqr_split<C, 2>(qx, qxo, c1mask);
+            Fp29<C> M = add29(add29(xx, xx), xx); norm29(M);
+            const Fp29<C> Mo = xch_all(M);
+            Fp29<C> X3 = sub29<C, 2>(sub29<C, 2>(f2sqr_split<C, 7>(M, Mo, c1mask), S), S); norm29(X3);
+            Fp29<C> Tt = sub29<C, 7>(S, X3); norm29(Tt);
+            const Fp29<C> MT = f2mul_split(M, Mo, b_role29(Tt, neg29<C, 9>(Tt)));
+            const Fp29<C> Wy = f2mul_split(W, xch_all(W), b_role29(qy, neg29<C, 3>(qy)));
+            Fp29<C> Y3 = sub29<C, 2>(MT, Wy); norm29(Y3);
+            a.X = X3; a.Y = Y3; a.ZZ = V; a.ZZZ = W;
+        } else inf = true;
+        return;
+    }
+    const Fp29<C> Po = xch_all(P);
+    const Fp29<C> PP = f2sqr_split<C, 11>(P, Po, c1mask);
+    ZK_SFENCE();
+    const BRole29<C> bPP = b_role29(PP, neg29<C, 4>(PP));
+    const Fp29<C> PPP = f2mul_split(P, Po, bPP);
+    ZK_SFENCE();
+    const Fp29<C> nPPP = neg29<C, 2>(PPP);
+    const BRole29<C> bPPP = b_role29(PPP, nPPP);
+    a.ZZ = f2mul_split(a.ZZ, ZZo, bPP);
+    ZK_SFENCE();
+    a.ZZZ = f2mul_split(a.ZZZ, ZZZo, bPPP);
+    ZK_SFENCE();
+    const Fp29<C> Q = f2mul_split(a.X, xch_all(a.X), bPP);
+    ZK_SFENCE();
+    const Fp29<C> RR = f2sqr_split<C, 6>(R, xch_all(R), c1mask);
+    Fp29<C> X3 = sub29<C, 2>(sub29<C, 2>(sub29<C, 2>(RR, PPP), Q), Q); norm29(X3);
+    a.X = X3;
+    ZK_SFENCE();
+    Fp29<C> Tq = sub29<C, 9>(Q, X3); norm29(Tq);
+    // Y3 = Tq R + Y1 (-PPP), one reduction per component: the right-hand operands of R and of N = (2p - PPP0, 2p - PPP1)
+    const BRole29<C> bR = b_role29(R, neg29<C, 6>(R));
+    const BRole29<C> bN{xch_into<C, 0xC>(nPPP, nPPP), xch_into<C, 0x3>(nPPP, PPP)};
+    a.Y = mul29_4(Tq, bR.y1, xch_all(Tq), bR.y2, a.Y, bN.y1, xch_all(a.Y), bN.y2);
+}
+#endif
+// 128 schedule lanes (buckets or shares of a bucket) per 256-thread block; same arguments and results as k_msm_accum29_g2
+constexpr unsigned G2S_SLOTS = 128;
+template <class C> __global__ void __launch_bounds__(256, 3)
+k_msm_accum29_g2s(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ infmask, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts,
+                  const uint32_t* __restrict__ starts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub,
+                  const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials, int bucket_r29) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(Lim29<C>::NL <= 9, "one component per lane: 9-limb moduli (the 14-limb curve keeps its packed Jacobian accumulator in LDS)");
+    constexpr int N = C::N, HV = N / 4;                              // 16-byte vectors per component of a coordinate
+    const uint32_t t = threadIdx.x, comp = (t >> 3) & 1u, c1mask = comp ? 0xffffffffu : 0u;
+    const uint32_t lane = blockIdx.x * G2S_SLOTS + (((t >> 4) << 3) | (t & 7u));      // the schedule lane this PAIR works for
+    if (lane >= meta[0]) return;                                     // the partner leaves with it
+    const uint32_t g = lane_g[lane];
+    const uint32_t cnt = counts[g];
+    const uint32_t j = msm_key_lanes_log(msm_key(cnt, cap), cap);
+    uint32_t lo = 0, hi = cnt;
+    if (j) {
+        const uint32_t chunk = (cnt + (1u << j) - 1) >> j;
+        lo = min(cnt, lane_sub[lane] * chunk);
+        hi = min(cnt, lo + chunk);
+    }
+    AccS29<C> a;
+    bool inf = true;
+    const uint32_t s0 = starts[g];
+    ListReader list(sorted, s0 + lo, s0 + hi);
+    struct Raw { uint4 v[2 * HV]; };                                 // own component of x, own component of y
+    auto fetch = [&](uint32_t& e_out, Raw& r_out) -> bool {
+        while (list.more()) {
+            const uint32_t e = list.next();
+            uint32_t idx = e & 0x7fffffffu;
+            if (idx < skip) continue;
+            idx -= skip;
+            if ((infmask[idx >> 5] >> (idx & 31)) & 1u) continue;
+            const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)idx * (4 * N) + comp * N);
+#pragma unroll
+            for (int i = 0; i < HV; i++) { r_out.v[i] = p[i]; r_out.v[HV + i] = p[2 * HV + i]; }
+            e_out = e;
+            return true;
+        }
+        return false;
+    };
+    uint32_t e_next = 0;
+    Raw r_next;
+    bool have = fetch(e_next, r_next);
+    while (have) {
+        const uint32_t e = e_next;
+        const Raw r = r_next;
+        have = fetch(e_next, r_next);                               // the next gather is in flight during this addition
+        const Fp29<C> qx = unpack29_v<C>(r.v);
+        Fp29<C> qy = unpack29_v<C>(r.v + HV);
+        if (e >> 31) qy = neg29<C, 2>(qy);                          // 2p - y
+        madd29_split<C>(a, inf, qx, qy, c1mask);
+    }
+    // own component of every coordinate: word offset (2 coordinate + component) N of the point
+    uint32_t* dst = (j ? lane_partials + (size_t)lane * (8 * N) : buckets + (size_t)g * (8 * N)) + comp * N;
+    const bool keep29 = !j && bucket_r29;
+    if (inf) {
+#pragma unroll
+        for (int cdn = 0; cdn < 4; cdn++)
+#pragma unroll
+            for (int i = 0; i < HV; i++) reinterpret_cast<uint4*>(dst + cdn * 2 * N)[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    if (keep29) { store_r256<C, true>(dst, a.X); store_r256<C, true>(dst + 2 * N, a.Y); store_r256<C, true>(dst + 4 * N, a.ZZ); store_r256<C, true>(dst + 6 * N, a.ZZZ); }
+    else { store_r256<C, false>(dst, a.X); store_r256<C, false>(dst + 2 * N, a.Y); store_r256<C, false>(dst + 4 * N, a.ZZ); store_r256<C, false>(dst + 6 * N, a.ZZZ); }
+#endif
+}
+
 // ---- row / column sums of the Fq2 bucket reduction on unsaturated limbs ------------------------------------------------------------------
 // acc (XYZZ over Fq2, parked in LDS) = 2 acc (dbl-2008-s-1, a = 0): the rare equal-points branch of padd29_lds
 template <class C, class Acc> ZK_HD void dbl29_lds(const Acc& A) {

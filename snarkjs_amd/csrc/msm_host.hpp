@@ -220,6 +220,17 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
                                    lane_partials, (int)r29_buckets);
                 done = true;
             }
+            // r06: 9-limb moduli accumulate with one Fq2 component per lane, accumulators in registers (msm29.cuh: k_msm_accum29_g2s; ZKMI_G2_SPLIT=0: the
+            // LDS-parked layout, bit-identical)
+            if constexpr (Lim29<C>::NL <= 9) {
+                static const bool split_on = !(getenv("ZKMI_G2_SPLIT") && atoi(getenv("ZKMI_G2_SPLIT")) == 0);
+                if (split_on) {
+                    hipLaunchKernelGGL((k_msm_accum29_g2s<C>), dim3((unsigned)((pl.lane_bound + G2S_SLOTS - 1) / G2S_SLOTS)), dim3(256), 0, st, (const uint32_t*)d_bases,
+                                       d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets,
+                                       lane_partials, (int)r29_buckets);
+                    done = true;
+                }
+            }
             if (!done) hipLaunchKernelGGL((k_msm_accum29_g2<C>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
                                     d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials,
                                     (int)r29_buckets);

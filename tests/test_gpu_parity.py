@@ -90,8 +90,9 @@ def test_ntt29_passes_opt_in_parity(force):
 
 @pytest.mark.skipif(os.environ.get("ZKMI_TEST_NESTED") == "1", reason="already the nested run")
 @pytest.mark.parametrize("env", [{"ZKMI_R29_REDUCE_G2": "0", "ZKMI_R29_REDUCE": "0"}, {"ZKMI_ACC29_BLOCK": "64"}, {"ZKMI_R29_G2": "0"}, {"ZKMI_COMPACT_CODE": "31"},
-                                 {"ZKMI_COMPACT_CODE": "0"}],
-                         ids=["generic-rowcol-both-groups", "accum-64-thread-blocks", "generic-g2-accumulation", "compact-code-kernels", "inlined-kernels"])
+                                 {"ZKMI_COMPACT_CODE": "0"}, {"ZKMI_G2_SPLIT": "0"}],
+                         ids=["generic-rowcol-both-groups", "accum-64-thread-blocks", "generic-g2-accumulation", "compact-code-kernels", "inlined-kernels",
+                              "g2-lds-parked-accumulators"])
 def test_non_default_kernel_variants_parity(env):
     """The A/B switches select kernels that the default configuration no longer runs where a window table is resident (the generic 32-bit row /
     column sums of both groups, the generic Fq2 accumulation, other block shapes) or picks per box (the Compact instantiations with called

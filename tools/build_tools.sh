@@ -9,6 +9,7 @@ $H -o tools/bin/fieldbench29 tools/fieldbench29.hip &
 $H -DZK_MAD_PLAIN -o tools/bin/fieldbench29_plain tools/fieldbench29.hip &
 $H -DZK_MAD_PLAIN -DZK_MAD_ASM -o tools/bin/fieldbench29_asm tools/fieldbench29.hip &
 $H -o tools/bin/maddbench29 tools/maddbench29.hip &
+$H -o tools/bin/maddbench29_g2 tools/maddbench29_g2.hip &
 $H -o tools/bin/gatherbench tools/gatherbench.hip &
 wait
 ls -la tools/bin

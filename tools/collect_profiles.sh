@@ -47,7 +47,7 @@ rm -f $O/stats_real/*/*kernel_trace.csv $O/stats_p24/*/*kernel_trace.csv $O/stat
 # everywhere); _asm = -DZK_MAD_PLAIN -DZK_MAD_ASM (one asm statement per multiply-add: the r03 build)
 { echo "== the shipped build: one asm statement per COLUMN of the product scanning (every field)"; tools/bin/fieldbench29;
   echo "== -DZK_MAD_PLAIN: multiply-adds in plain C everywhere"; tools/bin/fieldbench29_plain;
-  echo "== -DZK_MAD_PLAIN -DZK_MAD_ASM: one inline-asm statement per multiply-add (the r03 build: one s_nop behind each)"; tools/bin/fieldbench29_asm; tools/bin/maddbench29; } > $O/fieldbench29.txt 2>&1
+  echo "== -DZK_MAD_PLAIN -DZK_MAD_ASM: one inline-asm statement per multiply-add (the r03 build: one s_nop behind each)"; tools/bin/fieldbench29_asm; tools/bin/maddbench29; tools/bin/maddbench29_g2; } > $O/fieldbench29.txt 2>&1
 # r06: every kernel of ONE table MSM by itself (sort and accumulation on one stream: the sort kernels' own durations)
 bash tools/lab/r6_sort_probe.sh > $O/sort_probe.txt 2>&1
 # the multi-rank code path of bench.py on this ONE GPU (a 1-rank RCCL communicator): sharded MSM over resident tables, one proof over all ranks at 2^20 and at 2^24 (BASELINE configs[2])
