@@ -62,43 +62,6 @@ def agg(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-fc, wc = glob.glob(f"{src}/pmc_fetch/**/*counter_collection.csv", recursive=True), glob.glob(f"{src}/pmc_write/**/*counter_collection.csv", recursive=True)
-if fc and wc:
-    F, W = agg(fc[0], "FETCH_SIZE"), agg(wc[0], "WRITE_SIZE")
-    adds = bench.get("accum_mixed_additions", {})
-    g1_adds = next((v for k, v in adds.items() if "(A)" in k), 0)
-    g2_adds = next((v for k, v in adds.items() if "(B2)" in k), 0)
-    out = {"__workload__": f"groth16:{bench['config']['curve']}:2^{bench['config']['log_n']}:b_zero_every={0 if bench['config']['b_density'] == 1.0 else round(1 / (1 - bench['config']['b_density']))}:{bench['config']['witness']}"}
-    rows = []
-    for k in sorted(F):
-        raw, wr = F[k], W.get(k, 0.0)
-        is_g2 = k.startswith("k_msm_accum29_g2") or k.startswith("k_msm_accum<Fp2")
-        corr = raw + (64.0 * g2_adds if is_g2 else 0.0)
-        if not (k.startswith("k_msm_accum") or k.startswith("k_ntt") or k.startswith("k_msm_rowcol") or k.startswith("k_build_abc")):
-            corr = 2 * raw                                       # coalesced streaming kernels: 128-byte requests tallied at 64 B (MI355X_MICROARCH.md)
-        key = k
-        while key.endswith(">") and any(key.endswith(s) for s in (", true>", ", false>")):
-            key = key[:key.rfind(",")] + ">"
-        out[key] = int(corr + wr)
-        rows.append((k, raw, wr, corr + wr))
-    json.dump(out, open(f"{dst}/pmc_traffic.json", "w"), indent=1, sort_keys=True)
-    shutil.copy(f"{dst}/pmc_traffic.json", f"{dst}/{tag}_pmc_traffic.json")
-    with open(f"{dst}/{tag}_pmc_traffic.md", "w") as f:
-        f.write(f"# HBM traffic per launch, accumulation kernels ({tag}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, `bench.py --steps 2 --warmup 1 --pipeline 1`)\n\n"
-                "FETCH_SIZE tallies memory-side read requests at 64 B each (`r02_gather_calibration.md`): exact for the 64-byte gathers of a G1 table entry and for the sector\n"
-                "behind a 16-byte list read, half the bytes of a 128-byte G2 gather. Correction per access class: G1 bytes = raw; G2 bytes = raw + 64 B x gathers (= mixed\n"
-                f"additions counted on the device: {g2_adds}).\n\n| kernel | FETCH raw MB | WRITE MB | corrected total MB |\n|---|---|---|---|\n")
-        for k, raw, wr, tot in rows:
-            if "accum" in k:
-                f.write(f"| `{k}` | {raw/1e6:.0f} | {wr/1e6:.0f} | {tot/1e6:.0f} |\n")
-        m1 = g1_adds * 64 + g1_adds / 4 * 64 + (1 << 19) * 128
-        m2 = g2_adds * 128 + g2_adds / 4 * 64 + (1 << 19) * 256
-        f.write(f"\nModel per 2^20 launch (c = 20: 13 table rows, 2^19 buckets): G1 = gathers {g1_adds * 64 / 1e6:.0f} + list sectors (one 64-byte sector per 4 entries) {g1_adds / 4 * 64 / 1e6:.0f} + bucket stores "
-                f"{(1 << 19) * 128 / 1e6:.0f} = {m1 / 1e6:.0f} MB; G2 = {g2_adds * 128 / 1e6:.0f} + {g2_adds / 4 * 64 / 1e6:.0f} + {(1 << 19) * 256 / 1e6:.0f} = {m2 / 1e6:.0f} MB.\n"
-                "r02 (4-byte list reads, one sector per ENTRY): G1 1 937 MB, G2 3 558 MB under r02's x2-everything correction = 2 870 MB under this one.\n"
-                "The residual over the model (G1 ~15-20 %, G2 ~25 %) is not list traffic any more: page-table walks of 0.9 / 1.7 GB of random gathers are\n"
-                "tallied by the same counter, and the G2 kernel's WRITE_SIZE includes its scratch stores.\n")
-
 # ---- r06: the same for every other config of the driver line -> profiles/pmc_traffic.json["workloads"][<tag>] (bench.py looks its own workload up there)
 # Correction per access class from THIS round's calibration (gatherbench under the same counter: <tag>_gather_calibration.md): a gather of w bytes
 # is tallied at factor(w) of its bytes; G1 / G2 accumulation kernels gather one table entry per mixed addition (BN254 64 / 128 B, BLS12-381 96 / 192 B),
@@ -121,6 +84,11 @@ def gather_factors():
             val = max(per[k])
             out[w] = val / (lanes * w)
             rows.append((k, lanes * w, val, out[w]))
+    kp = next((x for x in per if x.startswith("k_gather_pair")), None)
+    if kp:                                                   # r06: a 128-byte entry read by TWO lanes, 2 x 32 bytes each (k_msm_accum29_g2s)
+        val = max(per[kp])
+        out["pair128"] = val / ((lanes // 2) * 128)
+        rows.append((kp, (lanes // 2) * 128, val, out["pair128"]))
     ks = next((x for x in per if x.startswith("k_stream")), None)
     if ks:
         rows.append((ks, 1 << 30, max(per[ks]), max(per[ks]) / (1 << 30)))
@@ -135,6 +103,47 @@ def gather_factors():
 
 
 factors, _cal = gather_factors()
+
+fc, wc = glob.glob(f"{src}/pmc_fetch/**/*counter_collection.csv", recursive=True), glob.glob(f"{src}/pmc_write/**/*counter_collection.csv", recursive=True)
+if fc and wc:
+    F, W = agg(fc[0], "FETCH_SIZE"), agg(wc[0], "WRITE_SIZE")
+    adds = bench.get("accum_mixed_additions", {})
+    g1_adds = next((v for k, v in adds.items() if "(A)" in k), 0)
+    g2_adds = next((v for k, v in adds.items() if "(B2)" in k), 0)
+    out = {"__workload__": f"groth16:{bench['config']['curve']}:2^{bench['config']['log_n']}:b_zero_every={0 if bench['config']['b_density'] == 1.0 else round(1 / (1 - bench['config']['b_density']))}:{bench['config']['witness']}"}
+    rows = []
+    for k in sorted(F):
+        raw, wr = F[k], W.get(k, 0.0)
+        is_g2 = k.startswith("k_msm_accum29_g2") or k.startswith("k_msm_accum<Fp2")
+        # r06: the split layout (k_msm_accum29_g2s) reads a 128-byte entry as 2 x 32 bytes in each of two lanes: its own calibration factor
+        g2_fr = (factors.get("pair128") or 1.0) if k.startswith("k_msm_accum29_g2s") else (factors.get(128) or 0.5)
+        corr = raw + ((1.0 - g2_fr) * 128.0 * g2_adds if is_g2 else 0.0)
+        if not (k.startswith("k_msm_accum") or k.startswith("k_ntt") or k.startswith("k_msm_rowcol") or k.startswith("k_build_abc")):
+            corr = 2 * raw                                       # coalesced streaming kernels: 128-byte requests tallied at 64 B (MI355X_MICROARCH.md)
+        key = k
+        while key.endswith(">") and any(key.endswith(s) for s in (", true>", ", false>")):
+            key = key[:key.rfind(",")] + ">"
+        out[key] = int(corr + wr)
+        rows.append((k, raw, wr, corr + wr))
+    json.dump(out, open(f"{dst}/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+    shutil.copy(f"{dst}/pmc_traffic.json", f"{dst}/{tag}_pmc_traffic.json")
+    with open(f"{dst}/{tag}_pmc_traffic.md", "w") as f:
+        f.write(f"# HBM traffic per launch, accumulation kernels ({tag}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, `bench.py --steps 2 --warmup 1 --pipeline 1`)\n\n"
+                "FETCH_SIZE tallies memory-side read requests at 64 B each (`r02_gather_calibration.md`): exact for the 64-byte gathers of a G1 table entry and for the sector\n"
+                "behind a 16-byte list read, half the bytes of a 128-byte G2 gather by one lane. Correction per access class: G1 bytes = raw; G2 bytes = raw + (1 - tallied\n"
+                f"fraction) x 128 B x gathers (= mixed additions counted on the device: {g2_adds}); r06: k_msm_accum29_g2s reads an entry as 2 x 32 bytes in each of two\n"
+                f"lanes, tallied at {factors.get('pair128')} (k_gather_pair in the calibration).\n\n| kernel | FETCH raw MB | WRITE MB | corrected total MB |\n|---|---|---|---|\n")
+        for k, raw, wr, tot in rows:
+            if "accum" in k:
+                f.write(f"| `{k}` | {raw/1e6:.0f} | {wr/1e6:.0f} | {tot/1e6:.0f} |\n")
+        m1 = g1_adds * 64 + g1_adds / 4 * 64 + (1 << 19) * 128
+        m2 = g2_adds * 128 + g2_adds / 4 * 64 + (1 << 19) * 256
+        f.write(f"\nModel per 2^20 launch (c = 20: 13 table rows, 2^19 buckets): G1 = gathers {g1_adds * 64 / 1e6:.0f} + list sectors (one 64-byte sector per 4 entries) {g1_adds / 4 * 64 / 1e6:.0f} + bucket stores "
+                f"{(1 << 19) * 128 / 1e6:.0f} = {m1 / 1e6:.0f} MB; G2 = {g2_adds * 128 / 1e6:.0f} + {g2_adds / 4 * 64 / 1e6:.0f} + {(1 << 19) * 256 / 1e6:.0f} = {m2 / 1e6:.0f} MB.\n"
+                "r02 (4-byte list reads, one sector per ENTRY): G1 1 937 MB, G2 3 558 MB under r02's x2-everything correction = 2 870 MB under this one.\n"
+                "The residual over the model (G1 ~15-20 %, G2 ~25 %) is not list traffic any more: page-table walks of 0.9 / 1.7 GB of random gathers are\n"
+                "tallied by the same counter, and the G2 kernel's WRITE_SIZE includes its scratch stores.\n")
+
 workloads = {}
 try:
     workloads = json.load(open(f"{dst}/pmc_traffic.json")).get("workloads", {})
@@ -163,7 +172,10 @@ for nm, entry_g1, entry_g2 in (("bls", 96, 192), ("plonk", 64, 128), ("real", 64
     out = {}
     for k in sorted(F):
         raw, wr = F[k], W.get(k, 0.0)
-        if k.startswith("k_msm_accum29_g2") or k.startswith("k_msm_accum<Fp2"):
+        if k.startswith("k_msm_accum29_g2s"):
+            fr = factors.get("pair128") or 1.0
+            corr = raw + (1.0 - fr) * entry_g2 * g2_adds
+        elif k.startswith("k_msm_accum29_g2") or k.startswith("k_msm_accum<Fp2"):
             fr = factors.get(entry_g2) or 0.5
             corr = raw + (1.0 - fr) * entry_g2 * g2_adds
         elif k.startswith("k_msm_accum"):
@@ -206,7 +218,9 @@ with open(f"{dst}/{tag}_isa_counts.md", "w") as f:
             "multiply-add). Each kernel is: gather + unpack + the head of the addition (first big segment), the rare equal-points doubling (the segment skipped\n"
             "by a forward branch right after it), the body of the addition (the segment that ends in the backward jump), then three copies of the once-per-lane\n"
             "store. Main path of ONE mixed addition = head + body (+ the small gather / loop-control segments): BN254 G1 616 + 1 554 (+ ~60) = 2 230 VALU\n"
-            "(1 467 MACs, 283 s_nop; r03: 2 238 VALU + 1 307 s_nop); BN254 G2 1 354 + 4 434 (+ ~140) = 5 930 (4 374 MACs, 767 s_nop; r03: 5 944 + 4 113 s_nop);\n"
+            "(1 467 MACs, 283 s_nop; r03: 2 238 VALU + 1 307 s_nop); BN254 G2, LDS-parked layout (`k_msm_accum29_g2`, ZKMI_G2_SPLIT=0) 1 354 + 4 434 (+ ~140) = 5 930 (4 374 MACs,\n"
+            "767 s_nop; r03: 5 944 + 4 113 s_nop); r06 default `k_msm_accum29_g2s` (one Fq2 component per lane): 929 + 2 431 = 3 360 per LANE (2 196 MACs, 213 s_nop), two lanes\n"
+            "per addition = 6 720 (+13 %: the DPP exchanges and the negations both lanes form);\n"
             "BLS12-381 G1 1 224 + 3 404 (+ ~370) = 5 002 (453 s_nop; r03: 5 012 + 3 262 s_nop); BLS12-381 G2 (packed Jacobian accumulator, 8M + 3S) 5 438 + 9 442 =\n"
             "14 880 VALU (1 387 s_nop; r03: 14 902 + 11 242 s_nop). These are the constants `bench.py` divides by (`VALU_PER_ADD`). Plain C multiply-adds\n"
             "(measured, not shipped: `-DZK_MAD_PLAIN`) carry no s_nop but 4-6 % more VALU (64-bit merge adds of the partial chains): 2 375 / 6 200 / 5 237 / 15 730.\n")
