@@ -28,8 +28,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # (the hand order of r03 — the same VALU counts — with 283 / 767 / 453 / 1 387 s_nop per addition instead of 1 307 / 4 113 / 3 262 / 11 242)
 # r06: BN254 G2 accumulates with one Fq2 component per lane (k_msm_accum29_g2s): 3 360 VALU per LANE and addition (929 head + 2 431 body,
 # profiles/r06_isa_counts.md), two lanes per addition = 6 720 per addition (the LDS-parked layout, ZKMI_G2_SPLIT=0: 5 930 in one lane)
+# BLS12-381 G2 the same way (XYZZ in registers, 8M + 2S): 7 431 per lane (1 860 + 5 571) = 14 862 per addition (packed Jacobian in LDS, 8M + 3S: 14 880)
 G2_SPLIT = os.environ.get("ZKMI_G2_SPLIT", "1") != "0"
-VALU_PER_ADD = {"bn128": {"g1": 2230, "g2": 6720 if G2_SPLIT else 5930}, "bls12381": {"g1": 5002, "g2": 14880}}
+G2_SPLIT_BLS = G2_SPLIT and os.environ.get("ZKMI_G2_SPLIT_BLS", "1") != "0"
+VALU_PER_ADD = {"bn128": {"g1": 2230, "g2": 6720 if G2_SPLIT else 5930}, "bls12381": {"g1": 5002, "g2": 14862 if G2_SPLIT_BLS else 14880}}
 VALU_ISSUE_PEAK_G = 614.4                      # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave instruction
 # measured Montgomery-multiply ceilings of the chip, Gmul/s at 8 waves per SIMD, in the limb form the accumulation kernels of the curve use
 # (tools/fieldbench29 on the library's own mul29): BN254 Fq 9 x 29-bit limbs, BLS12-381 Fq 14 x 28-bit limbs; the saturated 32-bit forms they
@@ -972,7 +974,7 @@ def main():
         fq = "Bn254Fq" if cid == 0 else "Bls12381Fq"
         b1, b2 = 2 * q8 + 32, 4 * q8 + 32                     # affine base + 32-byte scalar per term
         r29 = os.environ.get("ZKMI_R29", "1") != "0" and not (cid == 1 and os.environ.get("ZKMI_R29_BLS", "1") == "0")     # accumulation kernels on unsaturated limbs (msm29.cuh)
-        k1, k2 = (f"k_msm_accum29<{fq}>", f"k_msm_accum29_g2{'s' if (cid == 0 and G2_SPLIT) else ''}<{fq}>") if r29 else (f"k_msm_accum<Fp<{fq}>>", f"k_msm_accum<Fp2<{fq}>>")
+        k1, k2 = (f"k_msm_accum29<{fq}>", f"k_msm_accum29_g2{'s' if (G2_SPLIT if cid == 0 else G2_SPLIT_BLS) else ''}<{fq}>") if r29 else (f"k_msm_accum<Fp<{fq}>>", f"k_msm_accum<Fp2<{fq}>>")
         names = {0: (f"{k1} (A)", b1), 1: (f"{k1} (B1)", b1), 2: (f"{k2} (B2)", b2), 3: (f"{k1} (C)", b1), 4: (f"{k1} (H)", b1)}
         dom = max(acc, key=lambda k: acc[k])
         units = {0: m, 1: m, 2: m, 3: m - zk["nPublic"] - 1, 4: zk["domainSize"]}[dom]
@@ -1002,7 +1004,7 @@ def main():
             vpa = VALU_PER_ADD[args.curve]["g2" if dom == 2 else "g1"]
             wrate = adds * vpa / 64 / (acc[dom] * 1e-3) / 1e9
             int_alu["valu_issue"] = {"valu_instr_per_addition": vpa, "achieved": round(wrate, 1), "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instr/s", "frac": round(wrate / VALU_ISSUE_PEAK_G, 4),
-                                     "note": "VALU instructions of the main path of one mixed addition (tools/isa_counts.py) x additions / 64 / launch time against one wave instruction per SIMD every 4 cycles; BN254 G2 (r06) holds one Fq2 component per lane in registers at 3 waves per SIMD, two lanes per addition (its count is per addition: 2 x 3 360); the BLS12-381 G2 kernel holds 2 waves per SIMD (packed Jacobian accumulators parked in LDS, four 128-lane blocks per CU), where a dependent v_mad_u64_u32 chain reaches 0.82 - 0.9 of that peak (tools/fieldbench29: wps=2)"}
+                                     "note": "VALU instructions of the main path of one mixed addition (tools/isa_counts.py) x additions / 64 / launch time against one wave instruction per SIMD every 4 cycles; the G2 kernels (r06) hold one Fq2 component per lane in registers, two lanes per addition (their counts are per addition: BN254 2 x 3 360 at 3 waves per SIMD, BLS12-381 2 x 7 431 at 2 waves per SIMD), where a dependent v_mad_u64_u32 chain reaches 0.82 - 0.9 of that peak (tools/fieldbench29: wps=2)"}
         out = {
             "metric": "groth16_proofs_per_sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),

@@ -749,12 +749,14 @@ k_msm_accum29_g2(const uint32_t* __restrict__ bases, const uint32_t* __restrict_
     else Accum29G2<C>::template store<false>(buckets + (size_t)g * (8 * N), A, inf);
 }
 
-// ---- r06: G2 accumulation with ONE Fq2 COMPONENT PER LANE (9-limb moduli) ------------------------------------------------------------------
+// ---- r06: G2 accumulation with ONE Fq2 COMPONENT PER LANE (both curves) --------------------------------------------------------------------
 // The two components of a bucket sit eight lanes apart in a row of sixteen (lanes 0-7 of a row: c0, lanes 8-15: c1). The accumulator is half as wide
 // and stays in REGISTERS (151 VGPRs, three waves per SIMD, no LDS), and every Fq2 product fetches the partner's operands with DPP moves (row_ror:8; the
 // move's bank mask does the per-component selection, no v_cndmask is spent): (a0 + a1 u)(b0 + b1 u) — the c0 lane forms a0 b0 + a1 (K p - b1), the c1
 // lane a1 b0 + a0 b1, each ONE mul29_2 on the operands madd29_lds hands the same product, so every coordinate leaves with the same words. Measured first
-// in isolation (tools/maddbench29_g2, profiles/r06_g2_layout.txt): 5.10 against 4.60 G additions/s for the LDS-parked layout.
+// in isolation (tools/maddbench29_g2, profiles/r06_g2_layout.txt): 5.10 against 4.60 G additions/s for the LDS-parked layout. 14-limb moduli: 248 VGPRs, two
+// waves per SIMD, no spill (the packed Jacobian in LDS: 256 + 111 spilled) and a hot loop of 61 KB instead of 118 KB; XYZZ there too, so the buckets are another
+// representative of the same points than k_msm_accum29_g2's.
 #if defined(__HIP_DEVICE_COMPILE__)
 constexpr int DPP_ROR8 = 0x128;                                      // row_ror:8 — lane i of a row of 16 reads lane i ^ 8
 // the partner's value in every lane
@@ -857,17 +859,22 @@ template <class C> ZK_DEV void madd29_split(AccS29<C>& a, bool& inf, const Fp29<
     // Y3 = Tq R + Y1 (-PPP), one reduction per component: the right-hand operands of R and of N = (2p - PPP0, 2p - PPP1)
     const BRole29<C> bR = b_role29(R, neg29<C, 6>(R));
     const BRole29<C> bN{xch_into<C, 0xC>(nPPP, nPPP), xch_into<C, 0x3>(nPPP, PPP)};
-    a.Y = mul29_4(Tq, bR.y1, xch_all(Tq), bR.y2, a.Y, bN.y1, xch_all(a.Y), bN.y2);
+    if constexpr (ZK_Y3_SPLIT(C)) {                                 // 14-limb moduli: two 2-product sums instead of one 4-product sum (half the live operands), as in madd29_lds
+        const Fp29<C> TR = mul29_2(Tq, bR.y1, xch_all(Tq), bR.y2);
+        ZK_SFENCE();
+        Fp29<C> Y3 = add29(TR, mul29_2(a.Y, bN.y1, xch_all(a.Y), bN.y2));
+        norm29(Y3);
+        a.Y = Y3;
+    } else a.Y = mul29_4(Tq, bR.y1, xch_all(Tq), bR.y2, a.Y, bN.y1, xch_all(a.Y), bN.y2);
 }
 #endif
 // 128 schedule lanes (buckets or shares of a bucket) per 256-thread block; same arguments and results as k_msm_accum29_g2
 constexpr unsigned G2S_SLOTS = 128;
-template <class C> __global__ void __launch_bounds__(256, 3)
+template <class C> __global__ void __launch_bounds__(256, Lim29<C>::NL <= 9 ? 3 : 2)
 k_msm_accum29_g2s(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ infmask, MsmShape sh, uint32_t skip, uint32_t cap, const uint32_t* __restrict__ counts,
                   const uint32_t* __restrict__ starts, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ lane_g, const uint32_t* __restrict__ lane_sub,
                   const uint32_t* __restrict__ meta, uint32_t* __restrict__ buckets, uint32_t* __restrict__ lane_partials, int bucket_r29) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(Lim29<C>::NL <= 9, "one component per lane: 9-limb moduli (the 14-limb curve keeps its packed Jacobian accumulator in LDS)");
     constexpr int N = C::N, HV = N / 4;                              // 16-byte vectors per component of a coordinate
     const uint32_t t = threadIdx.x, comp = (t >> 3) & 1u, c1mask = comp ? 0xffffffffu : 0u;
     const uint32_t lane = blockIdx.x * G2S_SLOTS + (((t >> 4) << 3) | (t & 7u));      // the schedule lane this PAIR works for

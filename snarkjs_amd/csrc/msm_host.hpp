@@ -214,22 +214,25 @@ template <class F> int msm_accumulate(const void* d_bases, const MsmPlan& pl, ui
             // was not affected there, instead of the 320 - 750 KB of k_msm_rowcol_wave29_g2 (7.1 instead of 2.1 ms on such a box)
             r29_buckets = wave_ok && g2r && !(compact_code() & 8) && (sh.c - 1) / 2 >= 6;
             bool done = false;
-            if constexpr (Lim29<C>::NL > 9) if (cc) {
-                hipLaunchKernelGGL((k_msm_accum29_g2<Compact<C>>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
-                                   d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets,
-                                   lane_partials, (int)r29_buckets);
-                done = true;
-            }
-            // r06: 9-limb moduli accumulate with one Fq2 component per lane, accumulators in registers (msm29.cuh: k_msm_accum29_g2s; ZKMI_G2_SPLIT=0: the
-            // LDS-parked layout, bit-identical)
-            if constexpr (Lim29<C>::NL <= 9) {
-                static const bool split_on = !(getenv("ZKMI_G2_SPLIT") && atoi(getenv("ZKMI_G2_SPLIT")) == 0);
+            // r06: one Fq2 component per lane, accumulators in registers (msm29.cuh: k_msm_accum29_g2s) — BN254: 168 VGPRs, 3 waves per SIMD, bit-identical buckets;
+            // BLS12-381: XYZZ in 248 VGPRs without a spill instead of the packed Jacobian in LDS with 111 spilled registers (another representative of the same
+            // bucket), and a hot loop of 61 KB instead of 118 KB — it fits the instruction cache, so it also takes the place of the Compact instantiation on a
+            // slow-fetch box. ZKMI_G2_SPLIT=0: the LDS-parked layouts (and their Compact twin where compact_code() asks for it); ZKMI_G2_SPLIT_BLS=0: 14-limb only
+            {
+                static const bool split_on = !(getenv("ZKMI_G2_SPLIT") && atoi(getenv("ZKMI_G2_SPLIT")) == 0) &&
+                                             !(Lim29<C>::NL > 9 && getenv("ZKMI_G2_SPLIT_BLS") && atoi(getenv("ZKMI_G2_SPLIT_BLS")) == 0);
                 if (split_on) {
                     hipLaunchKernelGGL((k_msm_accum29_g2s<C>), dim3((unsigned)((pl.lane_bound + G2S_SLOTS - 1) / G2S_SLOTS)), dim3(256), 0, st, (const uint32_t*)d_bases,
                                        d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets,
                                        lane_partials, (int)r29_buckets);
                     done = true;
                 }
+            }
+            if constexpr (Lim29<C>::NL > 9) if (cc && !done) {
+                hipLaunchKernelGGL((k_msm_accum29_g2<Compact<C>>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
+                                   d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets,
+                                   lane_partials, (int)r29_buckets);
+                done = true;
             }
             if (!done) hipLaunchKernelGGL((k_msm_accum29_g2<C>), dim3((unsigned)((pl.lane_bound + T29 - 1) / T29)), dim3(T29), lds29, st, (const uint32_t*)d_bases,
                                     d_infmask ? d_infmask : r29->second, sh, skip, pl.cap, pl.counts, pl.starts, pl.sorted, pl.lane_g, pl.lane_sub, pl.meta, buckets, lane_partials,

@@ -89,7 +89,7 @@ def test_ntt29_passes_opt_in_parity(force):
 
 
 @pytest.mark.skipif(os.environ.get("ZKMI_TEST_NESTED") == "1", reason="already the nested run")
-@pytest.mark.parametrize("env", [{"ZKMI_R29_REDUCE_G2": "0", "ZKMI_R29_REDUCE": "0"}, {"ZKMI_ACC29_BLOCK": "64"}, {"ZKMI_R29_G2": "0"}, {"ZKMI_COMPACT_CODE": "31"},
+@pytest.mark.parametrize("env", [{"ZKMI_R29_REDUCE_G2": "0", "ZKMI_R29_REDUCE": "0"}, {"ZKMI_ACC29_BLOCK": "64"}, {"ZKMI_R29_G2": "0"}, {"ZKMI_COMPACT_CODE": "31", "ZKMI_G2_SPLIT": "0"},
                                  {"ZKMI_COMPACT_CODE": "0"}, {"ZKMI_G2_SPLIT": "0"}],
                          ids=["generic-rowcol-both-groups", "accum-64-thread-blocks", "generic-g2-accumulation", "compact-code-kernels", "inlined-kernels",
                               "g2-lds-parked-accumulators"])

@@ -27,6 +27,18 @@ __global__ void k_gather_pair(const uint4* __restrict__ tab, size_t n_pts, uint3
     const uint4 a = p[0], b = p[1], c = p[4], d = p[5];
     out[t] = a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
 }
+// the 14-limb curve's 192-byte G2 entry the same way: each of the two lanes reads 2 x 48 bytes (x.c_s at 48 s, y.c_s at 96 + 48 s)
+__global__ void k_gather_pair192(const uint4* __restrict__ tab, size_t n_pts, uint32_t* __restrict__ out, uint32_t lanes) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    const uint32_t comp = (t >> 3) & 1u, slot = ((t >> 4) << 3) | (t & 7u);
+    uint64_t h = (uint64_t)slot * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    const uint4* p = tab + (h % n_pts) * 12 + comp * 3;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { const uint4 a = p[i], b = p[6 + i]; acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w; }
+    out[t] = acc;
+}
 // the same 64-byte gathers, but lane t only picks inside a window of `win_pts` points that slides with the lane index: what the MSM
 // would do if every bucket list were sorted by table row (all lanes in flight gather from the same ~64 MB row at the same time)
 __global__ void k_gather_window(const uint4* __restrict__ tab, size_t n_pts, size_t win_pts, uint32_t* __restrict__ out, uint32_t lanes) {
@@ -61,6 +73,8 @@ int main() {
         hipEventElapsedTime(&ms, e0, e1); printf("k_gather<8>  %u lanes x 128 B = %.1f MB  %.3f ms  %.1f GB/s\n", lanes, lanes * 128.0 / 1e6, ms, lanes * 128.0 / ms / 1e6);
         hipEventRecord(e0); k_gather_pair<<<lanes / 256, 256>>>(tab, bytes / 128, out, lanes); hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1); printf("k_gather_pair %u lanes, %u entries x 128 B = %.1f MB  %.3f ms  %.1f GB/s\n", lanes, lanes / 2, lanes * 64.0 / 1e6, ms, lanes * 64.0 / ms / 1e6);
+        hipEventRecord(e0); k_gather_pair192<<<lanes / 256, 256>>>(tab, bytes / 192, out, lanes); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1); printf("k_gather_pair192 %u lanes, %u entries x 192 B = %.1f MB  %.3f ms  %.1f GB/s\n", lanes, lanes / 2, lanes * 96.0 / 1e6, ms, lanes * 96.0 / ms / 1e6);
         // r06: the 14-limb curve's table entries (BLS12-381: 96 B per G1 point, 192 B per G2 point; entries are 96 / 192-byte aligned only)
         hipEventRecord(e0); k_gather<6><<<lanes / 256, 256>>>(tab, bytes / 96, out, lanes); hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1); printf("k_gather<6>  %u lanes x 96 B  = %.1f MB  %.3f ms  %.1f GB/s\n", lanes, lanes * 96.0 / 1e6, ms, lanes * 96.0 / ms / 1e6);

@@ -84,11 +84,12 @@ def gather_factors():
             val = max(per[k])
             out[w] = val / (lanes * w)
             rows.append((k, lanes * w, val, out[w]))
-    kp = next((x for x in per if x.startswith("k_gather_pair")), None)
-    if kp:                                                   # r06: a 128-byte entry read by TWO lanes, 2 x 32 bytes each (k_msm_accum29_g2s)
-        val = max(per[kp])
-        out["pair128"] = val / ((lanes // 2) * 128)
-        rows.append((kp, (lanes // 2) * 128, val, out["pair128"]))
+    for kn, w in (("k_gather_pair192", 192), ("k_gather_pair", 128)):      # r06: an entry read by TWO lanes, half of it each (k_msm_accum29_g2s)
+        kp = next((x for x in per if x.split("(")[0] == kn), None)
+        if kp:
+            val = max(per[kp])
+            out[f"pair{w}"] = val / ((lanes // 2) * w)
+            rows.append((kp, (lanes // 2) * w, val, out[f"pair{w}"]))
     ks = next((x for x in per if x.startswith("k_stream")), None)
     if ks:
         rows.append((ks, 1 << 30, max(per[ks]), max(per[ks]) / (1 << 30)))
@@ -116,7 +117,7 @@ if fc and wc:
         raw, wr = F[k], W.get(k, 0.0)
         is_g2 = k.startswith("k_msm_accum29_g2") or k.startswith("k_msm_accum<Fp2")
         # r06: the split layout (k_msm_accum29_g2s) reads a 128-byte entry as 2 x 32 bytes in each of two lanes: its own calibration factor
-        g2_fr = (factors.get("pair128") or 1.0) if k.startswith("k_msm_accum29_g2s") else (factors.get(128) or 0.5)
+        g2_fr = (factors.get("pair128") or 0.5) if k.startswith("k_msm_accum29_g2s") else (factors.get(128) or 0.5)
         corr = raw + ((1.0 - g2_fr) * 128.0 * g2_adds if is_g2 else 0.0)
         if not (k.startswith("k_msm_accum") or k.startswith("k_ntt") or k.startswith("k_msm_rowcol") or k.startswith("k_build_abc")):
             corr = 2 * raw                                       # coalesced streaming kernels: 128-byte requests tallied at 64 B (MI355X_MICROARCH.md)
@@ -173,7 +174,7 @@ for nm, entry_g1, entry_g2 in (("bls", 96, 192), ("plonk", 64, 128), ("real", 64
     for k in sorted(F):
         raw, wr = F[k], W.get(k, 0.0)
         if k.startswith("k_msm_accum29_g2s"):
-            fr = factors.get("pair128") or 1.0
+            fr = factors.get(f"pair{entry_g2}") or (0.5 if entry_g2 == 128 else 0.666)
             corr = raw + (1.0 - fr) * entry_g2 * g2_adds
         elif k.startswith("k_msm_accum29_g2") or k.startswith("k_msm_accum<Fp2"):
             fr = factors.get(entry_g2) or 0.5
@@ -221,6 +222,8 @@ with open(f"{dst}/{tag}_isa_counts.md", "w") as f:
             "(1 467 MACs, 283 s_nop; r03: 2 238 VALU + 1 307 s_nop); BN254 G2, LDS-parked layout (`k_msm_accum29_g2`, ZKMI_G2_SPLIT=0) 1 354 + 4 434 (+ ~140) = 5 930 (4 374 MACs,\n"
             "767 s_nop; r03: 5 944 + 4 113 s_nop); r06 default `k_msm_accum29_g2s` (one Fq2 component per lane): 929 + 2 431 = 3 360 per LANE (2 196 MACs, 213 s_nop), two lanes\n"
             "per addition = 6 720 (+13 %: the DPP exchanges and the negations both lanes form);\n"
+            "BLS12-381 G2, r06 default `k_msm_accum29_g2s` (XYZZ in registers, 8M + 2S): 1 860 + 5 571 = 7 431 per lane (5 503 MACs), 14 862 per addition, hot loop 61 KB; the\n"
+            "packed-Jacobian LDS layout (`k_msm_accum29_g2`, ZKMI_G2_SPLIT=0):\n"
             "BLS12-381 G1 1 224 + 3 404 (+ ~370) = 5 002 (453 s_nop; r03: 5 012 + 3 262 s_nop); BLS12-381 G2 (packed Jacobian accumulator, 8M + 3S) 5 438 + 9 442 =\n"
             "14 880 VALU (1 387 s_nop; r03: 14 902 + 11 242 s_nop). These are the constants `bench.py` divides by (`VALU_PER_ADD`). Plain C multiply-adds\n"
             "(measured, not shipped: `-DZK_MAD_PLAIN`) carry no s_nop but 4-6 % more VALU (64-bit merge adds of the partial chains): 2 375 / 6 200 / 5 237 / 15 730.\n")
