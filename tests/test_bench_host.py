@@ -28,7 +28,7 @@ def test_pmc_traffic_is_looked_up_per_workload():
     bench = importlib.import_module("bench")
     t = bench.pmc_traffic("groth16:bn128:2^20:b_zero_every=0:uniform", "k_msm_accum29_g2s<Bn254Fq>")     # r06: one Fq2 component per lane
     assert t is not None and 2.0e9 < t < 3.5e9
-    assert bench.pmc_traffic("groth16:bls12381:2^20:b_zero_every=0:uniform", "k_msm_accum29_g2<Bls12381Fq>") > 3.0e9
+    assert bench.pmc_traffic("groth16:bls12381:2^20:b_zero_every=0:uniform", "k_msm_accum29_g2s<Bls12381Fq>") > 3.0e9
     assert bench.pmc_traffic("plonk:bn128:2^20:additions=524285", "k_msm_accum29<Bn254Fq>") > 1.0e9
     assert bench.pmc_traffic("groth16:bn128:2^24:b_zero_every=0:uniform", "k_msm_accum29_g2s<Bn254Fq>") > 3.5e10
     # a workload that was never counted gets no figure from another one
