@@ -364,7 +364,16 @@ def test_g1_additions(tool, curve):
 
 
 @pytest.mark.parametrize("curve", POINT_CURVES)
-def test_g2_lds_parked_additions(tool, curve):
+def test_g2_split_layout_additions(tool, curve):
+    """r06: the arithmetic of k_msm_accum29_g2s (one Fq2 component per lane) — per component exactly madd29_lds's XYZZ products, offsets and carry passes, on an
+    unpacked accumulator, for both limb forms (the 14-limb curve ran the packed Jacobian before): main path, doubling, cancellation, first point. What the split
+    kernel does beyond madd29_lds is form K p - b for BOTH components of a right-hand operand (madd29_lds negates c1 only, c0 where a formula needs it) and
+    a0 - a1 + KB p in both orders inside a square: the invariants bound both components of every value alike, so the same offsets cover them."""
+    test_g2_lds_parked_additions(tool, curve, op="madd2xyzz")
+
+
+@pytest.mark.parametrize("curve", POINT_CURVES)
+def test_g2_lds_parked_additions(tool, curve, op="madd2seq"):
     F = Form(curve)
     K = Fp2(F.p)
     rng = random.Random(0x71 + F.NL)
@@ -385,7 +394,7 @@ def test_g2_lds_parked_additions(tool, curve):
             for q, neg in seq[:upto]:
                 want = aff_add(K, want, aff_neg(K, q) if neg else q)
                 req += [1 if neg else 0] + F.to29(q[0][0]) + F.to29(q[0][1]) + F.to29(q[1][0]) + F.to29(q[1][1])
-            out = tool("madd2seq", curve, req)
+            out = tool(op, curve, req)
             inf, w = out[0], out[1:]
             if want is None:
                 assert inf == 1 and not any(w)
@@ -541,6 +550,7 @@ def test_worst_case_bounds_of_the_point_formulas(tool_bounds, curve):
     verified for ALL admissible inputs, not only for the sampled ones."""
     test_g1_additions(tool_bounds, curve)
     test_g2_lds_parked_additions(tool_bounds, curve)
+    test_g2_lds_parked_additions(tool_bounds, curve, op="madd2xyzz")            # r06: the split layout's formulas, both limb forms
     test_g2_bucket_reduction_additions(tool_bounds, curve)
     test_g2_row_sum_wave_flow(tool_bounds, curve)
     col = _no_violations(tool_bounds, curve)

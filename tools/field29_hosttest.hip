@@ -136,6 +136,31 @@ template <class C> static std::string run(const std::string& op, const std::vect
         o.push_back(inf ? 1u : 0u);
         for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
     }
+    else if (op == "madd2xyzz") {
+        // r06: the XYZZ form of the G2 accumulation for EVERY curve, accumulator unpacked — the arithmetic of k_msm_accum29_g2s (one Fq2 component per lane:
+        // madd29_split forms, per component, exactly the products, offsets and carry passes of madd29_lds; the 14-limb curve's default was the packed
+        // Jacobian before, so its XYZZ offsets had never met the worst-case check). Same in / out as madd2seq.
+        typedef LdsAcc29<C, 1, false> Acc;
+        std::vector<uint32_t> lds((size_t)8 * Lim29<C>::NL, 0xdeadbeefu);
+        const Acc A{lds.data()};
+        bool inf = true;
+        const uint32_t cnt = v.at(at++);
+        for (uint32_t k = 0; k < cnt; k++) {
+            const bool neg = v.at(at++) != 0;
+            F2x<C> qx, qy;
+            qx.c0 = rd<C>(v, at); qx.c1 = rd<C>(v, at); qy.c0 = rd<C>(v, at); qy.c1 = rd<C>(v, at);
+            if (neg) { qy.c0 = neg29<C, 2>(qy.c0); qy.c1 = neg29<C, 2>(qy.c1); }
+            bound_in(qx.c0, 1.0); bound_in(qx.c1, 1.0); bound_in(qy.c0, 2.0); bound_in(qy.c1, 2.0);
+            if (!inf) park_in<C>(A, 4, INV_G2A);
+            madd29_lds<C>(A, inf, qx, qy);
+            if (!inf) park_out<C>(A, 4, INV_G2A);
+        }
+        alignas(16) uint32_t w[8 * N];
+        if (!inf) park_in<C>(A, 4, INV_G2A);
+        store_xyzz29_lds<C, Acc, false>(w, A, inf);
+        o.push_back(inf ? 1u : 0u);
+        for (int i = 0; i < 8 * N; i++) o.push_back(w[i]);
+    }
     else if (op == "padd2") {
         // G2 bucket reduction: groups of signed affine points are accumulated into buckets the way the accumulation kernel does and stored as
         // R'-form words; a reduction accumulator (XYZZ, LDS-parked, the reduction kernel's packing) then folds the buckets from the words
