@@ -96,7 +96,10 @@ template <int NW> static int msm_launch_digits_radix(const uint8_t* d_scalars, c
     // level-1 scatter: ranked in LDS and written as runs where a block's pairs fit (ZKMI_RSORT_STAGED=0: the direct scatter everywhere)
     const uint32_t stage_cap = (uint32_t)sh.Wd * RSORT_TILE;
     const size_t stage_lds = ((size_t)2 * P + 1024 + (size_t)2 * stage_cap) * 4;
-    if (rsort_staged_fits<NW>(stage_lds))
+    // ... and where a block's share of a partition is long enough to be worth a run: >= 8 pairs on uniform scalars (26 at 2^20 terms with 512 partitions; with
+    // thousands of partitions and 2 - 3 pairs per block and partition there is nothing to coalesce, and the staged kernel reads two entries of the scanned matrix per
+    // partition where the direct one reads one)
+    if (rsort_staged_fits<NW>(stage_lds) && (size_t)stage_cap >= (size_t)8 * P)
         hipLaunchKernelGGL((k_rsort_scatter1_staged<NW>), dim3(nblk), dim3(1024), stage_lds, st, d_scalars, sh, dropmask, P, lb, bhoff, stage_cap, tmp);
     else
         hipLaunchKernelGGL((k_rsort_scatter1<NW>), dim3(nblk), dim3(256), 0, st, d_scalars, sh, dropmask, P, lb, bhoff, tmp);
@@ -107,7 +110,8 @@ template <int NW> static int msm_launch_digits_radix(const uint8_t* d_scalars, c
     }
     // the chunk kernels walk the table (meta[0] chunks, usually none: every block that only reads meta[0] and leaves still costs ~10 ns of dispatch —
     // 17 us per launch at 1 024 blocks, measured standalone); real witnesses leave a few dozen chunks (the bucket of digit 1), 256 blocks take them in one pass
-    const unsigned chunk_blocks = (unsigned)std::min<size_t>(nch_max, 256);
+    // — where the fused level 2 is on. Without it (2^11-bucket partitions: MSMs beyond ~2^20 terms) EVERY partition is cut into chunks (26 000 of them at 2^24): one block each
+    const unsigned chunk_blocks = (unsigned)(fused_cap ? std::min<size_t>(nch_max, 256) : nch_max);
     hipLaunchKernelGGL(k_rsort_hist2, dim3(chunk_blocks), dim3(256), 0, st, tmp, ck, meta, h2);
     hipLaunchKernelGGL(k_rsort_scan2, dim3(P), dim3(1024), 0, st, bhoff, nblk, lb, fused_cap ? 1u : 0u, pchunk0, h2, counts, starts);
     hipLaunchKernelGGL(k_rsort_scatter2, dim3(chunk_blocks), dim3(256), 0, st, tmp, ck, meta, h2, starts, lb, sorted);
